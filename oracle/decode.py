@@ -1,0 +1,129 @@
+"""Autoregressive decoding in numpy float32 (oracle; test infrastructure only).
+
+  GRUDecoder.forward_sample   models/decoder.py:86-109   (one decode step = one "decoder eval")
+  RNN_VAE.sample_G greedy     models/model.py:225-363    (argmax; finished rows forced to PAD; early break)
+  beam mode                   models/model.py:258-276,314-328,364-376 ; models/Beam.py:15-132
+"""
+import numpy as np
+
+from .gru import gru_cell_fwd, F32
+
+UNK, PAD, START, EOS = 0, 1, 2, 3
+
+
+def decoder_step(P, tok, zc, h):
+    """logits [N,V], h' [N,H] for current tokens tok [N] (eval mode: no dropout)."""
+    x = np.concatenate([P["word_emb.weight"][tok], zc], 1).astype(F32)
+    gi = (x @ P["decoder.rnn.weight_ih_l0"].T + P["decoder.rnn.bias_ih_l0"]).astype(F32)
+    h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+    logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
+    return logits, h
+
+
+def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=False):
+    """ids [N, 1+steps] int64 with column 0 = START; steps <= max_len (stops once every row has emitted EOS)."""
+    N = z.shape[0]
+    zc = np.concatenate([z, c], 1).astype(F32)
+    h = zc.copy()
+    tok = np.full(N, START, np.int64)
+    finished = np.zeros(N, bool)
+    cols, all_logits = [tok], []
+    for i in range(max_len):
+        logits, h = decoder_step(P, tok, zc, h)
+        if prevent_empty and i == 0:
+            neg = F32(-2.0) * np.abs(logits.min())
+            logits[:, [PAD, START, EOS]] = neg
+        all_logits.append(logits.copy())
+        tok = logits.argmax(1).astype(np.int64)
+        tok[finished] = PAD
+        finished |= tok == EOS
+        cols.append(tok)
+        if finished.all() and len(cols) >= min_length:
+            break
+    ids = np.stack(cols, 1)
+    return (ids, np.stack(all_logits, 1)) if return_logits else ids
+
+
+def _log_softmax(x):
+    m = x.max(1, keepdims=True)
+    return (x - (m + np.log(np.exp(x - m).sum(1, keepdims=True)))).astype(F32)
+
+
+class _Beam:
+    """Per-sentence beam bookkeeping (restates models/Beam.py)."""
+
+    def __init__(self, size, n_best, min_length):
+        self.size, self.n_best, self.min_length = size, n_best, min_length
+        self.scores = np.zeros(size, F32)
+        self.prev_ks = []
+        first = np.full(size, PAD, np.int64)
+        first[0] = START
+        self.next_ys = [first]
+        self.finished = []
+        self.eos_top = False
+
+    def done(self):
+        return self.eos_top and len(self.finished) >= self.n_best
+
+    def advance(self, logp):
+        V = logp.shape[1]
+        logp = logp.copy()
+        if len(self.next_ys) < self.min_length:
+            logp[:, EOS] = F32(-1e20)
+        logp[:, START] = F32(-1e20)  # never predict BOS (Beam.py:72)
+        if self.prev_ks:
+            cand = (logp + self.scores[:, None]).astype(F32)
+            cand[self.next_ys[-1] == EOS] = F32(-1e20)  # EOS has no children (Beam.py:78-80)
+        else:
+            cand = logp[0:1]  # first step: only beam 0 is live
+        flat = cand.reshape(-1)
+        order = np.argsort(-flat, kind="stable")[: self.size]
+        self.scores = flat[order].astype(F32)
+        prev = order // V
+        self.prev_ks.append(prev)
+        self.next_ys.append(order - prev * V)
+        for i in range(self.size):
+            if self.next_ys[-1][i] == EOS:
+                self.finished.append((self.scores[i], len(self.next_ys) - 1, i))
+        if self.next_ys[-1][0] == EOS:
+            self.eos_top = True
+
+    def best(self):
+        fin = list(self.finished)
+        i = 0
+        while len(fin) < self.n_best:  # pad from the live beam (Beam.py:111-117)
+            fin.append((self.scores[i], len(self.next_ys) - 1, i))
+            i += 1
+        fin.sort(key=lambda a: -a[0])  # stable, raw summed log-prob, no length norm
+        hyps, scores = [], []
+        for s, t, k in fin[: self.n_best]:
+            hyp = []
+            for j in range(len(self.prev_ks[:t]) - 1, -2, -1):
+                hyp.append(int(self.next_ys[j + 1][k]))
+                k = self.prev_ks[j][k] if j >= 0 else k
+            hyps.append(hyp[::-1])
+            scores.append(float(s))
+        return hyps, scores
+
+
+def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1):
+    """Returns (hyps, scores): hyps[i][j] = token list incl. leading START."""
+    N = z.shape[0]
+    zc1 = np.concatenate([z, c], 1).astype(F32)
+    zc = np.tile(zc1, (beam_size, 1))  # beam-major [beam*N] (model.py:262-263)
+    h = zc.copy()
+    beams = [_Beam(beam_size, n_best, min_length) for _ in range(N)]
+    tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
+    for _ in range(max_len):
+        logits, h = decoder_step(P, tok, zc, h)
+        lg = logits.reshape(beam_size, N, -1)
+        hv = h.reshape(beam_size, N, -1)
+        for j, b in enumerate(beams):
+            if not b.done():
+                b.advance(_log_softmax(lg[:, j]))
+            hv[:, j] = hv[b.prev_ks[-1], j]  # _update_hidden (model.py:387-404), applied even when done
+        tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
+        if all(b.done() for b in beams):
+            break
+    out = [b.best() for b in beams]
+    return [o[0] for o in out], [o[1] for o in out]

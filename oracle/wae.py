@@ -1,0 +1,255 @@
+"""WAE/VAE forward, losses and hand-derived backward in numpy float32 (oracle; test infrastructure only).
+
+Follows the reference's training step (train_vae.py:24-42):
+  RNN_VAE.forward            models/model.py:146-195
+  GRUEncoder.forward         models/encoder.py:38-52
+  GRUDecoder.forward         models/decoder.py:56-84   (WordDropout :117-133)
+  losses.recon_dec           losses.py:18-31
+  losses.kl_gaussianprior    losses.py:8-10 ; kl_gaussian_sharedmu losses.py:13-15
+  losses.mmd_full_kernel     losses.py:47-56,96-108    (incl. the `H - diag(H)` broadcast quirk)
+  losses.mmd_rf              losses.py:59-93
+All randomness (eps, c, word-dropout mask, out-dropout keep mask, z_prior, rf_w, rf_b) is an INPUT.
+Parameters are a dict keyed by the reference's state-dict names.
+"""
+import numpy as np
+
+from .gru import gru_seq_fwd, gru_seq_bwd, F32
+
+UNK, PAD, START, EOS = 0, 1, 2, 3  # models/mutils.py:5-8
+
+
+# ----------------------------------------------------------------------------- encoder
+def _enc_layers(P):
+    n = 0
+    while f"encoder.rnn.weight_ih_l{n}" in P:
+        n += 1
+    return n
+
+
+def encoder_fwd(P, ids):
+    """ids [B,T] int -> mu, logvar [B,Z]; cache for backward.  Steps through ALL T positions incl. pads (F4)."""
+    x = P["word_emb.weight"][ids]  # [B,T,E]
+    B, T, _ = x.shape
+    L = _enc_layers(P)
+    cache = {"ids": ids, "layers": []}
+    for l in range(L):
+        outs, lc = [], {"x": x}
+        for sfx, rev in (("", False), ("_reverse", True)):
+            w_ih, w_hh = P[f"encoder.rnn.weight_ih_l{l}{sfx}"], P[f"encoder.rnn.weight_hh_l{l}{sfx}"]
+            b_ih, b_hh = P[f"encoder.rnn.bias_ih_l{l}{sfx}"], P[f"encoder.rnn.bias_hh_l{l}{sfx}"]
+            H = w_hh.shape[1]
+            gi = (x.reshape(B * T, -1) @ w_ih.T + b_ih).reshape(B, T, 3 * H).astype(F32)
+            hs, h_last, cs = gru_seq_fwd(gi, np.zeros((B, H), F32), w_hh, b_hh, reverse=rev)
+            outs.append((hs, h_last))
+            lc[sfx] = cs
+        cache["layers"].append(lc)
+        x = np.concatenate([outs[0][0], outs[1][0]], 2)
+    h = np.concatenate([outs[0][1], outs[1][1]], 1)  # top layer fwd/bwd final states (encoder.py:46-47)
+    mu = (h @ P["encoder.q_mu.weight"].T + P["encoder.q_mu.bias"]).astype(F32)
+    logvar = (h @ P["encoder.q_logvar.weight"].T + P["encoder.q_logvar.bias"]).astype(F32)
+    cache["h"] = h
+    return mu, logvar, cache
+
+
+def encoder_bwd(P, dmu, dlogvar, cache, G):
+    h = cache["h"]
+    G["encoder.q_mu.weight"] = (dmu.T @ h).astype(F32)
+    G["encoder.q_mu.bias"] = dmu.sum(0).astype(F32)
+    G["encoder.q_logvar.weight"] = (dlogvar.T @ h).astype(F32)
+    G["encoder.q_logvar.bias"] = dlogvar.sum(0).astype(F32)
+    dh = (dmu @ P["encoder.q_mu.weight"] + dlogvar @ P["encoder.q_logvar.weight"]).astype(F32)
+    L = len(cache["layers"])
+    He = dh.shape[1] // 2
+    ids = cache["ids"]
+    B, T = ids.shape
+    dlast = {"": dh[:, :He], "_reverse": dh[:, He:]}
+    dout = np.zeros((B, T, 2 * He), F32)  # gradient wrt the layer's concatenated output sequence
+    for l in range(L - 1, -1, -1):
+        lc = cache["layers"][l]
+        x = lc["x"]
+        dx = np.zeros_like(x)
+        for di, (sfx, rev) in enumerate((("", False), ("_reverse", True))):
+            w_ih, w_hh = P[f"encoder.rnn.weight_ih_l{l}{sfx}"], P[f"encoder.rnn.weight_hh_l{l}{sfx}"]
+            dhs = dout[:, :, di * He:(di + 1) * He]
+            dgi, _, dW_hh, db_hh = gru_seq_bwd(dhs, dlast[sfx] if l == L - 1 else None, lc[sfx], w_hh, reverse=rev)
+            G[f"encoder.rnn.weight_hh_l{l}{sfx}"] = dW_hh
+            G[f"encoder.rnn.bias_hh_l{l}{sfx}"] = db_hh
+            flat = dgi.reshape(B * T, -1)
+            G[f"encoder.rnn.weight_ih_l{l}{sfx}"] = (flat.T @ x.reshape(B * T, -1)).astype(F32)
+            G[f"encoder.rnn.bias_ih_l{l}{sfx}"] = flat.sum(0).astype(F32)
+            dx += (flat @ w_ih).reshape(x.shape)
+        dout = dx
+    # embedding gradient (padding_idx row gets none: nn.Embedding(..., PAD_IDX), models/model.py:47)
+    demb = np.zeros_like(P["word_emb.weight"])
+    np.add.at(demb, ids.reshape(-1), dout.reshape(B * T, -1))
+    demb[PAD] = 0
+    return demb
+
+
+# ----------------------------------------------------------------------------- decoder
+def word_dropout(ids, wd_mask):
+    """WordDropout.forward (decoder.py:117-133): masked positions become <unk>; no exemption for START/PAD."""
+    out = ids.copy()
+    out[wd_mask.astype(bool)] = UNK
+    return out
+
+
+def decoder_fwd(P, ids, z, c, wd_mask, out_keep, p_out):
+    """Teacher-forced GRU decoder -> logits [B,T,V]."""
+    B, T = ids.shape
+    tok = word_dropout(ids, wd_mask)
+    zc = np.concatenate([z, c], 1).astype(F32)  # init_hidden (decoder.py:53-54) and per-step input tail
+    emb = P["word_emb.weight"][tok]
+    x = np.concatenate([emb, np.broadcast_to(zc[:, None, :], (B, T, zc.shape[1]))], 2).astype(F32)
+    w_ih, w_hh = P["decoder.rnn.weight_ih_l0"], P["decoder.rnn.weight_hh_l0"]
+    b_ih, b_hh = P["decoder.rnn.bias_ih_l0"], P["decoder.rnn.bias_hh_l0"]
+    H = w_hh.shape[1]
+    gi = (x.reshape(B * T, -1) @ w_ih.T + b_ih).reshape(B, T, 3 * H).astype(F32)
+    hs, _, cs = gru_seq_fwd(gi, zc, w_hh, b_hh)
+    scale = F32(1.0 / (1.0 - p_out)) if p_out > 0 else F32(1.0)
+    hd = (hs * (out_keep.astype(F32) * scale)).astype(F32)
+    logits = (hd.reshape(B * T, H) @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).reshape(B, T, -1)
+    cache = dict(tok=tok, x=x, cs=cs, hd=hd, keep=out_keep.astype(F32) * scale, zc=zc)
+    return logits.astype(F32), cache
+
+
+def decoder_bwd(P, dlogits, cache, G, E):
+    B, T, V = dlogits.shape
+    hd, x = cache["hd"], cache["x"]
+    H = hd.shape[2]
+    dl = dlogits.reshape(B * T, V)
+    G["decoder.fc.1.weight"] = (dl.T @ hd.reshape(B * T, H)).astype(F32)
+    G["decoder.fc.1.bias"] = dl.sum(0).astype(F32)
+    dhs = ((dl @ P["decoder.fc.1.weight"]).reshape(B, T, H) * cache["keep"]).astype(F32)
+    w_ih, w_hh = P["decoder.rnn.weight_ih_l0"], P["decoder.rnn.weight_hh_l0"]
+    dgi, dh0, dW_hh, db_hh = gru_seq_bwd(dhs, None, cache["cs"], w_hh)
+    G["decoder.rnn.weight_hh_l0"], G["decoder.rnn.bias_hh_l0"] = dW_hh, db_hh
+    flat = dgi.reshape(B * T, -1)
+    G["decoder.rnn.weight_ih_l0"] = (flat.T @ x.reshape(B * T, -1)).astype(F32)
+    G["decoder.rnn.bias_ih_l0"] = flat.sum(0).astype(F32)
+    dx = (flat @ w_ih).reshape(B, T, -1)
+    dzc = (dx[:, :, E:].sum(1) + dh0).astype(F32)
+    demb = np.zeros_like(P["word_emb.weight"])
+    np.add.at(demb, cache["tok"].reshape(-1), dx[:, :, :E].reshape(B * T, E))
+    demb[PAD] = 0
+    return dzc, demb
+
+
+# ----------------------------------------------------------------------------- losses
+def recon_dec(ids, logits):
+    """Mean NLL over non-PAD next-token targets of the whole batch.  Returns loss, dlogits."""
+    B, T, V = logits.shape
+    tgt = np.concatenate([ids[:, 1:], np.full((B, 1), PAD, ids.dtype)], 1).reshape(-1)
+    lg = logits.reshape(B * T, V).astype(F32)
+    m = lg.max(1, keepdims=True)
+    lse = m + np.log(np.exp(lg - m).sum(1, keepdims=True))
+    logp = lg - lse
+    valid = tgt != PAD
+    cnt = max(int(valid.sum()), 1)
+    nll = -logp[np.arange(B * T), tgt]
+    loss = F32(nll[valid].sum() / cnt)
+    d = np.exp(logp)
+    d[np.arange(B * T), tgt] -= 1.0
+    d[~valid] = 0.0
+    return loss, (d / cnt).reshape(B, T, V).astype(F32)
+
+
+def kl_gaussianprior(mu, lv):
+    B = mu.shape[0]
+    loss = F32(np.mean(0.5 * np.sum(np.exp(lv) + mu * mu - 1.0 - lv, 1)))
+    return loss, (mu / B).astype(F32), (0.5 * (np.exp(lv) - 1.0) / B).astype(F32)
+
+
+def kl_gaussian_sharedmu(mu, lv):
+    B = mu.shape[0]
+    loss = F32(np.mean(0.5 * np.sum(np.exp(lv) - 1.0 - lv, 1)))
+    return loss, (0.5 * (np.exp(lv) - 1.0) / B).astype(F32)
+
+
+def logvar_l1(lv):
+    B = lv.shape[0]
+    return F32(np.abs(lv).sum(1).mean(0)), (np.sign(lv) / B).astype(F32)
+
+
+def _sqdist(x, y):
+    return ((x[:, None, :].astype(np.float64) - y[None, :, :].astype(np.float64)) ** 2).sum(2)
+
+
+def mmd_full_kernel(z1, z2, sigma):
+    """Gaussian kernel exp(-|x-y|^2/sigma^2); H = K11+K22-2K12; then `H - diag(H)` BROADCASTS the diagonal
+    vector over rows (every column j loses H_jj in every row): loss = (sum H - N*sum_j H_jj)/(N(N-1))."""
+    N = z1.shape[0]
+    s2 = float(sigma) ** 2
+    K11, K22, K12 = np.exp(-_sqdist(z1, z1) / s2), np.exp(-_sqdist(z2, z2) / s2), np.exp(-_sqdist(z1, z2) / s2)
+    Hm = K11 + K22 - 2.0 * K12
+    loss = (Hm.sum() - N * np.trace(Hm)) / (N * (N - 1))
+    # d loss / d z1.  Coefficient on each H_ij: (1 - N*[i==j]) / (N(N-1))
+    coef = (np.ones((N, N)) - N * np.eye(N)) / (N * (N - 1))
+    z1d, z2d = z1.astype(np.float64), z2.astype(np.float64)
+    # K11_ij depends on z1_i and z1_j ; K12_ij on z1_i only
+    A = coef * K11
+    A = A + A.T
+    g = -(2.0 / s2) * (A.sum(1)[:, None] * z1d - A @ z1d)
+    Bm = -2.0 * coef * K12
+    g += -(2.0 / s2) * (Bm.sum(1)[:, None] * z1d - Bm @ z2d)
+    return F32(loss), g.astype(F32)
+
+
+def gaussian_rf(z, rf_w, rf_b, sigma):
+    R = rf_w.shape[1]
+    pre = (z @ rf_w) / F32(sigma) + rf_b
+    return (np.cos(pre) * F32((2.0 / R) ** 0.5)).astype(F32), pre
+
+
+def mmd_rf(z1, z2, rf_w, rf_b, sigma):
+    R = rf_w.shape[1]
+    f1, pre1 = gaussian_rf(z1, rf_w, rf_b, sigma)
+    f2, _ = gaussian_rf(z2, rf_w, rf_b, sigma)
+    diff = f1.mean(0) - f2.mean(0)
+    loss = F32((diff * diff).sum())
+    B = z1.shape[0]
+    dpre = (-np.sin(pre1) * F32((2.0 / R) ** 0.5)) * (2.0 * diff / B)[None, :]
+    dz1 = (dpre @ rf_w.T) / F32(sigma)
+    return loss, dz1.astype(F32)
+
+
+# ----------------------------------------------------------------------------- full training-loss evaluation
+def train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, z_regu, sigma=7.0, p_out=0.3):
+    """One train_vae loss evaluation + backward (train_vae.py:26-40).
+    rnd: dict with eps, c, wd_mask, out_mask, z_prior_full, z_prior_rf, rf_w, rf_b.
+    Returns (terms dict, grads dict keyed like the state dict, aux dict with z/logits/mu/logvar)."""
+    E = P["word_emb.weight"].shape[1]
+    mu, lv, ec = encoder_fwd(P, ids)
+    std = np.exp(lv / 2).astype(F32)
+    z = (mu + std * rnd["eps"]).astype(F32)
+    c = rnd["c"].astype(F32)
+    logits, dc = decoder_fwd(P, ids, z, c, rnd["wd_mask"], rnd["out_mask"], p_out)
+    recon, dlogits = recon_dec(ids, logits)
+    kl, dmu_kl, dlv_kl = kl_gaussianprior(mu, lv)
+    mmd, dz_mmd = mmd_full_kernel(z, rnd["z_prior_full"], sigma)
+    mmdrf, dz_rf = mmd_rf(z, rnd["z_prior_rf"], rnd["rf_w"], rnd["rf_b"], sigma)
+    l1, dlv_l1 = logvar_l1(lv)
+    klmu, dlv_klmu = kl_gaussian_sharedmu(mu, lv)
+    regu = {"kl": kl, "mmd": mmd, "mmdrf": mmdrf}[z_regu]
+    total = F32(recon + beta * regu + lam_l1 * l1 + lam_kl * klmu)
+    # backward
+    G = {}
+    dzc, demb_dec = decoder_bwd(P, dlogits, dc, G, E)
+    Z = z.shape[1]
+    dz = dzc[:, :Z].copy()
+    dmu = np.zeros_like(mu)
+    dlv = (lam_l1 * dlv_l1 + lam_kl * dlv_klmu).astype(F32)
+    if z_regu == "kl":
+        dmu += beta * dmu_kl
+        dlv += beta * dlv_kl
+    elif z_regu == "mmd":
+        dz += beta * dz_mmd
+    else:
+        dz += beta * dz_rf
+    dmu += dz
+    dlv += dz * rnd["eps"] * 0.5 * std
+    demb_enc = encoder_bwd(P, dmu.astype(F32), dlv.astype(F32), ec, G)
+    G["word_emb.weight"] = (demb_enc + demb_dec).astype(F32)
+    terms = dict(total=total, recon=recon, kl=kl, mmd=mmd, mmdrf=mmdrf, l1=l1, klmu=klmu)
+    aux = dict(mu=mu, logvar=lv, z=z, logits=logits, dz=dz.astype(F32), dlogits=dlogits)
+    return terms, G, aux
