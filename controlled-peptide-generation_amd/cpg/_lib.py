@@ -1,0 +1,93 @@
+"""ctypes binding of libcpg_hip.so, generated from include/cpg_api.h so header and binding cannot drift apart."""
+import ctypes
+import os
+import re
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(PKG_DIR)
+HEADER = os.path.join(ROOT, "include", "cpg_api.h")
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libcpg_hip.so")
+SOURCES = ["api.hip", "gemm.hip", "gru.hip", "decode.hip", "losses.hip", "optim.hip", "rng.hip", "class.hip"]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+    "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64, "void": None,
+}
+
+
+def _ctype(decl):
+    decl = decl.strip()
+    if decl.endswith("*") or "*" in decl:
+        if decl.replace(" ", "") == "constchar*":
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    base = decl.replace("const", "").strip()
+    return _CT[base]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [(argtype, argname), ...])} for every CPG_API declaration."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"CPG_API\s+([^;(]+?)\s*(\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        alist = []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"(.*?)(\w+)$", a)
+                alist.append((_ctype(mm.group(1)), mm.group(2)))
+        out[name] = (_ctype(ret), alist)
+    return out
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into the in-tree libcpg_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-I", CSRC, *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the cpg hot path.")
+        self.dll = ctypes.CDLL(LIB_PATH)
+        self.sigs = parse_header()
+        for name, (ret, args) in self.sigs.items():
+            fn = getattr(self.dll, name)  # AttributeError here = header declares a symbol the library lacks
+            fn.restype = ret
+            fn.argtypes = [a for a, _ in args]
+        self.dll.cpg_last_error.restype = ctypes.c_char_p
+
+    def last_error(self):
+        return (self.dll.cpg_last_error() or b"").decode()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

@@ -1,0 +1,149 @@
+"""Device-resident autoregressive decoding loops (RNN_VAE.sample_G hard modes, models/model.py:225-385).
+
+greedy / categorical: one fused GRU-step launch + one vocab projection + one select kernel per step, no host sync
+inside the loop (the reference syncs every step for `finished.sum() == mbsize`); the output is cut where the
+reference's loop would have stopped using a per-step counter read back once.
+beam: Beam.advance for all sentences in one kernel per step (models/Beam.py:56-105), hypotheses rebuilt on the host
+from the recorded back-pointers exactly as Beam.sort_finished / get_hyp do (Beam.py:110-132).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .ops import _p, _stream, call, PAD_IDX, START_IDX, EOS_IDX
+
+
+def _fc(decoder, h, logits):
+    fc = decoder.fc[1]
+    N, H = h.shape
+    call("cpg_vocab_fc_fwd", _p(h), None, 1.0, _p(fc.weight), _p(fc.bias), _p(logits), N, H, logits.shape[1], _stream())
+
+
+@torch.no_grad()
+def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1):
+    """ids int64 [N, 1+steps] (column 0 = <start>), steps <= max_len."""
+    N = z.shape[0]
+    dev = z.device
+    zc = decoder.init_hidden(z, c).contiguous()
+    tab, rowc = decoder._tables(zc)
+    tab, rowc = tab.contiguous(), rowc.contiguous()
+    w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
+    V = decoder.fc[1].weight.shape[0]
+    h_a, h_b = zc.clone(), torch.empty_like(zc)
+    tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
+    finished = torch.zeros(N, device=dev, dtype=torch.uint8)
+    ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
+    ids[:, 0] = START_IDX
+    unfinished = torch.zeros(max_len, device=dev, dtype=torch.int32)
+    logits = torch.empty(N, V, device=dev, dtype=torch.float32)
+    scratch = torch.empty(264, device=dev, dtype=torch.float32)
+    for i in range(max_len):
+        ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
+        _fc(decoder, h_b, logits)
+        pe = 1 if (prevent_empty and i == 0) else 0
+        if mode == "greedy":
+            call("cpg_greedy_select", _p(logits), N, V, _p(finished), _p(ids), max_len + 1, i + 1, _p(tok), PAD_IDX,
+                 START_IDX, EOS_IDX, pe, _p(scratch), _p(unfinished), i, _stream())
+        elif mode == "categorical":
+            lg = logits
+            if pe:
+                lg = logits.clone()
+                lg[:, [PAD_IDX, START_IDX, EOS_IDX]] = -2 * torch.abs(logits.min())
+            s = torch.distributions.Categorical(logits=lg / temp).sample()
+            s.masked_fill_(finished.bool(), PAD_IDX)
+            finished |= (s == EOS_IDX).to(torch.uint8)
+            ids[:, i + 1] = s
+            tok = s.to(torch.int32)
+            unfinished[i] = (finished == 0).sum()
+        else:
+            raise ValueError(mode)
+        h_a, h_b = h_b, h_a
+    unf = unfinished.cpu().numpy()
+    steps = max_len
+    for i in range(max_len):
+        if unf[i] == 0 and (i + 2) >= min_length:  # reference: all finished and len(seqIx) >= min_length
+            steps = i + 1
+            break
+    return ids[:, :steps + 1]
+
+
+@torch.no_grad()
+def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
+    """Runs the device beam search; returns numpy (tok, prev, score) each [T,N,K] (tok = -1 where a sentence had
+    already finished) for host-side hypothesis reconstruction."""
+    N = z.shape[0]
+    K = beam_size
+    dev = z.device
+    zc1 = decoder.init_hidden(z, c).contiguous()
+    tab, rowc1 = decoder._tables(zc1)
+    tab = tab.contiguous()
+    rowc = rowc1.repeat(K, 1).contiguous()            # beam-major rows: row = k*N + i (model.py:262-263)
+    h_a = zc1.repeat(K, 1).contiguous()
+    h_b = torch.empty_like(h_a)
+    w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
+    H = h_a.shape[1]
+    V = decoder.fc[1].weight.shape[0]
+    i32 = dict(device=dev, dtype=torch.int32)
+    scores = torch.zeros(N, K, device=dev, dtype=torch.float32)
+    last_tok = torch.full((N, K), PAD_IDX, **i32)
+    last_tok[:, 0] = START_IDX
+    n_fin = torch.zeros(N, **i32)
+    done = torch.zeros(N, device=dev, dtype=torch.uint8)
+    hist_tok = torch.full((max_len, N, K), -1, **i32)
+    hist_prev = torch.zeros(max_len, N, K, **i32)
+    hist_score = torch.zeros(max_len, N, K, device=dev, dtype=torch.float32)
+    origin = torch.zeros(N, K, **i32)
+    tok = torch.full((K, N), PAD_IDX, **i32)
+    tok[0] = START_IDX
+    tok = tok.view(-1).contiguous()
+    n_active = torch.zeros(max_len, **i32)
+    logits = torch.empty(K * N, V, device=dev, dtype=torch.float32)
+    steps_run = 0
+    for i in range(max_len):
+        ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
+        _fc(decoder, h_b, logits)
+        call("cpg_beam_select", _p(logits), N, V, K, i, n_best, min_length, START_IDX, EOS_IDX, _p(scores), _p(last_tok),
+             _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active), _p(h_b),
+             _p(h_a), H, _stream())
+        steps_run = i + 1
+        if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early
+            break
+    return (hist_tok[:steps_run].cpu().numpy(), hist_prev[:steps_run].cpu().numpy(), hist_score[:steps_run].cpu().numpy())
+
+
+def beam_hypotheses(tok, prev, score, n_best):
+    """Vectorised Beam.sort_finished + get_hyp over all sentences.
+    Returns (hyps int64 [N,n_best,T+1] padded with -1, lengths [N,n_best], scores [N,n_best])."""
+    T, N, K = tok.shape
+    adv = (tok[:, :, 0] >= 0)                          # [T,N] step advanced for sentence i
+    Ti = adv.sum(0)                                    # number of advanced steps per sentence
+    fin = (tok == EOS_IDX)                             # [T,N,K]
+    nfin = fin.reshape(T, N * K).reshape(T, N, K).sum((0, 2))
+    cand = np.where(fin, score, -np.inf).transpose(1, 0, 2).reshape(N, T * K)   # insertion order: t asc, k asc
+    need = np.clip(n_best - nfin, 0, n_best)           # entries taken from the live beam (Beam.py:111-117)
+    last = np.clip(Ti - 1, 0, T - 1)
+    fill = score[last, np.arange(N), :][:, :n_best].copy()
+    fill[np.arange(n_best)[None, :] >= need[:, None]] = -np.inf
+    allc = np.concatenate([cand, fill], 1)
+    order = np.argsort(-allc, axis=1, kind="stable")[:, :n_best]
+    out_scores = np.take_along_axis(allc, order, 1)
+    is_fill = order >= T * K
+    tl = np.where(is_fill, Ti[:, None], order // K + 1)         # hypothesis length in steps
+    k = np.where(is_fill, order - T * K, order % K)
+    hyps = np.full((N, n_best, T + 1), -1, np.int64)
+    hyps[:, :, 0] = START_IDX
+    rows = np.arange(N)[:, None]
+    cur = k.copy()
+    for j in range(T - 1, -1, -1):
+        act = j < tl
+        tj = tok[j][rows, cur]
+        hyps[:, :, j + 1] = np.where(act, tj, -1)
+        cur = np.where(act, prev[j][rows, cur], cur)
+    return hyps, tl + 1, out_scores
+
+
+def decode_beam(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
+    """Reference-format result: list over sentences of n_best hypotheses, each a list of ints incl. leading <start>."""
+    tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length)
+    hyps, lens, _ = beam_hypotheses(tok, prev, score, n_best)
+    return [[hyps[i, j, :lens[i, j]].tolist() for j in range(n_best)] for i in range(hyps.shape[0])]

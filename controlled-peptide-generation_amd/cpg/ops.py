@@ -1,0 +1,492 @@
+"""torch.autograd wrappers over the libcpg_hip.so kernels.
+
+Every function here takes CUDA tensors and launches HIP kernels on torch's current stream; torch supplies device
+memory, the stream and the autograd tape - nothing else.  There is no CPU path: tensors that are not on a GPU raise.
+Reference call sites are cited per op (paths relative to the reference repo).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from ._lib import lib
+
+PAD_IDX, UNK_IDX, START_IDX, EOS_IDX = 1, 0, 2, 3  # models/mutils.py:5-8
+
+
+class CpgError(RuntimeError):
+    pass
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CpgError("cpg ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L.dll, name)(*args)
+    if rc != 0:
+        raise CpgError(f"{name} failed (rc={rc}): {L.last_error()}")
+
+
+def query(name, *args):
+    return getattr(lib().dll, name)(*args)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag=0):
+    """Stream-keyed scratch buffer (grown on demand, reused across calls: launches on one stream are ordered)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _rowmajor(t):
+    """(tensor, ld) for a 2-D tensor whose last dim is contiguous (row stride may exceed the width)."""
+    assert t.dim() == 2
+    if t.stride(1) != 1 or t.stride(0) < t.size(1):
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+# ----------------------------------------------------------------------------------------------- dense
+def linear_raw(x, w, b, out=None, accumulate=False):
+    x, ldx = _rowmajor(x)
+    w, ldw = _rowmajor(w)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    call("cpg_linear_fwd", _p(x), ldx, _p(w), ldw, _p(b), _p(out), out.stride(0), M, N, K, int(accumulate), _stream())
+    return out
+
+
+class LinearFn(Function):
+    """y = x W^T + b (nn.Linear: models/encoder.py:35-36,50-51; also the token-table and [z;c] projections that
+    replace the W_ih half of nn.GRU at models/decoder.py:70-77)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return linear_raw(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy, lddy = _rowmajor(dy)
+        xx, ldx = _rowmajor(x)
+        ww, ldw = _rowmajor(w)
+        M, K = xx.shape
+        N = ww.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            call("cpg_linear_bwd_input", _p(dy), lddy, _p(ww), ldw, _p(dx), K, M, N, K, 0, _stream())
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+            db = torch.empty(N, device=dy.device, dtype=torch.float32) if ctx.has_b else None
+            nb = query("cpg_linear_bwd_weight_workspace", M, N, K)
+            ws = workspace(nb, dy.device)
+            call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw), K, _p(db), M, N, K, 0, _p(ws), ws.numel(),
+                 _stream())
+        return dx, dw, db
+
+
+class Linear2Fn(Function):
+    """y = x1 W[:, :K1]^T + x2 W[:, K1:]^T + b  (input projection of an upper biGRU layer: its input is the
+    concatenation of the lower layer's two directions, which are two separate state slabs here)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        ctx.save_for_backward(x1, x2, w)
+        K1 = x1.shape[1]
+        y = linear_raw(x1, w[:, :K1], b)
+        linear_raw(x2, w[:, K1:], None, out=y, accumulate=True)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w = ctx.saved_tensors
+        K1, K2 = x1.shape[1], x2.shape[1]
+        dy, lddy = _rowmajor(dy)
+        M, N = dy.shape
+        dw = torch.empty_like(w)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32)
+        dxs = []
+        for x, k0, kk in ((x1, 0, K1), (x2, K1, K2)):
+            xx, ldx = _rowmajor(x)
+            wv = w[:, k0:k0 + kk]
+            dx = torch.empty(M, kk, device=dy.device, dtype=torch.float32)
+            call("cpg_linear_bwd_input", _p(dy), lddy, _p(wv), w.stride(0), _p(dx), kk, M, N, kk, 0, _stream())
+            nb = query("cpg_linear_bwd_weight_workspace", M, N, kk)
+            ws = workspace(nb, dy.device)
+            call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw[:, k0:]), dw.stride(0),
+                 _p(db) if k0 == 0 else None, M, N, kk, 0, _p(ws), ws.numel(), _stream())
+            dxs.append(dx)
+        return dxs[0], dxs[1], dw, db
+
+
+class ZeroRowGradFn(Function):
+    """Identity whose backward zeroes one row: nn.Embedding(padding_idx=PAD) gives <pad> no gradient (models/model.py:47)."""
+
+    @staticmethod
+    def forward(ctx, w, row):
+        ctx.row = row
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.clone()
+        g[ctx.row].zero_()
+        return g, None
+
+
+def tokens_prepare(ids, wd_mask=None):
+    """ids int64 [B,T] -> int32 [T,B] time-major, WordDropout applied (models/decoder.py:117-133)."""
+    B, T = ids.shape
+    ids = ids.contiguous()
+    tok = torch.empty(T, B, device=ids.device, dtype=torch.int32)
+    if wd_mask is not None:
+        wd_mask = wd_mask.to(torch.uint8).contiguous()
+    call("cpg_tokens_prepare", _p(ids), _p(wd_mask), B, T, UNK_IDX, _p(tok), _stream())
+    return tok
+
+
+class Transpose01Fn(Function):
+    """[d0,d1,inner] -> [d1,d0,inner] contiguous (time-major logits back to the reference's [B,T,V])."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        d0, d1, inner = x.shape
+        y = torch.empty(d1, d0, inner, device=x.device, dtype=torch.float32)
+        call("cpg_transpose01_f32", _p(x), d0, d1, inner, _p(y), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        d1, d0, inner = g.shape
+        y = torch.empty(d0, d1, inner, device=g.device, dtype=torch.float32)
+        call("cpg_transpose01_f32", _p(g), d1, d0, inner, _p(y), _stream())
+        return y
+
+
+def transpose01_u8(x):
+    x = x.contiguous()
+    d0, d1, inner = x.shape
+    y = torch.empty(d1, d0, inner, device=x.device, dtype=torch.uint8)
+    call("cpg_transpose01_u8", _p(x), d0, d1, inner, _p(y), _stream())
+    return y
+
+
+# ----------------------------------------------------------------------------------------------- GRU
+class GruSeqFn(Function):
+    """One direction of one GRU layer over the whole sequence (torch.nn.GRU at models/encoder.py:25-30,42 and
+    models/decoder.py:40-41,77).  Returns the state slab [(T+1),B,H] (layout in include/cpg_api.h)."""
+
+    @staticmethod
+    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse):
+        dev = w_hh.device
+        H = w_hh.shape[1]
+        B = tok.shape[1] if tok is not None else (rowc.shape[0] if rowc is not None else dense.shape[1])
+        w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
+        tab_c = tab.contiguous() if tab is not None else None
+        rowc_c = rowc.contiguous() if rowc is not None else None
+        dense_c = dense.contiguous() if dense is not None else None
+        hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        slot0 = T if reverse else 0
+        if h0 is None:
+            hs[slot0].zero_()
+        else:
+            hs[slot0].copy_(h0)
+        need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, w_hh, b_hh))
+        gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
+             _p(hs), _p(gates), _stream())
+        ctx.save_for_backward(tok, w_hh_c, hs, gates)
+        ctx.dims = (T, B, H, bool(reverse))
+        ctx.V = tab.shape[0] if tab is not None else 0
+        ctx.has = (tab is not None, rowc is not None, dense is not None, h0 is not None)
+        return hs
+
+    @staticmethod
+    def backward(ctx, ghs):
+        tok, w_hh, hs, gates = ctx.saved_tensors
+        T, B, H, reverse = ctx.dims
+        dev = ghs.device
+        ghs = ghs.contiguous()
+        BH = B * H
+        flat = ghs.view(-1)
+        # time-aligned gradients on the step outputs: slots 1..T (forward) / 0..T-1 (reverse)
+        dhs_ext = flat[BH:] if not reverse else flat[:T * BH]
+        has_tab, has_rowc, has_dense, has_h0 = ctx.has
+        dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+        dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
+        call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG), _p(scratch),
+             _p(dh0), _stream())
+        if has_h0:
+            dh0 = dh0 + (ghs[T] if reverse else ghs[0])
+        nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
+        ws = workspace(nb, dev)
+        dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
+        db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
+        call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), _p(db_hh), 0, _p(ws), ws.numel(), _stream())
+        dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32) if has_tab else None
+        drowc = torch.empty(B, 3 * H, device=dev, dtype=torch.float32) if has_rowc else None
+        if has_tab or has_rowc:
+            call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(drowc), 0, _p(ws), ws.numel(), _stream())
+        ddense = None
+        if has_dense:
+            # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
+            ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2)
+        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None
+
+
+def gru_step(tok, tab, rowc, h_prev, h_out, w_hh, b_hh):
+    """One decode step's recurrent part (GRUDecoder.forward_sample, models/decoder.py:86-99); inference only."""
+    B, H = h_prev.shape
+    call("cpg_gru_step_fwd", B, H, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(h_prev), _p(h_out), _stream())
+    return h_out
+
+
+# ----------------------------------------------------------------------------------------------- vocab projection
+class VocabFcFn(Function):
+    """nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab) (models/decoder.py:43-45,83): logits = (hs .* keep/(1-p)) W^T + b."""
+
+    @staticmethod
+    def forward(ctx, hs, keep, scale, w, b):
+        hs = hs.contiguous()
+        R, H = hs.shape
+        V = w.shape[0]
+        w_c, b_c = w.contiguous(), b.contiguous()
+        logits = torch.empty(R, V, device=hs.device, dtype=torch.float32)
+        call("cpg_vocab_fc_fwd", _p(hs), _p(keep), float(scale), _p(w_c), _p(b_c), _p(logits), R, H, V, _stream())
+        ctx.save_for_backward(hs, keep, w_c)
+        ctx.scale = float(scale)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        hs, keep, w = ctx.saved_tensors
+        dl = dl.contiguous()
+        R, H = hs.shape
+        V = w.shape[0]
+        dev = dl.device
+        dhs = torch.empty(R, H, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(V, H, device=dev, dtype=torch.float32)
+        db = torch.empty(V, device=dev, dtype=torch.float32)
+        nb = query("cpg_vocab_fc_bwd_workspace", R, H, V)
+        ws = workspace(nb, dev)
+        call("cpg_vocab_fc_bwd", _p(dl), _p(hs), _p(keep), ctx.scale, _p(w), _p(dhs), _p(dw), _p(db), R, H, V, 0, _p(ws),
+             ws.numel(), _stream())
+        return dhs, None, None, dw, db
+
+
+# ----------------------------------------------------------------------------------------------- latent / losses
+class ReparamFn(Function):
+    """z = mu + exp(logvar/2) * eps (RNN_VAE.sample_z, models/model.py:107-112)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        z = torch.empty_like(mu)
+        call("cpg_reparam_fwd", _p(mu), _p(logvar), _p(eps), _p(z), mu.numel(), _stream())
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = dz.contiguous()
+        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        call("cpg_reparam_bwd", _p(dz), _p(logvar), _p(eps), _p(dmu), _p(dlv), dz.numel(), _stream())
+        return dmu, dlv, None
+
+
+def latent_sums(mu, logvar):
+    """Device tensor [5]: sums behind kl, kl_sharedmu, |logvar|, |mu|, logvar (losses.py:8-15, train_vae.py:33,44-45)."""
+    mu, logvar = mu.contiguous(), logvar.contiguous()
+    out = torch.empty(5, device=mu.device, dtype=torch.float32)
+    ws = workspace(1280 * 4, mu.device, tag=1)
+    call("cpg_latent_stats_fwd", _p(mu), _p(logvar), mu.numel(), _p(out), _p(ws), _stream())
+    return out
+
+
+class LatentTermFn(Function):
+    """One of the three analytic latent penalties as a differentiable scalar: which = 0 kl_gaussianprior,
+    1 kl_gaussian_sharedmu, 2 logvar L1 (mean over the batch of per-row sums)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, which, b_global):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        sums = latent_sums(mu, logvar)
+        ctx.save_for_backward(mu, logvar)
+        ctx.which, ctx.bg = which, b_global
+        return sums[which] / b_global
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        gs = [None, None, None]
+        gs[ctx.which] = _p(g)
+        call("cpg_latent_stats_bwd", _p(mu), _p(logvar), mu.numel(), ctx.bg, gs[0], gs[1], gs[2], _p(dmu), _p(dlv), 0,
+             _stream())
+        return dmu, dlv, None, None
+
+
+class ReconCEFn(Function):
+    """losses.recon_dec (losses.py:18-31).  Returns (sum_nll, count) as device scalars; loss = sum/count is formed by
+    the caller so a data-parallel run can all-reduce both first."""
+
+    @staticmethod
+    def forward(ctx, logits, ids):
+        logits, ids = logits.contiguous(), ids.contiguous()
+        B, T, V = logits.shape
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        ws = workspace(512 * 4, logits.device, tag=1)
+        call("cpg_recon_ce_fwd", _p(ids), _p(logits), B, T, V, PAD_IDX, _p(out), _p(ws), _stream())
+        ctx.save_for_backward(logits, ids)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):  # pragma: no cover - the differentiable form is ReconLossFn
+        raise CpgError("use ReconLossFn")
+
+
+class ReconLossFn(Function):
+    @staticmethod
+    def forward(ctx, logits, ids, count_override):
+        logits, ids = logits.contiguous(), ids.contiguous()
+        B, T, V = logits.shape
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        ws = workspace(512 * 4, logits.device, tag=1)
+        call("cpg_recon_ce_fwd", _p(ids), _p(logits), B, T, V, PAD_IDX, _p(out), _p(ws), _stream())
+        count = out[1:2] if count_override is None else count_override.reshape(1).to(torch.float32)
+        ctx.save_for_backward(logits, ids, count.contiguous())
+        return out[0] / count.clamp(min=1.0)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, ids, count = ctx.saved_tensors
+        B, T, V = logits.shape
+        g = g.contiguous()
+        dl = torch.empty_like(logits)
+        call("cpg_recon_ce_bwd", _p(ids), _p(logits), B, T, V, PAD_IDX, _p(g), _p(count), _p(dl), _stream())
+        return dl, None, None
+
+
+def rf_sums(z, rf_w, rf_b, sigma):
+    """(raw [B,R] = z @ rf_w, sums [R] = sum_b phi(z_b))  - compute_gaussian_rf, losses.py:84-88."""
+    z = z.contiguous()
+    B, Z = z.shape
+    R = rf_w.shape[1]
+    raw = torch.empty(B, R, device=z.device, dtype=torch.float32)
+    call("cpg_matmul_nn", _p(z), Z, _p(rf_w), R, _p(raw), R, B, R, Z, 0, _stream())
+    sums = torch.empty(R, device=z.device, dtype=torch.float32)
+    ws = workspace(128 * R * 4, z.device, tag=1)
+    call("cpg_rf_feature_sums", _p(raw), _p(rf_b), B, R, float(sigma), _p(sums), _p(ws), ws.numel(), _stream())
+    return raw, sums
+
+
+class MmdRfFn(Function):
+    """losses.mmd_rf (losses.py:59-93) with a fixed random-feature basis.  `reduce` (optional) all-reduces the two
+    feature sums across data-parallel ranks; b_global is the global batch."""
+
+    @staticmethod
+    def forward(ctx, z, z_prior, rf_w, rf_b, sigma, b_global, reduce, world=1):
+        rf_w, rf_b = rf_w.contiguous(), rf_b.contiguous()
+        raw1, s1 = rf_sums(z, rf_w, rf_b, sigma)
+        _, s2 = rf_sums(z_prior, rf_w, rf_b, sigma)
+        if reduce is not None:
+            reduce(s1)
+            reduce(s2)
+        R = rf_w.shape[1]
+        loss = torch.empty(1, device=z.device, dtype=torch.float32)
+        diff = torch.empty(R, device=z.device, dtype=torch.float32)
+        call("cpg_rf_loss", _p(s1), _p(s2), R, int(b_global), _p(loss), _p(diff), _stream())
+        ctx.save_for_backward(raw1, rf_w, rf_b, diff)
+        # every rank differentiates the GLOBAL loss wrt its local rows; the later gradient all-reduce averages over
+        # ranks (SUM * 1/world), so the local contribution is pre-scaled by world: 1/B_global -> 1/B_local.
+        ctx.sigma, ctx.bg = float(sigma), max(int(b_global) // max(int(world), 1), 1)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        raw1, rf_w, rf_b, diff = ctx.saved_tensors
+        B, R = raw1.shape
+        Z = rf_w.shape[0]
+        g = g.contiguous()
+        dpre = torch.empty_like(raw1)
+        call("cpg_rf_bwd", _p(raw1), _p(rf_b), _p(diff), _p(g), B, R, ctx.sigma, ctx.bg, _p(dpre), _stream())
+        dz = linear_raw(dpre, rf_w, None)  # dpre [B,R] @ rf_w^T ([Z,R] rows) -> [B,Z]
+        return dz, None, None, None, None, None, None, None
+
+
+class MmdFullFn(Function):
+    """losses.mmd_full_kernel with the Gaussian kernel (losses.py:47-56,96-108), F7 quirk included."""
+
+    @staticmethod
+    def forward(ctx, z, z_prior, sigma):
+        z, z_prior = z.contiguous(), z_prior.contiguous()
+        N, D = z.shape
+        dev = z.device
+        out = torch.empty(3, device=dev, dtype=torch.float32)
+        need = z.requires_grad
+        P = torch.empty(N, N, device=dev, dtype=torch.float32) if need else None
+        Q = torch.empty(N, N, device=dev, dtype=torch.float32) if need else None
+        nb = query("cpg_mmd_full_workspace", N)
+        ws = workspace(nb, dev)
+        call("cpg_mmd_full_fwd", _p(z), _p(z_prior), N, D, float(sigma), _p(out), _p(P), _p(Q), _p(ws), ws.numel(), _stream())
+        ctx.save_for_backward(z, z_prior, P, Q)
+        ctx.sigma = float(sigma)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        z, z_prior, P, Q = ctx.saved_tensors
+        N, D = z.shape
+        g = g.contiguous()
+        dz = torch.empty_like(z)
+        ws = workspace((N * D + N) * 4 + 256, z.device)
+        call("cpg_mmd_full_bwd", _p(z), _p(z_prior), _p(P), _p(Q), _p(g), N, D, ctx.sigma, _p(dz), _p(ws), ws.numel(),
+             _stream())
+        return dz, None, None
+
+
+# ----------------------------------------------------------------------------------------------- random streams
+def rng_normal(shape, seed, offset, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("cpg_rng_normal", _p(out), out.numel(), int(seed), int(offset), _stream())
+    return out
+
+
+def rng_uniform(shape, seed, offset, device, dtype=torch.float32):
+    out = torch.empty(shape, device=device, dtype=dtype)
+    name = "cpg_rng_uniform_f64" if dtype == torch.float64 else "cpg_rng_uniform"
+    call(name, _p(out), out.numel(), int(seed), int(offset), _stream())
+    return out
+
+
+def rng_bernoulli(shape, p_one, seed, offset, device):
+    out = torch.empty(shape, device=device, dtype=torch.uint8)
+    call("cpg_rng_bernoulli_u8", _p(out), out.numel(), float(p_one), int(seed), int(offset), _stream())
+    return out

@@ -1,0 +1,232 @@
+// Vocabulary projection and the per-step token selection of autoregressive decoding.
+//   cpg_vocab_fc_fwd / _bwd   nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab)        models/decoder.py:43-45,83
+//   cpg_greedy_select         argmax + finished masking of RNN_VAE.sample_G         models/model.py:310-311,350-353,362-363
+//   cpg_beam_select           log_softmax + Beam.advance + hidden-state reorder      models/model.py:314-328,387-404; models/Beam.py:56-105
+#include "cpg_internal.h"
+
+CPG_EXPORT int cpg_vocab_fc_fwd(const float* hs, const uint8_t* keep, float scale, const float* w, const float* b,
+                                float* logits, int R, int H, int V, void* stream) {
+    CPG_CHECK_ARG(hs && w && logits && R > 0 && H > 0 && V > 0);
+    return cpg_gemm_nt(hs, H, keep, scale, w, H, b, logits, V, R, V, H, 0, (hipStream_t)stream);
+}
+
+CPG_EXPORT size_t cpg_vocab_fc_bwd_workspace(int R, int H, int V) {
+    size_t a = cpg_gemm_tn_workspace(R, V, H), b = cpg_colsum_workspace(R, V);
+    return (a > b ? a : b) + 256;
+}
+
+// dhs[R,H] = (dlogits W) .* keep*scale ; dw[V,H] (+)= dlogits^T (hs .* keep*scale) ; db[V] (+)= colsum(dlogits)
+CPG_EXPORT int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uint8_t* keep, float scale, const float* w,
+                                float* dhs, float* dw, float* db, int R, int H, int V, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(dlogits && hs && w && R > 0 && H > 0 && V > 0);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    if (dhs) rc = cpg_gemm_nn(dlogits, V, w, H, dhs, H, R, H, V, 0, keep, scale, s);
+    if (rc) return rc;
+    if (dw) {
+        rc = cpg_gemm_tn(dlogits, V, hs, H, keep, scale, dw, H, R, V, H, accumulate, (float*)workspace, workspace_bytes, s);
+        if (rc) return rc;
+    }
+    if (db) rc = cpg_colsum(dlogits, V, R, V, db, accumulate, (float*)workspace, workspace_bytes, s);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------ greedy
+__global__ void min_partial_kernel(const float* x, size_t n, float* part) {
+    __shared__ float red[4];
+    float m = INFINITY;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fminf(m, x[i]);
+    m = -wave_max(-m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+
+__global__ void min_final_kernel(const float* part, int n, float* out) {
+    float m = INFINITY;
+    for (int i = threadIdx.x; i < n; i += 64) m = fminf(m, part[i]);
+    m = -wave_max(-m);
+    if (threadIdx.x == 0) out[0] = m;
+}
+
+// One thread per row.  tok = first-max index (torch.argmax tie rule); finished rows emit PAD; rows that emit EOS become
+// finished.  unfinished[step] counts rows still running AFTER this step so the host can cut the output where the
+// reference's loop breaks (model.py:362-363) with a single sync at the end.
+__global__ void greedy_select_kernel(const float* logits, int N, int V, uint8_t* finished, int64_t* ids, int ld_ids, int col,
+                                     int32_t* tok_next, int pad, int eos, const float* neg_src, int m0, int m1, int m2,
+                                     int* unfinished, int step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int live = 0;
+    if (i < N) {
+        const float* l = logits + (size_t)i * V;
+        const float neg = neg_src ? -2.f * fabsf(neg_src[0]) : 0.f;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int v = 0; v < V; ++v) {
+            float x = l[v];
+            if (neg_src && (v == m0 || v == m1 || v == m2)) x = neg;
+            if (x > best) {
+                best = x;
+                arg = v;
+            }
+        }
+        const bool fin = finished[i] != 0;
+        const int t = fin ? pad : arg;
+        if (t == eos) finished[i] = 1;
+        live = (fin || t == eos) ? 0 : 1;
+        ids[(size_t)i * ld_ids + col] = t;
+        tok_next[i] = t;
+    }
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&unfinished[step], __popcll(b));
+}
+
+CPG_EXPORT int cpg_greedy_select(const float* logits, int N, int V, uint8_t* finished, int64_t* ids, int ld_ids, int col,
+                                 int32_t* tok_next, int pad, int start, int eos, int prevent_empty, float* scratch,
+                                 int* unfinished, int step, void* stream) {
+    CPG_CHECK_ARG(logits && finished && ids && tok_next && unfinished && N > 0 && V > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const float* neg = nullptr;
+    if (prevent_empty) {
+        // large_neg = -2*|min(logits)| over the whole batch (model.py:299-305)
+        CPG_CHECK_ARG(scratch);
+        const int nb = 256;
+        hipLaunchKernelGGL(min_partial_kernel, dim3(nb), dim3(256), 0, s, logits, (size_t)N * V, scratch + 1);
+        hipLaunchKernelGGL(min_final_kernel, dim3(1), dim3(64), 0, s, scratch + 1, nb, scratch);
+        neg = scratch;
+    }
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, logits, N, V, finished, ids, ld_ids, col,
+                       tok_next, pad, eos, neg, pad, start, eos, unfinished, step);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ beam
+// One wave per sentence.  Rows are beam-major (row = k*N + i).  State per sentence: scores[K], last tokens, flags.
+// Restates Beam.advance: BOS column := -1e20; first step uses beam 0 only; children of EOS-ended beams := -1e20;
+// top-K over the flat K*V candidates (ties: lower flat index first); done when top beam is EOS and >= n_best finished.
+#define CPG_MAX_BEAM 8
+#define CPG_BEAM_Q 8   // candidates per lane: K*V <= 64*CPG_BEAM_Q
+__global__ void beam_select_kernel(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos,
+                                   int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
+                                   int32_t* hist_tok, int32_t* hist_prev, float* hist_score, int32_t* origin,
+                                   int32_t* tok_next, int* n_active) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N) return;
+    const int i = wave;
+    int32_t* org = origin + (size_t)i * K;
+    if (done[i]) {  // not advanced: keeps its last tokens; reference re-applies the last origin (irrelevant once done)
+        if (lane < K) tok_next[(size_t)lane * N + i] = last_tok[(size_t)i * K + lane];
+        return;
+    }
+    const int nc = K * V;
+    // candidates handled by this lane: flat index c = lane + 64*q (q < CPG_BEAM_Q, static indexing keeps them in VGPRs)
+    float cand[CPG_BEAM_Q];
+#pragma unroll
+    for (int q = 0; q < CPG_BEAM_Q; ++q) cand[q] = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const float* l = logits + ((size_t)k * N + i) * V;
+        // log_softmax over V by the whole wave
+        float m = -INFINITY;
+        for (int v = lane; v < V; v += 64) m = fmaxf(m, l[v]);
+        m = wave_max(m);
+        float se = 0.f;
+        for (int v = lane; v < V; v += 64) se += expf(l[v] - m);
+        se = wave_sum(se);
+        const float lse = m + logf(se);
+        const bool parent_eos = (step > 0) && last_tok[(size_t)i * K + k] == eos;
+        const float base = step > 0 ? scores[(size_t)i * K + k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < CPG_BEAM_Q; ++q) {
+            const int c = lane + 64 * q;
+            if (c >= nc || c / V != k) continue;
+            const int v = c % V;
+            float lp = l[v] - lse;
+            if (step + 1 < min_length && v == eos) lp = -1e20f;
+            if (v == bos) lp = -1e20f;
+            float sc = step > 0 ? lp + base : lp;
+            if (parent_eos) sc = -1e20f;
+            if (step == 0 && k > 0) sc = -INFINITY;  // first step: only beam 0 is a candidate row
+            cand[q] = sc;
+        }
+    }
+    float new_sc[CPG_MAX_BEAM];
+    int new_c[CPG_MAX_BEAM];
+#pragma unroll
+    for (int sel = 0; sel < CPG_MAX_BEAM; ++sel) {
+        if (sel >= K) break;
+        float bv = -INFINITY;
+        int bc = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < CPG_BEAM_Q; ++q) {
+            const int c = lane + 64 * q;
+            if (c < nc && (cand[q] > bv || (cand[q] == bv && c < bc))) {
+                bv = cand[q];
+                bc = c;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oc = __shfl_xor(bc, o, 64);
+            if (ov > bv || (ov == bv && oc < bc)) {
+                bv = ov;
+                bc = oc;
+            }
+        }
+        new_sc[sel] = bv;
+        new_c[sel] = bc;
+#pragma unroll
+        for (int q = 0; q < CPG_BEAM_Q; ++q)
+            if (lane + 64 * q == bc) cand[q] = -INFINITY;  // remove the winner (exactly one lane owns it)
+    }
+    if (lane == 0) {
+        int nf = n_finished[i];
+#pragma unroll
+        for (int k = 0; k < CPG_MAX_BEAM; ++k) {
+            if (k >= K) break;
+            const int pk = new_c[k] / V, tk = new_c[k] - pk * V;
+            scores[(size_t)i * K + k] = new_sc[k];
+            last_tok[(size_t)i * K + k] = tk;
+            org[k] = pk;
+            const size_t h = ((size_t)step * N + i) * K + k;
+            hist_tok[h] = tk;
+            hist_prev[h] = pk;
+            hist_score[h] = new_sc[k];
+            tok_next[(size_t)k * N + i] = tk;
+            if (tk == eos) ++nf;
+        }
+        n_finished[i] = nf;
+        const int top = new_c[0] % V;
+        if (top == eos && nf >= n_best) done[i] = 1; else atomicAdd(n_active, 1);
+    }
+}
+
+// h_out[k*N+i] = h_in[origin[i][k]*N + i]
+__global__ void beam_reorder_kernel(const float* h_in, float* h_out, const int32_t* origin, int N, int K, int H) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)K * N * H) return;
+    const int c = idx % H;
+    const size_t r = idx / H;
+    const int i = r % N, k = r / N;
+    const int pk = origin[(size_t)i * K + k];
+    h_out[idx] = h_in[((size_t)pk * N + i) * H + c];
+}
+
+CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos, int eos,
+                               float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done, int32_t* hist_tok,
+                               int32_t* hist_prev, float* hist_score, int32_t* origin, int32_t* tok_next, int* n_active,
+                               const float* h_in, float* h_out, int H, void* stream) {
+    CPG_CHECK_ARG(logits && scores && last_tok && n_finished && done && hist_tok && hist_prev && hist_score && origin);
+    CPG_CHECK_ARG(N > 0 && V > 0 && K > 0 && K <= CPG_MAX_BEAM && K * V <= 64 * CPG_BEAM_Q && h_in && h_out && h_in != h_out && tok_next && n_active);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(beam_select_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, logits, N, V, K, step, n_best, min_length, bos,
+                       eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,
+                       n_active + step);
+    CPG_LAUNCH_CHECK();
+    const size_t n = (size_t)K * N * H;
+    hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h_in, h_out, origin, N, K, H);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}

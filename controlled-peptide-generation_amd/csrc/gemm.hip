@@ -1,0 +1,240 @@
+// Dense f32 products behind nn.Linear / `@` on the hot path, on the f32 MFMA tile engine (gemm_core.h).
+//   cpg_linear_fwd         Y = X W^T + b          (models/encoder.py:35-36,50-51; models/decoder.py:43-45,83)
+//   cpg_linear_bwd_input   dX = dY W
+//   cpg_linear_bwd_weight  dW = dY^T X, db = colsum(dY)   (split-K over the batch dimension, deterministic slab reduce)
+//   cpg_matmul_nn          Y = X B                (losses.py:85  z @ rf_w)
+#include "gemm_core.h"
+#include "cpg_internal.h"
+
+struct GemmArgs {
+    const float* A; int lda; int M;
+    const float* B; int ldb; int N;
+    int K;
+    float* C; int ldc;
+    const float* bias;
+    int accumulate;
+    const uint8_t* a_mask; float a_mscale;   // multiplies A on load
+    const uint8_t* b_mask; float b_mscale;   // multiplies B on load
+    const uint8_t* c_mask; float c_mscale;   // multiplies C on store (same indexing as C)
+    int k_chunk;        // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)), writes slab z
+    size_t slab_stride; // floats between slabs (0 when not split)
+};
+
+template <class TC, bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m0 = blockIdx.y * TC::BM, n0 = blockIdx.x * TC::BN;
+    int kb = 0, K = g.K;
+    if (g.k_chunk > 0) {
+        kb = blockIdx.z * g.k_chunk;
+        K = min(g.K - kb, g.k_chunk);
+    }
+    const size_t aoff = A_KC ? (size_t)kb : (size_t)kb * g.lda;
+    const size_t boff = B_KC ? (size_t)kb : (size_t)kb * g.ldb;
+    OpA a{g.A + aoff, g.lda, m0, g.M, g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale};
+    OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale};
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    MainLoop<TC, A_KC, B_KC, VEC, VEC>::run(a, b, K, smem, acc);
+    float* C = g.C + (size_t)blockIdx.z * g.slab_stride;
+    const bool plain = g.k_chunk == 0;
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) {
+            const int col = n0 + acc_col<TC>(ni);
+            if (col >= g.N) continue;
+            const float bv = (plain && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                if (row >= g.M) continue;
+                const size_t o = (size_t)row * g.ldc + col;
+                float v = acc[mi][ni][r] + bv;
+                if (plain) {
+                    if (g.accumulate) v += C[o];
+                    if (g.c_mask) v = g.c_mask[o] ? v * g.c_mscale : 0.f;
+                }
+                C[o] = v;
+            }
+        }
+}
+
+// out[m,n] (+)= sum_z slab[z][m,n]
+__global__ void slab_reduce_kernel(const float* slabs, size_t slab_stride, int S, float* C, int ldc, int M, int N,
+                                   int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = i / N, n = i % N;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[z * slab_stride + (size_t)m * N + n];
+    const size_t o = (size_t)m * ldc + n;
+    C[o] = accumulate ? C[o] + s : s;
+}
+
+// part[chunk][n] = sum over rows of the chunk of X[m, n]; 64 columns x 4 row lanes per block.
+__global__ void colsum_partial_kernel(const float* X, int ld, int M, int N, int rows_per_chunk, float* part) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
+    const int mb = blockIdx.y * rows_per_chunk, me = min(M, mb + rows_per_chunk);
+    float s = 0.f;
+    if (n < N)
+        for (int m = mb + ty; m < me; m += 4) s += X[(size_t)m * ld + n];
+    red[ty][threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                              red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void colsum_final_kernel(const float* part, int chunks, int N, float* out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+template <class TC, bool A_KC, bool B_KC>
+static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(g.N, TC::BN), cdiv(g.M, TC::BM), zdim);
+    const size_t smem = TC::template smem_floats<A_KC, B_KC>() * sizeof(float);
+    if (vec)
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true>), grid, dim3(256), smem, s, g);
+    else
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false>), grid, dim3(256), smem, s, g);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+using T128x64 = TileCfg<128, 64, 32, 2, 2, 1>;
+using T128x32 = TileCfg<128, 32, 32, 4, 1, 1>;
+using T32x128 = TileCfg<32, 128, 32, 1, 4, 1>;
+using T64x64 = TileCfg<64, 64, 32, 2, 2, 1>;
+
+template <bool A_KC, bool B_KC>
+static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s) {
+    const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+                     (!g.a_mask || (((uintptr_t)g.a_mask) & 3) == 0) && (!g.b_mask || (((uintptr_t)g.b_mask) & 3) == 0) &&
+                     (g.k_chunk % 4 == 0);
+    if (g.M <= 32) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
+    if (g.N <= 32) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
+    const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * zdim;
+    if (tiles128 < 256) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
+    return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
+}
+
+int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const float* W, int ldw, const float* bias,
+                float* Y, int ldy, int M, int N, int K, int accumulate, hipStream_t s) {
+    GemmArgs g{X, ldx, M, W, ldw, N, K, Y, ldy, bias, accumulate, xmask, xms, nullptr, 1.f, nullptr, 1.f, 0, 0};
+    return launch_gemm<true, true>(g, 1, s);
+}
+
+int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K, int accumulate,
+                const uint8_t* cmask, float cms, hipStream_t s) {
+    GemmArgs g{X, ldx, M, Bm, ldb, N, K, Y, ldy, nullptr, accumulate, nullptr, 1.f, nullptr, 1.f, cmask, cms, 0, 0};
+    return launch_gemm<true, false>(g, 1, s);
+}
+
+static void pick_split(int M, int N, int K, int& S, int& k_chunk) {
+    // enough workgroups to fill 256 CUs a couple of times over, chunks a multiple of the slab depth
+    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
+    long want = (768 + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    long maxs = cdiv(K, 256);
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want > 64) want = 64;
+    k_chunk = cdiv(cdiv(K, (int)want), 32) * 32;
+    S = cdiv(K, k_chunk);
+}
+
+// C[N,Kd] (+)= A^T B where A = dY[Mr, N] (ld lddy), B = X[Mr, Kd] (ld ldx); contraction over the Mr rows.
+int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
+                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+    int S, k_chunk;
+    pick_split(N, Kd, Mr, S, k_chunk);
+    const size_t slab = (size_t)N * Kd;
+    if (S > 1 && ws_bytes < slab * S * sizeof(float)) {
+        S = 1;
+    }
+    if (S <= 1) {
+        GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, dW, lddw, nullptr, accumulate, nullptr, 1.f, xmask, xms, nullptr, 1.f, 0, 0};
+        return launch_gemm<false, false>(g, 1, s);
+    }
+    GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, ws, Kd, nullptr, 0, nullptr, 1.f, xmask, xms, nullptr, 1.f, k_chunk, slab};
+    int rc = launch_gemm<false, false>(g, S, s);
+    if (rc) return rc;
+    const size_t n = slab;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, slab, S, dW, lddw, N, Kd,
+                       accumulate);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
+    int S, k_chunk;
+    pick_split(N, Kd, Mr, S, k_chunk);
+    return (size_t)N * Kd * S * sizeof(float) + 256;
+}
+
+int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+    int chunks = cdiv(M, 256);
+    if (chunks > 512) chunks = 512;
+    if (chunks < 1) chunks = 1;
+    if ((size_t)chunks * N * sizeof(float) > ws_bytes) {
+        cpg_set_error("cpg_colsum: workspace too small (%zu < %zu)", ws_bytes, (size_t)chunks * N * sizeof(float));
+        return -3;
+    }
+    const int rows = cdiv(M, chunks);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), chunks), dim3(64, 4), 0, s, X, ld, M, N, rows, ws);
+    CPG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, chunks, N, out, accumulate);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t cpg_colsum_workspace(int M, int N) {
+    int chunks = cdiv(M, 256);
+    if (chunks > 512) chunks = 512;
+    if (chunks < 1) chunks = 1;
+    return (size_t)chunks * N * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+CPG_EXPORT int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
+                              int N, int K, int accumulate, void* stream) {
+    CPG_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
+    return cpg_gemm_nt(X, ldx, nullptr, 1.f, W, ldw, bias, Y, ldy, M, N, K, accumulate, (hipStream_t)stream);
+}
+
+CPG_EXPORT int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,
+                                    int K, int accumulate, void* stream) {
+    CPG_CHECK_ARG(dY && W && dX && M > 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K);
+    // dX[M,K] = dY[M,N] * W[N,K]   (contraction over N; W rows are the contraction index: "XC" operand)
+    return cpg_gemm_nn(dY, lddy, W, ldw, dX, lddx, M, K, N, accumulate, nullptr, 1.f, (hipStream_t)stream);
+}
+
+CPG_EXPORT size_t cpg_linear_bwd_weight_workspace(int M, int N, int K) {
+    size_t a = cpg_gemm_tn_workspace(M, N, K), b = cpg_colsum_workspace(M, N);
+    return (a > b ? a : b) + 256;
+}
+
+CPG_EXPORT int cpg_linear_bwd_weight(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
+                                     int M, int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    CPG_CHECK_ARG(dY && X && dW && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K);
+    int rc = cpg_gemm_tn(dY, lddy, X, ldx, nullptr, 1.f, dW, lddw, M, N, K, accumulate, (float*)workspace, workspace_bytes,
+                         (hipStream_t)stream);
+    if (rc) return rc;
+    if (db) rc = cpg_colsum(dY, lddy, M, N, db, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    return rc;
+}
+
+CPG_EXPORT int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K,
+                             int accumulate, void* stream) {
+    CPG_CHECK_ARG(X && Bm && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldb >= N && ldy >= N);
+    return cpg_gemm_nn(X, ldx, Bm, ldb, Y, ldy, M, N, K, accumulate, nullptr, 1.f, (hipStream_t)stream);
+}

@@ -1,0 +1,396 @@
+// GRU sequence forward / backward for gfx950: one fused launch per time step.
+//
+// Replaces torch.nn.GRU as the reference drives it (models/encoder.py:25-30,42; models/decoder.py:40-41,77,98).
+// Gate row order r,z,n;  n = tanh(gi_n + r*(W_hn h + b_hn));  h' = (1-z)*n + z*h.
+//
+// Forward step  (gru_step_fwd_kernel):  [B,H] x [H,3H] recurrent product on the f32 MFMA engine with the r/z/n rows of the
+//   same hidden units in one tile, and the whole cell (input-side gather, sigmoid/tanh, blend, save-for-backward) as the
+//   epilogue - the [B,T,3H] input pre-activation tensor is never materialised: it is rebuilt per element from
+//     tab[tok[b]]  (token table  emb @ W_ih[:, :E]^T + b_ih, V rows)   +   rowc[b]  (constant over time: [z;c] @ W_ih[:, E:]^T)
+//     + dense[b]   (upper encoder layers).
+// Backward step (gru_step_bwd_kernel):  dH_s = ext_s + z_{s+1}*dH_{s+1} + dgh_{s+1} W_hh  ([B,3H] x [3H,H] product), and the
+//   cell backward as the epilogue, writing dG_s = [dr_pre, dz_pre, dhn, dn_pre] (dgh = first 3H columns, contiguous).
+//
+// State slab hs[(T+1),B,H]:  forward direction: hs[0]=h0, h_t at hs[t+1];  reverse: hs[T]=h0, h_t at hs[t].
+// So h_{prev}(t) is one contiguous [T*B,H] block in both directions (offset 0 / B*H) for the dW_hh product.
+#include "gemm_core.h"
+#include "cpg_internal.h"
+
+struct GruFwdArgs {
+    const float* h_prev;
+    const float* w_hh;
+    const float* b_hh;
+    const int32_t* tok;  // [B] ids of this step, or null
+    const float* tab;    // [V,3H]
+    const float* rowc;   // [B,3H]
+    const float* dense;  // [B,3H] of this step
+    float* h_out;        // [B,H]
+    float* gates;        // [4,B,H] of this step (r,z,n,hn), or null
+    int B, H;
+};
+
+template <class TC, bool VEC>
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = g.H, B = g.B;
+    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 3);
+    OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
+    OpB b{g.w_hh, H, j0, H, H, nullptr, 1.f};
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, smem, acc);
+
+    static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave % TC::WN;
+    const size_t BH = (size_t)B * H;
+#pragma unroll
+    for (int jb = 0; jb < TC::NI / 3; ++jb) {
+        const int j = j0 + (wn * (TC::NI / 3) + jb) * 16 + (lane & 15);
+        if (j >= H) continue;
+        const float bh_r = g.b_hh[j], bh_z = g.b_hh[H + j], bh_n = g.b_hh[2 * H + j];
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                if (row >= B) continue;
+                float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+                if (g.tok) {
+                    const float* t = g.tab + (size_t)g.tok[row] * 3 * H;
+                    gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
+                }
+                if (g.rowc) {
+                    const float* t = g.rowc + (size_t)row * 3 * H;
+                    gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
+                }
+                if (g.dense) {
+                    const float* t = g.dense + (size_t)row * 3 * H;
+                    gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
+                }
+                const float hn = acc[mi][jb * 3 + 2][r] + bh_n;
+                const float rg = sigmoidf_(gi_r + (acc[mi][jb * 3 + 0][r] + bh_r));
+                const float zg = sigmoidf_(gi_z + (acc[mi][jb * 3 + 1][r] + bh_z));
+                const float ng = tanhf(gi_n + rg * hn);
+                const size_t o = (size_t)row * H + j;
+                const float hp = g.h_prev[o];
+                g.h_out[o] = (1.f - zg) * ng + zg * hp;
+                if (g.gates) {
+                    g.gates[o] = rg;
+                    g.gates[BH + o] = zg;
+                    g.gates[2 * BH + o] = ng;
+                    g.gates[3 * BH + o] = hn;
+                }
+            }
+    }
+}
+
+struct GruBwdArgs {
+    const float* dG_next;  // [B,4H] of the step processed just before this one (s+1), null on the first launch
+    const float* w_hh;     // [3H,H]
+    const float* dH_next;  // [B,H] total gradient of h_{s+1}, null on the first launch
+    const float* z_next;   // [B,H] z gate of step s+1
+    const float* ext;      // [B,H] external gradient on h_s (time-aligned slice) or null
+    const float* ext2;     // [B,H] second external gradient (final-state gradient on the first launch) or null
+    const float* gates;    // [4,B,H] of step s; null on the closing launch that only emits dh0
+    const float* h_prev;   // [B,H] h_{s-1}
+    float* dH_out;         // [B,H] total gradient of h_s (closing launch: dh0)
+    float* dG_out;         // [B,4H]
+    int B, H;
+};
+
+template <class TC, bool VEC>
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = g.H, B = g.B;
+    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.dG_next) {
+        OpA a{g.dG_next, 4 * H, m0, B, nullptr, 1.f};
+        OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
+        MainLoop<TC, true, false, VEC, VEC>::run(a, b, 3 * H, smem, acc);
+    }
+    const size_t BH = (size_t)B * H;
+#pragma unroll
+    for (int ni = 0; ni < TC::NI; ++ni) {
+        const int j = j0 + acc_col<TC>(ni);
+        if (j >= H) continue;
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                if (row >= B) continue;
+                const size_t o = (size_t)row * H + j;
+                float dh = acc[mi][ni][r];
+                if (g.dH_next) dh += g.z_next[o] * g.dH_next[o];
+                if (g.ext) dh += g.ext[o];
+                if (g.ext2) dh += g.ext2[o];
+                g.dH_out[o] = dh;
+                if (!g.gates) continue;
+                const float rg = g.gates[o], zg = g.gates[BH + o], ng = g.gates[2 * BH + o], hn = g.gates[3 * BH + o];
+                const float hp = g.h_prev[o];
+                const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+                const float dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+                const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+                float* d = g.dG_out + (size_t)row * 4 * H;
+                d[j] = dr_pre;
+                d[H + j] = dz_pre;
+                d[2 * H + j] = dn_pre * rg;
+                d[3 * H + j] = dn_pre;
+            }
+    }
+}
+
+using GF128 = TileCfg<128, 96, 32, 2, 2, 3>;
+using GF64 = TileCfg<64, 96, 32, 2, 2, 3>;
+using GF32 = TileCfg<32, 96, 32, 2, 2, 3>;
+using GB128 = TileCfg<128, 32, 32, 4, 1, 1>;
+using GB64 = TileCfg<64, 32, 32, 4, 1, 1>;
+using GB32 = TileCfg<32, 64, 32, 2, 2, 1>;
+
+template <class TC>
+static void launch_fwd(const GruFwdArgs& a, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.B, TC::BM));
+    const size_t smem = TC::template smem_floats<true, true>() * sizeof(float);
+    if (vec)
+        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true>), grid, dim3(256), smem, s, a);
+    else
+        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false>), grid, dim3(256), smem, s, a);
+}
+
+template <class TC>
+static void launch_bwd(const GruBwdArgs& a, bool vec, hipStream_t s) {
+    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.B, TC::BM));
+    const size_t smem = TC::template smem_floats<true, false>() * sizeof(float);
+    if (vec)
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, a);
+    else
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false>), grid, dim3(256), smem, s, a);
+}
+
+// pick the row-tile height so that the launch has at least ~256 workgroups when the problem allows it
+static int pick_bm(int B, int ntile_n) {
+    if ((long)cdiv(B, 128) * ntile_n >= 256) return 128;
+    if ((long)cdiv(B, 64) * ntile_n >= 256 || B > 64) return B > 32 ? 64 : 32;
+    return 32;
+}
+
+int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
+    const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
+    const int bm = pick_bm(a.B, cdiv(a.H, 32));
+    if (bm == 128) launch_fwd<GF128>(a, vec, s);
+    else if (bm == 64) launch_fwd<GF64>(a, vec, s);
+    else launch_fwd<GF32>(a, vec, s);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int gru_step_bwd_launch(const GruBwdArgs& a, hipStream_t s) {
+    const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
+    const int bm = pick_bm(a.B, cdiv(a.H, 32));
+    if (bm == 128) launch_bwd<GB128>(a, vec, s);
+    else if (bm == 64) launch_bwd<GB64>(a, vec, s);
+    else launch_bwd<GB32>(a, vec, s);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ reductions over dG
+// dgi column c in [0,3H) lives at dG column c (c < 2H) or 3H + (c - 2H).
+__device__ __forceinline__ int dgi_col(int c, int H) { return c < 2 * H ? c : c + H; }
+
+// part[chunk][v][c] = sum over rows (t,b) of the chunk with tok == v of dgi[row][c].   block: 64 columns x RL row lanes.
+__global__ void dgi_by_token_kernel(const float* dG, const int32_t* tok, int rows, int H, int V, int rows_per_chunk,
+                                    float* part) {
+    extern __shared__ float accs[];  // [RL][V][64]
+    const int RL = blockDim.y;
+    const int c = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
+    float* mine = accs + (size_t)ty * V * 64;
+    for (int v = 0; v < V; ++v) mine[v * 64 + threadIdx.x] = 0.f;
+    const int rb = blockIdx.y * rows_per_chunk, re = min(rows, rb + rows_per_chunk);
+    if (c < 3 * H) {
+        const int gc = dgi_col(c, H);
+        for (int row = rb + ty; row < re; row += RL) {
+            const int v = tok[row];
+            mine[v * 64 + threadIdx.x] += dG[(size_t)row * 4 * H + gc];
+        }
+    }
+    __syncthreads();
+    if (c < 3 * H)
+        for (int v = ty; v < V; v += RL) {
+            float s = 0.f;
+            for (int q = 0; q < RL; ++q) s += accs[((size_t)q * V + v) * 64 + threadIdx.x];
+            part[((size_t)blockIdx.y * V + v) * 3 * H + c] = s;
+        }
+}
+
+__global__ void chunk_reduce_kernel(const float* part, int chunks, size_t n, float* out, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// drowc[b][c] (+)= sum_t dgi[t][b][c]
+__global__ void dgi_over_time_kernel(const float* dG, int T, int B, int H, float* out, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * 3 * H) return;
+    const int b = i / (3 * H), c = i % (3 * H);
+    const int gc = dgi_col(c, H);
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += dG[((size_t)t * B + b) * 4 * H + gc];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
+                               const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
+                               void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs);
+    CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
+    const size_t BH = (size_t)B * H;
+    for (int p = 0; p < T; ++p) {
+        const int t = reverse ? T - 1 - p : p;
+        GruFwdArgs a;
+        a.h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
+        a.h_out = reverse ? hs + (size_t)t * BH : hs + (size_t)(t + 1) * BH;
+        a.w_hh = w_hh;
+        a.b_hh = b_hh;
+        a.tok = tok ? tok + (size_t)t * B : nullptr;
+        a.tab = tab;
+        a.rowc = rowc;
+        a.dense = dense ? dense + (size_t)t * B * 3 * H : nullptr;
+        a.gates = gates ? gates + (size_t)t * 4 * BH : nullptr;
+        a.B = B;
+        a.H = H;
+        int rc = cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// One decode step (GRUDecoder.forward_sample, models/decoder.py:86-109, without the vocab projection).
+CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
+                                const float* rowc, const float* h_prev, float* h_out, void* stream) {
+    CPG_CHECK_ARG(B > 0 && H > 0 && w_hh && b_hh && h_prev && h_out && h_prev != h_out);
+    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, B, H};
+    return cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
+}
+
+// dhs_ext: [T,B,H] time-aligned external gradients on every step's output (or null); dh_last: gradient on the final state.
+// dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
+CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                               const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
+                               void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
+    const size_t BH = (size_t)B * H;
+    int prev_t = -1;
+    for (int p = T - 1; p >= -1; --p) {  // p = processing index of the step whose dH we form; p=-1 closes with dh0
+        if (p < 0 && !dh0) break;
+        const int t = p < 0 ? -1 : (reverse ? T - 1 - p : p);
+        GruBwdArgs a;
+        a.B = B;
+        a.H = H;
+        a.w_hh = w_hh;
+        const int cur = (p + 2) & 1;
+        if (prev_t >= 0) {
+            a.dG_next = dG + (size_t)prev_t * B * 4 * H;
+            a.dH_next = dH_scratch + (size_t)(cur ^ 1) * BH;
+            a.z_next = gates + (size_t)prev_t * 4 * BH + BH;
+        } else {
+            a.dG_next = nullptr;
+            a.dH_next = nullptr;
+            a.z_next = nullptr;
+        }
+        a.ext2 = (p == T - 1) ? dh_last : nullptr;
+        if (p >= 0) {
+            a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
+            a.gates = gates + (size_t)t * 4 * BH;
+            a.h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
+            a.dH_out = dH_scratch + (size_t)cur * BH;
+            a.dG_out = dG + (size_t)t * B * 4 * H;
+        } else {
+            a.ext = nullptr;
+            a.gates = nullptr;
+            a.h_prev = nullptr;
+            a.dH_out = dh0;
+            a.dG_out = nullptr;
+        }
+        int rc = gru_step_bwd_launch(a, (hipStream_t)stream);
+        if (rc) return rc;
+        prev_t = t;
+    }
+    return 0;
+}
+
+CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
+    size_t a = cpg_gemm_tn_workspace(T * B, 3 * H, H);
+    size_t b = cpg_colsum_workspace(T * B, 3 * H);
+    int chunks = cdiv(T * B, 512);
+    if (chunks > 256) chunks = 256;
+    size_t c = (size_t)chunks * (V > 0 ? V : 1) * 3 * H * sizeof(float);
+    size_t m = a > b ? a : b;
+    return (m > c ? m : c) + 256;
+}
+
+// dW_hh[3H,H] (+)= sum_t dgh_t^T h_prev(t) ; db_hh[3H] (+)= sum dgh.
+CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
+                                float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && db_hh && workspace);
+    const float* hprev = reverse ? hs + (size_t)B * H : hs;
+    int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 3 * H, H, accumulate, (float*)workspace,
+                         workspace_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    return cpg_colsum(dG, 4 * H, T * B, 3 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Input-side reductions of dgi = [dr_pre, dz_pre, dn_pre]:
+//   dtab[V,3H]  (+)= sum over (t,b) with tok[t,b]==v     (gradient of the token table; null to skip)
+//   drowc[B,3H] (+)= sum over t                          (gradient of the constant-over-time term; null to skip)
+CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+                                  float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtab) {
+        CPG_CHECK_ARG(tok && V > 0 && workspace);
+        const int rows = T * B;
+        int chunks = cdiv(rows, 512);
+        if (chunks > 256) chunks = 256;
+        const int rpc = cdiv(rows, chunks);
+        chunks = cdiv(rows, rpc);
+        const size_t n = (size_t)V * 3 * H;
+        if (workspace_bytes < n * chunks * sizeof(float)) {
+            cpg_set_error("cpg_gru_dgi_reduce: workspace too small");
+            return -3;
+        }
+        int RL = 4;
+        while (RL > 1 && (size_t)RL * V * 64 * sizeof(float) > 96 * 1024) RL >>= 1;
+        const size_t smem = (size_t)RL * V * 64 * sizeof(float);
+        if (smem > 150 * 1024) {
+            cpg_set_error("cpg_gru_dgi_reduce: vocabulary of %d rows does not fit the LDS accumulators", V);
+            return -4;
+        }
+        hipLaunchKernelGGL(dgi_by_token_kernel, dim3(cdiv(3 * H, 64), chunks), dim3(64, RL), smem, s, dG, tok, rows, H, V, rpc,
+                           (float*)workspace);
+        CPG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+                           chunks, n, dtab, accumulate);
+        CPG_LAUNCH_CHECK();
+    }
+    if (drowc) {
+        const size_t n = (size_t)B * 3 * H;
+        hipLaunchKernelGGL(dgi_over_time_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dG, T, B, H, drowc,
+                           accumulate);
+        CPG_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,370 @@
+// Loss terms of the WAE/VAE training step (reference losses.py, train_vae.py:27-37) and their gradients.
+// Every reduction is two-stage with a fixed partition (block partials in a fixed order, then one block) so results are
+// run-to-run deterministic; sums and counts are returned separately so a data-parallel caller can all-reduce them and
+// still obtain the single-device value.
+#include "cpg_internal.h"
+
+#define RED_BLOCKS 256
+
+// block-wide sum of NV values per thread; result valid in thread 0. 256 threads.
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red /*[4*NV]*/) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[w * NV + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = (red[k] + red[NV + k]) + (red[2 * NV + k] + red[3 * NV + k]);
+}
+
+template <int NV>
+__global__ void final_sum_kernel(const float* part, int nblocks, float* out) {
+    __shared__ float red[4 * NV];
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += part[(size_t)i * NV + k];
+    block_sum<NV>(v, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) out[k] = v[k];
+}
+
+// ------------------------------------------------------------------------------------------ reconstruction CE
+// losses.recon_dec (losses.py:18-31): targets = cat(ids[:,1:], PAD); mean NLL over non-PAD targets of the whole batch.
+__global__ void recon_ce_partial_kernel(const int64_t* ids, const float* logits, int B, int T, int V, int pad, float* part) {
+    __shared__ float red[8];
+    float v[2] = {0.f, 0.f};
+    const int rows = B * T;
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < rows; row += RED_BLOCKS * 256) {
+        const int b = row / T, t = row % T;
+        const int tgt = (t + 1 < T) ? (int)ids[(size_t)b * T + t + 1] : pad;
+        if (tgt == pad) continue;
+        const float* l = logits + (size_t)row * V;
+        float m = -INFINITY;
+        for (int k = 0; k < V; ++k) m = fmaxf(m, l[k]);
+        float se = 0.f;
+        for (int k = 0; k < V; ++k) se += expf(l[k] - m);
+        v[0] += (m + logf(se)) - l[tgt];
+        v[1] += 1.f;
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = v[0];
+        part[blockIdx.x * 2 + 1] = v[1];
+    }
+}
+
+// out[0] = sum of NLL over valid targets, out[1] = number of valid targets
+CPG_EXPORT int cpg_recon_ce_fwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, float* out,
+                                float* workspace, void* stream) {
+    CPG_CHECK_ARG(ids && logits && out && workspace && B > 0 && T > 0 && V > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(recon_ce_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, ids, logits, B, T, V, pad, workspace);
+    hipLaunchKernelGGL(final_sum_kernel<2>, dim3(1), dim3(256), 0, s, (const float*)workspace, RED_BLOCKS, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dlogits = gout * (softmax - onehot) / count on valid rows, 0 elsewhere.  gout and count are device scalars (no host sync).
+__global__ void recon_ce_bwd_kernel(const int64_t* ids, const float* logits, int B, int T, int V, int pad, const float* gout,
+                                    const float* count, float* dlogits) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B * T) return;
+    const int b = row / T, t = row % T;
+    const int tgt = (t + 1 < T) ? (int)ids[(size_t)b * T + t + 1] : pad;
+    float* d = dlogits + (size_t)row * V;
+    if (tgt == pad) {
+        for (int k = 0; k < V; ++k) d[k] = 0.f;
+        return;
+    }
+    const float* l = logits + (size_t)row * V;
+    float m = -INFINITY;
+    for (int k = 0; k < V; ++k) m = fmaxf(m, l[k]);
+    float se = 0.f;
+    for (int k = 0; k < V; ++k) se += expf(l[k] - m);
+    const float lse = m + logf(se);
+    const float sc = gout[0] / fmaxf(count[0], 1.f);
+    for (int k = 0; k < V; ++k) d[k] = (expf(l[k] - lse) - (k == tgt ? 1.f : 0.f)) * sc;
+}
+
+CPG_EXPORT int cpg_recon_ce_bwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, const float* gout,
+                                const float* count, float* dlogits, void* stream) {
+    CPG_CHECK_ARG(ids && logits && gout && count && dlogits && B > 0 && T > 0 && V > 0);
+    hipLaunchKernelGGL(recon_ce_bwd_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, (hipStream_t)stream, ids, logits, B, T, V,
+                       pad, gout, count, dlogits);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ reparameterisation
+// RNN_VAE.sample_z (models/model.py:107-112): z = mu + exp(logvar/2) * eps
+__global__ void reparam_fwd_kernel(const float* mu, const float* lv, const float* eps, float* z, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = mu[i] + expf(lv[i] * 0.5f) * eps[i];
+}
+__global__ void reparam_bwd_kernel(const float* dz, const float* lv, const float* eps, float* dmu, float* dlv, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dmu[i] = dz[i];
+        dlv[i] = dz[i] * eps[i] * 0.5f * expf(lv[i] * 0.5f);
+    }
+}
+CPG_EXPORT int cpg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, void* stream) {
+    CPG_CHECK_ARG(mu && logvar && eps && z && n > 0);
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar,
+                       eps, z, n);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+CPG_EXPORT int cpg_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar, size_t n,
+                               void* stream) {
+    CPG_CHECK_ARG(dz && logvar && eps && dmu && dlogvar && n > 0);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz, logvar,
+                       eps, dmu, dlogvar, n);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ latent statistics
+// out[0] = sum 0.5(e^lv + mu^2 - 1 - lv)   (kl_gaussianprior * B,      losses.py:8-10)
+// out[1] = sum 0.5(e^lv - 1 - lv)          (kl_gaussian_sharedmu * B,  losses.py:13-15)
+// out[2] = sum |lv|                        (z_logvar_L1 * B,           train_vae.py:33)
+// out[3] = sum |mu| ; out[4] = sum lv      (logged means,              train_vae.py:44-45)
+__global__ void latent_stats_partial_kernel(const float* mu, const float* lv, size_t n, float* part) {
+    __shared__ float red[20];
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)RED_BLOCKS * 256) {
+        const float m = mu[i], l = lv[i], e = expf(l);
+        v[0] += 0.5f * (e + m * m - 1.f - l);
+        v[1] += 0.5f * (e - 1.f - l);
+        v[2] += fabsf(l);
+        v[3] += fabsf(m);
+        v[4] += l;
+    }
+    block_sum<5>(v, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 5; ++k) part[blockIdx.x * 5 + k] = v[k];
+}
+CPG_EXPORT int cpg_latent_stats_fwd(const float* mu, const float* logvar, size_t n, float* out, float* workspace,
+                                    void* stream) {
+    CPG_CHECK_ARG(mu && logvar && out && workspace && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(latent_stats_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, mu, logvar, n, workspace);
+    hipLaunchKernelGGL(final_sum_kernel<5>, dim3(1), dim3(256), 0, s, (const float*)workspace, RED_BLOCKS, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// dmu (+)= g_kl*mu/B ; dlv (+)= (g_kl+g_klmu)*0.5(e^lv-1)/B + g_l1*sign(lv)/B.  g_* are device scalars or null.
+__global__ void latent_stats_bwd_kernel(const float* mu, const float* lv, size_t n, float invB, const float* g_kl,
+                                        const float* g_klmu, const float* g_l1, float* dmu, float* dlv, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = g_kl ? g_kl[0] : 0.f, b = g_klmu ? g_klmu[0] : 0.f, c = g_l1 ? g_l1[0] : 0.f;
+    const float l = lv[i];
+    const float sgn = (l > 0.f) ? 1.f : ((l < 0.f) ? -1.f : 0.f);
+    const float gm = a * mu[i] * invB;
+    const float gl = ((a + b) * 0.5f * (expf(l) - 1.f) + c * sgn) * invB;
+    dmu[i] = accumulate ? dmu[i] + gm : gm;
+    dlv[i] = accumulate ? dlv[i] + gl : gl;
+}
+CPG_EXPORT int cpg_latent_stats_bwd(const float* mu, const float* logvar, size_t n, int B, const float* g_kl,
+                                    const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar, int accumulate,
+                                    void* stream) {
+    CPG_CHECK_ARG(mu && logvar && dmu && dlogvar && n > 0 && B > 0);
+    hipLaunchKernelGGL(latent_stats_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu,
+                       logvar, n, 1.f / (float)B, g_kl, g_klmu, g_l1, dmu, dlogvar, accumulate);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ MMD, random Fourier features
+// losses.mmd_rf / compute_gaussian_rf (losses.py:59-93): phi(x) = cos(x W / sigma + b) * sqrt(2/R); loss = |mean phi(z1) - mean phi(z2)|^2
+// raw = z @ rf_w comes from the MFMA engine (cpg_matmul_nn); this kernel adds the phase, takes cos and column-sums.
+__global__ void rf_colsum_partial_kernel(const float* raw, const float* rf_b, int Bn, int R, float inv_sigma, float amp,
+                                         int rows_per_chunk, float* part) {
+    __shared__ float red[4][64];
+    const int r = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
+    const int mb = blockIdx.y * rows_per_chunk, me = min(Bn, mb + rows_per_chunk);
+    float s = 0.f;
+    if (r < R) {
+        const float ph = rf_b[r];
+        for (int m = mb + ty; m < me; m += 4) s += cosf(raw[(size_t)m * R + r] * inv_sigma + ph) * amp;
+    }
+    red[ty][threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && r < R)
+        part[(size_t)blockIdx.y * R + r] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void rf_colsum_final_kernel(const float* part, int chunks, int R, float* out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * R + r];
+    out[r] = s;
+}
+// feature column sums: sums[R] = sum_b phi(z_b)   (raw [B,R] = z @ rf_w computed by the caller)
+CPG_EXPORT int cpg_rf_feature_sums(const float* raw, const float* rf_b, int Bn, int R, float sigma, float* sums,
+                                   float* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(raw && rf_b && sums && workspace && Bn > 0 && R > 0 && sigma > 0.f);
+    hipStream_t s = (hipStream_t)stream;
+    int chunks = cdiv(Bn, 64);
+    if (chunks > 128) chunks = 128;
+    const int rpc = cdiv(Bn, chunks);
+    chunks = cdiv(Bn, rpc);
+    CPG_CHECK_ARG(workspace_bytes >= (size_t)chunks * R * sizeof(float));
+    const float amp = sqrtf(2.f / (float)R);
+    hipLaunchKernelGGL(rf_colsum_partial_kernel, dim3(cdiv(R, 64), chunks), dim3(64, 4), 0, s, raw, rf_b, Bn, R, 1.f / sigma,
+                       amp, rpc, workspace);
+    hipLaunchKernelGGL(rf_colsum_final_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, (const float*)workspace, chunks, R, sums);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// loss[0] = sum_r ((s1[r]-s2[r])*invB)^2 ; diff[r] = (s1[r]-s2[r])*invB
+__global__ void rf_loss_kernel(const float* s1, const float* s2, int R, float invB, float* loss, float* diff) {
+    __shared__ float red[4];
+    float v[1] = {0.f};
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float d = (s1[r] - s2[r]) * invB;
+        diff[r] = d;
+        v[0] += d * d;
+    }
+    block_sum<1>(v, red);
+    if (threadIdx.x == 0) loss[0] = v[0];
+}
+CPG_EXPORT int cpg_rf_loss(const float* sums1, const float* sums2, int R, int B_global, float* loss, float* diff,
+                           void* stream) {
+    CPG_CHECK_ARG(sums1 && sums2 && loss && diff && R > 0 && B_global > 0);
+    hipLaunchKernelGGL(rf_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums1, sums2, R, 1.f / (float)B_global, loss,
+                       diff);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// dpre[b,r] = gout * (2*diff[r]/B_global) * (-sin(raw/sigma + b) * sqrt(2/R)) / sigma    (then dz1 = dpre @ rf_w^T)
+__global__ void rf_bwd_kernel(const float* raw, const float* rf_b, const float* diff, const float* gout, int Bn, int R,
+                              float inv_sigma, float amp, float invB, float* dpre) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Bn * R) return;
+    const int r = i % R;
+    dpre[i] = gout[0] * 2.f * diff[r] * invB * (-sinf(raw[i] * inv_sigma + rf_b[r]) * amp) * inv_sigma;
+}
+CPG_EXPORT int cpg_rf_bwd(const float* raw, const float* rf_b, const float* diff, const float* gout, int Bn, int R,
+                          float sigma, int B_global, float* dpre, void* stream) {
+    CPG_CHECK_ARG(raw && rf_b && diff && gout && dpre && Bn > 0 && R > 0 && sigma > 0.f && B_global > 0);
+    const size_t n = (size_t)Bn * R;
+    hipLaunchKernelGGL(rf_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, raw, rf_b, diff,
+                       gout, Bn, R, 1.f / sigma, sqrtf(2.f / (float)R), 1.f / (float)B_global, dpre);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ MMD, full Gaussian kernel
+// losses.mmd_full_kernel (losses.py:47-56,96-108), Gram form: |x-y|^2 = |x|^2 + |y|^2 - 2 x.y with the three Gram matrices
+// from the MFMA engine; squared norms are read off the Gram diagonals so K11_ii = K22_ii = 1 exactly, as in the reference.
+// Quirk kept: `H - torch.diag(H)` broadcasts the diagonal VECTOR over rows, so
+//     loss = (sum_ij H_ij - N * sum_j H_jj) / (N (N-1)),  H = K11 + K22 - 2 K12,  K = exp(-d/sigma^2).
+// Optional outputs for the backward pass: P = 2*coef.*K11, Q = -2*coef.*K12 with coef_ij = (1 - N[i==j])/(N(N-1)).
+__global__ void mmd_full_partial_kernel(const float* G11, const float* G22, const float* G12, int N, float inv_s2, float* part,
+                                        float* P, float* Q) {
+    __shared__ float red[8];
+    float v[2] = {0.f, 0.f};
+    const size_t n2 = (size_t)N * N;
+    const float cf = 1.f / ((float)N * (float)(N - 1));
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n2; idx += (size_t)RED_BLOCKS * 256) {
+        const int i = idx / N, j = idx % N;
+        const float a_i = G11[(size_t)i * N + i], a_j = G11[(size_t)j * N + j];
+        const float b_i = G22[(size_t)i * N + i], b_j = G22[(size_t)j * N + j];
+        const float k11 = (i == j) ? 1.f : expf(-fmaxf(a_i + a_j - 2.f * G11[idx], 0.f) * inv_s2);
+        const float k22 = (i == j) ? 1.f : expf(-fmaxf(b_i + b_j - 2.f * G22[idx], 0.f) * inv_s2);
+        const float k12 = expf(-fmaxf(a_i + b_j - 2.f * G12[idx], 0.f) * inv_s2);
+        const float h = k11 + k22 - 2.f * k12;
+        v[0] += h;
+        if (i == j) v[1] += h;
+        if (P) {
+            const float coef = (i == j) ? cf * (1.f - (float)N) : cf;
+            P[idx] = 2.f * coef * k11;
+            Q[idx] = -2.f * coef * k12;
+        }
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = v[0];
+        part[blockIdx.x * 2 + 1] = v[1];
+    }
+}
+__global__ void mmd_full_final_kernel(const float* part, int N, float* out) {
+    __shared__ float red[8];
+    float v[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) {
+        v[0] += part[i * 2];
+        v[1] += part[i * 2 + 1];
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        out[0] = (v[0] - (float)N * v[1]) / ((float)N * (float)(N - 1));
+        out[1] = v[0];
+        out[2] = v[1];
+    }
+}
+CPG_EXPORT size_t cpg_mmd_full_workspace(int N) { return ((size_t)3 * N * N + 2 * RED_BLOCKS) * sizeof(float) + 256; }
+
+// z1,z2 [N,D].  out[0] = loss.  P,Q [N,N] optional (null when no gradient is needed).  workspace: cpg_mmd_full_workspace(N).
+CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, float* out, float* P, float* Q,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(z1 && z2 && out && workspace && N > 1 && D > 0 && sigma > 0.f && ((P == nullptr) == (Q == nullptr)));
+    CPG_CHECK_ARG(workspace_bytes >= cpg_mmd_full_workspace(N));
+    hipStream_t s = (hipStream_t)stream;
+    float* G11 = (float*)workspace;
+    float* G22 = G11 + (size_t)N * N;
+    float* G12 = G22 + (size_t)N * N;
+    float* part = G12 + (size_t)N * N;
+    int rc = cpg_gemm_nt(z1, D, nullptr, 1.f, z1, D, nullptr, G11, N, N, N, D, 0, s);
+    if (!rc) rc = cpg_gemm_nt(z2, D, nullptr, 1.f, z2, D, nullptr, G22, N, N, N, D, 0, s);
+    if (!rc) rc = cpg_gemm_nt(z1, D, nullptr, 1.f, z2, D, nullptr, G12, N, N, N, D, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mmd_full_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, G11, G22, G12, N, 1.f / (sigma * sigma),
+                       part, P, Q);
+    hipLaunchKernelGGL(mmd_full_final_kernel, dim3(1), dim3(256), 0, s, (const float*)part, N, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dz1 = gout * (-(2/sigma^2)) * ( (rowsum(P)+rowsum(Q)) .* z1 - P z1 - Q z2 )
+__global__ void rowsum2_kernel(const float* P, const float* Q, int N, float* rs) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N) return;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s += P[(size_t)wave * N + j] + Q[(size_t)wave * N + j];
+    s = wave_sum(s);
+    if (lane == 0) rs[wave] = s;
+}
+__global__ void mmd_full_bwd_combine_kernel(const float* z1, const float* rs, const float* Mz, const float* gout, int N, int D,
+                                            float c, float* dz1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * D) return;
+    const int r = i / D;
+    dz1[i] = gout[0] * c * (rs[r] * z1[i] - Mz[i]);
+}
+CPG_EXPORT int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P, const float* Q, const float* gout, int N,
+                                int D, float sigma, float* dz1, void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(z1 && z2 && P && Q && gout && dz1 && workspace && N > 1 && D > 0);
+    CPG_CHECK_ARG(workspace_bytes >= ((size_t)N * D + N) * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    float* Mz = (float*)workspace;
+    float* rs = Mz + (size_t)N * D;
+    int rc = cpg_gemm_nn(P, N, z1, D, Mz, D, N, D, N, 0, nullptr, 1.f, s);
+    if (!rc) rc = cpg_gemm_nn(Q, N, z2, D, Mz, D, N, D, N, 1, nullptr, 1.f, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rowsum2_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, P, Q, N, rs);
+    const size_t n = (size_t)N * D;
+    hipLaunchKernelGGL(mmd_full_bwd_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z1, (const float*)rs,
+                       (const float*)Mz, gout, N, D, -2.f / (sigma * sigma), dz1);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}

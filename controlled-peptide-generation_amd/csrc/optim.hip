@@ -1,0 +1,76 @@
+// Global-norm clipping + Adam on flat f32 buffers (train_vae.py:15,39-42: Adam(lr) ; clip_grad_norm_(clip) ; step()).
+// The clip coefficient stays on the device (no host sync): coef = min(max_norm / (sqrt(sumsq) + 1e-6), 1).
+// Duplicate-parameter semantics of the reference (word_emb.weight is yielded twice by vae_params()) are
+// expressed by the caller: the embedding segment is added to the norm twice (mult=2), its gradient is scaled by coef^2
+// (coef_pow=2) and cpg_adam_step is applied to it twice with consecutive step numbers.
+#include "cpg_internal.h"
+
+#define SUMSQ_BLOCKS 512
+
+__global__ void sumsq_partial_kernel(const float* x, size_t n, float* part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * 256) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sumsq_final_kernel(const float* part, float mult, int accumulate, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 256) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = ((red[0] + red[1]) + (red[2] + red[3])) * mult;
+        out[0] = accumulate ? out[0] + t : t;
+    }
+}
+
+CPG_EXPORT size_t cpg_sumsq_workspace(void) { return SUMSQ_BLOCKS * sizeof(float); }
+
+// out[0] (+)= mult * sum x^2
+CPG_EXPORT int cpg_sumsq(const float* x, size_t n, float mult, int accumulate, float* out, float* workspace, void* stream) {
+    CPG_CHECK_ARG(x && out && workspace && n > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, x, n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, mult, accumulate, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                                 float eps, float bc1, float bc2_sqrt, const float* sumsq, float max_norm, int coef_pow,
+                                 float gscale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float coef = 1.f;
+    if (sumsq) {
+        const float c = fminf(max_norm / (sqrtf(sumsq[0]) * gscale + 1e-6f), 1.f);  // norm of the scaled gradient
+        coef = c;
+        for (int k = 1; k < coef_pow; ++k) coef *= c;
+    }
+    const float gi = g[i] * gscale * coef;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+// One Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad) of p[0..n) with step number `step` (1-based).
+// gscale multiplies the raw gradient first (1/world_size after a SUM all-reduce).  sumsq may be null (no clipping).
+CPG_EXPORT int cpg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                             float eps, int step, const float* sumsq, float max_norm, int coef_pow, float gscale,
+                             void* stream) {
+    CPG_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && coef_pow >= 1);
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), sumsq, max_norm, coef_pow, gscale);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,112 @@
+// Counter-based random streams for the training step's stochastic inputs when the caller does not inject them:
+//   eps / z_prior ~ N(0,1)      (models/model.py:111,118 ; losses.py:37)
+//   word-dropout / out-dropout Bernoulli masks  (models/decoder.py:117-133 ; nn.Dropout at decoder.py:44)
+//   uniforms for the CLaSS accept test          (density_modeling.py:58)
+// Philox4x32-10 keyed by (seed), counter = (offset + element/4, stream id): reproducible for a given (seed, offset)
+// independent of launch geometry.  These are NEW streams (the reference mixes torch and numpy generators); parity tests
+// inject the reference's captured draws instead.
+#include "cpg_internal.h"
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr, uint32_t stream, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+
+__global__ void rng_normal_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 outputs per thread
+    if (q * 4 >= n) return;
+    uint32_t r[4];
+    philox4x32(seed, offset + q, 0u, r);
+    float v[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float rad = sqrtf(-2.f * logf(u01(r[2 * h])));
+        const float ang = 6.283185307179586f * u01(r[2 * h + 1]);
+        v[2 * h] = rad * cosf(ang);
+        v[2 * h + 1] = rad * sinf(ang);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q * 4 + k < n) out[q * 4 + k] = v[k];
+}
+
+__global__ void rng_uniform_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    uint32_t r[4];
+    philox4x32(seed, offset + q, 1u, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q * 4 + k < n) out[q * 4 + k] = u01(r[k]);
+}
+
+__global__ void rng_uniform_f64_kernel(double* out, size_t n, uint64_t seed, uint64_t offset) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // 2 outputs per thread
+    if (q * 2 >= n) return;
+    uint32_t r[4];
+    philox4x32(seed, offset + q, 3u, r);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (q * 2 + k < n) {
+            const uint64_t bits = ((uint64_t)r[2 * k] << 21) ^ (uint64_t)(r[2 * k + 1] >> 11);  // 53 random bits
+            out[q * 2 + k] = (double)(bits & ((1ull << 53) - 1)) * (1.0 / 9007199254740992.0);
+        }
+}
+
+// out[i] = 1 with probability p_one
+__global__ void rng_bernoulli_kernel(uint8_t* out, size_t n, float p_one, uint64_t seed, uint64_t offset) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    uint32_t r[4];
+    philox4x32(seed, offset + q, 2u, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q * 4 + k < n) out[q * 4 + k] = u01(r[k]) < p_one ? 1 : 0;
+}
+
+#define RNG_LAUNCH(kern, per, ...)                                                                                  \
+    do {                                                                                                            \
+        const size_t nq = (n + (per) - 1) / (per);                                                                  \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        CPG_LAUNCH_CHECK();                                                                                         \
+    } while (0)
+
+CPG_EXPORT int cpg_rng_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    CPG_CHECK_ARG(out && n > 0);
+    RNG_LAUNCH(rng_normal_kernel, 4, out, n, seed, offset);
+    return 0;
+}
+CPG_EXPORT int cpg_rng_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    CPG_CHECK_ARG(out && n > 0);
+    RNG_LAUNCH(rng_uniform_kernel, 4, out, n, seed, offset);
+    return 0;
+}
+CPG_EXPORT int cpg_rng_uniform_f64(double* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    CPG_CHECK_ARG(out && n > 0);
+    RNG_LAUNCH(rng_uniform_f64_kernel, 2, out, n, seed, offset);
+    return 0;
+}
+CPG_EXPORT int cpg_rng_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint64_t seed, uint64_t offset, void* stream) {
+    CPG_CHECK_ARG(out && n > 0 && p_one >= 0.f && p_one <= 1.f);
+    RNG_LAUNCH(rng_bernoulli_kernel, 4, out, n, p_one, seed, offset);
+    return 0;
+}

@@ -1,0 +1,122 @@
+"""GRU decoder with [emb; z; c] input at every step and h0 = [z; c].
+
+Counterpart of the reference's GRUDecoder / WordDropout (models/decoder.py:23-133).  `self.rnn`, `self.fc` are torch
+modules used only as parameter containers (state-dict keys `decoder.rnn.*`, `decoder.fc.1.*`).  The input projection
+is split exactly: W_ih [emb(tok); z; c] + b_ih = tab[tok] + rowc with tab = emb @ W_ih[:, :E]^T + b_ih (V rows) and
+rowc = [z;c] @ W_ih[:, E:]^T (constant over time), so the [B,T,E+Hd] concatenation is never built.
+The DeconvDecoder alternative (G_class='deconv', decoder.py:136-323) is not on the hot path and not provided.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from cpg import ops
+from models.mutils import UNK_IDX
+
+
+def build_decoder(G_class, GRU_args, deconv_args, **common_args):
+    if G_class == 'gru':
+        kw = dict(GRU_args)
+        kw.update(common_args)
+        return GRUDecoder(**kw)
+    if G_class == 'deconv':
+        raise NotImplementedError("G_class='deconv' is outside the MI355X hot path (SURVEY section 2: out of scope)")
+    raise ValueError('Please use one of the following for dec_type: gru | deconv.')
+
+
+class WordDropout(nn.Module):
+    """Replaces tokens by <unk> with probability p - in train AND eval mode, like the reference (no self.training
+    check, decoder.py:117-133).  `sample_mask` draws the mask; callers may inject one instead (parity tests)."""
+
+    def __init__(self, p_word_dropout):
+        super().__init__()
+        self.p = p_word_dropout
+        self.rng = None  # (seed, counter) device stream when set by the model; numpy global stream otherwise
+
+    def sample_mask(self, x):
+        if self.rng is not None:
+            seed, off = self.rng.next(x.numel())
+            return ops.rng_bernoulli(tuple(x.shape), self.p, seed, off, x.device)
+        m = np.random.binomial(1, p=self.p, size=tuple(x.size())).astype('uint8')  # reference's generator & call order
+        return torch.from_numpy(m).to(x.device)
+
+    def forward(self, x, mask=None):
+        mask = self.sample_mask(x) if mask is None else mask
+        out = x.clone()
+        out[mask.bool()] = UNK_IDX
+        return out
+
+
+class GRUDecoder(nn.Module):
+    def __init__(self, embedding, emb_dim, output_dim, h_dim, p_word_dropout, p_out_dropout, skip_connetions):
+        super().__init__()
+        self.emb = embedding
+        self.rnn = nn.GRU(emb_dim, h_dim, batch_first=True)
+        self.fc = nn.Sequential(nn.Dropout(p_out_dropout), nn.Linear(h_dim, output_dim))
+        self.word_dropout = WordDropout(p_word_dropout)
+        self.p_out = p_out_dropout
+        self.h_dim = h_dim
+        self.skip_connetions = skip_connetions
+        if skip_connetions:
+            raise NotImplementedError('skip connections are off by default (cfg.py:281) and not on the MI355X path')
+        self.rng = None
+
+    def init_hidden(self, z, c):
+        return torch.cat([z, c], dim=1)
+
+    def _tables(self, zc):
+        E = self.emb.weight.shape[1]
+        w_ih = self.rnn.weight_ih_l0
+        emb_w = ops.ZeroRowGradFn.apply(self.emb.weight, self.emb.padding_idx) if self.emb.padding_idx is not None \
+            else self.emb.weight
+        tab = ops.LinearFn.apply(emb_w, w_ih[:, :E], self.rnn.bias_ih_l0)   # [V,3H]
+        rowc = ops.LinearFn.apply(zc, w_ih[:, E:], None)                    # [B,3H]
+        return tab, rowc
+
+    def forward(self, x, z, c, wd_mask=None, out_keep=None):
+        """Teacher forcing.  x ids [B,T]; returns logits [B,T,V].
+        wd_mask uint8 [B,T] / out_keep uint8 [B,T,H] inject the two dropout masks (otherwise sampled here)."""
+        B, T = x.shape
+        zc = self.init_hidden(z, c)
+        if wd_mask is None:
+            wd_mask = self.word_dropout.sample_mask(x)
+        tok = ops.tokens_prepare(x, wd_mask)
+        tab, rowc = self._tables(zc)
+        slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)
+        hs = slab[1:].reshape(T * B, self.h_dim)
+        keep, scale = None, 1.0
+        if out_keep is not None:
+            keep = ops.transpose01_u8(out_keep.to(torch.uint8))          # [B,T,H] -> [T,B,H]
+            scale = 1.0 / (1.0 - self.p_out) if self.p_out > 0 else 1.0
+        elif self.training and self.p_out > 0:
+            keep = self._sample_keep((T, B, self.h_dim), x.device)
+            scale = 1.0 / (1.0 - self.p_out)
+        fc = self.fc[1]
+        logits_tm = ops.VocabFcFn.apply(hs, keep, scale, fc.weight, fc.bias).view(T, B, -1)
+        return ops.Transpose01Fn.apply(logits_tm)
+
+    def _sample_keep(self, shape, device):
+        if self.rng is not None:
+            n = shape[0] * shape[1] * shape[2]
+            seed, off = self.rng.next(n)
+            return ops.rng_bernoulli(shape, 1.0 - self.p_out, seed, off, device)
+        return (torch.rand(shape, device=device) >= self.p_out).to(torch.uint8)
+
+    def forward_sample(self, sampleSoft, sampleHard, z, c, h):
+        """One decode step (reference signature, decoder.py:86-109): h is [1,N,H]; returns logits [N,V], h [1,N,H]."""
+        if sampleSoft is not None:
+            raise NotImplementedError('soft sampling modes are a "next" row (SURVEY 8f rank 4)')
+        zc = self.init_hidden(z, c)
+        with torch.no_grad():
+            tab, rowc = self._tables(zc)
+            tok = sampleHard.to(torch.int32).contiguous()
+            h_prev = h[0].contiguous()
+            h_new = torch.empty_like(h_prev)
+            ops.gru_step(tok, tab, rowc, h_prev, h_new, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
+            fc = self.fc[1]
+            keep, scale = None, 1.0
+            if self.training and self.p_out > 0:
+                keep = self._sample_keep((1,) + tuple(h_new.shape), h_new.device)[0]
+                scale = 1.0 / (1.0 - self.p_out)
+            logits = ops.VocabFcFn.apply(h_new, keep, scale, fc.weight, fc.bias)
+        return logits, h_new.unsqueeze(0)

@@ -1,0 +1,78 @@
+"""GRU encoder: (bi)GRU over the embedded sequence, final hidden state -> (mu, logvar).
+
+Counterpart of the reference's models/encoder.py:13-52.  `self.rnn` is a torch.nn.GRU used ONLY as the parameter
+container (same state-dict keys, same default initialisation / RNG consumption as the reference); the recurrence
+itself runs in the HIP kernels behind cpg.ops.GruSeqFn.  Like the reference (no pack_padded_sequence) the
+encoder steps through ALL T positions including pads.
+"""
+import torch
+import torch.nn as nn
+
+from cpg import ops
+
+
+def build_encoder(enc_type, **E_args):
+    if enc_type != 'gru':
+        raise ValueError('Please use GRU Encoder')
+    return GRUEncoder(**E_args)
+
+
+class GRUEncoder(nn.Module):
+    def __init__(self, emb_dim, h_dim, z_dim, biGRU, layers, p_dropout):
+        super().__init__()
+        self.rnn = nn.GRU(input_size=emb_dim, hidden_size=h_dim, num_layers=layers, dropout=p_dropout,
+                          bidirectional=biGRU, batch_first=True)
+        self.biGRU = biGRU
+        self.biGRU_factor = 2 if biGRU else 1
+        self.h_dim, self.layers, self.p_dropout = h_dim, layers, p_dropout
+        self.q_mu = nn.Linear(self.biGRU_factor * h_dim, z_dim)
+        self.q_logvar = nn.Linear(self.biGRU_factor * h_dim, z_dim)
+        if p_dropout > 0 and layers > 1:
+            raise NotImplementedError('inter-layer GRU dropout is not on the MI355X path (reference default p_dropout=0.0)')
+
+    def _dirs(self):
+        return [("", False), ("_reverse", True)] if self.biGRU else [("", False)]
+
+    def _w(self, name, layer, sfx):
+        return getattr(self.rnn, f"{name}_l{layer}{sfx}")
+
+    def _run(self, T, tok=None, emb_weight=None, dense_x=None):
+        """Either (tok int32 [T,B], emb_weight) - token-table path - or dense_x [T,B,E] embeddings."""
+        slabs = None
+        for l in range(self.layers):
+            new = []
+            for sfx, rev in self._dirs():
+                w_ih, w_hh = self._w("weight_ih", l, sfx), self._w("weight_hh", l, sfx)
+                b_ih, b_hh = self._w("bias_ih", l, sfx), self._w("bias_hh", l, sfx)
+                tab = dense = None
+                if l == 0 and tok is not None:
+                    tab = ops.LinearFn.apply(emb_weight, w_ih, b_ih)  # [V,3H]: W_ih emb[v] + b_ih for every token
+                elif l == 0:
+                    B = dense_x.shape[1]
+                    dense = ops.LinearFn.apply(dense_x.reshape(T * B, -1), w_ih, b_ih).view(T, B, -1)
+                else:
+                    B = slabs[0].shape[1]
+                    xf = slabs[0][1:].reshape(T * B, -1)            # forward direction: h_t at slot t+1
+                    if self.biGRU:
+                        xb = slabs[1][:T].reshape(T * B, -1)        # reverse direction: h_t at slot t
+                        dense = ops.Linear2Fn.apply(xf, xb, w_ih, b_ih).view(T, B, -1)
+                    else:
+                        dense = ops.LinearFn.apply(xf, w_ih, b_ih).view(T, B, -1)
+                new.append(ops.GruSeqFn.apply(tok if l == 0 else None, tab, None, dense, None, w_hh, b_hh, T, rev))
+            slabs = new
+        # final states of the top layer: forward slab slot T, reverse slab slot 0 (reference: cat(h[-2], h[-1]))
+        finals = [slabs[0][T]] + ([slabs[1][0]] if self.biGRU else [])
+        h = torch.cat(finals, 1) if len(finals) > 1 else finals[0]
+        mu = ops.LinearFn.apply(h, self.q_mu.weight, self.q_mu.bias)
+        logvar = ops.LinearFn.apply(h, self.q_logvar.weight, self.q_logvar.bias)
+        return mu, logvar
+
+    def forward_tokens(self, ids, emb_weight):
+        """ids int64 [B,T]: fused path, W_ih emb[tok] is a V-row lookup table (never a [B,T,E] GEMM)."""
+        tok = ops.tokens_prepare(ids)
+        return self._run(ids.shape[1], tok=tok, emb_weight=emb_weight)
+
+    def forward(self, x):
+        """x: embeddings [mbsize, seq_len, emb_dim] (reference signature; used for soft inputs)."""
+        T = x.shape[1]
+        return self._run(T, dense_x=x.transpose(0, 1).contiguous())

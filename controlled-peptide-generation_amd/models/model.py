@@ -1,0 +1,196 @@
+"""RNN_VAE on the MI355X hot path.
+
+Mirrors the public surface of the reference's models/model.py (ctor signature :23-35, forward :146-195,
+forward_encoder :96-105, sample_z / sample_z_prior / sample_c_prior :107-126, generate_sentences :197-223,
+sample_G :225-385, the parameter groups :75-94) so main.py / train_vae.py / sample_pipeline.py / api.py style callers
+work unchanged, with the same state-dict keys and the same default initialisation.  All arithmetic runs in the HIP
+kernels of libcpg_hip.so through cpg.ops / cpg.decode; torch modules below are parameter containers.
+
+Differences that are deliberate and documented:
+  * `forward` accepts optional keyword `rnd=dict(eps=, c=, wd_mask=, out_mask=)` to inject the step's random draws
+    (the reference mixes torch and numpy generators; parity tests inject its captured draws);
+  * `.device` defaults to cuda (as in the reference, model.py:41) and stays an assignable attribute (api.py:96);
+  * flows (flow>0) and soft sampling modes are not on this path and raise.
+"""
+from itertools import chain
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from cpg import ops
+from cpg import decode as cdecode
+from models.decoder import build_decoder
+from models.encoder import build_encoder
+from models.classifier import build_classifier
+from models.mutils import UNK_IDX, PAD_IDX, START_IDX, EOS_IDX
+
+HARD_MODES = ('categorical', 'greedy', 'beam')
+SOFT_MODES = ('gumbel_soft', 'gumbel_ST', 'greedy_softmax', 'categorical_softmax', 'none_softmax')
+
+
+class DeviceRng:
+    """(seed, running offset) for the Philox streams of cpg_rng_*; one instance per model so every draw is distinct."""
+
+    def __init__(self, seed):
+        self.seed, self.offset = int(seed), 0
+
+    def next(self, n):
+        off = self.offset
+        self.offset += (int(n) + 3) // 4 + 1
+        return self.seed, off
+
+
+class RNN_VAE(nn.Module):
+    def __init__(self, n_vocab, max_seq_len, z_dim, c_dim, emb_dim, pretrained_emb, freeze_embeddings, flow, flow_type,
+                 E_args, G_args, C_args):
+        super().__init__()
+        self.MAX_SEQ_LEN = max_seq_len
+        self.n_vocab = n_vocab
+        self.z_dim = z_dim
+        self.c_dim = c_dim
+        self.emb_dim = emb_dim
+        self.device = torch.device('cuda')
+        self.UNK_IDX, self.PAD_IDX, self.START_IDX, self.EOS_IDX = UNK_IDX, PAD_IDX, START_IDX, EOS_IDX
+
+        self.word_emb = nn.Embedding(n_vocab, emb_dim, PAD_IDX)
+        if pretrained_emb is not None:
+            assert emb_dim == pretrained_emb.size(1), 'emb dim dont match with pretrained'
+            self.word_emb = nn.Embedding(n_vocab, emb_dim, PAD_IDX)
+            self.word_emb.weight.data.copy_(pretrained_emb)
+        if freeze_embeddings:
+            self.word_emb.weight.requires_grad = False
+
+        self.encoder = build_encoder('gru', emb_dim=emb_dim, z_dim=z_dim, **E_args)
+        self.decoder = build_decoder(embedding=self.word_emb, emb_dim=emb_dim + z_dim + c_dim, output_dim=n_vocab,
+                                     h_dim=z_dim + c_dim, **G_args)
+        self.classifier = build_classifier('cnn', emb_dim, **C_args)
+        self.use_flow = flow > 0
+        if self.use_flow:
+            raise NotImplementedError('normalizing flows are dead code in the reference training path '
+                                      '(models/model.py:173-177 raises) and are not provided')
+        self.rng = None  # DeviceRng -> on-device Philox draws; None -> the reference's torch/numpy generators
+
+    # ------------------------------------------------------------------ randomness
+    def use_device_rng(self, seed):
+        """Draw eps / z_prior / c / dropout masks with the on-device counter-based streams (no host RNG, no H2D)."""
+        self.rng = DeviceRng(seed)
+        self.decoder.rng = self.rng
+        self.decoder.word_dropout.rng = self.rng
+        return self
+
+    def _randn(self, n, d):
+        if self.rng is not None:
+            seed, off = self.rng.next(n * d)
+            return ops.rng_normal((n, d), seed, off, self.device)
+        return torch.randn(n, d).to(self.device)
+
+    # ------------------------------------------------------------------ parameter groups (model.py:75-94)
+    def classifier_params(self):
+        return filter(lambda p: p.requires_grad, self.classifier.parameters())
+
+    def decoder_params(self):
+        return filter(lambda p: p.requires_grad, self.decoder.parameters())
+
+    def encoder_params(self):
+        return filter(lambda p: p.requires_grad, chain(self.word_emb.parameters(), self.encoder.parameters()))
+
+    def vae_params(self):
+        # NB: word_emb.weight appears twice (decoder.emb is the same module) exactly like the reference
+        return filter(lambda p: p.requires_grad,
+                      chain(self.word_emb.parameters(), self.encoder.parameters(), self.decoder.parameters()))
+
+    # ------------------------------------------------------------------ pieces of the forward pass
+    def _emb_weight(self):
+        return ops.ZeroRowGradFn.apply(self.word_emb.weight, PAD_IDX)
+
+    def forward_encoder(self, inputs):
+        """ids [mbsize, seq_len] -> (mu, logvar);  soft inputs [mbsize, seq_len, n_vocab] go through soft_embed."""
+        if inputs.dim() == 2:
+            return self.encoder.forward_tokens(inputs, self._emb_weight())
+        from models.mutils import soft_embed
+        return self.encoder(soft_embed(self.word_emb, inputs))
+
+    def sample_z(self, mu, logvar, eps=None):
+        if eps is None:
+            eps = self._randn(mu.size(0), self.z_dim)
+        return ops.ReparamFn.apply(mu, logvar, eps)
+
+    def sample_z_prior(self, mbsize):
+        return self._randn(mbsize, self.z_dim)
+
+    def sample_c_prior(self, mbsize):
+        """c ~ Cat([.5,.5]) one-hot [mbsize, 2]."""
+        if self.rng is not None:
+            seed, off = self.rng.next(mbsize)
+            bit = ops.rng_bernoulli((mbsize,), 0.5, seed, off, self.device).long()
+            c = torch.zeros(mbsize, 2, device=self.device)
+            c.scatter_(1, bit.unsqueeze(1), 1.0)
+            return c
+        return torch.from_numpy(np.random.multinomial(1, [0.5, 0.5], mbsize).astype('float32')).to(self.device)
+
+    def forward_decoder(self, inputs, z, c, wd_mask=None, out_keep=None):
+        return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep)
+
+    def forward_classifier(self, inputs):
+        if inputs.dim() == 2:
+            x = self.word_emb(inputs)
+        else:
+            from models.mutils import soft_embed
+            x = soft_embed(self.word_emb, inputs)
+        return self.classifier(x)
+
+    def forward(self, sequences, q_c='prior', sample_z=1, rnd=None):
+        """-> ((mu, logvar), (z, c), dec_logits [mbsize, seq_len, n_vocab])"""
+        rnd = rnd or {}
+        mbsize = sequences.size(0)
+        mu, logvar = self.forward_encoder(sequences)
+        assert mu.size(0) == logvar.size(0) == mbsize
+        if sample_z == 'max':
+            z = mu
+        else:
+            assert sample_z == 1, 'sample_z > 1 is not supported (reference: TODO)'
+            z = self.sample_z(mu, logvar, rnd.get('eps'))
+        if 'c' in rnd:
+            c = rnd['c']
+        elif isinstance(q_c, torch.Tensor):
+            c = torch.zeros(mbsize, 2, device=self.device)
+            c.scatter_(1, q_c.unsqueeze(1), 1)
+        elif q_c == 'prior':
+            c = self.sample_c_prior(mbsize)
+        elif q_c == 'classifier':
+            c = torch.softmax(self.forward_classifier(sequences), dim=1)
+        else:
+            raise ValueError("q_c is not labels, prior, or classifier")
+        dec_logits = self.forward_decoder(sequences, z, c, wd_mask=rnd.get('wd_mask'), out_keep=rnd.get('out_mask'))
+        return (mu, logvar), (z, c), dec_logits
+
+    # ------------------------------------------------------------------ generation
+    def generate_sentences(self, mbsize, z=None, c=None, eval_mode=True, **sample_kwargs):
+        if z is None:
+            z = self.sample_z_prior(mbsize)
+        if c is None:
+            c = self.sample_c_prior(mbsize)
+        if eval_mode:
+            self.eval()
+        sentences = self.sample_G(mbsize, z, c, **sample_kwargs)
+        if eval_mode:
+            self.train()  # the reference ALWAYS returns to train mode here
+        return sentences, z, c.argmax(dim=1)
+
+    def sample_G(self, mbsize, z, c, sample_mode='categorical', temp=1.0, gumbel_temp=1.0, prepend_start_idx=True,
+                 prevent_empty=False, min_length=1, beam_size=5, n_best=3):
+        if sample_mode in SOFT_MODES:
+            raise NotImplementedError('soft sampling modes are a "next" row (SURVEY 8f rank 4), not on the MI355X path yet')
+        if sample_mode not in HARD_MODES:
+            raise Exception('Sample mode {} not implemented.'.format(sample_mode))
+        assert beam_size >= n_best, "Can't return more than max hypothesis"
+        assert mbsize == z.size(0) == c.size(0), 'oops sizes dont match {} {} {}'.format(mbsize, z.size(0), c.size(0))
+        z, c = z.to(self.device).float(), c.to(self.device).float()
+        if sample_mode == 'beam':
+            return cdecode.decode_beam(self.decoder, z, c, self.MAX_SEQ_LEN, beam_size, n_best, min_length)
+        if self.training and self.decoder.p_out > 0:
+            raise NotImplementedError('hard sampling with out-dropout active (eval_mode=False) is not on the MI355X path')
+        ids = cdecode.decode_hard(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
+                                  prevent_empty=prevent_empty, min_length=min_length)
+        return ids if prepend_start_idx else ids[:, 1:]

@@ -1,0 +1,171 @@
+/* libcpg_hip.so - C ABI of the MI355X (gfx950) peptide WAE-training + CLaSS-sampling hot path.
+ *
+ * The reference (IBM/controlled-peptide-generation) is pure Python on PyTorch and has NO native/FFI boundary of
+ * its own; the operations below are the ones PyTorch dispatched for it (cuDNN GRU, cuBLAS, fused
+ * cross-entropy, elementwise kernels) plus the numpy/sklearn arithmetic of the CLaSS sampler.  Each entry point cites
+ * the reference call site it stands behind.  The Python host above this ABI (package
+ * `controlled-peptide-generation_amd/`) mirrors the reference's own API (models.model.RNN_VAE, losses.*, train_vae,
+ * density_modeling.RejSampleBase) and binds these symbols with ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a hipError_t (>0) or a negative cpg code otherwise;
+ *     `cpg_last_error()` returns a thread-local message;
+ *   - the caller owns every buffer (device pointers, e.g. torch tensor.data_ptr()); nothing is allocated inside;
+ *     scratch comes in through `workspace` arguments sized by the matching `*_workspace()` query;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; 0 = default stream);
+ *   - dense arrays are row-major f32 unless stated; `ld*` = leading dimension in elements;
+ *   - all randomness is an input (or comes from the explicit cpg_rng_* counter-based streams);
+ *   - no global mutable state; re-entrant across streams; one process per GPU.
+ *   - reductions use a fixed two-stage partition: results are run-to-run deterministic.
+ */
+#ifndef CPG_API_H
+#define CPG_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPG_API
+
+/* ---- library ---------------------------------------------------------------------------------------------- */
+CPG_API const char* cpg_last_error(void);
+CPG_API int cpg_version(void);
+CPG_API int cpg_device_count(void);
+
+/* ---- layout ----------------------------------------------------------------------------------------------- */
+/* ids int64 [B,T] (loader layout, data_processing/dataset.py:242-244) -> tok int32 [T,B] time-major; applies
+ * WordDropout (models/decoder.py:117-133: masked positions := <unk>) when wd_mask (uint8 [B,T]) is non-null. */
+CPG_API int cpg_tokens_prepare(const int64_t* ids, const uint8_t* wd_mask, int B, int T, int unk, int32_t* tok,
+                               void* stream);
+/* dst[d1][d0][inner] = src[d0][d1][inner]  (time-major <-> batch-major views of [T,B,*]) */
+CPG_API int cpg_transpose01_f32(const float* src, int d0, int d1, int inner, float* dst, void* stream);
+CPG_API int cpg_transpose01_u8(const uint8_t* src, int d0, int d1, int inner, uint8_t* dst, void* stream);
+
+/* ---- dense products (nn.Linear / `@`): models/encoder.py:35-36,50-51; models/decoder.py:43-45; losses.py:85 ------ */
+/* Y[M,N] (+)= X[M,K] W[N,K]^T + bias[N] */
+CPG_API int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                           int M, int N, int K, int accumulate, void* stream);
+/* dX[M,K] (+)= dY[M,N] W[N,K] */
+CPG_API int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,
+                                 int K, int accumulate, void* stream);
+CPG_API size_t cpg_linear_bwd_weight_workspace(int M, int N, int K);
+/* dW[N,K] (+)= dY[M,N]^T X[M,K] ; db[N] (+)= column sums of dY (db may be null) */
+CPG_API int cpg_linear_bwd_weight(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
+                                  int M, int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+/* Y[M,N] (+)= X[M,K] B[K,N] */
+CPG_API int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K,
+                          int accumulate, void* stream);
+
+/* ---- GRU (torch.nn.GRU as used at models/encoder.py:25-30,42 and models/decoder.py:40-41,77,98) ---------------------
+ * Gate row order r,z,n.  The input-side pre-activation of step t, row b is the SUM of the non-null sources
+ *     tab[tok[t,b], :]   token table  emb @ W_ih[:, :E]^T + b_ih           ([V,3H]; tok int32 [T,B])
+ *     rowc[b, :]         constant over time, e.g. [z;c] @ W_ih[:, E:]^T    ([B,3H])
+ *     dense[t,b,:]       arbitrary per-step term (upper encoder layers)    ([T,B,3H])
+ * State slab hs [(T+1),B,H]: forward direction hs[0]=h0 (caller fills), h_t -> hs[t+1];
+ *                            reverse direction hs[T]=h0 (caller fills), h_t -> hs[t].
+ * gates [T,4,B,H] receives r,z,n and (W_hn h + b_hn) per step for the backward pass (null for inference). */
+CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
+                            const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
+                            void* stream);
+/* one decode step = GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) */
+CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
+                             const float* rowc, const float* h_prev, float* h_out, void* stream);
+/* BPTT.  dhs_ext [T,B,H]: gradient arriving at each step's output (time-aligned; may be null);
+ * dh_last [B,H]: gradient on the final state (may be null); dG out [T,B,4H] = (dr_pre, dz_pre, d(W_hn h+b_hn), dn_pre):
+ * columns 0..3H are the hidden-side gate gradients, columns {0..2H, 3H..4H} the input-side ones;
+ * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip). */
+CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                            const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
+                            void* stream);
+CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
+/* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh */
+CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
+                             float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* dtab[V,3H] (+)= sum of input-side gate gradients grouped by token ; drowc[B,3H] (+)= sum over time (either may be null) */
+CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+                               float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- vocabulary projection: nn.Dropout(p_out)+nn.Linear(h_dim,n_vocab), models/decoder.py:43-45,83,107 ----------- */
+/* logits[R,V] = (hs[R,H] .* keep*scale) W[V,H]^T + b   (keep uint8 [R,H] or null) */
+CPG_API int cpg_vocab_fc_fwd(const float* hs, const uint8_t* keep, float scale, const float* w, const float* b,
+                             float* logits, int R, int H, int V, void* stream);
+CPG_API size_t cpg_vocab_fc_bwd_workspace(int R, int H, int V);
+CPG_API int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uint8_t* keep, float scale, const float* w,
+                             float* dhs, float* dw, float* db, int R, int H, int V, int accumulate, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* ---- decoding: RNN_VAE.sample_G, models/model.py:225-385; models/Beam.py ----------------------------------------- */
+/* greedy: tok = argmax (first max), finished rows emit <pad>, rows that emit <eos> become finished; writes column `col`
+ * of ids [N,ld_ids] and tok_next; unfinished[step] += rows still running after this step.  prevent_empty masks
+ * pad/start/eos with -2*|min(logits)| (model.py:299-305); scratch: 257 floats. */
+CPG_API int cpg_greedy_select(const float* logits, int N, int V, uint8_t* finished, int64_t* ids, int ld_ids, int col,
+                              int32_t* tok_next, int pad, int start, int eos, int prevent_empty, float* scratch,
+                              int* unfinished, int step, void* stream);
+/* beam: one Beam.advance for every sentence (rows beam-major: row = k*N + i) + hidden-state reorder.
+ * scores/last_tok/origin [N,K]; n_finished, done [N]; hist_* [T,N,K]; n_active[step] += sentences not yet done. */
+CPG_API int cpg_beam_select(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos,
+                            int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
+                            int32_t* hist_tok, int32_t* hist_prev, float* hist_score, int32_t* origin, int32_t* tok_next,
+                            int* n_active, const float* h_in, float* h_out, int H, void* stream);
+
+/* ---- losses (losses.py) ------------------------------------------------------------------------------------ */
+/* recon_dec, losses.py:18-31: targets = cat(ids[:,1:], PAD). out[0] = sum NLL over non-PAD targets, out[1] = their count.
+ * workspace: 512 floats. */
+CPG_API int cpg_recon_ce_fwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, float* out,
+                             float* workspace, void* stream);
+/* dlogits = gout[0] * (softmax - onehot) / count[0] on valid rows (gout, count: device scalars) */
+CPG_API int cpg_recon_ce_bwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, const float* gout,
+                             const float* count, float* dlogits, void* stream);
+/* RNN_VAE.sample_z, models/model.py:107-112: z = mu + exp(logvar/2)*eps */
+CPG_API int cpg_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n, void* stream);
+CPG_API int cpg_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar, size_t n,
+                            void* stream);
+/* out[0..4] = sums for kl_gaussianprior (losses.py:8-10), kl_gaussian_sharedmu (:13-15), |logvar| (train_vae.py:33),
+ * |mu|, logvar (train_vae.py:44-45).  workspace: 1280 floats. */
+CPG_API int cpg_latent_stats_fwd(const float* mu, const float* logvar, size_t n, float* out, float* workspace,
+                                 void* stream);
+CPG_API int cpg_latent_stats_bwd(const float* mu, const float* logvar, size_t n, int B, const float* g_kl,
+                                 const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar, int accumulate,
+                                 void* stream);
+/* mmd_rf, losses.py:59-93: raw = z @ rf_w by cpg_matmul_nn; sums[R] = sum_b cos(raw/sigma + rf_b)*sqrt(2/R) */
+CPG_API int cpg_rf_feature_sums(const float* raw, const float* rf_b, int Bn, int R, float sigma, float* sums,
+                                float* workspace, size_t workspace_bytes, void* stream);
+CPG_API int cpg_rf_loss(const float* sums1, const float* sums2, int R, int B_global, float* loss, float* diff,
+                        void* stream);
+CPG_API int cpg_rf_bwd(const float* raw, const float* rf_b, const float* diff, const float* gout, int Bn, int R,
+                       float sigma, int B_global, float* dpre, void* stream);
+/* mmd_full_kernel, losses.py:47-56,96-108 (Gaussian kernel, incl. the `H - diag(H)` broadcast) */
+CPG_API size_t cpg_mmd_full_workspace(int N);
+CPG_API int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, float* out, float* P, float* Q,
+                             void* workspace, size_t workspace_bytes, void* stream);
+CPG_API int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P, const float* Q, const float* gout, int N,
+                             int D, float sigma, float* dz1, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- optimiser: clip_grad_norm_ + Adam, train_vae.py:15,39-42 ---------------------------------------------------- */
+CPG_API size_t cpg_sumsq_workspace(void);
+CPG_API int cpg_sumsq(const float* x, size_t n, float mult, int accumulate, float* out, float* workspace, void* stream);
+CPG_API int cpg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                          float eps, int step, const float* sumsq, float max_norm, int coef_pow, float gscale,
+                          void* stream);
+
+/* ---- CLaSS sampler: density_modeling.py:43-60,79-80 (sklearn GaussianMixture.sample / LogisticRegression) ---------- */
+CPG_API int cpg_gmm_sample(const double* means, const double* covars, const int32_t* comp, const double* normals, int n,
+                           int D, float* z, void* stream);
+CPG_API int cpg_lr_score_accept(const float* z, int n, int D, const double* coef, const double* intercept,
+                                const int32_t* target, int A, const double* uniforms, double* probs, double* accum,
+                                uint8_t* accepted, void* stream);
+
+/* ---- counter-based random streams (Philox4x32-10) for callers that do not inject the draws ----------------------- */
+CPG_API int cpg_rng_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+CPG_API int cpg_rng_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+CPG_API int cpg_rng_uniform_f64(double* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+CPG_API int cpg_rng_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPG_API_H */
