@@ -42,6 +42,7 @@ def query(name, *args):
 
 
 _ws_cache = {}
+PROFILE = None  # set to a list by bench.py to collect (name, start_event, end_event, launches, B, H) records
 
 
 def workspace(nbytes, device, tag=0):
@@ -216,8 +217,15 @@ class GruSeqFn(Function):
             hs[slot0].copy_(h0)
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, w_hh, b_hh))
         gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        ev = None
+        if PROFILE is not None:  # bench.py: HIP events on the launch stream around the T fused step launches
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
              _p(hs), _p(gates), _stream())
+        if ev is not None:
+            ev[1].record()
+            PROFILE.append(("gru_step_fwd", ev[0], ev[1], T, B, H))
         ctx.save_for_backward(tok, w_hh_c, hs, gates)
         ctx.dims = (T, B, H, bool(reverse))
         ctx.V = tab.shape[0] if tab is not None else 0

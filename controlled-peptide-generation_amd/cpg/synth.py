@@ -1,0 +1,68 @@
+"""Synthetic random-vocab peptide batches and a minimal loader with the interface train_vae / main /
+sample_pipeline use from the reference's AttributeDataLoader (data_processing/dataset.py:285-300):
+`next_batch(name).text`, `idx2sentence(s)`, `idx2sentences(...)`, `n_vocab`, `TEXT.vocab.{itos,stoi}`.
+
+The reference's curated CSVs are not reproducible from its repo and torchtext 0.3.1 is not installable
+here, so this loader is the data source of this build.  Vocabulary: ids 0..3 = <unk>,<pad>,<start>,<eos>
+(models/mutils.py:5-8), 4..23 = the 20 amino acids.  Sequence: <start> aa{L} <eos> <pad>*, L ~ U{5..T-2}.
+"""
+import torch
+
+SPECIALS = ['<unk>', '<pad>', '<start>', '<eos>']
+AMINO = list("ACDEFGHIKLMNPQRSTVWY")
+
+
+def synth_ids(B, T, V=24, generator=None, device="cpu"):
+    """int64 [B,T] peptide batch (vectorised; same distribution as tests/golden/make_golden.py:synth_ids)."""
+    g = generator
+    L = torch.randint(5, T - 1, (B,), generator=g)
+    body = torch.randint(4, V, (B, T), generator=g)
+    pos = torch.arange(T).unsqueeze(0)
+    ids = torch.where(pos <= L.unsqueeze(1), body, torch.ones_like(body))
+    ids[:, 0] = 2
+    ids[torch.arange(B), L + 1] = 3
+    ids = torch.where(pos > (L + 1).unsqueeze(1), torch.ones_like(ids), ids)
+    return ids.to(device)
+
+
+class _Vocab:
+    def __init__(self):
+        self.itos = SPECIALS + AMINO
+        self.stoi = {w: i for i, w in enumerate(self.itos)}
+
+
+class _Text:
+    def __init__(self):
+        self.vocab = _Vocab()
+
+
+class _Batch:
+    def __init__(self, text):
+        self.text = text
+
+
+class SyntheticPeptideLoader:
+    def __init__(self, mbsize, max_seq_len, device, size=20000, seed=1238, rank=0, **_ignored):
+        self.mbsize, self.T, self.device = mbsize, max_seq_len, device
+        self.TEXT = _Text()
+        self.n_vocab = len(self.TEXT.vocab.itos)
+        g = torch.Generator().manual_seed(seed)
+        self.pool = synth_ids(size, max_seq_len, self.n_vocab, g).to(device)
+        self.gen = torch.Generator().manual_seed(seed + 1000 * (rank + 1))
+
+    def print_stats(self):
+        print('SyntheticPeptideLoader: {} sequences, vocab {}, max_seq_len {}'.format(self.pool.shape[0], self.n_vocab, self.T))
+
+    def next_batch(self, iterator_name):
+        """Random batch WITH replacement, like the reference's weighted multinomial sampler (dataset.py:72-77)."""
+        idx = torch.randint(0, self.pool.shape[0], (self.mbsize,), generator=self.gen).to(self.pool.device)
+        return _Batch(self.pool[idx])
+
+    def idx2sentence(self, idxs, print_special_tokens=True):
+        toks = [int(i) for i in idxs]
+        if not print_special_tokens:
+            toks = [i for i in toks if i >= len(SPECIALS)]
+        return ' '.join(self.TEXT.vocab.itos[i] for i in toks)
+
+    def idx2sentences(self, batch, print_special_tokens=True):
+        return [self.idx2sentence(s, print_special_tokens) for s in batch]

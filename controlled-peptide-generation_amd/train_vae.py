@@ -1,0 +1,72 @@
+"""Phase-1 WAE/VAE training loop on the MI355X hot path (counterpart of the reference's train_vae.py:13-68).
+
+Per iteration, as in the reference: batch -> model forward (encoder, reparameterisation, teacher-forced decoder) ->
+recon CE + KL + full-kernel MMD + random-feature MMD (all four are evaluated every step; cfgv.z_regu_loss picks the
+one that regularises) -> loss = recon + beta*regu + lambda_L1*|logvar|_1 + lambda_KL*KL(N(mu,s)||N(mu,I)) -> backward
+-> global-norm clip -> Adam, with n_iter+1 iterations, the same metric names, logging cadence and checkpoint naming.
+Differences: the optimiser is the fused HIP clip+Adam (same observable semantics incl. the duplicate-embedding quirk,
+SURVEY F6); metrics are read back from the device only on logging iterations (the reference calls .item() ten times
+every step); `train_step` is exposed so bench.py times exactly this body.
+"""
+import sys
+
+import torch
+
+import losses
+import utils
+from cpg.optim import FusedAdamClip
+from models.mutils import save_model
+from tb_json_logger import log_value
+
+
+def make_optimizer(cfgv, model, reduce_fn=None, world=1):
+    return FusedAdamClip(model.vae_params(), lr=cfgv.lr, max_norm=cfgv.clip_grad, reduce_fn=reduce_fn, world=world)
+
+
+def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
+    """One full iteration.  Returns a dict of device scalars (no host sync)."""
+    beta = utils.anneal(cfgv.beta, it)
+    (z_mu, z_logvar), (z, c), dec_logits = model(text, q_c='prior', sample_z=1, rnd=rnd)
+    recon_loss = losses.recon_dec(text, dec_logits)
+    kl_loss = losses.kl_gaussianprior(z_mu, z_logvar)
+    wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0])
+    wae_mmdrf_loss = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=z_priors[1])
+    z_regu_loss = {'kl': kl_loss, 'mmd': wae_mmd_loss, 'mmdrf': wae_mmdrf_loss}[cfgv.z_regu_loss]
+    z_logvar_L1 = losses.logvar_l1(z_logvar)
+    z_logvar_KL_penalty = losses.kl_gaussian_sharedmu(z_mu, z_logvar)
+    loss = recon_loss + beta * z_regu_loss + cfgv.lambda_logvar_L1 * z_logvar_L1 \
+        + cfgv.lambda_logvar_KL * z_logvar_KL_penalty
+    trainer.zero_grad()
+    loss.backward()
+    trainer.step()
+    return dict(z_mu=z_mu, z_logvar=z_logvar, z_logvar_L1=z_logvar_L1, z_logvar_KL_penalty=z_logvar_KL_penalty, L_vae=loss,
+                L_vae_recon=recon_loss, L_vae_kl=kl_loss, L_wae_mmd=wae_mmd_loss, L_wae_mmdrf=wae_mmdrf_loss, beta=beta)
+
+
+def train_vae(cfgv, model, dataset, reduce_fn=None, world=1, rank=0):
+    print('Training base vae ...')
+    trainer = make_optimizer(cfgv, model, reduce_fn, world)
+    for it in range(cfgv.s_iter, cfgv.s_iter + cfgv.n_iter + 1):
+        logging_it = it % cfgv.cheaplog_every == 0 or it % cfgv.expsvlog_every == 0
+        inputs = dataset.next_batch('train_vae')
+        t = train_step(cfgv, model, trainer, inputs.text, it)
+        if logging_it and rank == 0:
+            from cpg.ops import latent_sums
+            with torch.no_grad():
+                s = latent_sums(t['z_mu'].detach(), t['z_logvar'].detach()).cpu()
+            n = t['z_mu'].numel()
+            vals = {'z_mu_L1': s[3].item() / n, 'z_logvar': s[4].item() / n,
+                    'z_logvar_L1': t['z_logvar_L1'].item(), 'z_logvar_KL_penalty': t['z_logvar_KL_penalty'].item(),
+                    'L_vae': t['L_vae'].item(), 'L_vae_recon': t['L_vae_recon'].item(), 'L_vae_kl': t['L_vae_kl'].item(),
+                    'L_wae_mmd': t['L_wae_mmd'].item(), 'L_wae_mmdrf': t['L_wae_mmdrf'].item(), 'beta': t['beta']}
+            for k, v in vals.items():
+                log_value('train_' + k, v, it)
+            print('ITER {} TRAINING (phase 1). loss_vae: {:.4f}; loss_recon: {:.4f}; loss_kl: {:.4f}; loss_mmd: {:.4f}; '
+                  'Grad_norm: {:.4e} '.format(it, vals['L_vae'], vals['L_vae_recon'], vals['L_vae_kl'], vals['L_wae_mmd'],
+                                              trainer.grad_norm().item()))
+            log_sent, _, _ = model.generate_sentences(1, sample_mode='categorical')
+            print('Sample (cat T=1.0): "{}"'.format(dataset.idx2sentence(log_sent.squeeze())))
+            sys.stdout.flush()
+        if it % cfgv.expsvlog_every == 0 and it > 0 and rank == 0:
+            save_model(model, cfgv.chkpt_path.format(it))
+    return trainer
