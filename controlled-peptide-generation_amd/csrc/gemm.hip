@@ -5,6 +5,7 @@
 //   cpg_matmul_nn          Y = X B                (losses.py:85  z @ rf_w)
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include <stdlib.h>
 
 struct GemmArgs {
     const float* A; int lda; int M;
@@ -22,7 +23,6 @@ struct GemmArgs {
 
 template <class TC, bool A_KC, bool B_KC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m0 = blockIdx.y * TC::BM, n0 = blockIdx.x * TC::BN;
     int kb = 0, K = g.K;
     if (g.k_chunk > 0) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    MainLoop<TC, A_KC, B_KC, VEC, VEC>::run(a, b, K, smem, acc);
+    MainLoop<TC, A_KC, B_KC, VEC, VEC>::run(a, b, K, acc);
     float* C = g.C + (size_t)blockIdx.z * g.slab_stride;
     const bool plain = g.k_chunk == 0;
 #pragma unroll
@@ -116,9 +116,11 @@ using T64x64 = TileCfg<64, 64, 32, 2, 2, 1>;
 
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s) {
+    // 16-byte operand loads need aligned bases / leading dimensions and vectors that never straddle a bound
     const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
                      (!g.a_mask || (((uintptr_t)g.a_mask) & 3) == 0) && (!g.b_mask || (((uintptr_t)g.b_mask) & 3) == 0) &&
-                     (g.k_chunk % 4 == 0);
+                     (g.k_chunk % 4 == 0) && ((A_KC || B_KC) ? g.K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) &&
+                     (B_KC || g.N % 4 == 0);
     if (g.M <= 32) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
     if (g.N <= 32) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * zdim;
@@ -139,6 +141,13 @@ int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int
 }
 
 static void pick_split(int M, int N, int K, int& S, int& k_chunk) {
+    const char* e = getenv("CPG_TN_SPLIT");  // tuning knob (tools/kbench.py)
+    if (e && atoi(e) > 0) {
+        S = atoi(e);
+        k_chunk = cdiv(cdiv(K, S), 32) * 32;
+        S = cdiv(K, k_chunk);
+        return;
+    }
     // enough workgroups to fill 256 CUs a couple of times over, chunks a multiple of the slab depth
     const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
     long want = (768 + tiles - 1) / tiles;

@@ -69,36 +69,53 @@ __device__ __forceinline__ void bmap(const OpB& b, int n_local, int& idx, int& j
     idx = seg * b.seg_stride + j;
 }
 
-__device__ __forceinline__ float4 apply_mask4(float4 v, const uint8_t* m, float s, bool vec) {
-    if (vec) {
-        const uchar4 k = *reinterpret_cast<const uchar4*>(m);
-        v.x = k.x ? v.x * s : 0.f;
-        v.y = k.y ? v.y * s : 0.f;
-        v.z = k.z ? v.z * s : 0.f;
-        v.w = k.w ? v.w * s : 0.f;
+// 4-wide operand fetch of p[off .. off+3]; element c is in range iff c < nvalid.  Loads are UNCONDITIONAL (clamped to
+// offset 0, which always exists); the validity bits are returned and applied when the registers are written to LDS,
+// i.e. AFTER the MFMA phase the loads overlap with - a branch or a select right behind a load makes hipcc wait for the
+// load where it is issued and serialises the staging phase (cdna guide section 5, trap (c)).
+// VEC (16-byte loads) requires the caller to guarantee alignment AND that vectors never straddle a bound
+// (nvalid is then either <= 0 or >= 4).
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* p, size_t off, int nvalid, unsigned& okbits) {
+    if (VEC) {
+        const bool ok = nvalid >= 4;
+        okbits = ok ? 0xFu : 0u;
+        return *reinterpret_cast<const float4*>(p + (ok ? off : 0));
     }
-    return v;
+    float t[4];
+    okbits = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool ok = c < nvalid;
+        okbits |= ok ? (1u << c) : 0u;
+        t[c] = p[ok ? off + c : 0];
+    }
+    return make_float4(t[0], t[1], t[2], t[3]);
 }
 
-// Guarded 4-wide load of p[0..3] where element c is in range iff c < nvalid.
 template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* p, int nvalid, const uint8_t* mask, float ms) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nvalid <= 0) return v;
-    if (VEC && nvalid >= 4) {
-        v = *reinterpret_cast<const float4*>(p);
-        if (mask) v = apply_mask4(v, mask, ms, true);
-        return v;
+__device__ __forceinline__ uchar4 loadmask4(const uint8_t* m, size_t off, unsigned okbits) {
+    if (VEC) return *reinterpret_cast<const uchar4*>(m + (okbits ? off : 0));
+    uchar4 k;
+    k.x = m[(okbits & 1u) ? off : 0];
+    k.y = m[(okbits & 2u) ? off + 1 : 0];
+    k.z = m[(okbits & 4u) ? off + 2 : 0];
+    k.w = m[(okbits & 8u) ? off + 3 : 0];
+    return k;
+}
+
+__device__ __forceinline__ float4 finish4(float4 v, unsigned okbits, bool has_mask, uchar4 k, float ms) {
+    if (has_mask) {
+        v.x = k.x ? v.x * ms : 0.f;
+        v.y = k.y ? v.y * ms : 0.f;
+        v.z = k.z ? v.z * ms : 0.f;
+        v.w = k.w ? v.w * ms : 0.f;
     }
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        if (c < nvalid) {
-            float x = p[c];
-            if (mask) x = mask[c] ? x * ms : 0.f;
-            t[c] = x;
-        }
-    return make_float4(t[0], t[1], t[2], t[3]);
+    v.x = (okbits & 1u) ? v.x : 0.f;
+    v.y = (okbits & 2u) ? v.y : 0.f;
+    v.z = (okbits & 4u) ? v.z : 0.f;
+    v.w = (okbits & 8u) ? v.w : 0.f;
+    return v;
 }
 
 template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC>
@@ -109,132 +126,141 @@ struct MainLoop {
     static constexpr int ASZ = TC::template a_elems<A_KC>();
     static constexpr int BSZ = TC::template b_elems<B_KC>();
 
-    __device__ static __forceinline__ void gload_a(const OpA& a, int k0, int K, float4 (&r)[TC::AV]) {
+    struct Stage {  // one K-slab of both operands in flight in registers
+        float4 a[TC::AV], b[TC::BV];
+        uchar4 am[TC::AV], bm[TC::BV];
+        unsigned aok[TC::AV], bok[TC::BV];
+    };
+
+    __device__ static __forceinline__ void gload(const OpA& a, const OpB& b, int k0, int K, Stage& st) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) {
             const int v = tid + i * TC::NT;
+            size_t off;
+            int nvalid;
             if (A_KC) {
                 const int row = v / (BK / 4), kq = v % (BK / 4);
                 const int gm = a.m0 + row, k = k0 + 4 * kq;
-                const int nvalid = (gm < a.M) ? (K - k) : 0;
-                const size_t off = (size_t)gm * a.ld + k;
-                r[i] = load4<AVEC>(a.p + off, nvalid, a.mask ? a.mask + off : nullptr, a.mscale);
+                nvalid = (gm < a.M) ? (K - k) : 0;
+                off = (size_t)gm * a.ld + k;
             } else {
                 const int kk = v / (BM / 4), mq = v % (BM / 4);
                 const int gk = k0 + kk, gm = a.m0 + 4 * mq;
-                const int nvalid = (gk < K) ? (a.M - gm) : 0;
-                const size_t off = (size_t)gk * a.ld + gm;
-                r[i] = load4<AVEC>(a.p + off, nvalid, a.mask ? a.mask + off : nullptr, a.mscale);
+                nvalid = (gk < K) ? (a.M - gm) : 0;
+                off = (size_t)gk * a.ld + gm;
             }
+            st.a[i] = load4<AVEC>(a.p, off, nvalid, st.aok[i]);
+            if (a.mask) st.am[i] = loadmask4<AVEC>(a.mask, off, st.aok[i]);
         }
-    }
-
-    __device__ static __forceinline__ void gload_b(const OpB& b, int k0, int K, float4 (&r)[TC::BV]) {
-        const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
             const int v = tid + i * TC::NT;
+            size_t off;
+            int nvalid, idx, j;
             if (B_KC) {
                 const int nl = v / (BK / 4), kq = v % (BK / 4);
-                int idx, j;
                 bmap<TC::NSEG>(b, nl, idx, j);
                 const int k = k0 + 4 * kq;
-                const int nvalid = (j < b.seg_len) ? (K - k) : 0;
-                const size_t off = (size_t)idx * b.ld + k;
-                r[i] = load4<BVEC>(b.p + off, nvalid, b.mask ? b.mask + off : nullptr, b.mscale);
+                nvalid = (j < b.seg_len) ? (K - k) : 0;
+                off = (size_t)idx * b.ld + k;
             } else {
                 const int kk = v / (BN / 4), nq = v % (BN / 4);
-                int idx, j;
                 bmap<TC::NSEG>(b, 4 * nq, idx, j);
                 const int gk = k0 + kk;
-                const int nvalid = (gk < K) ? (b.seg_len - j) : 0;
-                const size_t off = (size_t)gk * b.ld + idx;
-                r[i] = load4<BVEC>(b.p + off, nvalid, b.mask ? b.mask + off : nullptr, b.mscale);
+                nvalid = (gk < K) ? (b.seg_len - j) : 0;
+                off = (size_t)gk * b.ld + idx;
             }
+            st.b[i] = load4<BVEC>(b.p, off, nvalid, st.bok[i]);
+            if (b.mask) st.bm[i] = loadmask4<BVEC>(b.mask, off, st.bok[i]);
         }
     }
 
-    __device__ static __forceinline__ void sstore_a(float* As, const float4 (&r)[TC::AV]) {
+    __device__ static __forceinline__ void sstore(const OpA& a, const OpB& b, float* As, float* Bs, const Stage& st) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) {
             const int v = tid + i * TC::NT;
+            const float4 r = finish4(st.a[i], st.aok[i], a.mask != nullptr, st.am[i], a.mscale);
             if (A_KC) {
                 const int row = v / (BK / 4), kq = v % (BK / 4);
                 float2* d = reinterpret_cast<float2*>(As + row * LDA + 4 * kq);
-                d[0] = make_float2(r[i].x, r[i].y);
-                d[1] = make_float2(r[i].z, r[i].w);
+                d[0] = make_float2(r.x, r.y);
+                d[1] = make_float2(r.z, r.w);
             } else {
                 const int kk = v / (BM / 4), mq = v % (BM / 4);
-                *reinterpret_cast<float4*>(As + kk * LDA + 4 * mq) = r[i];
+                *reinterpret_cast<float4*>(As + kk * LDA + 4 * mq) = r;
             }
         }
-    }
-
-    __device__ static __forceinline__ void sstore_b(float* Bs, const float4 (&r)[TC::BV]) {
-        const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
             const int v = tid + i * TC::NT;
+            const float4 r = finish4(st.b[i], st.bok[i], b.mask != nullptr, st.bm[i], b.mscale);
             if (B_KC) {
                 const int nl = v / (BK / 4), kq = v % (BK / 4);
                 float2* d = reinterpret_cast<float2*>(Bs + nl * LDB + 4 * kq);
-                d[0] = make_float2(r[i].x, r[i].y);
-                d[1] = make_float2(r[i].z, r[i].w);
+                d[0] = make_float2(r.x, r.y);
+                d[1] = make_float2(r.z, r.w);
             } else {
                 const int kk = v / (BN / 4), nq = v % (BN / 4);
-                *reinterpret_cast<float4*>(Bs + kk * LDB + 4 * nq) = r[i];
+                *reinterpret_cast<float4*>(Bs + kk * LDB + 4 * nq) = r;
             }
         }
     }
 
-    // acc[mi][ni] += A_tile * B_tile over the whole K range.  smem: TC::smem_floats<A_KC,B_KC>() floats.
-    __device__ static __forceinline__ void run(const OpA& a, const OpB& b, int K, float* smem,
-                                               f32x4 (&acc)[TC::MI][TC::NI]) {
-        float* As[2] = {smem, smem + ASZ};
-        float* Bs[2] = {smem + 2 * ASZ, smem + 2 * ASZ + BSZ};
+    template <int K0, int K1>
+    __device__ static __forceinline__ void compute(const float* Ac, const float* Bc, f32x4 (&acc)[TC::MI][TC::NI]) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave / TC::WN, wn = wave % TC::WN;
         const int l15 = lane & 15, lq = lane >> 4;
-        float4 ra[TC::AV], rb[TC::BV];
+        const float* Ab = A_KC ? Ac + (wm * TC::WTM + l15) * LDA + lq : Ac + lq * LDA + wm * TC::WTM + l15;
+        const float* Bb = B_KC ? Bc + (wn * TC::WTN + l15) * LDB + lq : Bc + lq * LDB + wn * TC::WTN + l15;
+#pragma unroll
+        for (int kk = K0; kk < K1; kk += 4) {
+            float af[TC::MI], bf[TC::NI];
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi) af[mi] = A_KC ? Ab[mi * 16 * LDA + kk] : Ab[kk * LDA + mi * 16];
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) bf[ni] = B_KC ? Bb[ni * 16 * LDB + kk] : Bb[kk * LDB + ni * 16];
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC::NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    // acc[mi][ni] += A_tile * B_tile over the whole K range.  Uses TC::smem_floats<A_KC,B_KC>() floats of dynamic LDS.
+    // The two LDS buffers are addressed with compile-time offsets from the __shared__ symbol itself (2x unrolled slab
+    // loop): runtime-selected buffer pointers degrade to flat_* accesses whose waits also drain the global prefetch.
+    __device__ static __forceinline__ void run(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI]) {
+        extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+        float* const A0 = cpg_smem;
+        float* const A1 = cpg_smem + ASZ;
+        float* const B0 = cpg_smem + 2 * ASZ;
+        float* const B1 = cpg_smem + 2 * ASZ + BSZ;
+        Stage st;
         const int KT = (K + BK - 1) / BK;
-        gload_a(a, 0, K, ra);
-        gload_b(b, 0, K, rb);
-        sstore_a(As[0], ra);
-        sstore_b(Bs[0], rb);
+        gload(a, b, 0, K, st);
+        sstore(a, b, A0, B0, st);
         __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < KT) {
-                gload_a(a, (kt + 1) * BK, K, ra);
-                gload_b(b, (kt + 1) * BK, K, rb);
-            }
-            const float* Ac = As[cur];
-            const float* Bc = Bs[cur];
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 4) {
-                float af[TC::MI], bf[TC::NI];
-#pragma unroll
-                for (int mi = 0; mi < TC::MI; ++mi) {
-                    const int x = wm * TC::WTM + mi * 16 + l15;
-                    af[mi] = A_KC ? Ac[x * LDA + kk + lq] : Ac[(kk + lq) * LDA + x];
-                }
-#pragma unroll
-                for (int ni = 0; ni < TC::NI; ++ni) {
-                    const int x = wn * TC::WTN + ni * 16 + l15;
-                    bf[ni] = B_KC ? Bc[x * LDB + kk + lq] : Bc[(kk + lq) * LDB + x];
-                }
-#pragma unroll
-                for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TC::NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-            }
-            if (kt + 1 < KT) {
-                sstore_a(As[cur ^ 1], ra);
-                sstore_b(Bs[cur ^ 1], rb);
-            }
+        // per slab: issue the next slab's global loads, run the first half of the MFMAs, write the (by now landed)
+        // registers into the idle LDS buffer, run the second half, one barrier.  The LDS writes and their wait sit
+        // behind queued MFMAs instead of in front of the barrier.
+        constexpr int KH = (BK / 8) * 4;
+        for (int kt = 0; kt < KT; kt += 2) {
+            const bool more1 = kt + 1 < KT;
+            if (more1) gload(a, b, (kt + 1) * BK, K, st);
+            compute<0, KH>(A0, B0, acc);
+            if (more1) sstore(a, b, A1, B1, st);
+            compute<KH, BK>(A0, B0, acc);
+            __syncthreads();
+            if (!more1) break;
+            const bool more2 = kt + 2 < KT;
+            if (more2) gload(a, b, (kt + 2) * BK, K, st);
+            compute<0, KH>(A1, B1, acc);
+            if (more2) sstore(a, b, A0, B0, st);
+            compute<KH, BK>(A1, B1, acc);
             __syncthreads();
         }
     }

@@ -15,6 +15,7 @@
 // So h_{prev}(t) is one contiguous [T*B,H] block in both directions (offset 0 / B*H) for the dW_hh product.
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include <stdlib.h>
 
 struct GruFwdArgs {
     const float* h_prev;
@@ -31,7 +32,6 @@ struct GruFwdArgs {
 
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = g.H, B = g.B;
     const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 3);
     OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, smem, acc);
+    MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
 
     static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,7 +104,6 @@ struct GruBwdArgs {
 
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = g.H, B = g.B;
     const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
     f32x4 acc[TC::MI][TC::NI];
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
     if (g.dG_next) {
         OpA a{g.dG_next, 4 * H, m0, B, nullptr, 1.f};
         OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
-        MainLoop<TC, true, false, VEC, VEC>::run(a, b, 3 * H, smem, acc);
+        MainLoop<TC, true, false, VEC, VEC>::run(a, b, 3 * H, acc);
     }
     const size_t BH = (size_t)B * H;
 #pragma unroll
@@ -177,15 +176,22 @@ static void launch_bwd(const GruBwdArgs& a, bool vec, hipStream_t s) {
 }
 
 // pick the row-tile height so that the launch has at least ~256 workgroups when the problem allows it
-static int pick_bm(int B, int ntile_n) {
-    if ((long)cdiv(B, 128) * ntile_n >= 256) return 128;
-    if ((long)cdiv(B, 64) * ntile_n >= 256 || B > 64) return B > 32 ? 64 : 32;
+// (CPG_GRU_FWD_BM / CPG_GRU_BWD_BM force 128|64|32: tuning knobs for tools/kbench.py)
+static int pick_bm(int B, int ntile_n, const char* knob) {
+    const char* e = getenv(knob);
+    if (e) {
+        const int v = atoi(e);
+        if (v == 128 || v == 64 || v == 32) return v;
+    }
+    // measured on MI355X (tools/kbench.py, B=2048 H=512): 64-row tiles (2 workgroups per CU) beat 128-row tiles by
+    // 20-25 % - the second resident workgroup covers the other's staging waits and epilogue traffic
+    if ((long)cdiv(B, 64) * ntile_n >= 256 || B > 32) return 64;
     return 32;
 }
 
 int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
-    const int bm = pick_bm(a.B, cdiv(a.H, 32));
+    const int bm = pick_bm(a.B, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
     if (bm == 128) launch_fwd<GF128>(a, vec, s);
     else if (bm == 64) launch_fwd<GF64>(a, vec, s);
     else launch_fwd<GF32>(a, vec, s);
@@ -195,7 +201,7 @@ int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
 
 static int gru_step_bwd_launch(const GruBwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
-    const int bm = pick_bm(a.B, cdiv(a.H, 32));
+    const int bm = pick_bm(a.B, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
     if (bm == 128) launch_bwd<GB128>(a, vec, s);
     else if (bm == 64) launch_bwd<GB64>(a, vec, s);
     else launch_bwd<GB32>(a, vec, s);

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the GRU step kernels and the weight-gradient product at a given (B, H, T) - for A/B tuning runs
+on the GPU box (within-process interleaved variants selected through CPG_* environment knobs read by the library)."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "controlled-peptide-generation_amd"))
+import torch  # noqa: E402
+from cpg import ops  # noqa: E402
+from cpg.ops import _p, _stream, call, query  # noqa: E402
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=2048)
+    ap.add_argument("--H", type=int, default=512)
+    ap.add_argument("--T", type=int, default=25)
+    ap.add_argument("--V", type=int, default=24)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--no-gates", action="store_true")
+    ap.add_argument("--knob", action="append", default=[], help="NAME=v1,v2,... environment knob values to sweep")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    B, H, T, V = a.B, a.H, a.T, a.V
+    g = torch.Generator(device="cpu").manual_seed(0)
+    w_hh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(dev)
+    b_hh = torch.randn(3 * H, generator=g).to(dev) * 0.1
+    tab = torch.randn(V, 3 * H, generator=g).to(dev) * 0.3
+    rowc = torch.randn(B, 3 * H, generator=g).to(dev) * 0.3
+    tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
+    hs = torch.zeros(T + 1, B, H, device=dev)
+    hs[0] = torch.randn(B, H, generator=g).to(dev)
+    gates = torch.empty(T, 4, B, H, device=dev)
+    dhs = torch.randn(T, B, H, generator=g).to(dev) * 0.1
+    dG = torch.empty(T, B, 4 * H, device=dev)
+    scr = torch.empty(2, B, H, device=dev)
+    dh0 = torch.empty(B, H, device=dev)
+    dw = torch.empty(3 * H, H, device=dev)
+    db = torch.empty(3 * H, device=dev)
+    nb = query("cpg_gru_wgrad_workspace", T, B, H, V)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+
+    def fwd():
+        call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), None if a.no_gates else _p(gates), _stream())
+
+    def bwd():
+        call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), _stream())
+
+    def wgrad():
+        call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), _stream())
+
+    sweeps = [("base", {})]
+    for k in a.knob:
+        name, vals = k.split("=")
+        for v in vals.split(","):
+            sweeps.append((f"{name}={v}", {name: v}))
+    fl_step = 2.0 * B * H * 3 * H
+    for rnd in range(2):
+        for label, env in sweeps:
+            for k, v in env.items():
+                os.environ[k] = v
+            f = timeit(fwd, a.iters) / T
+            b = timeit(bwd, a.iters) / (T + 1)
+            w = timeit(wgrad, a.iters)
+            for k in env:
+                os.environ.pop(k, None)
+            print(f"[{rnd}] {label:24s} fwd {f:7.1f} us/step ({fl_step / f / 1e6:6.1f} TF)  bwd {b:7.1f} us/step "
+                  f"({fl_step / b / 1e6:6.1f} TF)  wgrad {w:8.1f} us ({fl_step * T / w / 1e6:6.1f} TF)")
+
+
+if __name__ == "__main__":
+    main()
