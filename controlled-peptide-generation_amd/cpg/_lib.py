@@ -36,6 +36,7 @@ def parse_header(path=HEADER):
     """-> {name: (restype, [(argtype, argname), ...])} for every CPG_API declaration."""
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)  # preprocessor lines (incl. `#define CPG_API`)
     out = {}
     for m in re.finditer(r"CPG_API\s+([^;(]+?)\s*(\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)

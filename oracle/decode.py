@@ -106,24 +106,34 @@ class _Beam:
         return hyps, scores
 
 
-def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1):
-    """Returns (hyps, scores): hyps[i][j] = token list incl. leading START."""
+def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=False):
+    """Returns (hyps, scores): hyps[i][j] = token list incl. leading START.
+    return_history adds (tok, prev, score) arrays [steps,N,K] (tok=-1 where a sentence was not advanced): the record the
+    device beam kernel keeps, used to test the host-side hypothesis reconstruction."""
     N = z.shape[0]
     zc1 = np.concatenate([z, c], 1).astype(F32)
     zc = np.tile(zc1, (beam_size, 1))  # beam-major [beam*N] (model.py:262-263)
     h = zc.copy()
     beams = [_Beam(beam_size, n_best, min_length) for _ in range(N)]
     tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
+    hist = []
     for _ in range(max_len):
         logits, h = decoder_step(P, tok, zc, h)
         lg = logits.reshape(beam_size, N, -1)
         hv = h.reshape(beam_size, N, -1)
+        ht = np.full((N, beam_size), -1, np.int64)
+        hp = np.zeros((N, beam_size), np.int64)
+        hsc = np.zeros((N, beam_size), F32)
+        hist.append((ht, hp, hsc))
         for j, b in enumerate(beams):
             if not b.done():
                 b.advance(_log_softmax(lg[:, j]))
+                ht[j], hp[j], hsc[j] = b.next_ys[-1], b.prev_ks[-1], b.scores
             hv[:, j] = hv[b.prev_ks[-1], j]  # _update_hidden (model.py:387-404), applied even when done
         tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
         if all(b.done() for b in beams):
             break
     out = [b.best() for b in beams]
+    if return_history:
+        return [o[0] for o in out], [o[1] for o in out], tuple(np.stack([h[i] for h in hist]) for i in range(3))
     return [o[0] for o in out], [o[1] for o in out]

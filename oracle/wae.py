@@ -136,8 +136,10 @@ def decoder_bwd(P, dlogits, cache, G, E):
 
 
 # ----------------------------------------------------------------------------- losses
-def recon_dec(ids, logits):
-    """Mean NLL over non-PAD next-token targets of the whole batch.  Returns loss, dlogits."""
+def recon_dec(ids, logits, dp=None):
+    """Mean NLL over non-PAD next-token targets of the whole batch.  Returns loss, dlogits.
+    dp = (allreduce_sum, world): data-parallel form - the count is the GLOBAL count / world, so that the later
+    SUM-all-reduce / world of the gradients equals the single-device gradient."""
     B, T, V = logits.shape
     tgt = np.concatenate([ids[:, 1:], np.full((B, 1), PAD, ids.dtype)], 1).reshape(-1)
     lg = logits.reshape(B * T, V).astype(F32)
@@ -146,6 +148,8 @@ def recon_dec(ids, logits):
     logp = lg - lse
     valid = tgt != PAD
     cnt = max(int(valid.sum()), 1)
+    if dp is not None:
+        cnt = max(float(dp[0](np.array([float(valid.sum())]))[0]) / dp[1], 1.0)
     nll = -logp[np.arange(B * T), tgt]
     loss = F32(nll[valid].sum() / cnt)
     d = np.exp(logp)
@@ -201,20 +205,24 @@ def gaussian_rf(z, rf_w, rf_b, sigma):
     return (np.cos(pre) * F32((2.0 / R) ** 0.5)).astype(F32), pre
 
 
-def mmd_rf(z1, z2, rf_w, rf_b, sigma):
+def mmd_rf(z1, z2, rf_w, rf_b, sigma, dp=None):
     R = rf_w.shape[1]
     f1, pre1 = gaussian_rf(z1, rf_w, rf_b, sigma)
     f2, _ = gaussian_rf(z2, rf_w, rf_b, sigma)
-    diff = f1.mean(0) - f2.mean(0)
-    loss = F32((diff * diff).sum())
     B = z1.shape[0]
+    if dp is None:
+        diff = f1.mean(0) - f2.mean(0)
+    else:  # global feature means; every rank differentiates the global loss wrt its own rows (pre-scaled by world)
+        s1, s2 = dp[0](f1.sum(0).astype(np.float64)), dp[0](f2.sum(0).astype(np.float64))
+        diff = ((s1 - s2) / (B * dp[1])).astype(F32)
+    loss = F32((diff * diff).sum())
     dpre = (-np.sin(pre1) * F32((2.0 / R) ** 0.5)) * (2.0 * diff / B)[None, :]
     dz1 = (dpre @ rf_w.T) / F32(sigma)
     return loss, dz1.astype(F32)
 
 
 # ----------------------------------------------------------------------------- full training-loss evaluation
-def train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, z_regu, sigma=7.0, p_out=0.3):
+def train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, z_regu, sigma=7.0, p_out=0.3, dp=None):
     """One train_vae loss evaluation + backward (train_vae.py:26-40).
     rnd: dict with eps, c, wd_mask, out_mask, z_prior_full, z_prior_rf, rf_w, rf_b.
     Returns (terms dict, grads dict keyed like the state dict, aux dict with z/logits/mu/logvar)."""
@@ -224,10 +232,10 @@ def train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, z_regu, sigma=7.0, p
     z = (mu + std * rnd["eps"]).astype(F32)
     c = rnd["c"].astype(F32)
     logits, dc = decoder_fwd(P, ids, z, c, rnd["wd_mask"], rnd["out_mask"], p_out)
-    recon, dlogits = recon_dec(ids, logits)
+    recon, dlogits = recon_dec(ids, logits, dp)
     kl, dmu_kl, dlv_kl = kl_gaussianprior(mu, lv)
     mmd, dz_mmd = mmd_full_kernel(z, rnd["z_prior_full"], sigma)
-    mmdrf, dz_rf = mmd_rf(z, rnd["z_prior_rf"], rnd["rf_w"], rnd["rf_b"], sigma)
+    mmdrf, dz_rf = mmd_rf(z, rnd["z_prior_rf"], rnd["rf_w"], rnd["rf_b"], sigma, dp)
     l1, dlv_l1 = logvar_l1(lv)
     klmu, dlv_klmu = kl_gaussian_sharedmu(mu, lv)
     regu = {"kl": kl, "mmd": mmd, "mmdrf": mmdrf}[z_regu]

@@ -1,0 +1,54 @@
+"""The C-ABI shared library: it loads on a host without a GPU and exports exactly what include/cpg_api.h declares."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from cpg._lib import HEADER, LIB_PATH, parse_header, build_library
+
+
+@pytest.fixture(scope="module")
+def built():
+    build_library()
+    assert os.path.exists(LIB_PATH)
+    return LIB_PATH
+
+
+def test_header_parses():
+    sigs = parse_header(HEADER)
+    assert len(sigs) >= 40
+    ret, args = sigs["cpg_gru_seq_fwd"]
+    assert ret is ctypes.c_int and len(args) == 13
+    assert sigs["cpg_last_error"][0] is ctypes.c_char_p
+    assert sigs["cpg_mmd_full_workspace"][0] is ctypes.c_size_t
+
+
+def test_library_loads_and_exports_every_declared_symbol(built):
+    dll = ctypes.CDLL(built)
+    for name in parse_header(HEADER):
+        assert hasattr(dll, name), f"{name} declared in cpg_api.h but not exported"
+    dll.cpg_version.restype = ctypes.c_int
+    assert dll.cpg_version() >= 100
+
+
+def test_no_undeclared_exports(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    declared = set(parse_header(HEADER))
+    assert exported - declared == set(), f"exported but not declared in the header: {sorted(exported - declared)}"
+
+
+def test_workspace_queries_do_not_need_a_gpu(built):
+    from cpg import lib
+    L = lib()
+    assert L.dll.cpg_mmd_full_workspace(2048) >= 3 * 2048 * 2048 * 4
+    assert L.dll.cpg_gru_wgrad_workspace(25, 2048, 512, 24) > 0
+    assert L.dll.cpg_sumsq_workspace() > 0
+
+
+def test_bad_arguments_are_reported_not_crashed(built):
+    from cpg import lib
+    L = lib()
+    rc = L.dll.cpg_linear_fwd(None, 1, None, 1, None, None, 1, 0, 0, 0, 0, None)
+    assert rc == -2 and "bad argument" in L.last_error()
