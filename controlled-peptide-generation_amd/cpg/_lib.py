@@ -8,7 +8,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, "include", "cpg_api.h")
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libcpg_hip.so")
+LIB_PATH = os.environ.get("CPG_LIB_PATH", os.path.join(PKG_DIR, "libcpg_hip.so"))  # override: diagnostic builds only
 SOURCES = ["api.hip", "gemm.hip", "gru.hip", "decode.hip", "losses.hip", "optim.hip", "rng.hip", "class.hip"]
 
 

@@ -21,7 +21,7 @@ struct GemmArgs {
     size_t slab_stride; // floats between slabs (0 when not split)
 };
 
-template <class TC, bool A_KC, bool B_KC, bool VEC>
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int m0 = blockIdx.y * TC::BM, n0 = blockIdx.x * TC::BN;
     int kb = 0, K = g.K;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    MainLoop<TC, A_KC, B_KC, VEC, VEC>::run(a, b, K, acc);
+    MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS>::run(a, b, K, acc);
     float* C = g.C + (size_t)blockIdx.z * g.slab_stride;
     const bool plain = g.k_chunk == 0;
 #pragma unroll
@@ -101,10 +101,15 @@ template <class TC, bool A_KC, bool B_KC>
 static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.N, TC::BN), cdiv(g.M, TC::BM), zdim);
     const size_t smem = TC::template smem_floats<A_KC, B_KC>() * sizeof(float);
-    if (vec)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true>), grid, dim3(256), smem, s, g);
+    const bool masks = g.a_mask || g.b_mask;
+    if (vec && masks)
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true>), grid, dim3(256), smem, s, g);
+    else if (vec)
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false>), grid, dim3(256), smem, s, g);
+    else if (masks)
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, true>), grid, dim3(256), smem, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false>), grid, dim3(256), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, false>), grid, dim3(256), smem, s, g);
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -134,8 +139,31 @@ int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const 
     return launch_gemm<true, true>(g, 1, s);
 }
 
+// Y[m,n] (+)= sum_k X[m,k] B[k,n] for a handful of rows (M <= 32) and long K: one (64-column, row) block with 4 K-lanes
+// and a fixed-order LDS reduction.  The tile engine would put such a problem on 1-2 workgroups walking K serially.
+__global__ void skinny_nn_kernel(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int N, int K,
+                                 int accumulate) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + threadIdx.x, m = blockIdx.y, ty = threadIdx.y;
+    float s = 0.f;
+    if (n < N)
+        for (int k = ty; k < K; k += 4) s += X[(size_t)m * ldx + k] * Bm[(size_t)k * ldb + n];
+    red[ty][threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const size_t o = (size_t)m * ldy + n;
+        Y[o] = accumulate ? Y[o] + v : v;
+    }
+}
+
 int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K, int accumulate,
                 const uint8_t* cmask, float cms, hipStream_t s) {
+    if (M <= 32 && K >= 256 && !cmask) {
+        hipLaunchKernelGGL(skinny_nn_kernel, dim3(cdiv(N, 64), M), dim3(64, 4), 0, s, X, ldx, Bm, ldb, Y, ldy, N, K, accumulate);
+        CPG_LAUNCH_CHECK();
+        return 0;
+    }
     GemmArgs g{X, ldx, M, Bm, ldb, N, K, Y, ldy, nullptr, accumulate, nullptr, 1.f, nullptr, 1.f, cmask, cms, 0, 0};
     return launch_gemm<true, false>(g, 1, s);
 }
@@ -148,11 +176,12 @@ static void pick_split(int M, int N, int K, int& S, int& k_chunk) {
         S = cdiv(K, k_chunk);
         return;
     }
-    // enough workgroups to fill 256 CUs a couple of times over, chunks a multiple of the slab depth
-    const long tiles = (long)cdiv(M, 64) * cdiv(N, 64);
-    long want = (768 + tiles - 1) / tiles;
+    // Two 128x64 workgroups are resident per CU (57 KB LDS each): aim at ~3 full rounds of 512 workgroups so the
+    // last round is not half empty (measured at M=1536,N=512,K=51200: S=4 (384 WGs) 1356 us, S=16 (1536 WGs) 1084 us).
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, 64);
+    long want = (1536 + tiles - 1) / tiles;
     if (want < 1) want = 1;
-    long maxs = cdiv(K, 256);
+    long maxs = cdiv(K, 128);
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
     if (want > 64) want = 64;

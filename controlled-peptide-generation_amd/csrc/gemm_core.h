@@ -18,6 +18,13 @@
 #pragma once
 #include "cpg_common.h"
 
+// Diagnostic builds only (tools/ablate.sh): -DCPG_ABLATE=<mask> removes one phase of the slab loop after the first slab so its
+// cost can be measured in isolation.  1: no global loads / LDS writes   2: no LDS fragment reads   4: no barrier.
+// Results of such builds are wrong by construction; the shipped library is built without the macro.
+#ifndef CPG_ABLATE
+#define CPG_ABLATE 0
+#endif
+
 struct OpA {
     const float* p;
     int ld;
@@ -118,7 +125,7 @@ __device__ __forceinline__ float4 finish4(float4 v, unsigned okbits, bool has_ma
     return v;
 }
 
-template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC>
+template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC, bool MASKS = false>
 struct MainLoop {
     static constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK;
     static constexpr int LDA = TC::template lda<A_KC>();
@@ -151,7 +158,7 @@ struct MainLoop {
                 off = (size_t)gk * a.ld + gm;
             }
             st.a[i] = load4<AVEC>(a.p, off, nvalid, st.aok[i]);
-            if (a.mask) st.am[i] = loadmask4<AVEC>(a.mask, off, st.aok[i]);
+            if (MASKS && a.mask) st.am[i] = loadmask4<AVEC>(a.mask, off, st.aok[i]);
         }
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
@@ -172,7 +179,7 @@ struct MainLoop {
                 off = (size_t)gk * b.ld + idx;
             }
             st.b[i] = load4<BVEC>(b.p, off, nvalid, st.bok[i]);
-            if (b.mask) st.bm[i] = loadmask4<BVEC>(b.mask, off, st.bok[i]);
+            if (MASKS && b.mask) st.bm[i] = loadmask4<BVEC>(b.mask, off, st.bok[i]);
         }
     }
 
@@ -181,7 +188,7 @@ struct MainLoop {
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) {
             const int v = tid + i * TC::NT;
-            const float4 r = finish4(st.a[i], st.aok[i], a.mask != nullptr, st.am[i], a.mscale);
+            const float4 r = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
             if (A_KC) {
                 const int row = v / (BK / 4), kq = v % (BK / 4);
                 float2* d = reinterpret_cast<float2*>(As + row * LDA + 4 * kq);
@@ -195,7 +202,7 @@ struct MainLoop {
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
             const int v = tid + i * TC::NT;
-            const float4 r = finish4(st.b[i], st.bok[i], b.mask != nullptr, st.bm[i], b.mscale);
+            const float4 r = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
             if (B_KC) {
                 const int nl = v / (BK / 4), kq = v % (BK / 4);
                 float2* d = reinterpret_cast<float2*>(Bs + nl * LDB + 4 * kq);
@@ -208,26 +215,70 @@ struct MainLoop {
         }
     }
 
-    template <int K0, int K1>
-    __device__ static __forceinline__ void compute(const float* Ac, const float* Bc, f32x4 (&acc)[TC::MI][TC::NI]) {
+    static constexpr int KH = (BK / 8) * 4;      // k-steps are split in two halves per slab
+    static constexpr int NS0 = KH / 4, NS1 = (BK - KH) / 4;
+
+    template <int NS>
+    struct Frag {  // fragments of NS consecutive k-steps
+        float a[NS][TC::MI], b[NS][TC::NI];
+    };
+
+    template <int NS>
+    __device__ static __forceinline__ void read_frags(const float* Ab, const float* Bb, int k0, Frag<NS>& f) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int kk = k0 + 4 * s;
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi) f.a[s][mi] = A_KC ? Ab[mi * 16 * LDA + kk] : Ab[kk * LDA + mi * 16];
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) f.b[s][ni] = B_KC ? Bb[ni * 16 * LDB + kk] : Bb[kk * LDB + ni * 16];
+        }
+    }
+
+    template <int NS>
+    __device__ static __forceinline__ void mfmas(const Frag<NS>& f, f32x4 (&acc)[TC::MI][TC::NI]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC::NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s][mi], f.b[s][ni], acc[mi][ni], 0, 0, 0);
+    }
+
+    // One slab: [reads half0] [reads half1] | MFMAs half0 | LDS writes of the next slab | MFMAs half1.
+    // The sched_barriers pin that order: left alone, hipcc sinks every ds_read next to its first use and reuses the
+    // same two VGPRs (read -> lgkmcnt(0) -> 4 MFMAs -> read ...), exposing the LDS latency 8 times per slab
+    // (measured: 40-45 % MFMA utilisation in steady state).  With both halves' fragments in flight the counted
+    // lgkmcnt waits fall behind >= 16 queued MFMAs.
+    template <bool STORE>
+    __device__ static __forceinline__ void slab(const OpA& a, const OpB& b, const float* Ac, const float* Bc, float* An,
+                                                float* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave / TC::WN, wn = wave % TC::WN;
         const int l15 = lane & 15, lq = lane >> 4;
         const float* Ab = A_KC ? Ac + (wm * TC::WTM + l15) * LDA + lq : Ac + lq * LDA + wm * TC::WTM + l15;
         const float* Bb = B_KC ? Bc + (wn * TC::WTN + l15) * LDB + lq : Bc + lq * LDB + wn * TC::WTN + l15;
+        Frag<NS0> f0;
+        Frag<NS1> f1;
+        if (CPG_ABLATE & 2) {  // keep the registers live and opaque, but do not touch the LDS
 #pragma unroll
-        for (int kk = K0; kk < K1; kk += 4) {
-            float af[TC::MI], bf[TC::NI];
+            for (int s = 0; s < NS0; ++s) {
 #pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi) af[mi] = A_KC ? Ab[mi * 16 * LDA + kk] : Ab[kk * LDA + mi * 16];
+                for (int mi = 0; mi < TC::MI; ++mi) { f0.a[s][mi] = acc[mi][0][0]; f1.a[s][mi] = acc[mi][0][1]; }
 #pragma unroll
-            for (int ni = 0; ni < TC::NI; ++ni) bf[ni] = B_KC ? Bb[ni * 16 * LDB + kk] : Bb[kk * LDB + ni * 16];
-#pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC::NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                for (int ni = 0; ni < TC::NI; ++ni) { f0.b[s][ni] = acc[0][ni][2]; f1.b[s][ni] = acc[0][ni][3]; }
+            }
+        } else {
+            read_frags<NS0>(Ab, Bb, 0, f0);
+            read_frags<NS1>(Ab, Bb, KH, f1);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas<NS0>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas<NS1>(f1, acc);
     }
 
     // acc[mi][ni] += A_tile * B_tile over the whole K range.  Uses TC::smem_floats<A_KC,B_KC>() floats of dynamic LDS.
@@ -244,24 +295,22 @@ struct MainLoop {
         gload(a, b, 0, K, st);
         sstore(a, b, A0, B0, st);
         __syncthreads();
-        // per slab: issue the next slab's global loads, run the first half of the MFMAs, write the (by now landed)
-        // registers into the idle LDS buffer, run the second half, one barrier.  The LDS writes and their wait sit
-        // behind queued MFMAs instead of in front of the barrier.
-        constexpr int KH = (BK / 8) * 4;
         for (int kt = 0; kt < KT; kt += 2) {
-            const bool more1 = kt + 1 < KT;
-            if (more1) gload(a, b, (kt + 1) * BK, K, st);
-            compute<0, KH>(A0, B0, acc);
-            if (more1) sstore(a, b, A1, B1, st);
-            compute<KH, BK>(A0, B0, acc);
-            __syncthreads();
-            if (!more1) break;
-            const bool more2 = kt + 2 < KT;
-            if (more2) gload(a, b, (kt + 2) * BK, K, st);
-            compute<0, KH>(A1, B1, acc);
-            if (more2) sstore(a, b, A0, B0, st);
-            compute<KH, BK>(A1, B1, acc);
-            __syncthreads();
+            if (kt + 1 < KT) {
+                if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 1) * BK, K, st);
+                slab<true>(a, b, A0, B0, A1, B1, st, acc);
+            } else {
+                slab<false>(a, b, A0, B0, A1, B1, st, acc);
+            }
+            if (!(CPG_ABLATE & 4)) __syncthreads();
+            if (kt + 1 >= KT) break;
+            if (kt + 2 < KT) {
+                if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 2) * BK, K, st);
+                slab<true>(a, b, A1, B1, A0, B0, st, acc);
+            } else {
+                slab<false>(a, b, A1, B1, A0, B0, st, acc);
+            }
+            if (!(CPG_ABLATE & 4)) __syncthreads();
         }
     }
 };

@@ -34,6 +34,44 @@ template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
     const int H = g.H, B = g.B;
     const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 3);
+    static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
+    constexpr int NJ = TC::NI / 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave % TC::WN;
+
+    // Epilogue operands (input-side pre-activations gathered from the token table / row constant / dense term, and
+    // h_prev) do not depend on the matrix product: fetch them FIRST so their two dependent global-load latencies
+    // (tok -> table row) run under the MFMA loop instead of after it.
+    float gi[NJ][TC::MI][4][3], hp[NJ][TC::MI][4];
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+        const int j = j0 + (wn * NJ + jb) * 16 + (lane & 15);
+        const bool jok = j < H;
+        const int jc = jok ? j : 0;
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                const int rc = (row < B) ? row : 0;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                if (g.tok) {
+                    const float* t = g.tab + (size_t)g.tok[rc] * 3 * H;
+                    a0 += t[jc]; a1 += t[H + jc]; a2 += t[2 * H + jc];
+                }
+                if (g.rowc) {
+                    const float* t = g.rowc + (size_t)rc * 3 * H;
+                    a0 += t[jc]; a1 += t[H + jc]; a2 += t[2 * H + jc];
+                }
+                if (g.dense) {
+                    const float* t = g.dense + (size_t)rc * 3 * H;
+                    a0 += t[jc]; a1 += t[H + jc]; a2 += t[2 * H + jc];
+                }
+                gi[jb][mi][r][0] = a0; gi[jb][mi][r][1] = a1; gi[jb][mi][r][2] = a2;
+                hp[jb][mi][r] = g.h_prev[(size_t)rc * H + jc];
+            }
+    }
+
     OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
     OpB b{g.w_hh, H, j0, H, H, nullptr, 1.f};
     f32x4 acc[TC::MI][TC::NI];
@@ -43,13 +81,10 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
 
-    static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wn = wave % TC::WN;
     const size_t BH = (size_t)B * H;
 #pragma unroll
-    for (int jb = 0; jb < TC::NI / 3; ++jb) {
-        const int j = j0 + (wn * (TC::NI / 3) + jb) * 16 + (lane & 15);
+    for (int jb = 0; jb < NJ; ++jb) {
+        const int j = j0 + (wn * NJ + jb) * 16 + (lane & 15);
         if (j >= H) continue;
         const float bh_r = g.b_hh[j], bh_z = g.b_hh[H + j], bh_n = g.b_hh[2 * H + j];
 #pragma unroll
@@ -58,31 +93,17 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 if (row >= B) continue;
-                float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
-                if (g.tok) {
-                    const float* t = g.tab + (size_t)g.tok[row] * 3 * H;
-                    gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
-                }
-                if (g.rowc) {
-                    const float* t = g.rowc + (size_t)row * 3 * H;
-                    gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
-                }
-                if (g.dense) {
-                    const float* t = g.dense + (size_t)row * 3 * H;
-                    gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
-                }
                 const float hn = acc[mi][jb * 3 + 2][r] + bh_n;
-                const float rg = sigmoidf_(gi_r + (acc[mi][jb * 3 + 0][r] + bh_r));
-                const float zg = sigmoidf_(gi_z + (acc[mi][jb * 3 + 1][r] + bh_z));
-                const float ng = tanhf(gi_n + rg * hn);
+                const float rg = sigmoidf_(gi[jb][mi][r][0] + (acc[mi][jb * 3 + 0][r] + bh_r));
+                const float zg = sigmoidf_(gi[jb][mi][r][1] + (acc[mi][jb * 3 + 1][r] + bh_z));
+                const float ng = tanhf(gi[jb][mi][r][2] + rg * hn);
                 const size_t o = (size_t)row * H + j;
-                const float hp = g.h_prev[o];
-                g.h_out[o] = (1.f - zg) * ng + zg * hp;
-                if (g.gates) {
-                    g.gates[o] = rg;
-                    g.gates[BH + o] = zg;
-                    g.gates[2 * BH + o] = ng;
-                    g.gates[3 * BH + o] = hn;
+                g.h_out[o] = (1.f - zg) * ng + zg * hp[jb][mi][r];
+                if (g.gates) {  // written once, read once by the backward pass much later: keep them out of the L2
+                    __builtin_nontemporal_store(rg, g.gates + o);
+                    __builtin_nontemporal_store(zg, g.gates + BH + o);
+                    __builtin_nontemporal_store(ng, g.gates + 2 * BH + o);
+                    __builtin_nontemporal_store(hn, g.gates + 3 * BH + o);
                 }
             }
     }
@@ -106,6 +127,33 @@ template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
     const int H = g.H, B = g.B;
     const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
+    const size_t BH = (size_t)B * H;
+    // epilogue operands first (see the forward kernel): saved gates, h_prev and the non-GEMM part of dH
+    float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][5];
+#pragma unroll
+    for (int ni = 0; ni < TC::NI; ++ni) {
+        const int j = j0 + acc_col<TC>(ni);
+        const int jc = (j < H) ? j : 0;
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                const size_t o = (size_t)((row < B) ? row : 0) * H + jc;
+                float p = 0.f;
+                if (g.dH_next) p += g.z_next[o] * g.dH_next[o];
+                if (g.ext) p += g.ext[o];
+                if (g.ext2) p += g.ext2[o];
+                pre[ni][mi][r] = p;
+                if (g.gates) {
+                    sv[ni][mi][r][0] = g.gates[o];
+                    sv[ni][mi][r][1] = g.gates[BH + o];
+                    sv[ni][mi][r][2] = g.gates[2 * BH + o];
+                    sv[ni][mi][r][3] = g.gates[3 * BH + o];
+                    sv[ni][mi][r][4] = g.h_prev[o];
+                }
+            }
+    }
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -116,7 +164,6 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
         OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
         MainLoop<TC, true, false, VEC, VEC>::run(a, b, 3 * H, acc);
     }
-    const size_t BH = (size_t)B * H;
 #pragma unroll
     for (int ni = 0; ni < TC::NI; ++ni) {
         const int j = j0 + acc_col<TC>(ni);
@@ -128,14 +175,11 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 if (row >= B) continue;
                 const size_t o = (size_t)row * H + j;
-                float dh = acc[mi][ni][r];
-                if (g.dH_next) dh += g.z_next[o] * g.dH_next[o];
-                if (g.ext) dh += g.ext[o];
-                if (g.ext2) dh += g.ext2[o];
+                const float dh = acc[mi][ni][r] + pre[ni][mi][r];
                 g.dH_out[o] = dh;
                 if (!g.gates) continue;
-                const float rg = g.gates[o], zg = g.gates[BH + o], ng = g.gates[2 * BH + o], hn = g.gates[3 * BH + o];
-                const float hp = g.h_prev[o];
+                const float rg = sv[ni][mi][r][0], zg = sv[ni][mi][r][1], ng = sv[ni][mi][r][2], hn = sv[ni][mi][r][3];
+                const float hp = sv[ni][mi][r][4];
                 const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
                 const float dz_pre = dh * (hp - ng) * zg * (1.f - zg);
                 const float dr_pre = dn_pre * hn * rg * (1.f - rg);

@@ -61,8 +61,10 @@ def main():
     def bwd():
         call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), _stream())
 
+    big_ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)  # large enough for any split the knobs select
+
     def wgrad():
-        call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), _stream())
+        call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(big_ws), big_ws.numel(), _stream())
 
     sweeps = [("base", {})]
     for k in a.knob:
