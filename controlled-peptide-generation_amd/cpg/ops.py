@@ -55,6 +55,71 @@ def workspace(nbytes, device, tag=0):
     return buf
 
 
+_side = {}
+import os as _os
+OVERLAP = _os.environ.get('CPG_NO_OVERLAP', '') == ''  # run independent launch chains (encoder directions, deferred weight gradients) on side streams
+
+
+def side_streams(device, n=3):
+    """Per-device pool of side HIP streams (created once)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _side:
+        _side[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _side[key]
+
+
+def _alloc_guard(*tensors):
+    """Tensors allocated while a side stream is current but consumed on the main stream: tell the caching allocator."""
+    cur = torch.cuda.current_stream()
+    main = torch.cuda.default_stream()
+    if cur != main:
+        for t in tensors:
+            if t is not None:
+                t.record_stream(main)
+
+
+def row_groups(B):
+    """Split the batch rows of one recurrent sequence into independent launch chains (one per side stream).  Rows are
+    independent recurrences, so the chains need no synchronisation with each other; running them on separate streams lets
+    one group's matrix phase overlap another group's load/epilogue phases instead of the whole batch moving in lockstep."""
+    g = int(_os.environ.get("CPG_ROW_GROUPS", "0"))
+    if g <= 0:
+        g = 1  # measured on MI355X at B=2048,H=512: 2 groups 13.78 ms/step vs 13.62 with one chain (no gain) -> off
+    g = max(1, min(g, 2, B // 64 if B >= 64 else 1))
+    step = -(-B // g)
+    step = -(-step // 64) * 64
+    return [(r, min(B, r + step)) for r in range(0, B, step)]
+
+
+class fork:
+    """`with fork(device) as f: f.run(i, fn)` runs fn on side stream i after everything already queued on the current
+    stream; leaving the block makes the current stream wait for all branches."""
+
+    def __init__(self, device):
+        self.device = device
+        self.done = []
+
+    def __enter__(self):
+        self.main = torch.cuda.current_stream()
+        self.ev = self.main.record_event()
+        return self
+
+    def run(self, i, fn):
+        if not OVERLAP:
+            return fn()
+        s = side_streams(self.device)[i]
+        s.wait_event(self.ev)
+        with torch.cuda.stream(s):
+            out = fn()
+        self.done.append(s.record_event())
+        return out
+
+    def __exit__(self, *exc):
+        for e in self.done:
+            self.main.wait_event(e)
+        return False
+
+
 def _rowmajor(t):
     """(tensor, ld) for a 2-D tensor whose last dim is contiguous (row stride may exceed the width)."""
     assert t.dim() == 2
@@ -201,8 +266,13 @@ class GruSeqFn(Function):
     models/decoder.py:40-41,77).  Returns the state slab [(T+1),B,H] (layout in include/cpg_api.h)."""
 
     @staticmethod
-    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse):
+    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse, defer=False):
         dev = w_hh.device
+        # deferred mode: the 80-GFLOP dW_hh product of this sequence runs on a side stream and is added straight into the
+        # parameters' existing .grad buffers, overlapping with the rest of the backward pass (only with FusedAdamClip,
+        # which joins before it reads the gradients)
+        ctx.defer = (w_hh, b_hh) if (defer and DEFER_WGRAD and OVERLAP and w_hh.grad is not None and b_hh.grad is not None
+                                     and w_hh.is_leaf and b_hh.is_leaf) else None
         H = w_hh.shape[1]
         B = tok.shape[1] if tok is not None else (rowc.shape[0] if rowc is not None else dense.shape[1])
         w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
@@ -217,12 +287,21 @@ class GruSeqFn(Function):
             hs[slot0].copy_(h0)
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, w_hh, b_hh))
         gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        _alloc_guard(hs, gates)
         ev = None
         if PROFILE is not None:  # bench.py: HIP events on the launch stream around the T fused step launches
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
-             _p(hs), _p(gates), _stream())
+        groups = row_groups(B)
+        if len(groups) == 1:
+            call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
+                 _p(hs), _p(gates), 0, B, _stream())
+        else:
+            with fork(dev) as f:
+                for gi, (r0, r1) in enumerate(groups):
+                    f.run(gi, lambda r0=r0, r1=r1: call(
+                        "cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
+                        _p(dense_c), _p(hs), _p(gates), r0, r1, _stream()))
         if ev is not None:
             ev[1].record()
             PROFILE.append(("gru_step_fwd", ev[0], ev[1], T, B, H))
@@ -246,15 +325,38 @@ class GruSeqFn(Function):
         dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
-        call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG), _p(scratch),
-             _p(dh0), _stream())
+        groups = row_groups(B)
+        if len(groups) == 1:
+            call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG), _p(scratch),
+                 _p(dh0), 0, B, _stream())
+        else:
+            with fork(dev) as f:
+                for gi, (r0, r1) in enumerate(groups):
+                    f.run(gi, lambda r0=r0, r1=r1: call(
+                        "cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
+                        _p(scratch), _p(dh0), r0, r1, _stream()))
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
         db_hh = torch.empty(3 * H, device=dev, dtype=torch.float32)
-        call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), _p(db_hh), 0, _p(ws), ws.numel(), _stream())
+        if ctx.defer is not None:
+            side = side_streams(dev)[2]
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ws2 = workspace(nb, dev)
+                call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), _p(db_hh), 0, _p(ws2), ws2.numel(),
+                     _stream())
+                ctx.defer[0].grad.add_(dw_hh)
+                ctx.defer[1].grad.add_(db_hh)
+                _pending_events.append(side.record_event())
+            for t in (dG, hs, dw_hh, db_hh):
+                t.record_stream(side)
+            dw_hh = db_hh = None
+        else:
+            call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), _p(db_hh), 0, _p(ws), ws.numel(),
+                 _stream())
         dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32) if has_tab else None
         drowc = torch.empty(B, 3 * H, device=dev, dtype=torch.float32) if has_rowc else None
         if has_tab or has_rowc:
@@ -263,7 +365,18 @@ class GruSeqFn(Function):
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
             ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2)
-        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None
+        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None
+
+
+_pending_events = []
+DEFER_WGRAD = False  # set by FusedAdamClip: w_hh/b_hh gradients of flagged sequences are accumulated on a side stream
+
+
+def join_deferred():
+    """Make the current stream wait for every deferred weight-gradient accumulation (called by the optimiser)."""
+    cur = torch.cuda.current_stream()
+    while _pending_events:
+        cur.wait_event(_pending_events.pop())
 
 
 def gru_step(tok, tab, rowc, h_prev, h_out, w_hh, b_hh):

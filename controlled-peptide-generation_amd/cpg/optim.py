@@ -52,8 +52,10 @@ class FusedAdamClip:
         self.steps = [0] * len(self.order)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.ws = torch.empty(ops.query("cpg_sumsq_workspace") // 4, device=dev, dtype=torch.float32)
+        ops.DEFER_WGRAD = True  # this optimiser joins the deferred weight-gradient stream before touching gradients
 
     def zero_grad(self):
+        ops.join_deferred()
         self.flat_g.zero_()
 
     def grad_norm(self):
@@ -61,6 +63,7 @@ class FusedAdamClip:
         return torch.sqrt(self.sumsq[0]) / self.world
 
     def step(self):
+        ops.join_deferred()
         for p, (off, k) in zip(self.order, self.segs):  # autograd may have replaced .grad if it was None'd by the user
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + off * 4:
                 if p.grad is not None:

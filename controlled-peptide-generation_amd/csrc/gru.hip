@@ -28,12 +28,14 @@ struct GruFwdArgs {
     float* h_out;        // [B,H]
     float* gates;        // [4,B,H] of this step (r,z,n,hn), or null
     int B, H;
+    int row0, row1;      // this launch covers batch rows [row0,row1): rows are independent recurrences, so row groups
+                         // can run as separate launch chains on separate streams, out of phase with each other
 };
 
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
-    const int H = g.H, B = g.B;
-    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 3);
+    const int H = g.H, B = g.row1;  // row bound of this launch
+    const int m0 = g.row0 + blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 3);
     static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
     constexpr int NJ = TC::NI / 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
 
-    const size_t BH = (size_t)B * H;
+    const size_t BH = (size_t)g.B * H;
 #pragma unroll
     for (int jb = 0; jb < NJ; ++jb) {
         const int j = j0 + (wn * NJ + jb) * 16 + (lane & 15);
@@ -121,13 +123,14 @@ struct GruBwdArgs {
     float* dH_out;         // [B,H] total gradient of h_s (closing launch: dh0)
     float* dG_out;         // [B,4H]
     int B, H;
+    int row0, row1;
 };
 
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
-    const int H = g.H, B = g.B;
-    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
-    const size_t BH = (size_t)B * H;
+    const int H = g.H, B = g.row1;  // row bound of this launch
+    const int m0 = g.row0 + blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
+    const size_t BH = (size_t)g.B * H;
     // epilogue operands first (see the forward kernel): saved gates, h_prev and the non-GEMM part of dH
     float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][5];
 #pragma unroll
@@ -201,7 +204,7 @@ using GB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 
 template <class TC>
 static void launch_fwd(const GruFwdArgs& a, bool vec, hipStream_t s) {
-    dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.B, TC::BM));
+    dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.row1 - a.row0, TC::BM));
     const size_t smem = TC::template smem_floats<true, true>() * sizeof(float);
     if (vec)
         hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true>), grid, dim3(256), smem, s, a);
@@ -211,7 +214,7 @@ static void launch_fwd(const GruFwdArgs& a, bool vec, hipStream_t s) {
 
 template <class TC>
 static void launch_bwd(const GruBwdArgs& a, bool vec, hipStream_t s) {
-    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.B, TC::BM));
+    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM));
     const size_t smem = TC::template smem_floats<true, false>() * sizeof(float);
     if (vec)
         hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, a);
@@ -235,7 +238,7 @@ static int pick_bm(int B, int ntile_n, const char* knob) {
 
 int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
-    const int bm = pick_bm(a.B, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
+    const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
     if (bm == 128) launch_fwd<GF128>(a, vec, s);
     else if (bm == 64) launch_fwd<GF64>(a, vec, s);
     else launch_fwd<GF32>(a, vec, s);
@@ -245,7 +248,7 @@ int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
 
 static int gru_step_bwd_launch(const GruBwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
-    const int bm = pick_bm(a.B, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
+    const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
     if (bm == 128) launch_bwd<GB128>(a, vec, s);
     else if (bm == 64) launch_bwd<GB64>(a, vec, s);
     else launch_bwd<GB32>(a, vec, s);
@@ -304,8 +307,8 @@ __global__ void dgi_over_time_kernel(const float* dG, int T, int B, int H, float
 // ------------------------------------------------------------------------------------------ C ABI
 CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                                const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                               void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs);
+                               int row_begin, int row_end, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && 0 <= row_begin && row_begin < row_end && row_end <= B);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     const size_t BH = (size_t)B * H;
     for (int p = 0; p < T; ++p) {
@@ -322,6 +325,8 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
         a.gates = gates ? gates + (size_t)t * 4 * BH : nullptr;
         a.B = B;
         a.H = H;
+        a.row0 = row_begin;
+        a.row1 = row_end;
         int rc = cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -332,7 +337,7 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
 CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                                 const float* rowc, const float* h_prev, float* h_out, void* stream) {
     CPG_CHECK_ARG(B > 0 && H > 0 && w_hh && b_hh && h_prev && h_out && h_prev != h_out);
-    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, B, H};
+    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, B, H, 0, B};
     return cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
 }
 
@@ -340,8 +345,9 @@ CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_
 // dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
 CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                               void* stream) {
+                               int row_begin, int row_end, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
+    CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
     int prev_t = -1;
     for (int p = T - 1; p >= -1; --p) {  // p = processing index of the step whose dH we form; p=-1 closes with dh0
@@ -350,6 +356,8 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         GruBwdArgs a;
         a.B = B;
         a.H = H;
+        a.row0 = row_begin;
+        a.row1 = row_end;
         a.w_hh = w_hh;
         const int cur = (p + 2) & 1;
         if (prev_t >= 0) {

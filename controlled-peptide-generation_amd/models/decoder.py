@@ -82,7 +82,7 @@ class GRUDecoder(nn.Module):
             wd_mask = self.word_dropout.sample_mask(x)
         tok = ops.tokens_prepare(x, wd_mask)
         tab, rowc = self._tables(zc)
-        slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)
+        slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True)
         hs = slab[1:].reshape(T * B, self.h_dim)
         keep, scale = None, 1.0
         if out_keep is not None:

@@ -39,11 +39,11 @@ class GRUEncoder(nn.Module):
     def _run(self, T, tok=None, emb_weight=None, dense_x=None):
         """Either (tok int32 [T,B], emb_weight) - token-table path - or dense_x [T,B,E] embeddings."""
         slabs = None
+        dev = self.q_mu.weight.device
         for l in range(self.layers):
-            new = []
+            pre = []
             for sfx, rev in self._dirs():
-                w_ih, w_hh = self._w("weight_ih", l, sfx), self._w("weight_hh", l, sfx)
-                b_ih, b_hh = self._w("bias_ih", l, sfx), self._w("bias_hh", l, sfx)
+                w_ih, b_ih = self._w("weight_ih", l, sfx), self._w("bias_ih", l, sfx)
                 tab = dense = None
                 if l == 0 and tok is not None:
                     tab = ops.LinearFn.apply(emb_weight, w_ih, b_ih)  # [V,3H]: W_ih emb[v] + b_ih for every token
@@ -58,6 +58,11 @@ class GRUEncoder(nn.Module):
                         dense = ops.Linear2Fn.apply(xf, xb, w_ih, b_ih).view(T, B, -1)
                     else:
                         dense = ops.LinearFn.apply(xf, w_ih, b_ih).view(T, B, -1)
+                pre.append((tab, dense))
+            new = []
+            for d, (sfx, rev) in enumerate(self._dirs()):
+                tab, dense = pre[d]
+                w_hh, b_hh = self._w("weight_hh", l, sfx), self._w("bias_hh", l, sfx)
                 new.append(ops.GruSeqFn.apply(tok if l == 0 else None, tab, None, dense, None, w_hh, b_hh, T, rev))
             slabs = new
         # final states of the top layer: forward slab slot T, reverse slab slot 0 (reference: cat(h[-2], h[-1]))

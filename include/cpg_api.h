@@ -67,10 +67,13 @@ CPG_API int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, flo
  *     dense[t,b,:]       arbitrary per-step term (upper encoder layers)    ([T,B,3H])
  * State slab hs [(T+1),B,H]: forward direction hs[0]=h0 (caller fills), h_t -> hs[t+1];
  *                            reverse direction hs[T]=h0 (caller fills), h_t -> hs[t].
- * gates [T,4,B,H] receives r,z,n and (W_hn h + b_hn) per step for the backward pass (null for inference). */
+ * gates [T,4,B,H] receives r,z,n and (W_hn h + b_hn) per step for the backward pass (null for inference).
+ * Batch rows are independent recurrences: a call covers rows [row_begin,row_end) of the B-row problem (0,B for all),
+ * so a caller may run row groups as separate launch chains on separate streams (their MFMA and memory phases then
+ * overlap instead of running in lockstep). */
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                            void* stream);
+                            int row_begin, int row_end, void* stream);
 /* one decode step = GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) */
 CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                              const float* rowc, const float* h_prev, float* h_out, void* stream);
@@ -80,7 +83,7 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
  * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip). */
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                            void* stream);
+                            int row_begin, int row_end, void* stream);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
