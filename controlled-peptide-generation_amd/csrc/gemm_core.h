@@ -24,6 +24,9 @@
 #ifndef CPG_ABLATE
 #define CPG_ABLATE 0
 #endif
+#ifndef CPG_LOOP_UNROLL2
+#define CPG_LOOP_UNROLL2 1
+#endif
 
 struct OpA {
     const float* p;
@@ -295,6 +298,7 @@ struct MainLoop {
         gload(a, b, 0, K, st);
         sstore(a, b, A0, B0, st);
         __syncthreads();
+#if CPG_LOOP_UNROLL2
         for (int kt = 0; kt < KT; kt += 2) {
             if (kt + 1 < KT) {
                 if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 1) * BK, K, st);
@@ -312,6 +316,24 @@ struct MainLoop {
             }
             if (!(CPG_ABLATE & 4)) __syncthreads();
         }
+#else
+        // single loop body; the buffer toggle is integer arithmetic on offsets from the __shared__ symbol (keeps the
+        // accesses ds_*), and avoids the accumulator copies hipcc inserts between the two halves of an unrolled pair
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            const float* Ac = cpg_smem + cur * ASZ;
+            const float* Bc = cpg_smem + 2 * ASZ + cur * BSZ;
+            float* An = cpg_smem + (cur ^ 1) * ASZ;
+            float* Bn = cpg_smem + 2 * ASZ + (cur ^ 1) * BSZ;
+            if (kt + 1 < KT) {
+                if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 1) * BK, K, st);
+                slab<true>(a, b, Ac, Bc, An, Bn, st, acc);
+            } else {
+                slab<false>(a, b, Ac, Bc, An, Bn, st, acc);
+            }
+            if (!(CPG_ABLATE & 4)) __syncthreads();
+        }
+#endif
     }
 };
 
