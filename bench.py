@@ -26,21 +26,21 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X f32-input MFMA = f32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150):
+def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, cell='gru'):
     return dict(
         z_dim=z_dim, c_dim=2, emb_dim=emb_dim, pretrained_emb=None, freeze_embeddings=False, flow=0, flow_type='',
-        E_args=dict(h_dim=enc_h, biGRU=True, layers=enc_layers, p_dropout=0.0),
-        G_args=dict(G_class='gru', GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False),
+        E_args=dict(h_dim=enc_h, biGRU=True, layers=enc_layers, p_dropout=0.0, cell=cell),
+        G_args=dict(G_class='gru', GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False, cell=cell),
                     deconv_args=dict()),
         C_args=dict(min_filter_width=3, max_filter_width=5, num_filters=100, dropout=0.5))
 
 
-def train_flops_per_seq(T, E, He, Z, V, R, B):
+def train_flops_per_seq(T, E, He, Z, V, R, B, gates=3):
     """Executed FLOPs (2*MAC) of one training step per sequence on this implementation (token-table form), for the
     whole-step rate quoted in `extra`; the algorithmic count with the dense W_ih product is SURVEY 8d's."""
     Hd = Z + 2
-    rec = 2 * T * 2 * 3 * He * He + T * 2 * 3 * Hd * Hd            # recurrent products, fwd
-    small = 2 * 3 * Hd * Hd + 2 * 2 * 2 * He * Z + T * 2 * Hd * V + 2 * 2 * Z * R
+    rec = 2 * T * 2 * gates * He * He + T * 2 * gates * Hd * Hd    # recurrent products, fwd
+    small = 2 * gates * Hd * Hd + 2 * 2 * 2 * He * Z + T * 2 * Hd * V + 2 * 2 * Z * R
     fwd = rec + small
     return fwd + 2 * rec + 2 * small + 3 * 2 * B * Z                  # bwd: dh product + dW product (+ Gram MMD)
 
@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048, help="sequences per GPU per step")
     ap.add_argument("--hidden", type=int, default=512, help="encoder h_dim and decoder hidden (z_dim = hidden-2)")
     ap.add_argument("--seq-len", type=int, default=25)
+    ap.add_argument("--cell", default="gru", choices=["gru", "lstm"], help="gru = the reference's cell (parity pinned); lstm = extension")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=256)
@@ -111,7 +112,7 @@ def main():
     T, V, B, Hh = args.seq_len, 24, args.batch, args.hidden
     Z, E, R = Hh - 2, 150, 500
     torch.manual_seed(1238)
-    model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh)).to(dev)
+    model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh, cell=args.cell)).to(dev)
     model.device = dev
     losses.rf.clear()
     losses._rf_basis(torch.zeros(1, Z, device=dev), R, False)          # same basis on every rank (same seed)
@@ -156,17 +157,20 @@ def main():
     seq_per_s = B * world * args.steps / dt
 
     # dominant kernel: the fused GRU forward step (one launch per time step; decoder sequence = H 512, B rows)
-    recs = [r for r in prof if r[0] == "gru_step_fwd" and r[5] == Hh]
+    gates = 3 if args.cell == "gru" else 4
+    recs = [r for r in prof if r[0] == args.cell + "_step_fwd" and r[5] == Hh]
     tot_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
     launches = sum(r[3] for r in recs)
     avg_us = tot_ms * 1e3 / max(launches, 1)
-    flops_launch = 2.0 * B * Hh * 3 * Hh
+    flops_launch = 2.0 * B * Hh * gates * Hh
     achieved = flops_launch / (avg_us * 1e-6) / 1e12 if launches else 0.0
-    roofline = {"bound": "mfma", "kernel": "gru_step_fwd_kernel<TileCfg<128,96,32,2,2,3>>", "achieved": round(achieved, 2),
+    kname = ("gru_step_fwd_kernel<TileCfg<64,96,32,2,2,3>,true>" if args.cell == "gru"
+             else "lstm_step_fwd_kernel<TileCfg<64,128,32,2,2,4>,true>")
+    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                 "traffic": None, "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
                 "flops_per_launch": flops_launch}
-    step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B) * B / (ms * 1e-3) / 1e12
+    step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
     extra = {"loss_last_step": round(loss_val, 4), "executed_step_tflops_per_gpu": round(step_tflops, 2),
              "executed_step_frac_of_f32_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)}
 
@@ -175,8 +179,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"WAE train step (BASELINE.json configs[1]): biGRU encoder h={Hh} 1 layer, z={Z}, GRU decoder "
-                               f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; GRU cell (the reference has no LSTM), "
-                               f"f32 storage + f32 MFMA",
+                               f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; "
+                               + ("GRU cell = the reference's cell, parity pinned (the reference has no LSTM; --cell lstm runs "
+                                  "the LSTM extension)" if args.cell == "gru" else
+                                  "LSTM cell (extension, torch.nn.LSTM semantics; parity unpinned against the GRU-only reference)")
+                               + ", f32 storage + f32 MFMA",
                    "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
         "roofline": roofline, "extra": extra,
     }

@@ -185,10 +185,10 @@ max_seq_len = 25
 
 model = _bunchify(dict(
     z_dim=100, c_dim=2, emb_dim=150, pretrained_emb=None, freeze_embeddings=False, flow=0, flow_type='',
-    E_args=dict(h_dim=80, biGRU=True, layers=1, p_dropout=0.0),
+    E_args=dict(h_dim=80, biGRU=True, layers=1, p_dropout=0.0, cell='gru'),   # cell: 'gru' (reference) | 'lstm' (extension)
     G_args=dict(
         G_class='gru',
-        GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False),
+        GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False, cell='gru'),
         deconv_args=dict(max_seq_len=max_seq_len, num_filters=100, kernel_size=4, num_deconv_layers=3, useRNN=False,
                          temperature=1.0, use_batch_norm=True, num_conv_layers=2, add_final_conv_layer=True),
     ),

@@ -30,6 +30,9 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
     V = decoder.fc[1].weight.shape[0]
     h_a, h_b = zc.clone(), torch.empty_like(zc)
+    lstm = getattr(decoder, "cell", "gru") == "lstm"
+    if lstm:
+        c_a, c_b = torch.zeros_like(zc), torch.empty_like(zc)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
     finished = torch.zeros(N, device=dev, dtype=torch.uint8)
     ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
@@ -38,7 +41,11 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     logits = torch.empty(N, V, device=dev, dtype=torch.float32)
     scratch = torch.empty(264, device=dev, dtype=torch.float32)
     for i in range(max_len):
-        ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
+        if lstm:
+            ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
+            c_a, c_b = c_b, c_a
+        else:
+            ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
         _fc(decoder, h_b, logits)
         pe = 1 if (prevent_empty and i == 0) else 0
         if mode == "greedy":
@@ -71,6 +78,8 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
 def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
     """Runs the device beam search; returns numpy (tok, prev, score) each [T,N,K] (tok = -1 where a sentence had
     already finished) for host-side hypothesis reconstruction."""
+    if getattr(decoder, "cell", "gru") != "gru":
+        raise NotImplementedError("beam search is implemented for the GRU decoder (the reference's cell)")
     N = z.shape[0]
     K = beam_size
     dev = z.device

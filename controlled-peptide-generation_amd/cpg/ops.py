@@ -386,6 +386,80 @@ def gru_step(tok, tab, rowc, h_prev, h_out, w_hh, b_hh):
     return h_out
 
 
+class LstmSeqFn(Function):
+    """One direction of one LSTM layer (torch.nn.LSTM semantics; not a reference component - SURVEY F2).
+    Returns the hidden-state slab [(T+1),B,H]; the cell slab stays internal."""
+
+    @staticmethod
+    def forward(ctx, tok, tab, rowc, dense, h0, c0, w_hh, b_hh, T, reverse):
+        dev = w_hh.device
+        H = w_hh.shape[1]
+        B = tok.shape[1] if tok is not None else (rowc.shape[0] if rowc is not None else dense.shape[1])
+        w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
+        tab_c = tab.contiguous() if tab is not None else None
+        rowc_c = rowc.contiguous() if rowc is not None else None
+        dense_c = dense.contiguous() if dense is not None else None
+        hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        cs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        slot0 = T if reverse else 0
+        hs[slot0].zero_() if h0 is None else hs[slot0].copy_(h0)
+        cs[slot0].zero_() if c0 is None else cs[slot0].copy_(c0)
+        need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, c0, w_hh, b_hh))
+        gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        ev = None
+        if PROFILE is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        call("cpg_lstm_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
+             _p(hs), _p(cs), _p(gates), _stream())
+        if ev is not None:
+            ev[1].record()
+            PROFILE.append(("lstm_step_fwd", ev[0], ev[1], T, B, H))
+        ctx.save_for_backward(tok, w_hh_c, hs, cs, gates)
+        ctx.dims = (T, B, H, bool(reverse))
+        ctx.V = tab.shape[0] if tab is not None else 0
+        ctx.has = (tab is not None, rowc is not None, dense is not None, h0 is not None, c0 is not None)
+        return hs
+
+    @staticmethod
+    def backward(ctx, ghs):
+        tok, w_hh, hs, cs, gates = ctx.saved_tensors
+        T, B, H, reverse = ctx.dims
+        dev = ghs.device
+        ghs = ghs.contiguous()
+        BH = B * H
+        flat = ghs.view(-1)
+        dhs_ext = flat[BH:] if not reverse else flat[:T * BH]
+        has_tab, has_rowc, has_dense, has_h0, has_c0 = ctx.has
+        dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
+        need0 = has_h0 or has_c0
+        dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
+        dc0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
+        call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
+             _p(dh0), _p(dc0), _stream())
+        if has_h0:
+            dh0 = dh0 + (ghs[T] if reverse else ghs[0])
+        nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
+        ws = workspace(nb, dev)
+        dw_hh = torch.empty(4 * H, H, device=dev, dtype=torch.float32)
+        db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
+        call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), _p(db_hh), 0, _p(ws), ws.numel(), _stream())
+        dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32) if has_tab else None
+        drowc = torch.empty(B, 4 * H, device=dev, dtype=torch.float32) if has_rowc else None
+        if has_tab or has_rowc:
+            call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(drowc), 0, _p(ws), ws.numel(), _stream())
+        return (None, dtab, drowc, dG if has_dense else None, dh0 if has_h0 else None, dc0 if has_c0 else None, dw_hh, db_hh,
+                None, None)
+
+
+def lstm_step(tok, tab, rowc, h_prev, c_prev, h_out, c_out, w_hh, b_hh):
+    B, H = h_prev.shape
+    call("cpg_lstm_step_fwd", B, H, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(h_prev), _p(c_prev), _p(h_out),
+         _p(c_out), _stream())
+    return h_out, c_out
+
+
 # ----------------------------------------------------------------------------------------------- vocab projection
 class VocabFcFn(Function):
     """nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab) (models/decoder.py:43-45,83): logits = (hs .* keep/(1-p)) W^T + b."""

@@ -258,30 +258,31 @@ static int gru_step_bwd_launch(const GruBwdArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------ reductions over dG
 // dgi column c in [0,3H) lives at dG column c (c < 2H) or 3H + (c - 2H).
-__device__ __forceinline__ int dgi_col(int c, int H) { return c < 2 * H ? c : c + H; }
+__device__ __forceinline__ int dgi_col(int c, int H, int lstm) { return (lstm || c < 2 * H) ? c : c + H; }
 
 // part[chunk][v][c] = sum over rows (t,b) of the chunk with tok == v of dgi[row][c].   block: 64 columns x RL row lanes.
 __global__ void dgi_by_token_kernel(const float* dG, const int32_t* tok, int rows, int H, int V, int rows_per_chunk,
-                                    float* part) {
+                                    float* part, int lstm) {
+    const int NC = lstm ? 4 * H : 3 * H;
     extern __shared__ float accs[];  // [RL][V][64]
     const int RL = blockDim.y;
     const int c = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
     float* mine = accs + (size_t)ty * V * 64;
     for (int v = 0; v < V; ++v) mine[v * 64 + threadIdx.x] = 0.f;
     const int rb = blockIdx.y * rows_per_chunk, re = min(rows, rb + rows_per_chunk);
-    if (c < 3 * H) {
-        const int gc = dgi_col(c, H);
+    if (c < NC) {
+        const int gc = dgi_col(c, H, lstm);
         for (int row = rb + ty; row < re; row += RL) {
             const int v = tok[row];
             mine[v * 64 + threadIdx.x] += dG[(size_t)row * 4 * H + gc];
         }
     }
     __syncthreads();
-    if (c < 3 * H)
+    if (c < NC)
         for (int v = ty; v < V; v += RL) {
             float s = 0.f;
             for (int q = 0; q < RL; ++q) s += accs[((size_t)q * V + v) * 64 + threadIdx.x];
-            part[((size_t)blockIdx.y * V + v) * 3 * H + c] = s;
+            part[((size_t)blockIdx.y * V + v) * NC + c] = s;
         }
 }
 
@@ -294,11 +295,12 @@ __global__ void chunk_reduce_kernel(const float* part, int chunks, size_t n, flo
 }
 
 // drowc[b][c] (+)= sum_t dgi[t][b][c]
-__global__ void dgi_over_time_kernel(const float* dG, int T, int B, int H, float* out, int accumulate) {
+__global__ void dgi_over_time_kernel(const float* dG, int T, int B, int H, float* out, int accumulate, int lstm) {
+    const int NC = lstm ? 4 * H : 3 * H;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * 3 * H) return;
-    const int b = i / (3 * H), c = i % (3 * H);
-    const int gc = dgi_col(c, H);
+    if (i >= (size_t)B * NC) return;
+    const int b = i / NC, c = i % NC;
+    const int gc = dgi_col(c, H, lstm);
     float s = 0.f;
     for (int t = 0; t < T; ++t) s += dG[((size_t)t * B + b) * 4 * H + gc];
     out[i] = accumulate ? out[i] + s : s;
@@ -391,11 +393,11 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
 }
 
 CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
-    size_t a = cpg_gemm_tn_workspace(T * B, 3 * H, H);
-    size_t b = cpg_colsum_workspace(T * B, 3 * H);
+    size_t a = cpg_gemm_tn_workspace(T * B, 4 * H, H);
+    size_t b = cpg_colsum_workspace(T * B, 4 * H);
     int chunks = cdiv(T * B, 512);
     if (chunks > 256) chunks = 256;
-    size_t c = (size_t)chunks * (V > 0 ? V : 1) * 3 * H * sizeof(float);
+    size_t c = (size_t)chunks * (V > 0 ? V : 1) * 4 * H * sizeof(float);  // sized for the 4-gate (LSTM) case too
     size_t m = a > b ? a : b;
     return (m > c ? m : c) + 256;
 }
@@ -414,9 +416,10 @@ CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* d
 // Input-side reductions of dgi = [dr_pre, dz_pre, dn_pre]:
 //   dtab[V,3H]  (+)= sum over (t,b) with tok[t,b]==v     (gradient of the token table; null to skip)
 //   drowc[B,3H] (+)= sum over t                          (gradient of the constant-over-time term; null to skip)
-CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
-                                  float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* drowc,
+                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG);
+    const int NC = lstm ? 4 * H : 3 * H;
     hipStream_t s = (hipStream_t)stream;
     if (dtab) {
         CPG_CHECK_ARG(tok && V > 0 && workspace);
@@ -425,7 +428,7 @@ CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const in
         if (chunks > 256) chunks = 256;
         const int rpc = cdiv(rows, chunks);
         chunks = cdiv(rows, rpc);
-        const size_t n = (size_t)V * 3 * H;
+        const size_t n = (size_t)V * NC;
         if (workspace_bytes < n * chunks * sizeof(float)) {
             cpg_set_error("cpg_gru_dgi_reduce: workspace too small");
             return -3;
@@ -437,18 +440,23 @@ CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const in
             cpg_set_error("cpg_gru_dgi_reduce: vocabulary of %d rows does not fit the LDS accumulators", V);
             return -4;
         }
-        hipLaunchKernelGGL(dgi_by_token_kernel, dim3(cdiv(3 * H, 64), chunks), dim3(64, RL), smem, s, dG, tok, rows, H, V, rpc,
-                           (float*)workspace);
+        hipLaunchKernelGGL(dgi_by_token_kernel, dim3(cdiv(NC, 64), chunks), dim3(64, RL), smem, s, dG, tok, rows, H, V, rpc,
+                           (float*)workspace, lstm);
         CPG_LAUNCH_CHECK();
         hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
                            chunks, n, dtab, accumulate);
         CPG_LAUNCH_CHECK();
     }
     if (drowc) {
-        const size_t n = (size_t)B * 3 * H;
+        const size_t n = (size_t)B * NC;
         hipLaunchKernelGGL(dgi_over_time_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dG, T, B, H, drowc,
-                           accumulate);
+                           accumulate, lstm);
         CPG_LAUNCH_CHECK();
     }
     return 0;
+}
+
+CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+                                  float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, drowc, accumulate, workspace, workspace_bytes, stream);
 }

@@ -1,0 +1,310 @@
+// LSTM sequence forward / backward for gfx950 - same structure as gru.hip (one fused launch per time step, the
+// [B,T,4H] input pre-activation rebuilt per element from token table + row constant + dense term).
+//
+// NOT a reference component: IBM/controlled-peptide-generation has no LSTM.  BASELINE.json's configs name an
+// LSTM cell, so the build offers one; its semantics are torch.nn.LSTM's (gate row order i,f,g,o;
+// c' = f*c + i*g ; h' = o*tanh(c')) and it is pinned to torch.nn.LSTM only (oracle/lstm.py, tests/test_lstm.py).
+//
+// State slabs hs, cs [(T+1),B,H] (layout as in gru.hip).  gates [T,4,B,H] = i,f,g,o.  dG [T,B,4H] = pre-activation
+// gradients (identical for the input side and the hidden side).
+#include "gemm_core.h"
+#include "cpg_internal.h"
+
+struct LstmFwdArgs {
+    const float* h_prev;
+    const float* c_prev;
+    const float* w_hh;   // [4H,H]
+    const float* b_hh;   // [4H]
+    const int32_t* tok;
+    const float* tab;    // [V,4H]
+    const float* rowc;   // [B,4H]
+    const float* dense;  // [B,4H]
+    float* h_out;
+    float* c_out;
+    float* gates;        // [4,B,H] or null
+    int B, H;
+};
+
+template <class TC, bool VEC>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs g) {
+    const int H = g.H, B = g.B;
+    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 4);
+    static_assert(TC::NI % 4 == 0, "wave tile holds i,f,g,o blocks");
+    constexpr int NJ = TC::NI / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave % TC::WN;
+    float gi[NJ][TC::MI][4][4], cp[NJ][TC::MI][4];
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+        const int j = j0 + (wn * NJ + jb) * 16 + (lane & 15);
+        const int jc = (j < H) ? j : 0;
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                const int rc = (row < B) ? row : 0;
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                if (g.tok) {
+                    const float* t = g.tab + (size_t)g.tok[rc] * 4 * H;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] += t[q * H + jc];
+                }
+                if (g.rowc) {
+                    const float* t = g.rowc + (size_t)rc * 4 * H;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] += t[q * H + jc];
+                }
+                if (g.dense) {
+                    const float* t = g.dense + (size_t)rc * 4 * H;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] += t[q * H + jc];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gi[jb][mi][r][q] = a[q];
+                cp[jb][mi][r] = g.c_prev[(size_t)rc * H + jc];
+            }
+    }
+    OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
+    OpB b{g.w_hh, H, j0, H, H, nullptr, 1.f};
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
+    const size_t BH = (size_t)B * H;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+        const int j = j0 + (wn * NJ + jb) * 16 + (lane & 15);
+        if (j >= H) continue;
+        const float b_i = g.b_hh[j], b_f = g.b_hh[H + j], b_g = g.b_hh[2 * H + j], b_o = g.b_hh[3 * H + j];
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                if (row >= B) continue;
+                const float ig = sigmoidf_(gi[jb][mi][r][0] + (acc[mi][jb * 4 + 0][r] + b_i));
+                const float fg = sigmoidf_(gi[jb][mi][r][1] + (acc[mi][jb * 4 + 1][r] + b_f));
+                const float gg = tanhf(gi[jb][mi][r][2] + (acc[mi][jb * 4 + 2][r] + b_g));
+                const float og = sigmoidf_(gi[jb][mi][r][3] + (acc[mi][jb * 4 + 3][r] + b_o));
+                const float cn = fg * cp[jb][mi][r] + ig * gg;
+                const size_t o = (size_t)row * H + j;
+                g.c_out[o] = cn;
+                g.h_out[o] = og * tanhf(cn);
+                if (g.gates) {
+                    __builtin_nontemporal_store(ig, g.gates + o);
+                    __builtin_nontemporal_store(fg, g.gates + BH + o);
+                    __builtin_nontemporal_store(gg, g.gates + 2 * BH + o);
+                    __builtin_nontemporal_store(og, g.gates + 3 * BH + o);
+                }
+            }
+    }
+}
+
+struct LstmBwdArgs {
+    const float* dG_next;  // [B,4H] of the step processed just before (s+1), null on the first launch
+    const float* w_hh;     // [4H,H]
+    const float* dC_next;  // [B,H] carried cell gradient dc_{s+1} * f_{s+1}, null on the first launch
+    const float* ext;      // [B,H] external gradient on h_s
+    const float* gates;    // [4,B,H] of step s; null on the closing launch (emits dh0 / dc0)
+    const float* c_prev;   // [B,H] c_{s-1}
+    const float* c_cur;    // [B,H] c_s
+    float* dH_out;         // closing launch: dh0
+    float* dC_out;         // [B,H] dc_s * f_s   (closing launch: dc0 = dC_next passthrough)
+    float* dG_out;         // [B,4H]
+    int B, H;
+};
+
+template <class TC, bool VEC>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
+    const int H = g.H, B = g.B;
+    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
+    const size_t BH = (size_t)B * H;
+    float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][7];
+#pragma unroll
+    for (int ni = 0; ni < TC::NI; ++ni) {
+        const int j = j0 + acc_col<TC>(ni);
+        const int jc = (j < H) ? j : 0;
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                const size_t o = (size_t)((row < B) ? row : 0) * H + jc;
+                pre[ni][mi][r] = g.ext ? g.ext[o] : 0.f;
+                sv[ni][mi][r][6] = g.dC_next ? g.dC_next[o] : 0.f;
+                if (g.gates) {
+                    sv[ni][mi][r][0] = g.gates[o];
+                    sv[ni][mi][r][1] = g.gates[BH + o];
+                    sv[ni][mi][r][2] = g.gates[2 * BH + o];
+                    sv[ni][mi][r][3] = g.gates[3 * BH + o];
+                    sv[ni][mi][r][4] = g.c_prev[o];
+                    sv[ni][mi][r][5] = g.c_cur[o];
+                }
+            }
+    }
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.dG_next) {
+        OpA a{g.dG_next, 4 * H, m0, B, nullptr, 1.f};
+        OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
+        MainLoop<TC, true, false, VEC, VEC>::run(a, b, 4 * H, acc);
+    }
+#pragma unroll
+    for (int ni = 0; ni < TC::NI; ++ni) {
+        const int j = j0 + acc_col<TC>(ni);
+        if (j >= H) continue;
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                if (row >= B) continue;
+                const size_t o = (size_t)row * H + j;
+                const float dh = acc[mi][ni][r] + pre[ni][mi][r];
+                const float dcn = sv[ni][mi][r][6];
+                if (!g.gates) {
+                    g.dH_out[o] = dh;
+                    g.dC_out[o] = dcn;
+                    continue;
+                }
+                const float ig = sv[ni][mi][r][0], fg = sv[ni][mi][r][1], gg = sv[ni][mi][r][2], og = sv[ni][mi][r][3];
+                const float cpv = sv[ni][mi][r][4], tc = tanhf(sv[ni][mi][r][5]);
+                const float dc = dcn + dh * og * (1.f - tc * tc);
+                g.dC_out[o] = dc * fg;
+                float* d = g.dG_out + (size_t)row * 4 * H;
+                d[j] = dc * gg * ig * (1.f - ig);
+                d[H + j] = dc * cpv * fg * (1.f - fg);
+                d[2 * H + j] = dc * ig * (1.f - gg * gg);
+                d[3 * H + j] = dh * tc * og * (1.f - og);
+            }
+    }
+}
+
+using LF64 = TileCfg<64, 128, 32, 2, 2, 4>;
+using LF32 = TileCfg<32, 128, 32, 2, 2, 4>;
+using LB64 = TileCfg<64, 32, 32, 4, 1, 1>;
+using LB32 = TileCfg<32, 64, 32, 2, 2, 1>;
+
+static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
+    const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
+    if (a.B > 32) {
+        dim3 grid(cdiv(a.H, LF64::BN / 4), cdiv(a.B, LF64::BM));
+        const size_t smem = LF64::smem_floats<true, true>() * sizeof(float);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, true>), grid, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, false>), grid, dim3(256), smem, s, a);
+    } else {
+        dim3 grid(cdiv(a.H, LF32::BN / 4), cdiv(a.B, LF32::BM));
+        const size_t smem = LF32::smem_floats<true, true>() * sizeof(float);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF32, true>), grid, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF32, false>), grid, dim3(256), smem, s, a);
+    }
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
+    const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
+    if (a.B > 32) {
+        dim3 grid(cdiv(a.H, LB64::BN), cdiv(a.B, LB64::BM));
+        const size_t smem = LB64::smem_floats<true, false>() * sizeof(float);
+        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, true>), grid, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, false>), grid, dim3(256), smem, s, a);
+    } else {
+        dim3 grid(cdiv(a.H, LB32::BN), cdiv(a.B, LB32::BM));
+        const size_t smem = LB32::smem_floats<true, false>() * sizeof(float);
+        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32, true>), grid, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32, false>), grid, dim3(256), smem, s, a);
+    }
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// hs, cs: state slabs [(T+1),B,H] with h0 / c0 in slot 0 (forward) or T (reverse); gates [T,4,B,H] or null.
+CPG_EXPORT int cpg_lstm_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
+                                const float* tab, const float* rowc, const float* dense, float* hs, float* cs, float* gates,
+                                void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && cs);
+    CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
+    const size_t BH = (size_t)B * H;
+    for (int p = 0; p < T; ++p) {
+        const int t = reverse ? T - 1 - p : p;
+        const size_t ip = reverse ? (size_t)(t + 1) * BH : (size_t)t * BH;
+        const size_t io = reverse ? (size_t)t * BH : (size_t)(t + 1) * BH;
+        LstmFwdArgs a{hs + ip, cs + ip, w_hh, b_hh, tok ? tok + (size_t)t * B : nullptr, tab, rowc,
+                      dense ? dense + (size_t)t * B * 4 * H : nullptr, hs + io, cs + io,
+                      gates ? gates + (size_t)t * 4 * BH : nullptr, B, H};
+        int rc = lstm_fwd_launch(a, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+CPG_EXPORT int cpg_lstm_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
+                                 const float* rowc, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
+                                 void* stream) {
+    CPG_CHECK_ARG(B > 0 && H > 0 && w_hh && b_hh && h_prev && c_prev && h_out && c_out && h_prev != h_out && c_prev != c_out);
+    LstmFwdArgs a{h_prev, c_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, c_out, nullptr, B, H};
+    return lstm_fwd_launch(a, (hipStream_t)stream);
+}
+
+// dhs_ext [T,B,H] (time-aligned, may be null); dG out [T,B,4H]; scratch [2,B,H] (carried cell gradient);
+// dh0, dc0 [B,H] (both or neither).
+CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
+                                const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && cs && gates && dG && scratch && ((dh0 == nullptr) == (dc0 == nullptr)));
+    const size_t BH = (size_t)B * H;
+    int prev_t = -1;
+    for (int p = T - 1; p >= -1; --p) {
+        if (p < 0 && !dh0) break;
+        const int t = p < 0 ? -1 : (reverse ? T - 1 - p : p);
+        const int cur = (p + 2) & 1;
+        LstmBwdArgs a;
+        a.B = B;
+        a.H = H;
+        a.w_hh = w_hh;
+        a.dG_next = prev_t >= 0 ? dG + (size_t)prev_t * B * 4 * H : nullptr;
+        a.dC_next = prev_t >= 0 ? scratch + (size_t)(cur ^ 1) * BH : nullptr;
+        if (p >= 0) {
+            a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
+            a.gates = gates + (size_t)t * 4 * BH;
+            a.c_prev = reverse ? cs + (size_t)(t + 1) * BH : cs + (size_t)t * BH;
+            a.c_cur = reverse ? cs + (size_t)t * BH : cs + (size_t)(t + 1) * BH;
+            a.dH_out = nullptr;
+            a.dC_out = scratch + (size_t)cur * BH;
+            a.dG_out = dG + (size_t)t * B * 4 * H;
+        } else {
+            a.ext = nullptr;
+            a.gates = nullptr;
+            a.c_prev = a.c_cur = nullptr;
+            a.dH_out = dh0;
+            a.dC_out = dc0;
+            a.dG_out = nullptr;
+        }
+        int rc = lstm_bwd_launch(a, (hipStream_t)stream);
+        if (rc) return rc;
+        prev_t = t;
+    }
+    return 0;
+}
+
+// dw_hh[4H,H] (+)= sum_t dG_t^T h_prev(t) ; db_hh[4H] (+)= sum dG.   workspace: cpg_gru_wgrad_workspace(T,B,H,V)
+CPG_EXPORT int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
+                                 float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && db_hh && workspace);
+    const float* hprev = reverse ? hs + (size_t)B * H : hs;
+    int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 4 * H, H, accumulate, (float*)workspace,
+                         workspace_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    return cpg_colsum(dG, 4 * H, T * B, 4 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+CPG_EXPORT int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+                                   float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    return cpg_dgi_reduce_impl(T, B, H, 1, dG, tok, V, dtab, drowc, accumulate, workspace, workspace_bytes, stream);
+}

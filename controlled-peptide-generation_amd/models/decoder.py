@@ -48,10 +48,13 @@ class WordDropout(nn.Module):
 
 
 class GRUDecoder(nn.Module):
-    def __init__(self, embedding, emb_dim, output_dim, h_dim, p_word_dropout, p_out_dropout, skip_connetions):
+    def __init__(self, embedding, emb_dim, output_dim, h_dim, p_word_dropout, p_out_dropout, skip_connetions, cell='gru'):
         super().__init__()
         self.emb = embedding
-        self.rnn = nn.GRU(emb_dim, h_dim, batch_first=True)
+        # cell='lstm': extension with torch.nn.LSTM semantics, h0 = [z;c], c0 = 0 (the reference is GRU-only)
+        assert cell in ('gru', 'lstm')
+        self.cell = cell
+        self.rnn = (nn.GRU if cell == 'gru' else nn.LSTM)(emb_dim, h_dim, batch_first=True)
         self.fc = nn.Sequential(nn.Dropout(p_out_dropout), nn.Linear(h_dim, output_dim))
         self.word_dropout = WordDropout(p_word_dropout)
         self.p_out = p_out_dropout
@@ -82,7 +85,10 @@ class GRUDecoder(nn.Module):
             wd_mask = self.word_dropout.sample_mask(x)
         tok = ops.tokens_prepare(x, wd_mask)
         tab, rowc = self._tables(zc)
-        slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True)
+        if self.cell == 'gru':
+            slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True)
+        else:
+            slab = ops.LstmSeqFn.apply(tok, tab, rowc, None, zc, None, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)
         hs = slab[1:].reshape(T * B, self.h_dim)
         keep, scale = None, 1.0
         if out_keep is not None:
@@ -106,6 +112,8 @@ class GRUDecoder(nn.Module):
         """One decode step (reference signature, decoder.py:86-109): h is [1,N,H]; returns logits [N,V], h [1,N,H]."""
         if sampleSoft is not None:
             raise NotImplementedError('soft sampling modes are a "next" row (SURVEY 8f rank 4)')
+        if self.cell != 'gru':
+            raise NotImplementedError('forward_sample keeps the reference signature (h only); LSTM decoding goes through cpg.decode')
         zc = self.init_hidden(z, c)
         with torch.no_grad():
             tab, rowc = self._tables(zc)

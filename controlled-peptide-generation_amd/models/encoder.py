@@ -18,10 +18,14 @@ def build_encoder(enc_type, **E_args):
 
 
 class GRUEncoder(nn.Module):
-    def __init__(self, emb_dim, h_dim, z_dim, biGRU, layers, p_dropout):
+    def __init__(self, emb_dim, h_dim, z_dim, biGRU, layers, p_dropout, cell='gru'):
         super().__init__()
-        self.rnn = nn.GRU(input_size=emb_dim, hidden_size=h_dim, num_layers=layers, dropout=p_dropout,
-                          bidirectional=biGRU, batch_first=True)
+        # cell='lstm' is an extension with torch.nn.LSTM semantics (the reference is GRU-only)
+        assert cell in ('gru', 'lstm')
+        self.cell = cell
+        rnn_cls = nn.GRU if cell == 'gru' else nn.LSTM
+        self.rnn = rnn_cls(input_size=emb_dim, hidden_size=h_dim, num_layers=layers, dropout=p_dropout,
+                           bidirectional=biGRU, batch_first=True)
         self.biGRU = biGRU
         self.biGRU_factor = 2 if biGRU else 1
         self.h_dim, self.layers, self.p_dropout = h_dim, layers, p_dropout
@@ -63,7 +67,10 @@ class GRUEncoder(nn.Module):
             for d, (sfx, rev) in enumerate(self._dirs()):
                 tab, dense = pre[d]
                 w_hh, b_hh = self._w("weight_hh", l, sfx), self._w("bias_hh", l, sfx)
-                new.append(ops.GruSeqFn.apply(tok if l == 0 else None, tab, None, dense, None, w_hh, b_hh, T, rev))
+                if self.cell == 'gru':
+                    new.append(ops.GruSeqFn.apply(tok if l == 0 else None, tab, None, dense, None, w_hh, b_hh, T, rev))
+                else:
+                    new.append(ops.LstmSeqFn.apply(tok if l == 0 else None, tab, None, dense, None, None, w_hh, b_hh, T, rev))
             slabs = new
         # final states of the top layer: forward slab slot T, reverse slab slot 0 (reference: cat(h[-2], h[-1]))
         finals = [slabs[0][T]] + ([slabs[1][0]] if self.biGRU else [])

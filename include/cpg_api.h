@@ -92,6 +92,22 @@ CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, 
 CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
                                float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- LSTM (NOT in the reference, which is GRU-only - SURVEY F2; semantics = torch.nn.LSTM, gate row order i,f,g,o) --------
+ * Same conventions as the GRU entry points; cs is the cell-state slab [(T+1),B,H] (c0 in slot 0 / T), gates [T,4,B,H] =
+ * i,f,g,o, dG [T,B,4H] = pre-activation gradients (identical for the input and the hidden side). */
+CPG_API int cpg_lstm_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
+                             const float* tab, const float* rowc, const float* dense, float* hs, float* cs, float* gates,
+                             void* stream);
+CPG_API int cpg_lstm_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
+                              const float* rowc, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
+                              void* stream);
+CPG_API int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
+                             const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, void* stream);
+CPG_API int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
+                              float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+CPG_API int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+                                float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- vocabulary projection: nn.Dropout(p_out)+nn.Linear(h_dim,n_vocab), models/decoder.py:43-45,83,107 ----------- */
 /* logits[R,V] = (hs[R,H] .* keep*scale) W[V,H]^T + b   (keep uint8 [R,H] or null) */
 CPG_API int cpg_vocab_fc_fwd(const float* hs, const uint8_t* keep, float scale, const float* w, const float* b,
