@@ -118,6 +118,7 @@ using T128x64 = TileCfg<128, 64, 32, 2, 2, 1>;
 using T128x32 = TileCfg<128, 32, 32, 4, 1, 1>;
 using T32x128 = TileCfg<32, 128, 32, 1, 4, 1>;
 using T64x64 = TileCfg<64, 64, 32, 2, 2, 1>;
+using T128x128 = TileCfg<128, 128, 32, 2, 2, 1>;
 
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s) {
@@ -126,6 +127,7 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s) {
                      (!g.a_mask || (((uintptr_t)g.a_mask) & 3) == 0) && (!g.b_mask || (((uintptr_t)g.b_mask) & 3) == 0) &&
                      (g.k_chunk % 4 == 0) && ((A_KC || B_KC) ? g.K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) &&
                      (B_KC || g.N % 4 == 0);
+    if (getenv("CPG_TN_TILE128") && !A_KC && !B_KC && g.M >= 128 && g.N >= 128) return launch_tc<T128x128, A_KC, B_KC>(g, zdim, vec, s);
     if (g.M <= 32) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
     if (g.N <= 32) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * zdim;

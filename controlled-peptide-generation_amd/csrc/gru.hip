@@ -17,6 +17,10 @@
 #include "cpg_internal.h"
 #include <stdlib.h>
 
+#ifndef CPG_FWD_PREFETCH
+#define CPG_FWD_PREFETCH 0   // measured: fetching the epilogue operands ahead of the MFMA loop costs registers (occupancy) for no gain
+#endif
+
 struct GruFwdArgs {
     const float* h_prev;
     const float* w_hh;
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
     // h_prev) do not depend on the matrix product: fetch them FIRST so their two dependent global-load latencies
     // (tok -> table row) run under the MFMA loop instead of after it.
     float gi[NJ][TC::MI][4][3], hp[NJ][TC::MI][4];
+    auto fetch = [&]() {
 #pragma unroll
     for (int jb = 0; jb < NJ; ++jb) {
         const int j = j0 + (wn * NJ + jb) * 16 + (lane & 15);
@@ -73,6 +78,10 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
                 hp[jb][mi][r] = g.h_prev[(size_t)rc * H + jc];
             }
     }
+    };
+#if CPG_FWD_PREFETCH
+    fetch();
+#endif
 
     OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
     OpB b{g.w_hh, H, j0, H, H, nullptr, 1.f};
@@ -82,6 +91,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
+#if !CPG_FWD_PREFETCH
+    fetch();
+#endif
 
     const size_t BH = (size_t)g.B * H;
 #pragma unroll
@@ -238,7 +250,9 @@ static int pick_bm(int B, int ntile_n, const char* knob) {
 
 int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
-    const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
+    int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
+    // forward: 32-row tiles (4 resident workgroups per CU) measured 43.5 us vs 46.9 us for 64-row tiles at B=2048,H=512
+    if (bm == 64 && !getenv("CPG_GRU_FWD_BM") && (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) >= 1024) bm = 32;
     if (bm == 128) launch_fwd<GF128>(a, vec, s);
     else if (bm == 64) launch_fwd<GF64>(a, vec, s);
     else launch_fwd<GF32>(a, vec, s);
