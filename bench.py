@@ -99,6 +99,7 @@ def main():
     world, rank, local = cdist.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs; there is no CPU path"
+    local = cdist.local_device(local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -164,7 +165,7 @@ def main():
     avg_us = tot_ms * 1e3 / max(launches, 1)
     flops_launch = 2.0 * B * Hh * gates * Hh
     achieved = flops_launch / (avg_us * 1e-6) / 1e12 if launches else 0.0
-    kname = ("gru_step_fwd_kernel<TileCfg<64,96,32,2,2,3>,true>" if args.cell == "gru"
+    kname = ("gru_step_fwd_kernel<TileCfg<32,96,32,2,2,3>,true>" if args.cell == "gru"
              else "lstm_step_fwd_kernel<TileCfg<64,128,32,2,2,4>,true>")
     roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),

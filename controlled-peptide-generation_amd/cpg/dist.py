@@ -22,11 +22,18 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CPG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local_device(local))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local
+
+
+def local_device(local_rank):
+    """GPU index of this rank.  One process per GPU; with fewer GPUs than ranks (single-GPU functional test of the
+    data-parallel path with CPG_DIST_BACKEND=gloo) ranks wrap around."""
+    n = torch.cuda.device_count()
+    return local_rank % n if n else 0
 
 
 def allreduce_sum(t):

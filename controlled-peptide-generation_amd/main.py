@@ -43,6 +43,7 @@ def run(argv=None):
         cfg._save_config(args, cfg, cfg.savepath)
     if not torch.cuda.is_available() or cfg.ignore_gpu:
         raise RuntimeError('the MI355X build has no CPU path (cfg.ignore_gpu / no visible GPU)')
+    local = cdist.local_device(local)
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     cfg.seed = cfg.seed if cfg.seed else random.randint(1, 10000)
