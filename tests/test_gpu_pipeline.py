@@ -167,3 +167,30 @@ def test_full_size_properties():
     b, _, _ = m.generate_sentences(128, zg[:128], cg[:128], sample_mode='greedy')
     w = min(a.shape[1], b.shape[1])
     assert torch.equal(a[:128, :w], b[:, :w])
+
+
+def test_api_helpers_roundtrip(tmp_path, golden):
+    """api.py helpers: vocab file -> checkpoint load (reference key names) -> encode / greedy reconstruction / interpolation."""
+    import importlib
+    import cfg
+    importlib.reload(cfg)
+    import api
+    import utils
+    from cpg.synth import SyntheticPeptideLoader
+    from models.mutils import save_model
+    g = golden("model_A")
+    m = build_model(weights_of(g))
+    ds = SyntheticPeptideLoader(4, 25, 'cuda', size=16)
+    utils.save_vocab(ds.TEXT.vocab, str(tmp_path / 'vocab.dict'))
+    save_model(m, str(tmp_path / 'model_1.pt'))
+    vocab = api.Vocab(str(tmp_path / 'vocab.dict'))
+    assert vocab.size() == 24 and vocab.to_ix("A C D").shape == (1, 25)
+    m2 = api.load_trained_model(str(tmp_path / 'model_1.pt'), vocab.size())
+    assert not m2.training
+    z, mu, lv = api.encode_sequence(m2, vocab, "A C D E F G")
+    ids = vocab.to_ix("A C D E F G").cuda()
+    mu_ref, _ = m.forward_encoder(ids)
+    assert torch.allclose(mu, mu_ref)
+    out = api.recon_sequence(m2, vocab, "A C D E F G", sample_mode='greedy')
+    assert isinstance(out, str)
+    assert len(api.interpolate_peptides(m2, vocab, "A C D", "W Y V", steps=4, sample_mode='greedy')) == 4
