@@ -23,10 +23,12 @@ struct GemmArgs {
 
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    const int m0 = blockIdx.y * TC::BM, n0 = blockIdx.x * TC::BN;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = by * TC::BM, n0 = bx * TC::BN;
     int kb = 0, K = g.K;
     if (g.k_chunk > 0) {
-        kb = blockIdx.z * g.k_chunk;
+        kb = bz * g.k_chunk;
         K = min(g.K - kb, g.k_chunk);
     }
     const size_t aoff = A_KC ? (size_t)kb : (size_t)kb * g.lda;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS>::run(a, b, K, acc);
-    float* C = g.C + (size_t)blockIdx.z * g.slab_stride;
+    float* C = g.C + (size_t)bz * g.slab_stride;
     const bool plain = g.k_chunk == 0;
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -141,19 +143,21 @@ int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const 
     return launch_gemm<true, true>(g, 1, s);
 }
 
-// Y[m,n] (+)= sum_k X[m,k] B[k,n] for a handful of rows (M <= 32) and long K: one (64-column, row) block with 4 K-lanes
+// Y[m,n] (+)= sum_k X[m,k] B[k,n] for a handful of rows (M <= 32) and long K: one (64-column, row) block with 16 K-lanes
 // and a fixed-order LDS reduction.  The tile engine would put such a problem on 1-2 workgroups walking K serially.
 __global__ void skinny_nn_kernel(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int N, int K,
                                  int accumulate) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int n = blockIdx.x * 64 + threadIdx.x, m = blockIdx.y, ty = threadIdx.y;
     float s = 0.f;
     if (n < N)
-        for (int k = ty; k < K; k += 4) s += X[(size_t)m * ldx + k] * Bm[(size_t)k * ldb + n];
+        for (int k = ty; k < K; k += 16) s += X[(size_t)m * ldx + k] * Bm[(size_t)k * ldb + n];
     red[ty][threadIdx.x] = s;
     __syncthreads();
     if (ty == 0 && n < N) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][threadIdx.x];
         const size_t o = (size_t)m * ldy + n;
         Y[o] = accumulate ? Y[o] + v : v;
     }
@@ -162,7 +166,7 @@ __global__ void skinny_nn_kernel(const float* X, int ldx, const float* Bm, int l
 int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K, int accumulate,
                 const uint8_t* cmask, float cms, hipStream_t s) {
     if (M <= 32 && K >= 256 && !cmask) {
-        hipLaunchKernelGGL(skinny_nn_kernel, dim3(cdiv(N, 64), M), dim3(64, 4), 0, s, X, ldx, Bm, ldb, Y, ldy, N, K, accumulate);
+        hipLaunchKernelGGL(skinny_nn_kernel, dim3(cdiv(N, 64), M), dim3(64, 16), 0, s, X, ldx, Bm, ldb, Y, ldy, N, K, accumulate);
         CPG_LAUNCH_CHECK();
         return 0;
     }
@@ -222,7 +226,7 @@ size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
 
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
     int chunks = cdiv(M, 256);
-    if (chunks > 512) chunks = 512;
+    if (chunks > 96) chunks = 96;
     if (chunks < 1) chunks = 1;
     if ((size_t)chunks * N * sizeof(float) > ws_bytes) {
         cpg_set_error("cpg_colsum: workspace too small (%zu < %zu)", ws_bytes, (size_t)chunks * N * sizeof(float));
@@ -238,7 +242,7 @@ int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate,
 
 size_t cpg_colsum_workspace(int M, int N) {
     int chunks = cdiv(M, 256);
-    if (chunks > 512) chunks = 512;
+    if (chunks > 96) chunks = 96;
     if (chunks < 1) chunks = 1;
     return (size_t)chunks * N * sizeof(float);
 }

@@ -71,6 +71,26 @@ struct TileCfg {
     static constexpr int smem_floats() { return 2 * (a_elems<AKC>() + b_elems<BKC>()); }
 };
 
+// XCD-aware tile order (MI355X: 8 XCDs with private 4 MiB L2s; workgroup `id` is observed to run on XCD id % 8 - used for
+// speed only, any placement is correct).  The default x-fastest order puts every N-tile column on its own XCD, so each
+// XCD streams the WHOLE M-side operand (measured on the dW_hh product: FETCH_SIZE 1.29 GB raw vs 0.52 GB algorithmic).
+// Remapped order: the gx workgroups that share one (y,z) - the same M-side rows / K-chunk - run back to back on ONE XCD,
+// and each XCD owns a contiguous 1/8 of the (y,z) combinations.
+__device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int combos = gy * gz;
+    if (combos % 8 != 0) {
+        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+        return;
+    }
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int xcd = lin & 7, idx = lin >> 3;
+    bx = idx % gx;
+    const int combo = xcd * (combos / 8) + idx / gx;
+    by = combo % gy;
+    bz = combo / gy;
+}
+
 template <int NSEG>
 __device__ __forceinline__ void bmap(const OpB& b, int n_local, int& idx, int& j) {
     const int jblk = n_local / (16 * NSEG);

@@ -39,7 +39,9 @@ struct GruFwdArgs {
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
     const int H = g.H, B = g.row1;  // row bound of this launch
-    const int m0 = g.row0 + blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 3);
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = g.row0 + by * TC::BM, j0 = bx * (TC::BN / 3);
     static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
     constexpr int NJ = TC::NI / 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -141,7 +143,9 @@ struct GruBwdArgs {
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
     const int H = g.H, B = g.row1;  // row bound of this launch
-    const int m0 = g.row0 + blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = g.row0 + by * TC::BM, j0 = bx * TC::BN;
     const size_t BH = (size_t)g.B * H;
     // epilogue operands first (see the forward kernel): saved gates, h_prev and the non-GEMM part of dH
     float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][5];

@@ -28,7 +28,9 @@ struct LstmFwdArgs {
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs g) {
     const int H = g.H, B = g.B;
-    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * (TC::BN / 4);
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = by * TC::BM, j0 = bx * (TC::BN / 4);
     static_assert(TC::NI % 4 == 0, "wave tile holds i,f,g,o blocks");
     constexpr int NJ = TC::NI / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,7 +122,9 @@ struct LstmBwdArgs {
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
     const int H = g.H, B = g.B;
-    const int m0 = blockIdx.y * TC::BM, j0 = blockIdx.x * TC::BN;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = by * TC::BM, j0 = bx * TC::BN;
     const size_t BH = (size_t)B * H;
     float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][7];
 #pragma unroll
