@@ -24,6 +24,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X f32-input MFMA = f32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
+# HBM bytes per launch of the dominant kernel from PMC counters (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+# passes over tools/kbench.py at the bench shapes; (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 read-side correction
+# of MI355X_MICROARCH.md section HBM).  Counters cannot be collected from inside this script; the numbers and commands are
+# in profiles/r01_bench_n1_summary_final.md.  Only valid for the default GRU / B=2048 / H=512 workload.
+PMC_TRAFFIC_BYTES = {("gru", 2048, 512): (2 * 21.3 + 22.6) * 1024 * 1024}
 
 
 def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, cell='gru'):
@@ -169,7 +174,7 @@ def main():
              else "lstm_step_fwd_kernel<TileCfg<64,128,32,2,2,4>,true>")
     roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
+                "traffic": PMC_TRAFFIC_BYTES.get((args.cell, B, Hh)), "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
                 "flops_per_launch": flops_launch}
     step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
     extra = {"loss_last_step": round(loss_val, 4), "executed_step_tflops_per_gpu": round(step_tflops, 2),
