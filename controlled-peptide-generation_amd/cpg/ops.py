@@ -368,6 +368,70 @@ class GruSeqFn(Function):
         return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None
 
 
+class GruBiSeqFn(Function):
+    """Both directions of one biGRU layer with ONE launch per time step for the pair (cpg_gru_biseq_fwd/_bwd): twice the
+    work per launch amortises the fixed per-launch phases.  Returns (slab_fwd, slab_rev), layouts as GruSeqFn."""
+
+    @staticmethod
+    def forward(ctx, tok, tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r, T):
+        dev = w_hh_f.device
+        H = w_hh_f.shape[1]
+        B = tok.shape[1] if tok is not None else dense_f.shape[1]
+        cont = lambda t: t.contiguous() if t is not None else None
+        wf, bf, wr, br = cont(w_hh_f), cont(b_hh_f), cont(w_hh_r), cont(b_hh_r)
+        tf, tr, df, dr = cont(tab_f), cont(tab_r), cont(dense_f), cont(dense_r)
+        hs_f = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        hs_r = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        hs_f[0].zero_()
+        hs_r[T].zero_()
+        need_grad = any(t is not None and t.requires_grad for t in (tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r))
+        g_f = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        g_r = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        ev = None
+        if PROFILE is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr), _p(hs_f),
+             _p(hs_r), _p(g_f), _p(g_r), _stream())
+        if ev is not None:
+            ev[1].record()
+            PROFILE.append(("gru_bistep_fwd", ev[0], ev[1], T, B, H))
+        ctx.save_for_backward(tok, wf, wr, hs_f, hs_r, g_f, g_r)
+        ctx.dims = (T, B, H)
+        ctx.V = tab_f.shape[0] if tab_f is not None else 0
+        ctx.has_tab, ctx.has_dense = tab_f is not None, dense_f is not None
+        return hs_f, hs_r
+
+    @staticmethod
+    def backward(ctx, g_hs_f, g_hs_r):
+        tok, wf, wr, hs_f, hs_r, gt_f, gt_r = ctx.saved_tensors
+        T, B, H = ctx.dims
+        dev = hs_f.device
+        BH = B * H
+        ext_f = g_hs_f.contiguous().view(-1)[BH:] if g_hs_f is not None else None      # slots 1..T
+        ext_r = g_hs_r.contiguous().view(-1)[:T * BH] if g_hs_r is not None else None  # slots 0..T-1
+        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
+        call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+             _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _stream())
+        nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
+        ws = workspace(nb, dev)
+        outs = []
+        for rev, dG, hs in ((0, dG_f, hs_f), (1, dG_r, hs_r)):
+            dw = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
+            db = torch.empty(3 * H, device=dev, dtype=torch.float32)
+            call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), _stream())
+            dtab = None
+            if ctx.has_tab:
+                dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
+                call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), None, 0, _p(ws), ws.numel(), _stream())
+            ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2) if ctx.has_dense else None
+            outs.append((dtab, ddense, dw, db))
+        (dtab_f, dd_f, dw_f, db_f), (dtab_r, dd_r, dw_r, db_r) = outs
+        return None, dtab_f, dtab_r, dd_f, dd_r, dw_f, db_f, dw_r, db_r, None
+
+
 _pending_events = []
 DEFER_WGRAD = False  # set by FusedAdamClip: w_hh/b_hh gradients of flagged sequences are accumulated on a side stream
 

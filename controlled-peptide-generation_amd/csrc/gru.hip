@@ -36,11 +36,19 @@ struct GruFwdArgs {
                          // can run as separate launch chains on separate streams, out of phase with each other
 };
 
+// Up to two independent sequences (the two directions of a biGRU layer) share one launch: gridDim.z selects the
+// argument set.  Twice the work per launch amortises the launch ramp / first-slab / epilogue phases, which are a fixed
+// ~30 % of a single-direction launch at B=2048,H=512 (plain product: 59 TFLOP/s at M=2048, 91 at M=8192).
+struct GruFwdPair {
+    GruFwdArgs d[2];
+};
+
 template <class TC, bool VEC>
-__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdArgs g) {
-    const int H = g.H, B = g.row1;  // row bound of this launch
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
+    const GruFwdArgs& g = pr.d[bz];
+    const int H = g.H, B = g.row1;  // row bound of this launch
     const int m0 = g.row0 + by * TC::BM, j0 = bx * (TC::BN / 3);
     static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
     constexpr int NJ = TC::NI / 3;
@@ -140,11 +148,16 @@ struct GruBwdArgs {
     int row0, row1;
 };
 
+struct GruBwdPair {
+    GruBwdArgs d[2];
+};
+
 template <class TC, bool VEC>
-__global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
-    const int H = g.H, B = g.row1;  // row bound of this launch
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
+    const GruBwdArgs& g = pr.d[bz];
+    const int H = g.H, B = g.row1;  // row bound of this launch
     const int m0 = g.row0 + by * TC::BM, j0 = bx * TC::BN;
     const size_t BH = (size_t)g.B * H;
     // epilogue operands first (see the forward kernel): saved gates, h_prev and the non-GEMM part of dH
@@ -211,6 +224,68 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdArgs g) {
     }
 }
 
+// ---- split form of the forward step: plain product gh = h_prev W_hh^T (gemm.hip) + this memory-bound cell kernel.
+// Two row groups alternate the two kernels on two streams, so one group's cell kernel (HBM traffic, few registers)
+// co-runs with the other group's product (MFMA): the lockstep "everybody loads / everybody multiplies / everybody stores"
+// of the fused kernel is broken up at the price of writing and re-reading gh (24 MB per step at B=2048,H=512).
+__global__ void gru_cell_fwd_kernel(const float* gh, const float* b_hh, const int32_t* tok, const float* tab, const float* rowc,
+                                    const float* dense, const float* h_prev, float* h_out, float* gates, int B, int H,
+                                    int row0, int row1) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = row0 + blockIdx.y;
+    if (j >= H || row >= row1) return;
+    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
+    if (tok) {
+        const float* t = tab + (size_t)tok[row] * 3 * H;
+        gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
+    }
+    if (rowc) {
+        const float* t = rowc + (size_t)row * 3 * H;
+        gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
+    }
+    if (dense) {
+        const float* t = dense + (size_t)row * 3 * H;
+        gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
+    }
+    const float* g3 = gh + (size_t)row * 3 * H;
+    const float hn = g3[2 * H + j] + b_hh[2 * H + j];
+    const float rg = sigmoidf_(gi_r + (g3[j] + b_hh[j]));
+    const float zg = sigmoidf_(gi_z + (g3[H + j] + b_hh[H + j]));
+    const float ng = tanhf(gi_n + rg * hn);
+    const size_t o = (size_t)row * H + j;
+    h_out[o] = (1.f - zg) * ng + zg * h_prev[o];
+    if (gates) {
+        const size_t BH = (size_t)B * H;
+        __builtin_nontemporal_store(rg, gates + o);
+        __builtin_nontemporal_store(zg, gates + BH + o);
+        __builtin_nontemporal_store(ng, gates + 2 * BH + o);
+        __builtin_nontemporal_store(hn, gates + 3 * BH + o);
+    }
+}
+
+// Experimental entry point (tools/kbench3.py): same contract as cpg_gru_seq_fwd plus a gh scratch [B,3H].
+CPG_EXPORT int cpg_gru_seq_fwd_split(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
+                                     const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
+                                     float* gh, int row_begin, int row_end, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && gh && 0 <= row_begin && row_begin < row_end && row_end <= B);
+    const size_t BH = (size_t)B * H;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = row_end - row_begin;
+    for (int p = 0; p < T; ++p) {
+        const int t = reverse ? T - 1 - p : p;
+        const float* h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
+        float* h_out = reverse ? hs + (size_t)t * BH : hs + (size_t)(t + 1) * BH;
+        int rc = cpg_gemm_nt(h_prev + (size_t)row_begin * H, H, nullptr, 1.f, w_hh, H, nullptr, gh + (size_t)row_begin * 3 * H,
+                             3 * H, rows, 3 * H, H, 0, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, s, (const float*)gh, b_hh,
+                           tok ? tok + (size_t)t * B : nullptr, tab, rowc, dense ? dense + (size_t)t * B * 3 * H : nullptr,
+                           h_prev, h_out, gates ? gates + (size_t)t * 4 * BH : nullptr, B, H, row_begin, row_end);
+        CPG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 using GF128 = TileCfg<128, 96, 32, 2, 2, 3>;
 using GF64 = TileCfg<64, 96, 32, 2, 2, 3>;
 using GF32 = TileCfg<32, 96, 32, 2, 2, 3>;
@@ -219,23 +294,25 @@ using GB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using GB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 
 template <class TC>
-static void launch_fwd(const GruFwdArgs& a, bool vec, hipStream_t s) {
-    dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.row1 - a.row0, TC::BM));
+static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
+    const GruFwdArgs& a = pr.d[0];
+    dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.row1 - a.row0, TC::BM), nd);
     const size_t smem = TC::template smem_floats<true, true>() * sizeof(float);
     if (vec)
-        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true>), grid, dim3(256), smem, s, a);
+        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
     else
-        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false>), grid, dim3(256), smem, s, a);
+        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false>), grid, dim3(256), smem, s, pr);
 }
 
 template <class TC>
-static void launch_bwd(const GruBwdArgs& a, bool vec, hipStream_t s) {
-    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM));
+static void launch_bwd(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
+    const GruBwdArgs& a = pr.d[0];
+    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
     const size_t smem = TC::template smem_floats<true, false>() * sizeof(float);
     if (vec)
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, a);
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
     else
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false>), grid, dim3(256), smem, s, a);
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false>), grid, dim3(256), smem, s, pr);
 }
 
 // pick the row-tile height so that the launch has at least ~256 workgroups when the problem allows it
@@ -252,26 +329,44 @@ static int pick_bm(int B, int ntile_n, const char* knob) {
     return 32;
 }
 
-int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
-    const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
+static int gru_fwd_launch(const GruFwdPair& pr, int nd, hipStream_t s) {
+    const GruFwdArgs& a = pr.d[0];
+    bool vec = a.H % 4 == 0;
+    for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].h_prev) && aligned16(pr.d[d].w_hh);
     int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
     // forward: 32-row tiles (4 resident workgroups per CU) measured 43.5 us vs 46.9 us for 64-row tiles at B=2048,H=512
-    if (bm == 64 && !getenv("CPG_GRU_FWD_BM") && (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) >= 1024) bm = 32;
-    if (bm == 128) launch_fwd<GF128>(a, vec, s);
-    else if (bm == 64) launch_fwd<GF64>(a, vec, s);
-    else launch_fwd<GF32>(a, vec, s);
+    if (bm == 64 && !getenv("CPG_GRU_FWD_BM") && (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) * nd >= 1024) bm = 32;
+    if (bm == 128) launch_fwd<GF128>(pr, nd, vec, s);
+    else if (bm == 64) launch_fwd<GF64>(pr, nd, vec, s);
+    else launch_fwd<GF32>(pr, nd, vec, s);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
+    GruFwdPair pr;
+    pr.d[0] = a;
+    pr.d[1] = a;
+    return gru_fwd_launch(pr, 1, s);
+}
+
+static int gru_bwd_launch(const GruBwdPair& pr, int nd, hipStream_t s) {
+    const GruBwdArgs& a = pr.d[0];
+    bool vec = a.H % 4 == 0;
+    for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
+    const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
+    if (bm == 128) launch_bwd<GB128>(pr, nd, vec, s);
+    else if (bm == 64) launch_bwd<GB64>(pr, nd, vec, s);
+    else launch_bwd<GB32>(pr, nd, vec, s);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 
 static int gru_step_bwd_launch(const GruBwdArgs& a, hipStream_t s) {
-    const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
-    const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
-    if (bm == 128) launch_bwd<GB128>(a, vec, s);
-    else if (bm == 64) launch_bwd<GB64>(a, vec, s);
-    else launch_bwd<GB32>(a, vec, s);
-    CPG_LAUNCH_CHECK();
-    return 0;
+    GruBwdPair pr;
+    pr.d[0] = a;
+    pr.d[1] = a;
+    return gru_bwd_launch(pr, 1, s);
 }
 
 // ------------------------------------------------------------------------------------------ reductions over dG
@@ -477,4 +572,91 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
 CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
                                   float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, drowc, accumulate, workspace, workspace_bytes, stream);
+}
+
+static void fill_fwd(GruFwdArgs& a, int t, int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
+                     const int32_t* tok, const float* tab, const float* dense, float* hs, float* gates) {
+    const size_t BH = (size_t)B * H;
+    a.h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
+    a.h_out = reverse ? hs + (size_t)t * BH : hs + (size_t)(t + 1) * BH;
+    a.w_hh = w_hh;
+    a.b_hh = b_hh;
+    a.tok = tok ? tok + (size_t)t * B : nullptr;
+    a.tab = tab;
+    a.rowc = nullptr;
+    a.dense = dense ? dense + (size_t)t * B * 3 * H : nullptr;
+    a.gates = gates ? gates + (size_t)t * 4 * BH : nullptr;
+    a.B = B;
+    a.H = H;
+    a.row0 = 0;
+    a.row1 = B;
+}
+
+// Both directions of one biGRU layer (models/encoder.py:25-30,42) in lock step: launch p runs time p of the forward
+// direction and time T-1-p of the reverse direction.  *_f / *_r: per-direction arguments as in cpg_gru_seq_fwd.
+CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const float* b_hh_f, const float* w_hh_r,
+                                 const float* b_hh_r, const int32_t* tok, const float* tab_f, const float* tab_r,
+                                 const float* dense_f, const float* dense_r, float* hs_f, float* hs_r, float* gates_f,
+                                 float* gates_r, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && b_hh_f && w_hh_r && b_hh_r && hs_f && hs_r);
+    CPG_CHECK_ARG((tok == nullptr) == (tab_f == nullptr) && (tab_f == nullptr) == (tab_r == nullptr));
+    CPG_CHECK_ARG((dense_f == nullptr) == (dense_r == nullptr) && (gates_f == nullptr) == (gates_r == nullptr));
+    for (int p = 0; p < T; ++p) {
+        GruFwdPair pr;
+        fill_fwd(pr.d[0], p, T, B, H, 0, w_hh_f, b_hh_f, tok, tab_f, dense_f, hs_f, gates_f);
+        fill_fwd(pr.d[1], T - 1 - p, T, B, H, 1, w_hh_r, b_hh_r, tok, tab_r, dense_r, hs_r, gates_r);
+        int rc = gru_fwd_launch(pr, 2, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// BPTT of both directions in lock step (no initial-state gradient: the encoder starts from h0 = 0).
+// dhs_ext_* [T,B,H] time-aligned (null = zeros); dG_* [T,B,4H]; scratch_* [2,B,H].
+CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                                 const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                 const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
+                                 void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
+    CPG_CHECK_ARG(scratch_f && scratch_r);
+    const size_t BH = (size_t)B * H;
+    const float* W[2] = {w_hh_f, w_hh_r};
+    const float* HS[2] = {hs_f, hs_r};
+    const float* GT[2] = {gates_f, gates_r};
+    const float* EX[2] = {dhs_ext_f, dhs_ext_r};
+    float* DG[2] = {dG_f, dG_r};
+    float* SC[2] = {scratch_f, scratch_r};
+    int prev_t[2] = {-1, -1};
+    for (int p = T - 1; p >= 0; --p) {
+        GruBwdPair pr;
+        const int cur = (p + 2) & 1;
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - p : p;
+            GruBwdArgs& a = pr.d[d];
+            a.B = B;
+            a.H = H;
+            a.row0 = 0;
+            a.row1 = B;
+            a.w_hh = W[d];
+            if (prev_t[d] >= 0) {
+                a.dG_next = DG[d] + (size_t)prev_t[d] * B * 4 * H;
+                a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;
+                a.z_next = GT[d] + (size_t)prev_t[d] * 4 * BH + BH;
+            } else {
+                a.dG_next = nullptr;
+                a.dH_next = nullptr;
+                a.z_next = nullptr;
+            }
+            a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
+            a.ext2 = nullptr;
+            a.gates = GT[d] + (size_t)t * 4 * BH;
+            a.h_prev = d ? HS[d] + (size_t)(t + 1) * BH : HS[d] + (size_t)t * BH;
+            a.dH_out = SC[d] + (size_t)cur * BH;
+            a.dG_out = DG[d] + (size_t)t * B * 4 * H;
+            prev_t[d] = t;
+        }
+        int rc = gru_bwd_launch(pr, 2, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
 }

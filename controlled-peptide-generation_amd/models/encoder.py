@@ -64,6 +64,14 @@ class GRUEncoder(nn.Module):
                         dense = ops.LinearFn.apply(xf, w_ih, b_ih).view(T, B, -1)
                 pre.append((tab, dense))
             new = []
+            if self.cell == 'gru' and self.biGRU and ops.OVERLAP:
+                # both directions share one launch per time step (GruBiSeqFn)
+                (tab_f, dense_f), (tab_r, dense_r) = pre
+                new = list(ops.GruBiSeqFn.apply(tok if l == 0 else None, tab_f, tab_r, dense_f, dense_r,
+                                                self._w("weight_hh", l, ""), self._w("bias_hh", l, ""),
+                                                self._w("weight_hh", l, "_reverse"), self._w("bias_hh", l, "_reverse"), T))
+                slabs = new
+                continue
             for d, (sfx, rev) in enumerate(self._dirs()):
                 tab, dense = pre[d]
                 w_hh, b_hh = self._w("weight_hh", l, sfx), self._w("bias_hh", l, sfx)

@@ -74,6 +74,11 @@ CPG_API int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, flo
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
                             int row_begin, int row_end, void* stream);
+/* split form of the same sequence (plain product + memory-bound cell kernel per step; gh scratch [B,3H]) - lets two
+ * row groups on two streams overlap one group's cell traffic with the other group's product */
+CPG_API int cpg_gru_seq_fwd_split(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
+                                  const int32_t* tok, const float* tab, const float* rowc, const float* dense, float* hs,
+                                  float* gates, float* gh, int row_begin, int row_end, void* stream);
 /* one decode step = GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) */
 CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                              const float* rowc, const float* h_prev, float* h_out, void* stream);
@@ -84,6 +89,17 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
                             int row_begin, int row_end, void* stream);
+/* Both directions of one biGRU layer in lock step, ONE launch per step for the pair (launch p: time p forward, time
+ * T-1-p reverse).  Arguments as in cpg_gru_seq_fwd / _bwd per direction (_f forward, _r reverse); no initial-state
+ * gradient (the encoder starts from h0 = 0). */
+CPG_API int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const float* b_hh_f, const float* w_hh_r,
+                              const float* b_hh_r, const int32_t* tok, const float* tab_f, const float* tab_r,
+                              const float* dense_f, const float* dense_r, float* hs_f, float* hs_r, float* gates_f,
+                              float* gates_r, void* stream);
+CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                              const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                              const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
+                              void* stream);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
