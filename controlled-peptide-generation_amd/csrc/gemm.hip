@@ -277,6 +277,15 @@ CPG_EXPORT int cpg_linear_bwd_weight(const float* dY, int lddy, const float* X, 
     return rc;
 }
 
+CPG_EXPORT size_t cpg_colsum_workspace_bytes(int M, int N) { return cpg_colsum_workspace(M, N) + 256; }
+
+// out[N] (+)= column sums of X[M,N] (bias gradients; fixed two-stage partition)
+CPG_EXPORT int cpg_colsum_f32(const float* X, int ld, int M, int N, float* out, int accumulate, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(X && out && workspace && M > 0 && N > 0 && ld >= N);
+    return cpg_colsum(X, ld, M, N, out, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 CPG_EXPORT int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K,
                              int accumulate, void* stream) {
     CPG_CHECK_ARG(X && Bm && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldb >= N && ldy >= N);

@@ -518,11 +518,11 @@ CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
 // dW_hh[3H,H] (+)= sum_t dgh_t^T h_prev(t) ; db_hh[3H] (+)= sum dgh.
 CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
                                 float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && db_hh && workspace);
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && workspace);
     const float* hprev = reverse ? hs + (size_t)B * H : hs;
     int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 3 * H, H, accumulate, (float*)workspace,
                          workspace_bytes, (hipStream_t)stream);
-    if (rc) return rc;
+    if (rc || !db_hh) return rc;  // db_hh null: the caller derives it (shared r,z columns come from the token-table gradient)
     return cpg_colsum(dG, 4 * H, T * B, 3 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 

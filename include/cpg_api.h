@@ -56,6 +56,10 @@ CPG_API size_t cpg_linear_bwd_weight_workspace(int M, int N, int K);
 CPG_API int cpg_linear_bwd_weight(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
                                   int M, int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream);
+CPG_API size_t cpg_colsum_workspace_bytes(int M, int N);
+/* out[N] (+)= column sums of X[M,N] */
+CPG_API int cpg_colsum_f32(const float* X, int ld, int M, int N, float* out, int accumulate, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* Y[M,N] (+)= X[M,K] B[K,N] */
 CPG_API int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K,
                           int accumulate, void* stream);
@@ -101,7 +105,7 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
                               const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
                               void* stream);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
-/* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh */
+/* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
                              float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* dtab[V,3H] (+)= sum of input-side gate gradients grouped by token ; drowc[B,3H] (+)= sum over time (either may be null) */
