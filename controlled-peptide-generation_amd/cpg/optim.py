@@ -32,8 +32,12 @@ class FusedAdamClip:
         dev = self.order[0].device
         if dev.type != "cuda":
             raise ops.CpgError("FusedAdamClip needs parameters on the GPU; there is no CPU fallback")
-        n = sum(p.numel() for p in self.order)
-        self.flat_p = torch.empty(n, device=dev, dtype=torch.float32)
+        # every parameter starts on a 64-byte boundary of the flat buffers (the kernels take 16-byte vector loads only from
+        # aligned bases); the padding holds zeros: zero gradient, zero update, no effect on the norm
+        ALIGN = 16
+        pad = lambda k: -(-k // ALIGN) * ALIGN
+        n = sum(pad(p.numel()) for p in self.order)
+        self.flat_p = torch.zeros(n, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(n, device=dev, dtype=torch.float32)
         self.m = torch.zeros(n, device=dev, dtype=torch.float32)
         self.v = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -45,7 +49,7 @@ class FusedAdamClip:
             p.data = self.flat_p[off:off + k].view_as(p.data)
             p.grad = self.flat_g[off:off + k].view_as(p.data)
             self.segs.append((off, k))
-            off += k
+            off += pad(k)
         self.n_dup = sum(k for (o, k), mm in zip(self.segs, self.mult) if mm > 1)
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
         self.reduce_fn, self.world = reduce_fn, int(world)

@@ -187,8 +187,8 @@ static void pick_split(int M, int N, int K, int& S, int& k_chunk) {
     const long tiles = (long)cdiv(M, 128) * cdiv(N, 64);
     long want = (1536 + tiles - 1) / tiles;
     if (want < 1) want = 1;
-    long maxs = cdiv(K, 128);
-    if (maxs < 1) maxs = 1;
+    long maxs = K / 512;  // at least 16 slabs per workgroup: shorter chunks are all prologue (measured: K=2048 split 16 ways
+    if (maxs < 1) maxs = 1;  // ran a 3.2 GFLOP product in 0.46 ms)
     if (want > maxs) want = maxs;
     if (want > 64) want = 64;
     k_chunk = cdiv(cdiv(K, (int)want), 32) * 32;

@@ -292,6 +292,9 @@ using GF32 = TileCfg<32, 96, 32, 2, 2, 3>;
 using GB128 = TileCfg<128, 32, 32, 4, 1, 1>;
 using GB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using GB32 = TileCfg<32, 64, 32, 2, 2, 1>;
+using GB64W = TileCfg<64, 64, 32, 2, 2, 1>;    // wider N tile: 4 MFMAs per k-step per wave instead of 2
+using GB128W = TileCfg<128, 64, 32, 2, 2, 1>;
+using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
 template <class TC>
 static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
@@ -355,7 +358,14 @@ static int gru_bwd_launch(const GruBwdPair& pr, int nd, hipStream_t s) {
     bool vec = a.H % 4 == 0;
     for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
     const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
-    if (bm == 128) launch_bwd<GB128>(pr, nd, vec, s);
+    const char* wide = getenv("CPG_GRU_BWD_WIDE");
+    // 32x32 tiles (>= 1024 workgroups) measured 51.4 us vs 53.7 us for 64x32 at B=2048,H=512; wider tiles lose badly (77 / 116 us)
+    const bool small = !wide && !getenv("CPG_GRU_BWD_BM") && (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) * nd >= 1024;
+    if (small) launch_bwd<GB32N>(pr, nd, vec, s);
+    else if (wide && atoi(wide) == 64) launch_bwd<GB64W>(pr, nd, vec, s);
+    else if (wide && atoi(wide) == 128) launch_bwd<GB128W>(pr, nd, vec, s);
+    else if (wide && atoi(wide) == 32) launch_bwd<GB32N>(pr, nd, vec, s);
+    else if (bm == 128) launch_bwd<GB128>(pr, nd, vec, s);
     else if (bm == 64) launch_bwd<GB64>(pr, nd, vec, s);
     else launch_bwd<GB32>(pr, nd, vec, s);
     CPG_LAUNCH_CHECK();
