@@ -7,8 +7,9 @@
 // Each operand can be stored either with K contiguous ("KC": rows of h / rows of W, the natural torch
 // layouts) or with its free dimension contiguous ("XC": transposed use, e.g. dW = dY^T X).  The LDS image
 // is chosen per layout so that the per-lane fragment reads (ds_read_b32) are bank-conflict free:
-//   KC -> [X][BK+2]   (lanes 0..15 walk X: stride 2 mod 32 banks, lanes 16..31 sit on the odd banks)
-//   XC -> [BK][X+16]  (lanes 0..15 consecutive banks, lanes 16..31 shifted by 16)
+//   KC -> [X][BK+4]   rows 16-byte aligned: each lane fetches 4 consecutive k of its row with ONE ds_read_b128 (the
+//                     contraction index is permuted accordingly, see MainLoop::PERM), staged with ds_write_b128
+//   XC -> [BK][X+16]  ds_read_b32: lanes 0..15 consecutive banks, lanes 16..31 shifted by 16
 // MFMA fragment mapping (cdna guide section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 // C/D: col = l&15, row = (l>>4)*4 + reg.
 //
@@ -19,7 +20,8 @@
 #include "cpg_common.h"
 
 // Diagnostic builds only (tools/ablate.sh): -DCPG_ABLATE=<mask> removes one phase of the slab loop after the first slab so its
-// cost can be measured in isolation.  1: no global loads / LDS writes   2: no LDS fragment reads   4: no barrier.
+// cost can be measured in isolation.  1: no global loads / LDS writes   2: no LDS fragment reads   4: no barrier
+// 8: no MFMA (one VALU fma per fragment pair instead).
 // Results of such builds are wrong by construction; the shipped library is built without the macro.
 #ifndef CPG_ABLATE
 #define CPG_ABLATE 0
@@ -60,13 +62,13 @@ struct TileCfg {
     static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "staging must divide evenly");
     static_assert(WTN % (16 * NSEG) == 0, "a wave must own whole segment groups");
     template <bool KC>
-    static constexpr int lda() { return KC ? BK + 2 : BM + 16; }
+    static constexpr int lda() { return KC ? BK + 4 : BM + 16; }
     template <bool KC>
-    static constexpr int ldb() { return KC ? BK + 2 : BN + 16; }
+    static constexpr int ldb() { return KC ? BK + 4 : BN + 16; }
     template <bool KC>
-    static constexpr int a_elems() { return KC ? BM * (BK + 2) : BK * (BM + 16); }
+    static constexpr int a_elems() { return KC ? BM * (BK + 4) : BK * (BM + 16); }
     template <bool KC>
-    static constexpr int b_elems() { return KC ? BN * (BK + 2) : BK * (BN + 16); }
+    static constexpr int b_elems() { return KC ? BN * (BK + 4) : BK * (BN + 16); }
     template <bool AKC, bool BKC>
     static constexpr int smem_floats() { return 2 * (a_elems<AKC>() + b_elems<BKC>()); }
 };
@@ -99,41 +101,6 @@ __device__ __forceinline__ void bmap(const OpB& b, int n_local, int& idx, int& j
     idx = seg * b.seg_stride + j;
 }
 
-// 4-wide operand fetch of p[off .. off+3]; element c is in range iff c < nvalid.  Loads are UNCONDITIONAL (clamped to
-// offset 0, which always exists); the validity bits are returned and applied when the registers are written to LDS,
-// i.e. AFTER the MFMA phase the loads overlap with - a branch or a select right behind a load makes hipcc wait for the
-// load where it is issued and serialises the staging phase (cdna guide section 5, trap (c)).
-// VEC (16-byte loads) requires the caller to guarantee alignment AND that vectors never straddle a bound
-// (nvalid is then either <= 0 or >= 4).
-template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* p, size_t off, int nvalid, unsigned& okbits) {
-    if (VEC) {
-        const bool ok = nvalid >= 4;
-        okbits = ok ? 0xFu : 0u;
-        return *reinterpret_cast<const float4*>(p + (ok ? off : 0));
-    }
-    float t[4];
-    okbits = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const bool ok = c < nvalid;
-        okbits |= ok ? (1u << c) : 0u;
-        t[c] = p[ok ? off + c : 0];
-    }
-    return make_float4(t[0], t[1], t[2], t[3]);
-}
-
-template <bool VEC>
-__device__ __forceinline__ uchar4 loadmask4(const uint8_t* m, size_t off, unsigned okbits) {
-    if (VEC) return *reinterpret_cast<const uchar4*>(m + (okbits ? off : 0));
-    uchar4 k;
-    k.x = m[(okbits & 1u) ? off : 0];
-    k.y = m[(okbits & 2u) ? off + 1 : 0];
-    k.z = m[(okbits & 4u) ? off + 2 : 0];
-    k.w = m[(okbits & 8u) ? off + 3 : 0];
-    return k;
-}
-
 __device__ __forceinline__ float4 finish4(float4 v, unsigned okbits, bool has_mask, uchar4 k, float ms) {
     if (has_mask) {
         v.x = k.x ? v.x * ms : 0.f;
@@ -141,10 +108,12 @@ __device__ __forceinline__ float4 finish4(float4 v, unsigned okbits, bool has_ma
         v.z = k.z ? v.z * ms : 0.f;
         v.w = k.w ? v.w * ms : 0.f;
     }
-    v.x = (okbits & 1u) ? v.x : 0.f;
-    v.y = (okbits & 2u) ? v.y : 0.f;
-    v.z = (okbits & 4u) ? v.z : 0.f;
-    v.w = (okbits & 8u) ? v.w : 0.f;
+    if (okbits != 0xFu) {
+        v.x = (okbits & 1u) ? v.x : 0.f;
+        v.y = (okbits & 2u) ? v.y : 0.f;
+        v.z = (okbits & 4u) ? v.z : 0.f;
+        v.w = (okbits & 8u) ? v.w : 0.f;
+    }
     return v;
 }
 
@@ -155,54 +124,127 @@ struct MainLoop {
     static constexpr int LDB = TC::template ldb<B_KC>();
     static constexpr int ASZ = TC::template a_elems<A_KC>();
     static constexpr int BSZ = TC::template b_elems<B_KC>();
+    // K-index of MFMA k-step s (0..BK/4-1), lane group q (0..3).  When an operand is K-contiguous its fragments are read
+    // 16 bytes at a time (4 consecutive k per lane), so within each 16-deep half the contraction index is permuted:
+    // step j of half h contracts k = 16h + 4q + j.  Any bijection works as long as A and B agree.
+    static constexpr bool PERM = A_KC || B_KC;
+    static_assert(BK % 16 == 0, "slab depth must be a multiple of 16");
+    static constexpr int NH = BK / 16;  // 16-deep halves per slab
 
     struct Stage {  // one K-slab of both operands in flight in registers
         float4 a[TC::AV], b[TC::BV];
         uchar4 am[TC::AV], bm[TC::BV];
         unsigned aok[TC::AV], bok[TC::BV];
     };
+    struct Plan {  // per-thread, slab-invariant part of the staging addresses (hoisted out of the slab loop)
+        size_t a[TC::AV], b[TC::BV];  // element offset of the vector at k0 = 0 (clamped to a valid row / column)
+        int an[TC::AV], bn[TC::BV];   // KC: 4*kq (k offset inside the slab) ; XC: number of valid columns (0..4)
+        bool aok[TC::AV], bok[TC::BV];  // KC: row in range ; XC: unused
+    };
 
-    __device__ static __forceinline__ void gload(const OpA& a, const OpB& b, int k0, int K, Stage& st) {
+    __device__ static __forceinline__ void plan(const OpA& a, const OpB& b, Plan& pl) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) {
             const int v = tid + i * TC::NT;
-            size_t off;
-            int nvalid;
             if (A_KC) {
                 const int row = v / (BK / 4), kq = v % (BK / 4);
-                const int gm = a.m0 + row, k = k0 + 4 * kq;
-                nvalid = (gm < a.M) ? (K - k) : 0;
-                off = (size_t)gm * a.ld + k;
+                const int gm = a.m0 + row;
+                pl.aok[i] = gm < a.M;
+                pl.an[i] = 4 * kq;
+                pl.a[i] = (size_t)(pl.aok[i] ? gm : 0) * a.ld + 4 * kq;
             } else {
                 const int kk = v / (BM / 4), mq = v % (BM / 4);
-                const int gk = k0 + kk, gm = a.m0 + 4 * mq;
-                nvalid = (gk < K) ? (a.M - gm) : 0;
-                off = (size_t)gk * a.ld + gm;
+                const int gm = a.m0 + 4 * mq;
+                const int nc = min(max(a.M - gm, 0), 4);
+                pl.aok[i] = true;
+                pl.an[i] = nc;
+                pl.a[i] = (size_t)kk * a.ld + (nc > 0 ? gm : 0);
             }
-            st.a[i] = load4<AVEC>(a.p, off, nvalid, st.aok[i]);
-            if (MASKS && a.mask) st.am[i] = loadmask4<AVEC>(a.mask, off, st.aok[i]);
         }
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
             const int v = tid + i * TC::NT;
-            size_t off;
-            int nvalid, idx, j;
+            int idx, j;
             if (B_KC) {
                 const int nl = v / (BK / 4), kq = v % (BK / 4);
                 bmap<TC::NSEG>(b, nl, idx, j);
-                const int k = k0 + 4 * kq;
-                nvalid = (j < b.seg_len) ? (K - k) : 0;
-                off = (size_t)idx * b.ld + k;
+                pl.bok[i] = j < b.seg_len;
+                pl.bn[i] = 4 * kq;
+                pl.b[i] = (size_t)(pl.bok[i] ? idx : 0) * b.ld + 4 * kq;
             } else {
                 const int kk = v / (BN / 4), nq = v % (BN / 4);
                 bmap<TC::NSEG>(b, 4 * nq, idx, j);
-                const int gk = k0 + kk;
-                nvalid = (gk < K) ? (b.seg_len - j) : 0;
-                off = (size_t)gk * b.ld + idx;
+                const int nc = min(max(b.seg_len - j, 0), 4);
+                pl.bok[i] = true;
+                pl.bn[i] = nc;
+                pl.b[i] = (size_t)kk * b.ld + (nc > 0 ? idx : 0);
             }
-            st.b[i] = load4<BVEC>(b.p, off, nvalid, st.bok[i]);
-            if (MASKS && b.mask) st.bm[i] = loadmask4<BVEC>(b.mask, off, st.bok[i]);
+        }
+    }
+
+    // Unconditional (clamped) loads; validity bits are applied at LDS-store time, after the MFMA phase they overlap with.
+    template <bool KC, bool VEC>
+    __device__ static __forceinline__ float4 fetch(const float* p, const uint8_t* mask, size_t base, int n, bool rok, int ld,
+                                                   int k0, int K, int kk_xc, unsigned& okbits, uchar4& mk) {
+        if (KC) {
+            const int nk = K - (k0 + n);  // n = 4*kq
+            if (VEC) {
+                const bool ok = rok && nk >= 4;
+                okbits = ok ? 0xFu : 0u;
+                const size_t o = ok ? base + k0 : 0;
+                if (MASKS && mask) mk = *reinterpret_cast<const uchar4*>(mask + o);
+                return *reinterpret_cast<const float4*>(p + o);
+            }
+            float t[4];
+            unsigned char m4[4] = {1, 1, 1, 1};
+            okbits = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = rok && c < nk;
+                okbits |= ok ? (1u << c) : 0u;
+                const size_t o = ok ? base + k0 + c : 0;
+                t[c] = p[o];
+                if (MASKS && mask) m4[c] = mask[o];
+            }
+            mk = make_uchar4(m4[0], m4[1], m4[2], m4[3]);
+            return make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+            const bool kok = (k0 + kk_xc) < K;  // n = number of valid columns
+            if (VEC) {
+                const bool ok = kok && n >= 4;
+                okbits = ok ? 0xFu : 0u;
+                const size_t o = ok ? base + (size_t)k0 * ld : 0;
+                if (MASKS && mask) mk = *reinterpret_cast<const uchar4*>(mask + o);
+                return *reinterpret_cast<const float4*>(p + o);
+            }
+            float t[4];
+            unsigned char m4[4] = {1, 1, 1, 1};
+            okbits = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ok = kok && c < n;
+                okbits |= ok ? (1u << c) : 0u;
+                const size_t o = ok ? base + (size_t)k0 * ld + c : 0;
+                t[c] = p[o];
+                if (MASKS && mask) m4[c] = mask[o];
+            }
+            mk = make_uchar4(m4[0], m4[1], m4[2], m4[3]);
+            return make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+
+    __device__ static __forceinline__ void gload(const OpA& a, const OpB& b, const Plan& pl, int k0, int K, Stage& st) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < TC::AV; ++i) {
+            const int kk = (tid + i * TC::NT) / (BM / 4);
+            st.a[i] = fetch<A_KC, AVEC>(a.p, a.mask, pl.a[i], pl.an[i], pl.aok[i], a.ld, k0, K, kk, st.aok[i], st.am[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < TC::BV; ++i) {
+            const int kk = (tid + i * TC::NT) / (BN / 4);
+            st.b[i] = fetch<B_KC, BVEC>(b.p, b.mask, pl.b[i], pl.bn[i], pl.bok[i], b.ld, k0, K, kk, st.bok[i], st.bm[i]);
         }
     }
 
@@ -212,96 +254,103 @@ struct MainLoop {
         for (int i = 0; i < TC::AV; ++i) {
             const int v = tid + i * TC::NT;
             const float4 r = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
-            if (A_KC) {
-                const int row = v / (BK / 4), kq = v % (BK / 4);
-                float2* d = reinterpret_cast<float2*>(As + row * LDA + 4 * kq);
-                d[0] = make_float2(r.x, r.y);
-                d[1] = make_float2(r.z, r.w);
-            } else {
-                const int kk = v / (BM / 4), mq = v % (BM / 4);
-                *reinterpret_cast<float4*>(As + kk * LDA + 4 * mq) = r;
-            }
+            const int off = A_KC ? (v / (BK / 4)) * LDA + 4 * (v % (BK / 4)) : (v / (BM / 4)) * LDA + 4 * (v % (BM / 4));
+            *reinterpret_cast<float4*>(As + off) = r;
         }
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
             const int v = tid + i * TC::NT;
             const float4 r = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
-            if (B_KC) {
-                const int nl = v / (BK / 4), kq = v % (BK / 4);
-                float2* d = reinterpret_cast<float2*>(Bs + nl * LDB + 4 * kq);
-                d[0] = make_float2(r.x, r.y);
-                d[1] = make_float2(r.z, r.w);
-            } else {
-                const int kk = v / (BN / 4), nq = v % (BN / 4);
-                *reinterpret_cast<float4*>(Bs + kk * LDB + 4 * nq) = r;
-            }
+            const int off = B_KC ? (v / (BK / 4)) * LDB + 4 * (v % (BK / 4)) : (v / (BN / 4)) * LDB + 4 * (v % (BN / 4));
+            *reinterpret_cast<float4*>(Bs + off) = r;
         }
     }
 
-    static constexpr int KH = (BK / 8) * 4;      // k-steps are split in two halves per slab
-    static constexpr int NS0 = KH / 4, NS1 = (BK - KH) / 4;
-
-    template <int NS>
-    struct Frag {  // fragments of NS consecutive k-steps
-        float a[NS][TC::MI], b[NS][TC::NI];
+    struct Frag {  // fragments of one slab: [half][block][k-step inside the half]
+        float a[NH][TC::MI][4], b[NH][TC::NI][4];
     };
 
-    template <int NS>
-    __device__ static __forceinline__ void read_frags(const float* Ab, const float* Bb, int k0, Frag<NS>& f) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int kk = k0 + 4 * s;
-#pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi) f.a[s][mi] = A_KC ? Ab[mi * 16 * LDA + kk] : Ab[kk * LDA + mi * 16];
-#pragma unroll
-            for (int ni = 0; ni < TC::NI; ++ni) f.b[s][ni] = B_KC ? Bb[ni * 16 * LDB + kk] : Bb[kk * LDB + ni * 16];
-        }
-    }
-
-    template <int NS>
-    __device__ static __forceinline__ void mfmas(const Frag<NS>& f, f32x4 (&acc)[TC::MI][TC::NI]) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC::NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s][mi], f.b[s][ni], acc[mi][ni], 0, 0, 0);
-    }
-
-    // One slab: [reads half0] [reads half1] | MFMAs half0 | LDS writes of the next slab | MFMAs half1.
-    // The sched_barriers pin that order: left alone, hipcc sinks every ds_read next to its first use and reuses the
-    // same two VGPRs (read -> lgkmcnt(0) -> 4 MFMAs -> read ...), exposing the LDS latency 8 times per slab
-    // (measured: 40-45 % MFMA utilisation in steady state).  With both halves' fragments in flight the counted
-    // lgkmcnt waits fall behind >= 16 queued MFMAs.
-    template <bool STORE>
-    __device__ static __forceinline__ void slab(const OpA& a, const OpB& b, const float* Ac, const float* Bc, float* An,
-                                                float* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
+    __device__ static __forceinline__ void read_frags(const float* Ac, const float* Bc, Frag& f) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave / TC::WN, wn = wave % TC::WN;
         const int l15 = lane & 15, lq = lane >> 4;
-        const float* Ab = A_KC ? Ac + (wm * TC::WTM + l15) * LDA + lq : Ac + lq * LDA + wm * TC::WTM + l15;
-        const float* Bb = B_KC ? Bc + (wn * TC::WTN + l15) * LDB + lq : Bc + lq * LDB + wn * TC::WTN + l15;
-        Frag<NS0> f0;
-        Frag<NS1> f1;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi) {
+                const int x = wm * TC::WTM + mi * 16 + l15;
+                if (A_KC) {  // one 16-byte read: k = 16h + 4*lq + {0,1,2,3}
+                    const float4 v = *reinterpret_cast<const float4*>(Ac + x * LDA + 16 * h + 4 * lq);
+                    f.a[h][mi][0] = v.x; f.a[h][mi][1] = v.y; f.a[h][mi][2] = v.z; f.a[h][mi][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = PERM ? 16 * h + 4 * lq + j : 16 * h + 4 * j + lq;
+                        f.a[h][mi][j] = Ac[k * LDA + x];
+                    }
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) {
+                const int x = wn * TC::WTN + ni * 16 + l15;
+                if (B_KC) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bc + x * LDB + 16 * h + 4 * lq);
+                    f.b[h][ni][0] = v.x; f.b[h][ni][1] = v.y; f.b[h][ni][2] = v.z; f.b[h][ni][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = PERM ? 16 * h + 4 * lq + j : 16 * h + 4 * j + lq;
+                        f.b[h][ni][j] = Bc[k * LDB + x];
+                    }
+                }
+            }
+        }
+    }
+
+    template <int H0, int H1>
+    __device__ static __forceinline__ void mfmas(const Frag& f, f32x4 (&acc)[TC::MI][TC::NI]) {
+#pragma unroll
+        for (int h = H0; h < H1; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TC::NI; ++ni) {
+                        if (CPG_ABLATE & 8) {  // no matrix instructions: keep the operands live with one VALU op instead
+                            acc[mi][ni][0] += f.a[h][mi][j] * f.b[h][ni][j];
+                        } else {
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[h][mi][j], f.b[h][ni][j], acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+    }
+
+    // One slab: [fragment reads of the whole slab] | MFMAs first half | LDS writes of the next slab | MFMAs second half.
+    // The sched_barriers pin that order: left alone, hipcc sinks every ds_read next to its first use and reuses the
+    // same VGPRs (read -> lgkmcnt(0) -> 4 MFMAs -> read ...), exposing the LDS latency once per k-step.
+    template <bool STORE>
+    __device__ static __forceinline__ void slab(const OpA& a, const OpB& b, const float* Ac, const float* Bc, float* An,
+                                                float* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
+        Frag f;
         if (CPG_ABLATE & 2) {  // keep the registers live and opaque, but do not touch the LDS
 #pragma unroll
-            for (int s = 0; s < NS0; ++s) {
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int mi = 0; mi < TC::MI; ++mi) { f0.a[s][mi] = acc[mi][0][0]; f1.a[s][mi] = acc[mi][0][1]; }
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int ni = 0; ni < TC::NI; ++ni) { f0.b[s][ni] = acc[0][ni][2]; f1.b[s][ni] = acc[0][ni][3]; }
-            }
+                    for (int mi = 0; mi < TC::MI; ++mi) f.a[h][mi][j] = acc[mi][0][j];
+#pragma unroll
+                    for (int ni = 0; ni < TC::NI; ++ni) f.b[h][ni][j] = acc[0][ni][(j + 1) & 3];
+                }
         } else {
-            read_frags<NS0>(Ab, Bb, 0, f0);
-            read_frags<NS1>(Ab, Bb, KH, f1);
+            read_frags(Ac, Bc, f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfmas<NS0>(f0, acc);
+        mfmas<0, NH / 2>(f, acc);
         __builtin_amdgcn_sched_barrier(0);
         if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas<NS1>(f1, acc);
+        mfmas<NH / 2, NH>(f, acc);
     }
 
     // acc[mi][ni] += A_tile * B_tile over the whole K range.  Uses TC::smem_floats<A_KC,B_KC>() floats of dynamic LDS.
@@ -314,14 +363,15 @@ struct MainLoop {
         float* const B0 = cpg_smem + 2 * ASZ;
         float* const B1 = cpg_smem + 2 * ASZ + BSZ;
         Stage st;
+        Plan pl;
+        plan(a, b, pl);
         const int KT = (K + BK - 1) / BK;
-        gload(a, b, 0, K, st);
+        gload(a, b, pl, 0, K, st);
         sstore(a, b, A0, B0, st);
         __syncthreads();
-#if CPG_LOOP_UNROLL2
         for (int kt = 0; kt < KT; kt += 2) {
             if (kt + 1 < KT) {
-                if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 1) * BK, K, st);
+                if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 1) * BK, K, st);
                 slab<true>(a, b, A0, B0, A1, B1, st, acc);
             } else {
                 slab<false>(a, b, A0, B0, A1, B1, st, acc);
@@ -329,31 +379,13 @@ struct MainLoop {
             if (!(CPG_ABLATE & 4)) __syncthreads();
             if (kt + 1 >= KT) break;
             if (kt + 2 < KT) {
-                if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 2) * BK, K, st);
+                if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 2) * BK, K, st);
                 slab<true>(a, b, A1, B1, A0, B0, st, acc);
             } else {
                 slab<false>(a, b, A1, B1, A0, B0, st, acc);
             }
             if (!(CPG_ABLATE & 4)) __syncthreads();
         }
-#else
-        // single loop body; the buffer toggle is integer arithmetic on offsets from the __shared__ symbol (keeps the
-        // accesses ds_*), and avoids the accumulator copies hipcc inserts between the two halves of an unrolled pair
-        for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            const float* Ac = cpg_smem + cur * ASZ;
-            const float* Bc = cpg_smem + 2 * ASZ + cur * BSZ;
-            float* An = cpg_smem + (cur ^ 1) * ASZ;
-            float* Bn = cpg_smem + 2 * ASZ + (cur ^ 1) * BSZ;
-            if (kt + 1 < KT) {
-                if (!(CPG_ABLATE & 1)) gload(a, b, (kt + 1) * BK, K, st);
-                slab<true>(a, b, Ac, Bc, An, Bn, st, acc);
-            } else {
-                slab<false>(a, b, Ac, Bc, An, Bn, st, acc);
-            }
-            if (!(CPG_ABLATE & 4)) __syncthreads();
-        }
-#endif
     }
 };
 
