@@ -26,6 +26,9 @@
 #ifndef CPG_ABLATE
 #define CPG_ABLATE 0
 #endif
+#ifndef CPG_SCHED
+#define CPG_SCHED 0
+#endif
 #ifndef CPG_LOOP_UNROLL2
 #define CPG_LOOP_UNROLL2 1
 #endif
@@ -346,11 +349,28 @@ struct MainLoop {
             read_frags(Ac, Bc, f);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if CPG_SCHED == 0
         mfmas<0, NH / 2>(f, acc);
         __builtin_amdgcn_sched_barrier(0);
         if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
         __builtin_amdgcn_sched_barrier(0);
         mfmas<NH / 2, NH>(f, acc);
+#elif CPG_SCHED == 1
+        // free interleaving of the LDS stores with the matrix instructions
+        mfmas<0, NH / 2>(f, acc);
+        if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
+        mfmas<NH / 2, NH>(f, acc);
+#else
+        // explicit pattern: one MFMA, then up to CPG_SCHED-1 VALU/DS-write instructions of the staging code, repeated
+        mfmas<0, NH>(f, acc);
+        if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
+#pragma unroll
+        for (int i = 0; i < NH * 4 * TC::MI * TC::NI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, CPG_SCHED - 1, 0);  // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);              // DS write
+        }
+#endif
     }
 
     // acc[mi][ni] += A_tile * B_tile over the whole K range.  Uses TC::smem_floats<A_KC,B_KC>() floats of dynamic LDS.

@@ -196,3 +196,35 @@ def test_class_kernels_golden(golden):
     got = acc.cpu().numpy().astype(bool)
     near = np.abs(g["uniforms"] - g["prob_accum"]) < 1e-12
     assert np.array_equal(got[~near], g["accepted"][~near])
+
+
+def test_split_and_row_range_forms_match_fused():
+    """cpg_gru_seq_fwd over row ranges, and the split (product + cell kernel) form, are bit-identical to the fused full-batch
+    sequence: rows are independent recurrences and both forms run the same k-ordered f32 products."""
+    from cpg.ops import _p, _stream, call
+    g = torch.Generator().manual_seed(0)
+    B, H, T, V = 200, 96, 6, 24
+    dev = torch.device("cuda")
+    w_hh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(dev)
+    b_hh = (torch.randn(3 * H, generator=g) * 0.1).to(dev)
+    tab = (torch.randn(V, 3 * H, generator=g) * 0.3).to(dev)
+    rowc = (torch.randn(B, 3 * H, generator=g) * 0.3).to(dev)
+    tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
+    h0 = torch.randn(B, H, generator=g).to(dev)
+    outs = []
+    for mode in ("fused", "rows", "split"):
+        hs = torch.zeros(T + 1, B, H, device=dev)
+        hs[0] = h0
+        gates = torch.zeros(T, 4, B, H, device=dev)
+        gh = torch.empty(B, 3 * H, device=dev)
+        if mode == "fused":
+            call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, _stream())
+        elif mode == "rows":
+            for r0, r1 in ((0, 64), (64, 128), (128, B)):
+                call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1, _stream())
+        else:
+            call("cpg_gru_seq_fwd_split", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates),
+                 _p(gh), 0, B, _stream())
+        outs.append((hs.clone(), gates.clone()))
+    for hs, gates in outs[1:]:
+        assert torch.equal(hs, outs[0][0]) and torch.equal(gates, outs[0][1])
