@@ -194,10 +194,12 @@ using LF64 = TileCfg<64, 128, 32, 2, 2, 4>;
 using LF32 = TileCfg<32, 128, 32, 2, 2, 4>;
 using LB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using LB32 = TileCfg<32, 64, 32, 2, 2, 1>;
+using LB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
 static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
-    if (a.B > 32) {
+    // same tile policy as the GRU kernels: 32-row tiles once they give >= 1024 workgroups
+    if (a.B > 32 && (long)cdiv(a.B, 32) * cdiv(a.H, 32) < 1024) {
         dim3 grid(cdiv(a.H, LF64::BN / 4), cdiv(a.B, LF64::BM));
         const size_t smem = LF64::smem_floats<true, true>() * sizeof(float);
         if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, true>), grid, dim3(256), smem, s, a);
@@ -214,7 +216,12 @@ static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
 
 static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
-    if (a.B > 32) {
+    if ((long)cdiv(a.B, 32) * cdiv(a.H, 32) >= 1024) {
+        dim3 grid(cdiv(a.H, LB32N::BN), cdiv(a.B, LB32N::BM));
+        const size_t smem = LB32N::smem_floats<true, false>() * sizeof(float);
+        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, true>), grid, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, false>), grid, dim3(256), smem, s, a);
+    } else if (a.B > 32) {
         dim3 grid(cdiv(a.H, LB64::BN), cdiv(a.B, LB64::BM));
         const size_t smem = LB64::smem_floats<true, false>() * sizeof(float);
         if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, true>), grid, dim3(256), smem, s, a);
