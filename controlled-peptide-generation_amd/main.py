@@ -1,15 +1,15 @@
-"""Phase-1 entry point on the MI355X path: `python main.py [--tiny 1] [--phase 1] [--<cfg.key> value]`
-(counterpart of the reference's main.py:30-86; same flag syntax, same files under output/<run>/).
+"""Phase-1 entry point on the MI355X path: `python main.py [--tiny 1] [--phase 1] [--<cfg.key> value]`.
 
-cfg -> seeds -> json logger -> data -> RNN_VAE -> (load) -> train_vae -> sample `cfg.evals.sample_size` peptides ->
-vae_gen.txt -> result.json / vae_result.json.  Data: the reference's torchtext-0.3.1 CSV loader and its curated files
-are not reproducible, so batches come from cpg.synth.SyntheticPeptideLoader (cfg.hw.synthetic_data).
-Launch N ranks with `python -m torch.distributed.run --nproc-per-node N main.py ...` for data-parallel training.
+Counterpart of the reference's main.py:30-86 - same flag syntax and the same files under output/<run>/
+(config_overrides.json, config_complete.json, vocab.dict, model_<it>.pt, vae_gen.txt, result.json, vae_result.json).
+Stages: configuration -> seeding -> metric log -> data -> model (-> checkpoint) -> train_vae -> prior samples -> export.
+Data: the reference's torchtext-0.3.1 CSV loader and its curated files are not reproducible; batches come
+from cpg.synth.SyntheticPeptideLoader.  `python -m torch.distributed.run --nproc-per-node N main.py ...` trains data-parallel.
 """
 import argparse
 import logging
+import os
 import random
-from os.path import join as pjoin
 
 import numpy as np
 import torch
@@ -24,42 +24,37 @@ from models.model import RNN_VAE
 from train_vae import train_vae
 
 log = logging.getLogger()
-log.setLevel(logging.INFO)
-if not log.handlers:
-    h = logging.StreamHandler()
-    h.setFormatter(logging.Formatter('%(asctime)s - %(levelname)s(%(name)s): %(message)s'))
-    log.addHandler(h)
 
 
-def run(argv=None):
+def _console_logging():
+    log.setLevel(logging.INFO)
+    if log.handlers:
+        return
+    handler = logging.StreamHandler()
+    handler.setFormatter(logging.Formatter('%(asctime)s - %(levelname)s(%(name)s): %(message)s'))
+    log.addHandler(handler)
+
+
+def _configure(argv):
     parser = argparse.ArgumentParser(argument_default=argparse.SUPPRESS, description='Override config float & string values')
     cfg._cfg_import_export(parser, cfg, mode='fill_parser')
-    args = parser.parse_args(argv)
-    cfg._override_config(args, cfg)
+    overrides = parser.parse_args(argv)
+    cfg._override_config(overrides, cfg)
     cfg._update_cfg()
-    world, rank, local = cdist.init()
-    if rank == 0:
-        cfg._print(cfg)
-        cfg._save_config(args, cfg, cfg.savepath)
-    if not torch.cuda.is_available() or cfg.ignore_gpu:
-        raise RuntimeError('the MI355X build has no CPU path (cfg.ignore_gpu / no visible GPU)')
-    local = cdist.local_device(local)
-    torch.cuda.set_device(local)
-    device = torch.device('cuda', local)
-    cfg.seed = cfg.seed if cfg.seed else random.randint(1, 10000)
+    return overrides
+
+
+def _seed_everything(rank):
+    if not cfg.seed:
+        cfg.seed = random.randint(1, 10000)
     log.info('Random seed: {}'.format(cfg.seed))
-    torch.manual_seed(cfg.seed)
-    np.random.seed(cfg.seed + rank)
+    torch.manual_seed(cfg.seed)          # identical initial weights on every rank
+    np.random.seed(cfg.seed + rank)      # host-side draws differ per rank
     random.seed(cfg.seed)
-    tb_json_logger.configure(cfg.tbpath, pjoin(cfg.savepath, 'result.json') if cfg.resume_result_json else None)
 
-    dataset = SyntheticPeptideLoader(cfg.vae.batch_size, cfg.max_seq_len, device, size=cfg.hw.synthetic_size,
-                                     seed=cfg.seed, rank=rank)
-    dataset.print_stats()
-    if rank == 0:
-        utils.save_vocab(dataset.TEXT.vocab, cfg.vocab_path)
 
-    model = RNN_VAE(n_vocab=dataset.n_vocab, max_seq_len=cfg.max_seq_len, **cfg.model).to(device)
+def _build_model(n_vocab, device, rank, world):
+    model = RNN_VAE(n_vocab=n_vocab, max_seq_len=cfg.max_seq_len, **cfg.model).to(device)
     model.device = device
     log.info(model)
     if cfg.loadpath:
@@ -70,22 +65,48 @@ def run(argv=None):
         model.use_device_rng(cfg.seed + 7919 * rank)
         losses.set_prior_sampler(lambda z: model._randn(z.shape[0], z.shape[1]))
     cdist.broadcast_params(model.parameters())
-    reduce_fn = None
-    if world > 1:
-        reduce_fn = cdist.allreduce_sum
+    reduce_fn = cdist.allreduce_sum if world > 1 else None
+    if reduce_fn is not None:
         losses.set_distributed(reduce_fn, world)
+    return model, reduce_fn
+
+
+def run(argv=None):
+    _console_logging()
+    overrides = _configure(argv)
+    world, rank, local = cdist.init()
+    lead = rank == 0
+    if lead:
+        cfg._print(cfg)
+        cfg._save_config(overrides, cfg, cfg.savepath)
+    if cfg.ignore_gpu or not torch.cuda.is_available():
+        raise RuntimeError('the MI355X build has no CPU path (cfg.ignore_gpu / no visible GPU)')
+    local = cdist.local_device(local)
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    _seed_everything(rank)
+    resume = os.path.join(cfg.savepath, 'result.json') if cfg.resume_result_json else None
+    tb_json_logger.configure(cfg.tbpath, resume)
+
+    dataset = SyntheticPeptideLoader(cfg.vae.batch_size, cfg.max_seq_len, device, size=cfg.hw.synthetic_size,
+                                     seed=cfg.seed, rank=rank)
+    dataset.print_stats()
+    if lead:
+        utils.save_vocab(dataset.TEXT.vocab, cfg.vocab_path)
+    model, reduce_fn = _build_model(dataset.n_vocab, device, rank, world)
 
     if cfg.phase in [1]:
         train_vae(cfg.vae, model, dataset, reduce_fn=reduce_fn, world=world, rank=rank)
-        if rank == 0:
+        if lead:
             log.info("Evaluating base vae...")
             with torch.no_grad():
                 samples, _, _ = model.generate_sentences(cfg.evals.sample_size, sample_mode='categorical')
             utils.write_gen_samples(dataset.idx2sentences(samples.cpu(), False), cfg.vae.gen_samples_path)
-    if rank == 0:
+    if lead:
         log.info('saving result.json and vae_result.json at {}'.format(cfg.savepath))
-        tb_json_logger.export_to_json(pjoin(cfg.savepath, 'result.json'))
-        tb_json_logger.export_to_json(pjoin(cfg.savepath, 'vae_result.json'), it_filter=lambda k, v: k <= cfg.vae.n_iter)
+        tb_json_logger.export_to_json(os.path.join(cfg.savepath, 'result.json'))
+        tb_json_logger.export_to_json(os.path.join(cfg.savepath, 'vae_result.json'),
+                                      it_filter=lambda it, row: it <= cfg.vae.n_iter)
 
 
 if __name__ == "__main__":
