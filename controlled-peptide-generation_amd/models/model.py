@@ -134,11 +134,11 @@ class RNN_VAE(nn.Module):
 
     def forward_classifier(self, inputs):
         if inputs.dim() == 2:
-            x = self.word_emb(inputs)
+            return self.classifier.forward_tokens(inputs, self.word_emb.weight)
         else:
             from models.mutils import soft_embed
             x = soft_embed(self.word_emb, inputs)
-        return self.classifier(x)
+            return self.classifier(x)
 
     def forward(self, sequences, q_c='prior', sample_z=1, rnd=None):
         """-> ((mu, logvar), (z, c), dec_logits [mbsize, seq_len, n_vocab])"""

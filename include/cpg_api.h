@@ -198,6 +198,12 @@ CPG_API int cpg_lr_score_accept(const float* z, int n, int D, const double* coef
                                 const int32_t* target, int A, const double* uniforms, double* probs, double* accum,
                                 uint8_t* accepted, void* stream);
 
+/* ---- CNN classifier forward (ADJACENT row, inference only): models/classifier.py:39-60 ------------------------------
+ * pooled[B, nconv*F] = max_p relu(bias + sum_dw tab[dw][ids[b,p+dw]]) for filters of widths min_width..min_width+nconv-1;
+ * tabs = per layer [w][V][F] tables emb @ W[:,0,dw,:]^T (cpg_linear_fwd), layers back to back; bias [nconv,F]. */
+CPG_API int cpg_cnn_classifier_pool(const int64_t* ids, int B, int T, int V, int F, int min_width, int nconv,
+                                    const float* tabs, const float* bias, float* pooled, void* stream);
+
 /* ---- counter-based random streams (Philox4x32-10) for callers that do not inject the draws ----------------------- */
 CPG_API int cpg_rng_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
 CPG_API int cpg_rng_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);

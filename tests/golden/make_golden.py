@@ -445,7 +445,7 @@ def class_vectors(seed=1238, D=14, K=5, n=4000):
     print("class_small.npz: accept rate", accepted.mean())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("CPG_GOLDEN_ONLY"):
     torch.set_num_threads(4)
     # config A: reference defaults (cfg.py:262-274): z=100, enc h=80 biGRU 1 layer, emb 150
     model_vectors("A", 1238, B=16, N_greedy=256, N_beam=64, z_regu_variants=["mmdrf"],
@@ -463,3 +463,26 @@ if __name__ == "__main__":
     train_vectors("A_clip", 1238, B=8, n_iter=1, clip=0.25, z_regu="mmdrf",
                   **model_kwargs(z_dim=100, enc_h=80))
     class_vectors()
+
+
+# ------------------------------------------------------------------ CNN classifier logits (G11) - separate small fixture
+def classifier_vectors(name="A", seed=1238, B=16, **kw):
+    model = build(seed, **kw)
+    model.eval()
+    gen = torch.Generator().manual_seed(seed)
+    ids = synth_ids(B, T, V, gen)
+    with torch.no_grad():
+        logits = model.forward_classifier(ids)
+        np.random.seed(seed + 41)
+        cap = Capture()
+        with cap.on():
+            (mu, logvar), (z, c), dec = model(ids, q_c='classifier', sample_z='max')
+    out = {"w." + k: v.detach().numpy().copy() for k, v in model.state_dict().items()
+           if k.startswith("classifier") or k == "word_emb.weight"}
+    out.update(ids=ids.numpy(), logits=logits.numpy(), c_softmax=c.numpy())
+    np.savez_compressed(os.path.join(OUT, f"classifier_{name}.npz"), **out)
+    print(f"classifier_{name}.npz written")
+
+
+if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "classifier":
+    classifier_vectors("A", 1238, **model_kwargs(z_dim=100, enc_h=80))

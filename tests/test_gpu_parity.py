@@ -228,3 +228,19 @@ def test_split_and_row_range_forms_match_fused():
         outs.append((hs.clone(), gates.clone()))
     for hs, gates in outs[1:]:
         assert torch.equal(hs, outs[0][0]) and torch.equal(gates, outs[0][1])
+
+
+def test_cnn_classifier_forward_golden(golden):
+    """q_c='classifier' path (adjacent row): HIP token-table convolution + max-pool + fc vs the reference's CNNClassifier."""
+    g = golden("classifier_A")
+    full = golden("model_A")
+    P = dict(weights_of(full))
+    P.update(weights_of(g))
+    m = build_model({k: v for k, v in P.items()})
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights_of(g).items()}, strict=False)
+    m.eval()
+    ids = cu(g["ids"])
+    logits = m.forward_classifier(ids)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=1e-4)
+    (mu, lv), (z, c), dec = m(ids, q_c='classifier', sample_z='max')
+    np.testing.assert_allclose(c.cpu().numpy(), g["c_softmax"], atol=1e-4)

@@ -9,7 +9,7 @@ i=0
 for flags in "" "$@"; do
   i=$((i+1))
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden $flags -I $SRC \
-     $SRC/api.hip $SRC/gemm.hip $SRC/gru.hip $SRC/lstm.hip $SRC/decode.hip $SRC/losses.hip $SRC/optim.hip $SRC/rng.hip $SRC/class.hip \
+     $SRC/api.hip $SRC/gemm.hip $SRC/gru.hip $SRC/lstm.hip $SRC/decode.hip $SRC/losses.hip $SRC/optim.hip $SRC/rng.hip $SRC/class.hip $SRC/classifier.hip \
      -o /tmp/libcpg_var_$i.so
   echo "== flags: '$flags'"
   CPG_LIB_PATH=/tmp/libcpg_var_$i.so python tools/kbench.py --iters 5 $KBENCH_ARGS | grep "^\[1\]"
