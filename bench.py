@@ -227,9 +227,19 @@ def class_bench(dev, N=262144):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = 25  # the device loop always runs max_seq_len steps
-    return {"workload": f"config A (z=100, dec h=102), {N} z: LR score+accept, greedy decode of all z",
+    # beam-5 / n_best-3 decode (the reference's decode_from_z mode), incl. the host-side hypothesis reconstruction
+    from cpg import decode as cdecode
+    Nb = 32768
+    cdecode.decode_beam_raw(m.decoder, z[:1024], c[:1024], 25)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tok, prev, score = cdecode.decode_beam_raw(m.decoder, z[:Nb], c[:Nb], 25, beam_size=5, n_best=3)
+    hyps, lens, _ = cdecode.beam_hypotheses(tok, prev, score, 3)
+    dtb = time.perf_counter() - t0
+    return {"workload": f"config A (z=100, dec h=102), {N} z: LR score+accept, greedy decode of all z; beam-5 on {Nb} z",
             "z_per_s": round(N / dt, 1), "decoder_evals_per_s": round(N * steps / dt, 1),
-            "accepted_per_s": round(float(acc.sum().item()) / dt, 1)}
+            "accepted_per_s": round(float(acc.sum().item()) / dt, 1),
+            "beam5_z_per_s": round(Nb / dtb, 1), "beam5_decoder_evals_per_s": round(Nb * 5 * tok.shape[0] / dtb, 1)}
 
 
 if __name__ == "__main__":
