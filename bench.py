@@ -28,7 +28,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X f32-input MFMA = f32 vector peak (MI355X_
 # passes over tools/kbench.py at the bench shapes; (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 read-side correction
 # of MI355X_MICROARCH.md section HBM).  Counters cannot be collected from inside this script; the numbers and commands are
 # in profiles/r01_bench_n1_summary_final.md.  Only valid for the default GRU / B=2048 / H=512 workload.
-PMC_TRAFFIC_BYTES = {("gru", 2048, 512): (2 * 21.3 + 22.6) * 1024 * 1024}
+PMC_TRAFFIC_BYTES = {("gru", 2048, 512): (2 * 21.1 + 22.0) * 1024 * 1024}
 
 
 def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, cell='gru'):
