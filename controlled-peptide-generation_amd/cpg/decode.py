@@ -3,8 +3,8 @@
 greedy / categorical: one fused GRU-step launch + one vocab projection + one select kernel per step, no host sync
 inside the loop (the reference syncs every step for `finished.sum() == mbsize`); the output is cut where the
 reference's loop would have stopped using a per-step counter read back once.
-beam: Beam.advance for all sentences in one kernel per step (models/Beam.py:56-105), hypotheses rebuilt on the host
-from the recorded back-pointers exactly as Beam.sort_finished / get_hyp do (Beam.py:110-132).
+beam: Beam.advance for all sentences in one kernel per step (models/Beam.py:56-105), hypotheses rebuilt by one more
+kernel from the recorded back-pointers exactly as Beam.sort_finished / get_hyp do (Beam.py:110-132).
 """
 import numpy as np
 import torch
@@ -76,8 +76,8 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
 
 @torch.no_grad()
 def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
-    """Runs the device beam search; returns numpy (tok, prev, score) each [T,N,K] (tok = -1 where a sentence had
-    already finished) for host-side hypothesis reconstruction."""
+    """Runs the device beam search; returns device tensors (tok, prev, score) each [T,N,K] (tok = -1 where a sentence
+    had already finished): the recorded history cpg_beam_hypotheses walks back."""
     if getattr(decoder, "cell", "gru") != "gru":
         raise NotImplementedError("beam search is implemented for the GRU decoder (the reference's cell)")
     N = z.shape[0]
@@ -117,11 +117,26 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
         steps_run = i + 1
         if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early
             break
-    return (hist_tok[:steps_run].cpu().numpy(), hist_prev[:steps_run].cpu().numpy(), hist_score[:steps_run].cpu().numpy())
+    return hist_tok[:steps_run], hist_prev[:steps_run], hist_score[:steps_run]
+
+
+@torch.no_grad()
+def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
+    """Beam search + hypothesis walk-back, all on device.  Returns numpy (hyps int32 [N,n_best,T+1] padded with -1,
+    lengths [N,n_best] incl. the leading <start>, scores [N,n_best])."""
+    tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length)
+    T, N, K = tok.shape
+    hyps = torch.empty(N, n_best, T + 1, device=tok.device, dtype=torch.int32)
+    lens = torch.empty(N, n_best, device=tok.device, dtype=torch.int32)
+    sc = torch.empty(N, n_best, device=tok.device, dtype=torch.float32)
+    call("cpg_beam_hypotheses", _p(tok), _p(prev), _p(score), T, N, K, n_best, EOS_IDX, START_IDX, _p(hyps), _p(lens), _p(sc),
+         _stream())
+    return hyps.cpu().numpy(), lens.cpu().numpy(), sc.cpu().numpy()
 
 
 def beam_hypotheses(tok, prev, score, n_best):
-    """Vectorised Beam.sort_finished + get_hyp over all sentences.
+    """Host (numpy) statement of what cpg_beam_hypotheses computes - Beam.sort_finished + get_hyp over all sentences;
+    kept as the cross-check of the device kernel in tests/.  tok/prev/score: numpy [T,N,K].
     Returns (hyps int64 [N,n_best,T+1] padded with -1, lengths [N,n_best], scores [N,n_best])."""
     T, N, K = tok.shape
     adv = (tok[:, :, 0] >= 0)                          # [T,N] step advanced for sentence i
@@ -153,6 +168,5 @@ def beam_hypotheses(tok, prev, score, n_best):
 
 def decode_beam(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
     """Reference-format result: list over sentences of n_best hypotheses, each a list of ints incl. leading <start>."""
-    tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length)
-    hyps, lens, _ = beam_hypotheses(tok, prev, score, n_best)
+    hyps, lens, _ = decode_beam_arrays(decoder, z, c, max_len, beam_size, n_best, min_length)
     return [[hyps[i, j, :lens[i, j]].tolist() for j in range(n_best)] for i in range(hyps.shape[0])]

@@ -230,3 +230,85 @@ CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int ste
     CPG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------ beam hypotheses
+// Beam.sort_finished + Beam.get_hyp (models/Beam.py:110-132) for every sentence, one thread each, from the recorded
+// (token, back-pointer, score) history [T,N,K].  Finished entries are ranked in insertion order (step asc, beam asc) by
+// raw summed log-prob, ties keep the earlier entry (python's stable sort); when fewer than n_best finished the live beam's
+// first (n_best - n_finished) entries of the last advanced step are appended.  hyps[i][b] = <start> + tokens, -1 padded.
+__global__ void beam_hyp_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ prev,
+                                const float* __restrict__ score, int T, int N, int K, int n_best, int eos, int start,
+                                int32_t* __restrict__ hyps, int32_t* __restrict__ lens, float* __restrict__ out_sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float bs[CPG_MAX_BEAM];
+    int bt[CPG_MAX_BEAM], bk[CPG_MAX_BEAM];
+#pragma unroll
+    for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+        bs[p] = -INFINITY;
+        bt[p] = 0;
+        bk[p] = 0;
+    }
+    auto insert = [&](float cs, int ct, int ck) {
+        bool carried = false;  // a displaced entry is older than everything below it: it wins ties on the way down
+#pragma unroll
+        for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+            if (p >= n_best) break;
+            if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
+                const float fs = bs[p];
+                const int ft = bt[p], fk = bk[p];
+                bs[p] = cs;
+                bt[p] = ct;
+                bk[p] = ck;
+                cs = fs;
+                ct = ft;
+                ck = fk;
+                carried = true;
+            }
+        }
+    };
+    int Ti = 0, nfin = 0;
+    for (int t = 0; t < T; ++t) {
+        const size_t b = ((size_t)t * N + i) * K;
+        if (tok[b] >= 0) ++Ti;
+        for (int k = 0; k < K; ++k)
+            if (tok[b + k] == eos) {
+                ++nfin;
+                insert(score[b + k], t + 1, k);
+            }
+    }
+    const int need = min(max(n_best - nfin, 0), n_best);
+    const int last = min(max(Ti - 1, 0), T - 1);
+    for (int j = 0; j < need; ++j) insert(score[((size_t)last * N + i) * K + j], Ti, j);
+    const int L = T + 1;
+#pragma unroll
+    for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+        if (p >= n_best) break;
+        int32_t* h = hyps + ((size_t)i * n_best + p) * L;
+        const int tl = bt[p];
+        int cur = bk[p];
+        h[0] = start;
+        for (int j = T - 1; j >= 0; --j) {
+            if (j < tl) {
+                const size_t b = ((size_t)j * N + i) * K + cur;
+                h[j + 1] = tok[b];
+                cur = prev[b];
+            } else {
+                h[j + 1] = -1;
+            }
+        }
+        lens[(size_t)i * n_best + p] = tl + 1;
+        out_sc[(size_t)i * n_best + p] = bs[p];
+    }
+}
+
+CPG_EXPORT int cpg_beam_hypotheses(const int32_t* hist_tok, const int32_t* hist_prev, const float* hist_score, int T, int N,
+                                   int K, int n_best, int eos, int start, int32_t* hyps, int32_t* lens, float* scores,
+                                   void* stream) {
+    CPG_CHECK_ARG(hist_tok && hist_prev && hist_score && hyps && lens && scores);
+    CPG_CHECK_ARG(T > 0 && N > 0 && K > 0 && K <= CPG_MAX_BEAM && n_best > 0 && n_best <= K);
+    hipLaunchKernelGGL(beam_hyp_kernel, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, hist_tok, hist_prev, hist_score,
+                       T, N, K, n_best, eos, start, hyps, lens, scores);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}

@@ -150,6 +150,12 @@ CPG_API int cpg_beam_select(const float* logits, int N, int V, int K, int step, 
                             int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
                             int32_t* hist_tok, int32_t* hist_prev, float* hist_score, int32_t* origin, int32_t* tok_next,
                             int* n_active, const float* h_in, float* h_out, int H, void* stream);
+/* Beam.sort_finished + get_hyp (models/Beam.py:110-132) for all sentences from the recorded history: finished entries
+ * ranked by raw summed log-prob (stable, insertion order = step then beam), topped up from the live beam of the last
+ * advanced step.  hyps int32 [N,n_best,T+1] (<start> first, -1 padded), lens/scores [N,n_best]. */
+CPG_API int cpg_beam_hypotheses(const int32_t* hist_tok, const int32_t* hist_prev, const float* hist_score, int T, int N,
+                                int K, int n_best, int eos, int start, int32_t* hyps, int32_t* lens, float* scores,
+                                void* stream);
 
 /* ---- losses (losses.py) ------------------------------------------------------------------------------------ */
 /* recon_dec, losses.py:18-31: targets = cat(ids[:,1:], PAD). out[0] = sum NLL over non-PAD targets, out[1] = their count.

@@ -244,3 +244,31 @@ def test_cnn_classifier_forward_golden(golden):
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=1e-4)
     (mu, lv), (z, c), dec = m(ids, q_c='classifier', sample_z='max')
     np.testing.assert_allclose(c.cpu().numpy(), g["c_softmax"], atol=1e-4)
+
+
+@pytest.mark.parametrize("n_best", [1, 3, 5])
+def test_beam_hypotheses_kernel_matches_host_statement(n_best):
+    """cpg_beam_hypotheses vs cpg.decode.beam_hypotheses (itself pinned to the oracle and the reference's hypotheses in
+    test_host_logic) on synthetic histories: many EOS entries, exact score ties, sentences that stop advancing early."""
+    from cpg.decode import beam_hypotheses
+    from cpg.ops import call, _p, _stream
+    rs = np.random.RandomState(3)
+    T, N, K = 25, 777, 5
+    tok = rs.randint(3, 9, size=(T, N, K)).astype(np.int32)          # token 3 = <eos> appears often
+    prev = rs.randint(0, K, size=(T, N, K)).astype(np.int32)
+    score = np.round(rs.randn(T, N, K).astype(np.float32), 1)         # coarse grid -> plenty of exact ties
+    stop = rs.randint(1, T + 1, size=N)                               # steps advanced per sentence
+    stop[:50] = T
+    for i in range(N):
+        tok[stop[i]:, i, :] = -1
+    tok[:, 100:140, :][tok[:, 100:140, :] == 3] = 4                   # sentences with no finished entry at all
+    ref_h, ref_l, ref_s = beam_hypotheses(tok, prev, score, n_best)
+    d = torch.device("cuda:0")
+    hy = torch.empty(N, n_best, T + 1, device=d, dtype=torch.int32)
+    ln = torch.empty(N, n_best, device=d, dtype=torch.int32)
+    sc = torch.empty(N, n_best, device=d, dtype=torch.float32)
+    t_, p_, s_ = (torch.from_numpy(a).to(d) for a in (tok, prev, score))
+    call("cpg_beam_hypotheses", _p(t_), _p(p_), _p(s_), T, N, K, n_best, 3, 2, _p(hy), _p(ln), _p(sc), _stream())
+    assert np.array_equal(ln.cpu().numpy(), ref_l)
+    assert np.array_equal(sc.cpu().numpy(), ref_s)
+    assert np.array_equal(hy.cpu().numpy(), ref_h)
