@@ -104,103 +104,121 @@ CPG_EXPORT int cpg_greedy_select(const float* logits, int N, int V, uint8_t* fin
 }
 
 // ------------------------------------------------------------------------------------------ beam
-// One wave per sentence.  Rows are beam-major (row = k*N + i).  State per sentence: scores[K], last tokens, flags.
+// One THREAD per sentence (the whole Beam.advance of a sentence is ~K*V = 120 candidates: a wave per sentence spends its
+// time in cross-lane reductions with 40 of 64 lanes idle; a thread per sentence keeps the K-best list in registers and
+// reads its K logits rows as contiguous 96-byte runs).  Rows are beam-major (row = k*N + i).
 // Restates Beam.advance: BOS column := -1e20; first step uses beam 0 only; children of EOS-ended beams := -1e20;
 // top-K over the flat K*V candidates (ties: lower flat index first); done when top beam is EOS and >= n_best finished.
 #define CPG_MAX_BEAM 8
-#define CPG_BEAM_Q 8   // candidates per lane: K*V <= 64*CPG_BEAM_Q
-__global__ void beam_select_kernel(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos,
-                                   int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
+#define CPG_BEAM_VREG 32   // vocabularies up to this size are held in registers
+template <bool VREG>
+__global__ void beam_select_kernel(const float* __restrict__ logits, int N, int V, int K, int step, int n_best, int min_length,
+                                   int bos, int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
                                    int32_t* hist_tok, int32_t* hist_prev, float* hist_score, int32_t* origin,
                                    int32_t* tok_next, int* n_active) {
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave >= N) return;
-    const int i = wave;
-    int32_t* org = origin + (size_t)i * K;
-    if (done[i]) {  // not advanced: keeps its last tokens; reference re-applies the last origin (irrelevant once done)
-        if (lane < K) tok_next[(size_t)lane * N + i] = last_tok[(size_t)i * K + lane];
-        return;
-    }
-    const int nc = K * V;
-    // candidates handled by this lane: flat index c = lane + 64*q (q < CPG_BEAM_Q, static indexing keeps them in VGPRs)
-    float cand[CPG_BEAM_Q];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = false;
+    if (i < N) {
+        if (done[i]) {  // not advanced: keeps its last tokens; reference re-applies the last origin (irrelevant once done)
+            for (int k = 0; k < K; ++k) tok_next[(size_t)k * N + i] = last_tok[(size_t)i * K + k];
+        } else {
+            float bs[CPG_MAX_BEAM];
+            int bc[CPG_MAX_BEAM];
 #pragma unroll
-    for (int q = 0; q < CPG_BEAM_Q; ++q) cand[q] = -INFINITY;
-    for (int k = 0; k < K; ++k) {
-        const float* l = logits + ((size_t)k * N + i) * V;
-        // log_softmax over V by the whole wave
-        float m = -INFINITY;
-        for (int v = lane; v < V; v += 64) m = fmaxf(m, l[v]);
-        m = wave_max(m);
-        float se = 0.f;
-        for (int v = lane; v < V; v += 64) se += expf(l[v] - m);
-        se = wave_sum(se);
-        const float lse = m + logf(se);
-        const bool parent_eos = (step > 0) && last_tok[(size_t)i * K + k] == eos;
-        const float base = step > 0 ? scores[(size_t)i * K + k] : 0.f;
-#pragma unroll
-        for (int q = 0; q < CPG_BEAM_Q; ++q) {
-            const int c = lane + 64 * q;
-            if (c >= nc || c / V != k) continue;
-            const int v = c % V;
-            float lp = l[v] - lse;
-            if (step + 1 < min_length && v == eos) lp = -1e20f;
-            if (v == bos) lp = -1e20f;
-            float sc = step > 0 ? lp + base : lp;
-            if (parent_eos) sc = -1e20f;
-            if (step == 0 && k > 0) sc = -INFINITY;  // first step: only beam 0 is a candidate row
-            cand[q] = sc;
-        }
-    }
-    float new_sc[CPG_MAX_BEAM];
-    int new_c[CPG_MAX_BEAM];
-#pragma unroll
-    for (int sel = 0; sel < CPG_MAX_BEAM; ++sel) {
-        if (sel >= K) break;
-        float bv = -INFINITY;
-        int bc = 0x7fffffff;
-#pragma unroll
-        for (int q = 0; q < CPG_BEAM_Q; ++q) {
-            const int c = lane + 64 * q;
-            if (c < nc && (cand[q] > bv || (cand[q] == bv && c < bc))) {
-                bv = cand[q];
-                bc = c;
+            for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+                bs[p] = -INFINITY;
+                bc[p] = 0;
             }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oc = __shfl_xor(bc, o, 64);
-            if (ov > bv || (ov == bv && oc < bc)) {
-                bv = ov;
-                bc = oc;
+            float worst = -INFINITY;  // bs[K-1]
+            const int kmax = step == 0 ? 1 : K;  // first step: only beam 0 is a candidate row
+            for (int k = 0; k < kmax; ++k) {
+                const float* l = logits + ((size_t)k * N + i) * V;
+                float lv[CPG_BEAM_VREG];
+                float m = -INFINITY;
+                if (VREG) {
+#pragma unroll
+                    for (int v4 = 0; v4 < CPG_BEAM_VREG / 4; ++v4)
+                        if (v4 * 4 < V) {
+                            const float4 t = *reinterpret_cast<const float4*>(l + v4 * 4);
+                            lv[v4 * 4 + 0] = t.x;
+                            lv[v4 * 4 + 1] = t.y;
+                            lv[v4 * 4 + 2] = t.z;
+                            lv[v4 * 4 + 3] = t.w;
+                        }
+#pragma unroll
+                    for (int v = 0; v < CPG_BEAM_VREG; ++v)
+                        if (v < V) m = fmaxf(m, lv[v]);
+                } else {
+                    for (int v = 0; v < V; ++v) m = fmaxf(m, l[v]);
+                }
+                float se = 0.f;
+                if (VREG) {
+#pragma unroll
+                    for (int v = 0; v < CPG_BEAM_VREG; ++v)
+                        if (v < V) se += expf(lv[v] - m);
+                } else {
+                    for (int v = 0; v < V; ++v) se += expf(l[v] - m);
+                }
+                const float lse = m + logf(se);
+                const bool parent_eos = (step > 0) && last_tok[(size_t)i * K + k] == eos;
+                const float base = step > 0 ? scores[(size_t)i * K + k] : 0.f;
+                auto consider = [&](int v, float x) {
+                    float lp = x - lse;
+                    if (step + 1 < min_length && v == eos) lp = -1e20f;
+                    if (v == bos) lp = -1e20f;
+                    float cs = step > 0 ? lp + base : lp;
+                    if (parent_eos) cs = -1e20f;
+                    if (!(cs > worst)) return;  // ties keep the earlier (lower flat index) candidate
+                    int cc = k * V + v;
+                    bool carried = false;
+#pragma unroll
+                    for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+                        if (p >= K) break;
+                        if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
+                            const float fs = bs[p];
+                            const int fc = bc[p];
+                            bs[p] = cs;
+                            bc[p] = cc;
+                            cs = fs;
+                            cc = fc;
+                            carried = true;
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < CPG_MAX_BEAM; ++p)
+                        if (p == K - 1) worst = bs[p];
+                };
+                if (VREG) {
+#pragma unroll
+                    for (int v = 0; v < CPG_BEAM_VREG; ++v)
+                        if (v < V) consider(v, lv[v]);
+                } else {
+                    for (int v = 0; v < V; ++v) consider(v, l[v]);
+                }
             }
-        }
-        new_sc[sel] = bv;
-        new_c[sel] = bc;
+            int nf = n_finished[i];
+            int top = 0;
 #pragma unroll
-        for (int q = 0; q < CPG_BEAM_Q; ++q)
-            if (lane + 64 * q == bc) cand[q] = -INFINITY;  // remove the winner (exactly one lane owns it)
-    }
-    if (lane == 0) {
-        int nf = n_finished[i];
-#pragma unroll
-        for (int k = 0; k < CPG_MAX_BEAM; ++k) {
-            if (k >= K) break;
-            const int pk = new_c[k] / V, tk = new_c[k] - pk * V;
-            scores[(size_t)i * K + k] = new_sc[k];
-            last_tok[(size_t)i * K + k] = tk;
-            org[k] = pk;
-            const size_t h = ((size_t)step * N + i) * K + k;
-            hist_tok[h] = tk;
-            hist_prev[h] = pk;
-            hist_score[h] = new_sc[k];
-            tok_next[(size_t)k * N + i] = tk;
-            if (tk == eos) ++nf;
+            for (int k = 0; k < CPG_MAX_BEAM; ++k) {
+                if (k >= K) break;
+                const int pk = bc[k] / V, tk = bc[k] - pk * V;
+                if (k == 0) top = tk;
+                scores[(size_t)i * K + k] = bs[k];
+                last_tok[(size_t)i * K + k] = tk;
+                origin[(size_t)i * K + k] = pk;
+                const size_t h = ((size_t)step * N + i) * K + k;
+                hist_tok[h] = tk;
+                hist_prev[h] = pk;
+                hist_score[h] = bs[k];
+                tok_next[(size_t)k * N + i] = tk;
+                if (tk == eos) ++nf;
+            }
+            n_finished[i] = nf;
+            if (top == eos && nf >= n_best) done[i] = 1; else active = true;
         }
-        n_finished[i] = nf;
-        const int top = new_c[0] % V;
-        if (top == eos && nf >= n_best) done[i] = 1; else atomicAdd(n_active, 1);
     }
+    const unsigned long long mask = __ballot(active);
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(n_active, __popcll(mask));
 }
 
 // h_out[k*N+i] = h_in[origin[i][k]*N + i]
@@ -219,11 +237,16 @@ CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int ste
                                int32_t* hist_prev, float* hist_score, int32_t* origin, int32_t* tok_next, int* n_active,
                                const float* h_in, float* h_out, int H, void* stream) {
     CPG_CHECK_ARG(logits && scores && last_tok && n_finished && done && hist_tok && hist_prev && hist_score && origin);
-    CPG_CHECK_ARG(N > 0 && V > 0 && K > 0 && K <= CPG_MAX_BEAM && K * V <= 64 * CPG_BEAM_Q && h_in && h_out && h_in != h_out && tok_next && n_active);
+    CPG_CHECK_ARG(N > 0 && V > 0 && K > 0 && K <= CPG_MAX_BEAM && h_in && h_out && h_in != h_out && tok_next && n_active);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(beam_select_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, logits, N, V, K, step, n_best, min_length, bos,
-                       eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,
-                       n_active + step);
+    if (V <= CPG_BEAM_VREG && V % 4 == 0)
+        hipLaunchKernelGGL(beam_select_kernel<true>, dim3(cdiv(N, 64)), dim3(64), 0, s, logits, N, V, K, step, n_best, min_length,
+                           bos, eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,
+                           n_active + step);
+    else
+        hipLaunchKernelGGL(beam_select_kernel<false>, dim3(cdiv(N, 64)), dim3(64), 0, s, logits, N, V, K, step, n_best, min_length,
+                           bos, eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,
+                           n_active + step);
     CPG_LAUNCH_CHECK();
     const size_t n = (size_t)K * N * H;
     hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h_in, h_out, origin, N, K, H);
