@@ -1,11 +1,15 @@
 """Device-resident autoregressive decoding loops (RNN_VAE.sample_G hard modes, models/model.py:225-385).
 
+greedy, small decoders (the reference default h_dim=102): the WHOLE loop is one persistent launch
+(cpg_decode_greedy_fused: W_hh in registers, state in LDS).  Otherwise
 greedy / categorical: one fused GRU-step launch + one vocab projection + one select kernel per step, no host sync
 inside the loop (the reference syncs every step for `finished.sum() == mbsize`); the output is cut where the
 reference's loop would have stopped using a per-step counter read back once.
 beam: Beam.advance for all sentences in one kernel per step (models/Beam.py:56-105), hypotheses rebuilt by one more
 kernel from the recorded back-pointers exactly as Beam.sort_finished / get_hyp do (Beam.py:110-132).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -19,6 +23,43 @@ def _fc(decoder, h, logits):
     call("cpg_vocab_fc_fwd", _p(h), None, 1.0, _p(fc.weight), _p(fc.bias), _p(logits), N, H, logits.shape[1], _stream())
 
 
+LDS_PER_WORKGROUP = 160 * 1024  # gfx950
+FUSED_GREEDY = os.environ.get("CPG_NO_FUSED_DECODE", "") == ""
+
+
+def fused_greedy_fits(H, V, Vt):
+    """Whole-loop greedy kernel: decoder small enough for W_hh in registers and the tile state in LDS."""
+    if not FUSED_GREEDY or H > 128 or V > 32:
+        return False
+    need = ops.query("cpg_decode_greedy_fused_lds_bytes", H, V, Vt)
+    return 0 < need <= LDS_PER_WORKGROUP
+
+
+def _cut_at_all_finished(ids, unfinished, max_len, min_length):
+    """The reference leaves its loop once every row has finished (model.py:362-363): cut the columns it never made."""
+    unf = unfinished.cpu().numpy()
+    steps = max_len
+    for i in range(max_len):
+        if unf[i] == 0 and (i + 2) >= min_length:  # reference: all finished and len(seqIx) >= min_length
+            steps = i + 1
+            break
+    return ids[:, :steps + 1]
+
+
+def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length):
+    N, H = zc.shape
+    fc = decoder.fc[1]
+    V = fc.weight.shape[0]
+    dev = zc.device
+    ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
+    ids[:, 0] = START_IDX
+    unfinished = torch.zeros(max_len, device=dev, dtype=torch.int32)
+    call("cpg_decode_greedy_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
+         _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, V, max_len, START_IDX, PAD_IDX, EOS_IDX, _p(ids),
+         max_len + 1, _p(unfinished), _stream())
+    return _cut_at_all_finished(ids, unfinished, max_len, min_length)
+
+
 @torch.no_grad()
 def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1):
     """ids int64 [N, 1+steps] (column 0 = <start>), steps <= max_len."""
@@ -29,8 +70,10 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     tab, rowc = tab.contiguous(), rowc.contiguous()
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
     V = decoder.fc[1].weight.shape[0]
-    h_a, h_b = zc.clone(), torch.empty_like(zc)
     lstm = getattr(decoder, "cell", "gru") == "lstm"
+    if mode == "greedy" and not lstm and not prevent_empty and fused_greedy_fits(zc.shape[1], V, tab.shape[0]):
+        return _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length)
+    h_a, h_b = zc.clone(), torch.empty_like(zc)
     if lstm:
         c_a, c_b = torch.zeros_like(zc), torch.empty_like(zc)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
@@ -65,13 +108,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         else:
             raise ValueError(mode)
         h_a, h_b = h_b, h_a
-    unf = unfinished.cpu().numpy()
-    steps = max_len
-    for i in range(max_len):
-        if unf[i] == 0 and (i + 2) >= min_length:  # reference: all finished and len(seqIx) >= min_length
-            steps = i + 1
-            break
-    return ids[:, :steps + 1]
+    return _cut_at_all_finished(ids, unfinished, max_len, min_length)
 
 
 @torch.no_grad()

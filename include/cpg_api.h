@@ -144,6 +144,15 @@ CPG_API int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uint8_
 CPG_API int cpg_greedy_select(const float* logits, int N, int V, uint8_t* finished, int64_t* ids, int ld_ids, int col,
                               int32_t* tok_next, int pad, int start, int eos, int prevent_empty, float* scratch,
                               int* unfinished, int step, void* stream);
+/* Whole greedy loop (model.py:225-385 with decoder.py:86-109) as ONE persistent launch for small decoders: W_hh in
+ * registers, hidden state / rowc / token table / fc staged in LDS, only token ids leave the CU.  Requires H <= 128,
+ * V <= 32 and cpg_decode_greedy_fused_lds_bytes(H,V,Vt) <= the device's LDS per workgroup (returns -3 otherwise; the
+ * per-step entry points above cover every other shape).  ids [N,ld_ids] must be pre-filled with <pad> and column 0 with
+ * <start>; columns 1..T are written while a row is running; unfinished[t] += rows still running after step t. */
+CPG_API size_t cpg_decode_greedy_fused_lds_bytes(int H, int V, int Vt);
+CPG_API int cpg_decode_greedy_fused(const float* h0, const float* rowc, const float* tab, int Vt, const float* w_hh,
+                                    const float* b_hh, const float* fc_w, const float* fc_b, int N, int H, int V, int T,
+                                    int start, int pad, int eos, int64_t* ids, int ld_ids, int* unfinished, void* stream);
 /* beam: one Beam.advance for every sentence (rows beam-major: row = k*N + i) + hidden-state reorder.
  * scores/last_tok/origin [N,K]; n_finished, done [N]; hist_* [T,N,K]; n_active[step] += sentences not yet done. */
 CPG_API int cpg_beam_select(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos,
