@@ -1,7 +1,7 @@
 """Device-resident autoregressive decoding loops (RNN_VAE.sample_G hard modes, models/model.py:225-385).
 
 greedy, small decoders (the reference default h_dim=102): the WHOLE loop is one persistent launch
-(cpg_decode_greedy_fused: W_hh in registers, state in LDS).  Otherwise
+(cpg_decode_greedy_fused / cpg_decode_beam_fused: W_hh in registers, state in LDS).  Otherwise
 greedy / categorical: one fused GRU-step launch + one vocab projection + one select kernel per step, no host sync
 inside the loop (the reference syncs every step for `finished.sum() == mbsize`); the output is cut where the
 reference's loop would have stopped using a per-step counter read back once.
@@ -33,6 +33,26 @@ def fused_greedy_fits(H, V, Vt):
         return False
     need = ops.query("cpg_decode_greedy_fused_lds_bytes", H, V, Vt)
     return 0 < need <= LDS_PER_WORKGROUP
+
+
+def fused_beam_fits(H, V, Vt, K):
+    if not FUSED_GREEDY or H > 128 or V > 32 or K > 8 or K > V:
+        return False
+    need = ops.query("cpg_decode_beam_fused_lds_bytes", H, V, Vt, K)
+    return 0 < need <= LDS_PER_WORKGROUP
+
+
+def _decode_beam_fused(decoder, zc, tab, rowc, max_len, K, n_best, min_length):
+    N, H = zc.shape
+    fc = decoder.fc[1]
+    dev = zc.device
+    hist_tok = torch.full((max_len, N, K), -1, device=dev, dtype=torch.int32)
+    hist_prev = torch.zeros(max_len, N, K, device=dev, dtype=torch.int32)
+    hist_score = torch.zeros(max_len, N, K, device=dev, dtype=torch.float32)
+    call("cpg_decode_beam_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
+         _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, fc.weight.shape[0], max_len, K, n_best, min_length,
+         START_IDX, EOS_IDX, _p(hist_tok), _p(hist_prev), _p(hist_score), _stream())
+    return hist_tok, hist_prev, hist_score
 
 
 def _cut_at_all_finished(ids, unfinished, max_len, min_length):
@@ -123,6 +143,8 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
     zc1 = decoder.init_hidden(z, c).contiguous()
     tab, rowc1 = decoder._tables(zc1)
     tab = tab.contiguous()
+    if fused_beam_fits(zc1.shape[1], decoder.fc[1].weight.shape[0], tab.shape[0], K):
+        return _decode_beam_fused(decoder, zc1, tab, rowc1.contiguous(), max_len, K, n_best, min_length)
     rowc = rowc1.repeat(K, 1).contiguous()            # beam-major rows: row = k*N + i (model.py:262-263)
     h_a = zc1.repeat(K, 1).contiguous()
     h_b = torch.empty_like(h_a)

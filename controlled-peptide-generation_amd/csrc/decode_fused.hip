@@ -1,25 +1,33 @@
-// Whole-loop greedy decoding for small decoders (hidden <= 128, vocab <= 32): RNN_VAE.sample_G(sample_mode='greedy'),
-// models/model.py:225-385 with GRUDecoder.forward_sample, models/decoder.py:86-109, as ONE persistent launch.
+// Whole-loop decoding for small decoders (hidden <= 128, vocab <= 32) as ONE persistent launch:
+//   cpg_decode_greedy_fused   RNN_VAE.sample_G(sample_mode='greedy')   models/model.py:225-385
+//   cpg_decode_beam_fused     RNN_VAE.sample_G(sample_mode='beam')     models/model.py:258-276,314-328,364-376,387-404;
+//                             Beam.advance                             models/Beam.py:56-105
+// both over GRUDecoder.forward_sample, models/decoder.py:86-109.
 //
 // The reference's default decoder (h = z+c = 102, vocab 24) is far too small for one-launch-per-step to be efficient:
 // W_hh is 125 KB, a step over N rows re-reads h [N,H] and the constant input term rowc [N,3H] from HBM and writes h back,
-// 25 times.  Here a workgroup owns a tile of 64 latent samples for all T steps and nothing but the chosen token ids leaves
-// the CU:
+// 25 times.  Here a workgroup owns a tile of 64 decoder rows for all T steps and nothing but the chosen tokens (and the
+// beam back-pointers) leaves the CU:
 //   * W_hh lives in REGISTERS as f32 MFMA B-fragments: wave w owns hidden units [32w, 32w+32) of all three gates
 //     (6 column tiles x K/4 k-steps = 156 VGPRs at H=102), so the r/z/n pre-activations of a unit meet in one lane;
-//   * the hidden state tile [64][H], the per-sample constant term rowc [64][3H], the token table tab[V][3H] (= W_ih[:, :E]
-//     . emb, models/decoder.py:67,92) and fc [V][H] are staged in LDS once per tile (149 KB of the CU's 160 KB);
+//   * the hidden state tile [64][H], the per-sample constant term rowc, the token table tab[V][3H] (= W_ih[:, :E] . emb,
+//     models/decoder.py:67,92) and fc [V][H] are staged in LDS once per tile;
 //   * per step: h . W_hh^T on the matrix cores (A fragments read 16 B per lane from LDS with the contraction index
 //     permuted as in gemm_core.h), the GRU cell in the accumulator layout, h' back to LDS, the vocabulary projection as
-//     a second small MFMA product, first-max argmax + finished/EOS bookkeeping by 16 lanes per wave.
+//     a second small MFMA product, then the token selection:
+//       greedy - first-max argmax + finished/EOS bookkeeping, 16 lanes per wave;
+//       beam   - a tile holds whole sentences (rows = sentence-major, K beams each, so rowc is stored once per sentence):
+//                one lane per row does log_softmax + its row's K best, one lane per sentence merges them (Beam.advance),
+//                and the hidden rows are re-gathered by back-pointer inside LDS.
 // One workgroup (4 waves, 1 per SIMD) per CU; the launch is persistent over tiles.
 #include "cpg_internal.h"
 
 namespace {
 
-constexpr int RM = 64;  // latent samples per workgroup tile
+constexpr int RM = 64;  // decoder rows per workgroup tile
 constexpr int MT = RM / 16;
 constexpr int LGS = 33;  // logits row stride in LDS (floats)
+constexpr int MAXK = 8;  // beam width limit (CPG_MAX_BEAM of decode.hip)
 
 // K = 16*G + (up to 4*R) contraction steps: G full 16-deep groups (one ds_read_b128 per lane feeds four MFMA k-steps,
 // lane group q supplies k = 16g + 4q + j at step j) + R plain k-steps for the tail (k = 16G + 4r + q).
@@ -31,17 +39,13 @@ struct FusedCfg {
     static constexpr int LDH = ((KP / 4 + 1) % 2 == 1) ? KP + 4 : KP + 8;
 };
 
-struct GreedyArgs {
-    const float* h0;    // [N,H]   = [z;c]
-    const float* rowc;  // [N,3H]  W_ih[:, E:] . [z;c] + b_ih
+struct DecoderWeights {
     const float* tab;   // [Vt,3H] W_ih[:, :E] . emb[tok]
     const float* w_hh;  // [3H,H]
     const float* b_hh;  // [3H]
     const float* fc_w;  // [V,H]
     const float* fc_b;  // [V]
-    int64_t* ids;       // [N,ld_ids]; this kernel writes columns 1..T
-    int* unfinished;    // [T] += rows still running after each step
-    int N, H, V, Vt, T, ld_ids, start, pad, eos, ntiles;
+    int H, V, Vt;
 };
 
 template <int G, int R>
@@ -49,42 +53,178 @@ __device__ __forceinline__ int k_of_step(int s, int lq) {
     return s < 4 * G ? 16 * (s >> 2) + 4 * lq + (s & 3) : 16 * G + 4 * (s - 4 * G) + lq;
 }
 
+// Per-lane constants of one wave: its W_hh fragments and biases.
+template <int G, int R>
+struct WaveWeights {
+    float Bf[FusedCfg<G, R>::KSTEPS][6];
+    float bh[6];
+    int vclamp0, vclamp1;
+    float fcb0, fcb1;
+
+    __device__ __forceinline__ void load(const DecoderWeights& w) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const int g = nt >> 1, unit = 32 * wave + 16 * (nt & 1) + l15;
+            bh[nt] = unit < w.H ? w.b_hh[g * w.H + unit] : 0.f;
+#pragma unroll
+            for (int s = 0; s < FusedCfg<G, R>::KSTEPS; ++s) {
+                const int k = k_of_step<G, R>(s, lq);
+                Bf[s][nt] = (unit < w.H && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] : 0.f;
+            }
+        }
+        vclamp0 = min(l15, w.V - 1);
+        vclamp1 = min(16 + l15, w.V - 1);
+        fcb0 = l15 < w.V ? w.fc_b[l15] : 0.f;
+        fcb1 = 16 + l15 < w.V ? w.fc_b[16 + l15] : 0.f;
+    }
+};
+
+// tab -> LDS, fc_w -> LDS rows of stride LDH (zero padded in k)
+template <int G, int R>
+__device__ __forceinline__ void stage_tables(const DecoderWeights& w, float* tab_l, float* fc_l) {
+    using C = FusedCfg<G, R>;
+    for (int i = threadIdx.x; i < w.Vt * 3 * w.H; i += 256) tab_l[i] = w.tab[i];
+    for (int i = threadIdx.x; i < w.V * C::LDH; i += 256) {
+        const int v = i / C::LDH, k = i - v * C::LDH;
+        fc_l[i] = k < w.H ? w.fc_w[(size_t)v * w.H + k] : 0.f;
+    }
+}
+
+// acc[mt][gate*2+sub] = h_src[64 rows] . W_hh^T for this wave's 32 hidden units
+template <int G, int R>
+__device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const float* h_src, f32x4 (&acc)[MT][6]) {
+    using C = FusedCfg<G, R>;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        f32x4 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            af[mt] = *reinterpret_cast<const f32x4*>(&h_src[(mt * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], ww.Bf[4 * g + j][nt], acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float at[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) at[mt] = h_src[(mt * 16 + l15) * C::LDH + 16 * G + 4 * r + lq];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[mt], ww.Bf[4 * G + r][nt], acc[mt][nt], 0, 0, 0);
+    }
+}
+
+// GRU cell in the accumulator layout (gate order r,z,n; n = tanh(gi_n + r*(W_hn h + b_hn)); h' = (1-z)n + z h).
+// gi = tab[tok[row]] + rowc[rcrow[row]].  Reads the old state from h_src, writes h' to this wave's own columns of h_dst.
+template <int G, int R>
+__device__ __forceinline__ void gru_cell(const WaveWeights<G, R>& ww, const f32x4 (&acc)[MT][6], int H, const float* tab_l,
+                                         const float* rowc_l, const int* tok_l, const int* rcrow_l, const float* h_src,
+                                         float* h_dst) {
+    using C = FusedCfg<G, R>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int H3 = 3 * H;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int row = mt * 16 + 4 * lq + jj;
+            const float* tr = tab_l + tok_l[row] * H3;
+            const float* rc = rowc_l + rcrow_l[row] * H3;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int unit = 32 * wave + 16 * sub + l15;
+                if (unit < C::KP) {
+                    float hv = 0.f;
+                    if (unit < H) {
+                        const float gi_r = tr[unit] + rc[unit];
+                        const float gi_z = tr[H + unit] + rc[H + unit];
+                        const float gi_n = tr[2 * H + unit] + rc[2 * H + unit];
+                        const float hn = acc[mt][4 + sub][jj] + ww.bh[4 + sub];
+                        const float rg = sigmoidf_(gi_r + (acc[mt][sub][jj] + ww.bh[sub]));
+                        const float zg = sigmoidf_(gi_z + (acc[mt][2 + sub][jj] + ww.bh[2 + sub]));
+                        const float ng = tanhf(gi_n + rg * hn);
+                        const float hold = h_src[row * C::LDH + unit];
+                        hv = (1.f - zg) * ng + zg * hold;
+                    }
+                    h_dst[row * C::LDH + unit] = hv;
+                }
+            }
+        }
+}
+
+// logits[16 rows of this wave][V] = h fc_w^T + fc_b  -> logit_l
+template <int G, int R>
+__device__ __forceinline__ void vocab_logits(const WaveWeights<G, R>& ww, const float* h, const float* fc_l, float* logit_l) {
+    using C = FusedCfg<G, R>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    f32x4 lg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&h[(wave * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&fc_l[ww.vclamp0 * C::LDH + 16 * g + 4 * lq]);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&fc_l[ww.vclamp1 * C::LDH + 16 * g + 4 * lq]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], b0[j], lg[0], 0, 0, 0);
+            lg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], b1[j], lg[1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float at = h[(wave * 16 + l15) * C::LDH + 16 * G + 4 * r + lq];
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, fc_l[ww.vclamp0 * C::LDH + 16 * G + 4 * r + lq], lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, fc_l[ww.vclamp1 * C::LDH + 16 * G + 4 * r + lq], lg[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int row = wave * 16 + 4 * lq + jj;
+        logit_l[row * LGS + l15] = lg[0][jj] + ww.fcb0;
+        logit_l[row * LGS + 16 + l15] = lg[1][jj] + ww.fcb1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ greedy
+struct GreedyArgs {
+    DecoderWeights w;
+    const float* h0;    // [N,H]   = [z;c]
+    const float* rowc;  // [N,3H]  W_ih[:, E:] . [z;c] + b_ih
+    int64_t* ids;       // [N,ld_ids]; this kernel writes columns 1..T
+    int* unfinished;    // [T] += rows still running after each step
+    int N, T, ld_ids, start, pad, eos, ntiles;
+};
+
 template <int G, int R>
 __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs a) {
     using C = FusedCfg<G, R>;
     extern __shared__ float4 cpg_fused_smem[];
-    const int H = a.H, H3 = 3 * a.H, V = a.V;
-    float* h_l = reinterpret_cast<float*>(cpg_fused_smem);  // [RM][LDH]
-    float* fc_l = h_l + RM * C::LDH;                         // [V][LDH]
-    float* rowc_l = fc_l + V * C::LDH;                       // [RM][3H]
-    float* tab_l = rowc_l + RM * H3;                         // [Vt][3H]
-    float* logit_l = tab_l + a.Vt * H3;                      // [RM][LGS]
+    const int H = a.w.H, H3 = 3 * H, V = a.w.V;
+    float* h_l = reinterpret_cast<float*>(cpg_fused_smem);   // [RM][LDH]
+    float* fc_l = h_l + RM * C::LDH;                          // [V][LDH]
+    float* rowc_l = fc_l + V * C::LDH;                        // [RM][3H]
+    float* tab_l = rowc_l + RM * H3;                          // [Vt][3H]
+    float* logit_l = tab_l + a.w.Vt * H3;                     // [RM][LGS]
     int* tok_l = reinterpret_cast<int*>(logit_l + RM * LGS);  // [RM]
-    int* fin_l = tok_l + RM;                                 // [RM]
-    int* live_l = fin_l + RM;                                // [4] rows still running, per wave
+    int* fin_l = tok_l + RM;                                  // [RM]
+    int* rcrow_l = fin_l + RM;                                // [RM] identity here
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
-
-    // ---- once per workgroup: W_hh fragments -> registers, b_hh -> registers, tab / fc -> LDS
-    float Bf[C::KSTEPS][6];
-    float bh[6];
-#pragma unroll
-    for (int nt = 0; nt < 6; ++nt) {
-        const int g = nt >> 1, unit = 32 * wave + 16 * (nt & 1) + l15;
-        bh[nt] = unit < H ? a.b_hh[g * H + unit] : 0.f;
-#pragma unroll
-        for (int s = 0; s < C::KSTEPS; ++s) {
-            const int k = k_of_step<G, R>(s, lq);
-            Bf[s][nt] = (unit < H && k < H) ? a.w_hh[(size_t)(g * H + unit) * H + k] : 0.f;
-        }
-    }
-    for (int i = tid; i < a.Vt * H3; i += 256) tab_l[i] = a.tab[i];
-    for (int i = tid; i < V * C::LDH; i += 256) {
-        const int v = i / C::LDH, k = i - v * C::LDH;
-        fc_l[i] = k < H ? a.fc_w[(size_t)v * H + k] : 0.f;
-    }
-    const int vclamp0 = min(l15, V - 1), vclamp1 = min(16 + l15, V - 1);
-    const float fcb0 = l15 < V ? a.fc_b[l15] : 0.f, fcb1 = 16 + l15 < V ? a.fc_b[16 + l15] : 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    WaveWeights<G, R> ww;
+    ww.load(a.w);
+    stage_tables<G, R>(a.w, tab_l, fc_l);
+    if (tid < RM) rcrow_l[tid] = tid;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int row0 = tile * RM, nrows = min(RM, a.N - row0);
@@ -102,102 +242,18 @@ __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs 
             tok_l[tid] = a.start;
             fin_l[tid] = 0;
         }
-        if (tid < 4) live_l[tid] = 1;
         __syncthreads();
 
         for (int step = 0; step < a.T; ++step) {
-            // ---- h . W_hh^T for this wave's 32 hidden units x 3 gates, all 64 rows
             f32x4 acc[MT][6];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                f32x4 af[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    af[mt] = *reinterpret_cast<const f32x4*>(&h_l[(mt * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 6; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], Bf[4 * g + j][nt], acc[mt][nt], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                float at[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) at[mt] = h_l[(mt * 16 + l15) * C::LDH + 16 * G + 4 * r + lq];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 6; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[mt], Bf[4 * G + r][nt], acc[mt][nt], 0, 0, 0);
-            }
+            gru_product<G, R>(ww, h_l, acc);
             __syncthreads();  // every wave is done reading h (and last step's tokens are in tok_l)
-            if (live_l[0] + live_l[1] + live_l[2] + live_l[3] == 0) break;  // whole tile finished: the rest stays <pad>
-
-            // ---- GRU cell in the accumulator layout; h' goes straight back to this wave's own columns of h_l
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int row = mt * 16 + 4 * lq + jj;
-                    const float* tr = tab_l + tok_l[row] * H3;
-                    const float* rc = rowc_l + row * H3;
-#pragma unroll
-                    for (int sub = 0; sub < 2; ++sub) {
-                        const int unit = 32 * wave + 16 * sub + l15;
-                        if (unit < C::KP) {
-                            float hv = 0.f;
-                            if (unit < H) {
-                                const float gi_r = tr[unit] + rc[unit];
-                                const float gi_z = tr[H + unit] + rc[H + unit];
-                                const float gi_n = tr[2 * H + unit] + rc[2 * H + unit];
-                                const float hn = acc[mt][4 + sub][jj] + bh[4 + sub];
-                                const float rg = sigmoidf_(gi_r + (acc[mt][sub][jj] + bh[sub]));
-                                const float zg = sigmoidf_(gi_z + (acc[mt][2 + sub][jj] + bh[2 + sub]));
-                                const float ng = tanhf(gi_n + rg * hn);
-                                const float hold = h_l[row * C::LDH + unit];
-                                hv = (1.f - zg) * ng + zg * hold;
-                            }
-                            h_l[row * C::LDH + unit] = hv;
-                        }
-                    }
-                }
+            gru_cell<G, R>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, h_l, h_l);
+            __syncthreads();
+            vocab_logits<G, R>(ww, h_l, fc_l, logit_l);
             __syncthreads();
 
-            // ---- vocabulary projection of this wave's 16 rows: logits = h' fc_w^T + fc_b
-            f32x4 lg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 af = *reinterpret_cast<const f32x4*>(&h_l[(wave * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&fc_l[vclamp0 * C::LDH + 16 * g + 4 * lq]);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(&fc_l[vclamp1 * C::LDH + 16 * g + 4 * lq]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    lg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], b0[j], lg[0], 0, 0, 0);
-                    lg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], b1[j], lg[1], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float at = h_l[(wave * 16 + l15) * C::LDH + 16 * G + 4 * r + lq];
-                lg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, fc_l[vclamp0 * C::LDH + 16 * G + 4 * r + lq], lg[0], 0, 0, 0);
-                lg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, fc_l[vclamp1 * C::LDH + 16 * G + 4 * r + lq], lg[1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int row = wave * 16 + 4 * lq + jj;
-                logit_l[row * LGS + l15] = lg[0][jj] + fcb0;
-                logit_l[row * LGS + 16 + l15] = lg[1][jj] + fcb1;
-            }
-            __syncthreads();
-
-            // ---- token selection: lanes 0..15 of each wave take one row each (torch.argmax: first maximum)
+            // token selection: lanes 0..15 of each wave take one row each (torch.argmax: first maximum)
             int live = 0;
             if (lane < 16) {
                 const int row = wave * 16 + lane;
@@ -221,20 +277,19 @@ __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs 
                 }
             }
             const unsigned long long lb = __ballot(live);
-            if (lane == 0) {
-                const int nl = __popcll(lb);
-                live_l[wave] = nl;
-                if (nl) atomicAdd(&a.unfinished[step], nl);
-            }
+            if (lane == 0 && lb) atomicAdd(&a.unfinished[step], __popcll(lb));
+            if (__syncthreads_count(live) == 0) break;  // whole tile finished: the remaining columns stay <pad>
         }
     }
 }
 
+size_t greedy_lds_bytes(int ldh, int H, int V, int Vt) {
+    return ((size_t)RM * ldh + (size_t)V * ldh + (size_t)RM * 3 * H + (size_t)Vt * 3 * H + RM * LGS) * 4 + 3 * RM * sizeof(int);
+}
+
 template <int G, int R>
 int launch_greedy(const GreedyArgs& a, int device_cus, hipStream_t s) {
-    using C = FusedCfg<G, R>;
-    const size_t floats = (size_t)RM * C::LDH + (size_t)a.V * C::LDH + (size_t)RM * 3 * a.H + (size_t)a.Vt * 3 * a.H + RM * LGS;
-    const size_t bytes = floats * 4 + (2 * RM + 4) * sizeof(int);
+    const size_t bytes = greedy_lds_bytes(FusedCfg<G, R>::LDH, a.w.H, a.w.V, a.w.Vt);
     auto kern = decode_greedy_fused_kernel<G, R>;
     CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int grid = a.ntiles < device_cus ? a.ntiles : device_cus;
@@ -243,18 +298,245 @@ int launch_greedy(const GreedyArgs& a, int device_cus, hipStream_t s) {
     return 0;
 }
 
-// contraction depth the dispatch below pads H to
+// ------------------------------------------------------------------------------------------------ beam
+struct BeamArgs {
+    DecoderWeights w;
+    const float* h0;      // [N,H]  one row per sentence
+    const float* rowc;    // [N,3H] one row per sentence
+    int32_t* hist_tok;    // [T,N,K] pre-filled with -1: steps a sentence is not advanced on keep -1
+    int32_t* hist_prev;   // [T,N,K]
+    float* hist_score;    // [T,N,K]
+    int N, T, K, n_best, min_length, bos, eos, S, ntiles;  // S = sentences per tile = RM / K
+};
+
+template <int G, int R>
+__global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
+    using C = FusedCfg<G, R>;
+    extern __shared__ float4 cpg_fused_smem[];
+    const int H = a.w.H, H3 = 3 * H, V = a.w.V, K = a.K, S = a.S;
+    float* hx_l = reinterpret_cast<float*>(cpg_fused_smem);  // [RM][LDH] state the product reads (rows in beam order)
+    float* hy_l = hx_l + RM * C::LDH;                         // [RM][LDH] state after the cell, before the re-gather
+    float* fc_l = hy_l + RM * C::LDH;                         // [V][LDH]
+    float* rowc_l = fc_l + V * C::LDH;                        // [S][3H]
+    float* tab_l = rowc_l + S * H3;                           // [Vt][3H]
+    float* logit_l = tab_l + a.w.Vt * H3;                     // [RM][LGS]
+    float* cs_l = logit_l + RM * LGS;                         // [RM][MAXK] each row's K best scores ...
+    float* sc_l = cs_l + RM * MAXK;                           // [RM] beam scores (row = sentence*K + beam)
+    int* cv_l = reinterpret_cast<int*>(sc_l + RM);            // [RM][MAXK] ... and their tokens
+    int* tok_l = cv_l + RM * MAXK;                            // [RM] token each row consumes next
+    int* rcrow_l = tok_l + RM;                                // [RM] sentence of a row
+    int* org_l = rcrow_l + RM;                                // [RM] tile row a row's new state comes from
+    int* nfin_l = org_l + RM;                                 // [S]
+    int* done_l = nfin_l + RM;                                // [S]
+
+    const int tid = threadIdx.x;
+    WaveWeights<G, R> ww;
+    ww.load(a.w);
+    stage_tables<G, R>(a.w, tab_l, fc_l);
+    if (tid < RM) rcrow_l[tid] = min(tid / K, S - 1);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int s0 = tile * S, nsent = min(S, a.N - s0);
+        __syncthreads();
+        for (int i = tid; i < RM * C::LDH; i += 256) {
+            const int r = i / C::LDH, k = i - r * C::LDH, sl = r / K;
+            hx_l[i] = (sl < nsent && k < H) ? a.h0[(size_t)(s0 + sl) * H + k] : 0.f;
+        }
+        {
+            const float* src = a.rowc + (size_t)s0 * H3;
+            const int n = nsent * H3;
+            for (int i = tid; i < S * H3; i += 256) rowc_l[i] = i < n ? src[i] : 0.f;
+        }
+        if (tid < RM) {
+            tok_l[tid] = a.bos;
+            sc_l[tid] = 0.f;
+            org_l[tid] = tid;
+            nfin_l[tid] = 0;
+            done_l[tid] = 0;
+        }
+        __syncthreads();
+
+        for (int step = 0; step < a.T; ++step) {
+            f32x4 acc[MT][6];
+            gru_product<G, R>(ww, hx_l, acc);
+            gru_cell<G, R>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, hx_l, hy_l);
+            __syncthreads();
+            vocab_logits<G, R>(ww, hy_l, fc_l, logit_l);
+            __syncthreads();
+
+            // ---- Beam.advance, stage 1: one lane per row: log_softmax, masks, the row's K best (ties: lower token first)
+            if (tid < RM) {
+                const int sl = tid / K, k = tid - sl * K;
+                if (sl < nsent && !done_l[sl] && (step > 0 || k == 0)) {
+                    const float* l = logit_l + tid * LGS;
+                    float m = -INFINITY;
+                    for (int v = 0; v < V; ++v) m = fmaxf(m, l[v]);
+                    float se = 0.f;
+                    for (int v = 0; v < V; ++v) se += expf(l[v] - m);
+                    const float lse = m + logf(se);
+                    const bool parent_eos = step > 0 && tok_l[tid] == a.eos;
+                    const float base = sc_l[tid];
+                    float bs[MAXK];
+                    int bv[MAXK];
+#pragma unroll
+                    for (int p = 0; p < MAXK; ++p) {
+                        bs[p] = -INFINITY;
+                        bv[p] = 0;
+                    }
+                    float worst = -INFINITY;
+                    for (int v = 0; v < V; ++v) {
+                        float lp = l[v] - lse;
+                        if (step + 1 < a.min_length && v == a.eos) lp = -1e20f;
+                        if (v == a.bos) lp = -1e20f;
+                        float cs = step > 0 ? lp + base : lp;
+                        if (parent_eos) cs = -1e20f;
+                        if (!(cs > worst)) continue;
+                        int cc = v;
+                        bool carried = false;
+#pragma unroll
+                        for (int p = 0; p < MAXK; ++p) {
+                            if (p >= K) break;
+                            if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
+                                const float fs = bs[p];
+                                const int fv = bv[p];
+                                bs[p] = cs;
+                                bv[p] = cc;
+                                cs = fs;
+                                cc = fv;
+                                carried = true;
+                            }
+                        }
+#pragma unroll
+                        for (int p = 0; p < MAXK; ++p)
+                            if (p == K - 1) worst = bs[p];
+                    }
+#pragma unroll
+                    for (int p = 0; p < MAXK; ++p) {
+                        cs_l[tid * MAXK + p] = bs[p];
+                        cv_l[tid * MAXK + p] = bv[p];
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- stage 2: one lane per sentence merges its rows' lists (ties: lower beam first = lower flat index)
+            int active = 0;
+            int new_tok[MAXK], new_org[MAXK];
+            float new_sc[MAXK];
+            bool advanced = false;
+            if (tid < nsent && !done_l[tid]) {
+                advanced = true;
+                const int sl = tid, kmax = step == 0 ? 1 : K;
+                int ptr[MAXK];
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k) ptr[k] = 0;
+                int nf = nfin_l[sl];
+#pragma unroll
+                for (int sel = 0; sel < MAXK; ++sel) {
+                    if (sel >= K) break;
+                    float best = -INFINITY;
+                    int bk = 0, bp = 0;
+#pragma unroll
+                    for (int k = 0; k < MAXK; ++k) {
+                        if (k >= kmax) break;
+                        if (ptr[k] < K) {
+                            const float x = cs_l[(sl * K + k) * MAXK + ptr[k]];
+                            if (x > best) {
+                                best = x;
+                                bk = k;
+                                bp = ptr[k];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < MAXK; ++k)
+                        if (k == bk) ++ptr[k];
+                    const int tk = cv_l[(sl * K + bk) * MAXK + bp];
+                    new_sc[sel] = best;
+                    new_tok[sel] = tk;
+                    new_org[sel] = bk;
+                    if (tk == a.eos) ++nf;
+                }
+                nfin_l[sl] = nf;
+                if (new_tok[0] == a.eos && nf >= a.n_best) done_l[sl] = 1; else active = 1;
+            }
+            if (advanced) {  // stage 2 reads only the candidate lists: the per-row state can be replaced right away
+                const int sl = tid;
+#pragma unroll
+                for (int k = 0; k < MAXK; ++k) {
+                    if (k >= K) break;
+                    const int row = sl * K + k;
+                    sc_l[row] = new_sc[k];
+                    tok_l[row] = new_tok[k];
+                    org_l[row] = sl * K + new_org[k];
+                    const size_t h = ((size_t)step * a.N + (s0 + sl)) * K + k;
+                    a.hist_tok[h] = new_tok[k];
+                    a.hist_prev[h] = new_org[k];
+                    a.hist_score[h] = new_sc[k];
+                }
+            }
+            const int nact = __syncthreads_count(active);
+            if (nact == 0) break;  // every sentence of the tile is done (model.py:364-366)
+
+            // ---- re-gather the hidden rows by back-pointer (model.py:387-404): hx[row] = hy[org[row]]
+            for (int i = tid; i < RM * (C::KP / 4); i += 256) {
+                const int r = i / (C::KP / 4), c = i - r * (C::KP / 4);
+                *reinterpret_cast<f32x4*>(&hx_l[r * C::LDH + 4 * c]) = *reinterpret_cast<const f32x4*>(&hy_l[org_l[r] * C::LDH + 4 * c]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+size_t beam_lds_bytes(int ldh, int H, int V, int Vt, int K) {
+    const int S = RM / K;
+    return ((size_t)2 * RM * ldh + (size_t)V * ldh + (size_t)S * 3 * H + (size_t)Vt * 3 * H + RM * LGS + RM * MAXK + RM) * 4 +
+           ((size_t)RM * MAXK + 5 * RM) * sizeof(int);
+}
+
+template <int G, int R>
+int launch_beam(const BeamArgs& a, int device_cus, hipStream_t s) {
+    const size_t bytes = beam_lds_bytes(FusedCfg<G, R>::LDH, a.w.H, a.w.V, a.w.Vt, a.K);
+    auto kern = decode_beam_fused_kernel<G, R>;
+    CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    const int grid = a.ntiles < device_cus ? a.ntiles : device_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, s, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// contraction depth the dispatch pads H to, and the matching LDS row stride
 int fused_kp(int H) {
     if (H / 16 == 6 && (H % 16 + 3) / 4 == 2) return 104;
     return H <= 32 ? 32 : H <= 64 ? 64 : H <= 96 ? 96 : 128;
 }
+int fused_ldh(int H) {
+    const int kp = fused_kp(H);
+    return ((kp / 4 + 1) % 2 == 1) ? kp + 4 : kp + 8;
+}
+
+int device_limits(int* cus, int* lds) {
+    int dev = 0;
+    CPG_HIP(hipGetDevice(&dev));
+    CPG_HIP(hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev));
+    CPG_HIP(hipDeviceGetAttribute(lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    return 0;
+}
+
+#define CPG_FUSED_DISPATCH(LAUNCH, H, ...)                                     \
+    do {                                                                       \
+        if (fused_kp(H) == 104) return LAUNCH<6, 2>(__VA_ARGS__);              \
+        if ((H) <= 32) return LAUNCH<2, 0>(__VA_ARGS__);                       \
+        if ((H) <= 64) return LAUNCH<4, 0>(__VA_ARGS__);                       \
+        if ((H) <= 96) return LAUNCH<6, 0>(__VA_ARGS__);                       \
+        return LAUNCH<8, 0>(__VA_ARGS__);                                      \
+    } while (0)
 
 }  // namespace
 
 CPG_EXPORT size_t cpg_decode_greedy_fused_lds_bytes(int H, int V, int Vt) {
     if (H <= 0 || H > 128 || V <= 0 || V > 32 || Vt <= 0) return 0;
-    const int kp = fused_kp(H), ldh = ((kp / 4 + 1) % 2 == 1) ? kp + 4 : kp + 8;
-    return ((size_t)RM * ldh + (size_t)V * ldh + (size_t)RM * 3 * H + (size_t)Vt * 3 * H + RM * LGS) * 4 + (2 * RM + 4) * sizeof(int);
+    return greedy_lds_bytes(fused_ldh(H), H, V, Vt);
 }
 
 CPG_EXPORT int cpg_decode_greedy_fused(const float* h0, const float* rowc, const float* tab, int Vt, const float* w_hh,
@@ -263,22 +545,40 @@ CPG_EXPORT int cpg_decode_greedy_fused(const float* h0, const float* rowc, const
     CPG_CHECK_ARG(h0 && rowc && tab && w_hh && b_hh && fc_w && fc_b && ids && unfinished);
     CPG_CHECK_ARG(N > 0 && T > 0 && ld_ids >= T + 1 && H > 0 && H <= 128 && V > 0 && V <= 32 && Vt > 0);
     CPG_CHECK_ARG(start >= 0 && start < Vt && pad >= 0 && pad < Vt && eos >= 0 && V <= Vt);
-    int dev = 0, cus = 0, lds = 0;
-    CPG_HIP(hipGetDevice(&dev));
-    CPG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    CPG_HIP(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    int cus = 0, lds = 0;
+    if (int rc = device_limits(&cus, &lds)) return rc;
     const size_t need = cpg_decode_greedy_fused_lds_bytes(H, V, Vt);
     if (need > (size_t)lds) {
         cpg_set_error("cpg_decode_greedy_fused: needs %zu bytes of LDS per workgroup, device offers %d", need, lds);
         return -3;
     }
-    GreedyArgs a{h0, rowc, tab, w_hh, b_hh, fc_w, fc_b, ids, unfinished, N, H, V, Vt, T, ld_ids, start, pad, eos, cdiv(N, RM)};
+    GreedyArgs a{{tab, w_hh, b_hh, fc_w, fc_b, H, V, Vt}, h0, rowc, ids, unfinished, N, T, ld_ids, start, pad, eos, cdiv(N, RM)};
     hipStream_t s = (hipStream_t)stream;
-    const int g = H / 16, r = (H % 16 + 3) / 4;
-    // instantiated shapes: the reference default (h_dim = 102 -> 6 groups + 2 tail steps) and the padded general case
-    if (g == 6 && r == 2) return launch_greedy<6, 2>(a, cus, s);
-    if (H <= 32) return launch_greedy<2, 0>(a, cus, s);
-    if (H <= 64) return launch_greedy<4, 0>(a, cus, s);
-    if (H <= 96) return launch_greedy<6, 0>(a, cus, s);
-    return launch_greedy<8, 0>(a, cus, s);
+    CPG_FUSED_DISPATCH(launch_greedy, H, a, cus, s);
+}
+
+CPG_EXPORT size_t cpg_decode_beam_fused_lds_bytes(int H, int V, int Vt, int K) {
+    if (H <= 0 || H > 128 || V <= 0 || V > 32 || Vt <= 0 || K <= 0 || K > MAXK || K > V) return 0;
+    return beam_lds_bytes(fused_ldh(H), H, V, Vt, K);
+}
+
+CPG_EXPORT int cpg_decode_beam_fused(const float* h0, const float* rowc, const float* tab, int Vt, const float* w_hh,
+                                     const float* b_hh, const float* fc_w, const float* fc_b, int N, int H, int V, int T, int K,
+                                     int n_best, int min_length, int bos, int eos, int32_t* hist_tok, int32_t* hist_prev,
+                                     float* hist_score, void* stream) {
+    CPG_CHECK_ARG(h0 && rowc && tab && w_hh && b_hh && fc_w && fc_b && hist_tok && hist_prev && hist_score);
+    CPG_CHECK_ARG(N > 0 && T > 0 && H > 0 && H <= 128 && V > 0 && V <= 32 && Vt >= V && K > 0 && K <= MAXK && K <= V);
+    CPG_CHECK_ARG(n_best > 0 && n_best <= K && bos >= 0 && bos < Vt && eos >= 0);
+    int cus = 0, lds = 0;
+    if (int rc = device_limits(&cus, &lds)) return rc;
+    const size_t need = cpg_decode_beam_fused_lds_bytes(H, V, Vt, K);
+    if (need > (size_t)lds) {
+        cpg_set_error("cpg_decode_beam_fused: needs %zu bytes of LDS per workgroup, device offers %d", need, lds);
+        return -3;
+    }
+    const int S = RM / K;
+    BeamArgs a{{tab, w_hh, b_hh, fc_w, fc_b, H, V, Vt}, h0, rowc, hist_tok, hist_prev, hist_score, N, T, K, n_best, min_length,
+               bos, eos, S, cdiv(N, S)};
+    hipStream_t s = (hipStream_t)stream;
+    CPG_FUSED_DISPATCH(launch_beam, H, a, cus, s);
 }

@@ -153,6 +153,16 @@ CPG_API size_t cpg_decode_greedy_fused_lds_bytes(int H, int V, int Vt);
 CPG_API int cpg_decode_greedy_fused(const float* h0, const float* rowc, const float* tab, int Vt, const float* w_hh,
                                     const float* b_hh, const float* fc_w, const float* fc_b, int N, int H, int V, int T,
                                     int start, int pad, int eos, int64_t* ids, int ld_ids, int* unfinished, void* stream);
+/* Whole beam search (model.py:258-276,314-328,364-376,387-404; Beam.py:56-105) as ONE persistent launch for small
+ * decoders: a workgroup tile holds whole sentences (K beams each, sentence-major rows), Beam.advance and the hidden-state
+ * re-gather happen in LDS.  h0/rowc: one row per sentence.  hist_tok must be pre-filled with -1 (steps a finished
+ * sentence is not advanced on keep it); hist_* [T,N,K] feed cpg_beam_hypotheses.  Same shape limits as the greedy one
+ * plus K <= 8, K <= V; -3 if cpg_decode_beam_fused_lds_bytes exceeds the device's LDS per workgroup. */
+CPG_API size_t cpg_decode_beam_fused_lds_bytes(int H, int V, int Vt, int K);
+CPG_API int cpg_decode_beam_fused(const float* h0, const float* rowc, const float* tab, int Vt, const float* w_hh,
+                                  const float* b_hh, const float* fc_w, const float* fc_b, int N, int H, int V, int T, int K,
+                                  int n_best, int min_length, int bos, int eos, int32_t* hist_tok, int32_t* hist_prev,
+                                  float* hist_score, void* stream);
 /* beam: one Beam.advance for every sentence (rows beam-major: row = k*N + i) + hidden-state reorder.
  * scores/last_tok/origin [N,K]; n_finished, done [N]; hist_* [T,N,K]; n_active[step] += sentences not yet done. */
 CPG_API int cpg_beam_select(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos,
