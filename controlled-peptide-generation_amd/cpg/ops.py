@@ -341,11 +341,13 @@ class GruSeqFn(Function):
         ws = workspace(nb, dev)
         dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32) if has_tab else None
         drowc = torch.empty(B, 3 * H, device=dev, dtype=torch.float32) if has_rowc else None
+        # with a token table, its gradient and the column sums of dG (= the b_hh gradient) come out of one pass over dG
+        dsum = torch.empty(4 * H, device=dev, dtype=torch.float32) if has_tab else None
         if has_tab or has_rowc:
-            call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(drowc), 0, _p(ws), ws.numel(), _stream())
+            call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(),
+                 _stream())
         dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
-        # bias gradient: from the token-table gradient + a quarter pass over dG when a table exists, else a full column sum
-        db_hh = gru_bias_grad(dG, dtab, T, B, H, ws) if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
+        db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
         db_arg = None if has_tab else _p(db_hh)
         if ctx.defer is not None:
             side = side_streams(dev)[2]
@@ -367,19 +369,6 @@ class GruSeqFn(Function):
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
             ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2)
         return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None
-
-
-def gru_bias_grad(dG, dtab, T, B, H, ws):
-    """db_hh[3H] from the pieces already at hand: the r,z columns of the hidden-side gate gradient equal the input-side
-    ones, whose sum over all (t,b) is the column sum of the V-row token-table gradient; only the dhn columns [2H,3H) need a
-    pass over dG (a quarter of it instead of three quarters)."""
-    dev = dG.device
-    db = torch.empty(3 * H, device=dev, dtype=torch.float32)
-    V = dtab.shape[0]
-    call("cpg_colsum_f32", _p(dtab), 3 * H, V, 2 * H, _p(db), 0, _p(ws), ws.numel(), _stream())
-    flat = dG.view(T * B, 4 * H)
-    call("cpg_colsum_f32", _p(flat[:, 2 * H:]), 4 * H, T * B, H, _p(db[2 * H:]), 0, _p(ws), ws.numel(), _stream())
-    return db
 
 
 class GruBiSeqFn(Function):
@@ -438,8 +427,10 @@ class GruBiSeqFn(Function):
             if ctx.has_tab:
                 call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _stream())
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
-                call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), None, 0, _p(ws), ws.numel(), _stream())
-                db = gru_bias_grad(dG, dtab, T, B, H, ws)
+                dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
+                call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
+                     _stream())
+                db = dsum[:3 * H]
             else:
                 db = torch.empty(3 * H, device=dev, dtype=torch.float32)
                 call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), _stream())
@@ -525,11 +516,13 @@ class LstmSeqFn(Function):
         ws = workspace(nb, dev)
         dw_hh = torch.empty(4 * H, H, device=dev, dtype=torch.float32)
         db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
-        call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), _p(db_hh), 0, _p(ws), ws.numel(), _stream())
+        call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
+             ws.numel(), _stream())
         dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32) if has_tab else None
         drowc = torch.empty(B, 4 * H, device=dev, dtype=torch.float32) if has_rowc else None
         if has_tab or has_rowc:
-            call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(drowc), 0, _p(ws), ws.numel(), _stream())
+            call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(db_hh) if has_tab else None, _p(drowc), 0,
+                 _p(ws), ws.numel(), _stream())
         return (None, dtab, drowc, dG if has_dense else None, dh0 if has_h0 else None, dc0 if has_c0 else None, dw_hh, db_hh,
                 None, None)
 

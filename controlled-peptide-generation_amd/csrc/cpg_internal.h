@@ -15,6 +15,7 @@ size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd);
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_colsum_workspace(int M, int N);
 
-// token-grouped / over-time reductions of the input-side gate gradients; lstm=1: 4H identity-mapped columns
-int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* drowc,
-                        int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+// token-grouped / over-time reductions of the input-side gate gradients (+ dsum[4H] = column sums of dG);
+// lstm=1: 4H identity-mapped columns
+int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
+                        float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);

@@ -417,6 +417,31 @@ __global__ void chunk_reduce_kernel(const float* part, int chunks, size_t n, flo
     out[i] = accumulate ? out[i] + s : s;
 }
 
+// One-hot image of the step tokens with a column of ones appended: oh[row][v] = (tok[row] == v), oh[row][V] = 1.
+// dG^T . oh on the matrix cores then yields the token-grouped sums AND the plain column sums in one pass over dG.
+constexpr int OH_LD = 32;
+__global__ void onehot_kernel(const int32_t* tok, int rows, int V, float* oh) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * OH_LD) return;
+    const int row = i / OH_LD, c = i - (size_t)row * OH_LD;
+    oh[i] = (c == tok[row] || c == V) ? 1.f : 0.f;
+}
+
+// R [OH_LD, 4H] -> dtab[v][c] (+)= R[v][dgi_col(c)]; dsum[c4] (+)= R[V][c4]
+__global__ void dgi_scatter_kernel(const float* R, int H, int V, int lstm, float* dtab, float* dsum, int accumulate) {
+    const int NC = lstm ? 4 * H : 3 * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dtab && i < V * NC) {
+        const int v = i / NC, c = i - v * NC;
+        const float x = R[(size_t)v * 4 * H + dgi_col(c, H, lstm)];
+        dtab[i] = accumulate ? dtab[i] + x : x;
+    }
+    if (dsum && i < 4 * H) {
+        const float x = R[(size_t)V * 4 * H + i];
+        dsum[i] = accumulate ? dsum[i] + x : x;
+    }
+}
+
 // drowc[b][c] (+)= sum_t dgi[t][b][c]
 __global__ void dgi_over_time_kernel(const float* dG, int T, int B, int H, float* out, int accumulate, int lstm) {
     const int NC = lstm ? 4 * H : 3 * H;
@@ -515,14 +540,20 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     return 0;
 }
 
+static size_t dgi_mm_workspace(int T, int B, int H) {
+    return ((size_t)T * B * OH_LD + (size_t)OH_LD * 4 * H) * sizeof(float) + cpg_gemm_tn_workspace(T * B, OH_LD, 4 * H);
+}
+
 CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
     size_t a = cpg_gemm_tn_workspace(T * B, 4 * H, H);
     size_t b = cpg_colsum_workspace(T * B, 4 * H);
     int chunks = cdiv(T * B, 512);
     if (chunks > 256) chunks = 256;
     size_t c = (size_t)chunks * (V > 0 ? V : 1) * 4 * H * sizeof(float);  // sized for the 4-gate (LSTM) case too
+    size_t d = dgi_mm_workspace(T, B, H);
     size_t m = a > b ? a : b;
-    return (m > c ? m : c) + 256;
+    m = m > c ? m : c;
+    return (m > d ? m : d) + 256;
 }
 
 // dW_hh[3H,H] (+)= sum_t dgh_t^T h_prev(t) ; db_hh[3H] (+)= sum dgh.
@@ -539,36 +570,57 @@ CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* d
 // Input-side reductions of dgi = [dr_pre, dz_pre, dn_pre]:
 //   dtab[V,3H]  (+)= sum over (t,b) with tok[t,b]==v     (gradient of the token table; null to skip)
 //   drowc[B,3H] (+)= sum over t                          (gradient of the constant-over-time term; null to skip)
-int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* drowc,
-                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
+                        float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG);
     const int NC = lstm ? 4 * H : 3 * H;
     hipStream_t s = (hipStream_t)stream;
-    if (dtab) {
+    const int rows = T * B;
+    if ((dtab || dsum) && V + 1 <= OH_LD && workspace_bytes >= dgi_mm_workspace(T, B, H)) {
+        // R[OH_LD,4H] = onehot1^T . dG : token-grouped sums (rows 0..V-1) and column sums (row V), dG read once at HBM rate
         CPG_CHECK_ARG(tok && V > 0 && workspace);
-        const int rows = T * B;
-        int chunks = cdiv(rows, 512);
-        if (chunks > 256) chunks = 256;
-        const int rpc = cdiv(rows, chunks);
-        chunks = cdiv(rows, rpc);
-        const size_t n = (size_t)V * NC;
-        if (workspace_bytes < n * chunks * sizeof(float)) {
-            cpg_set_error("cpg_gru_dgi_reduce: workspace too small");
-            return -3;
-        }
-        int RL = 4;
-        while (RL > 1 && (size_t)RL * V * 64 * sizeof(float) > 96 * 1024) RL >>= 1;
-        const size_t smem = (size_t)RL * V * 64 * sizeof(float);
-        if (smem > 150 * 1024) {
-            cpg_set_error("cpg_gru_dgi_reduce: vocabulary of %d rows does not fit the LDS accumulators", V);
-            return -4;
-        }
-        hipLaunchKernelGGL(dgi_by_token_kernel, dim3(cdiv(NC, 64), chunks), dim3(64, RL), smem, s, dG, tok, rows, H, V, rpc,
-                           (float*)workspace, lstm);
+        float* oh = (float*)workspace;
+        float* R = oh + (size_t)rows * OH_LD;
+        float* gws = R + (size_t)OH_LD * 4 * H;
+        const size_t n = (size_t)rows * OH_LD;
+        hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tok, rows, V, oh);
         CPG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
-                           chunks, n, dtab, accumulate);
+        int rc = cpg_gemm_tn(oh, OH_LD, dG, 4 * H, nullptr, 1.f, R, 4 * H, rows, OH_LD, 4 * H, 0, gws,
+                             workspace_bytes - ((char*)gws - (char*)workspace), s);
+        if (rc) return rc;
+        const int m = V * NC > 4 * H ? V * NC : 4 * H;
+        hipLaunchKernelGGL(dgi_scatter_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, R, H, V, lstm, dtab, dsum, accumulate);
         CPG_LAUNCH_CHECK();
+    } else {
+        if (dtab) {
+            CPG_CHECK_ARG(tok && V > 0 && workspace);
+            int chunks = cdiv(rows, 512);
+            if (chunks > 256) chunks = 256;
+            const int rpc = cdiv(rows, chunks);
+            chunks = cdiv(rows, rpc);
+            const size_t n = (size_t)V * NC;
+            if (workspace_bytes < n * chunks * sizeof(float)) {
+                cpg_set_error("cpg_gru_dgi_reduce: workspace too small");
+                return -3;
+            }
+            int RL = 4;
+            while (RL > 1 && (size_t)RL * V * 64 * sizeof(float) > 96 * 1024) RL >>= 1;
+            const size_t smem = (size_t)RL * V * 64 * sizeof(float);
+            if (smem > 150 * 1024) {
+                cpg_set_error("cpg_gru_dgi_reduce: vocabulary of %d rows does not fit the LDS accumulators", V);
+                return -4;
+            }
+            hipLaunchKernelGGL(dgi_by_token_kernel, dim3(cdiv(NC, 64), chunks), dim3(64, RL), smem, s, dG, tok, rows, H, V, rpc,
+                               (float*)workspace, lstm);
+            CPG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+                               chunks, n, dtab, accumulate);
+            CPG_LAUNCH_CHECK();
+        }
+        if (dsum) {
+            int rc = cpg_colsum(dG, 4 * H, rows, 4 * H, dsum, accumulate, (float*)workspace, workspace_bytes, s);
+            if (rc) return rc;
+        }
     }
     if (drowc) {
         const size_t n = (size_t)B * NC;
@@ -579,9 +631,9 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
     return 0;
 }
 
-CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                   float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, drowc, accumulate, workspace, workspace_bytes, stream);
+    return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, dsum, drowc, accumulate, workspace, workspace_bytes, stream);
 }
 
 static void fill_fwd(GruFwdArgs& a, int t, int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,

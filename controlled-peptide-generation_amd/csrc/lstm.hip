@@ -307,15 +307,15 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
 // dw_hh[4H,H] (+)= sum_t dG_t^T h_prev(t) ; db_hh[4H] (+)= sum dG.   workspace: cpg_gru_wgrad_workspace(T,B,H,V)
 CPG_EXPORT int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
                                  float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && db_hh && workspace);
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && workspace);
     const float* hprev = reverse ? hs + (size_t)B * H : hs;
     int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 4 * H, H, accumulate, (float*)workspace,
                          workspace_bytes, (hipStream_t)stream);
-    if (rc) return rc;
+    if (rc || !db_hh) return rc;  // db_hh null: the caller takes it from cpg_lstm_dgi_reduce's column sums
     return cpg_colsum(dG, 4 * H, T * B, 4 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-CPG_EXPORT int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+CPG_EXPORT int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                    float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    return cpg_dgi_reduce_impl(T, B, H, 1, dG, tok, V, dtab, drowc, accumulate, workspace, workspace_bytes, stream);
+    return cpg_dgi_reduce_impl(T, B, H, 1, dG, tok, V, dtab, dsum, drowc, accumulate, workspace, workspace_bytes, stream);
 }

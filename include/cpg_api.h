@@ -108,8 +108,10 @@ CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
                              float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-/* dtab[V,3H] (+)= sum of input-side gate gradients grouped by token ; drowc[B,3H] (+)= sum over time (either may be null) */
-CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+/* dtab[V,3H] (+)= sum of input-side gate gradients grouped by token ; dsum[4H] (+)= column sums of dG (dsum[0:3H] is the
+ * b_hh gradient) ; drowc[B,3H] (+)= sum over time (any may be null).  dtab and dsum come from ONE pass over dG:
+ * dG^T . [onehot(tok) | 1] on the matrix cores. */
+CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LSTM (NOT in the reference, which is GRU-only - SURVEY F2; semantics = torch.nn.LSTM, gate row order i,f,g,o) --------
@@ -125,7 +127,7 @@ CPG_API int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh
                              const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, void* stream);
 CPG_API int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
                               float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
-CPG_API int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab,
+CPG_API int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                 float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- vocabulary projection: nn.Dropout(p_out)+nn.Linear(h_dim,n_vocab), models/decoder.py:43-45,83,107 ----------- */
