@@ -150,8 +150,17 @@ __global__ void skinny_nn_kernel(const float* X, int ldx, const float* Bm, int l
     __shared__ float red[16][64];
     const int n = blockIdx.x * 64 + threadIdx.x, m = blockIdx.y, ty = threadIdx.y;
     float s = 0.f;
-    if (n < N)
-        for (int k = ty; k < K; k += 16) s += X[(size_t)m * ldx + k] * Bm[(size_t)k * ldb + n];
+    if (n < N) {
+        // 8 independent loads in flight per lane (the loop is latency-bound otherwise: 96 dependent trips at K=1536)
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = ty;
+        for (; k + 16 * 7 < K; k += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] += X[(size_t)m * ldx + k + 16 * u] * Bm[(size_t)(k + 16 * u) * ldb + n];
+        }
+        for (; k < K; k += 16) p[0] += X[(size_t)m * ldx + k] * Bm[(size_t)k * ldb + n];
+        s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    }
     red[ty][threadIdx.x] = s;
     __syncthreads();
     if (ty == 0 && n < N) {
