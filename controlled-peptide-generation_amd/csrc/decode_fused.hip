@@ -37,6 +37,9 @@ struct FusedCfg {
     static constexpr int KP = 16 * G + 4 * R;
     // row stride = 4 * odd: the 8 rows one ds_read_b128 lane group touches land in disjoint bank quads
     static constexpr int LDH = ((KP / 4 + 1) % 2 == 1) ? KP + 4 : KP + 8;
+    // hidden units per wave: wave w owns [UPW*w, UPW*(w+1)); column tile `sub` holds its units 16*sub .. 16*sub+15, lanes
+    // past UPW are idle (their W_hh fragments are zero and nothing is stored), so every guard is a lane predicate
+    static constexpr int UPW = KP / 4;
 };
 
 struct DecoderWeights {
@@ -58,20 +61,32 @@ template <int G, int R>
 struct WaveWeights {
     float Bf[FusedCfg<G, R>::KSTEPS][6];
     float bh[6];
+    float ownf[2];  // 1 where this lane's unit of column tile `sub` is a real hidden unit, else 0
+    int ucl[2];     // that unit clamped into [0,H): the lane computes a throw-away duplicate instead of branching
+    int col[2];     // LDS column h' goes to: the unit, or one of the row's padding columns [KP, LDH) for idle lanes
     int vclamp0, vclamp1;
     float fcb0, fcb1;
 
     __device__ __forceinline__ void load(const DecoderWeights& w) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+        using C = FusedCfg<G, R>;
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) {
-            const int g = nt >> 1, unit = 32 * wave + 16 * (nt & 1) + l15;
-            bh[nt] = unit < w.H ? w.b_hh[g * w.H + unit] : 0.f;
+            const int g = nt >> 1, ul = 16 * (nt & 1) + l15, unit = C::UPW * wave + ul;
+            const bool own = ul < C::UPW && unit < w.H;
+            bh[nt] = own ? w.b_hh[g * w.H + unit] : 0.f;
 #pragma unroll
-            for (int s = 0; s < FusedCfg<G, R>::KSTEPS; ++s) {
+            for (int s = 0; s < C::KSTEPS; ++s) {
                 const int k = k_of_step<G, R>(s, lq);
-                Bf[s][nt] = (unit < w.H && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] : 0.f;
+                Bf[s][nt] = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] : 0.f;
             }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int ul = 16 * sub + l15, unit = C::UPW * wave + ul;
+            ownf[sub] = (ul < C::UPW && unit < w.H) ? 1.f : 0.f;
+            ucl[sub] = min(unit, w.H - 1);
+            col[sub] = ul < C::UPW ? unit : C::KP + (l15 & 3);
         }
         vclamp0 = min(l15, w.V - 1);
         vclamp1 = min(16 + l15, w.V - 1);
@@ -91,76 +106,86 @@ __device__ __forceinline__ void stage_tables(const DecoderWeights& w, float* tab
     }
 }
 
-// acc[mt][gate*2+sub] = h_src[64 rows] . W_hh^T for this wave's 32 hidden units
-template <int G, int R>
-__device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const float* h_src, f32x4 (&acc)[MT][6]) {
+// acc[mt][gate*2+sub] = h_src[rows of m-tiles MT0..MT0+NMT-1] . W_hh^T for this wave's hidden units
+template <int G, int R, int MT0, int NMT>
+__device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const float* h_src, f32x4 (&acc)[NMT][6]) {
     using C = FusedCfg<G, R>;
     const int lane = threadIdx.x & 63, l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        f32x4 af[MT];
+        f32x4 af[NMT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            af[mt] = *reinterpret_cast<const f32x4*>(&h_src[(mt * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
+        for (int mt = 0; mt < NMT; ++mt)
+            af[mt] = *reinterpret_cast<const f32x4*>(&h_src[((MT0 + mt) * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 6; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], ww.Bf[4 * g + j][nt], acc[mt][nt], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        float at[MT];
+        float at[NMT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) at[mt] = h_src[(mt * 16 + l15) * C::LDH + 16 * G + 4 * r + lq];
+        for (int mt = 0; mt < NMT; ++mt) at[mt] = h_src[((MT0 + mt) * 16 + l15) * C::LDH + 16 * G + 4 * r + lq];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[mt], ww.Bf[4 * G + r][nt], acc[mt][nt], 0, 0, 0);
     }
 }
 
+// tanh without control flow (the cell must stay one basic block so the scheduler can slide it under MFMAs):
+// |x| < 0.625: x + x^3 P(x^2), P fitted to <= 0.8 ulp; else 1 - 2/(e^{2|x|}+1) (<= 1.7 ulp); both evaluated, one selected.
+__device__ __forceinline__ float tanh_bf(float x) {
+    const float a = fabsf(x), t = a * a;
+    float p = 0.0023131025955080986f;
+    p = fmaf(p, t, -0.008364741690456867f);
+    p = fmaf(p, t, 0.021776489913463593f);
+    p = fmaf(p, t, -0.05396042391657829f);
+    p = fmaf(p, t, 0.13333310186862946f);
+    p = fmaf(p, t, -0.3333333432674408f);
+    const float small = fmaf(a * t, p, a);
+    const float big = 1.f - 2.f / (expf(2.f * a) + 1.f);
+    return copysignf(a < 0.625f ? small : big, x);
+}
+
 // GRU cell in the accumulator layout (gate order r,z,n; n = tanh(gi_n + r*(W_hn h + b_hn)); h' = (1-z)n + z h).
 // gi = tab[tok[row]] + rowc[rcrow[row]].  Reads the old state from h_src, writes h' to this wave's own columns of h_dst.
-template <int G, int R>
-__device__ __forceinline__ void gru_cell(const WaveWeights<G, R>& ww, const f32x4 (&acc)[MT][6], int H, const float* tab_l,
+template <int G, int R, int MT0, int NMT>
+__device__ __forceinline__ void gru_cell(const WaveWeights<G, R>& ww, const f32x4 (&acc)[NMT][6], int H, const float* tab_l,
                                          const float* rowc_l, const int* tok_l, const int* rcrow_l, const float* h_src,
                                          float* h_dst) {
     using C = FusedCfg<G, R>;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int lane = threadIdx.x & 63, lq = lane >> 4;
     const int H3 = 3 * H;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int row = mt * 16 + 4 * lq + jj;
+            const int row = (MT0 + mt) * 16 + 4 * lq + jj;
             const float* tr = tab_l + tok_l[row] * H3;
-            const float* rc = rowc_l + rcrow_l[row] * H3;
+            const float* rc = rowc_l + (rcrow_l ? rcrow_l[row] : row) * H3;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                const int unit = 32 * wave + 16 * sub + l15;
-                if (unit < C::KP) {
-                    float hv = 0.f;
-                    if (unit < H) {
-                        const float gi_r = tr[unit] + rc[unit];
-                        const float gi_z = tr[H + unit] + rc[H + unit];
-                        const float gi_n = tr[2 * H + unit] + rc[2 * H + unit];
-                        const float hn = acc[mt][4 + sub][jj] + ww.bh[4 + sub];
-                        const float rg = sigmoidf_(gi_r + (acc[mt][sub][jj] + ww.bh[sub]));
-                        const float zg = sigmoidf_(gi_z + (acc[mt][2 + sub][jj] + ww.bh[2 + sub]));
-                        const float ng = tanhf(gi_n + rg * hn);
-                        const float hold = h_src[row * C::LDH + unit];
-                        hv = (1.f - zg) * ng + zg * hold;
-                    }
-                    h_dst[row * C::LDH + unit] = hv;
-                }
+                const int uc = ww.ucl[sub];
+                const float gi_r = tr[uc] + rc[uc];
+                const float gi_z = tr[H + uc] + rc[H + uc];
+                const float gi_n = tr[2 * H + uc] + rc[2 * H + uc];
+                const float hn = acc[mt][4 + sub][jj] + ww.bh[4 + sub];
+                const float rg = sigmoidf_(gi_r + (acc[mt][sub][jj] + ww.bh[sub]));
+                const float zg = sigmoidf_(gi_z + (acc[mt][2 + sub][jj] + ww.bh[2 + sub]));
+                const float ng = tanh_bf(gi_n + rg * hn);
+                const float hold = h_src[row * C::LDH + uc];
+                // multiply (not select) by the ownership mask: a select lets the compiler sink the whole cell under a branch
+                h_dst[row * C::LDH + ww.col[sub]] = ((1.f - zg) * ng + zg * hold) * ww.ownf[sub];
             }
         }
 }
@@ -206,25 +231,100 @@ struct GreedyArgs {
     int N, T, ld_ids, start, pad, eos, ntiles;
 };
 
+// Scheduling directive for a barrier-to-barrier region that holds NMFMA matrix instructions and an independent body of
+// VALU / LDS work: emit them as {1 MFMA, PER others} groups.  An f32 16x16x4 MFMA occupies the matrix pipe for 32 cycles
+// (8 issue slots); left alone, hipcc emits all MFMAs first and the VALU work after them, i.e. serialises the two pipes.
+#ifndef CPG_FUSED_PER
+#define CPG_FUSED_PER 0
+#endif
+template <int NMFMA>
+__device__ __forceinline__ void interleave_mfma_with_rest() {
+#if CPG_FUSED_PER > 0
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x086, CPG_FUSED_PER, 0);  // VALU | SALU | DS
+    }
+#endif
+}
+
+// One quarter of a half-tile's vocabulary projection per wave: m-tile MT0 + (wave>>1), vocabulary columns 16*(wave&1)..+15.
+template <int G, int R, int MT0>
+__device__ __forceinline__ void half_logits(const float* h, const float* fc_l, const float* fc_b, int V, float* logit_l) {
+    using C = FusedCfg<G, R>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int mrow = (MT0 + (wave >> 1)) * 16, v = 16 * (wave & 1) + l15, vc = min(v, V - 1);
+    f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&h[(mrow + l15) * C::LDH + 16 * g + 4 * lq]);
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(&fc_l[vc * C::LDH + 16 * g + 4 * lq]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], lg, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        lg = __builtin_amdgcn_mfma_f32_16x16x4f32(h[(mrow + l15) * C::LDH + 16 * G + 4 * r + lq],
+                                                  fc_l[vc * C::LDH + 16 * G + 4 * r + lq], lg, 0, 0, 0);
+    const float bias = fc_b[vc];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) logit_l[(mrow + 4 * lq + jj) * LGS + v] = lg[jj] + bias;
+}
+
+// Greedy selection of one half-tile, done redundantly by EVERY wave (lanes 0..31 = the half's rows) so that the chosen
+// tokens reach the wave's own next cell pass through its private LDS copy without a workgroup barrier.  Returns the
+// number of rows still running (identical in all waves).  Wave 0 alone writes the ids and the step's running count.
+__device__ __forceinline__ int greedy_select_half(const GreedyArgs& a, const float* logit_l, int half, int row0, int step,
+                                                  int& fin, int* tokw_l) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int live = 0;
+    if (lane < 32) {
+        const int row = half * 32 + lane;
+        const float* l = logit_l + row * LGS;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int v = 0; v < a.w.V; ++v) {
+            const float x = l[v];
+            if (x > best) {
+                best = x;
+                arg = v;
+            }
+        }
+        const int t = fin ? a.pad : arg;
+        live = (fin || t == a.eos) ? 0 : 1;
+        if (t == a.eos) fin = 1;
+        tokw_l[row] = t;
+        if (wave == 0 && row0 + row < a.N) a.ids[(size_t)(row0 + row) * a.ld_ids + 1 + step] = t;
+    }
+    const int nl = __popcll(__ballot(live));
+    if (threadIdx.x == 0 && nl) atomicAdd(&a.unfinished[step], nl);
+    return nl;
+}
+
+// The tile is run as two half-tiles P (rows 0..31) and Q (rows 32..63) half a step out of phase, so that each
+// barrier-to-barrier region holds the matrix work of one half (its h . W_hh^T, plus the other half's vocabulary product)
+// and the VALU work of the other half's GRU cell: one basic block, which the scheduler interleaves (1 wave per SIMD:
+// nothing else can hide the cell's exp/div/tanh arithmetic behind the MFMA pipe).
+//   region 1 of step s:  cell(P,s) -> hP(s+1)   |  product(Q,s)   | logits(Q,s-1)      then select(Q,s-1)
+//   region 2 of step s:  cell(Q,s) -> hQ(s+1)   |  product(P,s+1) | logits(P,s)        then select(P,s)
 template <int G, int R>
 __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs a) {
     using C = FusedCfg<G, R>;
     extern __shared__ float4 cpg_fused_smem[];
     const int H = a.w.H, H3 = 3 * H, V = a.w.V;
-    float* h_l = reinterpret_cast<float*>(cpg_fused_smem);   // [RM][LDH]
-    float* fc_l = h_l + RM * C::LDH;                          // [V][LDH]
-    float* rowc_l = fc_l + V * C::LDH;                        // [RM][3H]
-    float* tab_l = rowc_l + RM * H3;                          // [Vt][3H]
-    float* logit_l = tab_l + a.w.Vt * H3;                     // [RM][LGS]
-    int* tok_l = reinterpret_cast<int*>(logit_l + RM * LGS);  // [RM]
-    int* fin_l = tok_l + RM;                                  // [RM]
-    int* rcrow_l = fin_l + RM;                                // [RM] identity here
+    float* h_l = reinterpret_cast<float*>(cpg_fused_smem);     // [RM][LDH]
+    float* fc_l = h_l + RM * C::LDH;                            // [V][LDH]
+    float* rowc_l = fc_l + V * C::LDH;                          // [RM][3H]
+    float* tab_l = rowc_l + RM * H3;                            // [Vt][3H]
+    float* logit_l = tab_l + a.w.Vt * H3;                       // [RM][LGS]
+    float* fcb_l = logit_l + RM * LGS;                          // [32]
+    int* tokw_l = reinterpret_cast<int*>(fcb_l + 32) + (threadIdx.x >> 6) * RM;  // [4][RM]: this wave's copy of the tokens
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     WaveWeights<G, R> ww;
     ww.load(a.w);
     stage_tables<G, R>(a.w, tab_l, fc_l);
-    if (tid < RM) rcrow_l[tid] = tid;
+    if (tid < 32) fcb_l[tid] = a.w.fc_b[min(tid, V - 1)];
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int row0 = tile * RM, nrows = min(RM, a.N - row0);
@@ -238,53 +338,40 @@ __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs 
             const int n = nrows * H3;
             for (int i = tid; i < RM * H3; i += 256) rowc_l[i] = i < n ? src[i] : 0.f;
         }
-        if (tid < RM) {
-            tok_l[tid] = a.start;
-            fin_l[tid] = 0;
-        }
+        tokw_l[lane] = a.start;
+        int finP = lane < 32 && lane >= nrows, finQ = lane < 32 && 32 + lane >= nrows;  // rows past N never run
+        int liveP = 1, liveQ = 1;
         __syncthreads();
 
+        f32x4 accP[2][6], accQ[2][6];
+        gru_product<G, R, 0, 2>(ww, h_l, accP);
         for (int step = 0; step < a.T; ++step) {
-            f32x4 acc[MT][6];
-            gru_product<G, R>(ww, h_l, acc);
-            __syncthreads();  // every wave is done reading h (and last step's tokens are in tok_l)
-            gru_cell<G, R>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, h_l, h_l);
+            // region 1
+            gru_product<G, R, 2, 2>(ww, h_l, accQ);
+            half_logits<G, R, 2>(h_l, fc_l, fcb_l, V, logit_l);  // step 0: hQ(0), result unused
+            gru_cell<G, R, 0, 2>(ww, accP, H, tab_l, rowc_l, tokw_l, nullptr, h_l, h_l);
+            interleave_mfma_with_rest<13 * C::KSTEPS>();
             __syncthreads();
-            vocab_logits<G, R>(ww, h_l, fc_l, logit_l);
+            if (step > 0) liveQ = greedy_select_half(a, logit_l, 1, row0, step - 1, finQ, tokw_l);
+            // region 2
+            gru_product<G, R, 0, 2>(ww, h_l, accP);  // last step: unused
+            half_logits<G, R, 0>(h_l, fc_l, fcb_l, V, logit_l);
+            gru_cell<G, R, 2, 2>(ww, accQ, H, tab_l, rowc_l, tokw_l, nullptr, h_l, h_l);
+            interleave_mfma_with_rest<13 * C::KSTEPS>();
             __syncthreads();
-
-            // token selection: lanes 0..15 of each wave take one row each (torch.argmax: first maximum)
-            int live = 0;
-            if (lane < 16) {
-                const int row = wave * 16 + lane;
-                if (row < nrows) {
-                    const float* l = logit_l + row * LGS;
-                    float best = -INFINITY;
-                    int arg = 0;
-                    for (int v = 0; v < V; ++v) {
-                        const float x = l[v];
-                        if (x > best) {
-                            best = x;
-                            arg = v;
-                        }
-                    }
-                    const bool fin = fin_l[row] != 0;
-                    const int t = fin ? a.pad : arg;
-                    if (t == a.eos) fin_l[row] = 1;
-                    live = (fin || t == a.eos) ? 0 : 1;
-                    a.ids[(size_t)(row0 + row) * a.ld_ids + 1 + step] = t;
-                    tok_l[row] = t;
-                }
-            }
-            const unsigned long long lb = __ballot(live);
-            if (lane == 0 && lb) atomicAdd(&a.unfinished[step], __popcll(lb));
-            if (__syncthreads_count(live) == 0) break;  // whole tile finished: the remaining columns stay <pad>
+            liveP = greedy_select_half(a, logit_l, 0, row0, step, finP, tokw_l);
+            if (liveP + liveQ == 0) break;  // whole tile finished (identical decision in every wave): the rest stays <pad>
+        }
+        if (liveP + liveQ != 0) {  // drain: Q's last step
+            half_logits<G, R, 2>(h_l, fc_l, fcb_l, V, logit_l);
+            __syncthreads();
+            greedy_select_half(a, logit_l, 1, row0, a.T - 1, finQ, tokw_l);
         }
     }
 }
 
 size_t greedy_lds_bytes(int ldh, int H, int V, int Vt) {
-    return ((size_t)RM * ldh + (size_t)V * ldh + (size_t)RM * 3 * H + (size_t)Vt * 3 * H + RM * LGS) * 4 + 3 * RM * sizeof(int);
+    return ((size_t)RM * ldh + (size_t)V * ldh + (size_t)RM * 3 * H + (size_t)Vt * 3 * H + RM * LGS + 32) * 4 + 4 * RM * sizeof(int);
 }
 
 template <int G, int R>
@@ -358,8 +445,8 @@ __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
 
         for (int step = 0; step < a.T; ++step) {
             f32x4 acc[MT][6];
-            gru_product<G, R>(ww, hx_l, acc);
-            gru_cell<G, R>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, hx_l, hy_l);
+            gru_product<G, R, 0, MT>(ww, hx_l, acc);
+            gru_cell<G, R, 0, MT>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, hx_l, hy_l);
             __syncthreads();
             vocab_logits<G, R>(ww, hy_l, fc_l, logit_l);
             __syncthreads();
