@@ -5,6 +5,10 @@
 //   cpg_matmul_nn          Y = X B                (losses.py:85  z @ rf_w)
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#ifndef CPG_TN_PRODUCT_SPLIT
+#define CPG_TN_PRODUCT_SPLIT 7  // 0: exact-f32 MFMA; 6 / 7: six bf16 MFMAs on 3-way split operands (f32-grade), split per
+                                // wave at fragment time / once at LDS-store time (gemm_core.h)
+#endif
 #include <stdlib.h>
 
 struct GemmArgs {
@@ -20,6 +24,13 @@ struct GemmArgs {
     int k_chunk;        // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)), writes slab z
     size_t slab_stride; // floats between slabs (0 when not split)
 };
+
+template <class TC, bool A_KC, bool B_KC>
+constexpr int gemm_split() {
+    return (!A_KC && !B_KC && TC::AV % 2 == 0 && TC::BV % 2 == 0) ? CPG_TN_PRODUCT_SPLIT : 0;
+}
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
+using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, B_KC>()>;
 
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -40,7 +51,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS>::run(a, b, K, acc);
+    // transposed-operand products (dW = dY^T X: the 80 GFLOP dW_hh product) run on split bf16 operands, see gemm_core.h
+    GemmLoop<TC, A_KC, B_KC, VEC, MASKS>::run(a, b, K, acc);
     float* C = g.C + (size_t)bz * g.slab_stride;
     const bool plain = g.k_chunk == 0;
 #pragma unroll
@@ -102,8 +114,18 @@ __global__ void colsum_final_kernel(const float* part, int chunks, int N, float*
 template <class TC, bool A_KC, bool B_KC>
 static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.N, TC::BN), cdiv(g.M, TC::BM), zdim);
-    const size_t smem = TC::template smem_floats<A_KC, B_KC>() * sizeof(float);
+    const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false>::smem_bytes();
     const bool masks = g.a_mask || g.b_mask;
+    if (smem > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in once per instantiation
+        static bool done = false;
+        if (!done) {
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            done = true;
+        }
+    }
     if (vec && masks)
         hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true>), grid, dim3(256), smem, s, g);
     else if (vec)

@@ -120,7 +120,56 @@ __device__ __forceinline__ float4 finish4(float4 v, unsigned okbits, bool has_ma
     return v;
 }
 
-template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC, bool MASKS = false>
+// bf16 split-operand products (SPLIT = 6).  Measured on MI355X (tools/micro/mfma_valu_overlap.hip): the f32 MFMA
+// (v_mfma_f32_16x16x4_f32, 32 cycles) cannot overlap with VALU work at all - {1 MFMA + n VALU} costs the SUM of the two,
+// it runs on the same f32 lanes - while v_mfma_f32_16x16x32_bf16 (20.5 cycles for 8x the contraction depth) does.
+// x = x0 + x1 + x2 with x_i bf16 (residual <= 2^-27 |x|); a.b ~= a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 (dropped terms
+// <= 2^-26 |a.b|), products exact in f32, accumulated in the MFMA's f32 accumulator: f32-grade results from six bf16
+// MFMAs (123 cycles) in place of eight f32 MFMAs (268 cycles) per 16x16x32 block, and the conversion VALU work overlaps.
+typedef __bf16 cpg_bf16x8 __attribute__((ext_vector_type(8)));
+
+// three bf16 planes of 8 f32 values
+__device__ __forceinline__ void split3(const float (&x)[8], cpg_bf16x8& p0, cpg_bf16x8& p1, cpg_bf16x8& p2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 b0 = (__bf16)x[i];
+        const float r1 = x[i] - (float)b0;
+        const __bf16 b1 = (__bf16)r1;
+        const float r2 = r1 - (float)b1;
+        p0[i] = b0;
+        p1[i] = b1;
+        p2[i] = (__bf16)r2;
+    }
+}
+
+// one (even k, odd k) pair -> one 32-bit word per plane (low half = even k): 3 packed converts + 4 unpacks + 4 subtractions.
+// (Written with the instruction itself: from scalar __bf16 casts hipcc emits one v_cvt_pk per ELEMENT plus moves - measured
+// 312 VALU instructions per slab and wave on the dW_hh product, VALU-bound.)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    w0 = cvt_pk_bf16(lo, hi);
+    const float l1 = lo - __uint_as_float(w0 << 16), h1 = hi - __uint_as_float(w0 & 0xffff0000u);
+    w1 = cvt_pk_bf16(l1, h1);
+    const float l2 = l1 - __uint_as_float(w1 << 16), h2 = h1 - __uint_as_float(w1 & 0xffff0000u);
+    w2 = cvt_pk_bf16(l2, h2);
+}
+
+// SPLIT = 0: exact-f32 MFMA on f32 LDS images (the layouts described at the top of this file).
+// SPLIT = 6: same LDS images; every wave splits its own fragments right before the bf16 MFMAs (conversion work is
+//            repeated by the waves that share an operand: VALU-bound, measured 886 -> 790 us on the dW_hh product).
+// SPLIT = 7: operands are split ONCE, when a slab is stored to LDS.  LDS then holds three bf16 planes per operand:
+//              KC -> plane[X][16 data + 4 pad words]   a lane's 8 consecutive k = one ds_read_b128
+//              XC -> plane[BK/2][X + 4 words]          word = (k even, k odd) of one x; a lane's 8 k = four ds_read_b32;
+//                                                      a thread stages rows k and k+1 of the same 4 columns and writes
+//                                                      the four packed words with one ds_write_b128 per plane
+//            MFMA slot i of lane group q contracts k = 8q + i for both layouts.
+// (Pre-splitting the weight operand once per call instead of in every tile was tried and measured: no gain - 37.5 vs 37.1 us
+// per forward step - the conversion VALU work is not what bounds the small-tile step kernels.)
+template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC, bool MASKS = false, int SPLIT = 0>
 struct MainLoop {
     static constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK;
     static constexpr int LDA = TC::template lda<A_KC>();
@@ -133,6 +182,30 @@ struct MainLoop {
     static constexpr bool PERM = A_KC || B_KC;
     static_assert(BK % 16 == 0, "slab depth must be a multiple of 16");
     static constexpr int NH = BK / 16;  // 16-deep halves per slab
+    // staging-time split (SPLIT == 7): plane geometry in 32-bit words
+    static constexpr int KCW = 20;
+    static constexpr int SXA = BM + 4, SXB = BN + 4;
+    static constexpr int APL = A_KC ? BM * KCW : (BK / 2) * SXA;
+    static constexpr int BPL = B_KC ? BN * KCW : (BK / 2) * SXB;
+    static constexpr int ASZ7 = 3 * APL, BSZ7 = 3 * BPL;
+    static_assert(SPLIT != 7 || BK == 32, "split products are written for 32-deep slabs");
+    static_assert(SPLIT != 7 || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
+    static constexpr size_t smem_bytes() {
+        return SPLIT == 7 ? (size_t)2 * (ASZ7 + BSZ7) * 4 : (size_t)2 * (ASZ + BSZ) * sizeof(float);
+    }
+    // staging vector i of this thread -> (k row inside the slab, column quad) for an XC operand X columns wide
+    template <int BX>
+    __device__ static __forceinline__ void xc_index(int i, int& kk, int& xq) {
+        if (SPLIT == 7) {
+            const int u = threadIdx.x + (i >> 1) * TC::NT;
+            xq = u % (BX / 4);
+            kk = 2 * (u / (BX / 4)) + (i & 1);
+        } else {
+            const int v = threadIdx.x + i * TC::NT;
+            kk = v / (BX / 4);
+            xq = v % (BX / 4);
+        }
+    }
 
     struct Stage {  // one K-slab of both operands in flight in registers
         float4 a[TC::AV], b[TC::BV];
@@ -157,7 +230,8 @@ struct MainLoop {
                 pl.an[i] = 4 * kq;
                 pl.a[i] = (size_t)(pl.aok[i] ? gm : 0) * a.ld + 4 * kq;
             } else {
-                const int kk = v / (BM / 4), mq = v % (BM / 4);
+                int kk, mq;
+                xc_index<BM>(i, kk, mq);
                 const int gm = a.m0 + 4 * mq;
                 const int nc = min(max(a.M - gm, 0), 4);
                 pl.aok[i] = true;
@@ -176,7 +250,8 @@ struct MainLoop {
                 pl.bn[i] = 4 * kq;
                 pl.b[i] = (size_t)(pl.bok[i] ? idx : 0) * b.ld + 4 * kq;
             } else {
-                const int kk = v / (BN / 4), nq = v % (BN / 4);
+                int kk, nq;
+                xc_index<BN>(i, kk, nq);
                 bmap<TC::NSEG>(b, 4 * nq, idx, j);
                 const int nc = min(max(b.seg_len - j, 0), 4);
                 pl.bok[i] = true;
@@ -238,15 +313,16 @@ struct MainLoop {
     }
 
     __device__ static __forceinline__ void gload(const OpA& a, const OpB& b, const Plan& pl, int k0, int K, Stage& st) {
-        const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) {
-            const int kk = (tid + i * TC::NT) / (BM / 4);
+            int kk, xq_;
+            xc_index<BM>(i, kk, xq_);
             st.a[i] = fetch<A_KC, AVEC>(a.p, a.mask, pl.a[i], pl.an[i], pl.aok[i], a.ld, k0, K, kk, st.aok[i], st.am[i]);
         }
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
-            const int kk = (tid + i * TC::NT) / (BN / 4);
+            int kk, xq_;
+            xc_index<BN>(i, kk, xq_);
             st.b[i] = fetch<B_KC, BVEC>(b.p, b.mask, pl.b[i], pl.bn[i], pl.bok[i], b.ld, k0, K, kk, st.bok[i], st.bm[i]);
         }
     }
@@ -266,6 +342,136 @@ struct MainLoop {
             const float4 r = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
             const int off = B_KC ? (v / (BK / 4)) * LDB + 4 * (v % (BK / 4)) : (v / (BN / 4)) * LDB + 4 * (v % (BN / 4));
             *reinterpret_cast<float4*>(Bs + off) = r;
+        }
+    }
+
+    // ---- SPLIT == 7: split at LDS-store time -------------------------------------------------------------------------
+    template <bool KC, int BX, int NV, int PLW, int SX>
+    __device__ static __forceinline__ void sstore7_op(uint32_t* dst, const float4 (&r)[NV]) {
+        const int tid = threadIdx.x;
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * TC::NT, row = v / (BK / 4), kq = v % (BK / 4);
+                uint32_t a0, a1, a2, b0, b1, b2;
+                split3_pair(r[i].x, r[i].y, a0, a1, a2);
+                split3_pair(r[i].z, r[i].w, b0, b1, b2);
+                uint32_t* q = dst + row * KCW + 2 * kq;
+                *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
+                *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV / 2; ++j) {
+                const int u = tid + j * TC::NT, xq = u % (BX / 4), p = u / (BX / 4);
+                const float4 e = r[2 * j], o = r[2 * j + 1];
+                uint32_t w0[4], w1[4], w2[4];
+                split3_pair(e.x, o.x, w0[0], w1[0], w2[0]);
+                split3_pair(e.y, o.y, w0[1], w1[1], w2[1]);
+                split3_pair(e.z, o.z, w0[2], w1[2], w2[2]);
+                split3_pair(e.w, o.w, w0[3], w1[3], w2[3]);
+                uint32_t* q = dst + p * SX + 4 * xq;
+                *reinterpret_cast<uint4*>(q) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+                *reinterpret_cast<uint4*>(q + PLW) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+                *reinterpret_cast<uint4*>(q + 2 * PLW) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+            }
+        }
+    }
+
+    __device__ static __forceinline__ void sstore7(const OpA& a, const OpB& b, uint32_t* As, uint32_t* Bs, const Stage& st) {
+        float4 ra[TC::AV], rb[TC::BV];
+#pragma unroll
+        for (int i = 0; i < TC::AV; ++i) ra[i] = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
+        sstore7_op<A_KC, BM, TC::AV, APL, SXA>(As, ra);
+#pragma unroll
+        for (int i = 0; i < TC::BV; ++i) rb[i] = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
+        sstore7_op<B_KC, BN, TC::BV, BPL, SXB>(Bs, rb);
+    }
+
+    template <bool KC, int PLW, int SX>
+    __device__ static __forceinline__ cpg_bf16x8 read7(const uint32_t* plane0, int pl, int x, int lq) {
+        const uint32_t* P = plane0 + pl * PLW;
+        if (KC) return *reinterpret_cast<const cpg_bf16x8*>(P + x * KCW + 4 * lq);
+        const uint4 w = make_uint4(P[(4 * lq + 0) * SX + x], P[(4 * lq + 1) * SX + x], P[(4 * lq + 2) * SX + x], P[(4 * lq + 3) * SX + x]);
+        return __builtin_bit_cast(cpg_bf16x8, w);
+    }
+
+    // One slab: for every column block read its three B planes once, then walk the row blocks (A planes re-read per column
+    // block: LDS reads are cheap here, registers are not - holding all planes of a 128x64 tile costs a resident wave), six
+    // bf16 MFMAs per 16x16 block; the next slab's conversion + LDS writes are left free to interleave with them.
+    template <bool STORE>
+    __device__ static __forceinline__ void slab7(const OpA& a, const OpB& b, const uint32_t* Ac, const uint32_t* Bc, uint32_t* An,
+                                                 uint32_t* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave / TC::WN, wn = wave % TC::WN;
+        const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) {
+            cpg_bf16x8 fb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if (CPG_ABLATE & 2) fb[pl] = __builtin_bit_cast(cpg_bf16x8, acc[0][ni]);
+                else fb[pl] = read7<B_KC, BPL, SXB>(Bc, pl, wn * TC::WTN + ni * 16 + l15, lq);
+            }
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi) {
+                cpg_bf16x8 fa[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (CPG_ABLATE & 2) fa[pl] = __builtin_bit_cast(cpg_bf16x8, acc[mi][0]);
+                    else fa[pl] = read7<A_KC, APL, SXA>(Ac, pl, wm * TC::WTM + mi * 16 + l15, lq);
+                }
+                f32x4 c = acc[mi][ni];
+                if (CPG_ABLATE & 8) {
+                    const f32x4 u = __builtin_bit_cast(f32x4, fa[0]), w = __builtin_bit_cast(f32x4, fb[0]);
+                    const f32x4 u1 = __builtin_bit_cast(f32x4, fa[1]), w1 = __builtin_bit_cast(f32x4, fb[1]);
+                    const f32x4 u2 = __builtin_bit_cast(f32x4, fa[2]), w2 = __builtin_bit_cast(f32x4, fb[2]);
+                    acc[mi][ni] = c + u * w + u1 * w1 + u2 * w2;
+                    continue;
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0], c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+        }
+        if (STORE && !(CPG_ABLATE & 1)) sstore7(a, b, An, Bn, st);
+    }
+
+    __device__ static __forceinline__ void run7(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI]) {
+        extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+        uint32_t* const base = reinterpret_cast<uint32_t*>(cpg_smem);
+        uint32_t* const A0 = base;
+        uint32_t* const A1 = base + ASZ7;
+        uint32_t* const B0 = base + 2 * ASZ7;
+        uint32_t* const B1 = base + 2 * ASZ7 + BSZ7;
+        Stage st;
+        Plan pl;
+        plan(a, b, pl);
+        const int KT = (K + BK - 1) / BK;
+        gload(a, b, pl, 0, K, st);
+        sstore7(a, b, A0, B0, st);
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 1 < KT) {
+                if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 1) * BK, K, st);
+                slab7<true>(a, b, A0, B0, A1, B1, st, acc);
+            } else {
+                slab7<false>(a, b, A0, B0, A1, B1, st, acc);
+            }
+            __syncthreads();
+            if (kt + 1 >= KT) break;
+            if (kt + 2 < KT) {
+                if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 2) * BK, K, st);
+                slab7<true>(a, b, A1, B1, A0, B0, st, acc);
+            } else {
+                slab7<false>(a, b, A1, B1, A0, B0, st, acc);
+            }
+            __syncthreads();
         }
     }
 
@@ -310,6 +516,39 @@ struct MainLoop {
         }
     }
 
+    // fragment-time split: the slab's 8 contraction indices per lane (2 halves x 4 steps; A and B use the same set) feed
+    // one 16x16x32 bf16 MFMA per plane pair.  BK = 32 only.
+    __device__ static __forceinline__ void mfmas_split(const Frag& f, f32x4 (&acc)[TC::MI][TC::NI]) {
+        static_assert(SPLIT == 0 || BK == 32, "split products are written for 32-deep slabs");
+        cpg_bf16x8 a0[TC::MI], a1[TC::MI], a2[TC::MI];
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = f.a[i >> 2][mi][i & 3];
+            split3(x, a0[mi], a1[mi], a2[mi]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = f.b[i >> 2][ni][i & 3];
+            cpg_bf16x8 b0, b1, b2;
+            split3(x, b0, b1, b2);
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi) {
+                f32x4 c = acc[mi][ni];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mi], b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0, c, 0, 0, 0);
+                acc[mi][ni] = c;
+            }
+        }
+    }
+
     template <int H0, int H1>
     __device__ static __forceinline__ void mfmas(const Frag& f, f32x4 (&acc)[TC::MI][TC::NI]) {
 #pragma unroll
@@ -349,6 +588,12 @@ struct MainLoop {
             read_frags(Ac, Bc, f);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (SPLIT == 6) {
+            // the conversion VALU work and the LDS writes of the next slab run beside the bf16 MFMAs: leave the order free
+            mfmas_split(f, acc);
+            if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
+            return;
+        }
 #if CPG_SCHED == 0
         mfmas<0, NH / 2>(f, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -377,6 +622,10 @@ struct MainLoop {
     // The two LDS buffers are addressed with compile-time offsets from the __shared__ symbol itself (2x unrolled slab
     // loop): runtime-selected buffer pointers degrade to flat_* accesses whose waits also drain the global prefetch.
     __device__ static __forceinline__ void run(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI]) {
+        if (SPLIT == 7) {
+            run7(a, b, K, acc);
+            return;
+        }
         extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
         float* const A0 = cpg_smem;
         float* const A1 = cpg_smem + ASZ;

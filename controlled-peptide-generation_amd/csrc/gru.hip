@@ -43,6 +43,13 @@ struct GruFwdPair {
     GruFwdArgs d[2];
 };
 
+// h . W_hh^T of the forward step: exact-f32 MFMA (0) or six bf16 MFMAs on operands split when the slab is stored (7)
+#ifndef CPG_STEP_FWD_SPLIT
+#define CPG_STEP_FWD_SPLIT 7
+#endif
+template <class TC, bool VEC>
+using FwdLoop = MainLoop<TC, true, true, VEC, VEC, false, (CPG_STEP_FWD_SPLIT == 7 && TC::BK == 32) ? 7 : 0>;
+
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
     int bx, by, bz;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
+    FwdLoop<TC, VEC>::run(a, b, H, acc);
 #if !CPG_FWD_PREFETCH
     fetch();
 #endif
@@ -300,7 +307,15 @@ template <class TC>
 static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = TC::template smem_floats<true, true>() * sizeof(float);
+    const size_t smem = FwdLoop<TC, true>::smem_bytes();
+    if (smem > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per instantiation
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done = true;
+        }
+    }
     if (vec)
         hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
     else
@@ -337,8 +352,12 @@ static int gru_fwd_launch(const GruFwdPair& pr, int nd, hipStream_t s) {
     bool vec = a.H % 4 == 0;
     for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].h_prev) && aligned16(pr.d[d].w_hh);
     int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
-    // forward: 32-row tiles (4 resident workgroups per CU) measured 43.5 us vs 46.9 us for 64-row tiles at B=2048,H=512
-    if (bm == 64 && !getenv("CPG_GRU_FWD_BM") && (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) * nd >= 1024) bm = 32;
+    // exact-f32 engine: 32-row tiles (4 resident workgroups per CU) measured 43.5 us vs 46.9 us for 64-row tiles at
+    // B=2048,H=512.  Split-bf16 engine: 64-row tiles 37.1 us vs 50.8 us for 32-row tiles (every row tile converts the
+    // whole W_hh slab again, and the slab barrier is paid twice as often per MFMA).
+    if (CPG_STEP_FWD_SPLIT != 7 && bm == 64 && !getenv("CPG_GRU_FWD_BM") &&
+        (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) * nd >= 1024)
+        bm = 32;
     if (bm == 128) launch_fwd<GF128>(pr, nd, vec, s);
     else if (bm == 64) launch_fwd<GF64>(pr, nd, vec, s);
     else launch_fwd<GF32>(pr, nd, vec, s);

@@ -199,8 +199,8 @@ def test_class_kernels_golden(golden):
 
 
 def test_split_and_row_range_forms_match_fused():
-    """cpg_gru_seq_fwd over row ranges, and the split (product + cell kernel) form, are bit-identical to the fused full-batch
-    sequence: rows are independent recurrences and both forms run the same k-ordered f32 products."""
+    """cpg_gru_seq_fwd over row ranges is bit-identical to the fused full-batch sequence (rows are independent recurrences);
+    the split (product + cell kernel) form agrees to f32 rounding."""
     from cpg.ops import _p, _stream, call
     g = torch.Generator().manual_seed(0)
     B, H, T, V = 200, 96, 6, 24
@@ -226,8 +226,11 @@ def test_split_and_row_range_forms_match_fused():
             call("cpg_gru_seq_fwd_split", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates),
                  _p(gh), 0, B, _stream())
         outs.append((hs.clone(), gates.clone()))
-    for hs, gates in outs[1:]:
-        assert torch.equal(hs, outs[0][0]) and torch.equal(gates, outs[0][1])
+    # row ranges run the same arithmetic on the same rows: bit-identical
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    # the split form takes its product from the exact-f32 MFMA kernel, the fused one from six bf16 MFMAs on 3-way split
+    # operands (csrc/gemm_core.h): same value to f32 rounding of the 96-term sums
+    assert torch.allclose(outs[2][0], outs[0][0], atol=2e-6, rtol=0) and torch.allclose(outs[2][1], outs[0][1], atol=2e-6, rtol=0)
 
 
 def test_cnn_classifier_forward_golden(golden):
