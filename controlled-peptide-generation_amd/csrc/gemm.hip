@@ -6,8 +6,7 @@
 #include "gemm_core.h"
 #include "cpg_internal.h"
 #ifndef CPG_TN_PRODUCT_SPLIT
-#define CPG_TN_PRODUCT_SPLIT 7  // 0: exact-f32 MFMA; 6 / 7: six bf16 MFMAs on 3-way split operands (f32-grade), split per
-                                // wave at fragment time / once at LDS-store time (gemm_core.h)
+#define CPG_TN_PRODUCT_SPLIT 7  // 0: exact-f32 MFMA; 7: six bf16 MFMAs on 3-way split operands, f32-grade (gemm_core.h)
 #endif
 #include <stdlib.h>
 

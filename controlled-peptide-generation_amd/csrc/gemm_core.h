@@ -1,4 +1,8 @@
-// f32 MFMA tile engine for gfx950 (v_mfma_f32_16x16x4_f32: exact f32, 64 FLOP/clk/SIMD).
+// MFMA tile engine for gfx950, f32 in / f32 out.  Two product forms share the staging, tiling and epilogue conventions:
+//   SPLIT = 0  v_mfma_f32_16x16x4_f32 (exact f32, 64 FLOP/clk/SIMD) on f32 LDS images - described first;
+//   SPLIT = 7  six v_mfma_f32_16x16x32_bf16 on operands split three ways into bf16 when a slab is stored to LDS
+//              (f32-grade results, 2.2x less matrix-pipe time, and - unlike the f32 MFMA - able to overlap VALU work);
+//              see the comment above MainLoop.
 //
 // One 256-thread workgroup (4 wave64) computes a BM x BN tile of  C = A * B  with the contraction
 // dimension K streamed through LDS in BK-deep slabs, double buffered (global -> registers while the
@@ -120,27 +124,13 @@ __device__ __forceinline__ float4 finish4(float4 v, unsigned okbits, bool has_ma
     return v;
 }
 
-// bf16 split-operand products (SPLIT = 6).  Measured on MI355X (tools/micro/mfma_valu_overlap.hip): the f32 MFMA
+// bf16 split-operand products (SPLIT = 7).  Measured on MI355X (tools/micro/mfma_valu_overlap.hip): the f32 MFMA
 // (v_mfma_f32_16x16x4_f32, 32 cycles) cannot overlap with VALU work at all - {1 MFMA + n VALU} costs the SUM of the two,
 // it runs on the same f32 lanes - while v_mfma_f32_16x16x32_bf16 (20.5 cycles for 8x the contraction depth) does.
 // x = x0 + x1 + x2 with x_i bf16 (residual <= 2^-27 |x|); a.b ~= a0b0 + a0b1 + a1b0 + a1b1 + a0b2 + a2b0 (dropped terms
 // <= 2^-26 |a.b|), products exact in f32, accumulated in the MFMA's f32 accumulator: f32-grade results from six bf16
 // MFMAs (123 cycles) in place of eight f32 MFMAs (268 cycles) per 16x16x32 block, and the conversion VALU work overlaps.
 typedef __bf16 cpg_bf16x8 __attribute__((ext_vector_type(8)));
-
-// three bf16 planes of 8 f32 values
-__device__ __forceinline__ void split3(const float (&x)[8], cpg_bf16x8& p0, cpg_bf16x8& p1, cpg_bf16x8& p2) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 b0 = (__bf16)x[i];
-        const float r1 = x[i] - (float)b0;
-        const __bf16 b1 = (__bf16)r1;
-        const float r2 = r1 - (float)b1;
-        p0[i] = b0;
-        p1[i] = b1;
-        p2[i] = (__bf16)r2;
-    }
-}
 
 // one (even k, odd k) pair -> one 32-bit word per plane (low half = even k): 3 packed converts + 4 unpacks + 4 subtractions.
 // (Written with the instruction itself: from scalar __bf16 casts hipcc emits one v_cvt_pk per ELEMENT plus moves - measured
@@ -159,8 +149,8 @@ __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, ui
 }
 
 // SPLIT = 0: exact-f32 MFMA on f32 LDS images (the layouts described at the top of this file).
-// SPLIT = 6: same LDS images; every wave splits its own fragments right before the bf16 MFMAs (conversion work is
-//            repeated by the waves that share an operand: VALU-bound, measured 886 -> 790 us on the dW_hh product).
+// (Splitting per wave at fragment-read time on the f32 LDS images was tried first: the conversion is then repeated by
+//  every wave that shares an operand - VALU-bound; not kept.)
 // SPLIT = 7: operands are split ONCE, when a slab is stored to LDS.  LDS then holds three bf16 planes per operand:
 //              KC -> plane[X][16 data + 4 pad words]   a lane's 8 consecutive k = one ds_read_b128
 //              XC -> plane[BK/2][X + 4 words]          word = (k even, k odd) of one x; a lane's 8 k = four ds_read_b32;
@@ -188,6 +178,7 @@ struct MainLoop {
     static constexpr int APL = A_KC ? BM * KCW : (BK / 2) * SXA;
     static constexpr int BPL = B_KC ? BN * KCW : (BK / 2) * SXB;
     static constexpr int ASZ7 = 3 * APL, BSZ7 = 3 * BPL;
+    static_assert(SPLIT == 0 || SPLIT == 7, "0: exact f32, 7: bf16 split at LDS-store time");
     static_assert(SPLIT != 7 || BK == 32, "split products are written for 32-deep slabs");
     static_assert(SPLIT != 7 || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
     static constexpr size_t smem_bytes() {
@@ -516,39 +507,6 @@ struct MainLoop {
         }
     }
 
-    // fragment-time split: the slab's 8 contraction indices per lane (2 halves x 4 steps; A and B use the same set) feed
-    // one 16x16x32 bf16 MFMA per plane pair.  BK = 32 only.
-    __device__ static __forceinline__ void mfmas_split(const Frag& f, f32x4 (&acc)[TC::MI][TC::NI]) {
-        static_assert(SPLIT == 0 || BK == 32, "split products are written for 32-deep slabs");
-        cpg_bf16x8 a0[TC::MI], a1[TC::MI], a2[TC::MI];
-#pragma unroll
-        for (int mi = 0; mi < TC::MI; ++mi) {
-            float x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = f.a[i >> 2][mi][i & 3];
-            split3(x, a0[mi], a1[mi], a2[mi]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < TC::NI; ++ni) {
-            float x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = f.b[i >> 2][ni][i & 3];
-            cpg_bf16x8 b0, b1, b2;
-            split3(x, b0, b1, b2);
-#pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi) {
-                f32x4 c = acc[mi][ni];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[mi], b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b2, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mi], b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b1, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mi], b0, c, 0, 0, 0);
-                acc[mi][ni] = c;
-            }
-        }
-    }
-
     template <int H0, int H1>
     __device__ static __forceinline__ void mfmas(const Frag& f, f32x4 (&acc)[TC::MI][TC::NI]) {
 #pragma unroll
@@ -588,12 +546,6 @@ struct MainLoop {
             read_frags(Ac, Bc, f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (SPLIT == 6) {
-            // the conversion VALU work and the LDS writes of the next slab run beside the bf16 MFMAs: leave the order free
-            mfmas_split(f, acc);
-            if (STORE && !(CPG_ABLATE & 1)) sstore(a, b, An, Bn, st);
-            return;
-        }
 #if CPG_SCHED == 0
         mfmas<0, NH / 2>(f, acc);
         __builtin_amdgcn_sched_barrier(0);

@@ -159,6 +159,14 @@ struct GruBwdPair {
     GruBwdArgs d[2];
 };
 
+// dgh . W_hh of the backward step: W_hh is the transposed-use (XC) operand, whose split staging works on k-row pairs
+// (tiles at least 64 columns wide); narrower tiles keep the exact-f32 MFMA.
+#ifndef CPG_STEP_BWD_SPLIT
+#define CPG_STEP_BWD_SPLIT 7
+#endif
+template <class TC, bool VEC>
+using BwdLoop = MainLoop<TC, true, false, VEC, VEC, false, (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && TC::BV % 2 == 0) ? 7 : 0>;
+
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     if (g.dG_next) {
         OpA a{g.dG_next, 4 * H, m0, B, nullptr, 1.f};
         OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
-        MainLoop<TC, true, false, VEC, VEC>::run(a, b, 3 * H, acc);
+        BwdLoop<TC, VEC>::run(a, b, 3 * H, acc);
     }
 #pragma unroll
     for (int ni = 0; ni < TC::NI; ++ni) {
@@ -326,7 +334,15 @@ template <class TC>
 static void launch_bwd(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = TC::template smem_floats<true, false>() * sizeof(float);
+    const size_t smem = BwdLoop<TC, true>::smem_bytes();
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done = true;
+        }
+    }
     if (vec)
         hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
     else
