@@ -189,11 +189,14 @@ def main():
     extra = {"loss_last_step": round(loss_val, 4), "executed_step_tflops_per_gpu": round(step_tflops, 2),
              "executed_step_frac_of_f32_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)}
 
+    cfg_tag = ("BASELINE.json configs[1]" if (Hh, T, args.enc_layers, B) == (512, 25, 1, 2048)
+               else "BASELINE.json configs[4] dimensions, GRU cells, 1-layer decoder as in the reference"
+               if (Hh, T, args.enc_layers) == (1024, 50, 2) else "non-default dimensions")
     line = {
         "metric": "peptide-seq/s per WAE training step", "value": round(seq_per_s, 1), "unit": "seq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"WAE train step (BASELINE.json configs[1]): biGRU encoder h={Hh} {args.enc_layers} layer, z={Z}, GRU decoder "
+        "config": {"workload": f"WAE train step ({cfg_tag}): biGRU encoder h={Hh} {args.enc_layers} layer, z={Z}, GRU decoder "
                                f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; "
                                + ("GRU cell = the reference's cell, parity pinned (the reference has no LSTM; --cell lstm runs "
                                   "the LSTM extension)" if args.cell == "gru" else
