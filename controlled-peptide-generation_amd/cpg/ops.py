@@ -266,7 +266,8 @@ class GruSeqFn(Function):
     models/decoder.py:40-41,77).  Returns the state slab [(T+1),B,H] (layout in include/cpg_api.h)."""
 
     @staticmethod
-    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse, defer=False):
+    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse, defer=False, step_rows=None):
+        """step_rows: optional device int32 [T] of live-row counts per step (length-sorted batch, see cpg_api.h)."""
         dev = w_hh.device
         # deferred mode: the 80-GFLOP dW_hh product of this sequence runs on a side stream and is added straight into the
         # parameters' existing .grad buffers, overlapping with the rest of the backward pass (only with FusedAdamClip,
@@ -279,7 +280,9 @@ class GruSeqFn(Function):
         tab_c = tab.contiguous() if tab is not None else None
         rowc_c = rowc.contiguous() if rowc is not None else None
         dense_c = dense.contiguous() if dense is not None else None
-        hs = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        # ragged batches leave the slots of dead (t,row) pairs untouched: they are read by the vocabulary projection and
+        # by the dW_hh product (against zero gradients), so they must hold finite numbers
+        hs = (torch.zeros if step_rows is not None else torch.empty)(T + 1, B, H, device=dev, dtype=torch.float32)
         slot0 = T if reverse else 0
         if h0 is None:
             hs[slot0].zero_()
@@ -295,17 +298,18 @@ class GruSeqFn(Function):
         groups = row_groups(B)
         if len(groups) == 1:
             call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
-                 _p(hs), _p(gates), 0, B, _stream())
+                 _p(hs), _p(gates), 0, B, _p(step_rows), _stream())
         else:
             with fork(dev) as f:
                 for gi, (r0, r1) in enumerate(groups):
                     f.run(gi, lambda r0=r0, r1=r1: call(
                         "cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
-                        _p(dense_c), _p(hs), _p(gates), r0, r1, _stream()))
+                        _p(dense_c), _p(hs), _p(gates), r0, r1, _p(step_rows), _stream()))
         if ev is not None:
             ev[1].record()
             PROFILE.append(("gru_step_fwd", ev[0], ev[1], T, B, H))
         ctx.save_for_backward(tok, w_hh_c, hs, gates)
+        ctx.step_rows = step_rows
         ctx.dims = (T, B, H, bool(reverse))
         ctx.V = tab.shape[0] if tab is not None else 0
         ctx.has = (tab is not None, rowc is not None, dense is not None, h0 is not None)
@@ -322,19 +326,21 @@ class GruSeqFn(Function):
         # time-aligned gradients on the step outputs: slots 1..T (forward) / 0..T-1 (reverse)
         dhs_ext = flat[BH:] if not reverse else flat[:T * BH]
         has_tab, has_rowc, has_dense, has_h0 = ctx.has
-        dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        step_rows = ctx.step_rows
+        # ragged batch: gradient rows of dead (t,row) pairs are not written but are read by the reductions below
+        dG = (torch.zeros if step_rows is not None else torch.empty)(T, B, 4 * H, device=dev, dtype=torch.float32)
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         groups = row_groups(B)
         if len(groups) == 1:
             call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG), _p(scratch),
-                 _p(dh0), 0, B, _stream())
+                 _p(dh0), 0, B, _p(step_rows), _stream())
         else:
             with fork(dev) as f:
                 for gi, (r0, r1) in enumerate(groups):
                     f.run(gi, lambda r0=r0, r1=r1: call(
                         "cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                        _p(scratch), _p(dh0), r0, r1, _stream()))
+                        _p(scratch), _p(dh0), r0, r1, _p(step_rows), _stream()))
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -368,7 +374,7 @@ class GruSeqFn(Function):
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
             ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2)
-        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None
+        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None, None
 
 
 class GruBiSeqFn(Function):

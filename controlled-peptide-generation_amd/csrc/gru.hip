@@ -34,6 +34,8 @@ struct GruFwdArgs {
     int B, H;
     int row0, row1;      // this launch covers batch rows [row0,row1): rows are independent recurrences, so row groups
                          // can run as separate launch chains on separate streams, out of phase with each other
+    const int32_t* nrows;  // device scalar or null: only rows < *nrows are live at this step (length-sorted batches:
+                           // rows whose remaining targets are all <pad> need no state) - read on the device, no host sync
 };
 
 // Up to two independent sequences (the two directions of a biGRU layer) share one launch: gridDim.z selects the
@@ -55,8 +57,9 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
     const GruFwdArgs& g = pr.d[bz];
-    const int H = g.H, B = g.row1;  // row bound of this launch
+    const int H = g.H, B = g.nrows ? min(g.row1, *g.nrows) : g.row1;  // row bound of this launch
     const int m0 = g.row0 + by * TC::BM, j0 = bx * (TC::BN / 3);
+    if (m0 >= B) return;  // tile entirely past the live rows (uniform for the workgroup)
     static_assert(TC::NI % 3 == 0, "wave tile holds r,z,n blocks");
     constexpr int NJ = TC::NI / 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -153,6 +156,8 @@ struct GruBwdArgs {
     float* dG_out;         // [B,4H]
     int B, H;
     int row0, row1;
+    const int32_t* nrows;       // device scalar or null: rows live at step s (see GruFwdArgs)
+    const int32_t* nrows_next;  // rows live at step s+1: beyond them dG_next / dH_next / z_next were never written
 };
 
 struct GruBwdPair {
@@ -172,8 +177,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
     const GruBwdArgs& g = pr.d[bz];
-    const int H = g.H, B = g.row1;  // row bound of this launch
+    const int H = g.H, B = g.nrows ? min(g.row1, *g.nrows) : g.row1;  // row bound of this launch
+    const int Bn = g.nrows_next ? min(B, *g.nrows_next) : B;            // rows that carry a gradient from step s+1
     const int m0 = g.row0 + by * TC::BM, j0 = bx * TC::BN;
+    if (m0 >= B) return;
     const size_t BH = (size_t)g.B * H;
     // epilogue operands first (see the forward kernel): saved gates, h_prev and the non-GEMM part of dH
     float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][5];
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 const size_t o = (size_t)((row < B) ? row : 0) * H + jc;
                 float p = 0.f;
-                if (g.dH_next) p += g.z_next[o] * g.dH_next[o];
+                if (g.dH_next && row < Bn) p += g.z_next[o] * g.dH_next[o];
                 if (g.ext) p += g.ext[o];
                 if (g.ext2) p += g.ext2[o];
                 pre[ni][mi][r] = p;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (g.dG_next) {
-        OpA a{g.dG_next, 4 * H, m0, B, nullptr, 1.f};
+        OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
         OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
         BwdLoop<TC, VEC>::run(a, b, 3 * H, acc);
     }
@@ -516,7 +523,7 @@ __global__ void dgi_over_time_vec_kernel(const float* dG, int T, int B, int H, f
 // ------------------------------------------------------------------------------------------ C ABI
 CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                                const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                               int row_begin, int row_end, void* stream) {
+                               int row_begin, int row_end, const int32_t* step_rows, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && 0 <= row_begin && row_begin < row_end && row_end <= B);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     const size_t BH = (size_t)B * H;
@@ -536,6 +543,7 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
         a.H = H;
         a.row0 = row_begin;
         a.row1 = row_end;
+        a.nrows = step_rows ? step_rows + t : nullptr;
         int rc = cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -546,7 +554,7 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
 CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                                 const float* rowc, const float* h_prev, float* h_out, void* stream) {
     CPG_CHECK_ARG(B > 0 && H > 0 && w_hh && b_hh && h_prev && h_out && h_prev != h_out);
-    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, B, H, 0, B};
+    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, B, H, 0, B, nullptr};
     return cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
 }
 
@@ -554,7 +562,7 @@ CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_
 // dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
 CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                               int row_begin, int row_end, void* stream) {
+                               int row_begin, int row_end, const int32_t* step_rows, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
@@ -568,6 +576,8 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         a.row0 = row_begin;
         a.row1 = row_end;
         a.w_hh = w_hh;
+        a.nrows = (step_rows && t >= 0) ? step_rows + t : nullptr;
+        a.nrows_next = (step_rows && prev_t >= 0) ? step_rows + prev_t : nullptr;
         const int cur = (p + 2) & 1;
         if (prev_t >= 0) {
             a.dG_next = dG + (size_t)prev_t * B * 4 * H;
@@ -715,6 +725,7 @@ static void fill_fwd(GruFwdArgs& a, int t, int T, int B, int H, int reverse, con
     a.H = H;
     a.row0 = 0;
     a.row1 = B;
+    a.nrows = nullptr;
 }
 
 // Both directions of one biGRU layer (models/encoder.py:25-30,42) in lock step: launch p runs time p of the forward
@@ -758,6 +769,8 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
         for (int d = 0; d < 2; ++d) {
             const int t = d ? T - 1 - p : p;
             GruBwdArgs& a = pr.d[d];
+            a.nrows = nullptr;
+            a.nrows_next = nullptr;
             a.B = B;
             a.H = H;
             a.row0 = 0;

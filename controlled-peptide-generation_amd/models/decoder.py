@@ -63,6 +63,11 @@ class GRUDecoder(nn.Module):
         if skip_connetions:
             raise NotImplementedError('skip connections are off by default (cfg.py:281) and not on the MI355X path')
         self.rng = None
+        # Length-sorted ("ragged") teacher forcing: rows are visited longest first and a row leaves the recurrence once all
+        # its remaining targets are <pad> (those positions carry no loss and no gradient, losses.py:27).  The logits of
+        # such positions are then fc(0) instead of the reference's values, so this is OFF for the model API and switched
+        # on by the trainer (train_vae.train_step), which only consumes the loss.
+        self.ragged = False
 
     def init_hidden(self, z, c):
         return torch.cat([z, c], dim=1)
@@ -85,20 +90,39 @@ class GRUDecoder(nn.Module):
             wd_mask = self.word_dropout.sample_mask(x)
         tok = ops.tokens_prepare(x, wd_mask)
         tab, rowc = self._tables(zc)
+        ragged = self.ragged and self.cell == 'gru' and torch.is_grad_enabled()
+        perm = inv = step_rows = None
+        if ragged:
+            # step t consumes x[:, t] and is scored against x[:, t+1]: live while some target at or after t is not <pad>
+            # (pads only ever trail).  All on the device: no host sync.
+            last = (x != self.emb.padding_idx).sum(1) - 2                       # index of the last scored step
+            perm = torch.argsort(last, descending=True)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(B, device=x.device)
+            steps = torch.arange(T, device=x.device)
+            step_rows = (last[None, :] >= steps[:, None]).sum(1).to(torch.int32)  # [T] live rows per step (a prefix)
+            tok = tok.index_select(1, perm).contiguous()
+            rowc = rowc.index_select(0, perm)
+            zc = zc.index_select(0, perm)
         if self.cell == 'gru':
-            slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True)
+            slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True,
+                                      step_rows)
         else:
             slab = ops.LstmSeqFn.apply(tok, tab, rowc, None, zc, None, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)
         hs = slab[1:].reshape(T * B, self.h_dim)
         keep, scale = None, 1.0
         if out_keep is not None:
             keep = ops.transpose01_u8(out_keep.to(torch.uint8))          # [B,T,H] -> [T,B,H]
+            if ragged:
+                keep = keep.index_select(1, perm).contiguous()
             scale = 1.0 / (1.0 - self.p_out) if self.p_out > 0 else 1.0
         elif self.training and self.p_out > 0:
             keep = self._sample_keep((T, B, self.h_dim), x.device)
             scale = 1.0 / (1.0 - self.p_out)
         fc = self.fc[1]
         logits_tm = ops.VocabFcFn.apply(hs, keep, scale, fc.weight, fc.bias).view(T, B, -1)
+        if ragged:
+            logits_tm = logits_tm.index_select(1, inv)                   # back to the caller's row order
         return ops.Transpose01Fn.apply(logits_tm)
 
     def _sample_keep(self, shape, device):

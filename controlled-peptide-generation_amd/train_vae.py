@@ -13,6 +13,7 @@ import sys
 import torch
 
 import losses
+import cfg
 import utils
 from cpg.optim import FusedAdamClip
 from models.mutils import save_model
@@ -26,7 +27,13 @@ def make_optimizer(cfgv, model, reduce_fn=None, world=1):
 def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
     """One full iteration.  Returns a dict of device scalars (no host sync)."""
     beta = utils.anneal(cfgv.beta, it)
-    (z_mu, z_logvar), (z, c), dec_logits = model(text, q_c='prior', sample_z=1, rnd=rnd)
+    # the trainer consumes the logits only through recon_dec (pad targets ignored): the decoder may skip dead rows
+    ragged_before = model.decoder.ragged
+    model.decoder.ragged = bool(cfg.hw.ragged_decoder)
+    try:
+        (z_mu, z_logvar), (z, c), dec_logits = model(text, q_c='prior', sample_z=1, rnd=rnd)
+    finally:
+        model.decoder.ragged = ragged_before
     recon_loss = losses.recon_dec(text, dec_logits)
     kl_loss = losses.kl_gaussianprior(z_mu, z_logvar)
     wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0])

@@ -75,9 +75,13 @@ CPG_API int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, flo
  * Batch rows are independent recurrences: a call covers rows [row_begin,row_end) of the B-row problem (0,B for all),
  * so a caller may run row groups as separate launch chains on separate streams (their MFMA and memory phases then
  * overlap instead of running in lockstep). */
+/* step_rows (optional, DEVICE int32 [T], may be null): only rows < step_rows[t] are live at time t.  For length-sorted
+ * teacher-forced batches: once all remaining targets of a row are <pad> (losses.py:27 ignores them) its state is never
+ * needed again, so the tail of the batch drops out step by step.  The counts are read by the kernels (no host sync);
+ * state / gate slots of dead (t,row) pairs are left untouched - hand in zeroed slabs if they are read elsewhere. */
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                            int row_begin, int row_end, void* stream);
+                            int row_begin, int row_end, const int32_t* step_rows, void* stream);
 /* split form of the same sequence (plain product + memory-bound cell kernel per step; gh scratch [B,3H]) - lets two
  * row groups on two streams overlap one group's cell traffic with the other group's product */
 CPG_API int cpg_gru_seq_fwd_split(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
@@ -92,7 +96,8 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
  * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip). */
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                            int row_begin, int row_end, void* stream);
+                            int row_begin, int row_end, const int32_t* step_rows /* as in cpg_gru_seq_fwd; dG rows of dead
+                            (t,row) pairs are not written: pass a zeroed dG */, void* stream);
 /* Both directions of one biGRU layer in lock step, ONE launch per step for the pair (launch p: time p forward, time
  * T-1-p reverse).  Arguments as in cpg_gru_seq_fwd / _bwd per direction (_f forward, _r reverse); no initial-state
  * gradient (the encoder starts from h0 = 0). */

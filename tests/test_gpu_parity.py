@@ -87,14 +87,18 @@ def _train_loss(m, losses, ids, rnd, g, regu, beta, lam_l1, lam_kl, idx=None):
     return loss, dict(recon=recon, kl=kl, mmd=mmd, mmdrf=mmdrf, l1=l1, klmu=klmu, z=z, logits=logits, mu=mu, lv=lv)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("name", MODELS)
-def test_losses_and_grads_golden(golden, name):
+def test_losses_and_grads_golden(golden, name, ragged):
+    """ragged=True: the trainer's length-sorted decoder (rows drop out once their remaining targets are <pad>) must give
+    the reference's losses and gradients too - only logits of unscored positions may differ."""
     import losses
     g = golden("model_" + name)
     _set_losses_cfg()
     variants = [""] + [p for p in ("v1.", "v2.") if p + "regu" in g]
     for p in variants:
         m = build_model(weights_of(g))
+        m.decoder.ragged = ragged
         losses.rf.clear()
         losses.rf['gaussian'] = (cu(g["rf_w"]), cu(g["rf_b"]))
         ids = cu(g["ids"])
@@ -147,8 +151,9 @@ def test_beam_golden(golden, name):
             assert hyps[i][j] == [int(t) for t in ref[i, j] if t >= 0], (i, j)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("name", ["micro_clip", "micro_noclip", "A_clip"])
-def test_train_trajectory_golden(golden, name):
+def test_train_trajectory_golden(golden, name, ragged):
     """k reference train_vae iterations: loss composition, clip, Adam and the F6 duplicate-embedding semantics."""
     import losses
     from cpg.optim import FusedAdamClip
@@ -156,6 +161,7 @@ def test_train_trajectory_golden(golden, name):
     _set_losses_cfg()
     P0 = {k: v for k, v in weights_of(g, "w0.").items()}
     m = build_model(P0)
+    m.decoder.ragged = ragged
     losses.rf.clear()
     losses.rf['gaussian'] = (cu(g["rf_w"]), cu(g["rf_b"]))
     opt = FusedAdamClip(m.vae_params(), lr=1e-3, max_norm=float(g["clip"]))
@@ -218,10 +224,10 @@ def test_split_and_row_range_forms_match_fused():
         gates = torch.zeros(T, 4, B, H, device=dev)
         gh = torch.empty(B, 3 * H, device=dev)
         if mode == "fused":
-            call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, _stream())
+            call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, None, _stream())
         elif mode == "rows":
             for r0, r1 in ((0, 64), (64, 128), (128, B)):
-                call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1, _stream())
+                call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1, None, _stream())
         else:
             call("cpg_gru_seq_fwd_split", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates),
                  _p(gh), 0, B, _stream())
@@ -275,3 +281,35 @@ def test_beam_hypotheses_kernel_matches_host_statement(n_best):
     assert np.array_equal(ln.cpu().numpy(), ref_l)
     assert np.array_equal(sc.cpu().numpy(), ref_s)
     assert np.array_equal(hy.cpu().numpy(), ref_h)
+
+
+def test_ragged_decoder_matches_dense_full_size():
+    """Config-B sized batch: ragged and dense teacher forcing give the same loss and the same parameter gradients, and the
+    ragged logits equal the dense ones at every scored position."""
+    import losses
+    from bench import model_kwargs
+    from cpg.synth import synth_ids
+    from models.model import RNN_VAE
+    torch.manual_seed(5)
+    B, T, V, Z = 512, 25, 24, 254
+    m = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, 256)).cuda()
+    m.device = torch.device("cuda")
+    ids = synth_ids(B, T, V, torch.Generator().manual_seed(3)).cuda()
+    rnd = dict(eps=torch.randn(B, Z, device="cuda"), c=torch.eye(2, device="cuda")[torch.randint(0, 2, (B,), device="cuda")],
+               wd_mask=(torch.rand(B, T, device="cuda") < 0.3).to(torch.uint8),
+               out_mask=(torch.rand(B, T, Z + 2, device="cuda") >= 0.3).to(torch.uint8))
+    res = []
+    for ragged in (False, True):
+        m.decoder.ragged = ragged
+        m.zero_grad()
+        _, _, logits = m(ids, q_c='prior', sample_z=1, rnd=rnd)
+        loss = losses.recon_dec(ids, logits)
+        loss.backward()
+        res.append((loss.item(), logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert abs(res[0][0] - res[1][0]) < 1e-6
+    scored = torch.cat([ids[:, 1:], torch.full((B, 1), 1, device="cuda")], 1) != 1
+    assert torch.allclose(res[0][1][scored], res[1][1][scored], atol=1e-5)
+    assert not torch.allclose(res[0][1][~scored], res[1][1][~scored], atol=1e-5)  # the dead rows really were skipped
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert torch.allclose(a, b, atol=1e-6 + 1e-5 * a.abs().max().item()), k

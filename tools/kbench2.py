@@ -15,7 +15,7 @@ tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
 hs = torch.zeros(T + 1, B, H, device=dev); gates = torch.empty(T, 4, B, H, device=dev)
 import ctypes
 def chain(r0, r1, stream):
-    call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1,
+    call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1, None,
          ctypes.c_void_p(stream.cuda_stream))
 main = torch.cuda.current_stream()
 for G in (1, 2, 4):

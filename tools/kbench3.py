@@ -21,7 +21,7 @@ def chain(split, hsb, r0, r1, stream):
     if split:
         call("cpg_gru_seq_fwd_split", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hsb), _p(gates), _p(gh), r0, r1, st)
     else:
-        call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hsb), _p(gates), r0, r1, st)
+        call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hsb), _p(gates), r0, r1, None, st)
 
 chain(False, hs, 0, B, main); chain(True, hs2, 0, B, main); torch.cuda.synchronize()
 print("max |fused - split| over the sequence:", float((hs - hs2).abs().max()))
