@@ -132,6 +132,78 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
 
 
 @torch.no_grad()
+def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_length=1):
+    """RNN_VAE.sample_G soft modes (models/model.py:337-359): 'none_softmax' | 'greedy_softmax' | 'categorical_softmax'.
+    Every step feeds the previous softmax row back through the embedding (mutils.soft_embed); W_ih[:, :E] . (soft @ emb)
+    = soft @ (emb W_e^T), a [N,V]x[V,3H] product, enters the fused step kernel as its dense input term.
+    Returns (ids int64 [N,1+steps], soft f32 [N,1+steps,V]); inference only.  The reference's quirks are kept: see
+    oracle/decode.py:soft_sample."""
+    if mode not in ("none_softmax", "greedy_softmax", "categorical_softmax"):
+        raise ValueError(mode)
+    if getattr(decoder, "cell", "gru") != "gru":
+        raise NotImplementedError("soft sampling is implemented for the GRU decoder (the reference's cell)")
+    N = z.shape[0]
+    dev = z.device
+    zc = decoder.init_hidden(z, c).contiguous()
+    tab, rowc = decoder._tables(zc)
+    tab, rowc = tab.contiguous(), rowc.contiguous()
+    rnn, fc = decoder.rnn, decoder.fc[1]
+    E = decoder.emb.weight.shape[1]
+    H, V = zc.shape[1], fc.weight.shape[0]
+    # dense term of a soft row: soft @ (emb W_e^T) + b_ih   (b_ih also reaches rows whose soft vector was zeroed)
+    w_soft = ops.LinearFn.apply(rnn.weight_ih_l0[:, :E].contiguous(), decoder.emb.weight, None).contiguous()   # [3H,V]
+    hs = torch.empty(2, N, H, device=dev, dtype=torch.float32)
+    hs[0].copy_(zc)
+    logits = torch.empty(N, V, device=dev, dtype=torch.float32)
+    tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
+    finished = torch.zeros(N, device=dev, dtype=torch.bool)
+    onehot = torch.zeros(N, V, device=dev)
+    onehot[:, START_IDX] = 1.0
+    ids, softs = [tok.to(torch.int64)], [onehot]
+    soft = None
+    for i in range(max_len):
+        if soft is None:
+            ops.gru_step(tok, tab, rowc, hs[0], hs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
+        else:
+            dense = ops.LinearFn.apply(soft, w_soft, rnn.bias_ih_l0).contiguous()
+            call("cpg_gru_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
+                 _p(hs), None, 0, N, None, _stream())
+        _fc(decoder, hs[1], logits)
+        soft = torch.softmax(logits / temp, dim=1)
+        if mode == "greedy_softmax":
+            t = torch.argmax(logits, 1)
+        elif mode == "categorical_softmax":
+            t = torch.distributions.Categorical(logits=logits / temp).sample()
+        else:
+            t = ids[-1].clone()            # 'none_softmax': the hard token is never updated (reference quirk)
+        t = t.masked_fill(finished, PAD_IDX)
+        finished = finished | (t == EOS_IDX)
+        soft = soft.masked_fill(finished.unsqueeze(1), 0.0)
+        ids.append(t)
+        softs.append(soft)
+        hs[0].copy_(hs[1])
+        if mode != "none_softmax" and (i % 4) == 3 and len(ids) >= min_length and bool(finished.all()):
+            # the reference tests this every step; steps run past the break only add all-<pad> columns, cut below
+            break
+    ids_t, soft_t = torch.stack(ids, 1), torch.stack(softs, 1)
+    if mode != "none_softmax":
+        # cut where the reference's loop would have stopped: first step after which every row is finished
+        fin_step = _first_all_finished(ids_t)
+        if fin_step is not None:
+            keep = max(fin_step + 1, min(min_length, ids_t.shape[1]))
+            ids_t, soft_t = ids_t[:, :keep], soft_t[:, :keep]
+    return ids_t, soft_t
+
+
+def _first_all_finished(ids):
+    """Number of columns (incl. <start>) after which every row has emitted <eos> (or None)."""
+    seen = torch.cumsum((ids == EOS_IDX).to(torch.int32), 1) > 0
+    done = seen.all(0).cpu().numpy()
+    nz = np.nonzero(done)[0]
+    return int(nz[0]) if len(nz) else None
+
+
+@torch.no_grad()
 def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
     """Runs the device beam search; returns device tensors (tok, prev, score) each [T,N,K] (tok = -1 where a sentence
     had already finished): the recorded history cpg_beam_hypotheses walks back."""

@@ -133,18 +133,28 @@ class GRUDecoder(nn.Module):
         return (torch.rand(shape, device=device) >= self.p_out).to(torch.uint8)
 
     def forward_sample(self, sampleSoft, sampleHard, z, c, h):
-        """One decode step (reference signature, decoder.py:86-109): h is [1,N,H]; returns logits [N,V], h [1,N,H]."""
-        if sampleSoft is not None:
-            raise NotImplementedError('soft sampling modes are a "next" row (SURVEY 8f rank 4)')
+        """One decode step (reference signature, decoder.py:86-109): h is [1,N,H]; returns logits [N,V], h [1,N,H].
+        sampleSoft [N,V] (a softmax row, or zeros) takes the soft-embedding branch; inference only (no autograd tape)."""
         if self.cell != 'gru':
             raise NotImplementedError('forward_sample keeps the reference signature (h only); LSTM decoding goes through cpg.decode')
         zc = self.init_hidden(z, c)
         with torch.no_grad():
             tab, rowc = self._tables(zc)
-            tok = sampleHard.to(torch.int32).contiguous()
             h_prev = h[0].contiguous()
             h_new = torch.empty_like(h_prev)
-            ops.gru_step(tok, tab, rowc, h_prev, h_new, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
+            if sampleSoft is not None:
+                # soft_embed (mutils.py:39-45): W_ih[:, :E] (soft @ emb) = soft @ (emb W_e^T), the step's dense input term
+                E = self.emb.weight.shape[1]
+                w_soft = ops.LinearFn.apply(self.rnn.weight_ih_l0[:, :E].contiguous(), self.emb.weight, None)
+                dense = ops.LinearFn.apply(sampleSoft.float().contiguous(), w_soft.contiguous(), self.rnn.bias_ih_l0)
+                hs = torch.stack([h_prev, h_new])
+                N, H = h_prev.shape
+                ops.call("cpg_gru_seq_fwd", 1, N, H, 0, ops._p(self.rnn.weight_hh_l0), ops._p(self.rnn.bias_hh_l0), None, None,
+                         ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), None, 0, N, None, ops._stream())
+                h_new = hs[1]
+            else:
+                tok = sampleHard.to(torch.int32).contiguous()
+                ops.gru_step(tok, tab, rowc, h_prev, h_new, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
             fc = self.fc[1]
             keep, scale = None, 1.0
             if self.training and self.p_out > 0:

@@ -10,7 +10,8 @@ Differences that are deliberate and documented:
   * `forward` accepts optional keyword `rnd=dict(eps=, c=, wd_mask=, out_mask=)` to inject the step's random draws
     (the reference mixes torch and numpy generators, SURVEY F8; parity tests inject its captured draws);
   * `.device` defaults to cuda (as in the reference, model.py:41) and stays an assignable attribute (api.py:96);
-  * flows (flow>0) and soft sampling modes are not on this path and raise.
+  * flows (flow>0) are not on this path and raise; the soft sampling modes run forward only (no autograd tape:
+    the reference never trains through them).
 """
 from itertools import chain
 
@@ -180,9 +181,10 @@ class RNN_VAE(nn.Module):
 
     def sample_G(self, mbsize, z, c, sample_mode='categorical', temp=1.0, gumbel_temp=1.0, prepend_start_idx=True,
                  prevent_empty=False, min_length=1, beam_size=5, n_best=3):
-        if sample_mode in SOFT_MODES:
-            raise NotImplementedError('soft sampling modes are a "next" row (SURVEY 8f rank 4), not on the MI355X path yet')
-        if sample_mode not in HARD_MODES:
+        if sample_mode in ('gumbel_soft', 'gumbel_ST'):
+            raise NotImplementedError('gumbel_soft / gumbel_ST are placeholders in the reference too (models/model.py:330-336 '
+                                      'leaves sampleSoftIx unset and fails)')
+        if sample_mode not in HARD_MODES + SOFT_MODES:
             raise Exception('Sample mode {} not implemented.'.format(sample_mode))
         assert beam_size >= n_best, "Can't return more than max hypothesis"
         assert mbsize == z.size(0) == c.size(0), 'oops sizes dont match {} {} {}'.format(mbsize, z.size(0), c.size(0))
@@ -190,7 +192,12 @@ class RNN_VAE(nn.Module):
         if sample_mode == 'beam':
             return cdecode.decode_beam(self.decoder, z, c, self.MAX_SEQ_LEN, beam_size, n_best, min_length)
         if self.training and self.decoder.p_out > 0:
-            raise NotImplementedError('hard sampling with out-dropout active (eval_mode=False) is not on the MI355X path')
+            raise NotImplementedError('sampling with out-dropout active (eval_mode=False) is not on the MI355X path')
+        if sample_mode in SOFT_MODES:
+            assert not prevent_empty, 'cant prevent_empty when soft sampling'
+            ids, soft = cdecode.decode_soft(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
+                                            min_length=min_length)
+            return (ids, soft) if prepend_start_idx else (ids[:, 1:], soft[:, 1:])
         ids = cdecode.decode_hard(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
                                   prevent_empty=prevent_empty, min_length=min_length)
         return ids if prepend_start_idx else ids[:, 1:]

@@ -137,3 +137,48 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
     if return_history:
         return [o[0] for o in out], [o[1] for o in out], tuple(np.stack([h[i] for h in hist]) for i in range(3))
     return [o[0] for o in out], [o[1] for o in out]
+
+
+def soft_sample(P, z, c, max_len, mode, temp=1.0, min_length=1, sampled=None):
+    """RNN_VAE.sample_G soft modes, models/model.py:337-359 with decoder.forward_sample's soft branch (decoder.py:87-89) and
+    mutils.soft_embed (:39-45).  mode: 'none_softmax' | 'greedy_softmax' | 'categorical_softmax' (the hard draws of the
+    latter are passed in as `sampled` [N, 1+steps], column 0 = <start>, to replay a recorded run).
+    Returns (ids int64 [N,1+steps], soft f32 [N,1+steps,V]).  Quirks kept: 'none_softmax' never updates the hard token
+    (ids stay <start>, nothing ever finishes); the soft row of the step that emits <eos> is already zeroed; a zeroed soft
+    row embeds to the zero vector, not to a token's embedding."""
+    N = z.shape[0]
+    V = P["decoder.fc.1.weight"].shape[0]
+    zc = np.concatenate([z, c], 1).astype(F32)
+    h = zc.copy()
+    tok = np.full(N, START, np.int64)
+    finished = np.zeros(N, bool)
+    onehot = np.zeros((N, V), F32)
+    onehot[:, START] = 1
+    cols, softs = [tok.copy()], [onehot]
+    soft_in = None
+    emb_w, w_ih, b_ih = P["word_emb.weight"], P["decoder.rnn.weight_ih_l0"], P["decoder.rnn.bias_ih_l0"]
+    for i in range(max_len):
+        e = emb_w[tok] if soft_in is None else (soft_in @ emb_w).astype(F32)
+        x = np.concatenate([e, zc], 1).astype(F32)
+        gi = (x @ w_ih.T + b_ih).astype(F32)
+        h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
+        sm = _log_softmax((logits / F32(temp)).astype(F32))
+        soft = np.exp(sm).astype(F32)
+        if mode == "greedy_softmax":
+            tok = logits.argmax(1).astype(np.int64)
+        elif mode == "categorical_softmax":
+            tok = sampled[:, i + 1].astype(np.int64).copy()   # recorded draw (already masked: idempotent below)
+        elif mode != "none_softmax":
+            raise ValueError(mode)
+        tok = tok.copy()
+        tok[finished] = PAD
+        finished = finished | (tok == EOS)
+        soft = soft.copy()
+        soft[finished] = 0
+        cols.append(tok.copy())
+        softs.append(soft)
+        soft_in = soft
+        if finished.all() and len(cols) >= min_length:
+            break
+    return np.stack(cols, 1), np.stack(softs, 1)

@@ -486,3 +486,33 @@ def classifier_vectors(name="A", seed=1238, B=16, **kw):
 
 if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "classifier":
     classifier_vectors("A", 1238, **model_kwargs(z_dim=100, enc_h=80))
+
+
+def soft_vectors(name="A", seed=1238, N=48, **kw):
+    """RNN_VAE.sample_G soft modes (models/model.py:337-359): none_softmax and greedy_softmax are deterministic given (z,c);
+    categorical_softmax is captured with the sampled indices so the soft outputs can be replayed."""
+    model = build(seed, **kw)
+    with torch.no_grad():
+        model.decoder.fc[1].weight.mul_(6.0)   # spread the logits so rows emit <eos> at varied steps
+        model.decoder.fc[1].bias[3] += 1.0
+    gen = torch.Generator().manual_seed(seed + 5)
+    z = torch.randn(N, model.z_dim, generator=gen)
+    c = torch.zeros(N, 2)
+    c[torch.arange(N), torch.randint(0, 2, (N,), generator=gen)] = 1
+    out = {"w." + k: v.detach().numpy().copy() for k, v in model.state_dict().items() if not k.startswith("classifier")}
+    out.update(z=z.numpy(), c=c.numpy())
+    for mode, temp in (("none_softmax", 1.0), ("greedy_softmax", 1.0), ("greedy_softmax", 0.7)):
+        (ids, soft), _, _ = model.generate_sentences(N, z, c, sample_mode=mode, temp=temp)
+        tag = f"{mode}_t{temp}"
+        out[tag + ".ids"] = ids.numpy()
+        out[tag + ".soft"] = soft.detach().numpy()
+    torch.manual_seed(seed + 9)
+    (ids, soft), _, _ = model.generate_sentences(N, z, c, sample_mode="categorical_softmax", temp=0.9)
+    out["categorical_softmax_t0.9.ids"] = ids.numpy()
+    out["categorical_softmax_t0.9.soft"] = soft.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, f"soft_{name}.npz"), **out)
+    print(f"soft_{name}.npz written", {k: v.shape for k, v in out.items() if not k.startswith("w.")})
+
+
+if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "soft":
+    soft_vectors("A", 1238, **model_kwargs(z_dim=100, enc_h=80))

@@ -194,3 +194,50 @@ def test_api_helpers_roundtrip(tmp_path, golden):
     out = api.recon_sequence(m2, vocab, "A C D E F G", sample_mode='greedy')
     assert isinstance(out, str)
     assert len(api.interpolate_peptides(m2, vocab, "A C D", "W Y V", steps=4, sample_mode='greedy')) == 4
+
+
+@pytest.mark.parametrize("mode,temp", [("none_softmax", 1.0), ("greedy_softmax", 1.0), ("greedy_softmax", 0.7)])
+def test_soft_sampling_modes_golden(golden, mode, temp):
+    """RNN_VAE.sample_G soft modes on the device vs the reference's outputs (ids exact, softmax rows within 1e-5)."""
+    from helpers import build_model, cu
+    from conftest import weights_of
+    g = golden("soft_A")
+    m = build_model(weights_of(g))
+    z, c = cu(g["z"]), cu(g["c"])
+    (ids, soft), _, _ = m.generate_sentences(z.shape[0], z, c, sample_mode=mode, temp=temp)
+    tag = f"{mode}_t{temp}"
+    assert ids.dtype == torch.int64 and np.array_equal(ids.cpu().numpy(), g[tag + ".ids"])
+    np.testing.assert_allclose(soft.cpu().numpy(), g[tag + ".soft"], atol=1e-5)
+    (ids2, soft2), _, _ = m.generate_sentences(z.shape[0], z, c, sample_mode=mode, temp=temp, prepend_start_idx=False)
+    assert ids2.shape[1] == ids.shape[1] - 1 and torch.equal(soft2, soft[:, 1:])
+
+
+def test_categorical_softmax_and_forward_sample_soft(golden):
+    """categorical_softmax: hard draws are random, but every soft row must be the softmax the oracle computes when fed the
+    same hard draws; forward_sample's soft-embedding branch against the oracle's single step."""
+    from helpers import build_model, cu
+    from conftest import weights_of
+    from oracle import decode as odecode
+    g = golden("soft_A")
+    P = weights_of(g)
+    m = build_model(P)
+    z, c = cu(g["z"]), cu(g["c"])
+    torch.manual_seed(0)
+    (ids, soft), _, _ = m.generate_sentences(z.shape[0], z, c, sample_mode="categorical_softmax", temp=0.9)
+    ref_ids, ref_soft = odecode.soft_sample(P, g["z"], g["c"], 25, "categorical_softmax", 0.9, sampled=ids.cpu().numpy())
+    assert np.array_equal(ids.cpu().numpy(), ref_ids)
+    np.testing.assert_allclose(soft.cpu().numpy(), ref_soft, atol=1e-5)
+    # one soft step through the reference-signature entry point
+    m.eval()
+    rs = np.random.RandomState(1)
+    p = rs.dirichlet(np.ones(24), size=z.shape[0]).astype(np.float32)
+    p[:5] = 0                                                   # zeroed rows embed to the zero vector
+    h0 = np.concatenate([g["z"], g["c"]], 1).astype(np.float32)
+    logits, h1 = m.decoder.forward_sample(cu(p), None, z, c, cu(h0).unsqueeze(0))
+    e = (p @ P["word_emb.weight"]).astype(np.float32)
+    x = np.concatenate([e, h0], 1)
+    gi = x @ P["decoder.rnn.weight_ih_l0"].T + P["decoder.rnn.bias_ih_l0"]
+    from oracle.gru import gru_cell_fwd
+    h_ref, _ = gru_cell_fwd(gi.astype(np.float32), h0, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+    np.testing.assert_allclose(h1[0].cpu().numpy(), h_ref, atol=2e-6)
+    np.testing.assert_allclose(logits.cpu().numpy(), h_ref @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"], atol=1e-5)

@@ -127,3 +127,17 @@ def test_class_rejection(golden):
     np.testing.assert_allclose(probs[1], g["prob_tox"], rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(accum, g["prob_accum"], rtol=1e-12, atol=1e-15)
     assert np.array_equal(acc, g["accepted"])
+
+
+@pytest.mark.parametrize("mode,temp", [("none_softmax", 1.0), ("greedy_softmax", 1.0), ("greedy_softmax", 0.7),
+                                       ("categorical_softmax", 0.9)])
+def test_soft_sampling_modes_golden(golden, mode, temp):
+    """sample_G soft modes (models/model.py:337-359) vs the reference's outputs, incl. its quirks (ids frozen at <start> for
+    none_softmax, soft row zeroed at the <eos> step); the categorical draws are replayed from the fixture."""
+    from oracle import decode as odecode
+    g = golden("soft_A")
+    P = weights_of(g)
+    tag = f"{mode}_t{temp}"
+    ids, soft = odecode.soft_sample(P, g["z"], g["c"], 25, mode, temp, sampled=g[tag + ".ids"])
+    assert np.array_equal(ids, g[tag + ".ids"])
+    np.testing.assert_allclose(soft, g[tag + ".soft"], atol=2e-6)
