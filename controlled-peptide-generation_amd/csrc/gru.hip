@@ -461,7 +461,7 @@ __global__ void chunk_reduce_kernel(const float* part, int chunks, size_t n, flo
 
 // One-hot image of the step tokens with a column of ones appended: oh[row][v] = (tok[row] == v), oh[row][V] = 1.
 // dG^T . oh on the matrix cores then yields the token-grouped sums AND the plain column sums in one pass over dG.
-constexpr int OH_LD = 32;
+constexpr int OH_LD = 64;  // 64 columns (V+1 used): wide enough for the 64-column tiles the split-operand engine needs
 __global__ void onehot_kernel(const int32_t* tok, int rows, int V, float* oh) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * OH_LD) return;
@@ -469,17 +469,17 @@ __global__ void onehot_kernel(const int32_t* tok, int rows, int V, float* oh) {
     oh[i] = (c == tok[row] || c == V) ? 1.f : 0.f;
 }
 
-// R [OH_LD, 4H] -> dtab[v][c] (+)= R[v][dgi_col(c)]; dsum[c4] (+)= R[V][c4]
+// R [4H, OH_LD] = dG^T . oh  ->  dtab[v][c] (+)= R[dgi_col(c)][v]; dsum[c4] (+)= R[c4][V]
 __global__ void dgi_scatter_kernel(const float* R, int H, int V, int lstm, float* dtab, float* dsum, int accumulate) {
     const int NC = lstm ? 4 * H : 3 * H;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (dtab && i < V * NC) {
         const int v = i / NC, c = i - v * NC;
-        const float x = R[(size_t)v * 4 * H + dgi_col(c, H, lstm)];
+        const float x = R[(size_t)dgi_col(c, H, lstm) * OH_LD + v];
         dtab[i] = accumulate ? dtab[i] + x : x;
     }
     if (dsum && i < 4 * H) {
-        const float x = R[(size_t)V * 4 * H + i];
+        const float x = R[(size_t)i * OH_LD + V];
         dsum[i] = accumulate ? dsum[i] + x : x;
     }
 }
@@ -610,7 +610,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
 }
 
 static size_t dgi_mm_workspace(int T, int B, int H) {
-    return ((size_t)T * B * OH_LD + (size_t)OH_LD * 4 * H) * sizeof(float) + cpg_gemm_tn_workspace(T * B, OH_LD, 4 * H);
+    return ((size_t)T * B * OH_LD + (size_t)OH_LD * 4 * H) * sizeof(float) + cpg_gemm_tn_workspace(T * B, 4 * H, OH_LD);
 }
 
 CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
@@ -646,7 +646,7 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
     hipStream_t s = (hipStream_t)stream;
     const int rows = T * B;
     if ((dtab || dsum) && V + 1 <= OH_LD && workspace_bytes >= dgi_mm_workspace(T, B, H)) {
-        // R[OH_LD,4H] = onehot1^T . dG : token-grouped sums (rows 0..V-1) and column sums (row V), dG read once at HBM rate
+        // R[4H,OH_LD] = dG^T . onehot1 : token-grouped sums (columns 0..V-1) and column sums of dG (column V), dG read once
         CPG_CHECK_ARG(tok && V > 0 && workspace);
         float* oh = (float*)workspace;
         float* R = oh + (size_t)rows * OH_LD;
@@ -654,7 +654,7 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
         const size_t n = (size_t)rows * OH_LD;
         hipLaunchKernelGGL(onehot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tok, rows, V, oh);
         CPG_LAUNCH_CHECK();
-        int rc = cpg_gemm_tn(oh, OH_LD, dG, 4 * H, nullptr, 1.f, R, 4 * H, rows, OH_LD, 4 * H, 0, gws,
+        int rc = cpg_gemm_tn(dG, 4 * H, oh, OH_LD, nullptr, 1.f, R, OH_LD, rows, 4 * H, OH_LD, 0, gws,
                              workspace_bytes - ((char*)gws - (char*)workspace), s);
         if (rc) return rc;
         const int m = V * NC > 4 * H ? V * NC : 4 * H;
