@@ -207,10 +207,10 @@ def main():
         "roofline": roofline, "extra": extra,
     }
     if world == 1 and not args.no_cpu_baseline:
-        v, sdt = cpu_baseline(model.state_dict(), T, V, args.cpu_sample_batch, 3)
+        v, sdt = cpu_baseline(model.state_dict(), T, V, args.cpu_sample_batch, 9)   # ~12 s of host work
         line["cpu_baseline"] = {"value": round(v, 1), "unit": "seq/s", "cores": os.cpu_count(), "kind": "port",
                                 "sample": f"numpy oracle (oracle/wae.py + oracle/optim.py), same model dims, batch "
-                                          f"{args.cpu_sample_batch}, median of 3 steps ({sdt:.2f} s/step), all four "
+                                          f"{args.cpu_sample_batch}, median of 9 steps after 1 warm-up ({sdt:.2f} s/step), all four "
                                           f"regularisers incl. the [N,N,D] full-kernel MMD"}
     if world == 1 and not args.no_class:
         line["extra"]["class"] = class_bench(dev)
