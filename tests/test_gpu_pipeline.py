@@ -241,3 +241,28 @@ def test_categorical_softmax_and_forward_sample_soft(golden):
     h_ref, _ = gru_cell_fwd(gi.astype(np.float32), h0, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
     np.testing.assert_allclose(h1[0].cpu().numpy(), h_ref, atol=2e-6)
     np.testing.assert_allclose(logits.cpu().numpy(), h_ref @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"], atol=1e-5)
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the contract's keys, a roofline object measured on the launch stream and (N=1) a
+    cpu_baseline object - run at reduced size so the test stays fast."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256",
+                          "--hidden", "64", "--no-class", "--cpu-sample-batch", "8"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["launches_timed"] == 2 * 25 and r["avg_launch_us"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "seq/s" and c["value"] > 0 and c["cores"] >= 1
