@@ -6,6 +6,7 @@ The reference's curated CSVs are not reproducible from its repo and
 here, so this loader is the data source of this build.  Vocabulary: ids 0..3 = <unk>,<pad>,<start>,<eos>
 (models/mutils.py:5-8), 4..23 = the 20 amino acids.  Sequence: <start> aa{L} <eos> <pad>*, L ~ U{5..T-2}.
 """
+import numpy as np
 import torch
 
 SPECIALS = ['<unk>', '<pad>', '<start>', '<eos>']
@@ -66,3 +67,21 @@ class SyntheticPeptideLoader:
 
     def idx2sentences(self, batch, print_special_tokens=True):
         return [self.idx2sentence(s, print_special_tokens) for s in batch]
+
+    def ids_to_peptides(self, ids):
+        """idx2sentences(rows, print_special_tokens=False) for an integer array [N,L] (entries < 0 = padding): the decode
+        loops hand over arrays, and a per-token python loop over 10^5..10^6 hypotheses costs more than decoding them.
+        Residues are single letters, so a row is built as bytes 'A C D' in one vectorised pass and trimmed per row."""
+        ids = np.asarray(ids)
+        itos = self.TEXT.vocab.itos
+        assert all(len(w) == 1 for w in itos[len(SPECIALS):]), 'vectorised form needs one-letter residue tokens'
+        lut = np.zeros(len(itos), np.uint8)
+        for i in range(len(SPECIALS), len(itos)):
+            lut[i] = ord(itos[i])
+        keep = ids >= len(SPECIALS)
+        order = np.argsort(~keep, axis=1, kind='stable')                     # residues first, original order kept
+        letters = np.take_along_axis(np.where(keep, lut[np.clip(ids, 0, len(itos) - 1)], 0), order, 1)
+        n = keep.sum(1)
+        buf = np.full((ids.shape[0], 2 * ids.shape[1]), ord(' '), np.uint8)
+        buf[:, 0::2] = letters
+        return [buf[i, :max(2 * k - 1, 0)].tobytes().decode('ascii') for i, k in enumerate(n)]

@@ -33,6 +33,26 @@ def decode_from_z(z, model, dataset, sample_mode='beam', beam_size=5, chunk=1024
     """All z -> peptide strings; chunks of 1024 like the reference (bigger chunks only change the c draw order)."""
     out = []
     LOG.info('Decoder decoding: {}'.format(sample_mode))
+    if hasattr(dataset, 'ids_to_peptides') and sample_mode in ('beam', 'greedy') and c is not None:
+        # array path: same decode kernels, best hypothesis / greedy row handed over as arrays and turned into strings
+        # in one vectorised pass (the nested python lists of the reference format cost more than the decoding)
+        from cpg import decode as cdecode
+        was_training = model.training
+        model.eval()
+        try:
+            for i, zchunk in enumerate(torch.split(z, chunk)):
+                cc = c[i * chunk:i * chunk + zchunk.size(0)].to(model.device).float()
+                zz = zchunk.to(model.device).float()
+                if sample_mode == 'beam':
+                    hyps, lens, _ = cdecode.decode_beam_arrays(model.decoder, zz, cc, model.MAX_SEQ_LEN, beam_size, 3, 1)
+                    best = hyps[:, 0, :].copy()
+                    best[np.arange(best.shape[1])[None, :] >= lens[:, 0:1]] = -1
+                    out += dataset.ids_to_peptides(best)
+                else:
+                    out += dataset.ids_to_peptides(cdecode.decode_hard(model.decoder, zz, cc, model.MAX_SEQ_LEN).cpu().numpy())
+        finally:
+            model.train()  # generate_sentences always leaves the model in train mode (SURVEY F8)
+        return out
     for i, zchunk in enumerate(torch.split(z, chunk)):
         cc = None if c is None else c[i * chunk:i * chunk + zchunk.size(0)]
         kw = dict(sample_mode=sample_mode)

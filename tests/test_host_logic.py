@@ -137,3 +137,14 @@ def test_model_state_dict_keys_and_param_groups():
     assert sum(p is m.word_emb.weight for p in ps) == 2  # the reference's duplicate
     assert m.device.type == 'cuda'
     m.device = torch.device('cpu')  # externally assignable, as api.py:96 does
+
+
+def test_vectorised_peptide_strings_match_idx2sentences():
+    from cpg.synth import SyntheticPeptideLoader
+    d = SyntheticPeptideLoader(4, 25, 'cpu', size=10)
+    rs = np.random.RandomState(0)
+    ids = rs.randint(-1, 24, (500, 26))
+    ids[0] = -1
+    ids[1] = 1
+    ref = d.idx2sentences([[t for t in row if t >= 0] for row in ids], print_special_tokens=False)
+    assert d.ids_to_peptides(ids) == ref and ref[0] == '' and ref[1] == ''
