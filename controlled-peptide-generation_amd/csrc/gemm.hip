@@ -9,6 +9,7 @@
 #define CPG_TN_PRODUCT_SPLIT 7  // 0: exact-f32 MFMA; 7: six bf16 MFMAs on 3-way split operands, f32-grade (gemm_core.h)
 #endif
 #include <stdlib.h>
+#include <string.h>
 
 struct GemmArgs {
     const float* A; int lda; int M;
@@ -150,7 +151,14 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s) {
                      (!g.a_mask || (((uintptr_t)g.a_mask) & 3) == 0) && (!g.b_mask || (((uintptr_t)g.b_mask) & 3) == 0) &&
                      (g.k_chunk % 4 == 0) && ((A_KC || B_KC) ? g.K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) &&
                      (B_KC || g.N % 4 == 0);
-    if (getenv("CPG_TN_TILE128") && !A_KC && !B_KC && g.M >= 128 && g.N >= 128) return launch_tc<T128x128, A_KC, B_KC>(g, zdim, vec, s);
+    if (!A_KC && !B_KC) {  // CPG_TN_TILE forces the tile of the transposed-use (dW = dY^T X) products: tools/kbench.py and
+        const char* e = getenv("CPG_TN_TILE");  // tests/test_gpu_tiles.py (every instantiation against the golden vectors)
+        if (e && !strcmp(e, "128x128")) return launch_tc<T128x128, A_KC, B_KC>(g, zdim, vec, s);
+        if (e && !strcmp(e, "128x64")) return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
+        if (e && !strcmp(e, "64x64")) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
+        if (e && !strcmp(e, "128x32")) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
+        if (e && !strcmp(e, "32x128")) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
+    }
     if (g.M <= 32) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
     if (g.N <= 32) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * zdim;

@@ -175,8 +175,21 @@ def logvar_l1(lv):
     return F32(np.abs(lv).sum(1).mean(0)), (np.sign(lv) / B).astype(F32)
 
 
-def _sqdist(x, y):
-    return ((x[:, None, :].astype(np.float64) - y[None, :, :].astype(np.float64)) ** 2).sum(2)
+SQDIST_BROADCAST_LIMIT = 1 << 26  # elements of the [N,M,D] float64 difference tensor the reference's form may take
+
+
+def _sqdist(x, y, form=None):
+    """|x_i - y_j|^2 in float64.  The reference builds the [N,M,D] difference tensor (losses.py:99-103); that form is kept
+    for every size the golden vectors use.  Above SQDIST_BROADCAST_LIMIT elements (config B: 2048 x 2048 x 510 doubles =
+    17 GB) the Gram form |x|^2 + |y|^2 - 2 x.y^T is evaluated instead, also in float64: the two agree to ~1e-12 relative
+    (tests/test_oracle_golden.py::test_sqdist_forms_agree), far below the 1e-4 bars."""
+    xd, yd = x.astype(np.float64), y.astype(np.float64)
+    if form is None:
+        form = "broadcast" if xd.shape[0] * yd.shape[0] * xd.shape[1] <= SQDIST_BROADCAST_LIMIT else "gram"
+    if form == "broadcast":
+        return ((xd[:, None, :] - yd[None, :, :]) ** 2).sum(2)
+    d = (xd * xd).sum(1)[:, None] + (yd * yd).sum(1)[None, :] - 2.0 * (xd @ yd.T)
+    return np.maximum(d, 0.0)
 
 
 def mmd_full_kernel(z1, z2, sigma):

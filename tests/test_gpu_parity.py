@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from conftest import weights_of
-from helpers import build_model, cu, rnd_cuda
+from helpers import (build_model, cu, rnd_cuda, check_encoder_golden, check_decoder_teacher_forced_golden,
+                     check_losses_and_grads_golden, check_train_trajectory_golden)
 
 pytestmark = pytest.mark.gpu
 MODELS = ["A", "micro", "enc2"]
@@ -15,11 +16,6 @@ MODELS = ["A", "micro", "enc2"]
 def _need_gpu():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a real MI355X: no CUDA/HIP device visible")
-
-
-def _set_losses_cfg(sigma=7.0, rf_dim=500):
-    import cfg
-    cfg.losses.wae_mmd.sigma, cfg.losses.wae_mmd.rf_dim = sigma, rf_dim
 
 
 def test_library_is_native():
@@ -49,42 +45,12 @@ def test_linear_fwd_bwd(M, N, K):
 
 @pytest.mark.parametrize("name", MODELS)
 def test_encoder_golden(golden, name):
-    g = golden("model_" + name)
-    m = build_model(weights_of(g))
-    with torch.no_grad():
-        mu, lv = m.forward_encoder(cu(g["ids"]))
-    np.testing.assert_allclose(mu.cpu().numpy(), g["enc_mu"], atol=1e-5)
-    np.testing.assert_allclose(lv.cpu().numpy(), g["enc_logvar"], atol=1e-5)
+    check_encoder_golden(golden("model_" + name))
 
 
 @pytest.mark.parametrize("name", MODELS)
 def test_decoder_teacher_forced_golden(golden, name):
-    g = golden("model_" + name)
-    m = build_model(weights_of(g))
-    ids = cu(g["ids"])
-    with torch.no_grad():
-        lg = m.forward_decoder(ids, cu(g["z"]), cu(g["c"]), wd_mask=cu(g["wd_mask"]), out_keep=cu(g["out_mask"]))
-        np.testing.assert_allclose(lg.cpu().numpy(), g["logits_train"], atol=2e-5)
-        m.eval()
-        lg = m.forward_decoder(ids, cu(g["z"]), cu(g["c"]), wd_mask=cu(g["wd_mask_eval"]))
-        np.testing.assert_allclose(lg.cpu().numpy(), g["logits_eval"], atol=2e-5)
-        (mu, lv), (z, c), lg = m(ids, q_c=cu(g["labels"]), sample_z='max', rnd=dict(wd_mask=cu(g["wd_mask_max"])))
-        np.testing.assert_allclose(lg.cpu().numpy(), g["logits_max"], atol=2e-5)
-        np.testing.assert_allclose(c.cpu().numpy(), g["c_lab"])
-
-
-def _train_loss(m, losses, ids, rnd, g, regu, beta, lam_l1, lam_kl, idx=None):
-    pick = (lambda a: a) if idx is None else (lambda a: a[idx])
-    (mu, lv), (z, c), logits = m(ids, q_c='prior', sample_z=1, rnd=rnd)
-    recon = losses.recon_dec(ids, logits)
-    kl = losses.kl_gaussianprior(mu, lv)
-    mmd = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=cu(pick(g["z_prior_full"])))
-    mmdrf = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=cu(pick(g["z_prior_rf"])))
-    l1 = losses.logvar_l1(lv)
-    klmu = losses.kl_gaussian_sharedmu(mu, lv)
-    regu_v = {'kl': kl, 'mmd': mmd, 'mmdrf': mmdrf}[regu]
-    loss = recon + beta * regu_v + lam_l1 * l1 + lam_kl * klmu
-    return loss, dict(recon=recon, kl=kl, mmd=mmd, mmdrf=mmdrf, l1=l1, klmu=klmu, z=z, logits=logits, mu=mu, lv=lv)
+    check_decoder_teacher_forced_golden(golden("model_" + name))
 
 
 @pytest.mark.parametrize("ragged", [False, True])
@@ -92,37 +58,7 @@ def _train_loss(m, losses, ids, rnd, g, regu, beta, lam_l1, lam_kl, idx=None):
 def test_losses_and_grads_golden(golden, name, ragged):
     """ragged=True: the trainer's length-sorted decoder (rows drop out once their remaining targets are <pad>) must give
     the reference's losses and gradients too - only logits of unscored positions may differ."""
-    import losses
-    g = golden("model_" + name)
-    _set_losses_cfg()
-    variants = [""] + [p for p in ("v1.", "v2.") if p + "regu" in g]
-    for p in variants:
-        m = build_model(weights_of(g))
-        m.decoder.ragged = ragged
-        losses.rf.clear()
-        losses.rf['gaussian'] = (cu(g["rf_w"]), cu(g["rf_b"]))
-        ids = cu(g["ids"])
-        loss, t = _train_loss(m, losses, ids, rnd_cuda(g), g, str(g[p + "regu"]), float(g["beta"]), float(g["lam_l1"]),
-                              float(g["lam_kl"]))
-        t["z"].retain_grad()
-        t["logits"].retain_grad()
-        loss.backward()
-        assert abs(t["recon"].item() - g["loss_recon"]) < 1e-4
-        assert abs(t["kl"].item() - g["loss_kl"]) < 1e-4
-        assert abs(t["klmu"].item() - g["loss_klmu"]) < 1e-4
-        assert abs(t["l1"].item() - g["loss_l1"]) < 1e-4
-        assert abs(t["mmd"].item() - g["loss_mmd_full"]) < 1e-4
-        assert abs(t["mmdrf"].item() - g["loss_mmd_rf"]) < 1e-4
-        assert abs(loss.item() - g[p + "loss_total"]) < 1e-4
-        np.testing.assert_allclose(t["z"].detach().cpu().numpy(), g["z"], atol=1e-5)
-        np.testing.assert_allclose(t["logits"].grad.cpu().numpy(), g[p + "g.logits"], atol=1e-6, rtol=1e-3)
-        np.testing.assert_allclose(t["z"].grad.cpu().numpy(), g[p + "g.z"], atol=2e-6, rtol=1e-3)
-        for k, prm in m.named_parameters():
-            if k.startswith("classifier") or k == "decoder.emb.weight":
-                continue
-            ref = g[p + "g." + k]
-            got = prm.grad.cpu().numpy()
-            np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=f"{p}{k}")
+    check_losses_and_grads_golden(golden("model_" + name), ragged)
 
 
 @pytest.mark.parametrize("name", MODELS)
@@ -155,36 +91,7 @@ def test_beam_golden(golden, name):
 @pytest.mark.parametrize("name", ["micro_clip", "micro_noclip", "A_clip"])
 def test_train_trajectory_golden(golden, name, ragged):
     """k reference train_vae iterations: loss composition, clip, Adam and the F6 duplicate-embedding semantics."""
-    import losses
-    from cpg.optim import FusedAdamClip
-    g = golden("train_" + name)
-    _set_losses_cfg()
-    P0 = {k: v for k, v in weights_of(g, "w0.").items()}
-    m = build_model(P0)
-    m.decoder.ragged = ragged
-    losses.rf.clear()
-    losses.rf['gaussian'] = (cu(g["rf_w"]), cu(g["rf_b"]))
-    opt = FusedAdamClip(m.vae_params(), lr=1e-3, max_norm=float(g["clip"]))
-    n_total = g["batches"].shape[0]
-    end_it = int(g["beta_end_iter"])
-    regu = str(g["z_regu"])
-    for it in range(n_total):
-        beta = 1.0 if it <= 0 else (2.0 if it >= end_it else 1.0 + it / end_it)
-        ids = cu(g["batches"][it])
-        loss, t = _train_loss(m, losses, ids, rnd_cuda(g, it), g, regu, beta, 0.0, 1e-3, idx=it)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        if it == 0:
-            assert abs(loss.item() - g["log0.train_L_vae"]) < 1e-4
-            assert abs(t["mmd"].item() - g["log0.train_L_wae_mmd"]) < 1e-4
-        snap = f"w{it + 1}."
-        if snap + "word_emb.weight" in g:
-            sd = m.state_dict()
-            for k in sd:
-                if k.startswith("classifier"):
-                    continue
-                np.testing.assert_allclose(sd[k].cpu().numpy(), g[snap + k], atol=3e-5, rtol=0, err_msg=f"{snap}{k}")
+    check_train_trajectory_golden(golden("train_" + name), ragged)
 
 
 def test_class_kernels_golden(golden):

@@ -141,3 +141,21 @@ def test_soft_sampling_modes_golden(golden, mode, temp):
     ids, soft = odecode.soft_sample(P, g["z"], g["c"], 25, mode, temp, sampled=g[tag + ".ids"])
     assert np.array_equal(ids, g[tag + ".ids"])
     np.testing.assert_allclose(soft, g[tag + ".soft"], atol=2e-6)
+
+
+def test_sqdist_forms_agree():
+    """The Gram form of |x-y|^2 the oracle switches to at config-B size equals the reference's broadcast form."""
+    rs = np.random.RandomState(0)
+    x, y = rs.randn(64, 100).astype(np.float32), rs.randn(64, 100).astype(np.float32)
+    a, b = wae._sqdist(x, y, "broadcast"), wae._sqdist(x, y, "gram")
+    np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(wae._sqdist(x, x, "gram").diagonal(), 0.0, atol=1e-10)
+    l1, g1 = wae.mmd_full_kernel(x, y, 7.0)
+    old = wae.SQDIST_BROADCAST_LIMIT
+    try:
+        wae.SQDIST_BROADCAST_LIMIT = 0
+        l2, g2 = wae.mmd_full_kernel(x, y, 7.0)
+    finally:
+        wae.SQDIST_BROADCAST_LIMIT = old
+    assert abs(float(l1) - float(l2)) < 1e-7
+    np.testing.assert_allclose(g1, g2, atol=1e-9)
