@@ -332,15 +332,16 @@ class GruSeqFn(Function):
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         groups = row_groups(B)
+        wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # W_hh^T for the split-bf16 backward step kernels
         if len(groups) == 1:
             call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG), _p(scratch),
-                 _p(dh0), 0, B, _p(step_rows), _stream())
+                 _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
         else:
             with fork(dev) as f:
                 for gi, (r0, r1) in enumerate(groups):
                     f.run(gi, lambda r0=r0, r1=r1: call(
                         "cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                        _p(scratch), _p(dh0), r0, r1, _p(step_rows), _stream()))
+                        _p(scratch), _p(dh0), r0, r1, _p(step_rows), None, _stream()))
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -422,8 +423,9 @@ class GruBiSeqFn(Function):
         dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
+        wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
         call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-             _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _stream())
+             _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []

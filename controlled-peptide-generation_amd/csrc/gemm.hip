@@ -27,13 +27,13 @@ struct GemmArgs {
 
 template <class TC, bool A_KC, bool B_KC>
 constexpr int gemm_split() {
-    return (!A_KC && !B_KC && TC::AV % 2 == 0 && TC::BV % 2 == 0) ? CPG_TN_PRODUCT_SPLIT : 0;
+    return (!A_KC && !B_KC) ? CPG_TN_PRODUCT_SPLIT : 0;
 }
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
 using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, B_KC>()>;
 
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
     const int m0 = by * TC::BM, n0 = bx * TC::BN;
@@ -127,13 +127,13 @@ static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
         }
     }
     if (vec && masks)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true>), grid, dim3(256), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true>), grid, dim3(TC::NT), smem, s, g);
     else if (vec)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false>), grid, dim3(256), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false>), grid, dim3(TC::NT), smem, s, g);
     else if (masks)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, true>), grid, dim3(256), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, true>), grid, dim3(TC::NT), smem, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, false>), grid, dim3(256), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, false>), grid, dim3(TC::NT), smem, s, g);
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -143,21 +143,43 @@ using T128x32 = TileCfg<128, 32, 32, 4, 1, 1>;
 using T32x128 = TileCfg<32, 128, 32, 1, 4, 1>;
 using T64x64 = TileCfg<64, 64, 32, 2, 2, 1>;
 using T128x128 = TileCfg<128, 128, 32, 2, 2, 1>;
+// 512-thread workgroup (two waves per SIMD from ONE workgroup), each wave a 64x64 block: the dW_hh product.  One such
+// workgroup per CU (150 KB of split-plane LDS images); operand traffic per MAC is 2/3 of the 128x64 tile's.
+using T256x128 = TileCfg<256, 128, 32, 4, 2, 1, 512>;
+
+enum TnTile { TN_AUTO = 0, TN_256x128, TN_128x128, TN_128x64, TN_64x64, TN_128x32, TN_32x128 };
+
+// CPG_TN_TILE forces the tile of the transposed-use (dW = dY^T X) products: tools/kbench.py and tests/test_gpu_tiles.py
+// (every instantiation against the golden vectors).
+static TnTile tn_tile_knob() {
+    const char* e = getenv("CPG_TN_TILE");
+    if (!e) return TN_AUTO;
+    if (!strcmp(e, "256x128")) return TN_256x128;
+    if (!strcmp(e, "128x128")) return TN_128x128;
+    if (!strcmp(e, "128x64")) return TN_128x64;
+    if (!strcmp(e, "64x64")) return TN_64x64;
+    if (!strcmp(e, "128x32")) return TN_128x32;
+    if (!strcmp(e, "32x128")) return TN_32x128;
+    return TN_AUTO;
+}
 
 template <bool A_KC, bool B_KC>
-static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s) {
+static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s, TnTile force = TN_AUTO) {
     // 16-byte operand loads need aligned bases / leading dimensions and vectors that never straddle a bound
     const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
                      (!g.a_mask || (((uintptr_t)g.a_mask) & 3) == 0) && (!g.b_mask || (((uintptr_t)g.b_mask) & 3) == 0) &&
                      (g.k_chunk % 4 == 0) && ((A_KC || B_KC) ? g.K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) &&
                      (B_KC || g.N % 4 == 0);
-    if (!A_KC && !B_KC) {  // CPG_TN_TILE forces the tile of the transposed-use (dW = dY^T X) products: tools/kbench.py and
-        const char* e = getenv("CPG_TN_TILE");  // tests/test_gpu_tiles.py (every instantiation against the golden vectors)
-        if (e && !strcmp(e, "128x128")) return launch_tc<T128x128, A_KC, B_KC>(g, zdim, vec, s);
-        if (e && !strcmp(e, "128x64")) return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
-        if (e && !strcmp(e, "64x64")) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
-        if (e && !strcmp(e, "128x32")) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
-        if (e && !strcmp(e, "32x128")) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
+    if constexpr (!A_KC && !B_KC) {
+        switch (force) {
+            case TN_256x128: return launch_tc<T256x128, A_KC, B_KC>(g, zdim, vec, s);
+            case TN_128x128: return launch_tc<T128x128, A_KC, B_KC>(g, zdim, vec, s);
+            case TN_128x64: return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
+            case TN_64x64: return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
+            case TN_128x32: return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
+            case TN_32x128: return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
+            default: break;
+        }
     }
     if (g.M <= 32) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
     if (g.N <= 32) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
@@ -212,42 +234,53 @@ int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int
     return launch_gemm<true, false>(g, 1, s);
 }
 
-static void pick_split(int M, int N, int K, int& S, int& k_chunk) {
+// Plan of a dW[M,N] = dY^T X product contracting K rows: tile and split-K factor.
+struct TnPlan {
+    TnTile tile;
+    int S, k_chunk;
+};
+static TnPlan tn_plan(int M, int N, int K) {
+    TnPlan p{tn_tile_knob(), 1, 0};
     const char* e = getenv("CPG_TN_SPLIT");  // tuning knob (tools/kbench.py)
-    if (e && atoi(e) > 0) {
-        S = atoi(e);
-        k_chunk = cdiv(cdiv(K, S), 32) * 32;
-        S = cdiv(K, k_chunk);
-        return;
+    // Large products (the dW_hh product: M=3H, N=H, K=T*B): 256x128 tiles, ONE 512-thread workgroup per CU, split-K chosen
+    // so that a single round of <= 256 workgroups covers the problem.
+    if (p.tile == TN_AUTO && M >= 512 && N >= 256 && K >= 8192 && M % 4 == 0 && N % 4 == 0) p.tile = TN_256x128;
+    long want;
+    if (p.tile == TN_256x128) {
+        const long tiles = (long)cdiv(M, 256) * cdiv(N, 128);
+        want = 256 / tiles;
+    } else {
+        // Two 128x64 workgroups are resident per CU (57 KB LDS each): aim at ~3 full rounds of 512 workgroups so the
+        // last round is not half empty (measured at M=1536,N=512,K=51200: S=4 (384 WGs) 1356 us, S=16 (1536 WGs) 1084 us).
+        const long tiles = (long)cdiv(M, 128) * cdiv(N, 64);
+        want = (1536 + tiles - 1) / tiles;
     }
-    // Two 128x64 workgroups are resident per CU (57 KB LDS each): aim at ~3 full rounds of 512 workgroups so the
-    // last round is not half empty (measured at M=1536,N=512,K=51200: S=4 (384 WGs) 1356 us, S=16 (1536 WGs) 1084 us).
-    const long tiles = (long)cdiv(M, 128) * cdiv(N, 64);
-    long want = (1536 + tiles - 1) / tiles;
+    if (e && atoi(e) > 0) want = atoi(e);
     if (want < 1) want = 1;
     long maxs = K / 512;  // at least 16 slabs per workgroup: shorter chunks are all prologue (measured: K=2048 split 16 ways
     if (maxs < 1) maxs = 1;  // ran a 3.2 GFLOP product in 0.46 ms)
-    if (want > maxs) want = maxs;
+    if (!(e && atoi(e) > 0) && want > maxs) want = maxs;
     if (want > 64) want = 64;
-    k_chunk = cdiv(cdiv(K, (int)want), 32) * 32;
-    S = cdiv(K, k_chunk);
+    p.k_chunk = cdiv(cdiv(K, (int)want), 32) * 32;
+    p.S = cdiv(K, p.k_chunk);
+    return p;
 }
 
 // C[N,Kd] (+)= A^T B where A = dY[Mr, N] (ld lddy), B = X[Mr, Kd] (ld ldx); contraction over the Mr rows.
 int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
                 int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
-    int S, k_chunk;
-    pick_split(N, Kd, Mr, S, k_chunk);
+    TnPlan p = tn_plan(N, Kd, Mr);
+    int S = p.S;
     const size_t slab = (size_t)N * Kd;
     if (S > 1 && ws_bytes < slab * S * sizeof(float)) {
         S = 1;
     }
     if (S <= 1) {
         GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, dW, lddw, nullptr, accumulate, nullptr, 1.f, xmask, xms, nullptr, 1.f, 0, 0};
-        return launch_gemm<false, false>(g, 1, s);
+        return launch_gemm<false, false>(g, 1, s, p.tile);
     }
-    GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, ws, Kd, nullptr, 0, nullptr, 1.f, xmask, xms, nullptr, 1.f, k_chunk, slab};
-    int rc = launch_gemm<false, false>(g, S, s);
+    GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, ws, Kd, nullptr, 0, nullptr, 1.f, xmask, xms, nullptr, 1.f, p.k_chunk, slab};
+    int rc = launch_gemm<false, false>(g, S, s, p.tile);
     if (rc) return rc;
     const size_t n = slab;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, slab, S, dW, lddw, N, Kd,
@@ -257,9 +290,8 @@ int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_
 }
 
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
-    int S, k_chunk;
-    pick_split(N, Kd, Mr, S, k_chunk);
-    return (size_t)N * Kd * S * sizeof(float) + 256;
+    const TnPlan p = tn_plan(N, Kd, Mr);
+    return (size_t)N * Kd * p.S * sizeof(float) + 256;
 }
 
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {

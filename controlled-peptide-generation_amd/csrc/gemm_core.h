@@ -56,15 +56,15 @@ struct OpB {
     float mscale;
 };
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSEG_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSEG_, int NT_ = 256>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NSEG = NSEG_;
-    static constexpr int NT = 256;
+    static constexpr int NT = NT_;  // 256 (one wave per SIMD per workgroup) or 512 (two: the 256x128 dW tiles)
     static constexpr int WTM = BM / WM, WTN = BN / WN;
     static constexpr int MI = WTM / 16, NI = WTN / 16;
     static constexpr int AV = BM * BK / 4 / NT;  // float4 staging registers per thread
     static constexpr int BV = BN * BK / 4 / NT;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN * 64 == NT, "one 16x16-block grid position per wave");
     static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tile must be a multiple of 16");
     static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "staging must divide evenly");
     static_assert(WTN % (16 * NSEG) == 0, "a wave must own whole segment groups");
@@ -175,19 +175,27 @@ struct MainLoop {
     // staging-time split (SPLIT == 7): plane geometry in 32-bit words
     static constexpr int KCW = 20;
     static constexpr int SXA = BM + 4, SXB = BN + 4;
-    static constexpr int APL = A_KC ? BM * KCW : (BK / 2) * SXA;
-    static constexpr int BPL = B_KC ? BN * KCW : (BK / 2) * SXB;
+    // TRX: both operands transposed-use (dW = dY^T X).  Each plane is then a row of [32 k][16 x] bf16 subtiles (1 KB + 32 B
+    // pad): the staging thread writes the four columns of one k it loaded as ONE ds_write_b64 per plane, and a fragment is
+    // two ds_read_b64_tr_b16 (the LDS transposes 4 k x 16 x blocks on the way out; tools/micro/tr_read_probe.hip pins the
+    // lane/slot mapping) over a contiguous subtile - instead of four ds_read_b32 per plane from a [k-pair][x] image, which
+    // at two waves per SIMD ran the LDS at a fraction of its rate and bounded the dW_hh product.
+    // Slot i of lane group q contracts k = 4q + i (i < 4) / 16 + 4q + (i - 4): any bijection works when A and B agree.
+    static constexpr bool TRX = SPLIT == 7 && !A_KC && !B_KC;
+    static constexpr int TRW = 264;  // words per subtile: 32 rows x 8 words + 8 pad (consecutive subtiles on distinct banks)
+    static constexpr int APL = A_KC ? BM * KCW : (TRX ? (BM / 16) * TRW : (BK / 2) * SXA);
+    static constexpr int BPL = B_KC ? BN * KCW : (TRX ? (BN / 16) * TRW : (BK / 2) * SXB);
     static constexpr int ASZ7 = 3 * APL, BSZ7 = 3 * BPL;
     static_assert(SPLIT == 0 || SPLIT == 7, "0: exact f32, 7: bf16 split at LDS-store time");
     static_assert(SPLIT != 7 || BK == 32, "split products are written for 32-deep slabs");
-    static_assert(SPLIT != 7 || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
+    static_assert(SPLIT != 7 || TRX || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
     static constexpr size_t smem_bytes() {
         return SPLIT == 7 ? (size_t)2 * (ASZ7 + BSZ7) * 4 : (size_t)2 * (ASZ + BSZ) * sizeof(float);
     }
     // staging vector i of this thread -> (k row inside the slab, column quad) for an XC operand X columns wide
     template <int BX>
     __device__ static __forceinline__ void xc_index(int i, int& kk, int& xq) {
-        if (SPLIT == 7) {
+        if (SPLIT == 7 && !TRX) {
             const int u = threadIdx.x + (i >> 1) * TC::NT;
             xq = u % (BX / 4);
             kk = 2 * (u / (BX / 4)) + (i & 1);
@@ -352,6 +360,18 @@ struct MainLoop {
                 *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
                 *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
             }
+        } else if (TRX) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int v = tid + i * TC::NT, kk = v / (BX / 4), xq = v % (BX / 4);
+                uint32_t a0, a1, a2, b0, b1, b2;
+                split3_pair(r[i].x, r[i].y, a0, a1, a2);
+                split3_pair(r[i].z, r[i].w, b0, b1, b2);
+                uint32_t* q = dst + (xq >> 2) * TRW + kk * 8 + (xq & 3) * 2;
+                *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
+                *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < NV / 2; ++j) {
@@ -384,6 +404,17 @@ struct MainLoop {
     __device__ static __forceinline__ cpg_bf16x8 read7(const uint32_t* plane0, int pl, int x, int lq) {
         const uint32_t* P = plane0 + pl * PLW;
         if (KC) return *reinterpret_cast<const cpg_bf16x8*>(P + x * KCW + 4 * lq);
+        if (TRX) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+            const int s = x & 15;
+            const uint32_t* c = P + (x >> 4) * TRW + (4 * lq + (s >> 2)) * 8 + (s & 3) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(c));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(c + 16 * 8));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 w = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(cpg_bf16x8, w);
+        }
         const uint4 w = make_uint4(P[(4 * lq + 0) * SX + x], P[(4 * lq + 1) * SX + x], P[(4 * lq + 2) * SX + x], P[(4 * lq + 3) * SX + x]);
         return __builtin_bit_cast(cpg_bf16x8, w);
     }
@@ -391,6 +422,10 @@ struct MainLoop {
     // One slab: for every column block read its three B planes once, then walk the row blocks (A planes re-read per column
     // block: LDS reads are cheap here, registers are not - holding all planes of a 128x64 tile costs a resident wave), six
     // bf16 MFMAs per 16x16 block; the next slab's conversion + LDS writes are left free to interleave with them.
+    // Column blocks are walked NG at a time: their B planes are read once and kept while the row blocks stream past (A planes
+    // re-read once per group).  NG = 1 at 128 registers per wave; NG = 2 for the 512-thread workgroups (256 registers per
+    // wave), which halves the LDS fragment traffic of the wide tiles (the XC image costs four ds_read_b32 per plane).
+    static constexpr int NG = (TC::NT == 512 && TC::NI % 2 == 0) ? 2 : 1;
     template <bool STORE>
     __device__ static __forceinline__ void slab7(const OpA& a, const OpB& b, const uint32_t* Ac, const uint32_t* Bc, uint32_t* An,
                                                  uint32_t* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
@@ -398,13 +433,15 @@ struct MainLoop {
         const int wm = wave / TC::WN, wn = wave % TC::WN;
         const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-        for (int ni = 0; ni < TC::NI; ++ni) {
-            cpg_bf16x8 fb[3];
+        for (int n0 = 0; n0 < TC::NI; n0 += NG) {
+            cpg_bf16x8 fb[NG][3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                if (CPG_ABLATE & 2) fb[pl] = __builtin_bit_cast(cpg_bf16x8, acc[0][ni]);
-                else fb[pl] = read7<B_KC, BPL, SXB>(Bc, pl, wn * TC::WTN + ni * 16 + l15, lq);
-            }
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (CPG_ABLATE & 2) fb[g][pl] = __builtin_bit_cast(cpg_bf16x8, acc[0][n0 + g]);
+                    else fb[g][pl] = read7<B_KC, BPL, SXB>(Bc, pl, wn * TC::WTN + (n0 + g) * 16 + l15, lq);
+                }
 #pragma unroll
             for (int mi = 0; mi < TC::MI; ++mi) {
                 cpg_bf16x8 fa[3];
@@ -413,21 +450,24 @@ struct MainLoop {
                     if (CPG_ABLATE & 2) fa[pl] = __builtin_bit_cast(cpg_bf16x8, acc[mi][0]);
                     else fa[pl] = read7<A_KC, APL, SXA>(Ac, pl, wm * TC::WTM + mi * 16 + l15, lq);
                 }
-                f32x4 c = acc[mi][ni];
-                if (CPG_ABLATE & 8) {
-                    const f32x4 u = __builtin_bit_cast(f32x4, fa[0]), w = __builtin_bit_cast(f32x4, fb[0]);
-                    const f32x4 u1 = __builtin_bit_cast(f32x4, fa[1]), w1 = __builtin_bit_cast(f32x4, fb[1]);
-                    const f32x4 u2 = __builtin_bit_cast(f32x4, fa[2]), w2 = __builtin_bit_cast(f32x4, fb[2]);
-                    acc[mi][ni] = c + u * w + u1 * w1 + u2 * w2;
-                    continue;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    f32x4 c = acc[mi][n0 + g];
+                    if (CPG_ABLATE & 8) {
+                        const f32x4 u = __builtin_bit_cast(f32x4, fa[0]), w = __builtin_bit_cast(f32x4, fb[g][0]);
+                        const f32x4 u1 = __builtin_bit_cast(f32x4, fa[1]), w1 = __builtin_bit_cast(f32x4, fb[g][1]);
+                        const f32x4 u2 = __builtin_bit_cast(f32x4, fa[2]), w2 = __builtin_bit_cast(f32x4, fb[g][2]);
+                        acc[mi][n0 + g] = c + u * w + u1 * w1 + u2 * w2;
+                        continue;
+                    }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[g][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][0], c, 0, 0, 0);
+                    acc[mi][n0 + g] = c;
                 }
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[0], c, 0, 0, 0);
-                acc[mi][ni] = c;
             }
         }
         if (STORE && !(CPG_ABLATE & 1)) sstore7(a, b, An, Bn, st);

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
 struct GruBwdArgs {
     const float* dG_next;  // [B,4H] of the step processed just before this one (s+1), null on the first launch
     const float* w_hh;     // [3H,H]
+    const float* w_hhT;    // [H,3H] = w_hh^T (the split-bf16 engine wants both operands K-contiguous), or null: exact-f32 path
     const float* dH_next;  // [B,H] total gradient of h_{s+1}, null on the first launch
     const float* z_next;   // [B,H] z gate of step s+1
     const float* ext;      // [B,H] external gradient on h_s (time-aligned slice) or null
@@ -164,15 +165,20 @@ struct GruBwdPair {
     GruBwdArgs d[2];
 };
 
-// dgh . W_hh of the backward step: W_hh is the transposed-use (XC) operand, whose split staging works on k-row pairs
-// (tiles at least 64 columns wide); narrower tiles keep the exact-f32 MFMA.
+// dgh . W_hh of the backward step, two forms:
+//   WT = false  W_hh [3H,H] as stored is the transposed-use (XC) operand.  Its split staging works on k-row pairs (tiles at
+//               least 64 columns wide); narrower tiles run the exact-f32 MFMA (v_mfma_f32_16x16x4_f32), whose issue slots
+//               are shared with every VALU instruction of the epilogue / staging code.
+//   WT = true   the caller hands over W_hh^T [H,3H] (one 3 MB transpose per sequence): both operands are K-contiguous, so
+//               every tile shape runs on the split-bf16 engine (six bf16 MFMAs on operands split when the slab is stored).
 #ifndef CPG_STEP_BWD_SPLIT
 #define CPG_STEP_BWD_SPLIT 7
 #endif
-template <class TC, bool VEC>
-using BwdLoop = MainLoop<TC, true, false, VEC, VEC, false, (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && TC::BV % 2 == 0) ? 7 : 0>;
+template <class TC, bool VEC, bool WT>
+using BwdLoop = MainLoop<TC, true, WT, VEC, VEC, false,
+                         (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && (WT || TC::BV % 2 == 0)) ? 7 : 0>;
 
-template <class TC, bool VEC>
+template <class TC, bool VEC, bool WT>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -215,8 +221,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (g.dG_next) {
         OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
-        OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
-        BwdLoop<TC, VEC>::run(a, b, 3 * H, acc);
+        OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
+        BwdLoop<TC, VEC, WT>::run(a, b, 3 * H, acc);
     }
 #pragma unroll
     for (int ni = 0; ni < TC::NI; ++ni) {
@@ -337,23 +343,23 @@ static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
         hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false>), grid, dim3(256), smem, s, pr);
 }
 
-template <class TC>
+template <class TC, bool WT>
 static void launch_bwd(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = BwdLoop<TC, true>::smem_bytes();
+    const size_t smem = BwdLoop<TC, true, WT>::smem_bytes();
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             done = true;
         }
     }
     if (vec)
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true, WT>), grid, dim3(256), smem, s, pr);
     else
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false>), grid, dim3(256), smem, s, pr);
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false, WT>), grid, dim3(256), smem, s, pr);
 }
 
 // pick the row-tile height so that the launch has at least ~256 workgroups when the problem allows it
@@ -395,21 +401,90 @@ int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
     return gru_fwd_launch(pr, 1, s);
 }
 
+// Tile of a backward-step launch.  Exact-f32 path (no W_hh^T handed over, or one of the CPG_GRU_BWD_BM / CPG_GRU_BWD_WIDE
+// knobs set): the round-1 policy.  Split path: CPG_GRU_BWD_TILE = 64x32 | 32x64 | 64x64 | 128x32 | 128x64 | 32x32 forces.
+enum BwdTile { BT_64x32, BT_32x64, BT_64x64, BT_128x32, BT_128x64, BT_32x32 };
+struct BwdChoice {
+    bool wt;
+    BwdTile tile;
+};
+static BwdChoice gru_bwd_choice(int rows, int H, int nd, bool have_wt) {
+    const char* wide = getenv("CPG_GRU_BWD_WIDE");
+    const char* bmk = getenv("CPG_GRU_BWD_BM");
+    const char* exact = getenv("CPG_GRU_BWD_EXACT");
+    const char* t = getenv("CPG_GRU_BWD_TILE");
+    // Measured on MI355X (tools/kbench.py, B=2048, H=512, us per step): exact-f32 32x32 tiles 48.1; split-bf16 engine with
+    // W_hh^T: 64x32 52.9, 32x32 52.9, 32x64 65.3, 64x64 68.0, 128x32 73.7, 128x64 93.5.  The launch is bound by its fixed
+    // prologue / epilogue traffic and slab-loop latency, not by the matrix pipe (PMC: MFMA busy 16 %), so the cheaper
+    // product does not pay for the extra staging conversions: the split path runs only when CPG_GRU_BWD_TILE asks for it.
+    if (!have_wt || wide || bmk || !t || (exact && atoi(exact))) {
+        const int bm = pick_bm(rows, cdiv(H, 32), "CPG_GRU_BWD_BM");
+        // 32x32 tiles (>= 1024 workgroups) measured 51.4 us vs 53.7 us for 64x32 at B=2048,H=512; wider tiles lose badly (77 / 116 us)
+        const bool small = !wide && !bmk && (long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024;
+        if (small) return {false, BT_32x32};
+        if (wide && atoi(wide) == 64) return {false, BT_64x64};
+        if (wide && atoi(wide) == 128) return {false, BT_128x64};
+        if (wide && atoi(wide) == 32) return {false, BT_32x32};
+        if (bm == 128) return {false, BT_128x32};
+        if (bm == 64) return {false, BT_64x32};
+        return {false, BT_32x64};
+    }
+    if (t) {
+        if (!strcmp(t, "64x32")) return {true, BT_64x32};
+        if (!strcmp(t, "32x64")) return {true, BT_32x64};
+        if (!strcmp(t, "64x64")) return {true, BT_64x64};
+        if (!strcmp(t, "128x32")) return {true, BT_128x32};
+        if (!strcmp(t, "128x64")) return {true, BT_128x64};
+        if (!strcmp(t, "32x32")) return {true, BT_32x32};
+    }
+    if (rows <= 32) return {true, BT_32x64};
+    return {true, BT_64x32};
+}
+
+template <bool WT>
+static void launch_bwd_tile(BwdTile t, const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
+    switch (t) {
+        case BT_64x32: launch_bwd<GB64, WT>(pr, nd, vec, s); break;
+        case BT_32x64: launch_bwd<GB32, WT>(pr, nd, vec, s); break;
+        case BT_64x64: launch_bwd<GB64W, WT>(pr, nd, vec, s); break;
+        case BT_128x32: launch_bwd<GB128, WT>(pr, nd, vec, s); break;
+        case BT_128x64: launch_bwd<GB128W, WT>(pr, nd, vec, s); break;
+        case BT_32x32: launch_bwd<GB32N, WT>(pr, nd, vec, s); break;
+    }
+}
+
 static int gru_bwd_launch(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
-    bool vec = a.H % 4 == 0;
-    for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
-    const int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_BWD_BM");
-    const char* wide = getenv("CPG_GRU_BWD_WIDE");
-    // 32x32 tiles (>= 1024 workgroups) measured 51.4 us vs 53.7 us for 64x32 at B=2048,H=512; wider tiles lose badly (77 / 116 us)
-    const bool small = !wide && !getenv("CPG_GRU_BWD_BM") && (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) * nd >= 1024;
-    if (small) launch_bwd<GB32N>(pr, nd, vec, s);
-    else if (wide && atoi(wide) == 64) launch_bwd<GB64W>(pr, nd, vec, s);
-    else if (wide && atoi(wide) == 128) launch_bwd<GB128W>(pr, nd, vec, s);
-    else if (wide && atoi(wide) == 32) launch_bwd<GB32N>(pr, nd, vec, s);
-    else if (bm == 128) launch_bwd<GB128>(pr, nd, vec, s);
-    else if (bm == 64) launch_bwd<GB64>(pr, nd, vec, s);
-    else launch_bwd<GB32>(pr, nd, vec, s);
+    bool vec = a.H % 4 == 0, have_wt = true;
+    for (int d = 0; d < nd; ++d) {
+        vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
+        have_wt = have_wt && pr.d[d].w_hhT != nullptr;
+        if (pr.d[d].w_hhT) vec = vec && aligned16(pr.d[d].w_hhT);
+    }
+    const BwdChoice c = gru_bwd_choice(a.row1 - a.row0, a.H, nd, have_wt);
+    if (c.wt) launch_bwd_tile<true>(c.tile, pr, nd, vec, s);
+    else launch_bwd_tile<false>(c.tile, pr, nd, vec, s);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[H,3H] = w[3H,H]^T
+__global__ void transpose_w_kernel(const float* w, int R, int C, float* out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[i][threadIdx.x] = w[(size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[(size_t)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, wT);
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -562,10 +637,14 @@ CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_
 // dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
 CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                               int row_begin, int row_end, const int32_t* step_rows, void* stream) {
+                               int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
+    if (w_hhT_scratch) {
+        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     int prev_t = -1;
     for (int p = T - 1; p >= -1; --p) {  // p = processing index of the step whose dH we form; p=-1 closes with dh0
         if (p < 0 && !dh0) break;
@@ -576,6 +655,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         a.row0 = row_begin;
         a.row1 = row_end;
         a.w_hh = w_hh;
+        a.w_hhT = w_hhT_scratch;
         a.nrows = (step_rows && t >= 0) ? step_rows + t : nullptr;
         a.nrows_next = (step_rows && prev_t >= 0) ? step_rows + prev_t : nullptr;
         const int cur = (p + 2) & 1;
@@ -752,9 +832,15 @@ CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const
 CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                                  const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                                  const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
-                                 void* stream) {
+                                 float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
-    CPG_CHECK_ARG(scratch_f && scratch_r);
+    CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
+    if (w_hhT_scratch_f) {
+        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream);
+        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    const float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
     const size_t BH = (size_t)B * H;
     const float* W[2] = {w_hh_f, w_hh_r};
     const float* HS[2] = {hs_f, hs_r};
@@ -776,6 +862,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.row0 = 0;
             a.row1 = B;
             a.w_hh = W[d];
+            a.w_hhT = WT[d];
             if (prev_t[d] >= 0) {
                 a.dG_next = DG[d] + (size_t)prev_t[d] * B * 4 * H;
                 a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;

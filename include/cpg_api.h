@@ -93,11 +93,13 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
 /* BPTT.  dhs_ext [T,B,H]: gradient arriving at each step's output (time-aligned; may be null);
  * dh_last [B,H]: gradient on the final state (may be null); dG out [T,B,4H] = (dr_pre, dz_pre, d(W_hn h+b_hn), dn_pre):
  * columns 0..3H are the hidden-side gate gradients, columns {0..2H, 3H..4H} the input-side ones;
- * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip). */
+ * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip).
+ * w_hhT_scratch [H,3H] (optional): receives W_hh^T once per call, which puts the dgh . W_hh product of every step on the
+ * split-bf16 MFMA engine (both operands K-contiguous); null keeps the exact-f32 MFMA kernels. */
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
                             int row_begin, int row_end, const int32_t* step_rows /* as in cpg_gru_seq_fwd; dG rows of dead
-                            (t,row) pairs are not written: pass a zeroed dG */, void* stream);
+                            (t,row) pairs are not written: pass a zeroed dG */, float* w_hhT_scratch, void* stream);
 /* Both directions of one biGRU layer in lock step, ONE launch per step for the pair (launch p: time p forward, time
  * T-1-p reverse).  Arguments as in cpg_gru_seq_fwd / _bwd per direction (_f forward, _r reverse); no initial-state
  * gradient (the encoder starts from h0 = 0). */
@@ -108,6 +110,7 @@ CPG_API int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const fl
 CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                               const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                               const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
+                              float* w_hhT_scratch_f, float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */,
                               void* stream);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */

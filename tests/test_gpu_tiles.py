@@ -18,7 +18,7 @@ from helpers import (check_decoder_teacher_forced_golden, check_encoder_golden, 
 
 pytestmark = pytest.mark.gpu
 MODELS = ["A", "micro", "enc2"]
-KNOBS = ("CPG_GRU_FWD_BM", "CPG_GRU_BWD_BM", "CPG_GRU_BWD_WIDE", "CPG_TN_TILE", "CPG_TN_SPLIT")
+KNOBS = ("CPG_GRU_FWD_BM", "CPG_GRU_BWD_BM", "CPG_GRU_BWD_WIDE", "CPG_GRU_BWD_TILE", "CPG_TN_TILE", "CPG_TN_SPLIT")
 
 
 @pytest.fixture(autouse=True)
@@ -57,23 +57,25 @@ def test_forward_tiles_golden(golden, knobs, name, bm):
 
 
 BWD_VARIANTS = [dict(CPG_GRU_BWD_BM=32), dict(CPG_GRU_BWD_BM=64), dict(CPG_GRU_BWD_BM=128),
-                dict(CPG_GRU_BWD_WIDE=32), dict(CPG_GRU_BWD_WIDE=64), dict(CPG_GRU_BWD_WIDE=128)]
+                dict(CPG_GRU_BWD_WIDE=32), dict(CPG_GRU_BWD_WIDE=64), dict(CPG_GRU_BWD_WIDE=128)] + \
+               [dict(CPG_GRU_BWD_TILE=t) for t in ("64x32", "32x64", "64x64", "128x32", "128x64", "32x32")]
 
 
-@pytest.mark.parametrize("variant", BWD_VARIANTS, ids=lambda v: "-".join(f"{k[8:]}{x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", BWD_VARIANTS, ids=lambda v: "-".join(f"{k[12:]}{x}" for k, x in v.items()))
 @pytest.mark.parametrize("name", MODELS)
 def test_backward_tiles_golden(golden, knobs, name, variant):
-    """gru_step_bwd_kernel<GB32|GB64|GB128|GB32N|GB64W|GB128W> (GB32N = exact-f32 32x32 tiles is the bench's)."""
+    """gru_step_bwd_kernel<GB32|GB64|GB128|GB32N|GB64W|GB128W> on the exact-f32 path (BM / WIDE knobs; GB32N = 32x32 tiles
+    is the bench's) and on the split-bf16 path with W_hh^T handed over (TILE knob)."""
     knobs(**variant)
     check_losses_and_grads_golden(golden("model_" + name))
 
 
-@pytest.mark.parametrize("tile", ["128x64", "64x64", "128x128", "128x32", "32x128"])
+@pytest.mark.parametrize("tile", ["256x128", "128x64", "64x64", "128x128", "128x32", "32x128"])
 @pytest.mark.parametrize("split", [1, 3])
 @pytest.mark.parametrize("name", MODELS)
 def test_wgrad_tiles_golden(golden, knobs, name, tile, split):
     """dW = dY^T X products (the dW_hh product and every nn.Linear weight gradient): each tile shape, with and without
-    split-K (128x64 split-K is the bench's dW_hh instantiation)."""
+    split-K (256x128 split-K, 512-thread workgroups, is the bench's dW_hh instantiation)."""
     knobs(CPG_TN_TILE=tile, CPG_TN_SPLIT=split)
     check_losses_and_grads_golden(golden("model_" + name))
 

@@ -159,3 +159,46 @@ def test_sqdist_forms_agree():
         wae.SQDIST_BROADCAST_LIMIT = old
     assert abs(float(l1) - float(l2)) < 1e-7
     np.testing.assert_allclose(g1, g2, atol=1e-9)
+
+
+# ---- the torch-CPU restatement that bench.py times as `cpu_baseline` (oracle/torch_ref.py), pinned to the same vectors
+@pytest.mark.parametrize("name", MODELS)
+def test_torch_ref_losses_and_grads(golden, name):
+    import torch
+    from oracle import torch_ref
+    g = golden("model_" + name)
+    P = weights_of(g)
+    rnd = {k: torch.from_numpy(np.ascontiguousarray(g[k])) for k in
+           ("eps", "c", "wd_mask", "out_mask", "z_prior_full", "z_prior_rf", "rf_w", "rf_b")}
+    m = torch_ref.RefWAE.from_state(P)
+    terms, aux = torch_ref.train_loss(m, torch.from_numpy(g["ids"]), rnd, float(g["beta"]), float(g["lam_l1"]),
+                                      float(g["lam_kl"]), str(g["regu"]))
+    terms["total"].backward()
+    for a, b in (("recon", "loss_recon"), ("kl", "loss_kl"), ("klmu", "loss_klmu"), ("mmd", "loss_mmd_full"),
+                 ("mmdrf", "loss_mmd_rf"), ("total", "loss_total")):
+        assert abs(terms[a].item() - float(g[b])) < 1e-5, a
+    np.testing.assert_allclose(aux["logits"].detach().numpy(), g["logits_train"], atol=5e-6, rtol=1e-5)
+    for k, p in m.named_parameters():
+        ref = g["g." + m.ref_name(k)]
+        np.testing.assert_allclose(p.grad.numpy(), ref, atol=5e-7 + 2e-5 * np.abs(ref).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["micro_clip", "A_clip"])
+def test_torch_ref_trajectory(golden, name):
+    """k iterations of clip + Adam with the duplicate embedding entry (F6) reproduce the reference's parameters."""
+    import torch
+    from oracle import torch_ref
+    g = golden("train_" + name)
+    m = torch_ref.RefWAE.from_state(weights_of(g, "w0."))
+    tr = torch_ref.Trainer(m, lr=1e-3, clip=float(g["clip"]))
+    end_it = int(g["beta_end_iter"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for it in range(g["batches"].shape[0]):
+        beta = 1.0 if it <= 0 else (2.0 if it >= end_it else 1.0 + it / end_it)
+        rnd = {k: t(g[k][it]) for k in ("eps", "c", "wd_mask", "out_mask", "z_prior_full", "z_prior_rf")}
+        rnd.update(rf_w=t(g["rf_w"]), rf_b=t(g["rf_b"]))
+        tr.step(t(g["batches"][it]), rnd, beta=beta, lam_l1=0.0, lam_kl=1e-3, z_regu=str(g["z_regu"]))
+        snap = f"w{it + 1}."
+        if snap + "word_emb.weight" in g:
+            for k, p in m.named_parameters():
+                np.testing.assert_allclose(p.detach().numpy(), g[snap + m.ref_name(k)], atol=3e-5, rtol=0, err_msg=snap + k)  # Adam is ill-conditioned where |g| ~ eps

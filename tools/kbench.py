@@ -58,8 +58,11 @@ def main():
     def fwd():
         call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), None if a.no_gates else _p(gates), 0, B, None, _stream())
 
+    wT = torch.empty(H, 3 * H, device=dev)
+
     def bwd():
-        call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), 0, B, None, _stream())
+        call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), 0, B, None,
+             _p(wT), _stream())
 
     big_ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)  # large enough for any split the knobs select
 
