@@ -261,6 +261,37 @@ def transpose01_u8(x):
 
 
 # ----------------------------------------------------------------------------------------------- GRU
+_persist_scratch = {}
+
+
+def persistent_fits(B, H):
+    """Whole-sequence persistent kernels (csrc/gru_persist.hip) cover this shape on this device."""
+    return bool(query("cpg_gru_persistent_fits", int(B), int(H)))
+
+
+def _persist_sync_scratch(B, dev):
+    nb = query("cpg_gru_persistent_scratch_bytes", B)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, B)
+    sc = _persist_scratch.get(key)
+    if sc is None:
+        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word
+    return sc
+
+
+def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, gates):
+    sc = _persist_sync_scratch(B, hs.device)
+    call("cpg_gru_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
+         _p(hs), _p(gates), _p(sc), _stream())
+
+
+def check_persistent():
+    """Raise if any in-kernel wait of a persistent launch has timed out since start-up (synchronises the streams used)."""
+    for (_, _, B), sc in _persist_scratch.items():
+        if query("cpg_gru_persistent_status", B, _p(sc), _stream()) != 0:
+            raise CpgError("persistent GRU kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
+                           "set CPG_GRU_PERSIST=0 to use the per-step kernels")
+
+
 class GruSeqFn(Function):
     """One direction of one GRU layer over the whole sequence (torch.nn.GRU at models/encoder.py:25-30,42 and
     models/decoder.py:40-41,77).  Returns the state slab [(T+1),B,H] (layout in include/cpg_api.h)."""
@@ -296,7 +327,9 @@ class GruSeqFn(Function):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         groups = row_groups(B)
-        if len(groups) == 1:
+        if step_rows is None and len(groups) == 1 and persistent_fits(B, H):
+            gru_seq_fwd_persistent(T, B, H, reverse, w_hh_c, b_hh_c, tok, tab_c, rowc_c, dense_c, hs, gates)
+        elif len(groups) == 1:
             call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
                  _p(hs), _p(gates), 0, B, _p(step_rows), _stream())
         else:
@@ -401,8 +434,13 @@ class GruBiSeqFn(Function):
         if PROFILE is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr), _p(hs_f),
-             _p(hs_r), _p(g_f), _p(g_r), _stream())
+        if persistent_fits(B, H):
+            # two persistent launches back to back on ONE stream (each needs all of its workgroups co-resident)
+            gru_seq_fwd_persistent(T, B, H, False, wf, bf, tok, tf, None, df, hs_f, g_f)
+            gru_seq_fwd_persistent(T, B, H, True, wr, br, tok, tr, None, dr, hs_r, g_r)
+        else:
+            call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr), _p(hs_f),
+                 _p(hs_r), _p(g_f), _p(g_r), _stream())
         if ev is not None:
             ev[1].record()
             PROFILE.append(("gru_bistep_fwd", ev[0], ev[1], T, B, H))

@@ -112,6 +112,21 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
                               const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
                               float* w_hhT_scratch_f, float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */,
                               void* stream);
+/* Persistent form: the WHOLE time loop of one direction in ONE launch (csrc/gru_persist.hip): each workgroup keeps the
+ * W_hh rows of 16 hidden units in LDS (already split into bf16 planes) for 256 batch rows and the column-tile workgroups of
+ * a row tile hand h_t to each other through the state slab (write-through stores + arrival counters), so nothing is
+ * re-staged, re-launched or re-gathered per step.  Same arguments and results as cpg_gru_seq_fwd over all rows.
+ * cpg_gru_persistent_fits: 1 when (B,H) is covered on this device (H % 32 == 0, H <= 512, one workgroup per CU co-resident;
+ * CPG_GRU_PERSIST=0 disables).  sync_scratch: cpg_gru_persistent_scratch_bytes(B) bytes of device memory, zeroed by the
+ * caller once (arrival counters, re-zeroed by every call, + a sticky error word).  cpg_gru_persistent_status synchronises the
+ * stream and returns the error word (0 = every in-kernel wait of every launch on this scratch completed).
+ * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident. */
+CPG_API int cpg_gru_persistent_fits(int B, int H);
+CPG_API size_t cpg_gru_persistent_scratch_bytes(int B);
+CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
+                                       const int32_t* tok, const float* tab, const float* rowc, const float* dense,
+                                       float* hs, float* gates, void* sync_scratch, void* stream);
+CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,

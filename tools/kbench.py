@@ -55,6 +55,9 @@ def main():
     nb = query("cpg_gru_wgrad_workspace", T, B, H, V)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
 
+    def fwdp():
+        ops.gru_seq_fwd_persistent(T, B, H, False, w_hh, b_hh, tok, tab, rowc, None, hs, None if a.no_gates else gates)
+
     def fwd():
         call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), None if a.no_gates else _p(gates), 0, B, None, _stream())
 
@@ -80,10 +83,12 @@ def main():
             for k, v in env.items():
                 os.environ[k] = v
             f = timeit(fwd, a.iters) / T
+            fp = timeit(fwdp, a.iters) / T if ops.persistent_fits(B, H) else float("nan")
             b = timeit(bwd, a.iters) / (T + 1)
             w = timeit(wgrad, a.iters)
             for k in env:
                 os.environ.pop(k, None)
+            print(f"[{rnd}] {label:24s} fwd-persistent {fp:7.1f} us/step ({fl_step / fp / 1e6:6.1f} TF)")
             print(f"[{rnd}] {label:24s} fwd {f:7.1f} us/step ({fl_step / f / 1e6:6.1f} TF)  bwd {b:7.1f} us/step "
                   f"({fl_step / b / 1e6:6.1f} TF)  wgrad {w:8.1f} us ({fl_step * T / w / 1e6:6.1f} TF)")
 
