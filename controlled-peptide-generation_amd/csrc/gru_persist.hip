@@ -10,28 +10,52 @@
 //   * a workgroup owns CT = 16 hidden units (the r, z, n rows of W_hh for them: 48 x H) for a group of 256 batch rows and
 //     keeps that W_hh slice in LDS for the whole sequence, ALREADY split into three bf16 planes (48 x H x 6 B = 147 KB at
 //     H = 512: the reason for CT = 16 and for one workgroup per CU);
-//   * each of its 4 waves owns 64 of the rows.  The state operand h_{t-1}[64 rows, H] goes global -> registers -> MFMA
-//     A fragments directly (every element is used by exactly one wave, so there is nothing to share through LDS and the
-//     time loop has NO workgroup barrier); the per-row constant input term and the previous state of the wave's own
-//     64 x 16 outputs stay in registers across steps;
-//   * the 32 column-tile workgroups of a row tile exchange h_t through the state slab itself: write-through (sc1) 16-byte
-//     stores, vmcnt(0), one relaxed agent-scope atomic add on the row tile's arrival counter; consumers poll that counter
-//     relaxed, then read the slab with sc1 loads (L1 bypassed: no acquire fence needed) - the placement-independent
-//     hand-off of the CDNA guide (Guideline 16, R1).  Every step writes its own slab slot: no buffer is ever reused,
-//     so there is no write-after-read hazard.  Counters are zeroed by the host before every launch; spins are bounded.
+//   * each of its 8 waves (two per SIMD: one wave's cell arithmetic and waits run under the other's MFMAs) owns 32 of the
+//     rows.  The state operand goes global -> registers -> MFMA A fragments directly: every element is used by exactly one
+//     wave of the workgroup, so nothing is shared through LDS and the time loop has NO workgroup barrier; the per-row
+//     constant input term and the previous state of the wave's own 32 x 16 outputs stay in registers across steps;
+//   * the 32 column-tile workgroups of a row tile hand h_t to each other ALREADY SPLIT: the producer converts its own
+//     32 x 16 outputs once and writes three bf16 planes into a two-slot exchange buffer (the first form of this kernel let
+//     every consumer convert the full state tile itself: 2816 VALU instructions per wave and step, the kernel was VALU-bound
+//     at 31.6 us per step - PMC in profiles/).  Hand-off = the placement-independent recipe of the CDNA guide (Guideline 16,
+//     R1): write-through (sc1) 16-byte stores, vmcnt(0), one relaxed agent-scope atomic add on the row tile's arrival
+//     counter; consumers poll that counter relaxed, then read with sc1 loads (L1 bypassed: no acquire fence needed).
+//     Slot reuse is safe: a wave overwrites slot (p+1)&1 only after all 32 producers of its row tile have ARRIVED for step
+//     p-1, i.e. finished reading it.  Counters are zeroed by the host before every launch; every spin is bounded.
+//   * the f32 state slab and the saved gates are plain / non-temporal stores issued behind the arrival.
 // Arithmetic is the per-step kernel's (same split, same MFMA order, same cell formulas): results are f32-grade and the
 // golden / oracle parity tests run unchanged on this path.
 #include "gemm_core.h"
 #include "cpg_internal.h"
 #include <stdlib.h>
 
+#ifndef CPG_PERSIST_ACQUIRE
+#define CPG_PERSIST_ACQUIRE 0
+#endif
+// Diagnostic builds only (results wrong by construction): 1 no waits, 2 A operand loaded once per step, 4 no MFMAs,
+// 8 no cell transcendental math, 16 no gate stores, 32 no publish drain (vmcnt) before the arrival
+#ifndef CPG_PERSIST_ABLATE
+#define CPG_PERSIST_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int P_CT = 16;          // hidden units per workgroup
-constexpr int P_WROWS = 64;       // rows per wave
-constexpr int P_WAVES = 4;
+#ifndef CPG_PERSIST_WAVES
+#define CPG_PERSIST_WAVES 4
+#endif
+#ifndef CPG_PERSIST_DEFER
+#define CPG_PERSIST_DEFER 0       // 1: the f32 state / gate stores of step p are issued after the wait of step p+1
+#endif
+#ifndef CPG_PERSIST_DEPTH
+#define CPG_PERSIST_DEPTH 2
+#endif
+constexpr int P_DEPTH = CPG_PERSIST_DEPTH;
+constexpr int P_WAVES = CPG_PERSIST_WAVES;
+constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
+constexpr int P_MI = P_WROWS / 16;
 constexpr int P_NC = 3 * P_CT;    // gate columns per workgroup
-constexpr int P_TBW = 20;         // words per row of the per-wave 16x16 transposition buffer
+constexpr int P_TBW = 16;         // words per row of the per-wave 16x16 transposition buffer
 constexpr unsigned P_SPIN_LIMIT = 400000u;  // ~0.2 s of polling before a wave gives up (sets the error word)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -46,7 +70,10 @@ struct PFwdArgs {
     float* hs;             // [(T+1),B,H]
     float* gates;          // [T,4,B,H] or null
     unsigned* cnt;         // [row tiles] arrival counters (zeroed before the launch)
-    unsigned* err;         // error word (zeroed before the launch)
+    unsigned* err;         // sticky error word
+    uint16_t* xch;         // [2 slots][3 planes][H/32 k-blocks][B][32] bf16: the state as the consumers want it - a wave's
+                           // A-fragment load (16 rows x 32 k of one plane) is ONE contiguous KB.  (With rows H apart the 32
+                           // CUs of an XCD that read the same tile at the same time camped on a few L2 channels: 62.8 us/step.)
     int T, B, H, reverse, groups, S;  // S: words per plane row (H/2 data + pad so that S % 64 == 8)
 };
 
@@ -71,7 +98,7 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* 
     return true;
 }
 
-// 16x16 tile held in the MFMA accumulator layout (lane (u = l&15, rq = l>>4), reg -> row 4rq+reg, col u) -> one float4 per
+// 16x16 tile held in the MFMA accumulator layout (lane (u = l&15, rq = l>>4), reg -> row 4rq+reg, col u) -> one f32x4 per
 // lane in row layout (lane -> row l>>2, cols 4(l&3)..+3), through the wave's own LDS buffer (no other wave touches it).
 __device__ __forceinline__ f32x4 acc_to_rows(float* tb, const float (&v)[4], int lane) {
     const int u = lane & 15, rq = lane >> 4;
@@ -80,7 +107,29 @@ __device__ __forceinline__ f32x4 acc_to_rows(float* tb, const float (&v)[4], int
     return *reinterpret_cast<const f32x4*>(tb + (lane >> 2) * P_TBW + 4 * (lane & 3));
 }
 
-__global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
+// value of the neighbouring lane (l ^ 1)
+__device__ __forceinline__ float lane_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+
+// Row-layout tile (lane -> row l>>2, 4 columns) -> three bf16 planes in the exchange slot: even lanes collect their odd
+// neighbour's four columns and store 8 columns = 16 bytes per plane, write-through.
+__device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffer_rsrc_t rx, int voff, unsigned plane_bytes,
+                                             unsigned slot_off, bool ok, int lane) {
+    const float n0 = lane_xor1(v[0]), n1 = lane_xor1(v[1]), n2 = lane_xor1(v[2]), n3 = lane_xor1(v[3]);
+    if ((lane & 1) == 0 && ok) {
+        uint32_t w0[4], w1[4], w2[4];
+        split3_pair(v[0], v[1], w0[0], w1[0], w2[0]);
+        split3_pair(v[2], v[3], w0[1], w1[1], w2[1]);
+        split3_pair(n0, n1, w0[2], w1[2], w2[2]);
+        split3_pair(n2, n3, w0[3], w1[3], w2[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w0[1], w0[2], w0[3]}, rx, voff, slot_off, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, slot_off + plane_bytes, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, slot_off + 2 * plane_bytes, 16);
+    }
+}
+
+__global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t psm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a)
     float* const tb = reinterpret_cast<float*>(psm + 3 * PLW) + wave * (16 * P_TBW);
 
     // ---- W_hh slice -> three bf16 planes in LDS, once per sequence: plane[c = gate*16 + u][k pair]
-    for (int idx = tid; idx < P_NC * (H / 2); idx += 256) {
+    for (int idx = tid; idx < P_NC * (H / 2); idx += P_WAVES * 64) {
         const int c = idx / (H / 2), kp = idx - c * (H / 2);
         const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c >> 4) * H + j0 + (c & 15))) * H + 2 * kp);
         uint32_t w0, w1, w2;
@@ -109,15 +158,20 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a)
     if (row0 >= B) return;               // wave-uniform; nobody waits for a tile that does not exist
     const int l15 = lane & 15, lq = lane >> 4;
     const int col = j0 + l15;            // hidden unit of this lane's accumulator elements
+    const int srow = lane >> 2, scq = lane & 3;  // row-layout coordinates after acc_to_rows
+
+    const unsigned plane_bytes = (unsigned)((size_t)B * H * 2), kb_bytes = (unsigned)B * 64u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xch, 6 * plane_bytes);
+    bool dead = false;
 
     // per-lane constants of the epilogue: row of accumulator element (mi, reg), clamped for the loads
-    float rc[4][4][3], hprev[4][4];
+    float rc[P_MI][4][3], hprev[P_MI][4];
     const size_t slot0 = (size_t)(a.reverse ? T : 0) * B * H;
     float bh[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) bh[q] = a.b_hh[q * H + col];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < P_MI; ++mi) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = min(row0 + 16 * mi + 4 * lq + r, B - 1);
@@ -125,23 +179,62 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a)
             for (int q = 0; q < 3; ++q) rc[mi][r][q] = a.rowc ? a.rowc[(size_t)row * 3 * H + q * H + col] : 0.f;
             hprev[mi][r] = a.hs[slot0 + (size_t)row * H + col];
         }
-    // A-operand addressing: lane (l15, lq) of row block mi reads 8 consecutive k of row row0 + 16 mi + l15
-    int aoff[4];
+        // h0 enters the exchange like any step's output: slot 0, arrival #1
+        const int row = row0 + 16 * mi + srow;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.hs + slot0 + (size_t)min(row, B - 1) * H + j0 + 4 * scq);
+        publish_rows(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // A-operand addressing: lane (l15, lq) of row block mi reads 8 consecutive k of row row0 + 16 mi + l15 (16 bytes of a plane)
+    int aoff[P_MI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) aoff[mi] = (min(row0 + 16 * mi + l15, B - 1) * H + 8 * lq) * 4;
+    for (int mi = 0; mi < P_MI; ++mi) aoff[mi] = min(row0 + 16 * mi + l15, B - 1) * 64 + 16 * lq;
     const uint32_t* const bbase = planes + l15 * S + 4 * lq;
-    const unsigned slab_bytes = (unsigned)((size_t)B * H * 4);
-    bool dead = false;
+
+    // saved-for-backward gates and the f32 state of the last finished step (not part of the hand-off)
+    float rg[P_MI][4], zg[P_MI][4], ng[P_MI][4], hn[P_MI][4];
+    f32x4 hrow[P_MI];
+    int pend_tt = -1;
+    auto flush = [&]() {
+        if (pend_tt < 0) return;
+        float* const hout = a.hs + (size_t)(a.reverse ? pend_tt : pend_tt + 1) * B * H;
+#pragma unroll
+        for (int mi = 0; mi < P_MI; ++mi) {
+            const int row = row0 + 16 * mi + srow;
+            if (row < B) *reinterpret_cast<f32x4*>(hout + (size_t)row * H + j0 + 4 * scq) = hrow[mi];
+        }
+        if (a.gates && !(CPG_PERSIST_ABLATE & 16)) {
+            const size_t BH = (size_t)B * H;
+            float* const gbase = a.gates + (size_t)pend_tt * 4 * BH;
+#pragma unroll
+            for (int mi = 0; mi < P_MI; ++mi) {
+                const int row = row0 + 16 * mi + srow;
+                const f32x4 v0 = acc_to_rows(tb, rg[mi], lane);
+                const f32x4 v1 = acc_to_rows(tb, zg[mi], lane);
+                const f32x4 v2 = acc_to_rows(tb, ng[mi], lane);
+                const f32x4 v3 = acc_to_rows(tb, hn[mi], lane);
+                if (row < B) {
+                    float* d = gbase + (size_t)row * H + j0 + 4 * scq;
+                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(d));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(d + BH));
+                    __builtin_nontemporal_store(v2, reinterpret_cast<f32x4*>(d + 2 * BH));
+                    __builtin_nontemporal_store(v3, reinterpret_cast<f32x4*>(d + 3 * BH));
+                }
+            }
+        }
+        pend_tt = -1;
+    };
 
     for (int p = 0; p < T; ++p) {
         const int tt = a.reverse ? T - 1 - p : p;
-        const float* const hin = a.hs + (size_t)(a.reverse ? tt + 1 : tt) * B * H;
-        float* const hout = a.hs + (size_t)(a.reverse ? tt : tt + 1) * B * H;
+        const unsigned in_off = (unsigned)(p & 1) * 3u * plane_bytes, out_off = (unsigned)((p + 1) & 1) * 3u * plane_bytes;
 
         // input-side pre-activations of this step: independent of the recurrence, fetched before the wait
-        float gi[4][4][3];
+        float gi[P_MI][4][3];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = min(row0 + 16 * mi + 4 * lq + r, B - 1);
@@ -157,24 +250,30 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a)
                 gi[mi][r][0] = x0; gi[mi][r][1] = x1; gi[mi][r][2] = x2;
             }
 
-        if (p > 0) wait_ge(a.cnt + rt, (unsigned)(NCT * p), a.err, dead);
+        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt, (unsigned)(NCT * (p + 1)), a.err, dead);
+        if (CPG_PERSIST_DEFER) flush();
+#if CPG_PERSIST_ACQUIRE
+        // plain (L2-allocating) loads behind ONE agent-scope acquire: the 32 column-tile workgroups of a row tile read the
+        // same planes, so all but the first reader hit the XCD's L2 (sc1 loads are served at the fabric rate: 60 us/step)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 
-        // ---- recurrent product: acc[mi][gate] = h_prev[64 rows, H] . W_hh[gate rows of 16 units, H]^T
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(hin, slab_bytes);
-        f32x4 acc[4][3];
+        // ---- recurrent product: acc[mi][gate] = h_prev[32 rows, H] . W_hh[gate rows of 16 units, H]^T
+        f32x4 acc[P_MI][3];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
             for (int q = 0; q < 3; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 bufA[4][2], bufB[4][2];
-        auto load = [&](u32x4 (&buf)[4][2], int kb) {
+        u32x4 buf[P_DEPTH][P_MI][3];  // register ring: the loads of k-block kb + P_DEPTH - 1 are in flight while kb is multiplied
+        auto load = [&](u32x4 (&b)[P_MI][3], int kb) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                buf[mi][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, aoff[mi] + kb * 128, 0, 16);
-                buf[mi][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, aoff[mi] + kb * 128 + 16, 0, 16);
-            }
+            for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes,
+                                                                      CPG_PERSIST_ACQUIRE ? 0 : 16);
         };
-        auto compute = [&](const u32x4 (&buf)[4][2], int kb) {
+        auto compute = [&](const u32x4 (&buf)[P_MI][3], int kb) {
             cpg_bf16x8 fb[3][3];
 #pragma unroll
             for (int q = 0; q < 3; ++q)
@@ -182,19 +281,19 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a)
                 for (int pl = 0; pl < 3; ++pl)
                     fb[q][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + q * 16 * S + kb * 16);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const f32x4 lo = __builtin_bit_cast(f32x4, buf[mi][0]), hi = __builtin_bit_cast(f32x4, buf[mi][1]);
-                uint32_t w0[4], w1[4], w2[4];
-                split3_pair(lo[0], lo[1], w0[0], w1[0], w2[0]);
-                split3_pair(lo[2], lo[3], w0[1], w1[1], w2[1]);
-                split3_pair(hi[0], hi[1], w0[2], w1[2], w2[2]);
-                split3_pair(hi[2], hi[3], w0[3], w1[3], w2[3]);
-                const cpg_bf16x8 fa0 = __builtin_bit_cast(cpg_bf16x8, make_uint4(w0[0], w0[1], w0[2], w0[3]));
-                const cpg_bf16x8 fa1 = __builtin_bit_cast(cpg_bf16x8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
-                const cpg_bf16x8 fa2 = __builtin_bit_cast(cpg_bf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+            for (int mi = 0; mi < P_MI; ++mi) {
+                const cpg_bf16x8 fa0 = __builtin_bit_cast(cpg_bf16x8, buf[mi][0]);
+                const cpg_bf16x8 fa1 = __builtin_bit_cast(cpg_bf16x8, buf[mi][1]);
+                const cpg_bf16x8 fa2 = __builtin_bit_cast(cpg_bf16x8, buf[mi][2]);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     f32x4 c = acc[mi][q];
+                    if (CPG_PERSIST_ABLATE & 4) {
+                        acc[mi][q] = c + __builtin_bit_cast(f32x4, fa0) * __builtin_bit_cast(f32x4, fb[q][0]) +
+                                     __builtin_bit_cast(f32x4, fa1) * __builtin_bit_cast(f32x4, fb[q][1]) +
+                                     __builtin_bit_cast(f32x4, fa2) * __builtin_bit_cast(f32x4, fb[q][2]);
+                        continue;
+                    }
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa2, fb[q][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][1], c, 0, 0, 0);
@@ -205,61 +304,52 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_persist_kernel(PFwdArgs a)
                 }
             }
         };
-        load(bufA, 0);
-        for (int kb = 0; kb < KB; kb += 2) {
-            if (kb + 1 < KB) load(bufB, kb + 1);
-            compute(bufA, kb);
-            if (kb + 2 < KB) load(bufA, kb + 2);
-            if (kb + 1 < KB) compute(bufB, kb + 1);
-        }
-
-        // ---- cell (same formulas and association as gru_step_fwd_kernel)
-        float rg[4][4], zg[4][4], ng[4][4], hn[4][4];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int d = 0; d < P_DEPTH - 1; ++d)
+            if (d < KB) load(buf[d], d);
+        for (int kb = 0; kb < KB; kb += P_DEPTH) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hn[mi][r] = acc[mi][2][r] + bh[2];
-                rg[mi][r] = sigmoidf_(gi[mi][r][0] + (acc[mi][0][r] + bh[0]));
-                zg[mi][r] = sigmoidf_(gi[mi][r][1] + (acc[mi][1][r] + bh[1]));
-                ng[mi][r] = tanhf(gi[mi][r][2] + rg[mi][r] * hn[mi][r]);
-                hprev[mi][r] = (1.f - zg[mi][r]) * ng[mi][r] + zg[mi][r] * hprev[mi][r];
-            }
-
-        // ---- publish h_t: write-through 16-byte stores, drain, one arrival per wave
-        const __amdgpu_buffer_rsrc_t rout = make_rsrc(hout, slab_bytes);
-        const int srow = lane >> 2, scq = lane & 3;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const f32x4 v = acc_to_rows(tb, hprev[mi], lane);
-            const int row = row0 + 16 * mi + srow;
-            if (row < B)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (row * H + j0 + 4 * scq) * 4, 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-        // ---- saved-for-backward gates (not part of the hand-off: streamed out behind the arrival)
-        if (a.gates) {
-            const size_t BH = (size_t)B * H;
-            float* const gbase = a.gates + (size_t)tt * 4 * BH;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int row = row0 + 16 * mi + srow;
-                const f32x4 v0 = acc_to_rows(tb, rg[mi], lane);
-                const f32x4 v1 = acc_to_rows(tb, zg[mi], lane);
-                const f32x4 v2 = acc_to_rows(tb, ng[mi], lane);
-                const f32x4 v3 = acc_to_rows(tb, hn[mi], lane);
-                if (row < B) {
-                    float* d = gbase + (size_t)row * H + j0 + 4 * scq;
-                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(d));
-                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(d + BH));
-                    __builtin_nontemporal_store(v2, reinterpret_cast<f32x4*>(d + 2 * BH));
-                    __builtin_nontemporal_store(v3, reinterpret_cast<f32x4*>(d + 3 * BH));
+            for (int d = 0; d < P_DEPTH; ++d) {
+                if (kb + d < KB) {
+                    if (kb + d + P_DEPTH - 1 < KB && !(CPG_PERSIST_ABLATE & 2)) load(buf[(d + P_DEPTH - 1) % P_DEPTH], kb + d + P_DEPTH - 1);
+                    compute(buf[d], kb + d);
                 }
             }
         }
+
+        // ---- cell (same formulas and association as gru_step_fwd_kernel)
+#pragma unroll
+        for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hn[mi][r] = acc[mi][2][r] + bh[2];
+                if (CPG_PERSIST_ABLATE & 8) {
+                    rg[mi][r] = gi[mi][r][0] + (acc[mi][0][r] + bh[0]);
+                    zg[mi][r] = gi[mi][r][1] + (acc[mi][1][r] + bh[1]);
+                    ng[mi][r] = gi[mi][r][2] + rg[mi][r] * hn[mi][r];
+                } else {
+                rg[mi][r] = sigmoidf_(gi[mi][r][0] + (acc[mi][0][r] + bh[0]));
+                zg[mi][r] = sigmoidf_(gi[mi][r][1] + (acc[mi][1][r] + bh[1]));
+                ng[mi][r] = tanhf(gi[mi][r][2] + rg[mi][r] * hn[mi][r]);
+                }
+                hprev[mi][r] = (1.f - zg[mi][r]) * ng[mi][r] + zg[mi][r] * hprev[mi][r];
+            }
+
+        // ---- publish h_t (split planes, write-through), drain, one arrival per wave; the f32 slab goes out behind it
+#pragma unroll
+        for (int mi = 0; mi < P_MI; ++mi) {
+            hrow[mi] = acc_to_rows(tb, hprev[mi], lane);
+            const int row = row0 + 16 * mi + srow;
+            if (p + 1 < T)
+                publish_rows(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
+                             out_off + (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
+        }
+        if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend_tt = tt;
+        if (!CPG_PERSIST_DEFER) flush();
     }
+    if (CPG_PERSIST_DEFER) flush();
 }
 
 int plane_stride_words(int H) {
@@ -296,11 +386,16 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
     return cus > 0 && wgs <= cus;
 }
 
-CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int B) { return (size_t)(cdiv(B, P_WROWS) + 16) * sizeof(unsigned); }
+static size_t sync_words(int B) { return ((size_t)cdiv(B, P_WROWS) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
+
+CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int B, int H) {
+    return sync_words(B) * sizeof(unsigned) + (size_t)6 * B * H * sizeof(uint16_t);  // + two exchange slots of three bf16 planes
+}
 
 // Whole forward sequence in one launch; arguments as cpg_gru_seq_fwd (all rows).  sync_scratch: device memory of
-// cpg_gru_persistent_scratch_bytes(B) bytes, ZEROED BY THE CALLER when allocated: arrival counters (re-zeroed here on the
-// stream before every launch) followed by a sticky error word (set by a wave whose wait timed out, never cleared here).
+// cpg_gru_persistent_scratch_bytes(B,H) bytes, ZEROED BY THE CALLER when allocated: arrival counters (re-zeroed here on the
+// stream before every launch), a sticky error word (set by a wave whose wait timed out, never cleared here) and the two
+// exchange slots.
 CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                           const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                           float* hs, float* gates, void* sync_scratch, void* stream) {
@@ -317,6 +412,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.gates = gates;
     a.cnt = (unsigned*)sync_scratch;
     a.err = a.cnt + nrt;
+    a.xch = (uint16_t*)(a.cnt + sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(nrt, P_WAVES);
     a.S = plane_stride_words(H);
@@ -326,7 +422,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
         CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(gru_seq_fwd_persist_kernel, dim3(a.groups * (H / P_CT)), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(gru_seq_fwd_persist_kernel, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), smem, s, a);
     CPG_LAUNCH_CHECK();
     return 0;
 }
