@@ -23,13 +23,67 @@ for p in (ROOT, PKG):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X f32-input MFMA = f32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
-# HBM bytes per launch of the dominant kernel from PMC counters (separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-# passes over tools/kbench.py at the bench shapes; (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 read-side correction
-# of MI355X_MICROARCH.md section HBM).  Counters cannot be collected from inside this script; the numbers and commands are
-# in profiles/r01_bench_n1_summary_final.md.  Only valid for the default GRU / B=2048 / H=512 workload.
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide); the forward step executes 6 bf16 MFMA flops per f32 flop
-PMC_TRAFFIC_BYTES = {("gru", 2048, 512): (2 * 21.1 + 21.4) * 1024 * 1024}
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X f32-input MFMA = f32 vector peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
+# Kernels on the split engine compute an f32-grade product as SIX bf16 MFMAs on 3-way split operands: the best f32-grade rate
+# that pipe can give is the bf16 peak / 6.  Exact kernels (v_mfma_f32_16x16x4_f32) are priced against the f32 MFMA peak.
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+HBM_PEAK_GBS = 8000.0
+# HBM bytes per launch from PMC counters (FETCH_SIZE / WRITE_SIZE in KB, separate rocprofv3 passes, tools/pmc_run.sh +
+# tools/pmc_summary.py --json): counters cannot be collected from inside this script, so the per-kernel means of the
+# committed profile are looked up BY THE KERNEL NAME THE LAUNCHER REPORTS - a tile-policy change yields null, not a stale
+# number.  (2*FETCH + WRITE)*1024: the gfx950 read-side correction of MI355X_MICROARCH.md, HBM section.
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+
+
+def pmc_traffic(kernel):
+    try:
+        d = json.load(open(PMC_JSON))
+    except (OSError, ValueError):
+        return None
+    r = d.get(kernel)
+    if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
+        return None
+    return (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
+
+
+def _cname(fn, *args):
+    import ctypes
+    from cpg import lib
+    buf = ctypes.create_string_buffer(256)
+    getattr(lib().dll, fn)(*args, buf, 256)
+    return buf.value.decode()
+
+
+def family_roofline(family, dims, avg_us, launches):
+    """Roofline object of one kernel family of the step (names and product form come from the launcher)."""
+    from cpg import lib
+    T, B, H, nd = dims["T"], dims["B"], dims["H"], dims["ndir"]
+    L = lib().dll
+    if family == "fwd_persist":
+        kernel, split, flops = "gru_seq_fwd_persist_kernel", True, T * 2.0 * B * H * 3 * H
+    elif family == "fwd_step":
+        kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), bool(L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0))
+        flops = nd * 2.0 * B * H * 3 * H
+    elif family == "bwd_step":
+        kernel, split = _cname("cpg_gru_step_kernel_name", 1, B, H, nd, 1), bool(L.cpg_gru_step_kernel_is_split(1, B, H, nd, 1))
+        flops = nd * 2.0 * B * 3 * H * H
+    elif family == "wgrad_hh":
+        kernel, split, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), True, 2.0 * 3 * H * H * T * B
+    else:
+        return None
+    ach = flops / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
+    peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    r = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+         "frac": round(ach / peak, 4), "traffic": pmc_traffic(kernel), "avg_launch_us": round(avg_us, 2),
+         "launches_timed": launches, "flops_per_launch": flops,
+         "pipe": ("bf16 MFMA, 6 x v_mfma_f32_16x16x32_bf16 on 3-way split operands per f32-grade block product: peak = 2500/6"
+                  if split else "exact f32 MFMA (v_mfma_f32_16x16x4_f32): peak = 157.3"),
+         "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+    if split:
+        r["executed_bf16_tflops"] = round(6 * ach, 1)
+        r["executed_frac_of_bf16_peak"] = round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4)
+    return r
 
 
 def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, cell='gru'):
@@ -51,40 +105,40 @@ def train_flops_per_seq(T, E, He, Z, V, R, B, gates=3):
     return fwd + 2 * rec + 2 * small + 3 * 2 * B * Z                  # bwd: dh product + dW product (+ Gram MMD)
 
 
-def cpu_baseline(sd, T, V, B_sample, steps):
-    """The numpy oracle (a port of the reference's algorithm, oracle/wae.py + oracle/optim.py) timed on the host cores
-    on a bounded sample of the same workload: same model dimensions, a smaller batch."""
-    from oracle import wae, optim
-    P = {k: v.detach().cpu().numpy().copy() for k, v in sd.items() if not k.startswith("classifier")}
-    Z = P["encoder.q_mu.weight"].shape[0]
-    Hd = Z + 2
-    rs = np.random.RandomState(0)
-    ids = torch.randint(4, V, (B_sample, T)).numpy()
-    ids[:, 0] = 2
-    ids[:, -2] = 3
-    ids[:, -1] = 1
-    opt = optim.AdamClip(P, lr=1e-3, max_norm=5.0)
+def cpu_baseline(T, V, threads):
+    """The torch-CPU restatement of the reference's training step (oracle/torch_ref.py: nn.GRU / F.cross_entropy / autograd /
+    Adam exactly as train_vae.py drives them, pinned to the golden vectors in tests/test_oracle_golden.py) timed on the
+    host cores at SURVEY 8(d)'s cases.  `value` is the case with this bench's dimensions (config B, batch 2048); the
+    reference-faithful [N,N,D] full-kernel MMD is off there (8.6 GB x 3 + autograd at z=510) and on in the config-A case."""
+    from oracle import torch_ref
+    from cpg.synth import synth_ids
+    torch.set_num_threads(threads)
+    cases = []
+    for tag, B, He, Z, full, nsteps in (("config B (enc h=512, z=510), batch 2048, full-kernel MMD off", 2048, 512, 510, False, 4),
+                                        ("config A (reference defaults: enc h=80, z=100), batch 32, all four regularisers", 32, 80, 100, True, 30),
+                                        ("config A, batch 2048, full-kernel MMD off", 2048, 80, 100, False, 6)):
+        torch.manual_seed(1238)
+        m = torch_ref.RefWAE(V, 150, He, 1, Z)
+        tr = torch_ref.Trainer(m)
+        rnd = dict(rf_w=torch.randn(Z, 500), rf_b=2 * np.pi * torch.rand(500))
+        ids = synth_ids(B, T, V, torch.Generator().manual_seed(1))
+        ts = []
+        note("  cpu case: " + tag)
+        t_case = time.perf_counter()
+        for i in range(nsteps + 1):
+            t0 = time.perf_counter()
+            tr.step(ids, rnd, full_mmd=full)
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_case > 25.0 and len(ts) >= 2:   # bounded sample: ~25 s of host work per case at most
+                break
+        dt = float(np.median(ts[1:]))
+        cases.append({"case": tag, "seq_per_s": round(B / dt, 1), "s_per_step": round(dt, 4), "steps": len(ts) - 1})
+    return cases
 
-    def draw():
-        c = np.zeros((B_sample, 2), np.float32)
-        c[np.arange(B_sample), rs.randint(0, 2, B_sample)] = 1
-        return dict(eps=rs.randn(B_sample, Z).astype(np.float32), c=c,
-                    wd_mask=(rs.rand(B_sample, T) < 0.3).astype(np.uint8),
-                    out_mask=(rs.rand(B_sample, T, Hd) >= 0.3).astype(np.uint8),
-                    z_prior_full=rs.randn(B_sample, Z).astype(np.float32),
-                    z_prior_rf=rs.randn(B_sample, Z).astype(np.float32),
-                    rf_w=rf_w, rf_b=rf_b)
-    rf_w = rs.randn(Z, 500).astype(np.float32)
-    rf_b = (2 * np.pi * rs.rand(500)).astype(np.float32)
-    times = []
-    for i in range(steps + 1):
-        rnd = draw()
-        t0 = time.perf_counter()
-        terms, G, _ = wae.train_loss_and_grads(P, ids, rnd, 1.0, 0.0, 1e-3, "mmdrf")
-        opt.step(P, G)
-        times.append(time.perf_counter() - t0)
-    dt = float(np.median(times[1:]))
-    return B_sample / dt, dt
+
+def note(msg):
+    """progress on stderr (stdout carries the one JSON line)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -99,7 +153,6 @@ def main():
     ap.add_argument("--cell", default="gru", choices=["gru", "lstm"], help="gru = the reference's cell (parity pinned); lstm = extension")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=256)
     args = ap.parse_args()
 
     from cpg import dist as cdist
@@ -139,6 +192,7 @@ def main():
     def step(it):
         return tv.train_step(cfgv, model, trainer, pool[it % len(pool)], it)
 
+    note("warm-up")
     for it in range(args.warmup):
         step(it)
     torch.cuda.synchronize()
@@ -161,33 +215,44 @@ def main():
     assert np.isfinite(loss_val), "non-finite loss in the timed region"
     if rank != 0:
         return
+    note(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
     ms = dt / args.steps * 1e3
     seq_per_s = B * world * args.steps / dt
 
-    # dominant kernel: the fused GRU forward step (one launch per time step; decoder sequence = H 512, B rows)
+    # kernel families of the step, timed with HIP events on their launch streams inside the timed region (cpg.ops._prof);
+    # the roofline object carries the family with the largest share of the step, the others follow in `extra`
+    fams = {}
+    for fam, e0, e1, launches, dims in prof:
+        key = (fam, dims["B"], dims["H"], dims["ndir"], dims["T"])
+        f = fams.setdefault(key, {"ms": 0.0, "launches": 0, "dims": dims, "family": fam})
+        f["ms"] += e0.elapsed_time(e1)
+        f["launches"] += launches
+    rows = []
+    for f in fams.values():
+        avg_us = f["ms"] * 1e3 / max(f["launches"], 1)
+        r = family_roofline(f["family"], f["dims"], avg_us, f["launches"])
+        if r is None:
+            continue
+        r["family"] = f["family"] + ("_pair" if f["dims"]["ndir"] == 2 else "")
+        r["ms_per_step"] = round(f["ms"] / args.steps, 3)
+        r["share_of_step"] = round(f["ms"] / args.steps / ms, 4)
+        rows.append(r)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    by_kernel = {}
+    for r in rows:   # single-direction and paired launches of one kernel: rank kernels by their summed share
+        by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0.0) + r["ms_per_step"]
+    top_kernel = max(by_kernel, key=by_kernel.get) if by_kernel else None
+    roofline = next((r for r in rows if r["kernel"] == top_kernel), {"bound": "mfma", "kernel": None, "achieved": 0.0,
+                                                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 0.0,
+                                                                     "traffic": None})
+    roofline = dict(roofline)
+    roofline["kernel_ms_per_step_all_launch_shapes"] = round(by_kernel.get(top_kernel, 0.0), 3)
     gates = 3 if args.cell == "gru" else 4
-    recs = [r for r in prof if r[0] == args.cell + "_step_fwd" and r[5] == Hh]
-    tot_ms = sum(r[1].elapsed_time(r[2]) for r in recs)
-    launches = sum(r[3] for r in recs)
-    avg_us = tot_ms * 1e3 / max(launches, 1)
-    flops_launch = 2.0 * B * Hh * gates * Hh
-    achieved = flops_launch / (avg_us * 1e-6) / 1e12 if launches else 0.0
-    kname = ("gru_step_fwd_kernel<TileCfg<64,96,32,2,2,3>,true>" if args.cell == "gru"
-             else "lstm_step_fwd_kernel<TileCfg<64,128,32,2,2,4>,true>")
-    # achieved / peak are quoted on the ALGORITHMIC f32 product (2*B*H*gates*H per launch) against the f32 MFMA peak: the
-    # result is an f32-grade product.  The GRU kernel executes it as six bf16 MFMAs on 3-way split operands,
-    # i.e. 6x the algorithmic flops on the bf16 pipe: that fraction is reported beside it.
-    roofline = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": PMC_TRAFFIC_BYTES.get((args.cell, B, Hh)), "avg_launch_us": round(avg_us, 2), "launches_timed": launches,
-                "flops_per_launch": flops_launch}
-    if args.cell == "gru":
-        roofline["product_form"] = "f32 in/out, 6 x v_mfma_f32_16x16x32_bf16 on 3-way split operands (f32-grade)"
-        roofline["executed_bf16_tflops"] = round(6 * achieved, 1)
-        roofline["executed_frac_of_bf16_peak"] = round(6 * achieved / PEAK_BF16_MFMA_TFLOPS, 4)
     step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
     extra = {"loss_last_step": round(loss_val, 4), "executed_step_tflops_per_gpu": round(step_tflops, 2),
-             "executed_step_frac_of_f32_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)}
+             "executed_step_frac_of_f32_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+             "kernel_families": [r for r in rows if r is not roofline]}
+    ops.check_persistent()
 
     cfg_tag = ("BASELINE.json configs[1]" if (Hh, T, args.enc_layers, B) == (512, 25, 1, 2048)
                else "BASELINE.json configs[4] dimensions, GRU cells, 1-layer decoder as in the reference"
@@ -207,51 +272,111 @@ def main():
         "roofline": roofline, "extra": extra,
     }
     if world == 1 and not args.no_cpu_baseline:
-        v, sdt = cpu_baseline(model.state_dict(), T, V, args.cpu_sample_batch, 9)   # ~12 s of host work
-        line["cpu_baseline"] = {"value": round(v, 1), "unit": "seq/s", "cores": os.cpu_count(), "kind": "port",
-                                "sample": f"numpy oracle (oracle/wae.py + oracle/optim.py), same model dims, batch "
-                                          f"{args.cpu_sample_batch}, median of 9 steps after 1 warm-up ({sdt:.2f} s/step), all four "
-                                          f"regularisers incl. the [N,N,D] full-kernel MMD"}
+        # ATen's CPU GRU forks/joins its thread pool at every time step: on the box's 256 hardware threads the step got SLOWER
+        # than on 8 (minutes per step); 32 threads is about the best these shapes get.  Stated in the output.
+        threads = min(32, os.cpu_count() or 1)
+        note("cpu baseline (torch-CPU restatement)")
+        cases = cpu_baseline(T, V, threads)
+        line["cpu_baseline"] = {"value": cases[0]["seq_per_s"], "unit": "seq/s", "cores": threads, "kind": "port",
+                                "sample": f"oracle/torch_ref.py (torch-CPU restatement of train_vae.py's step on ATen CPU kernels: the "
+                                          f"backend the reference runs on), torch.set_num_threads({threads}); {cases[0]['case']}: median of "
+                                          f"{cases[0]['steps']} steps after 1 warm-up ({cases[0]['s_per_step']} s/step)",
+                                "cases": cases}
     if world == 1 and not args.no_class:
-        line["extra"]["class"] = class_bench(dev)
+        note("CLaSS leg")
+        line["class"] = class_bench(dev, cpu=not args.no_cpu_baseline)
     print(json.dumps(line))
 
 
-def class_bench(dev, N=262144):
-    """CLaSS inner loop at the reference's default dims (config A): z-space LR scoring + accept, greedy decode of all z."""
-    from cpg import class_sampler, ops
+def class_setup(dev, Z=100, K=100, seed=1238):
+    """SURVEY 8(d) synthetic CLaSS problem at the reference's default dims: proposal = diagonal GMM (K=100, means N(0,0.8^2),
+    variances e^-2), two logistic-regression heads w ~ N(0,1/Z), b = 0, targets {amp: 1, tox: 0}."""
+    import types
+    from cpg.synth import SyntheticPeptideLoader
+    from density_modeling import mogQ
     from models.model import RNN_VAE
-    torch.manual_seed(1238)
-    m = RNN_VAE(n_vocab=24, max_seq_len=25, **model_kwargs(100, 80)).to(dev)
+    torch.manual_seed(seed)
+    m = RNN_VAE(n_vocab=24, max_seq_len=25, **model_kwargs(Z, 80)).to(dev)
     m.device = dev
-    z = ops.rng_normal((N, 100), 99, 0, dev)
-    c = torch.zeros(N, 2, device=dev)
+    rs = np.random.RandomState(seed)
+    Q = mogQ.from_params(np.ones(K) / K, rs.randn(K, Z) * 0.8, np.full((K, Z), np.exp(-2.0)), device=dev)
+    clf = lambda: types.SimpleNamespace(coef_=rs.randn(1, Z) / np.sqrt(Z), intercept_=np.zeros(1), classes_=np.array([0.0, 1.0]))
+    Q.init_attr_classifiers({'amp': clf(), 'tox': clf()}, clf_targets={'amp': 1, 'tox': 0})
+    Q.rng = 'device'
+    ds = SyntheticPeptideLoader(4, 25, dev, size=16)
+    return m, Q, ds
+
+
+def class_cpu_baseline(m, Q, n_score=1000000, n_decode=1024):
+    """CPU port of one CLaSS round on a bounded sample: the numpy oracle's LR scoring + accept test of n_score z and its
+    Beam.py-order beam-5 decode of n_decode z (python per-sentence bookkeeping, like the reference)."""
+    from oracle import class_sampler as ocs, decode as odec
+    P = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    rs = np.random.RandomState(0)
+    z = rs.randn(n_score, m.z_dim).astype(np.float32)
+    coef, icpt, tgt = (t.cpu().numpy() for t in Q._dev_clf)
+    t0 = time.perf_counter()
+    probs, accum, acc = ocs.rejection_mask(z, [(coef[i:i + 1], icpt[i:i + 1], int(tgt[i])) for i in range(len(tgt))], rs.rand(n_score))
+    t_score = time.perf_counter() - t0
+    c = np.zeros((n_decode, 2), np.float32)
     c[:, 1] = 1
-    coef = torch.randn(2, 100, device=dev, dtype=torch.float64) / 10
-    icpt = torch.zeros(2, device=dev, dtype=torch.float64)
-    tgt = torch.tensor([1, 0], device=dev, dtype=torch.int32)
-    u = ops.rng_uniform((N,), 5, 0, dev, dtype=torch.float64)
-    for _ in range(2):
-        ids, _, _ = m.generate_sentences(N, z, c, sample_mode='greedy')
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    probs, accum, acc = class_sampler.lr_score_accept(z, coef, icpt, tgt, u)
-    ids, _, _ = m.generate_sentences(N, z, c, sample_mode='greedy')
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    steps = 25  # the device loop always runs max_seq_len steps
-    # beam-5 / n_best-3 decode (the reference's decode_from_z mode), incl. the hypothesis walk-back and its D2H copy
-    from cpg import decode as cdecode
-    Nb = 131072
-    cdecode.decode_beam_raw(m.decoder, z[:1024], c[:1024], 25)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    hyps, lens, _ = cdecode.decode_beam_arrays(m.decoder, z[:Nb], c[:Nb], 25, beam_size=5, n_best=3)
-    dtb = time.perf_counter() - t0
-    return {"workload": f"config A (z=100, dec h=102), {N} z: LR score+accept, greedy decode of all z; beam-5 on {Nb} z",
-            "z_per_s": round(N / dt, 1), "decoder_evals_per_s": round(N * steps / dt, 1),
-            "accepted_per_s": round(float(acc.sum().item()) / dt, 1),
-            "beam5_z_per_s": round(Nb / dtb, 1), "beam5_decoder_evals_per_s": round(Nb * 5 * (hyps.shape[2] - 1) / dtb, 1)}
+    hyps, _ = odec.beam(P, z[:n_decode], c, 25, beam_size=5, n_best=3)
+    t_dec = time.perf_counter() - t0
+    steps = sum(len(h[0]) - 1 for h in hyps)
+    z_per_s = 1.0 / (t_score / n_score + t_dec / n_decode)     # reference behaviour: every proposal is decoded
+    return {"value": round(z_per_s * float(acc.mean()), 1), "unit": "accepted-samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy oracle (oracle/class_sampler.py + oracle/decode.py): LR scoring + accept of {n_score} z ({t_score:.2f} s), "
+                      f"beam-5 / n-best-3 decode of {n_decode} z ({t_dec:.1f} s, {5 * steps / t_dec:.0f} decoder row-step evals/s); "
+                      f"every proposal decoded, as sample_pipeline.py:129-139 does",
+            "z_per_s": round(z_per_s, 1), "decoder_evals_per_s": round(5 * steps / t_dec, 1)}
+
+
+def class_bench(dev, N=1000000, cpu=True):
+    """BASELINE.json configs[3] on one GPU: ONE sampling round of 1 M proposals through sample_pipeline.run_rounds - device
+    GMM draw, LR scoring + accept test, beam-5 / n-best-3 decode (the reference decodes EVERY proposal), residue rows,
+    de-duplication, the final pandas table - wall-clock, plus the accepted-only and greedy variants of the same round."""
+    import logging
+    import sample_pipeline as sp
+    from cpg import ops
+    logging.getLogger('GenerationAPI').setLevel(logging.WARNING)
+    m, Q, ds = class_setup(dev)
+    EVAL_FLOPS = 2.0 * 3 * 102 * (252 + 102) + 2.0 * 102 * 24    # one decoder row-step (SURVEY 8d: 221.5 kFLOP at config A)
+    out = {}
+    sp.run_rounds(m, ds, Q, 65536, 10 ** 9, max_rounds=1, sample_mode='beam')          # warm-up (code load, allocator)
+    for tag, kw in (("beam5_all", dict(sample_mode='beam')), ("beam5_accepted_only", dict(sample_mode='beam', decode_accepted_only=True)),
+                    ("greedy_all", dict(sample_mode='greedy'))):
+        torch.cuda.synchronize()
+        note("CLaSS variant " + tag)
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        df, st = sp.run_rounds(m, ds, Q, N, 10 ** 9, max_rounds=1, return_stats=True, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+        kms = sum(e0.elapsed_time(e1) for _, e0, e1, _, _ in prof)
+        launches = sum(l for _, _, _, l, _ in prof)
+        r = {"proposals": st["proposed"], "decoded": st["decoded"], "accepted_unique": int(df['accept'].sum()), "unique": len(df),
+             "wall_s": round(dt, 3), "accepted_per_s": round(float(df['accept'].sum()) / dt, 1),
+             "proposals_per_s": round(st["proposed"] / dt, 1), "decoder_evals_per_s": round(st["decoder_evals"] / dt, 1),
+             "decoder_evals": st["decoder_evals"], "decode_kernel_ms": round(kms, 2)}
+        if kms > 0:
+            ach = st["decoder_evals"] * EVAL_FLOPS / (kms * 1e-3) / 1e12
+            r["roofline"] = {"bound": "mfma", "kernel": "decode_beam_fused_kernel<6, 2>" if kw["sample_mode"] == "beam" else "decode_greedy_fused_kernel<6, 2>",
+                             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                             "traffic": None, "avg_launch_us": round(kms * 1e3 / max(launches, 1), 1), "launches_timed": launches,
+                             "flops_per_eval": EVAL_FLOPS, "pipe": "exact f32 MFMA, W_hh fragments in registers, state in LDS (csrc/decode_fused.hip); "
+                             "algorithmic flops = live row-steps x (dense W_ih + W_hh + fc)"}
+        out[tag] = r
+    head = out["beam5_all"]
+    res = {"workload": f"BASELINE.json configs[3] on 1 GPU: {N} z proposals (synthetic GMM K=100), 2 LR heads, reference defaults "
+                       f"z=100 / decoder h=102 / V=24 / T=25, beam-5 decode of every proposal through sample_pipeline.run_rounds",
+           "metric": "CLaSS accepted-samples/s", "value": head["accepted_per_s"], "unit": "accepted-samples/s",
+           "decoder_evals_per_s": head["decoder_evals_per_s"], "roofline": head.get("roofline"), "variants": out}
+    if cpu:
+        note("CLaSS cpu baseline")
+        res["cpu_baseline"] = class_cpu_baseline(m, Q)
+    return res
 
 
 if __name__ == "__main__":

@@ -43,10 +43,22 @@ class Vocab:
         return len(self.ix2word)
 
 
+def load_state_dict_checked(model, sd):
+    """load_state_dict that tolerates exactly what the reference's checkpoints legitimately lack or add - nothing on the
+    VAE path.  The reference passes strict=False (api.py:93), which silently ignores any mismatch; a mismatched checkpoint
+    would leave parts of the model randomly initialised, so every missing / unexpected key is an error here except the
+    aliased `decoder.emb.weight` (same tensor as `word_emb.weight`)."""
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if k != 'decoder.emb.weight']
+    if missing or unexpected:
+        raise RuntimeError('checkpoint does not match the model: missing {}, unexpected {}'.format(missing, unexpected))
+    return model
+
+
 def load_trained_model(model_path, n_vocab, device=None):
     device = device or torch.device('cuda')
     model = RNN_VAE(n_vocab, max_seq_len=cfg.max_seq_len, **cfg.model)
-    model.load_state_dict(torch.load(model_path, map_location='cpu'), strict=False)
+    load_state_dict_checked(model, torch.load(model_path, map_location='cpu'))
     model = model.to(device)
     model.device = device
     model.eval()

@@ -24,6 +24,8 @@ def _fc(decoder, h, logits):
 
 
 LDS_PER_WORKGROUP = 160 * 1024  # gfx950
+LAST_GREEDY_STEPS = 0   # decoder row-steps the last greedy decode needed: sum over steps of the rows not yet finished
+LAST_BEAM_STEPS = 0     # sentence-steps the last beam decode advanced (x beam_size = decoder row-steps)
 FUSED_GREEDY = os.environ.get("CPG_NO_FUSED_DECODE", "") == ""
 
 
@@ -49,15 +51,19 @@ def _decode_beam_fused(decoder, zc, tab, rowc, max_len, K, n_best, min_length):
     hist_tok = torch.full((max_len, N, K), -1, device=dev, dtype=torch.int32)
     hist_prev = torch.zeros(max_len, N, K, device=dev, dtype=torch.int32)
     hist_score = torch.zeros(max_len, N, K, device=dev, dtype=torch.float32)
-    call("cpg_decode_beam_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
-         _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, fc.weight.shape[0], max_len, K, n_best, min_length,
-         START_IDX, EOS_IDX, _p(hist_tok), _p(hist_prev), _p(hist_score), _stream())
+    with ops._prof("beam_fused", 1, T=max_len, B=N, H=H, ndir=K):
+        call("cpg_decode_beam_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
+             _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, fc.weight.shape[0], max_len, K, n_best, min_length,
+             START_IDX, EOS_IDX, _p(hist_tok), _p(hist_prev), _p(hist_score), _stream())
     return hist_tok, hist_prev, hist_score
 
 
 def _cut_at_all_finished(ids, unfinished, max_len, min_length):
     """The reference leaves its loop once every row has finished (model.py:362-363): cut the columns it never made."""
+    global LAST_GREEDY_STEPS
     unf = unfinished.cpu().numpy()
+    # rows live at step i = rows unfinished after step i-1 (all N at step 0): the row-steps an ideal decode evaluates
+    LAST_GREEDY_STEPS = int(ids.shape[0]) + int(unf[:max_len - 1].astype(np.int64).sum())
     steps = max_len
     for i in range(max_len):
         if unf[i] == 0 and (i + 2) >= min_length:  # reference: all finished and len(seqIx) >= min_length
@@ -74,9 +80,10 @@ def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length):
     ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
     ids[:, 0] = START_IDX
     unfinished = torch.zeros(max_len, device=dev, dtype=torch.int32)
-    call("cpg_decode_greedy_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
-         _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, V, max_len, START_IDX, PAD_IDX, EOS_IDX, _p(ids),
-         max_len + 1, _p(unfinished), _stream())
+    with ops._prof("greedy_fused", 1, T=max_len, B=N, H=H, ndir=1):
+        call("cpg_decode_greedy_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
+             _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, V, max_len, START_IDX, PAD_IDX, EOS_IDX, _p(ids),
+             max_len + 1, _p(unfinished), _stream())
     return _cut_at_all_finished(ids, unfinished, max_len, min_length)
 
 
@@ -255,8 +262,10 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
 def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
     """Beam search + hypothesis walk-back, all on device.  Returns numpy (hyps int32 [N,n_best,T+1] padded with -1,
     lengths [N,n_best] incl. the leading <start>, scores [N,n_best])."""
+    global LAST_BEAM_STEPS
     tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length)
     T, N, K = tok.shape
+    LAST_BEAM_STEPS = int((tok[:, :, 0] >= 0).sum().item())   # steps each sentence advanced before its beam was done
     hyps = torch.empty(N, n_best, T + 1, device=tok.device, dtype=torch.int32)
     lens = torch.empty(N, n_best, device=tok.device, dtype=torch.int32)
     sc = torch.empty(N, n_best, device=tok.device, dtype=torch.float32)

@@ -42,7 +42,28 @@ def query(name, *args):
 
 
 _ws_cache = {}
-PROFILE = None  # set to a list by bench.py to collect (name, start_event, end_event, launches, B, H) records
+PROFILE = None  # set to a list by bench.py to collect (family, start_event, end_event, launches, dims) records
+
+
+class _prof:
+    """HIP events on the CURRENT stream around a launch chain, recorded only while bench.py has PROFILE set.
+    family: fwd_step | fwd_persist | bwd_step | wgrad_hh; dims: dict(T=, B=, H=, ndir=)."""
+
+    def __init__(self, family, launches, **dims):
+        self.family, self.launches, self.dims = family, launches, dims
+
+    def __enter__(self):
+        self.ev = None
+        if PROFILE is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+            PROFILE.append((self.family, self.ev[0], self.ev[1], self.launches, self.dims))
+        return False
 
 
 def workspace(nbytes, device, tag=0):
@@ -322,25 +343,20 @@ class GruSeqFn(Function):
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, w_hh, b_hh))
         gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
         _alloc_guard(hs, gates)
-        ev = None
-        if PROFILE is not None:  # bench.py: HIP events on the launch stream around the T fused step launches
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
         groups = row_groups(B)
         if step_rows is None and len(groups) == 1 and persistent_fits(B, H):
-            gru_seq_fwd_persistent(T, B, H, reverse, w_hh_c, b_hh_c, tok, tab_c, rowc_c, dense_c, hs, gates)
+            with _prof("fwd_persist", 1, T=T, B=B, H=H, ndir=1):
+                gru_seq_fwd_persistent(T, B, H, reverse, w_hh_c, b_hh_c, tok, tab_c, rowc_c, dense_c, hs, gates)
         elif len(groups) == 1:
-            call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
-                 _p(hs), _p(gates), 0, B, _p(step_rows), _stream())
+            with _prof("fwd_step", T, T=T, B=B, H=H, ndir=1):
+                call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
+                     _p(dense_c), _p(hs), _p(gates), 0, B, _p(step_rows), _stream())
         else:
             with fork(dev) as f:
                 for gi, (r0, r1) in enumerate(groups):
                     f.run(gi, lambda r0=r0, r1=r1: call(
                         "cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
                         _p(dense_c), _p(hs), _p(gates), r0, r1, _p(step_rows), _stream()))
-        if ev is not None:
-            ev[1].record()
-            PROFILE.append(("gru_step_fwd", ev[0], ev[1], T, B, H))
         ctx.save_for_backward(tok, w_hh_c, hs, gates)
         ctx.step_rows = step_rows
         ctx.dims = (T, B, H, bool(reverse))
@@ -367,8 +383,9 @@ class GruSeqFn(Function):
         groups = row_groups(B)
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # W_hh^T for the split-bf16 backward step kernels
         if len(groups) == 1:
-            call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG), _p(scratch),
-                 _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
+            with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
+                call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
+                     _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
         else:
             with fork(dev) as f:
                 for gi, (r0, r1) in enumerate(groups):
@@ -394,8 +411,9 @@ class GruSeqFn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ws2 = workspace(nb, dev)
-                call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws2), ws2.numel(),
-                     _stream())
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                    call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws2), ws2.numel(),
+                         _stream())
                 ctx.defer[0].grad.add_(dw_hh)
                 ctx.defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
@@ -403,7 +421,8 @@ class GruSeqFn(Function):
                 t.record_stream(side)
             dw_hh = db_hh = None
         else:
-            call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws), ws.numel(), _stream())
+            with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws), ws.numel(), _stream())
         ddense = None
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
@@ -430,20 +449,15 @@ class GruBiSeqFn(Function):
         need_grad = any(t is not None and t.requires_grad for t in (tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r))
         g_f = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
         g_r = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
-        ev = None
-        if PROFILE is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
         if persistent_fits(B, H):
             # two persistent launches back to back on ONE stream (each needs all of its workgroups co-resident)
-            gru_seq_fwd_persistent(T, B, H, False, wf, bf, tok, tf, None, df, hs_f, g_f)
-            gru_seq_fwd_persistent(T, B, H, True, wr, br, tok, tr, None, dr, hs_r, g_r)
+            with _prof("fwd_persist", 2, T=T, B=B, H=H, ndir=1):
+                gru_seq_fwd_persistent(T, B, H, False, wf, bf, tok, tf, None, df, hs_f, g_f)
+                gru_seq_fwd_persistent(T, B, H, True, wr, br, tok, tr, None, dr, hs_r, g_r)
         else:
-            call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr), _p(hs_f),
-                 _p(hs_r), _p(g_f), _p(g_r), _stream())
-        if ev is not None:
-            ev[1].record()
-            PROFILE.append(("gru_bistep_fwd", ev[0], ev[1], T, B, H))
+            with _prof("fwd_step", T, T=T, B=B, H=H, ndir=2):
+                call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr),
+                     _p(hs_f), _p(hs_r), _p(g_f), _p(g_r), _stream())
         ctx.save_for_backward(tok, wf, wr, hs_f, hs_r, g_f, g_r)
         ctx.dims = (T, B, H)
         ctx.V = tab_f.shape[0] if tab_f is not None else 0
@@ -462,8 +476,9 @@ class GruBiSeqFn(Function):
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
-        call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-             _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+        with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
+            call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                 _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []
@@ -471,7 +486,8 @@ class GruBiSeqFn(Function):
             dw = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
             dtab = None
             if ctx.has_tab:
-                call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _stream())
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                    call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _stream())
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
                 dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
                 call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
@@ -524,15 +540,9 @@ class LstmSeqFn(Function):
         cs[slot0].zero_() if c0 is None else cs[slot0].copy_(c0)
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, c0, w_hh, b_hh))
         gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
-        ev = None
-        if PROFILE is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        call("cpg_lstm_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
-             _p(hs), _p(cs), _p(gates), _stream())
-        if ev is not None:
-            ev[1].record()
-            PROFILE.append(("lstm_step_fwd", ev[0], ev[1], T, B, H))
+        with _prof("lstm_fwd_step", T, T=T, B=B, H=H, ndir=1):
+            call("cpg_lstm_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
+                 _p(hs), _p(cs), _p(gates), _stream())
         ctx.save_for_backward(tok, w_hh_c, hs, cs, gates)
         ctx.dims = (T, B, H, bool(reverse))
         ctx.V = tab.shape[0] if tab is not None else 0

@@ -68,10 +68,10 @@ class SyntheticPeptideLoader:
     def idx2sentences(self, batch, print_special_tokens=True):
         return [self.idx2sentence(s, print_special_tokens) for s in batch]
 
-    def ids_to_peptides(self, ids):
-        """idx2sentences(rows, print_special_tokens=False) for an integer array [N,L] (entries < 0 = padding): the decode
-        loops hand over arrays, and a per-token python loop over 10^5..10^6 hypotheses costs more than decoding them.
-        Residues are single letters, so a row is built as bytes 'A C D' in one vectorised pass and trimmed per row."""
+    def ids_to_letters(self, ids):
+        """Integer array [N,L] (entries < 0 = padding) -> (letters uint8 [N,L]: the residues of each row, specials stripped,
+        left-aligned, zero-filled; counts [N]).  Two rows give the same peptide string iff their letter rows are equal, so
+        de-duplication can run on these fixed-width keys and strings are only built for rows that are kept."""
         ids = np.asarray(ids)
         itos = self.TEXT.vocab.itos
         assert all(len(w) == 1 for w in itos[len(SPECIALS):]), 'vectorised form needs one-letter residue tokens'
@@ -80,8 +80,18 @@ class SyntheticPeptideLoader:
             lut[i] = ord(itos[i])
         keep = ids >= len(SPECIALS)
         order = np.argsort(~keep, axis=1, kind='stable')                     # residues first, original order kept
-        letters = np.take_along_axis(np.where(keep, lut[np.clip(ids, 0, len(itos) - 1)], 0), order, 1)
-        n = keep.sum(1)
-        buf = np.full((ids.shape[0], 2 * ids.shape[1]), ord(' '), np.uint8)
+        letters = np.take_along_axis(np.where(keep, lut[np.clip(ids, 0, len(itos) - 1)], 0), order, 1).astype(np.uint8)
+        return letters, keep.sum(1)
+
+    @staticmethod
+    def letters_to_peptides(letters, counts):
+        """'A C D' strings (idx2sentences(rows, print_special_tokens=False)) from ids_to_letters output."""
+        buf = np.full((letters.shape[0], 2 * letters.shape[1]), ord(' '), np.uint8)
         buf[:, 0::2] = letters
-        return [buf[i, :max(2 * k - 1, 0)].tobytes().decode('ascii') for i, k in enumerate(n)]
+        return [buf[i, :max(2 * int(k) - 1, 0)].tobytes().decode('ascii') for i, k in enumerate(counts)]
+
+    def ids_to_peptides(self, ids):
+        """idx2sentences(rows, print_special_tokens=False) for an integer array [N,L] (entries < 0 = padding): the decode
+        loops hand over arrays, and a per-token python loop over 10^5..10^6 hypotheses costs more than decoding them.
+        Residues are single letters, so a row is built as bytes 'A C D' in one vectorised pass and trimmed per row."""
+        return self.letters_to_peptides(*self.ids_to_letters(ids))

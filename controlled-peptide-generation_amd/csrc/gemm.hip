@@ -289,6 +289,24 @@ int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_
     return 0;
 }
 
+// Name (as rocprofv3 prints it, without "void " and the argument list) and split-K factor of the kernel cpg_gemm_tn picks
+// for dW[N,Kd] = dY[Mr,N]^T X[Mr,Kd] with 16-byte aligned operands - for bench.py's roofline object.
+CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n) {
+    const TnPlan p = tn_plan(N, Kd, Mr);
+    TnTile t = p.tile;
+    if (t == TN_AUTO) {
+        if (N <= 32) t = TN_32x128;
+        else if (Kd <= 32) t = TN_128x32;
+        else t = ((long)cdiv(N, 128) * cdiv(Kd, 64) * p.S < 256) ? TN_64x64 : TN_128x64;
+    }
+    const char* tc = t == TN_256x128 ? "256, 128, 32, 4, 2, 1, 512" : t == TN_128x128 ? "128, 128, 32, 2, 2, 1, 256" :
+                     t == TN_128x64 ? "128, 64, 32, 2, 2, 1, 256" : t == TN_64x64 ? "64, 64, 32, 2, 2, 1, 256" :
+                     t == TN_128x32 ? "128, 32, 32, 4, 1, 1, 256" : "32, 128, 32, 1, 4, 1, 256";
+    const bool vec = N % 4 == 0 && Kd % 4 == 0 && p.k_chunk % 4 == 0;
+    return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false>", tc, vec ? "true" : "false");
+}
+CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
+
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
     const TnPlan p = tn_plan(N, Kd, Mr);
     return (size_t)N * Kd * p.S * sizeof(float) + 256;

@@ -376,17 +376,20 @@ static int pick_bm(int B, int ntile_n, const char* knob) {
     return 32;
 }
 
+static int fwd_bm_choice(int rows, int H, int nd) {
+    int bm = pick_bm(rows, cdiv(H, 32), "CPG_GRU_FWD_BM");
+    if (CPG_STEP_FWD_SPLIT != 7 && bm == 64 && !getenv("CPG_GRU_FWD_BM") && (long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024) bm = 32;
+    return bm;
+}
+
 static int gru_fwd_launch(const GruFwdPair& pr, int nd, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
     bool vec = a.H % 4 == 0;
     for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].h_prev) && aligned16(pr.d[d].w_hh);
-    int bm = pick_bm(a.row1 - a.row0, cdiv(a.H, 32), "CPG_GRU_FWD_BM");
     // exact-f32 engine: 32-row tiles (4 resident workgroups per CU) measured 43.5 us vs 46.9 us for 64-row tiles at
     // B=2048,H=512.  Split-bf16 engine: 64-row tiles 37.1 us vs 50.8 us for 32-row tiles (every row tile converts the
     // whole W_hh slab again, and the slab barrier is paid twice as often per MFMA).
-    if (CPG_STEP_FWD_SPLIT != 7 && bm == 64 && !getenv("CPG_GRU_FWD_BM") &&
-        (long)cdiv(a.row1 - a.row0, 32) * cdiv(a.H, 32) * nd >= 1024)
-        bm = 32;
+    const int bm = fwd_bm_choice(a.row1 - a.row0, a.H, nd);
     if (bm == 128) launch_fwd<GF128>(pr, nd, vec, s);
     else if (bm == 64) launch_fwd<GF64>(pr, nd, vec, s);
     else launch_fwd<GF32>(pr, nd, vec, s);
@@ -593,6 +596,50 @@ __global__ void dgi_over_time_vec_kernel(const float* dG, int T, int B, int H, f
     f32x4* dst = reinterpret_cast<f32x4*>(out + (size_t)b * 4 * NC4 + c);
     if (accumulate) s += *dst;
     *dst = s;
+}
+
+// ------------------------------------------------------------------------------------------ launcher introspection
+// Names of the kernels the launchers above would pick, in the form rocprofv3 prints them (without "void " and the argument
+// list): bench.py labels its roofline object with them instead of carrying literals that a tile-policy change would
+// silently desynchronise from the profile.
+template <class TC>
+static int tc_name(char* b, int n) {
+    return snprintf(b, n, "TileCfg<%d, %d, %d, %d, %d, %d, %d>", TC::BM, TC::BN, TC::BK, TC::WM, TC::WN, TC::NSEG, TC::NT);
+}
+
+// kind 0: forward step, 1: backward step.  ndir 1 | 2 (paired biGRU launches).  have_wt: W_hh^T handed to the backward.
+// Returns the length written (0 on a bad kind).
+CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int have_wt, char* buf, int n) {
+    char tc[96];
+    const bool vec = H % 4 == 0;
+    if (kind == 0) {
+        const int bm = fwd_bm_choice(B, H, ndir);
+        if (bm == 128) tc_name<GF128>(tc, sizeof tc);
+        else if (bm == 64) tc_name<GF64>(tc, sizeof tc);
+        else tc_name<GF32>(tc, sizeof tc);
+        return snprintf(buf, n, "gru_step_fwd_kernel<%s, %s>", tc, vec ? "true" : "false");
+    }
+    if (kind == 1) {
+        const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
+        switch (c.tile) {
+            case BT_64x32: tc_name<GB64>(tc, sizeof tc); break;
+            case BT_32x64: tc_name<GB32>(tc, sizeof tc); break;
+            case BT_64x64: tc_name<GB64W>(tc, sizeof tc); break;
+            case BT_128x32: tc_name<GB128>(tc, sizeof tc); break;
+            case BT_128x64: tc_name<GB128W>(tc, sizeof tc); break;
+            case BT_32x32: tc_name<GB32N>(tc, sizeof tc); break;
+        }
+        return snprintf(buf, n, "gru_step_bwd_kernel<%s, %s, %s>", tc, vec ? "true" : "false", c.wt ? "true" : "false");
+    }
+    return 0;
+}
+
+// 1 when the named step kernel runs its product on the split-bf16 engine (six bf16 MFMAs per block), 0: exact-f32 MFMA.
+CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt) {
+    if (kind == 0) return CPG_STEP_FWD_SPLIT == 7;
+    const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
+    if (c.wt) return CPG_STEP_BWD_SPLIT == 7;
+    return CPG_STEP_BWD_SPLIT == 7 && (c.tile == BT_64x64 || c.tile == BT_128x64 || c.tile == BT_32x64);  // XC pairs: BV even
 }
 
 // ------------------------------------------------------------------------------------------ C ABI

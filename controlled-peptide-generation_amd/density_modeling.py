@@ -20,6 +20,7 @@ class RejSampleBase:
     rng = 'numpy'
     device = torch.device('cuda')
     _philox = None
+    _cdf = None
 
     def init_attr_classifiers(self, attr_clfs, clf_targets):
         """attr_clfs: {attr: fitted binary sklearn LogisticRegression (or any object with coef_/intercept_)}."""
@@ -44,13 +45,21 @@ class RejSampleBase:
         probs, _, _ = class_sampler.lr_score_accept(z, coef[i:i + 1], icpt[i:i + 1], tgt[i:i + 1], u)
         return probs[0].cpu().numpy()
 
-    def rejection_sample(self, n_samples, prefix='clfZ', return_device=False):
-        samples_z = self.sample(n_samples, to_cpu=False)
+    def rejection_sample(self, n_samples, prefix='clfZ', return_device=False, shard=(0, 1)):
+        """shard = (rank, world) (device rng only): this call draws rows [rank*n/world, (rank+1)*n/world) of the round's
+        n_samples-row stream - the union over ranks is exactly what one rank would draw alone (counter-based streams)."""
+        rank, world = shard
+        n_local, row0 = n_samples, 0
+        if world > 1:
+            assert self.rng == 'device', "sharded rounds need rng='device' (numpy's global generator cannot be split by rows)"
+            assert n_samples % (4 * world) == 0, 'n_samples must be a multiple of 4*world'
+            n_local, row0 = n_samples // world, rank * (n_samples // world)
+        samples_z = self.sample(n_local, to_cpu=False, _rows=(row0, n_samples))
         if self.rng == 'numpy':
             uniforms = torch.from_numpy(np.random.uniform(size=n_samples)).to(self.device)
         else:
             seed, off = self._next_philox(n_samples)
-            uniforms = ops.rng_uniform((n_samples,), seed, off, self.device, dtype=torch.float64)
+            uniforms = ops.rng_uniform((n_local,), seed, off + row0 // 2, self.device, dtype=torch.float64)  # 2 doubles per counter
         coef, icpt, tgt = self._dev_clf
         probs, accum, acc = class_sampler.lr_score_accept(samples_z, coef, icpt, tgt, uniforms)
         if return_device:
@@ -59,6 +68,9 @@ class RejSampleBase:
         for i, attr in enumerate(self.attr_clfs):
             scores_z['{}_{}={}'.format(prefix, attr, self.clf_targets[attr])] = probs[i].cpu().numpy()
         return samples_z.cpu(), scores_z, acc.cpu().numpy().astype(bool)
+
+    def score_names(self, prefix='clfZ'):
+        return [prefix + '_prob_accum'] + ['{}_{}={}'.format(prefix, a, self.clf_targets[a]) for a in self.attr_clfs]
 
     def _next_philox(self, n):
         if self._philox is None:
@@ -104,7 +116,8 @@ class mogQ(RejSampleBase):
         assert x.dim() == 1, 'expecting  single sample'
         return self.mog.score(x.view(1, -1).cpu().numpy())
 
-    def sample(self, n_samples, to_cpu=True):
+    def sample(self, n_samples, to_cpu=True, _rows=None):
+        """_rows = (row0, n_total): draw rows [row0, row0 + n_samples) of an n_total-row device stream (sharded rounds)."""
         K, D = self._m.shape
         if self.rng == 'numpy':
             rs = np.random.mtrand._rand  # the generator scikit-learn's sample() uses for random_state=None
@@ -113,11 +126,16 @@ class mogQ(RejSampleBase):
             comp = torch.from_numpy(np.repeat(np.arange(K), counts).astype(np.int32)).to(self.device)
             normals = torch.from_numpy(normals).to(self.device)
         else:
-            seed, off = self._next_philox(n_samples)
-            u = ops.rng_uniform((n_samples,), seed, off, self.device)
-            cdf = torch.from_numpy(np.cumsum(self._w)).to(self.device).float()
-            comp = torch.searchsorted(cdf, u).clamp(max=K - 1).to(torch.int32).sort()[0]
-            seed, off = self._next_philox(n_samples * D)
-            normals = ops.rng_normal((n_samples, D), seed, off, self.device).double()
+            row0, n_total = _rows if _rows is not None else (0, n_samples)
+            assert row0 % 4 == 0
+            seed, off = self._next_philox(n_total)
+            u = ops.rng_uniform((n_samples,), seed, off + row0 // 4, self.device)
+            if getattr(self, '_cdf', None) is None:
+                self._cdf = torch.from_numpy(np.cumsum(self._w)).to(self.device).float()
+            # component of each row by inverse CDF (rows are iid: no need for scikit-learn's component-sorted order)
+            comp = torch.searchsorted(self._cdf, u).clamp(max=K - 1).to(torch.int32)
+            Dp = -(-D // 4) * 4   # rows start on a 4-element counter boundary, so any row range of the stream can be drawn alone
+            seed, off = self._next_philox(n_total * Dp)
+            normals = ops.rng_normal((n_samples, Dp), seed, off + row0 * (Dp // 4), self.device)[:, :D].double()
         z = class_sampler.gmm_sample(self._dm, self._dc, comp, normals)
         return z.cpu() if to_cpu else z

@@ -9,7 +9,13 @@ exist (:299-322).  Differences, all documented in DESIGN.md:
   * encodings come from `states_<split>_<iter>.npz` (same field names as the reference's h5: src, z, mu, logvar, label,
     split) or are computed on the fly; modlamp descriptors (H, uH, charge) need modlamp, which is not installed: columns
     are filled when it is importable, skipped otherwise;
-  * under data parallelism every rank runs its own rounds (rank-distinct seeds) and accepted rows are all-gathered.
+  * rounds are ARRAY frames end to end (`sample_round_arrays` / `run_rounds`): z, scores and the stripped residue rows stay
+    numpy / device arrays, de-duplication runs on fixed-width residue keys, and the pandas DataFrame (with the reference's
+    columns) is built once at the end - the reference builds `tuple(z.tolist())` and a string per proposal per round;
+  * multi-GPU (one process per GPU, cpg.dist): every round's proposals are SHARDED by rows across the ranks (counter-based
+    device streams: the union over ranks is the stream one rank would draw alone), every rank decodes its rows, the
+    round's rows are all-gathered (cpg.dist.allgather_rows), and the de-duplication against earlier rounds (:312-314) and
+    the stop rule (:303) then run on the gathered, identical-on-every-rank set.
 """
 import argparse
 import datetime
@@ -115,6 +121,8 @@ def compute_modlamp(df):
 
 
 def get_new_samples(model, dataset, Q, n_samples, sample_mode='beam', decode_accepted_only=False):
+    """Reference-format round (DataFrame per round, c drawn from the prior per 1024-chunk unless decode_accepted_only):
+    kept for RNG-order parity with the reference (`Q.rng = 'numpy'`); the throughput path is sample_round_arrays."""
     import pandas as pd
     samples_z, scores_z, accept_z = Q.rejection_sample(n_samples=n_samples)
     if decode_accepted_only:
@@ -122,10 +130,12 @@ def get_new_samples(model, dataset, Q, n_samples, sample_mode='beam', decode_acc
         samples_z = samples_z[keep]
         scores_z = {k: v[accept_z] for k, v in scores_z.items()}
         accept_z = accept_z[accept_z]
+    if samples_z.shape[0] == 0:   # a round may accept nothing
+        return pd.DataFrame({'peptide': [], 'z': [], 'accept_z': np.zeros(0, bool), **{k: v[:0] for k, v in scores_z.items()}})
     c = torch.zeros(samples_z.shape[0], 2, device=model.device)
     c[:, 1] = 1.0
     samples = decode_from_z(samples_z, model, dataset, sample_mode=sample_mode, c=c if decode_accepted_only else None)
-    return pd.DataFrame({'peptide': samples, 'z': [tuple(z.tolist()) for z in samples_z], 'accept_z': accept_z, **scores_z})
+    return pd.DataFrame({'peptide': samples, 'z': list(samples_z.numpy()), 'accept_z': accept_z, **scores_z})
 
 
 def one_sampling_round(model, dataset, Q, n_samples_per_round, **kw):
@@ -134,23 +144,151 @@ def one_sampling_round(model, dataset, Q, n_samples_per_round, **kw):
     return df
 
 
-def run_rounds(model, dataset, Q, n_samples_per_round, n_samples_acc, max_rounds=1000, **kw):
+# ------------------------------------------------------------------------------------------------ array rounds
+def decode_ids_from_z(z, c, model, sample_mode='beam', beam_size=5, chunk=65536):
+    """Device z [n,Z], c [n,2] -> (ids int16 [n, T+1] with -1 padding: best beam hypothesis / greedy row incl. <start>,
+    decoder row-step evaluations the decode needed).  Decoding is per-z independent, so the chunk size is a
+    memory knob only."""
+    from cpg import decode as cdecode
+    T = model.MAX_SEQ_LEN
+    out = np.full((z.shape[0], T + 1), -1, np.int16)
+    evals = 0
+    was_training = model.training
+    model.eval()
+    try:
+        for i0 in range(0, z.shape[0], chunk):
+            zz, cc = z[i0:i0 + chunk].float().contiguous(), c[i0:i0 + chunk].float().contiguous()
+            if sample_mode == 'beam':
+                hyps, lens, _ = cdecode.decode_beam_arrays(model.decoder, zz, cc, T, beam_size, 3, 1)
+                best = hyps[:, 0, :]
+                w = best.shape[1]
+                out[i0:i0 + zz.shape[0], :w] = np.where(np.arange(w)[None, :] < lens[:, 0:1], best, -1)
+                evals += int(beam_size) * int(cdecode.LAST_BEAM_STEPS)
+            elif sample_mode == 'greedy':
+                ids = cdecode.decode_hard(model.decoder, zz, cc, T).cpu().numpy()
+                out[i0:i0 + zz.shape[0], :ids.shape[1]] = ids
+                evals += int(cdecode.LAST_GREEDY_STEPS)
+            else:
+                raise ValueError('array rounds decode with beam or greedy')
+    finally:
+        model.train(True)  # generate_sentences always leaves the model in train mode (SURVEY F8)
+    return out, evals
+
+
+def sample_round_arrays(model, dataset, Q, n_samples, sample_mode='beam', decode_accepted_only=False, shard=(0, 1)):
+    """One sampling round (reference get_new_samples :195-207) as an array frame; with shard=(rank, world) this rank
+    proposes / scores / decodes its rows of the round only."""
+    z, probs, accum, acc = Q.rejection_sample(n_samples, return_device=True, shard=shard)
+    names = Q.score_names()
+    n_prop = z.shape[0]
+    if decode_accepted_only:
+        keep = torch.nonzero(acc).squeeze(1)
+        z, probs, accum, acc = z[keep], probs[:, keep], accum[keep], acc[keep]
+    T = model.MAX_SEQ_LEN
+    if z.shape[0] == 0:
+        ids, evals = np.full((0, T + 1), -1, np.int16), 0
+    else:
+        c = torch.zeros(z.shape[0], 2, device=z.device)
+        c[:, 1] = 1.0
+        ids, evals = decode_ids_from_z(z, c, model, sample_mode)
+    letters, n_res = dataset.ids_to_letters(ids)
+    frame = {'letters': letters, 'n_res': n_res.astype(np.int32), 'z': z.cpu().numpy(),
+             'accept_z': acc.cpu().numpy().astype(bool), names[0]: accum.cpu().numpy()}
+    for i, nm in enumerate(names[1:]):
+        frame[nm] = probs[i].cpu().numpy()
+    return frame, dict(proposed=n_prop, decoded=int(z.shape[0]), decoder_evals=evals)
+
+
+def gather_frame(frame):
+    """All-gather of a round's rows over the ranks (cpg.dist.allgather_rows: counts first, then padded payload)."""
+    from cpg import dist as cdist
+    import torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1):
+        return frame
+    dev = torch.device('cuda', torch.cuda.current_device()) if tdist.get_backend() == 'nccl' else torch.device('cpu')
+    out = {}
+    for k, v in frame.items():
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        as_u8 = t.dtype == torch.bool
+        g = cdist.allgather_rows((t.to(torch.uint8) if as_u8 else t).to(dev)).cpu().numpy()
+        out[k] = g.astype(bool) if as_u8 else g
+    return out
+
+
+def _keys(letters):
+    return np.ascontiguousarray(letters).view(np.dtype((np.void, letters.shape[1]))).ravel()
+
+
+def dedup_frame(frame, seen):
+    """drop_duplicates within the round (first occurrence kept) and against earlier rounds (reference :312-314), on the
+    stripped residue rows.  seen: void-key array of every row kept so far; returns (frame, new seen)."""
+    keys = _keys(frame['letters'])
+    _, first = np.unique(keys, return_index=True)
+    keep = np.sort(first)
+    if seen is not None and len(seen):
+        keep = keep[~np.isin(keys[keep], seen)]
+    out = {k: v[keep] for k, v in frame.items()}
+    kept = keys[keep]
+    return out, (kept if seen is None or not len(seen) else np.concatenate([seen, kept]))
+
+
+def frames_to_dataframe(frames, dataset):
+    """The reference's sample table (peptide, z, accept_z, clfZ_*, accept) from the kept array frames."""
     import pandas as pd
-    samples = pd.DataFrame(columns=['peptide'])
-    rounds = 0
+    if not frames:
+        return pd.DataFrame(columns=['peptide', 'z', 'accept_z', 'accept'])
+    cat = {k: np.concatenate([f[k] for f in frames], 0) for k in frames[0]}
+    df = pd.DataFrame({'peptide': dataset.letters_to_peptides(cat['letters'], cat['n_res']), 'z': list(cat['z']),
+                       'accept_z': cat['accept_z'], **{k: v for k, v in cat.items() if k not in ('letters', 'n_res', 'z', 'accept_z')}})
+    df = compute_modlamp(df)
+    df['accept'] = df['accept_z']
+    return df
 
-    def finished(df):
-        return len(df) >= n_samples_acc and df['accept'].sum() >= n_samples_acc
 
-    while not finished(samples) and rounds < max_rounds:
-        rounds += 1
-        LOG.info("Round #{}".format(rounds))
-        new = one_sampling_round(model, dataset, Q, n_samples_per_round, **kw)
-        new = new.loc[new.peptide.drop_duplicates().index]
-        new = new[~new['peptide'].isin(samples['peptide'])]
-        samples = pd.concat([samples, new], ignore_index=True, sort=False)
-        LOG.info('Q_xi(z|a) rejection sampling acceptance rate: {}/{}'.format(samples['accept_z'].sum(), len(samples)))
-    return samples
+def run_rounds(model, dataset, Q, n_samples_per_round, n_samples_acc, max_rounds=1000, sample_mode='beam',
+               decode_accepted_only=False, return_stats=False):
+    """Rounds until n_samples_acc distinct accepted peptides exist (reference main loop :299-322).  Array frames when the
+    loader offers `ids_to_letters` and the proposal draws on the device (the multi-GPU form); otherwise the reference-order
+    DataFrame rounds."""
+    from cpg import dist as cdist
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+    rank = tdist.get_rank() if world > 1 else 0
+    arrays = hasattr(dataset, 'ids_to_letters') and sample_mode in ('beam', 'greedy') and (Q.rng == 'device' or world > 1)
+    stats = dict(rounds=0, proposed=0, decoded=0, decoder_evals=0, kept=0, accepted=0)
+    if not arrays:
+        assert world == 1, 'reference-order rounds are single-process'
+        import pandas as pd
+        samples = pd.DataFrame(columns=['peptide', 'accept', 'accept_z'])
+
+        def finished(df):
+            return len(df) >= n_samples_acc and df['accept'].sum() >= n_samples_acc
+        while not finished(samples) and stats['rounds'] < max_rounds:
+            stats['rounds'] += 1
+            LOG.info("Round #{}".format(stats['rounds']))
+            new = one_sampling_round(model, dataset, Q, n_samples_per_round, sample_mode=sample_mode,
+                                     decode_accepted_only=decode_accepted_only)
+            new = new.loc[new.peptide.drop_duplicates().index]
+            new = new[~new['peptide'].isin(samples['peptide'])]
+            samples = pd.concat([samples, new], ignore_index=True, sort=False)
+            LOG.info('Q_xi(z|a) rejection sampling acceptance rate: {}/{}'.format(samples['accept_z'].sum(), len(samples)))
+        stats.update(kept=len(samples), accepted=int(samples['accept_z'].sum()) if len(samples) else 0)
+        return (samples, stats) if return_stats else samples
+    frames, seen = [], None
+    while not (stats['kept'] >= n_samples_acc and stats['accepted'] >= n_samples_acc) and stats['rounds'] < max_rounds:
+        stats['rounds'] += 1
+        LOG.info("Round #{}".format(stats['rounds']))
+        frame, st = sample_round_arrays(model, dataset, Q, n_samples_per_round, sample_mode, decode_accepted_only, (rank, world))
+        frame = gather_frame(frame)            # identical on every rank from here on
+        frame, seen = dedup_frame(frame, seen)
+        frames.append(frame)
+        for k in ('proposed', 'decoded', 'decoder_evals'):
+            stats[k] += st[k] * world if world > 1 else st[k]   # ranks do equal shares (decoded: this rank's count scaled)
+        stats['kept'] += len(frame['accept_z'])
+        stats['accepted'] += int(frame['accept_z'].sum())
+        LOG.info('Q_xi(z|a) rejection sampling acceptance rate: {}/{}'.format(stats['accepted'], stats['kept']))
+    samples = frames_to_dataframe(frames, dataset)
+    return (samples, stats) if return_stats else samples
 
 
 def save_samples(samples, basedir, fn_prefix):
@@ -167,18 +305,25 @@ def save_samples(samples, basedir, fn_prefix):
 
 
 def main(args):
+    from cpg import dist as cdist
     from cpg.synth import SyntheticPeptideLoader
     from models.model import RNN_VAE
-    device = torch.device('cuda')
+    world, rank, local = cdist.init()   # one process per GPU (torch.distributed.run); world 1 = plain run
+    torch.cuda.set_device(cdist.local_device(local))
+    device = torch.device('cuda', cdist.local_device(local))
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed)
     dataset = SyntheticPeptideLoader(cfg.vae.batch_size, cfg.max_seq_len, device, size=cfg.hw.synthetic_size, seed=cfg.seed)
     model = RNN_VAE(n_vocab=dataset.n_vocab, max_seq_len=cfg.max_seq_len, **cfg.model).to(device)
     model.device = device
     ckpt = cfg.vae.chkpt_path.format(cfg.vae.n_iter)
-    if os.path.exists(ckpt):
-        model.load_state_dict(torch.load(ckpt, map_location=device), strict=False)
-        LOG.info('Loaded model from ' + ckpt)
+    # the reference fails hard on a missing / mismatched checkpoint (api.py:91-94 torch.load): sampling from a randomly
+    # initialised decoder would silently write garbage "accepted" peptides
+    if not os.path.exists(ckpt):
+        raise FileNotFoundError('trained model checkpoint {} not found (run main.py --phase 1 first)'.format(ckpt))
+    from api import load_state_dict_checked
+    load_state_dict_checked(model, torch.load(ckpt, map_location=device))
+    LOG.info('Loaded model from ' + ckpt)
     model.eval()
     for k in Q_KWARGS:
         if hasattr(args, 'Q_' + k):
@@ -189,9 +334,12 @@ def main(args):
     z_clfs = {a: build_clfZ(get_encodings_from_states({a: 1}, 'train')[0], get_encodings_from_states({a: 0}, 'train')[0])
               for a in ['amp', 'tox']}
     Q.init_attr_classifiers(z_clfs, clf_targets={'amp': 1, 'tox': 0})
+    if world > 1 or args.device_rng:
+        Q.rng = 'device'   # counter-based streams: rounds shard by rows across the ranks
     samples = run_rounds(model, dataset, Q, args.n_samples_per_round, args.n_samples_acc, sample_mode=args.sample_mode,
                          decode_accepted_only=args.decode_accepted_only)
-    save_samples(samples, cfg.savepath, args.samples_outfn_prefix)
+    if rank == 0:
+        save_samples(samples, cfg.savepath, args.samples_outfn_prefix)
 
 
 if __name__ == "__main__":
@@ -206,6 +354,8 @@ if __name__ == "__main__":
     parser.add_argument('--Q_select_amppos', type=int, default=0)
     parser.add_argument('--sample_mode', default='beam')
     parser.add_argument('--decode_accepted_only', action='store_true', default=False)
+    parser.add_argument('--device_rng', action='store_true', default=False,
+                        help="draw proposals with the on-device counter streams (always on with more than one rank)")
     a = parser.parse_args()
     cfg._override_config(a, cfg)
     cfg._update_cfg()

@@ -127,6 +127,13 @@ CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const f
                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                        float* hs, float* gates, void* sync_scratch, void* stream);
 CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream);
+/* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
+ * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.
+ * kind 0 forward step, 1 backward step; ndir 1 | 2 (paired biGRU launches); have_wt: W_hh^T handed to the backward. */
+CPG_API int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int have_wt, char* buf, int n);
+CPG_API int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt);
+CPG_API int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n);
+CPG_API int cpg_gemm_tn_split(int Mr, int N, int Kd);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,

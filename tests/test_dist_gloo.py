@@ -38,7 +38,8 @@ def _worker(rank, world, port, fn, out):
     try:
         out[rank] = fn(rank, world)
     finally:
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def _run(fn, world=2):
@@ -102,3 +103,59 @@ def _dp_equal(rank, world):
     t = torch.from_numpy(np.concatenate([G[k].reshape(-1) for k in sorted(G)]).astype(np.float64))
     dist.all_reduce(t)
     return (t.numpy() / world), float(terms["mmdrf"]), float(terms["recon"])
+
+
+# ---------------------------------------------------------------------------------------------- CLaSS rounds, sharded
+class _FakeQ:
+    rng = 'device'
+
+
+def _fake_round_factory():
+    """Stands in for the device part of a sampling round (draw + score + decode: GPU kernels, covered by tests/test_gpu_pipeline.py)
+    with a deterministic function of (round, global row): the test is about the sharding / gather / de-duplication / stop-rule
+    logic of sample_pipeline.run_rounds, which must give the same table for 1 and 2 ranks."""
+    state = {"round": 0}
+
+    def fake(model, dataset, Q, n, sample_mode='beam', decode_accepted_only=False, shard=(0, 1)):
+        import numpy as np
+        rank, world = shard
+        rnd = state["round"]
+        state["round"] += 1
+        n_local = n // world
+        rows = np.arange(rank * n_local, (rank + 1) * n_local)
+        rs = np.random.RandomState(1000 + rnd)
+        table = rs.randint(4, 10, size=(n, 6))            # few distinct residue rows -> plenty of duplicates
+        acc_all = rs.rand(n) < 0.3
+        zs = rs.randn(n, 5).astype(np.float32)
+        ids = np.full((n_local, 26), -1, np.int16)
+        ids[:, 0] = 2
+        ids[:, 1:7] = table[rows]
+        ids[:, 7] = 3
+        letters, n_res = dataset.ids_to_letters(ids)
+        frame = {'letters': letters, 'n_res': n_res.astype(np.int32), 'z': zs[rows], 'accept_z': acc_all[rows],
+                 'clfZ_prob_accum': rs.rand(n)[rows]}
+        return frame, dict(proposed=n_local, decoded=n_local, decoder_evals=25 * n_local)
+    return fake
+
+
+def _class_rounds(rank, world):
+    import logging
+    import sample_pipeline as sp
+    from cpg.synth import SyntheticPeptideLoader
+    logging.getLogger('GenerationAPI').setLevel(logging.WARNING)
+    sp.sample_round_arrays = _fake_round_factory()
+    ds = SyntheticPeptideLoader(4, 25, 'cpu', size=8)
+    df, st = sp.run_rounds(None, ds, _FakeQ(), 64, 40, max_rounds=30, return_stats=True)
+    return list(df['peptide']), [bool(a) for a in df['accept']], [z.tolist() for z in df['z']], st
+
+
+def test_class_rounds_sharded_equal_single_rank():
+    """Reference main loop sample_pipeline.py:299-322 under sharding: the union of the ranks' rows, gathered, de-duplicated
+    within the round and against earlier rounds, with the stop rule on the gathered set, is the single-rank table."""
+    two = _run(_class_rounds, world=2)
+    one = _run(_class_rounds, world=1)[0]
+    assert two[0][:3] == two[1][:3]            # identical on every rank
+    assert two[0][:3] == one[:3]
+    pep, acc, _, st = one
+    assert len(set(pep)) == len(pep) and sum(acc) >= 40
+    assert st['rounds'] == two[0][3]['rounds'] and st['kept'] == len(pep)

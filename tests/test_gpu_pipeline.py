@@ -86,6 +86,85 @@ def test_sampling_rounds_and_accepted_only_equivalence(golden):
     assert out['accept'].sum() >= 20 and not out['peptide'].duplicated().any()
 
 
+def _micro_Q_model(golden, seed=0):
+    from cpg.synth import SyntheticPeptideLoader
+    from density_modeling import mogQ
+    gm = golden("model_micro")
+    m = build_model(weights_of(gm))
+    m.eval()
+    D = gm["greedy_z"].shape[1]
+    rs = np.random.RandomState(seed)
+    Q = mogQ.from_params(np.ones(3) / 3, rs.randn(3, D), np.full((3, D), 0.5))
+    Q.init_attr_classifiers({'amp': _clf(rs.randn(1, D), np.zeros(1)), 'tox': _clf(rs.randn(1, D), np.zeros(1))},
+                            clf_targets={'amp': 1, 'tox': 0})
+    Q.rng = 'device'
+    return m, Q, SyntheticPeptideLoader(4, 25, 'cuda', size=16), weights_of(gm)
+
+
+@pytest.mark.parametrize("mode", ["greedy", "beam"])
+def test_array_round_vs_oracle_and_sharding(golden, mode):
+    """One array round: (i) the decoded residue rows equal the numpy oracle's decode of the same z (greedy: oracle.decode.greedy,
+    beam: best hypothesis of oracle.decode.beam_search); (ii) the accept mask equals the oracle's LR scoring; (iii) the rows
+    drawn by ranks 0 and 1 of a 2-way sharded round are exactly the halves of the round one rank draws alone."""
+    import sample_pipeline as sp
+    from oracle import class_sampler as ocs, decode as odec
+    m, Q, ds, P = _micro_Q_model(golden)
+    n = 512
+    Q._philox = [77, 0]
+    frame, st = sp.sample_round_arrays(m, ds, Q, n, sample_mode=mode)
+    assert st['proposed'] == n and st['decoded'] == n and st['decoder_evals'] > 0
+    z = frame['z']
+    c = np.zeros((n, 2), np.float32)
+    c[:, 1] = 1
+    if mode == "greedy":
+        ids = odec.greedy(P, z, c, 25)
+        assert st['decoder_evals'] <= n * 25
+    else:
+        hyps, _ = odec.beam(P, z, c, 25, beam_size=5, n_best=3)
+        L = max(len(h[0]) for h in hyps)
+        ids = np.full((n, L), -1, np.int64)
+        for i, h in enumerate(hyps):
+            ids[i, :len(h[0])] = h[0]
+    ref_letters, ref_n = ds.ids_to_letters(ids)
+    w = min(ref_letters.shape[1], frame['letters'].shape[1])
+    assert np.array_equal(ref_n, frame['n_res'])
+    assert np.array_equal(ref_letters[:, :w], frame['letters'][:, :w])
+    coef, icpt, tgt = (t.cpu().numpy() for t in Q._dev_clf)
+    probs = np.stack([ocs.lr_prob(z, coef[i:i + 1], icpt[i:i + 1], int(tgt[i])) for i in range(coef.shape[0])])
+    np.testing.assert_allclose(frame['clfZ_prob_accum'], probs.prod(0), rtol=1e-9)
+    np.testing.assert_allclose(frame['clfZ_amp=1'], probs[0], rtol=1e-9)
+    # sharded draw: same stream, split by rows
+    halves = []
+    for r in range(2):
+        Q._philox = [77, 0]
+        f, _ = sp.sample_round_arrays(m, ds, Q, n, sample_mode=mode, shard=(r, 2))
+        halves.append(f)
+    for k in frame:
+        assert np.array_equal(np.concatenate([halves[0][k], halves[1][k]], 0), frame[k]), k
+
+
+def test_array_rounds_stop_rule_and_accepted_only(golden):
+    import sample_pipeline as sp
+    m, Q, ds, _ = _micro_Q_model(golden)
+    Q._philox = [5, 0]
+    out, st = sp.run_rounds(m, ds, Q, 256, 30, sample_mode='beam', max_rounds=50, return_stats=True)
+    assert out['accept'].sum() >= 30 and not out['peptide'].duplicated().any()
+    assert st['kept'] == len(out) and st['rounds'] >= 1 and st['proposed'] == st['rounds'] * 256
+    assert {'peptide', 'z', 'accept_z', 'clfZ_prob_accum', 'clfZ_amp=1', 'clfZ_tox=0', 'accept'} <= set(out.columns)
+    # rounds before the last one did not satisfy the stop rule
+    Q._philox = [5, 0]
+    out2, st2 = sp.run_rounds(m, ds, Q, 256, 30, sample_mode='beam', max_rounds=50, decode_accepted_only=True, return_stats=True)
+    assert out2['accept'].all() and st2['decoded'] < st2['proposed']
+    # (the two tables need not hold the same peptides: with every proposal decoded, a rejected duplicate that comes first
+    #  in a round shadows a later accepted one - drop_duplicates keeps the first occurrence, reference :312)
+    assert not out2['peptide'].duplicated().any() and out2['accept'].sum() >= 30
+    # a round that accepts nothing is an empty frame, not an error
+    Q2 = _micro_Q_model(golden)[1]
+    Q2._dev_clf = (Q2._dev_clf[0] * 0, Q2._dev_clf[1] - 50.0, Q2._dev_clf[2])
+    f, s2 = sp.sample_round_arrays(m, ds, Q2, 64, sample_mode='greedy', decode_accepted_only=True)
+    assert len(f['accept_z']) == 0 and s2['decoded'] == 0
+
+
 def test_main_tiny_phase1_plumbing(tmp_path, monkeypatch):
     """python main.py --tiny 1 --phase 1 (BASELINE.json configs[0]): 101 iterations, checkpoints at 25/50/75/100,
     30 generated samples, config + result files."""
