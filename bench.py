@@ -105,7 +105,7 @@ def train_flops_per_seq(T, E, He, Z, V, R, B, gates=3):
     return fwd + 2 * rec + 2 * small + 3 * 2 * B * Z                  # bwd: dh product + dW product (+ Gram MMD)
 
 
-def cpu_baseline(T, V, threads):
+def cpu_baseline(T, V, threads, budget_s=25.0):
     """The torch-CPU restatement of the reference's training step (oracle/torch_ref.py: nn.GRU / F.cross_entropy / autograd /
     Adam exactly as train_vae.py drives them, pinned to the golden vectors in tests/test_oracle_golden.py) timed on the
     host cores at SURVEY 8(d)'s cases.  `value` is the case with this bench's dimensions (config B, batch 2048); the
@@ -129,7 +129,7 @@ def cpu_baseline(T, V, threads):
             t0 = time.perf_counter()
             tr.step(ids, rnd, full_mmd=full)
             ts.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_case > 25.0 and len(ts) >= 2:   # bounded sample: ~25 s of host work per case at most
+            if time.perf_counter() - t_case > budget_s and len(ts) >= 2:   # bounded sample: ~25 s of host work per case at most
                 break
         dt = float(np.median(ts[1:]))
         cases.append({"case": tag, "seq_per_s": round(B / dt, 1), "s_per_step": round(dt, 4), "steps": len(ts) - 1})
@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--cell", default="gru", choices=["gru", "lstm"], help="gru = the reference's cell (parity pinned); lstm = extension")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="host seconds per cpu_baseline case (bounded sample)")
+    ap.add_argument("--class-proposals", type=int, default=1000000, help="z proposals of the CLaSS leg (BASELINE.json configs[3]: 1 M)")
     args = ap.parse_args()
 
     from cpg import dist as cdist
@@ -276,7 +278,7 @@ def main():
         # than on 8 (minutes per step); 32 threads is about the best these shapes get.  Stated in the output.
         threads = min(32, os.cpu_count() or 1)
         note("cpu baseline (torch-CPU restatement)")
-        cases = cpu_baseline(T, V, threads)
+        cases = cpu_baseline(T, V, threads, args.cpu_budget_s)
         line["cpu_baseline"] = {"value": cases[0]["seq_per_s"], "unit": "seq/s", "cores": threads, "kind": "port",
                                 "sample": f"oracle/torch_ref.py (torch-CPU restatement of train_vae.py's step on ATen CPU kernels: the "
                                           f"backend the reference runs on), torch.set_num_threads({threads}); {cases[0]['case']}: median of "
@@ -284,7 +286,7 @@ def main():
                                 "cases": cases}
     if world == 1 and not args.no_class:
         note("CLaSS leg")
-        line["class"] = class_bench(dev, cpu=not args.no_cpu_baseline)
+        line["class"] = class_bench(dev, N=args.class_proposals, cpu=not args.no_cpu_baseline)
     print(json.dumps(line))
 
 

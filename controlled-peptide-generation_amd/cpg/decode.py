@@ -88,8 +88,10 @@ def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length):
 
 
 @torch.no_grad()
-def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1):
-    """ids int64 [N, 1+steps] (column 0 = <start>), steps <= max_len."""
+def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1, uniforms=None):
+    """ids int64 [N, 1+steps] (column 0 = <start>), steps <= max_len.
+    uniforms (categorical only): device f64 [max_len, N], the draw of every step (row t feeds step t)."""
+    rng = getattr(decoder, "rng", None)
     N = z.shape[0]
     dev = z.device
     zc = decoder.init_hidden(z, c).contiguous()
@@ -122,16 +124,17 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
             call("cpg_greedy_select", _p(logits), N, V, _p(finished), _p(ids), max_len + 1, i + 1, _p(tok), PAD_IDX,
                  START_IDX, EOS_IDX, pe, _p(scratch), _p(unfinished), i, _stream())
         elif mode == "categorical":
-            lg = logits
-            if pe:
-                lg = logits.clone()
-                lg[:, [PAD_IDX, START_IDX, EOS_IDX]] = -2 * torch.abs(logits.min())
-            s = torch.distributions.Categorical(logits=lg / temp).sample()
-            s.masked_fill_(finished.bool(), PAD_IDX)
-            finished |= (s == EOS_IDX).to(torch.uint8)
-            ids[:, i + 1] = s
-            tok = s.to(torch.int32)
-            unfinished[i] = (finished == 0).sum()
+            # Categorical(logits/temp).sample() (model.py:308-309) on the device: one uniform per row and step, injected by
+            # the caller (parity tests replay the reference's draws) or drawn from the decoder's counter stream
+            if uniforms is not None:
+                u = uniforms[i]
+            elif rng is not None:
+                seed, off = rng.next(2 * N)
+                u = ops.rng_uniform((N,), seed, off, dev, dtype=torch.float64)
+            else:
+                u = torch.rand(N, dtype=torch.float64).to(dev)
+            call("cpg_categorical_select", _p(logits), N, V, float(temp), _p(u.contiguous()), _p(finished), _p(ids), max_len + 1,
+                 i + 1, _p(tok), PAD_IDX, START_IDX, EOS_IDX, pe, _p(scratch), _p(unfinished), i, _stream())
         else:
             raise ValueError(mode)
         h_a, h_b = h_b, h_a

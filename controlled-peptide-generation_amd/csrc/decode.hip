@@ -1,6 +1,7 @@
 // Vocabulary projection and the per-step token selection of autoregressive decoding.
 //   cpg_vocab_fc_fwd / _bwd   nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab)        models/decoder.py:43-45,83
 //   cpg_greedy_select         argmax + finished masking of RNN_VAE.sample_G         models/model.py:310-311,350-353,362-363
+//   cpg_categorical_select    Categorical(logits/temp).sample() by inverse CDF      models/model.py:308-309,350-353
 //   cpg_beam_select           log_softmax + Beam.advance + hidden-state reorder      models/model.py:314-328,387-404; models/Beam.py:56-105
 #include "cpg_internal.h"
 
@@ -99,6 +100,73 @@ CPG_EXPORT int cpg_greedy_select(const float* logits, int N, int V, uint8_t* fin
     }
     hipLaunchKernelGGL(greedy_select_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, logits, N, V, finished, ids, ld_ids, col,
                        tok_next, pad, eos, neg, pad, start, eos, unfinished, step);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ categorical
+// torch.distributions.Categorical(logits = logits / temp).sample() of RNN_VAE.sample_G (models/model.py:308-309) with the
+// uniform draw of every row passed in: token = first index whose cumulative softmax probability exceeds u (inverse CDF in
+// index order - what ATen's multinomial does with its own uniform).  One thread per row; finished / <eos> / <pad> handling
+// and the unfinished counter as in greedy_select_kernel.
+__global__ void categorical_select_kernel(const float* logits, int N, int V, float inv_temp, const double* u, uint8_t* finished,
+                                          int64_t* ids, int ld_ids, int col, int32_t* tok_next, int pad, int eos,
+                                          const float* neg_src, int m0, int m1, int m2, int* unfinished, int step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int live = 0;
+    if (i < N) {
+        const float* l = logits + (size_t)i * V;
+        const float neg = neg_src ? -2.f * fabsf(neg_src[0]) : 0.f;
+        float mx = -INFINITY;
+        for (int v = 0; v < V; ++v) {
+            float x = l[v];
+            if (neg_src && (v == m0 || v == m1 || v == m2)) x = neg;
+            mx = fmaxf(mx, x * inv_temp);
+        }
+        double tot = 0.0;
+        for (int v = 0; v < V; ++v) {
+            float x = l[v];
+            if (neg_src && (v == m0 || v == m1 || v == m2)) x = neg;
+            tot += (double)expf(x * inv_temp - mx);
+        }
+        const double thr = u[i] * tot;
+        double cum = 0.0;
+        int arg = V - 1;
+        for (int v = 0; v < V; ++v) {
+            float x = l[v];
+            if (neg_src && (v == m0 || v == m1 || v == m2)) x = neg;
+            cum += (double)expf(x * inv_temp - mx);
+            if (thr < cum) {
+                arg = v;
+                break;
+            }
+        }
+        const bool fin = finished[i] != 0;
+        const int t = fin ? pad : arg;
+        if (t == eos) finished[i] = 1;
+        live = (fin || t == eos) ? 0 : 1;
+        ids[(size_t)i * ld_ids + col] = t;
+        tok_next[i] = t;
+    }
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&unfinished[step], __popcll(b));
+}
+
+CPG_EXPORT int cpg_categorical_select(const float* logits, int N, int V, float temp, const double* uniforms, uint8_t* finished,
+                                      int64_t* ids, int ld_ids, int col, int32_t* tok_next, int pad, int start, int eos,
+                                      int prevent_empty, float* scratch, int* unfinished, int step, void* stream) {
+    CPG_CHECK_ARG(logits && uniforms && finished && ids && tok_next && unfinished && N > 0 && V > 0 && temp > 0.f);
+    hipStream_t s = (hipStream_t)stream;
+    const float* neg = nullptr;
+    if (prevent_empty) {
+        CPG_CHECK_ARG(scratch);
+        const int nb = 256;
+        hipLaunchKernelGGL(min_partial_kernel, dim3(nb), dim3(256), 0, s, logits, (size_t)N * V, scratch + 1);
+        hipLaunchKernelGGL(min_final_kernel, dim3(1), dim3(64), 0, s, scratch + 1, nb, scratch);
+        neg = scratch;
+    }
+    hipLaunchKernelGGL(categorical_select_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, logits, N, V, 1.f / temp, uniforms,
+                       finished, ids, ld_ids, col, tok_next, pad, eos, neg, pad, start, eos, unfinished, step);
     CPG_LAUNCH_CHECK();
     return 0;
 }

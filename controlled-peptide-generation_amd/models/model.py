@@ -180,7 +180,8 @@ class RNN_VAE(nn.Module):
         return sentences, z, c.argmax(dim=1)
 
     def sample_G(self, mbsize, z, c, sample_mode='categorical', temp=1.0, gumbel_temp=1.0, prepend_start_idx=True,
-                 prevent_empty=False, min_length=1, beam_size=5, n_best=3):
+                 prevent_empty=False, min_length=1, beam_size=5, n_best=3, uniforms=None):
+        """uniforms (extra, categorical only): f64 [MAX_SEQ_LEN, mbsize] draws to inject (parity tests)."""
         if sample_mode in ('gumbel_soft', 'gumbel_ST'):
             raise NotImplementedError('gumbel_soft / gumbel_ST are placeholders in the reference too (models/model.py:330-336 '
                                       'leaves sampleSoftIx unset and fails)')
@@ -199,5 +200,5 @@ class RNN_VAE(nn.Module):
                                             min_length=min_length)
             return (ids, soft) if prepend_start_idx else (ids[:, 1:], soft[:, 1:])
         ids = cdecode.decode_hard(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
-                                  prevent_empty=prevent_empty, min_length=min_length)
+                                  prevent_empty=prevent_empty, min_length=min_length, uniforms=uniforms)
         return ids if prepend_start_idx else ids[:, 1:]

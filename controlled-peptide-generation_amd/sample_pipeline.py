@@ -69,12 +69,34 @@ def decode_from_z(z, model, dataset, sample_mode='beam', beam_size=5, chunk=1024
     return dataset.idx2sentences(out, print_special_tokens=False)
 
 
+SPLIT_CODE = {'train': 0, 'val': 1, 'test': 2}   # vis/scripts/build_index.py encodes the split as an integer column
+
+
+def _states_path(split, savepath=None, n_iter=None, ext=None):
+    base = os.path.join(savepath or cfg.savepath, 'states_{}_{}'.format(split, n_iter if n_iter is not None else cfg.vae.n_iter))
+    if ext is not None:
+        return base + ext
+    for e in ('.h5', '.npz'):
+        if os.path.exists(base + e):
+            return base + e
+    return base + '.npz'
+
+
 def get_encodings_from_states(query, split, attributes=None, savepath=None, n_iter=None):
+    """mu, logvar (float64 tensors) of the dumped encodings whose labels match `query` ({attr: value}); reads the
+    reference's `states_<split>_<iter>.h5` (when h5py is importable) or this package's npz with the same fields
+    (reference reader: sample_pipeline.py:73-92)."""
     attributes = attributes if attributes is not None else cfg.attributes
-    fn = os.path.join(savepath or cfg.savepath, 'states_{}_{}.npz'.format(split, n_iter if n_iter is not None else cfg.vae.n_iter))
+    fn = _states_path(split, savepath, n_iter)
     assert os.path.exists(fn), 'need dumped states ({}); run dump_encodings first'.format(fn)
-    f = np.load(fn)
-    mu, logvar, lab = torch.from_numpy(f['mu']).double(), torch.from_numpy(f['logvar']).double(), torch.from_numpy(f['label'])
+    if fn.endswith('.h5'):
+        import h5py
+        with h5py.File(fn, 'r') as f:
+            mu_a, lv_a, lab_a = f['mu'][:], f['logvar'][:], f['label'][:]
+    else:
+        f = np.load(fn)
+        mu_a, lv_a, lab_a = f['mu'], f['logvar'], f['label']
+    mu, logvar, lab = torch.from_numpy(mu_a).double(), torch.from_numpy(lv_a).double(), torch.from_numpy(lab_a)
     col = {k: i for i, (k, _) in enumerate(attributes)}
     sel = torch.ones(lab.shape[0], dtype=torch.bool)
     for attr, val in query.items():
@@ -83,18 +105,40 @@ def get_encodings_from_states(query, split, attributes=None, savepath=None, n_it
 
 
 @torch.no_grad()
-def dump_encodings(model, ids, labels, split, savepath, n_iter, batch=4096):
-    """Encode-only pass (mu, logvar, z=mu) -> states_<split>_<iter>.npz (schema of vis/scripts/build_index.py:32-81)."""
-    mus, lvs = [], []
-    for chunk in torch.split(ids, batch):
-        mu, lv = model.forward_encoder(chunk.to(model.device))
-        mus.append(mu.cpu())
-        lvs.append(lv.cpu())
-    mu, lv = torch.cat(mus).numpy(), torch.cat(lvs).numpy()
+def dump_encodings(model, ids, labels, split, savepath, n_iter, batch=4096, fmt=None):
+    """The encode pass of vis/scripts/build_index.py:93-118 - `model(batch.text, q_c='classifier', sample_z='max')`, i.e.
+    encoder + CNN classifier + teacher-forced decoder with z = mu - and its on-disk schema (:32-81): src int [N,T];
+    z, mu, logvar float16 [N,Z]; label int [N,n_attr]; split int [N,1].  Written as gzip-9 h5 when h5py is importable
+    (the reference's format), else as a compressed npz with the same field names."""
+    was_training = model.training
+    model.eval()
+    zs, mus, lvs = [], [], []
+    try:
+        for chunk in torch.split(ids, batch):
+            (mu, lv), (z, c), _ = model(chunk.to(model.device), q_c='classifier', sample_z='max')
+            zs.append(z.cpu()), mus.append(mu.cpu()), lvs.append(lv.cpu())
+    finally:
+        model.train(was_training)
+    f16 = lambda ts: torch.cat(ts).numpy().astype(np.float16)
+    fields = dict(src=ids.cpu().numpy().astype(np.int64), z=f16(zs), mu=f16(mus), logvar=f16(lvs),
+                  label=np.asarray(labels).astype(np.int64).reshape(ids.shape[0], -1),
+                  split=np.full((ids.shape[0], 1), SPLIT_CODE.get(split, 0), np.int64))
     os.makedirs(savepath, exist_ok=True)
-    np.savez_compressed(os.path.join(savepath, 'states_{}_{}.npz'.format(split, n_iter)), src=ids.cpu().numpy(),
-                        z=mu.astype(np.float16), mu=mu.astype(np.float16), logvar=lv.astype(np.float16),
-                        label=np.asarray(labels), split=np.zeros((ids.shape[0], 1), np.int64))
+    if fmt is None:
+        try:
+            import h5py  # noqa: F401
+            fmt = 'h5'
+        except ImportError:
+            fmt = 'npz'
+    fn = _states_path(split, savepath, n_iter, '.' + fmt)
+    if fmt == 'h5':
+        import h5py
+        with h5py.File(fn, 'w') as f:
+            for k, v in fields.items():
+                f.create_dataset(k, data=v, maxshape=(None, None), compression='gzip', compression_opts=9)
+    else:
+        np.savez_compressed(fn, **fields)
+    return fn
 
 
 def build_clfZ(zpos_mu, zneg_mu):

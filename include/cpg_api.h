@@ -176,6 +176,12 @@ CPG_API int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uint8_
 CPG_API int cpg_greedy_select(const float* logits, int N, int V, uint8_t* finished, int64_t* ids, int ld_ids, int col,
                               int32_t* tok_next, int pad, int start, int eos, int prevent_empty, float* scratch,
                               int* unfinished, int step, void* stream);
+/* categorical: tok ~ Categorical(logits = logits/temp) (models/model.py:308-309) by inverse CDF in index order with one
+ * uniform per row PASSED IN (uniforms f64 [N], e.g. from cpg_rng_uniform_f64; parity tests replay the reference's draws);
+ * finished / <eos> / prevent_empty / unfinished[] exactly as cpg_greedy_select. */
+CPG_API int cpg_categorical_select(const float* logits, int N, int V, float temp, const double* uniforms, uint8_t* finished,
+                                   int64_t* ids, int ld_ids, int col, int32_t* tok_next, int pad, int start, int eos,
+                                   int prevent_empty, float* scratch, int* unfinished, int step, void* stream);
 /* Whole greedy loop (model.py:225-385 with decoder.py:86-109) as ONE persistent launch for small decoders: W_hh in
  * registers, hidden state / rowc / token table / fc staged in LDS, only token ids leave the CU.  Requires H <= 128,
  * V <= 32 and cpg_decode_greedy_fused_lds_bytes(H,V,Vt) <= the device's LDS per workgroup (returns -3 otherwise; the

@@ -44,6 +44,33 @@ def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=Fa
     return (ids, np.stack(all_logits, 1)) if return_logits else ids
 
 
+def categorical(P, z, c, max_len, uniforms, temp=1.0, prevent_empty=False, min_length=1):
+    """RNN_VAE.sample_G 'categorical' (models/model.py:308-309,350-353,362-363) with the uniform draw of every (step, row)
+    given: torch.distributions.Categorical(logits=logits/temp).sample() = torch.multinomial(softmax, 1), which picks the first
+    index whose cumulative probability exceeds its uniform.  uniforms [steps, N] float64."""
+    N = z.shape[0]
+    zc = np.concatenate([z, c], 1).astype(F32)
+    h = zc.copy()
+    tok = np.full(N, START, np.int64)
+    finished = np.zeros(N, bool)
+    cols = [tok]
+    for i in range(max_len):
+        logits, h = decoder_step(P, tok, zc, h)
+        if prevent_empty and i == 0:
+            logits[:, [PAD, START, EOS]] = F32(-2.0) * np.abs(logits.min())
+        x = (logits / F32(temp)).astype(F32)
+        p = np.exp((x - x.max(1, keepdims=True)).astype(F32)).astype(np.float64)
+        cum = np.cumsum(p, 1)
+        thr = uniforms[i].astype(np.float64) * cum[:, -1]
+        tok = np.minimum((cum <= thr[:, None]).sum(1), p.shape[1] - 1).astype(np.int64)
+        tok[finished] = PAD
+        finished |= tok == EOS
+        cols.append(tok)
+        if finished.all() and len(cols) >= min_length:
+            break
+    return np.stack(cols, 1)
+
+
 def _log_softmax(x):
     m = x.max(1, keepdims=True)
     return (x - (m + np.log(np.exp(x - m).sum(1, keepdims=True)))).astype(F32)

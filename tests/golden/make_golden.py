@@ -516,3 +516,47 @@ def soft_vectors(name="A", seed=1238, N=48, **kw):
 
 if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "soft":
     soft_vectors("A", 1238, **model_kwargs(z_dim=100, enc_h=80))
+
+
+def categorical_vectors(name="A", seed=1238, N=96, **kw):
+    """RNN_VAE.sample_G 'categorical' (models/model.py:308-309): the reference's draws are captured through torch.multinomial
+    (what Categorical.sample calls) and turned into the uniforms an inverse-CDF sampler needs to reproduce them - the midpoint
+    of the drawn token's cumulative-probability interval - so the ids below are the REFERENCE's ids for replayable draws."""
+    model = build(seed, **kw)
+    with torch.no_grad():
+        model.decoder.fc[1].weight.mul_(4.0)   # spread the logits a little: varied lengths
+        model.decoder.fc[1].bias[3] += 0.5
+    gen = torch.Generator().manual_seed(seed + 21)
+    z = torch.randn(N, model.z_dim, generator=gen)
+    c = torch.zeros(N, 2)
+    c[torch.arange(N), torch.randint(0, 2, (N,), generator=gen)] = 1
+    out = {"w." + k: v.detach().numpy().copy() for k, v in model.state_dict().items() if not k.startswith("classifier")}
+    out.update(z=z.numpy(), c=c.numpy())
+    orig = torch.multinomial
+    for tag, kwargs in (("t1.0", dict(temp=1.0)), ("t0.7", dict(temp=0.7)), ("t1.0_pe", dict(temp=1.0, prevent_empty=True))):
+        rec = []
+
+        def hooked(probs, num, replacement=False, **k2):
+            r = orig(probs, num, replacement, **k2)
+            rec.append((probs.detach().double().numpy().copy(), r.numpy().reshape(-1).copy()))
+            return r
+        torch.multinomial = hooked
+        try:
+            torch.manual_seed(seed + 31)
+            ids, _, _ = model.generate_sentences(N, z, c, sample_mode="categorical", **kwargs)
+        finally:
+            torch.multinomial = orig
+        u = np.zeros((25, N))
+        u[:] = 0.5
+        for t, (p, k) in enumerate(rec):
+            cum = np.cumsum(p, 1) / p.sum(1, keepdims=True)
+            lo = np.where(k > 0, cum[np.arange(N), np.maximum(k - 1, 0)], 0.0)
+            u[t] = 0.5 * (lo + cum[np.arange(N), k])
+        out[tag + ".ids"] = ids.numpy()
+        out[tag + ".u"] = u
+    np.savez_compressed(os.path.join(OUT, f"categorical_{name}.npz"), **out)
+    print(f"categorical_{name}.npz written", {k: v.shape for k, v in out.items() if not k.startswith("w.")})
+
+
+if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "categorical":
+    categorical_vectors("A", 1238, **model_kwargs(z_dim=100, enc_h=80))

@@ -165,6 +165,29 @@ def test_array_rounds_stop_rule_and_accepted_only(golden):
     assert len(f['accept_z']) == 0 and s2['decoded'] == 0
 
 
+@pytest.mark.parametrize("tag,kw", [("t1.0", dict(temp=1.0)), ("t0.7", dict(temp=0.7)), ("t1.0_pe", dict(temp=1.0, prevent_empty=True))])
+def test_categorical_injected_draws_golden(golden, tag, kw):
+    """sample_G 'categorical' on the device (cpg_categorical_select) with the reference's draws injected: ids bit-exact
+    against the reference's own ids (fixture: captured torch.multinomial draws as inverse-CDF uniforms)."""
+    g = golden("categorical_A")
+    m = build_model(weights_of(g))
+    z, c = cu(g["z"]), cu(g["c"])
+    ids, _, _ = m.generate_sentences(z.shape[0], z, c, sample_mode='categorical', uniforms=cu(g[tag + ".u"]), **kw)
+    got, ref = ids.cpu().numpy(), g[tag + ".ids"]
+    assert np.array_equal(got, ref[:, :got.shape[1]]) and (ref[:, got.shape[1]:] == 1).all()
+    # device-stream draws: valid ids, finished rows padded, and the empirical first-token law matches the softmax
+    m.use_device_rng(5)
+    N = 20000
+    zz, cc = cu(np.tile(g["z"][:1], (N, 1))), cu(np.tile(g["c"][:1], (N, 1)))
+    ids2, _, _ = m.generate_sentences(N, zz, cc, sample_mode='categorical')
+    from oracle import decode as odec
+    P = weights_of(g)
+    logits, _ = odec.decoder_step(P, np.full(1, 2), np.concatenate([g["z"][:1], g["c"][:1]], 1), np.concatenate([g["z"][:1], g["c"][:1]], 1))
+    p = np.exp(logits[0] - logits[0].max()); p /= p.sum()
+    freq = np.bincount(ids2[:, 1].cpu().numpy(), minlength=len(p)) / N
+    assert np.abs(freq - p).max() < 0.015
+
+
 def test_main_tiny_phase1_plumbing(tmp_path, monkeypatch):
     """python main.py --tiny 1 --phase 1 (BASELINE.json configs[0]): 101 iterations, checkpoints at 25/50/75/100,
     30 generated samples, config + result files."""
@@ -248,31 +271,84 @@ def test_full_size_properties():
     assert torch.equal(a[:128, :w], b[:, :w])
 
 
+def test_dump_encodings_roundtrip(tmp_path, golden):
+    """Encodings dump: the reference's encode pass model(ids, q_c='classifier', sample_z='max') and its
+    schema, read back through get_encodings_from_states with label queries; values = the reference's mu/logvar in float16."""
+    import importlib
+    import cfg
+    importlib.reload(cfg)
+    import sample_pipeline as sp
+    g, gc = golden("model_A"), golden("classifier_A")
+    m = build_model(weights_of(g))
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights_of(gc).items()}, strict=False)
+    ids = cu(g["ids"])
+    n = ids.shape[0]
+    attrs = cfg.amp.attributes
+    n_attr = len(attrs)
+    labels = np.zeros((n, n_attr), np.int64)
+    labels[::2, 0] = 1
+    fn = sp.dump_encodings(m, ids, labels, 'train', str(tmp_path), 7)
+    assert os.path.exists(fn) and m.training
+    raw = np.load(fn) if fn.endswith('.npz') else None
+    if raw is not None:
+        assert set(raw.files) == {'src', 'z', 'mu', 'logvar', 'label', 'split'}
+        assert raw['mu'].dtype == np.float16 and raw['z'].dtype == np.float16 and raw['src'].shape == (n, 25)
+        assert np.array_equal(raw['z'], raw['mu'])        # sample_z='max'
+    attr0 = attrs[0][0]
+    mu_all, lv_all = sp.get_encodings_from_states({}, 'train', attributes=attrs, savepath=str(tmp_path), n_iter=7)
+    assert mu_all.dtype == torch.float64 and mu_all.shape == (n, g["enc_mu"].shape[1])
+    np.testing.assert_allclose(mu_all.numpy(), g["enc_mu"].astype(np.float16).astype(np.float64), atol=2e-3)
+    np.testing.assert_allclose(lv_all.numpy(), g["enc_logvar"].astype(np.float16).astype(np.float64), atol=2e-3)
+    mu_pos, _ = sp.get_encodings_from_states({attr0: 1}, 'train', attributes=attrs, savepath=str(tmp_path), n_iter=7)
+    assert mu_pos.shape[0] == (n + 1) // 2 and torch.equal(mu_pos, mu_all[::2])
+    importlib.reload(cfg)
+
+
 def test_api_helpers_roundtrip(tmp_path, golden):
-    """api.py helpers: vocab file -> checkpoint load (reference key names) -> encode / greedy reconstruction / interpolation."""
+    """api.py helpers with the reference's signatures: a checkpoint in the REFERENCE's format (its own state-dict keys and
+    tensors, as captured by tests/golden/make_golden.py, classifier included) -> load_trained_model -> the reference's
+    enc_mu; encode / sample / reconstruct / interpolate; run-dir discovery and result lookup."""
     import importlib
     import cfg
     importlib.reload(cfg)
     import api
     import utils
     from cpg.synth import SyntheticPeptideLoader
-    from models.mutils import save_model
-    g = golden("model_A")
-    m = build_model(weights_of(g))
+    g, gc = golden("model_A"), golden("classifier_A")
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in {**weights_of(g), **weights_of(gc)}.items()}
+    sd["decoder.emb.weight"] = sd["word_emb.weight"]          # the reference's state_dict lists the shared table twice
     ds = SyntheticPeptideLoader(4, 25, 'cuda', size=16)
     utils.save_vocab(ds.TEXT.vocab, str(tmp_path / 'vocab.dict'))
-    save_model(m, str(tmp_path / 'model_1.pt'))
+    torch.save(sd, str(tmp_path / 'model_7.pt'))
+    json.dump([{"it": 7, "train_L_vae": 1.5}, {"it": 3, "train_L_vae": 2.5}], open(tmp_path / 'result.json', 'w'))
     vocab = api.Vocab(str(tmp_path / 'vocab.dict'))
     assert vocab.size() == 24 and vocab.to_ix("A C D").shape == (1, 25)
-    m2 = api.load_trained_model(str(tmp_path / 'model_1.pt'), vocab.size())
+    cfg.savepath = str(tmp_path)
+    path, vpath, base = api.get_model_and_vocab_path()       # model_<n_iter>.pt is absent: falls back to the highest
+    assert path.endswith('model_7.pt') and vpath.endswith('vocab.dict')
+    assert api.get_result_for_model(path)["train_L_vae"] == 1.5
+    m2 = api.load_trained_model(path, vocab.size())
     assert not m2.training
-    z, mu, lv = api.encode_sequence(m2, vocab, "A C D E F G")
-    ids = vocab.to_ix("A C D E F G").cuda()
-    mu_ref, _ = m.forward_encoder(ids)
-    assert torch.allclose(mu, mu_ref)
-    out = api.recon_sequence(m2, vocab, "A C D E F G", sample_mode='greedy')
-    assert isinstance(out, str)
-    assert len(api.interpolate_peptides(m2, vocab, "A C D", "W Y V", steps=4, sample_mode='greedy')) == 4
+    with torch.no_grad():
+        mu, lv = m2.forward_encoder(cu(g["ids"]))
+    np.testing.assert_allclose(mu.cpu().numpy(), g["enc_mu"], atol=1e-5)
+    bad = dict(sd)
+    bad.pop("encoder.q_mu.bias")
+    torch.save(bad, str(tmp_path / 'model_8.pt'))
+    with pytest.raises(RuntimeError):
+        api.load_trained_model(str(tmp_path / 'model_8.pt'), vocab.size())
+    z = api.encode_sequence(m2, vocab, "A C D E F G")
+    assert z.shape == (1, 100) and api.encode_sequence(m2, vocab, "A C D E F G", sample_q=3).shape == (3, 100)
+    out = api.recon_sequence(m2, vocab, "A C D E F G", 'max', None, sample_mode='greedy')
+    assert set(out) == {'predictions', 'z', 'c'} and isinstance(out['predictions'][0][0], list)
+    zs, w = api.interpolate_z(z, -z + 0.1, method='tanh', n_samples=3)
+    assert zs.shape == (5, 100) and w[0] == 0.0 and w[-1] == 1.0
+    for method in ('linear', 'tanh', 'slerp'):
+        s = api.interpolate_peptides(m2, vocab, "A C D", "W Y V", dict(interpolation_method=method, interpolation_samples=2),
+                                     dict(sample_mode='beam', beam_size=3, n_best=2))
+        assert len(s['predictions']) == 4 and len(s['predictions'][0]) == 2 and len(s['interpolation']) == 4
+    assert 'hyp' in api.pretty_print_samples(s['predictions'])
+    importlib.reload(cfg)
 
 
 @pytest.mark.parametrize("mode,temp", [("none_softmax", 1.0), ("greedy_softmax", 1.0), ("greedy_softmax", 0.7)])
@@ -329,8 +405,8 @@ def test_bench_json_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "256",
-                          "--hidden", "64", "--no-class", "--cpu-sample-batch", "8"], capture_output=True, text=True,
-                         timeout=600)
+                          "--hidden", "64", "--class-proposals", "8192", "--cpu-budget-s", "1"], capture_output=True, text=True,
+                         timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -342,6 +418,9 @@ def test_bench_json_contract():
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["launches_timed"] == 2 * 25 and r["avg_launch_us"] > 0
+    assert r["launches_timed"] > 0 and r["avg_launch_us"] > 0 and r["kernel"] and "pipe" in r
+    assert all(f["kernel"] and f["ms_per_step"] >= 0 for f in d["extra"]["kernel_families"])
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["unit"] == "seq/s" and c["value"] > 0 and c["cores"] >= 1
+    assert c["kind"] == "port" and c["unit"] == "seq/s" and c["value"] > 0 and c["cores"] >= 1 and len(c["cases"]) == 3
+    k = d["class"]
+    assert k["unit"] == "accepted-samples/s" and k["value"] > 0 and k["roofline"]["kernel"] and k["cpu_baseline"]["value"] > 0

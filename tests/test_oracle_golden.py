@@ -202,3 +202,14 @@ def test_torch_ref_trajectory(golden, name):
         if snap + "word_emb.weight" in g:
             for k, p in m.named_parameters():
                 np.testing.assert_allclose(p.detach().numpy(), g[snap + m.ref_name(k)], atol=3e-5, rtol=0, err_msg=snap + k)  # Adam is ill-conditioned where |g| ~ eps
+
+
+@pytest.mark.parametrize("tag,kw", [("t1.0", dict(temp=1.0)), ("t0.7", dict(temp=0.7)), ("t1.0_pe", dict(temp=1.0, prevent_empty=True))])
+def test_categorical_replay(golden, tag, kw):
+    """sample_G 'categorical' (models/model.py:308-309): with the uniforms that reproduce the reference's captured
+    torch.multinomial draws (tests/golden/make_golden.py:categorical_vectors) the inverse-CDF restatement gives its ids."""
+    g = golden("categorical_A")
+    ids = decode.categorical(weights_of(g), g["z"], g["c"], 25, g[tag + ".u"], **kw)
+    ref = g[tag + ".ids"]
+    assert np.array_equal(ids, ref[:, :ids.shape[1]]) and (ref[:, ids.shape[1]:] == 1).all()
+    assert (ref == 3).any(1).mean() > 0.3   # the fixture does exercise <eos> / finished rows
