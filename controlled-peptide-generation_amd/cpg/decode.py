@@ -58,21 +58,22 @@ def _decode_beam_fused(decoder, zc, tab, rowc, max_len, K, n_best, min_length):
     return hist_tok, hist_prev, hist_score
 
 
-def _cut_at_all_finished(ids, unfinished, max_len, min_length):
-    """The reference leaves its loop once every row has finished (model.py:362-363): cut the columns it never made."""
+def _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx=True):
+    """The reference leaves its loop once every row has finished AND len(seqIx) >= min_length (model.py:362-363): cut the
+    columns it never made.  seqIx holds the <start> column only when prepend_start_idx (model.py:290)."""
     global LAST_GREEDY_STEPS
     unf = unfinished.cpu().numpy()
     # rows live at step i = rows unfinished after step i-1 (all N at step 0): the row-steps an ideal decode evaluates
     LAST_GREEDY_STEPS = int(ids.shape[0]) + int(unf[:max_len - 1].astype(np.int64).sum())
     steps = max_len
     for i in range(max_len):
-        if unf[i] == 0 and (i + 2) >= min_length:  # reference: all finished and len(seqIx) >= min_length
+        if unf[i] == 0 and (i + (2 if prepend_start_idx else 1)) >= min_length:
             steps = i + 1
             break
     return ids[:, :steps + 1]
 
 
-def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length):
+def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length, prepend_start_idx=True):
     N, H = zc.shape
     fc = decoder.fc[1]
     V = fc.weight.shape[0]
@@ -84,11 +85,12 @@ def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length):
         call("cpg_decode_greedy_fused", _p(zc), _p(rowc), _p(tab), tab.shape[0], _p(decoder.rnn.weight_hh_l0),
              _p(decoder.rnn.bias_hh_l0), _p(fc.weight), _p(fc.bias), N, H, V, max_len, START_IDX, PAD_IDX, EOS_IDX, _p(ids),
              max_len + 1, _p(unfinished), _stream())
-    return _cut_at_all_finished(ids, unfinished, max_len, min_length)
+    return _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx)
 
 
 @torch.no_grad()
-def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1, uniforms=None):
+def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1, uniforms=None,
+                prepend_start_idx=True):
     """ids int64 [N, 1+steps] (column 0 = <start>), steps <= max_len.
     uniforms (categorical only): device f64 [max_len, N], the draw of every step (row t feeds step t)."""
     rng = getattr(decoder, "rng", None)
@@ -101,7 +103,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     V = decoder.fc[1].weight.shape[0]
     lstm = getattr(decoder, "cell", "gru") == "lstm"
     if mode == "greedy" and not lstm and not prevent_empty and fused_greedy_fits(zc.shape[1], V, tab.shape[0]):
-        return _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length)
+        return _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length, prepend_start_idx)
     h_a, h_b = zc.clone(), torch.empty_like(zc)
     if lstm:
         c_a, c_b = torch.zeros_like(zc), torch.empty_like(zc)
@@ -138,7 +140,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         else:
             raise ValueError(mode)
         h_a, h_b = h_b, h_a
-    return _cut_at_all_finished(ids, unfinished, max_len, min_length)
+    return _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx)
 
 
 @torch.no_grad()

@@ -150,6 +150,18 @@ def _rowmajor(t):
 
 
 # ----------------------------------------------------------------------------------------------- dense
+def _grad_buf(p):
+    """The existing gradient buffer of a LEAF parameter, or None.  autograd would add a returned gradient into it with one
+    elementwise kernel per parameter (AccumulateGrad: ~30 `add` launches per training step here); the weight-gradient
+    kernels accumulate straight into it instead (their `accumulate` flag) and the Function returns None for that input."""
+    if p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != p.shape:
+        return None
+    return g
+
+
 def linear_raw(x, w, b, out=None, accumulate=False):
     x, ldx = _rowmajor(x)
     w, ldw = _rowmajor(w)
@@ -169,6 +181,7 @@ class LinearFn(Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        ctx.leaves = (w, b)
         return linear_raw(x, w, b)
 
     @staticmethod
@@ -184,12 +197,16 @@ class LinearFn(Function):
             dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
             call("cpg_linear_bwd_input", _p(dy), lddy, _p(ww), ldw, _p(dx), K, M, N, K, 0, _stream())
         if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
-            dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
-            db = torch.empty(N, device=dy.device, dtype=torch.float32) if ctx.has_b else None
+            gw, gb = _grad_buf(ctx.leaves[0]), _grad_buf(ctx.leaves[1])
+            direct = gw is not None and (not ctx.has_b or gb is not None)
+            dw = gw if direct else torch.empty(N, K, device=dy.device, dtype=torch.float32)
+            db = (gb if direct else torch.empty(N, device=dy.device, dtype=torch.float32)) if ctx.has_b else None
             nb = query("cpg_linear_bwd_weight_workspace", M, N, K)
             ws = workspace(nb, dy.device)
-            call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw), K, _p(db), M, N, K, 0, _p(ws), ws.numel(),
+            call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw), K, _p(db), M, N, K, int(direct), _p(ws), ws.numel(),
                  _stream())
+            if direct:
+                dw = db = None
         return dx, dw, db
 
 
@@ -417,6 +434,10 @@ class GruSeqFn(Function):
                 ctx.defer[0].grad.add_(dw_hh)
                 ctx.defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
+            # the accumulation into .grad runs on the side stream: make the stream that called backward() wait for it when
+            # the backward pass ends, so ANY reader of .grad after loss.backward() (clip_grad_norm_, another optimiser, a
+            # test) sees the finished gradient - not only FusedAdamClip, which joins explicitly
+            torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
             for t in (dG, hs, dw_hh, db_hh):
                 t.record_stream(side)
             dw_hh = db_hh = None
@@ -459,6 +480,7 @@ class GruBiSeqFn(Function):
                 call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr),
                      _p(hs_f), _p(hs_r), _p(g_f), _p(g_r), _stream())
         ctx.save_for_backward(tok, wf, wr, hs_f, hs_r, g_f, g_r)
+        ctx.leaves = (w_hh_f, w_hh_r)
         ctx.dims = (T, B, H)
         ctx.V = tab_f.shape[0] if tab_f is not None else 0
         ctx.has_tab, ctx.has_dense = tab_f is not None, dense_f is not None
@@ -483,11 +505,15 @@ class GruBiSeqFn(Function):
         ws = workspace(nb, dev)
         outs = []
         for rev, dG, hs in ((0, dG_f, hs_f), (1, dG_r, hs_r)):
-            dw = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
+            gw = _grad_buf(ctx.leaves[rev]) if ctx.has_tab else None
+            dw = gw if gw is not None else torch.empty(3 * H, H, device=dev, dtype=torch.float32)
             dtab = None
             if ctx.has_tab:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                    call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _stream())
+                    call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, int(gw is not None), _p(ws), ws.numel(),
+                         _stream())
+                if gw is not None:
+                    dw = None
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
                 dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
                 call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
@@ -604,6 +630,7 @@ class VocabFcFn(Function):
         call("cpg_vocab_fc_fwd", _p(hs), _p(keep), float(scale), _p(w_c), _p(b_c), _p(logits), R, H, V, _stream())
         ctx.save_for_backward(hs, keep, w_c)
         ctx.scale = float(scale)
+        ctx.leaves = (w, b)
         return logits
 
     @staticmethod
@@ -614,12 +641,16 @@ class VocabFcFn(Function):
         V = w.shape[0]
         dev = dl.device
         dhs = torch.empty(R, H, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dw = torch.empty(V, H, device=dev, dtype=torch.float32)
-        db = torch.empty(V, device=dev, dtype=torch.float32)
+        gw, gb = _grad_buf(ctx.leaves[0]), _grad_buf(ctx.leaves[1])
+        direct = gw is not None and gb is not None
+        dw = gw if direct else torch.empty(V, H, device=dev, dtype=torch.float32)
+        db = gb if direct else torch.empty(V, device=dev, dtype=torch.float32)
         nb = query("cpg_vocab_fc_bwd_workspace", R, H, V)
         ws = workspace(nb, dev)
-        call("cpg_vocab_fc_bwd", _p(dl), _p(hs), _p(keep), ctx.scale, _p(w), _p(dhs), _p(dw), _p(db), R, H, V, 0, _p(ws),
+        call("cpg_vocab_fc_bwd", _p(dl), _p(hs), _p(keep), ctx.scale, _p(w), _p(dhs), _p(dw), _p(db), R, H, V, int(direct), _p(ws),
              ws.numel(), _stream())
+        if direct:
+            dw = db = None
         return dhs, None, None, dw, db
 
 

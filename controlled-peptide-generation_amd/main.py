@@ -48,7 +48,7 @@ def _seed_everything(rank):
     if not cfg.seed:
         cfg.seed = random.randint(1, 10000)
     log.info('Random seed: {}'.format(cfg.seed))
-    torch.manual_seed(cfg.seed)          # identical initial weights on every rank
+    torch.manual_seed(cfg.seed)          # identical initial weights on every rank (re-seeded per rank after the model is built)
     np.random.seed(cfg.seed + rank)      # host-side draws differ per rank
     random.seed(cfg.seed)
 
@@ -61,6 +61,13 @@ def _build_model(n_vocab, device, rank, world):
         model.load_state_dict(torch.load(cfg.loadpath, map_location=device))
         log.info('Loaded model from ' + cfg.loadpath)
     losses.rf.clear()
+    # the random-feature basis must be THE SAME on every rank (its feature sums are all-reduced): draw it now, from the
+    # common torch seed, then give the per-step host draws (eps, z_prior when device_rng is off) a rank-distinct stream
+    losses._rf_basis(torch.zeros(1, cfg.model.z_dim, device=device), cfg.losses.wae_mmd.rf_dim, False)
+    if world > 1:
+        if cfg.losses.wae_mmd.rf_resample:
+            raise NotImplementedError('rf_resample redraws the basis per call from rank-local streams: not data-parallel exact')
+        torch.manual_seed(cfg.seed + 104729 * rank)
     if cfg.hw.device_rng:
         model.use_device_rng(cfg.seed + 7919 * rank)
         losses.set_prior_sampler(lambda z: model._randn(z.shape[0], z.shape[1]))

@@ -134,6 +134,8 @@ class RNN_VAE(nn.Module):
         return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep)
 
     def forward_classifier(self, inputs):
+        """Token inputs run the inference-only HIP path (no autograd tape: with q_c='classifier' the reference would let
+        gradients reach word_emb through c; it never trains that way - SURVEY F11 - and neither path is trained here)."""
         if inputs.dim() == 2:
             return self.classifier.forward_tokens(inputs, self.word_emb.weight)
         else:
@@ -200,5 +202,6 @@ class RNN_VAE(nn.Module):
                                             min_length=min_length)
             return (ids, soft) if prepend_start_idx else (ids[:, 1:], soft[:, 1:])
         ids = cdecode.decode_hard(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
-                                  prevent_empty=prevent_empty, min_length=min_length, uniforms=uniforms)
+                                  prevent_empty=prevent_empty, min_length=min_length, uniforms=uniforms,
+                                  prepend_start_idx=prepend_start_idx)
         return ids if prepend_start_idx else ids[:, 1:]

@@ -27,6 +27,10 @@ def make_optimizer(cfgv, model, reduce_fn=None, world=1):
 def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
     """One full iteration.  Returns a dict of device scalars (no host sync)."""
     beta = utils.anneal(cfgv.beta, it)
+    if cfgv.z_regu_loss == 'mmd' and trainer.world > 1:
+        # the full-kernel MMD couples every pair of rows of the GLOBAL batch; ranks only hold their shard, so its gradient
+        # would not equal the single-device one (the logged-only value under 'mmdrf' / 'kl' stays rank-local, SURVEY 8e)
+        raise NotImplementedError("z_regu_loss='mmd' is not data-parallel exact; use 'mmdrf' (the default) with world > 1")
     # the trainer consumes the logits only through recon_dec (pad targets ignored): the decoder may skip dead rows
     ragged_before = model.decoder.ragged
     model.decoder.ragged = bool(cfg.hw.ragged_decoder)
