@@ -60,27 +60,30 @@ def family_roofline(family, dims, avg_us, launches):
     from cpg import lib
     T, B, H, nd = dims["T"], dims["B"], dims["H"], dims["ndir"]
     L = lib().dll
+    bf16 = L.cpg_get_compute_mode() == 1
     if family == "fwd_persist":
-        kernel, split, flops = "gru_seq_fwd_persist_kernel", True, T * 2.0 * B * H * 3 * H
+        kernel, split, flops = "gru_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 3 * H
     elif family == "fwd_step":
-        kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), bool(L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0))
+        kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0)
         flops = nd * 2.0 * B * H * 3 * H
     elif family == "bwd_step":
-        kernel, split = _cname("cpg_gru_step_kernel_name", 1, B, H, nd, 1), bool(L.cpg_gru_step_kernel_is_split(1, B, H, nd, 1))
+        kernel, split = _cname("cpg_gru_step_kernel_name", 1, B, H, nd, 1), L.cpg_gru_step_kernel_is_split(1, B, H, nd, 1)
         flops = nd * 2.0 * B * 3 * H * H
     elif family == "wgrad_hh":
-        kernel, split, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), True, 2.0 * 3 * H * H * T * B
+        kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), 2.0 * 3 * H * H * T * B
+        split = 2 if kernel.endswith(", 1>") else 1
     else:
         return None
     ach = flops / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
-    peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    peak = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_SPLIT_TFLOPS, 2: PEAK_BF16_MFMA_TFLOPS}[int(split)]
     r = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
          "frac": round(ach / peak, 4), "traffic": pmc_traffic(kernel), "avg_launch_us": round(avg_us, 2),
          "launches_timed": launches, "flops_per_launch": flops,
-         "pipe": ("bf16 MFMA, 6 x v_mfma_f32_16x16x32_bf16 on 3-way split operands per f32-grade block product: peak = 2500/6"
-                  if split else "exact f32 MFMA (v_mfma_f32_16x16x4_f32): peak = 157.3"),
+         "pipe": {1: "bf16 MFMA, 6 x v_mfma_f32_16x16x32_bf16 on 3-way split operands per f32-grade block product: peak = 2500/6",
+                  0: "exact f32 MFMA (v_mfma_f32_16x16x4_f32): peak = 157.3",
+                  2: "bf16 MFMA, one v_mfma_f32_16x16x32_bf16 per block on bf16-rounded operands: peak = 2500"}[int(split)],
          "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
-    if split:
+    if int(split) == 1:
         r["executed_bf16_tflops"] = round(6 * ach, 1)
         r["executed_frac_of_bf16_peak"] = round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4)
     return r
@@ -151,6 +154,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=25)
     ap.add_argument("--enc-layers", type=int, default=1, help="encoder biGRU layers (BASELINE.json configs[4] uses 2; the decoder stays 1 layer as in the reference)")
     ap.add_argument("--cell", default="gru", choices=["gru", "lstm"], help="gru = the reference's cell (parity pinned); lstm = extension")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = f32-grade products (the parity path, the headline line); bf16 = bf16 recurrent products "
+                         "(cfg.hw.dtype='bf16': one bf16 MFMA per block, f32 accumulate / storage / master weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="host seconds per cpu_baseline case (bounded sample)")
@@ -172,6 +178,7 @@ def main():
     from models.model import RNN_VAE
     import train_vae as tv
 
+    ops.set_compute_mode(args.dtype)
     T, V, B, Hh = args.seq_len, 24, args.batch, args.hidden
     Z, E, R = Hh - 2, 150, 500
     torch.manual_seed(1238)
@@ -262,14 +269,16 @@ def main():
     line = {
         "metric": "peptide-seq/s per WAE training step", "value": round(seq_per_s, 1), "unit": "seq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"WAE train step ({cfg_tag}): biGRU encoder h={Hh} {args.enc_layers} layer, z={Z}, GRU decoder "
                                f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; "
                                + ("GRU cell = the reference's cell, parity pinned (the reference has no LSTM; --cell lstm runs "
                                   "the LSTM extension)" if args.cell == "gru" else
                                   "LSTM cell (extension, torch.nn.LSTM semantics; parity unpinned against the GRU-only reference)")
-                               + ", f32 storage; recurrent products on the MFMA units in f32-grade forms (exact-f32 MFMA, or six bf16 MFMAs on 3-way "
-                                 "split operands)",
+                               + (", f32 storage; recurrent products on the MFMA units in f32-grade forms (exact-f32 MFMA, or six bf16 MFMAs on 3-way "
+                                  "split operands)" if args.dtype == "f32" else
+                                  ", bf16 compute mode: recurrent products with bf16-rounded operands, one bf16 MFMA per block, f32 accumulation, "
+                                  "f32 storage and master weights (NOT the parity path: agreement figures in profiles/)"),
                    "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
         "roofline": roofline, "extra": extra,
     }

@@ -201,6 +201,9 @@ hw = _bunchify(dict(
     world_size=1,         # data-parallel ranks (set by the launcher from WORLD_SIZE)
     synthetic_data=True,  # random-vocab peptide batches (the reference's curated CSVs are not reproducible)
     synthetic_size=20000,
+    dtype='f32',          # 'f32': f32-grade recurrent products (the parity path) | 'bf16': bf16 recurrent products - operands
+                          # rounded to bf16, one bf16 MFMA per block, f32 accumulation / storage / master weights
+                          # (BASELINE.json configs[1]/[4]); --hw.dtype bf16
     ragged_decoder=False,  # training only: decoder rows leave the recurrence once their remaining targets are <pad>.
                            # Exact (tests/test_gpu_parity.py) but OFF: at batch 2048 a step launch is one round of workgroups,
                            # i.e. latency-bound - dropping 40 % of them left its duration unchanged

@@ -41,6 +41,17 @@ def query(name, *args):
     return getattr(lib().dll, name)(*args)
 
 
+def set_compute_mode(mode):
+    """'f32' (default; f32-grade recurrent products: the parity path) or 'bf16' (BASELINE.json configs[1]/[4]: the recurrent
+    products - forward / backward step products and dW_hh - round their operands to bf16 and issue one bf16 MFMA per block,
+    f32 accumulation, f32 storage and master weights).  Process-wide (cpg_set_compute_mode)."""
+    call("cpg_set_compute_mode", {'f32': 0, 'bf16': 1}[mode])
+
+
+def get_compute_mode():
+    return 'bf16' if query("cpg_get_compute_mode") == 1 else 'f32'
+
+
 _ws_cache = {}
 PROFILE = None  # set to a list by bench.py to collect (family, start_event, end_event, launches, dims) records
 

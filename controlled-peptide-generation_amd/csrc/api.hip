@@ -14,6 +14,21 @@ void cpg_set_error(const char* fmt, ...) {
 CPG_EXPORT const char* cpg_last_error(void) { return g_err; }
 CPG_EXPORT int cpg_version(void) { return 100; }  // 0.1.0
 
+// Compute mode of the recurrent products (forward / backward step products and dW_hh = dG^T h): 0 = f32-grade (default:
+// exact-f32 MFMA or six bf16 MFMAs on 3-way split operands), 1 = bf16 (operands rounded to bf16 when staged, ONE bf16 MFMA
+// per block, f32 accumulation; BASELINE.json configs[1]/[4] "bf16").  Process-wide, read at launch time.
+static int g_compute_mode = 0;
+int cpg_compute_mode_get() { return g_compute_mode; }
+CPG_EXPORT int cpg_set_compute_mode(int mode) {
+    if (mode != 0 && mode != 1) {
+        cpg_set_error("cpg_set_compute_mode: mode %d (0 = f32-grade, 1 = bf16 recurrent products)", mode);
+        return -2;
+    }
+    g_compute_mode = mode;
+    return 0;
+}
+CPG_EXPORT int cpg_get_compute_mode(void) { return g_compute_mode; }
+
 // Number of visible gfx950 devices (0 on a host without a GPU).  The Python host refuses to run without one.
 CPG_EXPORT int cpg_device_count(void) {
     int n = 0;

@@ -19,3 +19,6 @@ size_t cpg_colsum_workspace(int M, int N);
 // lstm=1: 4H identity-mapped columns
 int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                         float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+// 0 = f32-grade products, 1 = bf16 recurrent products (cpg_set_compute_mode, api.hip)
+int cpg_compute_mode_get();

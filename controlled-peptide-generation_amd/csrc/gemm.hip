@@ -25,14 +25,16 @@ struct GemmArgs {
     size_t slab_stride; // floats between slabs (0 when not split)
 };
 
-template <class TC, bool A_KC, bool B_KC>
+// PREC: 7 = f32-grade, 1 = bf16 compute mode (cpg_set_compute_mode(1)); only the transposed-use (dW = dY^T X) products run on
+// the plane engine, everything else is the exact-f32 MFMA whatever PREC says
+template <class TC, bool A_KC, bool B_KC, int PREC>
 constexpr int gemm_split() {
-    return (!A_KC && !B_KC) ? CPG_TN_PRODUCT_SPLIT : 0;
+    return (!A_KC && !B_KC && CPG_TN_PRODUCT_SPLIT == 7) ? PREC : 0;
 }
-template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
-using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, B_KC>()>;
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC = 7>
+using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, B_KC, PREC>()>;
 
-template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS>
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC>
 __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     // transposed-operand products (dW = dY^T X: the 80 GFLOP dW_hh product) run on split bf16 operands, see gemm_core.h
-    GemmLoop<TC, A_KC, B_KC, VEC, MASKS>::run(a, b, K, acc);
+    GemmLoop<TC, A_KC, B_KC, VEC, MASKS, PREC>::run(a, b, K, acc);
     float* C = g.C + (size_t)bz * g.slab_stride;
     const bool plain = g.k_chunk == 0;
 #pragma unroll
@@ -111,31 +113,41 @@ __global__ void colsum_final_kernel(const float* part, int chunks, int N, float*
     out[n] = accumulate ? out[n] + s : s;
 }
 
-template <class TC, bool A_KC, bool B_KC>
-static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
+template <class TC, bool A_KC, bool B_KC, int PREC>
+static int launch_tc_p(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
     dim3 grid(cdiv(g.N, TC::BN), cdiv(g.M, TC::BM), zdim);
-    const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false>::smem_bytes();
+    const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false, PREC>::smem_bytes();
     const bool masks = g.a_mask || g.b_mask;
     if (smem > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in once per instantiation
         static bool done = false;
         if (!done) {
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, true, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, true, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, false, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             done = true;
         }
     }
     if (vec && masks)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true>), grid, dim3(TC::NT), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true, PREC>), grid, dim3(TC::NT), smem, s, g);
     else if (vec)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false>), grid, dim3(TC::NT), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false, PREC>), grid, dim3(TC::NT), smem, s, g);
     else if (masks)
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, true>), grid, dim3(TC::NT), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, true, PREC>), grid, dim3(TC::NT), smem, s, g);
     else
-        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, false>), grid, dim3(TC::NT), smem, s, g);
+        hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, false, false, PREC>), grid, dim3(TC::NT), smem, s, g);
     CPG_LAUNCH_CHECK();
     return 0;
+}
+
+// bf16 compute mode covers the big recurrent weight-gradient product only (the 256x128 tile: dW_hh); the small nn.Linear
+// weight gradients stay f32-grade
+template <class TC, bool A_KC, bool B_KC>
+static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
+    if constexpr (!A_KC && !B_KC && TC::NT == 512) {
+        if (cpg_compute_mode_get() == 1) return launch_tc_p<TC, A_KC, B_KC, 1>(g, zdim, vec, s);
+    }
+    return launch_tc_p<TC, A_KC, B_KC, 7>(g, zdim, vec, s);
 }
 
 using T128x64 = TileCfg<128, 64, 32, 2, 2, 1>;
@@ -303,7 +315,8 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n) 
                      t == TN_128x64 ? "128, 64, 32, 2, 2, 1, 256" : t == TN_64x64 ? "64, 64, 32, 2, 2, 1, 256" :
                      t == TN_128x32 ? "128, 32, 32, 4, 1, 1, 256" : "32, 128, 32, 1, 4, 1, 256";
     const bool vec = N % 4 == 0 && Kd % 4 == 0 && p.k_chunk % 4 == 0;
-    return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false>", tc, vec ? "true" : "false");
+    return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false, %d>", tc, vec ? "true" : "false",
+                    (t == TN_256x128 && cpg_compute_mode_get() == 1) ? 1 : 7);
 }
 CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
 

@@ -181,21 +181,26 @@ struct MainLoop {
     // lane/slot mapping) over a contiguous subtile - instead of four ds_read_b32 per plane from a [k-pair][x] image, which
     // at two waves per SIMD ran the LDS at a fraction of its rate and bounded the dW_hh product.
     // Slot i of lane group q contracts k = 4q + i (i < 4) / 16 + 4q + (i - 4): any bijection works when A and B agree.
-    static constexpr bool TRX = SPLIT == 7 && !A_KC && !B_KC;
+    static constexpr bool TRX = SPLIT != 0 && !A_KC && !B_KC;
+    // SPLIT = 1 ("bf16 compute mode", cfg.hw.dtype = 'bf16'): the same plane engine with ONE plane - operands rounded to
+    // bf16 (round to nearest even) when the slab is stored, one MFMA per block, f32 accumulation.  NOT f32-grade: its own
+    // tests state agreement thresholds instead of the 1e-4 bars.
+    static constexpr int NP = SPLIT == 7 ? 3 : 1;
     static constexpr int TRW = 264;  // words per subtile: 32 rows x 8 words + 8 pad (consecutive subtiles on distinct banks)
     static constexpr int APL = A_KC ? BM * KCW : (TRX ? (BM / 16) * TRW : (BK / 2) * SXA);
     static constexpr int BPL = B_KC ? BN * KCW : (TRX ? (BN / 16) * TRW : (BK / 2) * SXB);
-    static constexpr int ASZ7 = 3 * APL, BSZ7 = 3 * BPL;
-    static_assert(SPLIT == 0 || SPLIT == 7, "0: exact f32, 7: bf16 split at LDS-store time");
-    static_assert(SPLIT != 7 || BK == 32, "split products are written for 32-deep slabs");
-    static_assert(SPLIT != 7 || TRX || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
+    static constexpr int ASZ7 = NP * APL, BSZ7 = NP * BPL;
+    static_assert(SPLIT == 0 || SPLIT == 7 || SPLIT == 1,
+                  "0: exact f32; 7: f32-grade, three bf16 planes split at LDS-store time, six MFMAs; 1: bf16 compute mode, one plane, one MFMA");
+    static_assert(SPLIT == 0 || BK == 32, "plane products are written for 32-deep slabs");
+    static_assert(SPLIT == 0 || TRX || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
     static constexpr size_t smem_bytes() {
-        return SPLIT == 7 ? (size_t)2 * (ASZ7 + BSZ7) * 4 : (size_t)2 * (ASZ + BSZ) * sizeof(float);
+        return SPLIT != 0 ? (size_t)2 * (ASZ7 + BSZ7) * 4 : (size_t)2 * (ASZ + BSZ) * sizeof(float);
     }
     // staging vector i of this thread -> (k row inside the slab, column quad) for an XC operand X columns wide
     template <int BX>
     __device__ static __forceinline__ void xc_index(int i, int& kk, int& xq) {
-        if (SPLIT == 7 && !TRX) {
+        if (SPLIT != 0 && !TRX) {
             const int u = threadIdx.x + (i >> 1) * TC::NT;
             xq = u % (BX / 4);
             kk = 2 * (u / (BX / 4)) + (i & 1);
@@ -344,7 +349,15 @@ struct MainLoop {
         }
     }
 
-    // ---- SPLIT == 7: split at LDS-store time -------------------------------------------------------------------------
+    // ---- SPLIT != 0: split / round at LDS-store time ------------------------------------------------------------------
+    __device__ static __forceinline__ void split_pair(float lo, float hi, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+        if (NP == 3) {
+            split3_pair(lo, hi, w0, w1, w2);
+        } else {
+            w0 = cvt_pk_bf16(lo, hi);
+            w1 = w2 = 0u;
+        }
+    }
     template <bool KC, int BX, int NV, int PLW, int SX>
     __device__ static __forceinline__ void sstore7_op(uint32_t* dst, const float4 (&r)[NV]) {
         const int tid = threadIdx.x;
@@ -353,24 +366,28 @@ struct MainLoop {
             for (int i = 0; i < NV; ++i) {
                 const int v = tid + i * TC::NT, row = v / (BK / 4), kq = v % (BK / 4);
                 uint32_t a0, a1, a2, b0, b1, b2;
-                split3_pair(r[i].x, r[i].y, a0, a1, a2);
-                split3_pair(r[i].z, r[i].w, b0, b1, b2);
+                split_pair(r[i].x, r[i].y, a0, a1, a2);
+                split_pair(r[i].z, r[i].w, b0, b1, b2);
                 uint32_t* q = dst + row * KCW + 2 * kq;
                 *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
-                *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
+                if (NP == 3) {
+                    *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
+                }
             }
         } else if (TRX) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int v = tid + i * TC::NT, kk = v / (BX / 4), xq = v % (BX / 4);
                 uint32_t a0, a1, a2, b0, b1, b2;
-                split3_pair(r[i].x, r[i].y, a0, a1, a2);
-                split3_pair(r[i].z, r[i].w, b0, b1, b2);
+                split_pair(r[i].x, r[i].y, a0, a1, a2);
+                split_pair(r[i].z, r[i].w, b0, b1, b2);
                 uint32_t* q = dst + (xq >> 2) * TRW + kk * 8 + (xq & 3) * 2;
                 *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
-                *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
-                *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
+                if (NP == 3) {
+                    *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
+                }
             }
         } else {
 #pragma unroll
@@ -378,14 +395,16 @@ struct MainLoop {
                 const int u = tid + j * TC::NT, xq = u % (BX / 4), p = u / (BX / 4);
                 const float4 e = r[2 * j], o = r[2 * j + 1];
                 uint32_t w0[4], w1[4], w2[4];
-                split3_pair(e.x, o.x, w0[0], w1[0], w2[0]);
-                split3_pair(e.y, o.y, w0[1], w1[1], w2[1]);
-                split3_pair(e.z, o.z, w0[2], w1[2], w2[2]);
-                split3_pair(e.w, o.w, w0[3], w1[3], w2[3]);
+                split_pair(e.x, o.x, w0[0], w1[0], w2[0]);
+                split_pair(e.y, o.y, w0[1], w1[1], w2[1]);
+                split_pair(e.z, o.z, w0[2], w1[2], w2[2]);
+                split_pair(e.w, o.w, w0[3], w1[3], w2[3]);
                 uint32_t* q = dst + p * SX + 4 * xq;
                 *reinterpret_cast<uint4*>(q) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
-                *reinterpret_cast<uint4*>(q + PLW) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
-                *reinterpret_cast<uint4*>(q + 2 * PLW) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+                if (NP == 3) {
+                    *reinterpret_cast<uint4*>(q + PLW) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+                    *reinterpret_cast<uint4*>(q + 2 * PLW) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+                }
             }
         }
     }
@@ -438,7 +457,7 @@ struct MainLoop {
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NP; ++pl) {
                     if (CPG_ABLATE & 2) fb[g][pl] = __builtin_bit_cast(cpg_bf16x8, acc[0][n0 + g]);
                     else fb[g][pl] = read7<B_KC, BPL, SXB>(Bc, pl, wn * TC::WTN + (n0 + g) * 16 + l15, lq);
                 }
@@ -446,7 +465,7 @@ struct MainLoop {
             for (int mi = 0; mi < TC::MI; ++mi) {
                 cpg_bf16x8 fa[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
+                for (int pl = 0; pl < NP; ++pl) {
                     if (CPG_ABLATE & 2) fa[pl] = __builtin_bit_cast(cpg_bf16x8, acc[mi][0]);
                     else fa[pl] = read7<A_KC, APL, SXA>(Ac, pl, wm * TC::WTM + mi * 16 + l15, lq);
                 }
@@ -460,11 +479,13 @@ struct MainLoop {
                         acc[mi][n0 + g] = c + u * w + u1 * w1 + u2 * w2;
                         continue;
                     }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[g][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][1], c, 0, 0, 0);
+                    if (NP == 3) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[g][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][1], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][0], c, 0, 0, 0);
                     acc[mi][n0 + g] = c;
                 }
@@ -614,7 +635,7 @@ struct MainLoop {
     // The two LDS buffers are addressed with compile-time offsets from the __shared__ symbol itself (2x unrolled slab
     // loop): runtime-selected buffer pointers degrade to flat_* accesses whose waits also drain the global prefetch.
     __device__ static __forceinline__ void run(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI]) {
-        if (SPLIT == 7) {
+        if (SPLIT != 0) {
             run7(a, b, K, acc);
             return;
         }

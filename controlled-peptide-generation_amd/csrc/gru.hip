@@ -49,10 +49,11 @@ struct GruFwdPair {
 #ifndef CPG_STEP_FWD_SPLIT
 #define CPG_STEP_FWD_SPLIT 7
 #endif
-template <class TC, bool VEC>
-using FwdLoop = MainLoop<TC, true, true, VEC, VEC, false, (CPG_STEP_FWD_SPLIT == 7 && TC::BK == 32) ? 7 : 0>;
+// PREC: 7 = f32-grade (three planes, six MFMAs), 1 = bf16 compute mode (one plane, one MFMA; cpg_set_compute_mode(1))
+template <class TC, bool VEC, int PREC = 7>
+using FwdLoop = MainLoop<TC, true, true, VEC, VEC, false, (CPG_STEP_FWD_SPLIT == 7 && TC::BK == 32) ? PREC : 0>;
 
-template <class TC, bool VEC>
+template <class TC, bool VEC, int PREC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    FwdLoop<TC, VEC>::run(a, b, H, acc);
+    FwdLoop<TC, VEC, PREC>::run(a, b, H, acc);
 #if !CPG_FWD_PREFETCH
     fetch();
 #endif
@@ -174,11 +175,11 @@ struct GruBwdPair {
 #ifndef CPG_STEP_BWD_SPLIT
 #define CPG_STEP_BWD_SPLIT 7
 #endif
-template <class TC, bool VEC, bool WT>
+template <class TC, bool VEC, bool WT, int PREC = 7>
 using BwdLoop = MainLoop<TC, true, WT, VEC, VEC, false,
-                         (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && (WT || TC::BV % 2 == 0)) ? 7 : 0>;
+                         (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && (WT || TC::BV % 2 == 0)) ? PREC : 0>;
 
-template <class TC, bool VEC, bool WT>
+template <class TC, bool VEC, bool WT, int PREC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     if (g.dG_next) {
         OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
         OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
-        BwdLoop<TC, VEC, WT>::run(a, b, 3 * H, acc);
+        BwdLoop<TC, VEC, WT, PREC>::run(a, b, 3 * H, acc);
     }
 #pragma unroll
     for (int ni = 0; ni < TC::NI; ++ni) {
@@ -324,42 +325,55 @@ using GB64W = TileCfg<64, 64, 32, 2, 2, 1>;    // wider N tile: 4 MFMAs per k-st
 using GB128W = TileCfg<128, 64, 32, 2, 2, 1>;
 using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
-template <class TC>
-static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
+template <class TC, int PREC>
+static void launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = FwdLoop<TC, true>::smem_bytes();
+    const size_t smem = FwdLoop<TC, true, PREC>::smem_bytes();
     if (smem > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per instantiation
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, true, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, false, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             done = true;
         }
     }
     if (vec)
-        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
+        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true, PREC>), grid, dim3(256), smem, s, pr);
     else
-        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false>), grid, dim3(256), smem, s, pr);
+        hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false, PREC>), grid, dim3(256), smem, s, pr);
+}
+
+template <class TC>
+static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
+    if (cpg_compute_mode_get() == 1) launch_fwd_p<TC, 1>(pr, nd, vec, s);
+    else launch_fwd_p<TC, 7>(pr, nd, vec, s);
+}
+
+template <class TC, bool WT, int PREC>
+static void launch_bwd_p(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
+    const GruBwdArgs& a = pr.d[0];
+    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
+    const size_t smem = BwdLoop<TC, true, WT, PREC>::smem_bytes();
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true, WT, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false, WT, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done = true;
+        }
+    }
+    if (vec)
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true, WT, PREC>), grid, dim3(256), smem, s, pr);
+    else
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false, WT, PREC>), grid, dim3(256), smem, s, pr);
 }
 
 template <class TC, bool WT>
 static void launch_bwd(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
-    const GruBwdArgs& a = pr.d[0];
-    dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = BwdLoop<TC, true, WT>::smem_bytes();
-    if (smem > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false, WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done = true;
-        }
-    }
-    if (vec)
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true, WT>), grid, dim3(256), smem, s, pr);
-    else
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false, WT>), grid, dim3(256), smem, s, pr);
+    // bf16 compute mode exists on the W_hh^T (both operands K-contiguous) path only
+    if (WT && cpg_compute_mode_get() == 1) launch_bwd_p<TC, WT, WT ? 1 : 7>(pr, nd, vec, s);
+    else launch_bwd_p<TC, WT, 7>(pr, nd, vec, s);
 }
 
 // pick the row-tile height so that the launch has at least ~256 workgroups when the problem allows it
@@ -420,7 +434,8 @@ static BwdChoice gru_bwd_choice(int rows, int H, int nd, bool have_wt) {
     // W_hh^T: 64x32 52.9, 32x32 52.9, 32x64 65.3, 64x64 68.0, 128x32 73.7, 128x64 93.5.  The launch is bound by its fixed
     // prologue / epilogue traffic and slab-loop latency, not by the matrix pipe (PMC: MFMA busy 16 %), so the cheaper
     // product does not pay for the extra staging conversions: the split path runs only when CPG_GRU_BWD_TILE asks for it.
-    if (!have_wt || wide || bmk || !t || (exact && atoi(exact))) {
+    const bool bf16 = cpg_compute_mode_get() == 1 && have_wt && !wide && !bmk && !(exact && atoi(exact));
+    if (!bf16 && (!have_wt || wide || bmk || !t || (exact && atoi(exact)))) {
         const int bm = pick_bm(rows, cdiv(H, 32), "CPG_GRU_BWD_BM");
         // 32x32 tiles (>= 1024 workgroups) measured 51.4 us vs 53.7 us for 64x32 at B=2048,H=512; wider tiles lose badly (77 / 116 us)
         const bool small = !wide && !bmk && (long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024;
@@ -617,7 +632,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
         if (bm == 128) tc_name<GF128>(tc, sizeof tc);
         else if (bm == 64) tc_name<GF64>(tc, sizeof tc);
         else tc_name<GF32>(tc, sizeof tc);
-        return snprintf(buf, n, "gru_step_fwd_kernel<%s, %s>", tc, vec ? "true" : "false");
+        return snprintf(buf, n, "gru_step_fwd_kernel<%s, %s, %d>", tc, vec ? "true" : "false", cpg_compute_mode_get() == 1 ? 1 : 7);
     }
     if (kind == 1) {
         const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
@@ -629,16 +644,18 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
             case BT_128x64: tc_name<GB128W>(tc, sizeof tc); break;
             case BT_32x32: tc_name<GB32N>(tc, sizeof tc); break;
         }
-        return snprintf(buf, n, "gru_step_bwd_kernel<%s, %s, %s>", tc, vec ? "true" : "false", c.wt ? "true" : "false");
+        return snprintf(buf, n, "gru_step_bwd_kernel<%s, %s, %s, %d>", tc, vec ? "true" : "false", c.wt ? "true" : "false",
+                        (c.wt && cpg_compute_mode_get() == 1) ? 1 : 7);
     }
     return 0;
 }
 
 // 1 when the named step kernel runs its product on the split-bf16 engine (six bf16 MFMAs per block), 0: exact-f32 MFMA.
+// (2: one bf16 MFMA per block - the bf16 compute mode)
 CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt) {
-    if (kind == 0) return CPG_STEP_FWD_SPLIT == 7;
+    if (kind == 0) return CPG_STEP_FWD_SPLIT == 7 ? (cpg_compute_mode_get() == 1 ? 2 : 1) : 0;
     const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
-    if (c.wt) return CPG_STEP_BWD_SPLIT == 7;
+    if (c.wt) return CPG_STEP_BWD_SPLIT == 7 ? (cpg_compute_mode_get() == 1 ? 2 : 1) : 0;
     return CPG_STEP_BWD_SPLIT == 7 && (c.tile == BT_64x64 || c.tile == BT_128x64 || c.tile == BT_32x64);  // XC pairs: BV even
 }
 

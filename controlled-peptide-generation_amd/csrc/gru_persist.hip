@@ -114,21 +114,31 @@ __device__ __forceinline__ float lane_xor1(float x) {
 
 // Row-layout tile (lane -> row l>>2, 4 columns) -> three bf16 planes in the exchange slot: even lanes collect their odd
 // neighbour's four columns and store 8 columns = 16 bytes per plane, write-through.
+template <int NP>
 __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffer_rsrc_t rx, int voff, unsigned plane_bytes,
                                              unsigned slot_off, bool ok, int lane) {
     const float n0 = lane_xor1(v[0]), n1 = lane_xor1(v[1]), n2 = lane_xor1(v[2]), n3 = lane_xor1(v[3]);
     if ((lane & 1) == 0 && ok) {
         uint32_t w0[4], w1[4], w2[4];
-        split3_pair(v[0], v[1], w0[0], w1[0], w2[0]);
-        split3_pair(v[2], v[3], w0[1], w1[1], w2[1]);
-        split3_pair(n0, n1, w0[2], w1[2], w2[2]);
-        split3_pair(n2, n3, w0[3], w1[3], w2[3]);
+        if (NP == 3) {
+            split3_pair(v[0], v[1], w0[0], w1[0], w2[0]);
+            split3_pair(v[2], v[3], w0[1], w1[1], w2[1]);
+            split3_pair(n0, n1, w0[2], w1[2], w2[2]);
+            split3_pair(n2, n3, w0[3], w1[3], w2[3]);
+        } else {  // bf16 compute mode: one plane, operands rounded to nearest even
+            w0[0] = cvt_pk_bf16(v[0], v[1]); w0[1] = cvt_pk_bf16(v[2], v[3]);
+            w0[2] = cvt_pk_bf16(n0, n1); w0[3] = cvt_pk_bf16(n2, n3);
+        }
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w0[1], w0[2], w0[3]}, rx, voff, slot_off, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, slot_off + plane_bytes, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, slot_off + 2 * plane_bytes, 16);
+        if (NP == 3) {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, slot_off + plane_bytes, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, slot_off + 2 * plane_bytes, 16);
+        }
     }
 }
 
+// NP: planes of the split - 3 = f32-grade (six MFMAs per block), 1 = bf16 compute mode (cpg_set_compute_mode(1))
+template <int NP>
 __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t psm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -139,17 +149,20 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     const int NCT = H / P_CT, KB = H / 32;
     const int PLW = P_NC * S;
     uint32_t* const planes = psm;
-    float* const tb = reinterpret_cast<float*>(psm + 3 * PLW) + wave * (16 * P_TBW);
+    float* const tb = reinterpret_cast<float*>(psm + NP * PLW) + wave * (16 * P_TBW);
 
     // ---- W_hh slice -> three bf16 planes in LDS, once per sequence: plane[c = gate*16 + u][k pair]
     for (int idx = tid; idx < P_NC * (H / 2); idx += P_WAVES * 64) {
         const int c = idx / (H / 2), kp = idx - c * (H / 2);
         const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c >> 4) * H + j0 + (c & 15))) * H + 2 * kp);
-        uint32_t w0, w1, w2;
-        split3_pair(v.x, v.y, w0, w1, w2);
+        uint32_t w0, w1 = 0, w2 = 0;
+        if (NP == 3) split3_pair(v.x, v.y, w0, w1, w2);
+        else w0 = cvt_pk_bf16(v.x, v.y);
         planes[c * S + kp] = w0;
-        planes[PLW + c * S + kp] = w1;
-        planes[2 * PLW + c * S + kp] = w2;
+        if (NP == 3) {
+            planes[PLW + c * S + kp] = w1;
+            planes[2 * PLW + c * S + kp] = w2;
+        }
     }
     __syncthreads();
 
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         // h0 enters the exchange like any step's output: slot 0, arrival #1
         const int row = row0 + 16 * mi + srow;
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.hs + slot0 + (size_t)min(row, B - 1) * H + j0 + 4 * scq);
-        publish_rows(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
+        publish_rows<NP>(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -264,41 +277,43 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
             for (int q = 0; q < 3; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 buf[P_DEPTH][P_MI][3];  // register ring: the loads of k-block kb + P_DEPTH - 1 are in flight while kb is multiplied
-        auto load = [&](u32x4 (&b)[P_MI][3], int kb) {
+        u32x4 buf[P_DEPTH][P_MI][NP];  // register ring: the loads of k-block kb + P_DEPTH - 1 are in flight while kb is multiplied
+        auto load = [&](u32x4 (&b)[P_MI][NP], int kb) {
 #pragma unroll
             for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     b[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes,
                                                                       CPG_PERSIST_ACQUIRE ? 0 : 16);
         };
-        auto compute = [&](const u32x4 (&buf)[P_MI][3], int kb) {
-            cpg_bf16x8 fb[3][3];
+        auto compute = [&](const u32x4 (&buf)[P_MI][NP], int kb) {
+            cpg_bf16x8 fb[3][NP];
 #pragma unroll
             for (int q = 0; q < 3; ++q)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     fb[q][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + q * 16 * S + kb * 16);
 #pragma unroll
             for (int mi = 0; mi < P_MI; ++mi) {
                 const cpg_bf16x8 fa0 = __builtin_bit_cast(cpg_bf16x8, buf[mi][0]);
-                const cpg_bf16x8 fa1 = __builtin_bit_cast(cpg_bf16x8, buf[mi][1]);
-                const cpg_bf16x8 fa2 = __builtin_bit_cast(cpg_bf16x8, buf[mi][2]);
+                const cpg_bf16x8 fa1 = __builtin_bit_cast(cpg_bf16x8, buf[mi][NP == 3 ? 1 : 0]);
+                const cpg_bf16x8 fa2 = __builtin_bit_cast(cpg_bf16x8, buf[mi][NP == 3 ? 2 : 0]);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     f32x4 c = acc[mi][q];
                     if (CPG_PERSIST_ABLATE & 4) {
                         acc[mi][q] = c + __builtin_bit_cast(f32x4, fa0) * __builtin_bit_cast(f32x4, fb[q][0]) +
-                                     __builtin_bit_cast(f32x4, fa1) * __builtin_bit_cast(f32x4, fb[q][1]) +
-                                     __builtin_bit_cast(f32x4, fa2) * __builtin_bit_cast(f32x4, fb[q][2]);
+                                     __builtin_bit_cast(f32x4, fa1) * __builtin_bit_cast(f32x4, fb[q][NP == 3 ? 1 : 0]) +
+                                     __builtin_bit_cast(f32x4, fa2) * __builtin_bit_cast(f32x4, fb[q][NP - 1]);
                         continue;
                     }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa2, fb[q][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][1], c, 0, 0, 0);
+                    if (NP == 3) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa2, fb[q][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][NP - 1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][NP == 3 ? 1 : 0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][NP == 3 ? 1 : 0], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][0], c, 0, 0, 0);
                     acc[mi][q] = c;
                 }
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             hrow[mi] = acc_to_rows(tb, hprev[mi], lane);
             const int row = row0 + 16 * mi + srow;
             if (p + 1 < T)
-                publish_rows(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
+                publish_rows<NP>(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
                              out_off + (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,7 +373,7 @@ int plane_stride_words(int H) {
     return s;
 }
 
-size_t fwd_lds_bytes(int H) { return ((size_t)3 * P_NC * plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
+size_t fwd_lds_bytes(int H, int np = 3) { return ((size_t)np * P_NC * plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
 
 int device_cus() {
     static int cus = -1;
@@ -416,13 +431,16 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(nrt, P_WAVES);
     a.S = plane_stride_words(H);
-    const size_t smem = fwd_lds_bytes(H);
     static bool attr = false;
     if (!attr) {
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(gru_seq_fwd_persist_kernel, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), smem, s, a);
+    if (cpg_compute_mode_get() == 1)
+        hipLaunchKernelGGL(gru_seq_fwd_persist_kernel<1>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), fwd_lds_bytes(H, 1), s, a);
+    else
+        hipLaunchKernelGGL(gru_seq_fwd_persist_kernel<3>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), fwd_lds_bytes(H, 3), s, a);
     CPG_LAUNCH_CHECK();
     return 0;
 }

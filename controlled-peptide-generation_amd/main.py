@@ -54,6 +54,8 @@ def _seed_everything(rank):
 
 
 def _build_model(n_vocab, device, rank, world):
+    from cpg import ops
+    ops.set_compute_mode(cfg.hw.dtype)
     model = RNN_VAE(n_vocab=n_vocab, max_seq_len=cfg.max_seq_len, **cfg.model).to(device)
     model.device = device
     log.info(model)

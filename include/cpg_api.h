@@ -64,6 +64,12 @@ CPG_API int cpg_colsum_f32(const float* X, int ld, int M, int N, float* out, int
 CPG_API int cpg_matmul_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K,
                           int accumulate, void* stream);
 
+/* Compute mode of the recurrent products (step products and dW_hh): 0 = f32-grade (default, the parity path), 1 = bf16
+ * (BASELINE.json configs[1]/[4]: operands rounded to bf16 when staged, one bf16 MFMA per block, f32 accumulation, f32
+ * storage and f32 master weights).  Process-wide; read by the launchers at call time. */
+CPG_API int cpg_set_compute_mode(int mode);
+CPG_API int cpg_get_compute_mode(void);
+
 /* ---- GRU (torch.nn.GRU as used at models/encoder.py:25-30,42 and models/decoder.py:40-41,77,98) ---------------------
  * Gate row order r,z,n.  The input-side pre-activation of step t, row b is the SUM of the non-null sources
  *     tab[tok[t,b], :]   token table  emb @ W_ih[:, :E]^T + b_ih           ([V,3H]; tok int32 [T,B])
