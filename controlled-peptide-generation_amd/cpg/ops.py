@@ -318,9 +318,9 @@ def persistent_fits(B, H):
     return bool(query("cpg_gru_persistent_fits", int(B), int(H)))
 
 
-def _persist_sync_scratch(B, H, dev):
-    nb = query("cpg_gru_persistent_scratch_bytes", B, H)
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, H)
+def _persist_sync_scratch(T, B, H, dev):
+    nb = query("cpg_gru_persistent_scratch_bytes", T, B, H)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, H, T)
     sc = _persist_scratch.get(key)
     if sc is None:
         sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word
@@ -328,14 +328,14 @@ def _persist_sync_scratch(B, H, dev):
 
 
 def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, gates):
-    sc = _persist_sync_scratch(B, H, hs.device)
+    sc = _persist_sync_scratch(T, B, H, hs.device)
     call("cpg_gru_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
          _p(hs), _p(gates), _p(sc), _stream())
 
 
 def check_persistent():
     """Raise if any in-kernel wait of a persistent launch has timed out since start-up (synchronises the streams used)."""
-    for (_, _, B, _H), sc in _persist_scratch.items():
+    for (_, _, B, _H, _T), sc in _persist_scratch.items():
         if query("cpg_gru_persistent_status", B, _p(sc), _stream()) != 0:
             raise CpgError("persistent GRU kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
                            "set CPG_GRU_PERSIST=0 to use the per-step kernels")

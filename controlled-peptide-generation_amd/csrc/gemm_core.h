@@ -445,6 +445,7 @@ struct MainLoop {
     // re-read once per group).  NG = 1 at 128 registers per wave; NG = 2 for the 512-thread workgroups (256 registers per
     // wave), which halves the LDS fragment traffic of the wide tiles (the XC image costs four ds_read_b32 per plane).
     static constexpr int NG = (TC::NT == 512 && TC::NI % 2 == 0) ? 2 : 1;
+    static constexpr int MG = (TC::MI % 2 == 0) ? 2 : 1;   // row blocks walked together (independent accumulators)
     template <bool STORE>
     __device__ static __forceinline__ void slab7(const OpA& a, const OpB& b, const uint32_t* Ac, const uint32_t* Bc, uint32_t* An,
                                                  uint32_t* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
@@ -462,33 +463,34 @@ struct MainLoop {
                     else fb[g][pl] = read7<B_KC, BPL, SXB>(Bc, pl, wn * TC::WTN + (n0 + g) * 16 + l15, lq);
                 }
 #pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi) {
-                cpg_bf16x8 fa[3];
+            for (int m0 = 0; m0 < TC::MI; m0 += MG) {
+                cpg_bf16x8 fa[MG][3];
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-                    if (CPG_ABLATE & 2) fa[pl] = __builtin_bit_cast(cpg_bf16x8, acc[mi][0]);
-                    else fa[pl] = read7<A_KC, APL, SXA>(Ac, pl, wm * TC::WTM + mi * 16 + l15, lq);
-                }
+                for (int m = 0; m < MG; ++m)
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    f32x4 c = acc[mi][n0 + g];
-                    if (CPG_ABLATE & 8) {
-                        const f32x4 u = __builtin_bit_cast(f32x4, fa[0]), w = __builtin_bit_cast(f32x4, fb[g][0]);
-                        const f32x4 u1 = __builtin_bit_cast(f32x4, fa[1]), w1 = __builtin_bit_cast(f32x4, fb[g][1]);
-                        const f32x4 u2 = __builtin_bit_cast(f32x4, fa[2]), w2 = __builtin_bit_cast(f32x4, fb[g][2]);
-                        acc[mi][n0 + g] = c + u * w + u1 * w1 + u2 * w2;
-                        continue;
+                    for (int pl = 0; pl < NP; ++pl) {
+                        if (CPG_ABLATE & 2) fa[m][pl] = __builtin_bit_cast(cpg_bf16x8, acc[m0 + m][0]);
+                        else fa[m][pl] = read7<A_KC, APL, SXA>(Ac, pl, wm * TC::WTM + (m0 + m) * 16 + l15, lq);
                     }
-                    if (NP == 3) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[2], fb[g][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1], fb[g][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][1], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[g][0], c, 0, 0, 0);
-                    acc[mi][n0 + g] = c;
+                if (CPG_ABLATE & 8) {
+#pragma unroll
+                    for (int m = 0; m < MG; ++m)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[m0 + m][n0 + g] += __builtin_bit_cast(f32x4, fa[m][0]) * __builtin_bit_cast(f32x4, fb[g][0]);
+                    continue;
                 }
+                // The six products of a block go into ONE accumulator in a fixed order (the result depends on it); a
+                // dependent MFMA issues only when its predecessor has left the pipe (8 passes for 16x16x32 against a 4-pass
+                // issue slot), so the MG x NG independent blocks are walked term by term - same sums, no dependency stalls.
+                constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = (NP == 3 ? 0 : 5); t < 6; ++t)
+#pragma unroll
+                    for (int m = 0; m < MG; ++m)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[m0 + m][n0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][TA[t]], fb[g][TB[t]], acc[m0 + m][n0 + g], 0, 0, 0);
             }
         }
         if (STORE && !(CPG_ABLATE & 1)) sstore7(a, b, An, Bn, st);

@@ -32,13 +32,37 @@
 #ifndef CPG_PERSIST_ACQUIRE
 #define CPG_PERSIST_ACQUIRE 0
 #endif
+#ifndef CPG_PERSIST_PLAIN_LOADS
+#define CPG_PERSIST_PLAIN_LOADS 1   // 1: exchange slots are never reused inside a launch and are read with plain (L1/L2-allocating) loads
+#endif
 // Diagnostic builds only (results wrong by construction): 1 no waits, 2 A operand loaded once per step, 4 no MFMAs,
 // 8 no cell transcendental math, 16 no gate stores, 32 no publish drain (vmcnt) before the arrival
 #ifndef CPG_PERSIST_ABLATE
 #define CPG_PERSIST_ABLATE 0
 #endif
 
+#ifndef CPG_PERSIST_FAST_CELL
+#define CPG_PERSIST_FAST_CELL 0
+#endif
+
 namespace {
+
+// cell nonlinearities: the accurate library forms (as the per-step kernels) or hardware exp / rcp based ones (~2-3 ulp)
+__device__ __forceinline__ float p_sigmoid(float x) {
+#if CPG_PERSIST_FAST_CELL
+    return __frcp_rn(1.0f + __expf(-x));
+#else
+    return sigmoidf_(x);
+#endif
+}
+__device__ __forceinline__ float p_tanh(float x) {
+#if CPG_PERSIST_FAST_CELL
+    const float e = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - e) * __frcp_rn(1.0f + e), x);
+#else
+    return tanhf(x);
+#endif
+}
 
 constexpr int P_CT = 16;          // hidden units per workgroup
 #ifndef CPG_PERSIST_WAVES
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     const int srow = lane >> 2, scq = lane & 3;  // row-layout coordinates after acc_to_rows
 
     const unsigned plane_bytes = (unsigned)((size_t)B * H * 2), kb_bytes = (unsigned)B * 64u;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xch, 6 * plane_bytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xch, (unsigned)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3u * plane_bytes);
     bool dead = false;
 
     // per-lane constants of the epilogue: row of accumulator element (mi, reg), clamped for the loads
@@ -242,7 +266,13 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 
     for (int p = 0; p < T; ++p) {
         const int tt = a.reverse ? T - 1 - p : p;
-        const unsigned in_off = (unsigned)(p & 1) * 3u * plane_bytes, out_off = (unsigned)((p + 1) & 1) * 3u * plane_bytes;
+        // Exchange slot of step p's input / output.  One slot PER STEP (never reused inside the launch): an address is written
+        // once, write-through, and first read only after its row tile's arrival counter says every producer is done - so no
+        // cache anywhere can hold a stale copy of it, and the loads may be plain ones that allocate in L2: of the 32 column-
+        // tile workgroups that read the same planes all but the first hit the XCD's L2.  (sc1 loads of a two-slot ring were
+        // served at the fabric rate: 197 MB per step, 25 us - the bound of that form.)
+        const unsigned in_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p : (p & 1)) * 3u * plane_bytes;
+        const unsigned out_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p + 1 : ((p + 1) & 1)) * 3u * plane_bytes;
 
         // input-side pre-activations of this step: independent of the recurrence, fetched before the wait
         float gi[P_MI][4][3];
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     b[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes,
-                                                                      CPG_PERSIST_ACQUIRE ? 0 : 16);
+                                                                      (CPG_PERSIST_ACQUIRE || CPG_PERSIST_PLAIN_LOADS) ? 0 : 16);
         };
         auto compute = [&](const u32x4 (&buf)[P_MI][NP], int kb) {
             cpg_bf16x8 fb[3][NP];
@@ -293,31 +323,24 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     fb[q][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + q * 16 * S + kb * 16);
+            if (CPG_PERSIST_ABLATE & 4) {
 #pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi) {
-                const cpg_bf16x8 fa0 = __builtin_bit_cast(cpg_bf16x8, buf[mi][0]);
-                const cpg_bf16x8 fa1 = __builtin_bit_cast(cpg_bf16x8, buf[mi][NP == 3 ? 1 : 0]);
-                const cpg_bf16x8 fa2 = __builtin_bit_cast(cpg_bf16x8, buf[mi][NP == 3 ? 2 : 0]);
+                for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    f32x4 c = acc[mi][q];
-                    if (CPG_PERSIST_ABLATE & 4) {
-                        acc[mi][q] = c + __builtin_bit_cast(f32x4, fa0) * __builtin_bit_cast(f32x4, fb[q][0]) +
-                                     __builtin_bit_cast(f32x4, fa1) * __builtin_bit_cast(f32x4, fb[q][NP == 3 ? 1 : 0]) +
-                                     __builtin_bit_cast(f32x4, fa2) * __builtin_bit_cast(f32x4, fb[q][NP - 1]);
-                        continue;
-                    }
-                    if (NP == 3) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa2, fb[q][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][NP - 1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][NP == 3 ? 1 : 0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb[q][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][NP == 3 ? 1 : 0], c, 0, 0, 0);
-                    }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb[q][0], c, 0, 0, 0);
-                    acc[mi][q] = c;
-                }
+                    for (int q = 0; q < 3; ++q) acc[mi][q] += __builtin_bit_cast(f32x4, buf[mi][0]) * __builtin_bit_cast(f32x4, fb[q][0]);
+                return;
             }
+            // six products per block in the per-step kernel's order, walked TERM BY TERM over the 3 P_MI independent
+            // accumulators: a dependent MFMA waits for its predecessor to leave the pipe, independent ones issue back to back
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = (NP == 3 ? 0 : 5); t < 6; ++t)
+#pragma unroll
+                for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        acc[mi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, buf[mi][NP == 3 ? TA[t] : 0]),
+                                                                             fb[q][NP == 3 ? TB[t] : 0], acc[mi][q], 0, 0, 0);
         };
 #pragma unroll
         for (int d = 0; d < P_DEPTH - 1; ++d)
@@ -343,9 +366,9 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                     zg[mi][r] = gi[mi][r][1] + (acc[mi][1][r] + bh[1]);
                     ng[mi][r] = gi[mi][r][2] + rg[mi][r] * hn[mi][r];
                 } else {
-                rg[mi][r] = sigmoidf_(gi[mi][r][0] + (acc[mi][0][r] + bh[0]));
-                zg[mi][r] = sigmoidf_(gi[mi][r][1] + (acc[mi][1][r] + bh[1]));
-                ng[mi][r] = tanhf(gi[mi][r][2] + rg[mi][r] * hn[mi][r]);
+                rg[mi][r] = p_sigmoid(gi[mi][r][0] + (acc[mi][0][r] + bh[0]));
+                zg[mi][r] = p_sigmoid(gi[mi][r][1] + (acc[mi][1][r] + bh[1]));
+                ng[mi][r] = p_tanh(gi[mi][r][2] + rg[mi][r] * hn[mi][r]);
                 }
                 hprev[mi][r] = (1.f - zg[mi][r]) * ng[mi][r] + zg[mi][r] * hprev[mi][r];
             }
@@ -395,6 +418,7 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
     if (e && atoi(e) == 0) return 0;
     if (B <= 0 || H < 32 || H % 32 != 0) return 0;
     if (fwd_lds_bytes(H) > 160 * 1024) return 0;
+    if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
     const int groups = cdiv(cdiv(B, P_WROWS), P_WAVES);
     const long wgs = (long)groups * (H / P_CT);
     const int cus = device_cus();
@@ -403,12 +427,13 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
 
 static size_t sync_words(int B) { return ((size_t)cdiv(B, P_WROWS) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
 
-CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int B, int H) {
-    return sync_words(B) * sizeof(unsigned) + (size_t)6 * B * H * sizeof(uint16_t);  // + two exchange slots of three bf16 planes
+CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
+    // + one exchange slot of three bf16 planes per step (+ the initial state): slots are never reused inside a launch
+    return sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
 }
 
 // Whole forward sequence in one launch; arguments as cpg_gru_seq_fwd (all rows).  sync_scratch: device memory of
-// cpg_gru_persistent_scratch_bytes(B,H) bytes, ZEROED BY THE CALLER when allocated: arrival counters (re-zeroed here on the
+// cpg_gru_persistent_scratch_bytes(T,B,H) bytes, ZEROED BY THE CALLER when allocated: arrival counters (re-zeroed here on the
 // stream before every launch), a sticky error word (set by a wave whose wait timed out, never cleared here) and the two
 // exchange slots.
 CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,

@@ -123,12 +123,12 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
  * a row tile hand h_t to each other through the state slab (write-through stores + arrival counters), so nothing is
  * re-staged, re-launched or re-gathered per step.  Same arguments and results as cpg_gru_seq_fwd over all rows.
  * cpg_gru_persistent_fits: 1 when (B,H) is covered on this device (H % 32 == 0, H <= 512, one workgroup per CU co-resident;
- * CPG_GRU_PERSIST=0 disables).  sync_scratch: cpg_gru_persistent_scratch_bytes(B,H) bytes of device memory, zeroed by
- * the caller once (arrival counters, re-zeroed by every call, a sticky error word, two bf16-plane exchange slots).  cpg_gru_persistent_status synchronises the
+ * CPG_GRU_PERSIST=0 disables).  sync_scratch: cpg_gru_persistent_scratch_bytes(T,B,H) bytes of device memory, zeroed by
+ * the caller once (arrival counters, re-zeroed by every call, a sticky error word, one bf16-plane exchange slot per step).  cpg_gru_persistent_status synchronises the
  * stream and returns the error word (0 = every in-kernel wait of every launch on this scratch completed).
  * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident. */
 CPG_API int cpg_gru_persistent_fits(int B, int H);
-CPG_API size_t cpg_gru_persistent_scratch_bytes(int B, int H);
+CPG_API size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H);
 CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                        float* hs, float* gates, void* sync_scratch, void* stream);
