@@ -264,9 +264,9 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
 
 
 @torch.no_grad()
-def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
-    """Beam search + hypothesis walk-back, all on device.  Returns numpy (hyps int32 [N,n_best,T+1] padded with -1,
-    lengths [N,n_best] incl. the leading <start>, scores [N,n_best])."""
+def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1, device_out=False):
+    """Beam search + hypothesis walk-back, all on device.  Returns (hyps int32 [N,n_best,T+1] padded with -1,
+    lengths [N,n_best] incl. the leading <start>, scores [N,n_best]) as numpy arrays, or as device tensors (device_out)."""
     global LAST_BEAM_STEPS
     tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length)
     T, N, K = tok.shape
@@ -276,6 +276,8 @@ def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length
     sc = torch.empty(N, n_best, device=tok.device, dtype=torch.float32)
     call("cpg_beam_hypotheses", _p(tok), _p(prev), _p(score), T, N, K, n_best, EOS_IDX, START_IDX, _p(hyps), _p(lens), _p(sc),
          _stream())
+    if device_out:
+        return hyps, lens, sc
     return hyps.cpu().numpy(), lens.cpu().numpy(), sc.cpu().numpy()
 
 

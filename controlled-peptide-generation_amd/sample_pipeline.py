@@ -190,12 +190,12 @@ def one_sampling_round(model, dataset, Q, n_samples_per_round, **kw):
 
 # ------------------------------------------------------------------------------------------------ array rounds
 def decode_ids_from_z(z, c, model, sample_mode='beam', beam_size=5, chunk=65536):
-    """Device z [n,Z], c [n,2] -> (ids int16 [n, T+1] with -1 padding: best beam hypothesis / greedy row incl. <start>,
+    """Device z [n,Z], c [n,2] -> (DEVICE ids int16 [n, T+1] with -1 padding: best beam hypothesis / greedy row incl. <start>,
     decoder row-step evaluations the decode needed).  Decoding is per-z independent, so the chunk size is a
     memory knob only."""
     from cpg import decode as cdecode
     T = model.MAX_SEQ_LEN
-    out = np.full((z.shape[0], T + 1), -1, np.int16)
+    out = torch.full((z.shape[0], T + 1), -1, dtype=torch.int16, device=z.device)
     evals = 0
     was_training = model.training
     model.eval()
@@ -203,14 +203,15 @@ def decode_ids_from_z(z, c, model, sample_mode='beam', beam_size=5, chunk=65536)
         for i0 in range(0, z.shape[0], chunk):
             zz, cc = z[i0:i0 + chunk].float().contiguous(), c[i0:i0 + chunk].float().contiguous()
             if sample_mode == 'beam':
-                hyps, lens, _ = cdecode.decode_beam_arrays(model.decoder, zz, cc, T, beam_size, 3, 1)
+                hyps, lens, _ = cdecode.decode_beam_arrays(model.decoder, zz, cc, T, beam_size, 3, 1, device_out=True)
                 best = hyps[:, 0, :]
                 w = best.shape[1]
-                out[i0:i0 + zz.shape[0], :w] = np.where(np.arange(w)[None, :] < lens[:, 0:1], best, -1)
+                live = torch.arange(w, device=z.device)[None, :] < lens[:, 0:1]
+                out[i0:i0 + zz.shape[0], :w] = torch.where(live, best, torch.full_like(best, -1)).to(torch.int16)
                 evals += int(beam_size) * int(cdecode.LAST_BEAM_STEPS)
             elif sample_mode == 'greedy':
-                ids = cdecode.decode_hard(model.decoder, zz, cc, T).cpu().numpy()
-                out[i0:i0 + zz.shape[0], :ids.shape[1]] = ids
+                ids = cdecode.decode_hard(model.decoder, zz, cc, T)
+                out[i0:i0 + zz.shape[0], :ids.shape[1]] = ids.to(torch.int16)
                 evals += int(cdecode.LAST_GREEDY_STEPS)
             else:
                 raise ValueError('array rounds decode with beam or greedy')
@@ -219,9 +220,25 @@ def decode_ids_from_z(z, c, model, sample_mode='beam', beam_size=5, chunk=65536)
     return out, evals
 
 
+N_SPECIALS = 4   # <unk> <pad> <start> <eos> (models/mutils.py:5-8): ids below this are stripped from a peptide string
+
+
+def residue_rows(ids, n_vocab):
+    """ids int [n, L] (device or CPU tensor; < 0 = padding) -> (letters uint8 [n, L]: ids of the residues of each row, specials
+    stripped, left-aligned, zero-filled; counts int32 [n]).  The compaction idx2sentences(..., print_special_tokens=False)
+    does per row in python, as three tensor ops on the device the decode left the ids on.  Two rows give the same peptide
+    string iff their letter rows are equal."""
+    ids = ids.to(torch.int64)
+    keep = ids >= N_SPECIALS
+    pos = torch.cumsum(keep, 1) - 1
+    letters = torch.zeros(ids.shape[0], ids.shape[1] + 1, dtype=torch.uint8, device=ids.device)
+    letters.scatter_(1, torch.where(keep, pos, torch.full_like(pos, ids.shape[1])), torch.where(keep, ids, torch.zeros_like(ids)).to(torch.uint8))
+    return letters[:, :ids.shape[1]].contiguous(), keep.sum(1).to(torch.int32)
+
+
 def sample_round_arrays(model, dataset, Q, n_samples, sample_mode='beam', decode_accepted_only=False, shard=(0, 1)):
-    """One sampling round (reference get_new_samples :195-207) as an array frame; with shard=(rank, world) this rank
-    proposes / scores / decodes its rows of the round only."""
+    """One sampling round (reference get_new_samples :195-207) as a frame of DEVICE tensors; with shard=(rank, world) this
+    rank proposes / scores / decodes its rows of the round only."""
     z, probs, accum, acc = Q.rejection_sample(n_samples, return_device=True, shard=shard)
     names = Q.score_names()
     n_prop = z.shape[0]
@@ -230,16 +247,15 @@ def sample_round_arrays(model, dataset, Q, n_samples, sample_mode='beam', decode
         z, probs, accum, acc = z[keep], probs[:, keep], accum[keep], acc[keep]
     T = model.MAX_SEQ_LEN
     if z.shape[0] == 0:
-        ids, evals = np.full((0, T + 1), -1, np.int16), 0
+        ids, evals = torch.full((0, T + 1), -1, dtype=torch.int16, device=z.device), 0
     else:
         c = torch.zeros(z.shape[0], 2, device=z.device)
         c[:, 1] = 1.0
         ids, evals = decode_ids_from_z(z, c, model, sample_mode)
-    letters, n_res = dataset.ids_to_letters(ids)
-    frame = {'letters': letters, 'n_res': n_res.astype(np.int32), 'z': z.cpu().numpy(),
-             'accept_z': acc.cpu().numpy().astype(bool), names[0]: accum.cpu().numpy()}
+    letters, n_res = residue_rows(ids, dataset.n_vocab)
+    frame = {'letters': letters, 'n_res': n_res, 'z': z, 'accept_z': acc.to(torch.bool), names[0]: accum}
     for i, nm in enumerate(names[1:]):
-        frame[nm] = probs[i].cpu().numpy()
+        frame[nm] = probs[i]
     return frame, dict(proposed=n_prop, decoded=int(z.shape[0]), decoder_evals=evals)
 
 
@@ -249,41 +265,59 @@ def gather_frame(frame):
     import torch.distributed as tdist
     if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1):
         return frame
-    dev = torch.device('cuda', torch.cuda.current_device()) if tdist.get_backend() == 'nccl' else torch.device('cpu')
+    on_gpu = tdist.get_backend() == 'nccl'
     out = {}
-    for k, v in frame.items():
-        t = torch.from_numpy(np.ascontiguousarray(v))
+    for k, t in frame.items():
         as_u8 = t.dtype == torch.bool
-        g = cdist.allgather_rows((t.to(torch.uint8) if as_u8 else t).to(dev)).cpu().numpy()
-        out[k] = g.astype(bool) if as_u8 else g
+        t = t.to(torch.uint8) if as_u8 else t
+        g = cdist.allgather_rows(t.contiguous() if on_gpu else t.cpu().contiguous())
+        out[k] = g.to(torch.bool) if as_u8 else g
     return out
 
 
 def _keys(letters):
-    return np.ascontiguousarray(letters).view(np.dtype((np.void, letters.shape[1]))).ravel()
+    """Residue rows -> [n, W] int64 keys (8 letters per word): row equality = key equality."""
+    n, L = letters.shape
+    W = -(-L // 8)
+    pad = torch.zeros(n, W * 8, dtype=torch.uint8, device=letters.device)
+    pad[:, :L] = letters
+    return pad.view(torch.int64).reshape(n, W) if pad.is_contiguous() else pad.contiguous().view(torch.int64).reshape(n, W)
 
 
 def dedup_frame(frame, seen):
-    """drop_duplicates within the round (first occurrence kept) and against earlier rounds (reference :312-314), on the
-    stripped residue rows.  seen: void-key array of every row kept so far; returns (frame, new seen)."""
+    """drop_duplicates within the round (first occurrence kept, original order) and against earlier rounds (reference
+    :312-314), on the stripped residue rows, on the device the frame lives on.  seen: key tensor of every row kept so far;
+    returns (frame, new seen)."""
     keys = _keys(frame['letters'])
-    _, first = np.unique(keys, return_index=True)
-    keep = np.sort(first)
-    if seen is not None and len(seen):
-        keep = keep[~np.isin(keys[keep], seen)]
+    n = keys.shape[0]
+    if n == 0:
+        return frame, seen
+    n_seen = 0 if seen is None else seen.shape[0]
+    allk = keys if n_seen == 0 else torch.cat([seen, keys], 0)
+    _, inv = torch.unique(allk, dim=0, return_inverse=True)
+    first = torch.full((int(inv.max().item()) + 1,), allk.shape[0], dtype=torch.int64, device=keys.device)
+    first.scatter_reduce_(0, inv, torch.arange(allk.shape[0], device=keys.device), reduce='amin')
+    keep = torch.nonzero(first[inv[n_seen:]] == torch.arange(n_seen, n_seen + n, device=keys.device)).squeeze(1)  # sorted
     out = {k: v[keep] for k, v in frame.items()}
     kept = keys[keep]
-    return out, (kept if seen is None or not len(seen) else np.concatenate([seen, kept]))
+    return out, (kept if n_seen == 0 else torch.cat([seen, kept], 0))
 
 
 def frames_to_dataframe(frames, dataset):
-    """The reference's sample table (peptide, z, accept_z, clfZ_*, accept) from the kept array frames."""
+    """The reference's sample table (peptide, z, accept_z, clfZ_*, accept) from the kept frames."""
     import pandas as pd
     if not frames:
         return pd.DataFrame(columns=['peptide', 'z', 'accept_z', 'accept'])
-    cat = {k: np.concatenate([f[k] for f in frames], 0) for k in frames[0]}
-    df = pd.DataFrame({'peptide': dataset.letters_to_peptides(cat['letters'], cat['n_res']), 'z': list(cat['z']),
-                       'accept_z': cat['accept_z'], **{k: v for k, v in cat.items() if k not in ('letters', 'n_res', 'z', 'accept_z')}})
+    cat = {k: torch.cat([f[k] for f in frames], 0).cpu().numpy() for k in frames[0]}
+    # ids -> characters through the loader's vocabulary (one-letter residues), then one bytes.decode per kept row
+    itos = dataset.TEXT.vocab.itos
+    lut = np.zeros(256, np.uint8)
+    for i in range(N_SPECIALS, len(itos)):
+        assert len(itos[i]) == 1, 'vectorised form needs one-letter residue tokens'
+        lut[i] = ord(itos[i])
+    df = pd.DataFrame({'peptide': dataset.letters_to_peptides(lut[cat['letters']], cat['n_res']), 'z': list(cat['z']),
+                       'accept_z': cat['accept_z'].astype(bool),
+                       **{k: v for k, v in cat.items() if k not in ('letters', 'n_res', 'z', 'accept_z')}})
     df = compute_modlamp(df)
     df['accept'] = df['accept_z']
     return df
@@ -323,6 +357,7 @@ def run_rounds(model, dataset, Q, n_samples_per_round, n_samples_acc, max_rounds
         stats['rounds'] += 1
         LOG.info("Round #{}".format(stats['rounds']))
         frame, st = sample_round_arrays(model, dataset, Q, n_samples_per_round, sample_mode, decode_accepted_only, (rank, world))
+        frame = {k: torch.as_tensor(v) for k, v in frame.items()}
         frame = gather_frame(frame)            # identical on every rank from here on
         frame, seen = dedup_frame(frame, seen)
         frames.append(frame)

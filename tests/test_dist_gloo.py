@@ -131,9 +131,11 @@ def _fake_round_factory():
         ids[:, 0] = 2
         ids[:, 1:7] = table[rows]
         ids[:, 7] = 3
-        letters, n_res = dataset.ids_to_letters(ids)
-        frame = {'letters': letters, 'n_res': n_res.astype(np.int32), 'z': zs[rows], 'accept_z': acc_all[rows],
-                 'clfZ_prob_accum': rs.rand(n)[rows]}
+        import torch
+        import sample_pipeline as sp
+        letters, n_res = sp.residue_rows(torch.from_numpy(ids), dataset.n_vocab)
+        frame = {'letters': letters, 'n_res': n_res, 'z': torch.from_numpy(zs[rows]), 'accept_z': torch.from_numpy(acc_all[rows]),
+                 'clfZ_prob_accum': torch.from_numpy(rs.rand(n)[rows])}
         return frame, dict(proposed=n_local, decoded=n_local, decoder_evals=25 * n_local)
     return fake
 

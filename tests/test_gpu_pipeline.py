@@ -112,6 +112,7 @@ def test_array_round_vs_oracle_and_sharding(golden, mode):
     n = 512
     Q._philox = [77, 0]
     frame, st = sp.sample_round_arrays(m, ds, Q, n, sample_mode=mode)
+    frame = {k: v.cpu().numpy() for k, v in frame.items()}
     assert st['proposed'] == n and st['decoded'] == n and st['decoder_evals'] > 0
     z = frame['z']
     c = np.zeros((n, 2), np.float32)
@@ -125,7 +126,10 @@ def test_array_round_vs_oracle_and_sharding(golden, mode):
         ids = np.full((n, L), -1, np.int64)
         for i, h in enumerate(hyps):
             ids[i, :len(h[0])] = h[0]
-    ref_letters, ref_n = ds.ids_to_letters(ids)
+    ref_letters, ref_n = sp.residue_rows(torch.from_numpy(ids), ds.n_vocab)
+    ref_letters, ref_n = ref_letters.numpy(), ref_n.numpy()
+    # the vectorised compaction equals the loader's per-row python form
+    assert ds.letters_to_peptides(*ds.ids_to_letters(ids))[:20] == [ds.idx2sentence(r[r >= 0], False) for r in ids[:20]]
     w = min(ref_letters.shape[1], frame['letters'].shape[1])
     assert np.array_equal(ref_n, frame['n_res'])
     assert np.array_equal(ref_letters[:, :w], frame['letters'][:, :w])
@@ -138,7 +142,7 @@ def test_array_round_vs_oracle_and_sharding(golden, mode):
     for r in range(2):
         Q._philox = [77, 0]
         f, _ = sp.sample_round_arrays(m, ds, Q, n, sample_mode=mode, shard=(r, 2))
-        halves.append(f)
+        halves.append({k: v.cpu().numpy() for k, v in f.items()})
     for k in frame:
         assert np.array_equal(np.concatenate([halves[0][k], halves[1][k]], 0), frame[k]), k
 
