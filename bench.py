@@ -63,6 +63,8 @@ def family_roofline(family, dims, avg_us, launches):
     bf16 = L.cpg_get_compute_mode() == 1
     if family == "fwd_persist":
         kernel, split, flops = "gru_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 3 * H
+    elif family == "bwd_persist":
+        kernel, split, flops = "gru_seq_bwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * 3 * H * H
     elif family == "fwd_step":
         kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0)
         flops = nd * 2.0 * B * H * 3 * H

@@ -333,9 +333,24 @@ def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, 
          _p(hs), _p(gates), _p(sc), _stream())
 
 
+def persistent_bwd_fits(T, B, H):
+    return bool(query("cpg_gru_persistent_bwd_fits", int(T), int(B), int(H)))
+
+
+def gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dG, dh0):
+    dev = hs.device
+    nb = query("cpg_gru_persistent_bwd_scratch_bytes", T, B, H)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, H, -T)
+    sc = _persist_scratch.get(key)
+    if sc is None:
+        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    call("cpg_gru_seq_bwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), _p(dh_last), _p(dG),
+         _p(dh0), _p(sc), _stream())
+
+
 def check_persistent():
     """Raise if any in-kernel wait of a persistent launch has timed out since start-up (synchronises the streams used)."""
-    for (_, _, B, _H, _T), sc in _persist_scratch.items():
+    for (_, _, B, _H, _T), sc in list(_persist_scratch.items()):
         if query("cpg_gru_persistent_status", B, _p(sc), _stream()) != 0:
             raise CpgError("persistent GRU kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
                            "set CPG_GRU_PERSIST=0 to use the per-step kernels")
@@ -410,7 +425,10 @@ class GruSeqFn(Function):
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         groups = row_groups(B)
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # W_hh^T for the split-bf16 backward step kernels
-        if len(groups) == 1:
+        if step_rows is None and len(groups) == 1 and persistent_bwd_fits(T, B, H):
+            with _prof("bwd_persist", 1, T=T, B=B, H=H, ndir=1):
+                gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, None, dG, dh0)
+        elif len(groups) == 1:
             with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
                 call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
                      _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
@@ -509,9 +527,14 @@ class GruBiSeqFn(Function):
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
-        with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
-            call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                 _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+        if persistent_bwd_fits(T, B, H):
+            with _prof("bwd_persist", 2, T=T, B=B, H=H, ndir=1):
+                gru_seq_bwd_persistent(T, B, H, False, wf, hs_f, gt_f, ext_f, None, dG_f, None)
+                gru_seq_bwd_persistent(T, B, H, True, wr, hs_r, gt_r, ext_r, None, dG_r, None)
+        else:
+            with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
+                call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                     _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []

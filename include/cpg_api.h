@@ -133,6 +133,15 @@ CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const f
                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                        float* hs, float* gates, void* sync_scratch, void* stream);
 CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream);
+/* Persistent BPTT: the whole backward recurrence of one direction in one launch (same decomposition; what the column-tile
+ * workgroups exchange per step is dgh [rows,3H], already split).  Arguments and results as cpg_gru_seq_bwd over all rows of a
+ * dense batch (no step_rows).  sync_scratch: cpg_gru_persistent_bwd_scratch_bytes(T,B,H) bytes, zeroed by the caller once;
+ * cpg_gru_persistent_status reads its error word too. */
+CPG_API int cpg_gru_persistent_bwd_fits(int T, int B, int H);
+CPG_API size_t cpg_gru_persistent_bwd_scratch_bytes(int T, int B, int H);
+CPG_API int cpg_gru_seq_bwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                                       const float* dhs_ext, const float* dh_last, float* dG, float* dh0, void* sync_scratch,
+                                       void* stream);
 /* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
  * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.
  * kind 0 forward step, 1 backward step; ndir 1 | 2 (paired biGRU launches); have_wt: W_hh^T handed to the backward. */

@@ -33,9 +33,11 @@ def main():
     ap.add_argument("--V", type=int, default=24)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-gates", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--knob", action="append", default=[], help="NAME=v1,v2,... environment knob values to sweep")
     a = ap.parse_args()
     dev = torch.device("cuda")
+    ops.set_compute_mode(a.dtype)
     B, H, T, V = a.B, a.H, a.T, a.V
     g = torch.Generator(device="cpu").manual_seed(0)
     w_hh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(dev)
@@ -67,6 +69,9 @@ def main():
         call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), 0, B, None,
              _p(wT), _stream())
 
+    def bwdp():
+        ops.gru_seq_bwd_persistent(T, B, H, False, w_hh, hs, gates, dhs, None, dG, dh0)
+
     big_ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)  # large enough for any split the knobs select
 
     def wgrad():
@@ -84,11 +89,12 @@ def main():
                 os.environ[k] = v
             f = timeit(fwd, a.iters) / T
             fp = timeit(fwdp, a.iters) / T if ops.persistent_fits(B, H) else float("nan")
+            bp = timeit(bwdp, a.iters) / (T + 1) if ops.persistent_fits(B, H) else float("nan")
             b = timeit(bwd, a.iters) / (T + 1)
             w = timeit(wgrad, a.iters)
             for k in env:
                 os.environ.pop(k, None)
-            print(f"[{rnd}] {label:24s} fwd-persistent {fp:7.1f} us/step ({fl_step / fp / 1e6:6.1f} TF)")
+            print(f"[{rnd}] {label:24s} fwd-persistent {fp:7.1f} us/step ({fl_step / fp / 1e6:6.1f} TF)  bwd-persistent {bp:7.1f} us/step ({fl_step / bp / 1e6:6.1f} TF)")
             print(f"[{rnd}] {label:24s} fwd {f:7.1f} us/step ({fl_step / f / 1e6:6.1f} TF)  bwd {b:7.1f} us/step "
                   f"({fl_step / b / 1e6:6.1f} TF)  wgrad {w:8.1f} us ({fl_step * T / w / 1e6:6.1f} TF)")
 
