@@ -179,6 +179,15 @@ template <class TC, bool VEC, bool WT, int PREC = 7>
 using BwdLoop = MainLoop<TC, true, WT, VEC, VEC, false,
                          (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && (WT || TC::BV % 2 == 0)) ? PREC : 0>;
 
+// 16x16 accumulator block (lane (u = l&15, rq = l>>4), reg -> row 4rq+reg, col u) -> one f32x4 per lane in row layout
+// (lane -> row l>>2, cols 4(l&3)..+3) through a 1 KB per-wave LDS buffer no other wave touches
+__device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int lane) {
+    const int u = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tb[(4 * rq + r) * 16 + u] = v[r];
+    return *reinterpret_cast<const f32x4*>(tb + (lane >> 2) * 16 + 4 * (lane & 3));
+}
+
 template <class TC, bool VEC, bool WT, int PREC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
@@ -189,6 +198,67 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     const int m0 = g.row0 + by * TC::BM, j0 = bx * TC::BN;
     if (m0 >= B) return;
     const size_t BH = (size_t)g.B * H;
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (VEC) {
+        // ---- row-layout epilogue (H % 4 == 0, 16-byte aligned operands): every prologue / epilogue access is a 16-byte
+        // load or store of four consecutive columns of one row - a quarter of the memory instructions of the accumulator
+        // layout (one dword per lane, 64 B per row segment), which is what a step launch is bound by
+        extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float* const tb = cpg_smem + BwdLoop<TC, VEC, WT, PREC>::smem_bytes() / sizeof(float) + wave * 256;
+        const int rb0 = m0 + (wave / TC::WN) * TC::WTM + (lane >> 2), cb0 = j0 + (wave % TC::WN) * TC::WTN + 4 * (lane & 3);
+        f32x4 pre[TC::MI][TC::NI], sv[TC::MI][TC::NI][5];
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) {
+                const int row = rb0 + mi * 16, col = cb0 + ni * 16;
+                const size_t o = (size_t)((row < B) ? row : 0) * H + ((col < H) ? col : 0);
+                f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g.dH_next && row < Bn) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+                if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
+                if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
+                pre[mi][ni] = p;
+                if (g.gates) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[mi][ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                    sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
+                }
+            }
+        if (g.dG_next) {
+            OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
+            OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
+            BwdLoop<TC, VEC, WT, PREC>::run(a, b, 3 * H, acc);
+        }
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) {
+                const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
+                const int row = rb0 + mi * 16, col = cb0 + ni * 16;
+                if (row >= B || col >= H) continue;
+                const size_t o = (size_t)row * H + col;
+                *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+                if (!g.gates) continue;
+                const f32x4 rg = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
+                const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+                const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+                const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
+                float* d = g.dG_out + (size_t)row * 4 * H + col;
+                *reinterpret_cast<f32x4*>(d) = dr_pre;
+                *reinterpret_cast<f32x4*>(d + H) = dz_pre;
+                *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
+                *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+            }
+        return;
+    }
+
+    // ---- accumulator-layout epilogue (any H / alignment)
     // epilogue operands first (see the forward kernel): saved gates, h_prev and the non-GEMM part of dH
     float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][5];
 #pragma unroll
@@ -215,11 +285,6 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
                 }
             }
     }
-    f32x4 acc[TC::MI][TC::NI];
-#pragma unroll
-    for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (g.dG_next) {
         OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
         OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
@@ -354,7 +419,7 @@ template <class TC, bool WT, int PREC>
 static void launch_bwd_p(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = BwdLoop<TC, true, WT, PREC>::smem_bytes();
+    const size_t smem = BwdLoop<TC, true, WT, PREC>::smem_bytes() + 4 * 256 * sizeof(float);  // + per-wave transposition buffers
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -476,6 +541,10 @@ static int gru_bwd_launch(const GruBwdPair& pr, int nd, hipStream_t s) {
     bool vec = a.H % 4 == 0, have_wt = true;
     for (int d = 0; d < nd; ++d) {
         vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
+        // the row-layout epilogue moves four columns per lane: every state / gate / gradient base 16-byte aligned
+        const void* ptrs[] = {pr.d[d].dH_next, pr.d[d].z_next, pr.d[d].ext, pr.d[d].ext2, pr.d[d].gates, pr.d[d].h_prev,
+                              pr.d[d].dH_out, pr.d[d].dG_out};
+        for (const void* q : ptrs) vec = vec && (!q || aligned16(q));
         have_wt = have_wt && pr.d[d].w_hhT != nullptr;
         if (pr.d[d].w_hhT) vec = vec && aligned16(pr.d[d].w_hhT);
     }
