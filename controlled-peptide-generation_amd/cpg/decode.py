@@ -219,19 +219,20 @@ def _first_all_finished(ids):
 def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
     """Runs the device beam search; returns device tensors (tok, prev, score) each [T,N,K] (tok = -1 where a sentence
     had already finished): the recorded history cpg_beam_hypotheses walks back."""
-    if getattr(decoder, "cell", "gru") != "gru":
-        raise NotImplementedError("beam search is implemented for the GRU decoder (the reference's cell)")
+    lstm = getattr(decoder, "cell", "gru") == "lstm"   # extension (torch.nn.LSTM semantics, h0 = [z;c], c0 = 0): per-step path
     N = z.shape[0]
     K = beam_size
     dev = z.device
     zc1 = decoder.init_hidden(z, c).contiguous()
     tab, rowc1 = decoder._tables(zc1)
     tab = tab.contiguous()
-    if fused_beam_fits(zc1.shape[1], decoder.fc[1].weight.shape[0], tab.shape[0], K):
+    if not lstm and fused_beam_fits(zc1.shape[1], decoder.fc[1].weight.shape[0], tab.shape[0], K):
         return _decode_beam_fused(decoder, zc1, tab, rowc1.contiguous(), max_len, K, n_best, min_length)
     rowc = rowc1.repeat(K, 1).contiguous()            # beam-major rows: row = k*N + i (model.py:262-263)
     h_a = zc1.repeat(K, 1).contiguous()
     h_b = torch.empty_like(h_a)
+    if lstm:
+        c_a, c_b = torch.zeros_like(h_a), torch.empty_like(h_a)
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
     H = h_a.shape[1]
     V = decoder.fc[1].weight.shape[0]
@@ -252,11 +253,16 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
     logits = torch.empty(K * N, V, device=dev, dtype=torch.float32)
     steps_run = 0
     for i in range(max_len):
-        ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
+        if lstm:
+            ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
+        else:
+            ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
         _fc(decoder, h_b, logits)
         call("cpg_beam_select", _p(logits), N, V, K, i, n_best, min_length, START_IDX, EOS_IDX, _p(scores), _p(last_tok),
              _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active), _p(h_b),
              _p(h_a), H, _stream())
+        if lstm:   # the cell state follows the same back-pointers (Beam-major rows)
+            call("cpg_beam_reorder", _p(c_b), _p(c_a), _p(origin), N, K, H, _stream())
         steps_run = i + 1
         if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early
             break

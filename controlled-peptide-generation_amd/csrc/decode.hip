@@ -322,6 +322,16 @@ CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int ste
     return 0;
 }
 
+// h_out[k*N+i] = h_in[origin[i][k]*N + i] for one more [K*N,H] state array (the LSTM cell state: cpg_beam_select reorders h)
+CPG_EXPORT int cpg_beam_reorder(const float* h_in, float* h_out, const int32_t* origin, int N, int K, int H, void* stream) {
+    CPG_CHECK_ARG(h_in && h_out && origin && h_in != h_out && N > 0 && K > 0 && H > 0);
+    const size_t n = (size_t)K * N * H;
+    hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h_in, h_out, origin,
+                       N, K, H);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------ beam hypotheses
 // Beam.sort_finished + Beam.get_hyp (models/Beam.py:110-132) for every sentence, one thread each, from the recorded
 // (token, back-pointer, score) history [T,N,K].  Finished entries are ranked in insertion order (step asc, beam asc) by

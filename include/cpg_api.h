@@ -222,6 +222,8 @@ CPG_API int cpg_beam_select(const float* logits, int N, int V, int K, int step, 
                             int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
                             int32_t* hist_tok, int32_t* hist_prev, float* hist_score, int32_t* origin, int32_t* tok_next,
                             int* n_active, const float* h_in, float* h_out, int H, void* stream);
+/* the same back-pointer reorder for one more beam-major state array [K*N,H] (the LSTM extension's cell state) */
+CPG_API int cpg_beam_reorder(const float* h_in, float* h_out, const int32_t* origin, int N, int K, int H, void* stream);
 /* Beam.sort_finished + get_hyp (models/Beam.py:110-132) for all sentences from the recorded history: finished entries
  * ranked by raw summed log-prob (stable, insertion order = step then beam), topped up from the live beam of the last
  * advanced step.  hyps int32 [N,n_best,T+1] (<start> first, -1 padded), lens/scores [N,n_best]. */

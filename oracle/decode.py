@@ -20,6 +20,16 @@ def decoder_step(P, tok, zc, h):
     return logits, h
 
 
+def lstm_decoder_step(P, tok, zc, h, cst):
+    """The LSTM extension's decode step (torch.nn.LSTM semantics; NOT a reference component - parity unpinned)."""
+    from .lstm import lstm_cell_fwd
+    x = np.concatenate([P["word_emb.weight"][tok], zc], 1).astype(F32)
+    gi = (x @ P["decoder.rnn.weight_ih_l0"].T + P["decoder.rnn.bias_ih_l0"]).astype(F32)
+    h, cst, _ = lstm_cell_fwd(gi, h, cst, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+    logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
+    return logits, h, cst
+
+
 def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=False):
     """ids [N, 1+steps] int64 with column 0 = START; steps <= max_len (stops once every row has emitted EOS)."""
     N = z.shape[0]
@@ -133,21 +143,27 @@ class _Beam:
         return hyps, scores
 
 
-def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=False):
-    """Returns (hyps, scores): hyps[i][j] = token list incl. leading START.
+def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=False, cell="gru"):
+    """Returns (hyps, scores): hyps[i][j] = token list incl. leading START.  cell='lstm': the LSTM extension's decoder
+    (h0 = [z;c], c0 = 0), the cell state reordered by the same back-pointers.
     return_history adds (tok, prev, score) arrays [steps,N,K] (tok=-1 where a sentence was not advanced): the record the
     device beam kernel keeps, used to test the host-side hypothesis reconstruction."""
     N = z.shape[0]
     zc1 = np.concatenate([z, c], 1).astype(F32)
     zc = np.tile(zc1, (beam_size, 1))  # beam-major [beam*N] (model.py:262-263)
     h = zc.copy()
+    cst = np.zeros_like(h)
     beams = [_Beam(beam_size, n_best, min_length) for _ in range(N)]
     tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
     hist = []
     for _ in range(max_len):
-        logits, h = decoder_step(P, tok, zc, h)
+        if cell == "lstm":
+            logits, h, cst = lstm_decoder_step(P, tok, zc, h, cst)
+        else:
+            logits, h = decoder_step(P, tok, zc, h)
         lg = logits.reshape(beam_size, N, -1)
         hv = h.reshape(beam_size, N, -1)
+        cv = cst.reshape(beam_size, N, -1)
         ht = np.full((N, beam_size), -1, np.int64)
         hp = np.zeros((N, beam_size), np.int64)
         hsc = np.zeros((N, beam_size), F32)
@@ -157,6 +173,7 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
                 b.advance(_log_softmax(lg[:, j]))
                 ht[j], hp[j], hsc[j] = b.next_ys[-1], b.prev_ks[-1], b.scores
             hv[:, j] = hv[b.prev_ks[-1], j]  # _update_hidden (model.py:387-404), applied even when done
+            cv[:, j] = cv[b.prev_ks[-1], j]
         tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
         if all(b.done() for b in beams):
             break

@@ -124,3 +124,33 @@ def test_lstm_model_trains_and_decodes():
     assert s.shape[0] == 16 and s.dtype == torch.int64 and (s[:, 0] == 2).all()
     losses.rf.clear()
     losses.set_prior_sampler(None)
+
+
+@pytest.mark.gpu
+def test_lstm_beam_and_greedy_vs_oracle():
+    """Beam-5 / n-best-3 and greedy decoding with cell='lstm' against the numpy restatement (oracle/decode.py with the
+    torch.nn.LSTM-pinned cell of oracle/lstm.py): hypotheses exact.  Extension: parity unpinned against the reference."""
+    import bench
+    from models.model import RNN_VAE
+    from oracle import decode as odec
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    m = RNN_VAE(n_vocab=24, max_seq_len=25, **bench.model_kwargs(46, 32, cell='lstm')).to(dev)
+    m.device = dev
+    with torch.no_grad():
+        m.decoder.fc[1].weight.mul_(5.0)
+        m.decoder.fc[1].bias[3] += 1.0
+    P = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    rs = np.random.RandomState(2)
+    N = 48
+    z = rs.randn(N, 46).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+    zt, ct = torch.from_numpy(z).to(dev), torch.from_numpy(c).to(dev)
+    hyps, _, _ = m.generate_sentences(N, zt, ct, sample_mode='beam', beam_size=5, n_best=3)
+    ref, _ = odec.beam(P, z, c, 25, beam_size=5, n_best=3, cell="lstm")
+    for i in range(N):
+        for j in range(3):
+            assert hyps[i][j] == [int(t) for t in ref[i][j]], (i, j)
