@@ -831,11 +831,14 @@ class MmdRfFn(Function):
         return dz, None, None, None, None, None, None, None
 
 
+MMD_KERNELS = {"gaussian": 0, "laplace": 1, "energy": 2}  # compute_mmd_kernel, losses.py:102-107
+
+
 class MmdFullFn(Function):
-    """losses.mmd_full_kernel with the Gaussian kernel (losses.py:47-56,96-108), F7 quirk included."""
+    """losses.mmd_full_kernel (losses.py:47-56,96-108), F7 quirk included; kernel: index into MMD_KERNELS."""
 
     @staticmethod
-    def forward(ctx, z, z_prior, sigma):
+    def forward(ctx, z, z_prior, sigma, kernel=0):
         z, z_prior = z.contiguous(), z_prior.contiguous()
         N, D = z.shape
         dev = z.device
@@ -845,9 +848,10 @@ class MmdFullFn(Function):
         Q = torch.empty(N, N, device=dev, dtype=torch.float32) if need else None
         nb = query("cpg_mmd_full_workspace", N)
         ws = workspace(nb, dev)
-        call("cpg_mmd_full_fwd", _p(z), _p(z_prior), N, D, float(sigma), _p(out), _p(P), _p(Q), _p(ws), ws.numel(), _stream())
+        call("cpg_mmd_full_fwd", _p(z), _p(z_prior), N, D, float(sigma), int(kernel), _p(out), _p(P), _p(Q), _p(ws),
+             ws.numel(), _stream())
         ctx.save_for_backward(z, z_prior, P, Q)
-        ctx.sigma = float(sigma)
+        ctx.sigma, ctx.kernel = float(sigma), int(kernel)
         return out[0]
 
     @staticmethod
@@ -857,9 +861,9 @@ class MmdFullFn(Function):
         g = g.contiguous()
         dz = torch.empty_like(z)
         ws = workspace((N * D + N) * 4 + 256, z.device)
-        call("cpg_mmd_full_bwd", _p(z), _p(z_prior), _p(P), _p(Q), _p(g), N, D, ctx.sigma, _p(dz), _p(ws), ws.numel(),
-             _stream())
-        return dz, None, None
+        call("cpg_mmd_full_bwd", _p(z), _p(z_prior), _p(P), _p(Q), _p(g), N, D, ctx.sigma, ctx.kernel, _p(dz), _p(ws),
+             ws.numel(), _stream())
+        return dz, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------- random streams

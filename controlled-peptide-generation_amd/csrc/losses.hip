@@ -269,9 +269,26 @@ CPG_EXPORT int cpg_rf_bwd(const float* raw, const float* rf_b, const float* diff
 // from the MFMA engine; squared norms are read off the Gram diagonals so K11_ii = K22_ii = 1 exactly, as in the reference.
 // Quirk kept: `H - torch.diag(H)` broadcasts the diagonal VECTOR over rows, so
 //     loss = (sum_ij H_ij - N * sum_j H_jj) / (N (N-1)),  H = K11 + K22 - 2 K12,  K = exp(-d/sigma^2).
-// Optional outputs for the backward pass: P = 2*coef.*K11, Q = -2*coef.*K12 with coef_ij = (1 - N[i==j])/(N(N-1)).
-__global__ void mmd_full_partial_kernel(const float* G11, const float* G22, const float* G12, int N, float inv_s2, float* part,
-                                        float* P, float* Q) {
+// Optional outputs for the backward pass: P = 2*coef.*W11, Q = -2*coef.*W12 with coef_ij = (1 - N[i==j])/(N(N-1)) and
+// W = -dK/dd up to the constant the backward applies (Gaussian: W = K, constant 1/sigma^2; the others: constant 1).
+// KIND (compute_mmd_kernel, losses.py:102-107): 0 gaussian exp(-d/s^2), 1 laplace exp(-sqrt(d+s^2)), 2 energy (d+s^2)^-1/4.
+template <int KIND>
+__device__ __forceinline__ void mmd_kern(float d, float inv_s2, float s2, float& k, float& w) {
+    if (KIND == 0) {
+        k = w = expf(-d * inv_s2);
+    } else if (KIND == 1) {
+        const float r = sqrtf(d + s2);
+        k = expf(-r);
+        w = k / (2.f * r);
+    } else {
+        const float u = d + s2, q = rsqrtf(sqrtf(u));  // u^-1/4
+        k = q;
+        w = 0.25f * q / u;
+    }
+}
+template <int KIND>
+__global__ void mmd_full_partial_kernel(const float* G11, const float* G22, const float* G12, int N, float inv_s2, float s2,
+                                        float* part, float* P, float* Q) {
     __shared__ float red[8];
     float v[2] = {0.f, 0.f};
     const size_t n2 = (size_t)N * N;
@@ -280,16 +297,17 @@ __global__ void mmd_full_partial_kernel(const float* G11, const float* G22, cons
         const int i = idx / N, j = idx % N;
         const float a_i = G11[(size_t)i * N + i], a_j = G11[(size_t)j * N + j];
         const float b_i = G22[(size_t)i * N + i], b_j = G22[(size_t)j * N + j];
-        const float k11 = (i == j) ? 1.f : expf(-fmaxf(a_i + a_j - 2.f * G11[idx], 0.f) * inv_s2);
-        const float k22 = (i == j) ? 1.f : expf(-fmaxf(b_i + b_j - 2.f * G22[idx], 0.f) * inv_s2);
-        const float k12 = expf(-fmaxf(a_i + b_j - 2.f * G12[idx], 0.f) * inv_s2);
+        float k11, k22, k12, w11, w22, w12;  // the reference's diagonal distances are exactly 0
+        mmd_kern<KIND>((i == j) ? 0.f : fmaxf(a_i + a_j - 2.f * G11[idx], 0.f), inv_s2, s2, k11, w11);
+        mmd_kern<KIND>((i == j) ? 0.f : fmaxf(b_i + b_j - 2.f * G22[idx], 0.f), inv_s2, s2, k22, w22);
+        mmd_kern<KIND>(fmaxf(a_i + b_j - 2.f * G12[idx], 0.f), inv_s2, s2, k12, w12);
         const float h = k11 + k22 - 2.f * k12;
         v[0] += h;
         if (i == j) v[1] += h;
         if (P) {
             const float coef = (i == j) ? cf * (1.f - (float)N) : cf;
-            P[idx] = 2.f * coef * k11;
-            Q[idx] = -2.f * coef * k12;
+            P[idx] = 2.f * coef * w11;
+            Q[idx] = -2.f * coef * w12;
         }
     }
     block_sum<2>(v, red);
@@ -315,9 +333,11 @@ __global__ void mmd_full_final_kernel(const float* part, int N, float* out) {
 CPG_EXPORT size_t cpg_mmd_full_workspace(int N) { return ((size_t)3 * N * N + 2 * RED_BLOCKS) * sizeof(float) + 256; }
 
 // z1,z2 [N,D].  out[0] = loss.  P,Q [N,N] optional (null when no gradient is needed).  workspace: cpg_mmd_full_workspace(N).
-CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, float* out, float* P, float* Q,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+// kernel: 0 gaussian, 1 laplace, 2 energy (cfg.losses.wae_mmd.kernel, cfg.py:250).
+CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, int kernel, float* out, float* P,
+                                float* Q, void* workspace, size_t workspace_bytes, void* stream) {
     CPG_CHECK_ARG(z1 && z2 && out && workspace && N > 1 && D > 0 && sigma > 0.f && ((P == nullptr) == (Q == nullptr)));
+    CPG_CHECK_ARG(kernel >= 0 && kernel <= 2);
     CPG_CHECK_ARG(workspace_bytes >= cpg_mmd_full_workspace(N));
     hipStream_t s = (hipStream_t)stream;
     float* G11 = (float*)workspace;
@@ -328,14 +348,20 @@ CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, 
     if (!rc) rc = cpg_gemm_nt(z2, D, nullptr, 1.f, z2, D, nullptr, G22, N, N, N, D, 0, s);
     if (!rc) rc = cpg_gemm_nt(z1, D, nullptr, 1.f, z2, D, nullptr, G12, N, N, N, D, 0, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(mmd_full_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, G11, G22, G12, N, 1.f / (sigma * sigma),
-                       part, P, Q);
+    const float s2 = sigma * sigma;
+#define CPG_MMD_LAUNCH(KIND)                                                                                               \
+    hipLaunchKernelGGL(mmd_full_partial_kernel<KIND>, dim3(RED_BLOCKS), dim3(256), 0, s, G11, G22, G12, N, 1.f / s2, s2, part, \
+                       P, Q)
+    if (kernel == 0) CPG_MMD_LAUNCH(0);
+    else if (kernel == 1) CPG_MMD_LAUNCH(1);
+    else CPG_MMD_LAUNCH(2);
+#undef CPG_MMD_LAUNCH
     hipLaunchKernelGGL(mmd_full_final_kernel, dim3(1), dim3(256), 0, s, (const float*)part, N, out);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 
-// dz1 = gout * (-(2/sigma^2)) * ( (rowsum(P)+rowsum(Q)) .* z1 - P z1 - Q z2 )
+// dz1 = gout * c * ( (rowsum(P)+rowsum(Q)) .* z1 - P z1 - Q z2 ),  c = -2/sigma^2 (gaussian) or -2 (laplace, energy)
 __global__ void rowsum2_kernel(const float* P, const float* Q, int N, float* rs) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= N) return;
@@ -352,8 +378,9 @@ __global__ void mmd_full_bwd_combine_kernel(const float* z1, const float* rs, co
     dz1[i] = gout[0] * c * (rs[r] * z1[i] - Mz[i]);
 }
 CPG_EXPORT int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P, const float* Q, const float* gout, int N,
-                                int D, float sigma, float* dz1, void* workspace, size_t workspace_bytes, void* stream) {
-    CPG_CHECK_ARG(z1 && z2 && P && Q && gout && dz1 && workspace && N > 1 && D > 0);
+                                int D, float sigma, int kernel, float* dz1, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    CPG_CHECK_ARG(z1 && z2 && P && Q && gout && dz1 && workspace && N > 1 && D > 0 && kernel >= 0 && kernel <= 2);
     CPG_CHECK_ARG(workspace_bytes >= ((size_t)N * D + N) * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     float* Mz = (float*)workspace;
@@ -364,7 +391,7 @@ CPG_EXPORT int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P
     hipLaunchKernelGGL(rowsum2_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, P, Q, N, rs);
     const size_t n = (size_t)N * D;
     hipLaunchKernelGGL(mmd_full_bwd_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z1, (const float*)rs,
-                       (const float*)Mz, gout, N, D, -2.f / (sigma * sigma), dz1);
+                       (const float*)Mz, gout, N, D, kernel == 0 ? -2.f / (sigma * sigma) : -2.f, dz1);
     CPG_LAUNCH_CHECK();
     return 0;
 }

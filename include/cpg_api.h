@@ -257,12 +257,14 @@ CPG_API int cpg_rf_loss(const float* sums1, const float* sums2, int R, int B_glo
                         void* stream);
 CPG_API int cpg_rf_bwd(const float* raw, const float* rf_b, const float* diff, const float* gout, int Bn, int R,
                        float sigma, int B_global, float* dpre, void* stream);
-/* mmd_full_kernel, losses.py:47-56,96-108 (Gaussian kernel, incl. the `H - diag(H)` broadcast) */
+/* mmd_full_kernel, losses.py:47-56,96-108 (incl. the `H - diag(H)` broadcast).
+ * kernel: 0 "gaussian", 1 "laplace", 2 "energy" - compute_mmd_kernel, losses.py:102-107. */
 CPG_API size_t cpg_mmd_full_workspace(int N);
-CPG_API int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, float* out, float* P, float* Q,
-                             void* workspace, size_t workspace_bytes, void* stream);
+CPG_API int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, int kernel, float* out, float* P,
+                             float* Q, void* workspace, size_t workspace_bytes, void* stream);
 CPG_API int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P, const float* Q, const float* gout, int N,
-                             int D, float sigma, float* dz1, void* workspace, size_t workspace_bytes, void* stream);
+                             int D, float sigma, int kernel, float* dz1, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* ---- optimiser: clip_grad_norm_ + Adam, train_vae.py:15,39-42 ---------------------------------------------------- */
 CPG_API size_t cpg_sumsq_workspace(void);

@@ -114,16 +114,22 @@ def kl_gaussian_sharedmu(mu, logvar):
     return torch.mean(0.5 * torch.sum(logvar.exp() - 1 - logvar, 1))
 
 
-def _gauss_kernel(x, y, sigma):
-    """losses.py:96-103 with the reference's [N,M,D] broadcast (that tensor is why the step is memory-hungry on CPU)."""
+def _mmd_kernel(x, y, sigma, kernel="gaussian"):
+    """losses.py:96-108 with the reference's [N,M,D] broadcast (that tensor is why the step is memory-hungry on CPU)."""
     d = (x.unsqueeze(1) - y.unsqueeze(0)).pow(2).sum(2)
-    return torch.exp(-d / sigma ** 2)
+    if kernel == "gaussian":
+        return torch.exp(-d / sigma ** 2)
+    if kernel == "laplace":
+        return torch.exp(-torch.sqrt(d + sigma ** 2))
+    if kernel == "energy":
+        return torch.pow(d + sigma ** 2, -0.25)
+    raise ValueError(kernel)
 
 
-def mmd_full_kernel(z1, z2, sigma=7.0):
+def mmd_full_kernel(z1, z2, sigma=7.0, kernel="gaussian"):
     """losses.py:47-56: `H - diag(H)` broadcasts the diagonal VECTOR over rows."""
     N = z1.size(0)
-    H = _gauss_kernel(z1, z1, sigma) + _gauss_kernel(z2, z2, sigma) - 2 * _gauss_kernel(z1, z2, sigma)
+    H = _mmd_kernel(z1, z1, sigma, kernel) + _mmd_kernel(z2, z2, sigma, kernel) - 2 * _mmd_kernel(z1, z2, sigma, kernel)
     H = H - torch.diag(H)
     return H.sum() / (N * (N - 1))
 

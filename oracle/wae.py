@@ -192,23 +192,37 @@ def _sqdist(x, y, form=None):
     return np.maximum(d, 0.0)
 
 
-def mmd_full_kernel(z1, z2, sigma):
-    """Gaussian kernel exp(-|x-y|^2/sigma^2); H = K11+K22-2K12; then `H - diag(H)` BROADCASTS the diagonal
-    vector over rows (every column j loses H_jj in every row): loss = (sum H - N*sum_j H_jj)/(N(N-1))."""
-    N = z1.shape[0]
+def _mmd_kernel(d, sigma, kernel):
+    """compute_mmd_kernel (losses.py:96-108) on squared distances d -> K, dK/dd."""
     s2 = float(sigma) ** 2
-    K11, K22, K12 = np.exp(-_sqdist(z1, z1) / s2), np.exp(-_sqdist(z2, z2) / s2), np.exp(-_sqdist(z1, z2) / s2)
+    if kernel == "gaussian":
+        K = np.exp(-d / s2)
+        return K, -K / s2
+    if kernel == "laplace":
+        r = np.sqrt(d + s2)
+        K = np.exp(-r)
+        return K, -K / (2.0 * r)
+    if kernel == "energy":
+        return (d + s2) ** -0.25, -0.25 * (d + s2) ** -1.25
+    raise ValueError(kernel)
+
+
+def mmd_full_kernel(z1, z2, sigma, kernel="gaussian"):
+    """H = K11+K22-2K12 with K from compute_mmd_kernel; then `H - diag(H)` BROADCASTS the diagonal vector over rows
+    (every column j loses H_jj in every row): loss = (sum H - N*sum_j H_jj)/(N(N-1)).  -> loss, d loss / d z1."""
+    N = z1.shape[0]
+    (K11, W11), (K22, _), (K12, W12) = (_mmd_kernel(_sqdist(a, b), sigma, kernel) for a, b in ((z1, z1), (z2, z2), (z1, z2)))
     Hm = K11 + K22 - 2.0 * K12
     loss = (Hm.sum() - N * np.trace(Hm)) / (N * (N - 1))
-    # d loss / d z1.  Coefficient on each H_ij: (1 - N*[i==j]) / (N(N-1))
+    # d loss / d z1.  Coefficient on each H_ij: (1 - N*[i==j]) / (N(N-1)); d d_ij / d x_i = 2 (x_i - y_j)
     coef = (np.ones((N, N)) - N * np.eye(N)) / (N * (N - 1))
     z1d, z2d = z1.astype(np.float64), z2.astype(np.float64)
     # K11_ij depends on z1_i and z1_j ; K12_ij on z1_i only
-    A = coef * K11
+    A = coef * W11
     A = A + A.T
-    g = -(2.0 / s2) * (A.sum(1)[:, None] * z1d - A @ z1d)
-    Bm = -2.0 * coef * K12
-    g += -(2.0 / s2) * (Bm.sum(1)[:, None] * z1d - Bm @ z2d)
+    g = 2.0 * (A.sum(1)[:, None] * z1d - A @ z1d)
+    Bm = -2.0 * coef * W12
+    g += 2.0 * (Bm.sum(1)[:, None] * z1d - Bm @ z2d)
     return F32(loss), g.astype(F32)
 
 

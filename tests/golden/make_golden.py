@@ -560,3 +560,24 @@ def categorical_vectors(name="A", seed=1238, N=96, **kw):
 
 if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "categorical":
     categorical_vectors("A", 1238, **model_kwargs(z_dim=100, enc_h=80))
+
+
+def mmd_kernel_vectors(seed=1238, N=48, D=100, sigma=7.0):
+    """losses.mmd_full_kernel with each of compute_mmd_kernel's three kernels (losses.py:47-56,96-108): loss and d loss/d z1
+    from the reference's autograd, on an encoder-like z1 (shifted, narrower) against a N(0,I) prior sample."""
+    gen = torch.Generator().manual_seed(seed + 41)
+    z1 = (0.6 * torch.randn(N, D, generator=gen) + 0.3).requires_grad_(True)
+    z2 = torch.randn(N, D, generator=gen)
+    out = dict(z1=z1.detach().numpy().copy(), z2=z2.numpy().copy(), sigma=np.float32(sigma))
+    for kernel in ("gaussian", "laplace", "energy"):
+        z1.grad = None
+        loss = rlosses.mmd_full_kernel(z1, z2, sigma=sigma, kernel=kernel)
+        loss.backward()
+        out[kernel + ".loss"] = np.float32(loss.item())
+        out[kernel + ".dz1"] = z1.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "mmd_kernels.npz"), **out)
+    print("mmd_kernels.npz written", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
+
+
+if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "mmd_kernels":
+    mmd_kernel_vectors()

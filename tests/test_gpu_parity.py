@@ -94,6 +94,31 @@ def test_train_trajectory_golden(golden, name, ragged):
     check_train_trajectory_golden(golden("train_" + name), ragged)
 
 
+@pytest.mark.parametrize("kernel", ["gaussian", "laplace", "energy"])
+def test_mmd_full_kernels_golden(golden, kernel):
+    """losses.mmd_full_kernel with each compute_mmd_kernel kernel (losses.py:47-56,96-108): loss within 1e-4 (north_star's
+    bar) of the reference's, d loss/d z1 within 1e-4 of the gradient's own scale; then the oracle at config-B size."""
+    import losses
+    from oracle import wae
+    g = golden("mmd_kernels")
+    z1 = cu(g["z1"]).requires_grad_(True)
+    loss = losses.mmd_full_kernel(z1, cu(g["z2"]), sigma=float(g["sigma"]), kernel=kernel)
+    loss.backward()
+    ref_l, ref_g = float(g[kernel + ".loss"]), g[kernel + ".dz1"]
+    assert abs(loss.item() - ref_l) < 1e-4 * max(1.0, abs(ref_l))
+    assert np.abs(z1.grad.cpu().numpy() - ref_g).max() < 1e-4 * np.abs(ref_g).max()
+    rs = np.random.RandomState(5)
+    x, y = (0.5 * rs.randn(2048, 100) + 0.2).astype(np.float32), rs.randn(2048, 100).astype(np.float32)
+    ol, og = wae.mmd_full_kernel(x, y, 7.0, kernel)
+    z1 = cu(x).requires_grad_(True)
+    loss = losses.mmd_full_kernel(z1, cu(y), sigma=7.0, kernel=kernel)
+    loss.backward()
+    assert abs(loss.item() - float(ol)) < 1e-4 * max(1.0, abs(float(ol)))
+    assert np.abs(z1.grad.cpu().numpy() - og).max() < 1e-3 * np.abs(og).max()
+    with pytest.raises(ValueError):
+        losses.mmd_full_kernel(z1, cu(y), sigma=7.0, kernel="cauchy")
+
+
 def test_class_kernels_golden(golden):
     from cpg import class_sampler
     g = golden("class_small")

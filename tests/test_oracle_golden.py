@@ -161,6 +161,23 @@ def test_sqdist_forms_agree():
     np.testing.assert_allclose(g1, g2, atol=1e-9)
 
 
+@pytest.mark.parametrize("kernel", ["gaussian", "laplace", "energy"])
+def test_mmd_kernels(golden, kernel):
+    """compute_mmd_kernel's three kernels (losses.py:96-108): loss and d loss / d z1 against the reference's autograd."""
+    import torch
+    from oracle import torch_ref
+    g = golden("mmd_kernels")
+    loss, dz = wae.mmd_full_kernel(g["z1"], g["z2"], float(g["sigma"]), kernel)
+    ref_l, ref_g = float(g[kernel + ".loss"]), g[kernel + ".dz1"]
+    assert abs(float(loss) - ref_l) < 2e-6 * max(1.0, abs(ref_l))
+    assert np.abs(dz - ref_g).max() < 1e-5 * np.abs(ref_g).max()
+    z1 = torch.tensor(g["z1"], requires_grad=True)
+    lt = torch_ref.mmd_full_kernel(z1, torch.tensor(g["z2"]), float(g["sigma"]), kernel)
+    lt.backward()
+    assert abs(lt.item() - ref_l) < 1e-6 * max(1.0, abs(ref_l))
+    assert np.abs(z1.grad.numpy() - ref_g).max() < 1e-5 * np.abs(ref_g).max()
+
+
 # ---- the torch-CPU restatement that bench.py times as `cpu_baseline` (oracle/torch_ref.py), pinned to the same vectors
 @pytest.mark.parametrize("name", MODELS)
 def test_torch_ref_losses_and_grads(golden, name):
