@@ -348,9 +348,44 @@ def gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, 
          _p(dh0), _p(sc), _stream())
 
 
+def chain_bwd_fits(T, B, H):
+    """Launch policy of the one-launch BPTT (csrc/gru.hip, cpg_gru_*_bwd_chain): off unless CPG_GRU_BWD_CHAIN=1."""
+    return bool(query("cpg_gru_chain_bwd_fits", int(T), int(B), int(H)))
+
+
+def chain_bwd_covers(T, B, H):
+    """The one-launch BPTT covers this shape on this device (every workgroup co-resident)."""
+    return bool(query("cpg_gru_chain_bwd_covers", int(T), int(B), int(H)))
+
+
+def _chain_scratch(B, dev):
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, "chain", 0)
+    sc = _persist_scratch.get(key)
+    if sc is None:
+        nb = query("cpg_gru_chain_scratch_bytes", B)
+        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word
+    return sc
+
+
+def gru_seq_bwd_chain(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dG, dh0, wT=None):
+    call("cpg_gru_seq_bwd_chain", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), _p(dh_last), _p(dG), _p(dh0),
+         _p(wT), _p(_chain_scratch(B, hs.device)), _stream())
+
+
+def gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT=None):
+    call("cpg_gru_biseq_bwd_chain", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+         _p(dG_f), _p(dG_r), _p(wT[0] if wT is not None else None), _p(wT[1] if wT is not None else None),
+         _p(_chain_scratch(B, hs_f.device)), _stream())
+
+
 def check_persistent():
     """Raise if any in-kernel wait of a persistent launch has timed out since start-up (synchronises the streams used)."""
     for (_, _, B, _H, _T), sc in list(_persist_scratch.items()):
+        if _H == "chain":
+            if query("cpg_gru_chain_status", B, _p(sc), _stream()) != 0:
+                raise CpgError("one-launch BPTT: an inter-workgroup wait timed out (workgroups not co-resident?); "
+                               "set CPG_GRU_BWD_CHAIN=0 to use the per-step kernels")
+            continue
         if query("cpg_gru_persistent_status", B, _p(sc), _stream()) != 0:
             raise CpgError("persistent GRU kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
                            "set CPG_GRU_PERSIST=0 to use the per-step kernels")
@@ -428,6 +463,9 @@ class GruSeqFn(Function):
         if step_rows is None and len(groups) == 1 and persistent_bwd_fits(T, B, H):
             with _prof("bwd_persist", 1, T=T, B=B, H=H, ndir=1):
                 gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, None, dG, dh0)
+        elif step_rows is None and len(groups) == 1 and chain_bwd_fits(T, B, H):
+            with _prof("bwd_chain", 1, T=T, B=B, H=H, ndir=1, steps=T + (1 if has_h0 else 0)):
+                gru_seq_bwd_chain(T, B, H, reverse, w_hh, hs, gates, dhs_ext, None, dG, dh0, wT)
         elif len(groups) == 1:
             with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
                 call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
@@ -531,6 +569,9 @@ class GruBiSeqFn(Function):
             with _prof("bwd_persist", 2, T=T, B=B, H=H, ndir=1):
                 gru_seq_bwd_persistent(T, B, H, False, wf, hs_f, gt_f, ext_f, None, dG_f, None)
                 gru_seq_bwd_persistent(T, B, H, True, wr, hs_r, gt_r, ext_r, None, dG_r, None)
+        elif chain_bwd_fits(T, B, H):
+            with _prof("bwd_chain", 1, T=T, B=B, H=H, ndir=2, steps=T):
+                gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT)
         else:
             with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
                 call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),

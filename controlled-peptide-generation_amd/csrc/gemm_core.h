@@ -504,7 +504,9 @@ struct MainLoop {
         if (STORE && !(CPG_ABLATE & 1)) sstore7(a, b, An, Bn, st);
     }
 
-    __device__ static __forceinline__ void run7(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI]) {
+    template <class Hook>
+    __device__ static __forceinline__ void run7(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI], int hook_kt,
+                                                Hook&& hook) {
         extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
         uint32_t* const base = reinterpret_cast<uint32_t*>(cpg_smem);
         uint32_t* const A0 = base;
@@ -519,6 +521,7 @@ struct MainLoop {
         sstore7(a, b, A0, B0, st);
         __syncthreads();
         for (int kt = 0; kt < KT; kt += 2) {
+            if (kt == hook_kt) hook();
             if (kt + 1 < KT) {
                 if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 1) * BK, K, st);
                 slab7<true>(a, b, A0, B0, A1, B1, st, acc);
@@ -644,9 +647,19 @@ struct MainLoop {
     // acc[mi][ni] += A_tile * B_tile over the whole K range.  Uses TC::smem_floats<A_KC,B_KC>() floats of dynamic LDS.
     // The two LDS buffers are addressed with compile-time offsets from the __shared__ symbol itself (2x unrolled slab
     // loop): runtime-selected buffer pointers degrade to flat_* accesses whose waits also drain the global prefetch.
+    // `hook` runs once, ahead of slab `hook_kt` (even; < 0: never): the caller's own global loads, issued from inside the loop
+    // so that their latency and their HBM burst sit under the matrix work instead of ahead of it.
+    struct NoHook {
+        __device__ __forceinline__ void operator()() const {}
+    };
     __device__ static __forceinline__ void run(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI]) {
+        run(a, b, K, acc, -1, NoHook{});
+    }
+    template <class Hook>
+    __device__ static __forceinline__ void run(const OpA& a, const OpB& b, int K, f32x4 (&acc)[TC::MI][TC::NI], int hook_kt,
+                                               Hook&& hook) {
         if (SPLIT != 0) {
-            run7(a, b, K, acc);
+            run7(a, b, K, acc, hook_kt, hook);
             return;
         }
         extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
@@ -662,6 +675,7 @@ struct MainLoop {
         sstore(a, b, A0, B0, st);
         __syncthreads();
         for (int kt = 0; kt < KT; kt += 2) {
+            if (kt == hook_kt) hook();
             if (kt + 1 < KT) {
                 if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 1) * BK, K, st);
                 slab<true>(a, b, A0, B0, A1, B1, st, acc);

@@ -160,6 +160,7 @@ struct GruBwdArgs {
     int row0, row1;
     const int32_t* nrows;       // device scalar or null: rows live at step s (see GruFwdArgs)
     const int32_t* nrows_next;  // rows live at step s+1: beyond them dG_next / dH_next / z_next were never written
+    int ep_step;                // (even) slab spacing of the staggered epilogue-operand fetch; 0: every workgroup ahead of slab 0
 };
 
 struct GruBwdPair {
@@ -213,27 +214,36 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
         float* const tb = cpg_smem + BwdLoop<TC, VEC, WT, PREC>::smem_bytes() / sizeof(float) + wave * 256;
         const int rb0 = m0 + (wave / TC::WN) * TC::WTM + (lane >> 2), cb0 = j0 + (wave % TC::WN) * TC::WTN + 4 * (lane & 3);
         f32x4 pre[TC::MI][TC::NI], sv[TC::MI][TC::NI][5];
+        // The epilogue operands (36 B per element: saved gates, h_prev, z*dH of step s+1, external gradients) are fetched
+        // from INSIDE the slab loop, at a slab that differs between the workgroups sharing a CU: issued ahead of the loop by
+        // every workgroup at once they are one 36 MB burst the whole chip waits out before its first slab.
+        auto load_ep = [&]() {
 #pragma unroll
-        for (int mi = 0; mi < TC::MI; ++mi)
+            for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TC::NI; ++ni) {
-                const int row = rb0 + mi * 16, col = cb0 + ni * 16;
-                const size_t o = (size_t)((row < B) ? row : 0) * H + ((col < H) ? col : 0);
-                f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (g.dH_next && row < Bn) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
-                if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
-                if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
-                pre[mi][ni] = p;
-                if (g.gates) {
+                for (int ni = 0; ni < TC::NI; ++ni) {
+                    const int row = rb0 + mi * 16, col = cb0 + ni * 16;
+                    const size_t o = (size_t)((row < B) ? row : 0) * H + ((col < H) ? col : 0);
+                    f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (g.dH_next && row < Bn) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+                    if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
+                    if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
+                    pre[mi][ni] = p;
+                    if (g.gates) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) sv[mi][ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
-                    sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
+                        for (int q = 0; q < 4; ++q) sv[mi][ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                        sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
+                    }
                 }
-            }
+        };
         if (g.dG_next) {
             OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
             OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
-            BwdLoop<TC, VEC, WT, PREC>::run(a, b, 3 * H, acc);
+            const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);  // dispatch order: XCD = hb % 8
+            const int phase = ((hb >> 3) + (hb >> 8)) & 3, last = ((3 * H + TC::BK - 1) / TC::BK - 1) & ~1;
+            BwdLoop<TC, VEC, WT, PREC>::run(a, b, 3 * H, acc, min(phase * g.ep_step, last), load_ep);
+        } else {
+            load_ep();
         }
 #pragma unroll
         for (int mi = 0; mi < TC::MI; ++mi)
@@ -389,6 +399,7 @@ using GB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 using GB64W = TileCfg<64, 64, 32, 2, 2, 1>;    // wider N tile: 4 MFMAs per k-step per wave instead of 2
 using GB128W = TileCfg<128, 64, 32, 2, 2, 1>;
 using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
+using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab barriers (exact-f32 engine only)
 
 template <class TC, int PREC>
 static void launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
@@ -485,7 +496,7 @@ int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
 
 // Tile of a backward-step launch.  Exact-f32 path (no W_hh^T handed over, or one of the CPG_GRU_BWD_BM / CPG_GRU_BWD_WIDE
 // knobs set): the round-1 policy.  Split path: CPG_GRU_BWD_TILE = 64x32 | 32x64 | 64x64 | 128x32 | 128x64 | 32x32 forces.
-enum BwdTile { BT_64x32, BT_32x64, BT_64x64, BT_128x32, BT_128x64, BT_32x32 };
+enum BwdTile { BT_64x32, BT_32x64, BT_64x64, BT_128x32, BT_128x64, BT_32x32, BT_32x32K64 };
 struct BwdChoice {
     bool wt;
     BwdTile tile;
@@ -508,6 +519,7 @@ static BwdChoice gru_bwd_choice(int rows, int H, int nd, bool have_wt) {
         if (wide && atoi(wide) == 64) return {false, BT_64x64};
         if (wide && atoi(wide) == 128) return {false, BT_128x64};
         if (wide && atoi(wide) == 32) return {false, BT_32x32};
+        if (wide && atoi(wide) == 3264) return {false, BT_32x32K64};
         if (bm == 128) return {false, BT_128x32};
         if (bm == 64) return {false, BT_64x32};
         return {false, BT_32x64};
@@ -533,10 +545,24 @@ static void launch_bwd_tile(BwdTile t, const GruBwdPair& pr, int nd, bool vec, h
         case BT_128x32: launch_bwd<GB128, WT>(pr, nd, vec, s); break;
         case BT_128x64: launch_bwd<GB128W, WT>(pr, nd, vec, s); break;
         case BT_32x32: launch_bwd<GB32N, WT>(pr, nd, vec, s); break;
+        case BT_32x32K64:
+            if (!WT) launch_bwd_p<GB32K, false, 7>(pr, nd, vec, s);
+            break;
     }
 }
 
-static int gru_bwd_launch(const GruBwdPair& pr, int nd, hipStream_t s) {
+// Slab spacing of the staggered epilogue-operand fetch: a quarter of the slab count by default (the four workgroups a CU
+// holds fetch ahead of slabs 0, KT/4, KT/2, 3KT/4);  CPG_GRU_BWD_STAGGER=<slabs> overrides, 0 = all ahead of slab 0.
+static int bwd_ep_step(int H) {
+    const char* e = getenv("CPG_GRU_BWD_STAGGER");  // read per launch, like the tile knobs (A/B sweeps inside one process)
+    const int knob = e ? atoi(e) : -1;
+    const int kt = cdiv(3 * H, 32);
+    return (knob >= 0 ? knob : kt / 4) & ~1;
+}
+
+static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
+    GruBwdPair pr = pr_in;
+    for (int d = 0; d < 2; ++d) pr.d[d].ep_step = bwd_ep_step(pr.d[d].H);
     const GruBwdArgs& a = pr.d[0];
     bool vec = a.H % 4 == 0, have_wt = true;
     for (int d = 0; d < nd; ++d) {
@@ -712,6 +738,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
             case BT_128x32: tc_name<GB128>(tc, sizeof tc); break;
             case BT_128x64: tc_name<GB128W>(tc, sizeof tc); break;
             case BT_32x32: tc_name<GB32N>(tc, sizeof tc); break;
+            case BT_32x32K64: tc_name<GB32K>(tc, sizeof tc); break;
         }
         return snprintf(buf, n, "gru_step_bwd_kernel<%s, %s, %s, %d>", tc, vec ? "true" : "false", c.wt ? "true" : "false",
                         (c.wt && cpg_compute_mode_get() == 1) ? 1 : 7);
@@ -1017,4 +1044,304 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
         if (rc) return rc;
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------ BPTT as ONE launch ("chain")
+// The per-step backward launches are rounds of 1024 workgroups in lock step: all of them fetch their 36 B / element of
+// epilogue operands, then all of them multiply, then all of them store - the HBM phases and the matrix phase of a launch never
+// overlap, and every launch pays its ramp and its drain (18 us of a 48 us launch at B=2048, H=512: DESIGN.md 9).  Here the
+// same tiles run the WHOLE time loop: workgroup (row tile m, column tile j) needs, for step s, the dgh rows of tile m of step
+// s+1 - written by the column-tile workgroups of ITS row tile only - so the hand-off is an arrival counter per row tile
+// (write-through stores, vmcnt(0), one relaxed agent-scope add per wave; consumers poll relaxed and then read addresses that
+// were never read before in this launch: the placement-independent pattern of csrc/gru_persist.hip), not a grid barrier.
+// Row tiles are independent recurrences and drift apart, so a CU's four workgroups are in different phases; z (.) dH of the
+// workgroup's own elements stays in registers across steps (no dH round trip).  W_hh is not stationary (it is the L2-resident
+// operand it is for the step kernels).  Both directions of a biGRU layer run in the same workgroups, alternating, so the wait
+// for one direction's peers sits under the other direction's product.
+// Needs every workgroup co-resident (cpg_gru_chain_bwd_fits checks the occupancy); waits are bounded (sticky error word).
+struct GruChainDir {
+    const float* w_hh;     // [3H,H]
+    const float* w_hhT;    // [H,3H] or null (WT kernels)
+    const float* hs;       // [(T+1),B,H]
+    const float* gates;    // [T,4,B,H]
+    const float* ext;      // [T,B,H] time-aligned external gradient, or null
+    const float* dh_last;  // [B,H] gradient on the final state, or null
+    float* dG;             // [T,B,4H]
+    float* dh0;            // [B,H] or null
+    int reverse;
+};
+struct GruChainArgs {
+    GruChainDir d[2];
+    unsigned* cnt;  // [nd][row tiles][64 words] arrival counters (first word of each group), zeroed before the launch
+    unsigned* err;  // sticky error word
+    int nd, T, B, H, ep_step;
+};
+
+// Diagnostic builds (tools/ablate_chain.sh; results WRONG by construction): 1 no waits, 2 plain instead of write-through stores,
+// 4 no vmcnt(0) drain ahead of the arrival, 8 no dG stores, 16 no arrivals
+#ifndef CPG_CHAIN_ABLATE
+#define CPG_CHAIN_ABLATE 0
+#endif
+typedef unsigned chain_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned CHAIN_SPIN_LIMIT = 400000u;
+constexpr int CHAIN_CNT_STRIDE = 64;  // words between arrival counters
+
+__device__ __forceinline__ void chain_wait(unsigned* p, unsigned target, unsigned* err, bool& dead) {
+    if (dead) return;
+    unsigned spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > CHAIN_SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = true;
+            return;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+template <class TC, bool WT, int PREC>
+__global__ __launch_bounds__(256) void gru_seq_bwd_chain_kernel(GruChainArgs g) {
+    using Loop = BwdLoop<TC, true, WT, PREC>;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int H = g.H, B = g.B, T = g.T;
+    const int m0 = by * TC::BM, j0 = bx * TC::BN;
+    const size_t BH = (size_t)B * H;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* const tb = cpg_smem + Loop::smem_bytes() / sizeof(float) + wave * 256;
+    const int rb0 = m0 + (wave / TC::WN) * TC::WTM + (lane >> 2), cb0 = j0 + (wave % TC::WN) * TC::WTN + 4 * (lane & 3);
+    const unsigned peers = gridDim.x;  // arrivals per row tile, direction and step: one per column-tile workgroup
+    const int hb = blockIdx.x + gridDim.x * blockIdx.y;
+    const int phase = ((hb >> 3) + (hb >> 8)) & 3, last = ((3 * H + TC::BK - 1) / TC::BK - 1) & ~1;
+    const int hook_kt = min(phase * g.ep_step, last);
+    f32x4 zdh[2][TC::MI][TC::NI];  // z_{s+1} (.) dH_{s+1} of this lane's own elements, per direction
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) zdh[d][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+
+    for (int p = T - 1; p >= -1; --p) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            if (d >= g.nd) break;
+            const GruChainDir& D = g.d[d];
+            if (p < 0 && !D.dh0) continue;
+            // a counter per (direction, row tile), each in its own 256 bytes: arrivals and polls of different row tiles do not
+            // queue on one memory channel (4096 adds per step on two adjacent lines cost 90 us per step)
+            unsigned* const cnt = g.cnt + ((size_t)d * gridDim.y + by) * CHAIN_CNT_STRIDE;
+            const int t = p < 0 ? -1 : (D.reverse ? T - 1 - p : p);
+            const int prev_t = (p == T - 1) ? -1 : (D.reverse ? T - 2 - p : p + 1);
+            const float* const gates = t >= 0 ? D.gates + (size_t)t * 4 * BH : nullptr;
+            const float* const h_prev = t >= 0 ? D.hs + (size_t)(D.reverse ? t + 1 : t) * BH : nullptr;
+            const float* const ext = (t >= 0 && D.ext) ? D.ext + (size_t)t * BH : nullptr;
+            const float* const ext2 = (p == T - 1) ? D.dh_last : nullptr;
+
+            f32x4 acc[TC::MI][TC::NI], pre[TC::MI][TC::NI], sv[TC::MI][TC::NI][5];
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto load_ep = [&]() {
+#pragma unroll
+                for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TC::NI; ++ni) {
+                        const int row = rb0 + mi * 16, col = cb0 + ni * 16;
+                        const size_t o = (size_t)((row < B) ? row : 0) * H + ((col < H) ? col : 0);
+                        f32x4 q = zdh[d][mi][ni];   // exact zero on the first step: same sums as the step kernels
+                        if (ext) q += *reinterpret_cast<const f32x4*>(ext + o);
+                        if (ext2) q += *reinterpret_cast<const f32x4*>(ext2 + o);
+                        pre[mi][ni] = q;
+                        if (gates) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sv[mi][ni][k] = *reinterpret_cast<const f32x4*>(gates + k * BH + o);
+                            sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(h_prev + o);
+                        }
+                    }
+            };
+            if (prev_t >= 0) {
+                // one wave polls for the workgroup (the others sit in the barrier: no polling traffic from them)
+                if (!(CPG_CHAIN_ABLATE & 1)) {
+                    if (wave == 0) chain_wait(cnt, peers * (unsigned)(T - 1 - p), g.err, dead);
+                    __syncthreads();
+                }
+                OpA a{D.dG + (size_t)prev_t * B * 4 * H, 4 * H, m0, B, nullptr, 1.f};
+                OpB b{WT ? D.w_hhT : D.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
+                Loop::run(a, b, 3 * H, acc, hook_kt, load_ep);
+            } else {
+                load_ep();
+            }
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+                t >= 0 ? D.dG + (size_t)t * B * 4 * H : D.dG, 0, (unsigned)((size_t)B * 4 * H * sizeof(float)), 0x00020000);
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC::NI; ++ni) {
+                    const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
+                    const int row = rb0 + mi * 16, col = cb0 + ni * 16;
+                    if (row >= B || col >= H) continue;
+                    if (t < 0) {
+                        *reinterpret_cast<f32x4*>(D.dh0 + (size_t)row * H + col) = dh;
+                        continue;
+                    }
+                    const f32x4 rgt = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
+                    const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+                    const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+                    const f32x4 dr_pre = dn_pre * hn * rgt * (1.f - rgt);
+                    zdh[d][mi][ni] = zg * dh;
+                    const unsigned o = (unsigned)(((size_t)row * 4 * H + col) * sizeof(float));
+                    const unsigned hb4 = (unsigned)(H * sizeof(float));
+                    // write-through (sc1): the consumers of these rows run on other CUs and read them after the arrival below
+                    constexpr int AUX = (CPG_CHAIN_ABLATE & 2) ? 0 : 16;
+                    if (CPG_CHAIN_ABLATE & 8) continue;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dr_pre), rg, o, 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dz_pre), rg, o + hb4, 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre * rgt), rg, o + 2 * hb4, 0, AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre), rg, o + 3 * hb4, 0, AUX);
+                }
+            if (t >= 0 && p > 0 || (t >= 0 && D.dh0)) {  // somebody will wait for this step
+                // every wave drains its stores, then ONE arrival for the workgroup
+                if (!(CPG_CHAIN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0 && !(CPG_CHAIN_ABLATE & 16))
+                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+using GC32 = GB32N;   // exact-f32 product, 32 x 32 tiles: the f32-grade choice of the step kernels (gru_bwd_choice)
+using GC64 = GB64;    // bf16 compute mode: W_hh^T path, 64 x 32 tiles
+
+template <class TC, bool WT, int PREC>
+static size_t chain_smem() { return BwdLoop<TC, true, WT, PREC>::smem_bytes() + 4 * 256 * sizeof(float); }
+
+template <class TC, bool WT, int PREC>
+static int chain_resident_blocks() {  // workgroups of this kernel the device holds at once
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    const void* fn = reinterpret_cast<const void*>(gru_seq_bwd_chain_kernel<TC, WT, PREC>);
+    const size_t smem = chain_smem<TC, WT, PREC>();
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t pr;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    cached = per_cu * pr.multiProcessorCount;
+    return cached;
+}
+
+static bool chain_bf16() { return cpg_compute_mode_get() == 1; }
+
+// 1 when the one-launch BPTT covers (T, B, H) on this device: 16-byte row layout (H % 4 == 0), one dG step slice addressable
+// through a 32-bit buffer range, every workgroup co-resident.
+CPG_EXPORT int cpg_gru_chain_bwd_covers(int T, int B, int H) {
+    if (T <= 0 || B <= 0 || H < 4 || H % 4 != 0) return 0;
+    if ((size_t)B * 4 * H * sizeof(float) >= ((size_t)1 << 32)) return 0;
+    const bool bf = chain_bf16();
+    const long wgs = bf ? (long)cdiv(H, GC64::BN) * cdiv(B, GC64::BM) : (long)cdiv(H, GC32::BN) * cdiv(B, GC32::BM);
+    const int cap = bf ? chain_resident_blocks<GC64, true, 1>() : chain_resident_blocks<GC32, false, 7>();
+    return wgs <= cap;
+}
+// Policy: measured on MI355X at B=2048, H=512 the one-launch form takes 46-48 us per step (pairs 87) against 46.6-48 (pairs
+// 84) for the per-step launches - the step is bound by what a workgroup does, not by the launch boundaries -
+// so it runs only when CPG_GRU_BWD_CHAIN=1 asks for it.
+CPG_EXPORT int cpg_gru_chain_bwd_fits(int T, int B, int H) {
+    const char* e = getenv("CPG_GRU_BWD_CHAIN");
+    if (!e || atoi(e) == 0) return 0;
+    return cpg_gru_chain_bwd_covers(T, B, H);
+}
+
+// counters [2 directions][row tiles of 32][256 bytes] + the sticky error word
+static size_t chain_cnt_words(int B) { return (size_t)2 * cdiv(B, 32) * CHAIN_CNT_STRIDE; }
+CPG_EXPORT size_t cpg_gru_chain_scratch_bytes(int B) { return (chain_cnt_words(B) + CHAIN_CNT_STRIDE) * sizeof(unsigned); }
+
+static int chain_launch(GruChainArgs& g, void* sync_scratch, float* wT0, float* wT1, hipStream_t s) {
+    const bool bf = chain_bf16();
+    const int bm = bf ? GC64::BM : GC32::BM, bn = bf ? GC64::BN : GC32::BN;
+    const int nrt = cdiv(g.B, bm);
+    for (int d = 0; d < g.nd; ++d) {
+        const void* ptrs[] = {g.d[d].w_hh, g.d[d].hs, g.d[d].gates, g.d[d].ext, g.d[d].dh_last, g.d[d].dG, g.d[d].dh0};
+        for (const void* q : ptrs)
+            if (q && !aligned16(q)) {
+                cpg_set_error("cpg_gru_*_bwd_chain: operands must be 16-byte aligned");
+                return -2;
+            }
+    }
+    if (bf) {
+        float* wt[2] = {wT0, wT1};
+        for (int d = 0; d < g.nd; ++d) {
+            if (!wt[d]) {
+                cpg_set_error("cpg_gru_*_bwd_chain: the bf16 compute mode needs the W_hh^T scratch");
+                return -2;
+            }
+            int rc = transpose_w(g.d[d].w_hh, g.H, wt[d], s);
+            if (rc) return rc;
+            g.d[d].w_hhT = wt[d];
+        }
+    }
+    g.cnt = (unsigned*)sync_scratch;
+    g.err = g.cnt + chain_cnt_words(g.B);
+    CPG_HIP(hipMemsetAsync(sync_scratch, 0, chain_cnt_words(g.B) * sizeof(unsigned), s));  // the error word is sticky
+    g.ep_step = bwd_ep_step(g.H);
+    const dim3 grid(cdiv(g.H, bn), nrt, 1);
+    if (bf) {
+        (void)chain_resident_blocks<GC64, true, 1>();  // sets the dynamic-LDS attribute once
+        const size_t smem = chain_smem<GC64, true, 1>();
+        hipLaunchKernelGGL((gru_seq_bwd_chain_kernel<GC64, true, 1>), grid, dim3(256), smem, s, g);
+    } else {
+        (void)chain_resident_blocks<GC32, false, 7>();
+        const size_t smem = chain_smem<GC32, false, 7>();
+        hipLaunchKernelGGL((gru_seq_bwd_chain_kernel<GC32, false, 7>), grid, dim3(256), smem, s, g);
+    }
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Arguments and results as cpg_gru_seq_bwd over all rows of a dense batch; sync_scratch: cpg_gru_chain_scratch_bytes(B) bytes,
+// zeroed by the caller when allocated.  w_hhT_scratch [H,3H]: needed in the bf16 compute mode only.
+CPG_EXPORT int cpg_gru_seq_bwd_chain(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                                     const float* dhs_ext, const float* dh_last, float* dG, float* dh0, float* w_hhT_scratch,
+                                     void* sync_scratch, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && sync_scratch);
+    if (!cpg_gru_chain_bwd_covers(T, B, H)) {
+        cpg_set_error("cpg_gru_seq_bwd_chain: T=%d B=%d H=%d is not covered on this device", T, B, H);
+        return -5;
+    }
+    GruChainArgs g;
+    g.nd = 1; g.T = T; g.B = B; g.H = H;
+    g.d[0] = GruChainDir{w_hh, nullptr, hs, gates, dhs_ext, dh_last, dG, dh0, reverse};
+    g.d[1] = g.d[0];
+    return chain_launch(g, sync_scratch, w_hhT_scratch, nullptr, (hipStream_t)stream);
+}
+
+// Both directions of a biGRU layer (arguments as cpg_gru_biseq_bwd) in one launch.
+CPG_EXPORT int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                                       const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                       const float* dhs_ext_r, float* dG_f, float* dG_r, float* w_hhT_scratch_f,
+                                       float* w_hhT_scratch_r, void* sync_scratch, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r && sync_scratch);
+    if (!cpg_gru_chain_bwd_covers(T, B, H)) {
+        cpg_set_error("cpg_gru_biseq_bwd_chain: T=%d B=%d H=%d is not covered on this device", T, B, H);
+        return -5;
+    }
+    GruChainArgs g;
+    g.nd = 2; g.T = T; g.B = B; g.H = H;
+    g.d[0] = GruChainDir{w_hh_f, nullptr, hs_f, gates_f, dhs_ext_f, nullptr, dG_f, nullptr, 0};
+    g.d[1] = GruChainDir{w_hh_r, nullptr, hs_r, gates_r, dhs_ext_r, nullptr, dG_r, nullptr, 1};
+    return chain_launch(g, sync_scratch, w_hhT_scratch_f, w_hhT_scratch_r, (hipStream_t)stream);
+}
+
+// 0 = no wait has timed out since the scratch was zeroed (synchronises the stream)
+CPG_EXPORT int cpg_gru_chain_status(int B, const void* sync_scratch, void* stream) {
+    CPG_CHECK_ARG(sync_scratch && B > 0);
+    unsigned v = 0;
+    CPG_HIP(hipMemcpyAsync(&v, (const unsigned*)sync_scratch + chain_cnt_words(B), sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CPG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return (int)v;
 }

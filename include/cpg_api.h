@@ -142,6 +142,26 @@ CPG_API size_t cpg_gru_persistent_bwd_scratch_bytes(int T, int B, int H);
 CPG_API int cpg_gru_seq_bwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                        const float* dhs_ext, const float* dh_last, float* dG, float* dh0, void* sync_scratch,
                                        void* stream);
+/* BPTT as ONE launch without a stationary operand ("chain", csrc/gru.hip): the tiles of the per-step backward kernel run the
+ * whole time loop; the column-tile workgroups of a row tile hand dgh rows to each other through dG itself (write-through
+ * stores + one arrival counter per row tile), z (.) dH stays in registers, both directions of a biGRU layer alternate inside
+ * the same workgroups.  Arguments and results as cpg_gru_seq_bwd / cpg_gru_biseq_bwd over all rows of a dense batch (no
+ * step_rows); results are bit-identical to the per-step launches on the same tiles.  cpg_gru_chain_bwd_covers: 1 when every
+ * workgroup is co-resident on this device; cpg_gru_chain_bwd_fits: the launch policy on top of it (measured no faster than the
+ * per-step launches, so only with CPG_GRU_BWD_CHAIN=1).  sync_scratch: cpg_gru_chain_scratch_bytes(B) bytes, zeroed by
+ * the caller when allocated; cpg_gru_chain_status reads its sticky error word (0 = no wait has timed out).
+ * w_hhT_scratch [H,3H] per direction: used in the bf16 compute mode only (may be null otherwise). */
+CPG_API int cpg_gru_chain_bwd_covers(int T, int B, int H);
+CPG_API int cpg_gru_chain_bwd_fits(int T, int B, int H);
+CPG_API size_t cpg_gru_chain_scratch_bytes(int B);
+CPG_API int cpg_gru_seq_bwd_chain(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                                  const float* dhs_ext, const float* dh_last, float* dG, float* dh0, float* w_hhT_scratch,
+                                  void* sync_scratch, void* stream);
+CPG_API int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                                    const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                    const float* dhs_ext_r, float* dG_f, float* dG_r, float* w_hhT_scratch_f,
+                                    float* w_hhT_scratch_r, void* sync_scratch, void* stream);
+CPG_API int cpg_gru_chain_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
  * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.
  * kind 0 forward step, 1 backward step; ndir 1 | 2 (paired biGRU launches); have_wt: W_hh^T handed to the backward. */

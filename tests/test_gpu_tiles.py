@@ -18,7 +18,8 @@ from helpers import (check_decoder_teacher_forced_golden, check_encoder_golden, 
 
 pytestmark = pytest.mark.gpu
 MODELS = ["A", "micro", "enc2"]
-KNOBS = ("CPG_GRU_FWD_BM", "CPG_GRU_BWD_BM", "CPG_GRU_BWD_WIDE", "CPG_GRU_BWD_TILE", "CPG_TN_TILE", "CPG_TN_SPLIT")
+KNOBS = ("CPG_GRU_FWD_BM", "CPG_GRU_BWD_BM", "CPG_GRU_BWD_WIDE", "CPG_GRU_BWD_TILE", "CPG_TN_TILE", "CPG_TN_SPLIT",
+         "CPG_GRU_BWD_CHAIN", "CPG_GRU_BWD_STAGGER")
 
 
 @pytest.fixture(autouse=True)
@@ -58,14 +59,16 @@ def test_forward_tiles_golden(golden, knobs, name, bm):
 
 BWD_VARIANTS = [dict(CPG_GRU_BWD_BM=32), dict(CPG_GRU_BWD_BM=64), dict(CPG_GRU_BWD_BM=128),
                 dict(CPG_GRU_BWD_WIDE=32), dict(CPG_GRU_BWD_WIDE=64), dict(CPG_GRU_BWD_WIDE=128)] + \
-               [dict(CPG_GRU_BWD_TILE=t) for t in ("64x32", "32x64", "64x64", "128x32", "128x64", "32x32")]
+               [dict(CPG_GRU_BWD_TILE=t) for t in ("64x32", "32x64", "64x64", "128x32", "128x64", "32x32")] + \
+               [dict(CPG_GRU_BWD_WIDE=3264), dict(CPG_GRU_BWD_STAGGER=0), dict(CPG_GRU_BWD_STAGGER=2), dict(CPG_GRU_BWD_CHAIN=1)]
 
 
 @pytest.mark.parametrize("variant", BWD_VARIANTS, ids=lambda v: "-".join(f"{k[12:]}{x}" for k, x in v.items()))
 @pytest.mark.parametrize("name", MODELS)
 def test_backward_tiles_golden(golden, knobs, name, variant):
     """gru_step_bwd_kernel<GB32|GB64|GB128|GB32N|GB64W|GB128W> on the exact-f32 path (BM / WIDE knobs; GB32N = 32x32 tiles
-    is the bench's) and on the split-bf16 path with W_hh^T handed over (TILE knob)."""
+    is the bench's) and on the split-bf16 path with W_hh^T handed over (TILE knob); 64-deep slabs (WIDE=3264); the staggered
+    epilogue-operand fetch at other spacings; the one-launch BPTT (CHAIN=1: whole model through cpg_gru_*_bwd_chain)."""
     knobs(**variant)
     check_losses_and_grads_golden(golden("model_" + name))
 
@@ -177,6 +180,15 @@ def test_config_b_step_vs_oracle():
     m, P, ids, rnd = _random_case(2048, 25, 24, 510, 512, 1, seed=11)
     _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
     _check_greedy_vs_oracle(m, P, 512, 25, seed=12)
+
+
+def test_config_b_step_one_launch_bptt_vs_oracle(knobs):
+    """The same step with both backward recurrences (decoder, encoder pair) as one-launch chains (CPG_GRU_BWD_CHAIN=1)."""
+    knobs(CPG_GRU_BWD_CHAIN=1)
+    m, P, ids, rnd = _random_case(1024, 25, 24, 510, 512, 1, seed=21)
+    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
+    from cpg import ops
+    ops.check_persistent()
 
 
 def test_config_b_full_mmd_regulariser_vs_oracle():

@@ -72,6 +72,20 @@ def main():
     def bwdp():
         ops.gru_seq_bwd_persistent(T, B, H, False, w_hh, hs, gates, dhs, None, dG, dh0)
 
+    def bwdc():
+        ops.gru_seq_bwd_chain(T, B, H, False, w_hh, hs, gates, dhs, None, dG, dh0, wT)
+
+    dG2 = torch.empty(T, B, 4 * H, device=dev)
+    wT2 = torch.empty(2, H, 3 * H, device=dev)
+    sc2 = torch.empty(2, 2, B, H, device=dev)
+
+    def bwdc2():
+        ops.gru_biseq_bwd_chain(T, B, H, w_hh, w_hh, hs, hs, gates, gates, dhs, dhs, dG, dG2, wT2)
+
+    def bwd2():
+        call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), _p(dG), _p(dG2),
+             _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), _stream())
+
     big_ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)  # large enough for any split the knobs select
 
     def wgrad():
@@ -91,10 +105,15 @@ def main():
             fp = timeit(fwdp, a.iters) / T if ops.persistent_fits(B, H) else float("nan")
             bp = timeit(bwdp, a.iters) / (T + 1) if ops.persistent_fits(B, H) else float("nan")
             b = timeit(bwd, a.iters) / (T + 1)
+            chain_ok = ops.chain_bwd_fits(T, B, H)
+            bc = timeit(bwdc, a.iters) / (T + 1) if chain_ok else float("nan")
+            bc2 = timeit(bwdc2, a.iters) / T if chain_ok else float("nan")
+            b2 = timeit(bwd2, a.iters) / T
             w = timeit(wgrad, a.iters)
             for k in env:
                 os.environ.pop(k, None)
             print(f"[{rnd}] {label:24s} fwd-persistent {fp:7.1f} us/step ({fl_step / fp / 1e6:6.1f} TF)  bwd-persistent {bp:7.1f} us/step ({fl_step / bp / 1e6:6.1f} TF)")
+            print(f"[{rnd}] {label:24s} bwd-chain {bc:7.1f} us/step  pair: chain {bc2:7.1f} us/step, per-step launches {b2:7.1f} us/step")
             print(f"[{rnd}] {label:24s} fwd {f:7.1f} us/step ({fl_step / f / 1e6:6.1f} TF)  bwd {b:7.1f} us/step "
                   f"({fl_step / b / 1e6:6.1f} TF)  wgrad {w:8.1f} us ({fl_step * T / w / 1e6:6.1f} TF)")
 
