@@ -72,7 +72,8 @@ __device__ __forceinline__ float p_tanh(float x) {
 
 constexpr int P_CT = 16;          // hidden units per workgroup
 #ifndef CPG_PERSIST_WAVES
-#define CPG_PERSIST_WAVES 4
+#define CPG_PERSIST_WAVES 8       // two waves per SIMD: one wave's cell arithmetic, stores and waits run under the other's MFMAs
+                                  // (21.8 us per step against 26.8 with 4 - once the arrival counters sit on separate lines)
 #endif
 #ifndef CPG_PERSIST_DEFER
 #define CPG_PERSIST_DEFER 0       // 1: the f32 state / gate stores of step p are issued after the wait of step p+1
@@ -90,6 +91,11 @@ constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
 constexpr int P_NC = 3 * P_CT;    // gate columns per workgroup
 constexpr int P_TBW = 16;         // words per row of the per-wave 16x16 transposition buffer
+#ifndef CPG_PERSIST_CNT_STRIDE
+#define CPG_PERSIST_CNT_STRIDE 64  // words between arrival counters: one 256-byte line each, so the adds and polls of different
+                                   // row tiles do not queue on one memory channel
+#endif
+constexpr int P_CNT_STRIDE = CPG_PERSIST_CNT_STRIDE;
 constexpr unsigned P_SPIN_LIMIT = 400000u;  // ~0.2 s of polling before a wave gives up (sets the error word)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         publish_rows<NP>(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // A-operand addressing: lane (l15, lq) of row block mi reads 8 consecutive k of row row0 + 16 mi + l15 (16 bytes of a plane)
     int aoff[P_MI];
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 gi[mi][r][0] = x0; gi[mi][r][1] = x1; gi[mi][r][2] = x2;
             }
 
-        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt, (unsigned)(NCT * (p + 1)), a.err, dead);
+        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, dead);
         if (CPG_PERSIST_DEFER) flush();
 #if CPG_PERSIST_ACQUIRE
         // plain (L2-allocating) loads behind ONE agent-scope acquire: the 32 column-tile workgroups of a row tile read the
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                              out_off + (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_tt = tt;
         if (!CPG_PERSIST_DEFER) flush();
     }
@@ -508,7 +514,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            wait_ge(a.cnt + rt, (unsigned)(NCT * step), a.err, dead);
+            wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * step), a.err, dead);
             const unsigned in_off = (unsigned)(step - 1) * 3u * plane_bytes;
             u32x4 buf[PB_DEPTH][P_MI][NP];
             const int rot = CPG_PERSIST_ROTATE ? (ct * KB) / NCT : 0;   // see the forward kernel: spread the readers over the L2 channels
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist
         }
         if (closing) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -621,7 +627,8 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
     return cus > 0 && wgs <= cus;
 }
 
-static size_t sync_words(int B) { return ((size_t)cdiv(B, P_WROWS) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
+static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_CNT_STRIDE; }
+static size_t sync_words(int B) { return (cnt_words(B) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
 
 CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
     // + one exchange slot of three bf16 planes per step (+ the initial state): slots are never reused inside a launch
@@ -643,11 +650,11 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     }
     hipStream_t s = (hipStream_t)stream;
     const int nrt = cdiv(B, P_WROWS);
-    CPG_HIP(hipMemsetAsync(sync_scratch, 0, (size_t)nrt * sizeof(unsigned), s));  // counters only: the error word is sticky
+    CPG_HIP(hipMemsetAsync(sync_scratch, 0, cnt_words(B) * sizeof(unsigned), s));  // counters only: the error word is sticky
     PFwdArgs a;
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.gates = gates;
     a.cnt = (unsigned*)sync_scratch;
-    a.err = a.cnt + nrt;
+    a.err = a.cnt + cnt_words(B);
     a.xch = (uint16_t*)(a.cnt + sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(nrt, P_WAVES);
@@ -669,7 +676,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
 // Error word of the last persistent launch that used this scratch (synchronises the stream): 0 = every wait completed.
 CPG_EXPORT int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream) {
     unsigned v = 0;
-    const unsigned* p = (const unsigned*)sync_scratch + cdiv(B, P_WROWS);
+    const unsigned* p = (const unsigned*)sync_scratch + cnt_words(B);
     if (hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     return (int)v;
@@ -720,11 +727,11 @@ CPG_EXPORT int cpg_gru_seq_bwd_persistent(int T, int B, int H, int reverse, cons
     }
     hipStream_t s = (hipStream_t)stream;
     const int nrt = cdiv(B, P_WROWS);
-    CPG_HIP(hipMemsetAsync(sync_scratch, 0, (size_t)nrt * sizeof(unsigned), s));
+    CPG_HIP(hipMemsetAsync(sync_scratch, 0, cnt_words(B) * sizeof(unsigned), s));
     PBwdArgs a;
     a.w_hh = w_hh; a.hs = hs; a.gates = gates; a.dhs_ext = dhs_ext; a.dh_last = dh_last; a.dG = dG; a.dh0 = dh0;
     a.cnt = (unsigned*)sync_scratch;
-    a.err = a.cnt + nrt;
+    a.err = a.cnt + cnt_words(B);
     a.xch = (uint16_t*)(a.cnt + sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(nrt, P_WAVES);
