@@ -154,6 +154,9 @@ using T128x64 = TileCfg<128, 64, 32, 2, 2, 1>;
 using T128x32 = TileCfg<128, 32, 32, 4, 1, 1>;
 using T32x128 = TileCfg<32, 128, 32, 1, 4, 1>;
 using T64x64 = TileCfg<64, 64, 32, 2, 2, 1>;
+using T64x32 = TileCfg<64, 32, 32, 4, 1, 1>;   // small tiles for products with few 64x64 tiles (exact-f32 engine only)
+using T32x64 = TileCfg<32, 64, 32, 2, 2, 1>;
+using T32x32 = TileCfg<32, 32, 32, 2, 2, 1>;
 using T128x128 = TileCfg<128, 128, 32, 2, 2, 1>;
 // 512-thread workgroup (two waves per SIMD from ONE workgroup), each wave a 64x64 block: the dW_hh product.  One such
 // workgroup per CU (150 KB of split-plane LDS images); operand traffic per MAC is 2/3 of the 128x64 tile's.
@@ -193,9 +196,23 @@ static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s, TnTile force 
             default: break;
         }
     }
+    if constexpr (A_KC) {  // nn.Linear forward / input-gradient products (exact-f32 engine): CPG_GEMM_TILE forces a tile
+        if (const char* e = getenv("CPG_GEMM_TILE")) {
+            if (!strcmp(e, "128x64")) return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
+            if (!strcmp(e, "64x64")) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
+            if (!strcmp(e, "64x32")) return launch_tc<T64x32, A_KC, B_KC>(g, zdim, vec, s);
+            if (!strcmp(e, "32x64")) return launch_tc<T32x64, A_KC, B_KC>(g, zdim, vec, s);
+            if (!strcmp(e, "32x32")) return launch_tc<T32x32, A_KC, B_KC>(g, zdim, vec, s);
+            if (!strcmp(e, "128x32")) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
+            if (!strcmp(e, "32x128")) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
+        }
+    }
     if (g.M <= 32) return launch_tc<T32x128, A_KC, B_KC>(g, zdim, vec, s);
     if (g.N <= 32) return launch_tc<T128x32, A_KC, B_KC>(g, zdim, vec, s);
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * zdim;
+    // tools/gbench.py on MI355X: below two 128x64 tiles per CU, and for very short contractions (the launch is all epilogue),
+    // 64x64 tiles are 20-25 % faster (rowc product 50 -> 40 us, d logits -> d out at K=24 55 -> 41 us)
+    if (A_KC && (tiles128 < 512 || g.K <= 64)) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
     if (tiles128 < 256) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
     return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
 }

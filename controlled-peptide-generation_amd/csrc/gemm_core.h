@@ -36,6 +36,9 @@
 #ifndef CPG_KC_PAD
 #define CPG_KC_PAD 8
 #endif
+#ifndef CPG_XC_PERM_PAD
+#define CPG_XC_PERM_PAD 4   // pad of a transposed-use image whose partner operand is K-contiguous (see TileCfg::xc_pad)
+#endif
 #ifndef CPG_LOOP_UNROLL2
 #define CPG_LOOP_UNROLL2 1
 #endif
@@ -76,16 +79,23 @@ struct TileCfg {
     // 8, 24, 40 or 56 words modulo 64 (MI355X_MICROARCH.md LDS table; PMC: BK + 4 = 36 words cost 38 % of the backward step's
     // LDS cycles in bank conflicts, BK + 8 = 40 none)
     static constexpr int KPAD = CPG_KC_PAD;
-    template <bool KC>
-    static constexpr int lda() { return KC ? BK + KPAD : BM + 16; }
-    template <bool KC>
-    static constexpr int ldb() { return KC ? BK + KPAD : BN + 16; }
-    template <bool KC>
-    static constexpr int a_elems() { return KC ? BM * (BK + KPAD) : BK * (BM + 16); }
-    template <bool KC>
-    static constexpr int b_elems() { return KC ? BN * (BK + KPAD) : BK * (BN + 16); }
+    // Transposed-use ("XC", [k][x]) images are read one dword per lane: lane (x = l&15, q = l>>4) reads row k(q, j).  With both
+    // operands XC the four lane groups read CONSECUTIVE k rows (k = 16h + 4j + q) and a row stride of X + 16 words puts them on
+    // distinct bank quarters; when the OTHER operand is K-contiguous the contraction order is permuted (k = 16h + 4q + j, see
+    // MainLoop::PERM) and the groups read rows 4 apart: stride X + 16 then maps all four onto the SAME 16 banks (4-way conflict
+    // on every fragment read - PMC: 29 % of the backward step's LDS cycles), stride X + 4 (4 * stride = 16 mod 64) spreads them.
+    template <bool OTHER_KC>
+    static constexpr int xc_pad() { return OTHER_KC ? CPG_XC_PERM_PAD : 16; }
+    template <bool KC, bool OTHER_KC>
+    static constexpr int lda() { return KC ? BK + KPAD : BM + xc_pad<OTHER_KC>(); }
+    template <bool KC, bool OTHER_KC>
+    static constexpr int ldb() { return KC ? BK + KPAD : BN + xc_pad<OTHER_KC>(); }
+    template <bool KC, bool OTHER_KC>
+    static constexpr int a_elems() { return KC ? BM * (BK + KPAD) : BK * (BM + xc_pad<OTHER_KC>()); }
+    template <bool KC, bool OTHER_KC>
+    static constexpr int b_elems() { return KC ? BN * (BK + KPAD) : BK * (BN + xc_pad<OTHER_KC>()); }
     template <bool AKC, bool BKC>
-    static constexpr int smem_floats() { return 2 * (a_elems<AKC>() + b_elems<BKC>()); }
+    static constexpr int smem_floats() { return 2 * (a_elems<AKC, BKC>() + b_elems<BKC, AKC>()); }
 };
 
 // XCD-aware tile order (MI355X: 8 XCDs with private 4 MiB L2s; workgroup `id` is observed to run on XCD id % 8 - used for
@@ -170,10 +180,10 @@ __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, ui
 template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC, bool MASKS = false, int SPLIT = 0>
 struct MainLoop {
     static constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK;
-    static constexpr int LDA = TC::template lda<A_KC>();
-    static constexpr int LDB = TC::template ldb<B_KC>();
-    static constexpr int ASZ = TC::template a_elems<A_KC>();
-    static constexpr int BSZ = TC::template b_elems<B_KC>();
+    static constexpr int LDA = TC::template lda<A_KC, B_KC>();
+    static constexpr int LDB = TC::template ldb<B_KC, A_KC>();
+    static constexpr int ASZ = TC::template a_elems<A_KC, B_KC>();
+    static constexpr int BSZ = TC::template b_elems<B_KC, A_KC>();
     // K-index of MFMA k-step s (0..BK/4-1), lane group q (0..3).  When an operand is K-contiguous its fragments are read
     // 16 bytes at a time (4 consecutive k per lane), so within each 16-deep half the contraction index is permuted:
     // step j of half h contracts k = 16h + 4q + j.  Any bijection works as long as A and B agree.

@@ -801,6 +801,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
+    if (w_hhT_scratch && !gru_bwd_choice(row_end - row_begin, H, 1, true).wt) w_hhT_scratch = nullptr;  // exact-f32 tiles: W_hh as stored
     if (w_hhT_scratch) {
         int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream);
         if (rc) return rc;
@@ -995,6 +996,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
                                  float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
+    if (w_hhT_scratch_f && !gru_bwd_choice(B, H, 2, true).wt) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // exact-f32 tiles
     if (w_hhT_scratch_f) {
         int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream);
         if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream);
