@@ -213,6 +213,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(args.steps):
         out = step(args.warmup + it)
+    t_enqueued = time.perf_counter() - t0   # host time to enqueue the K steps (no host sync inside a step)
     torch.cuda.synchronize()
     cdist.barrier()
     torch.cuda.synchronize()
@@ -260,7 +261,7 @@ def main():
     roofline["kernel_ms_per_step_all_launch_shapes"] = round(by_kernel.get(top_kernel, 0.0), 3)
     gates = 3 if args.cell == "gru" else 4
     step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
-    extra = {"loss_last_step": round(loss_val, 4), "executed_step_tflops_per_gpu": round(step_tflops, 2),
+    extra = {"loss_last_step": round(loss_val, 4), "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3), "executed_step_tflops_per_gpu": round(step_tflops, 2),
              "executed_step_frac_of_f32_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
              "kernel_families": [r for r in rows if r is not roofline]}
     ops.check_persistent()

@@ -23,6 +23,7 @@ struct GemmArgs {
     const uint8_t* c_mask; float c_mscale;   // multiplies C on store (same indexing as C)
     int k_chunk;        // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)), writes slab z
     size_t slab_stride; // floats between slabs (0 when not split)
+    int pairs_a = 0, pairs_b = 0;  // 8-byte pairs of the scalar staging path are safe (OpA::pairs), set by launch_gemm
 };
 
 // PREC: 7 = f32-grade, 1 = bf16 compute mode (cpg_set_compute_mode(1)); only the transposed-use (dW = dY^T X) products run on
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     }
     const size_t aoff = A_KC ? (size_t)kb : (size_t)kb * g.lda;
     const size_t boff = B_KC ? (size_t)kb : (size_t)kb * g.ldb;
-    OpA a{g.A + aoff, g.lda, m0, g.M, g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale};
-    OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale};
+    OpA a{g.A + aoff, g.lda, m0, g.M, g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a};
+    OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale, g.pairs_b};
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -179,7 +180,12 @@ static TnTile tn_tile_knob() {
 }
 
 template <bool A_KC, bool B_KC>
-static int launch_gemm(const GemmArgs& g, int zdim, hipStream_t s, TnTile force = TN_AUTO) {
+static int launch_gemm(const GemmArgs& g_in, int zdim, hipStream_t s, TnTile force = TN_AUTO) {
+    GemmArgs g = g_in;
+    // rows that are only 8-byte aligned (z_dim = 510): the scalar staging path may move pairs (gemm_core.h, fetch)
+    const bool even_k = g.K % 2 == 0 && g.k_chunk % 2 == 0;
+    g.pairs_a = (((uintptr_t)g.A) & 7) == 0 && g.lda % 2 == 0 && (A_KC ? even_k : g.M % 2 == 0);
+    g.pairs_b = (((uintptr_t)g.B) & 7) == 0 && g.ldb % 2 == 0 && (B_KC ? even_k : g.N % 2 == 0);
     // 16-byte operand loads need aligned bases / leading dimensions and vectors that never straddle a bound
     const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
                      (!g.a_mask || (((uintptr_t)g.a_mask) & 3) == 0) && (!g.b_mask || (((uintptr_t)g.b_mask) & 3) == 0) &&

@@ -50,6 +50,7 @@ struct OpA {
     int M;                // bound on the M index
     const uint8_t* mask;  // optional keep-mask with the same indexing as p (value = p * (mask ? mscale : 0))
     float mscale;
+    int pairs = 0;        // 1: 8-byte pairs of the scalar (non-16-byte) staging path are aligned and never straddle a bound
 };
 
 struct OpB {
@@ -60,6 +61,7 @@ struct OpB {
     int seg_stride;  // row/col offset between segments
     const uint8_t* mask;
     float mscale;
+    int pairs = 0;   // as OpA::pairs
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSEG_, int NT_ = 256>
@@ -285,8 +287,11 @@ struct MainLoop {
 
     // Unconditional (clamped) loads; validity bits are applied at LDS-store time, after the MFMA phase they overlap with.
     template <bool KC, bool VEC>
+    // (pairs: operands whose rows are only 8-byte aligned - z_dim = 510 - go as two 8-byte loads instead of four dwords with
+    //  four predicates: half the memory instructions and a third of the VALU work of the scalar path, which the exact-f32
+    //  MFMA cannot overlap with)
     __device__ static __forceinline__ float4 fetch(const float* p, const uint8_t* mask, size_t base, int n, bool rok, int ld,
-                                                   int k0, int K, int kk_xc, unsigned& okbits, uchar4& mk) {
+                                                   int k0, int K, int kk_xc, unsigned& okbits, uchar4& mk, bool pairs) {
         if (KC) {
             const int nk = K - (k0 + n);  // n = 4*kq
             if (VEC) {
@@ -295,6 +300,14 @@ struct MainLoop {
                 const size_t o = ok ? base + k0 : 0;
                 if (MASKS && mask) mk = *reinterpret_cast<const uchar4*>(mask + o);
                 return *reinterpret_cast<const float4*>(p + o);
+            }
+            if (pairs && !(MASKS && mask)) {
+                const bool ok0 = rok && nk >= 2, ok1 = rok && nk >= 4;
+                okbits = (ok0 ? 3u : 0u) | (ok1 ? 12u : 0u);
+                const float2 lo = *reinterpret_cast<const float2*>(p + (ok0 ? base + k0 : 0));
+                const float2 hi = *reinterpret_cast<const float2*>(p + (ok1 ? base + k0 + 2 : 0));
+                mk = make_uchar4(1, 1, 1, 1);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
             }
             float t[4];
             unsigned char m4[4] = {1, 1, 1, 1};
@@ -318,6 +331,15 @@ struct MainLoop {
                 if (MASKS && mask) mk = *reinterpret_cast<const uchar4*>(mask + o);
                 return *reinterpret_cast<const float4*>(p + o);
             }
+            if (pairs && !(MASKS && mask)) {
+                const bool ok0 = kok && n >= 2, ok1 = kok && n >= 4;
+                okbits = (ok0 ? 3u : 0u) | (ok1 ? 12u : 0u);
+                const size_t o = base + (size_t)k0 * ld;
+                const float2 lo = *reinterpret_cast<const float2*>(p + (ok0 ? o : 0));
+                const float2 hi = *reinterpret_cast<const float2*>(p + (ok1 ? o + 2 : 0));
+                mk = make_uchar4(1, 1, 1, 1);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
             float t[4];
             unsigned char m4[4] = {1, 1, 1, 1};
             okbits = 0;
@@ -339,13 +361,13 @@ struct MainLoop {
         for (int i = 0; i < TC::AV; ++i) {
             int kk, xq_;
             xc_index<BM>(i, kk, xq_);
-            st.a[i] = fetch<A_KC, AVEC>(a.p, a.mask, pl.a[i], pl.an[i], pl.aok[i], a.ld, k0, K, kk, st.aok[i], st.am[i]);
+            st.a[i] = fetch<A_KC, AVEC>(a.p, a.mask, pl.a[i], pl.an[i], pl.aok[i], a.ld, k0, K, kk, st.aok[i], st.am[i], a.pairs != 0);
         }
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
             int kk, xq_;
             xc_index<BN>(i, kk, xq_);
-            st.b[i] = fetch<B_KC, BVEC>(b.p, b.mask, pl.b[i], pl.bn[i], pl.bok[i], b.ld, k0, K, kk, st.bok[i], st.bm[i]);
+            st.b[i] = fetch<B_KC, BVEC>(b.p, b.mask, pl.b[i], pl.bn[i], pl.bok[i], b.ld, k0, K, kk, st.bok[i], st.bm[i], b.pairs != 0);
         }
     }
 

@@ -514,13 +514,14 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (step > 0) {
-            wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * step), a.err, dead);
+            if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * step), a.err, dead);
             const unsigned in_off = (unsigned)(step - 1) * 3u * plane_bytes;
             u32x4 buf[PB_DEPTH][P_MI][NP];
             const int rot = CPG_PERSIST_ROTATE ? (ct * KB) / NCT : 0;   // see the forward kernel: spread the readers over the L2 channels
             auto load = [&](u32x4 (&b)[P_MI][NP], int kbi) {
                 int kb = kbi + rot;
                 kb = kb >= KB ? kb - KB : kb;
+                if ((CPG_PERSIST_ABLATE & 2) && kbi >= PB_DEPTH) return;
 #pragma unroll
                 for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
@@ -534,6 +535,11 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) fb[pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + kb * 16);
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+                if (CPG_PERSIST_ABLATE & 4) {
+#pragma unroll
+                    for (int mi = 0; mi < P_MI; ++mi) acc[mi] += __builtin_bit_cast(f32x4, b[mi][0]) * __builtin_bit_cast(f32x4, fb[0]);
+                    return;
+                }
 #pragma unroll
                 for (int tm = (NP == 3 ? 0 : 5); tm < 6; ++tm)
 #pragma unroll
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist
             publish_rows<NP>(dr_pre, rx, voff, plane_bytes, out_off + kb0, ok, lane);
             publish_rows<NP>(dz_pre, rx, voff, plane_bytes, out_off + kb0 + kbH, ok, lane);
             publish_rows<NP>(dhn, rx, voff, plane_bytes, out_off + kb0 + 2 * kbH, ok, lane);
-            if (ok) {
+            if (ok && !(CPG_PERSIST_ABLATE & 16)) {
                 float* d = a.dG + ((size_t)t * B + row) * 4 * H + j0 + 4 * scq;
                 *reinterpret_cast<f32x4*>(d) = dr_pre;
                 *reinterpret_cast<f32x4*>(d + H) = dz_pre;

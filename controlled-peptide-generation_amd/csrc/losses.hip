@@ -2,6 +2,7 @@
 // Every reduction is two-stage with a fixed partition (block partials in a fixed order, then one block) so results are
 // run-to-run deterministic; sums and counts are returned separately so a data-parallel caller can all-reduce them and
 // still obtain the single-device value.
+#include "gemm_core.h"
 #include "cpg_internal.h"
 
 #define RED_BLOCKS 256
@@ -286,51 +287,116 @@ __device__ __forceinline__ void mmd_kern(float d, float inv_s2, float s2, float&
         w = 0.25f * q / u;
     }
 }
-template <int KIND>
-__global__ void mmd_full_partial_kernel(const float* G11, const float* G22, const float* G12, int N, float inv_s2, float s2,
-                                        float* part, float* P, float* Q) {
+// ---- fused form: the three Gram products as ONE launch on the f32 MFMA tile engine (blockIdx.z: K11, K22, K12) whose epilogue
+// applies the kernel and reduces the workgroup's tile - the Gram matrices are never written (they were 48 MB of round trip
+// at N = 2048 plus a 77 us element-wise pass), K11 / K22 tiles below the diagonal are skipped (their mirror images count twice).
+// Squared norms come from a row-norm pre-pass; d_ii is exactly 0 as in the reference's broadcast form.
+#ifndef CPG_MMD_SPLIT
+#define CPG_MMD_SPLIT 0   // 0: exact-f32 MFMA; 7: six bf16 MFMAs on 3-way split operands (f32-grade)
+#endif
+using MmdTile = TileCfg<128, 64, 32, 2, 2, 1>;
+struct MmdArgs {
+    const float* z1;
+    const float* z2;
+    const float* n1;   // [N] squared row norms
+    const float* n2;
+    float* part;       // [3][tiles][2] per-workgroup (sum K, sum diag K), zero for skipped tiles
+    float* P;          // [N,N] or null
+    float* Q;
+    int N, D, pairs;
+    float inv_s2, s2;
+};
+__global__ void rownorm2_kernel(const float* z1, const float* z2, int N, int D, float* n1, float* n2) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= 2 * N) return;
+    const float* r = (wave < N ? z1 : z2) + (size_t)(wave % N) * D;
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) s += r[k] * r[k];
+    s = wave_sum(s);
+    if (lane == 0) (wave < N ? n1 : n2)[wave % N] = s;
+}
+template <bool VEC, int KIND>
+__global__ __launch_bounds__(256) void mmd_gram_fused_kernel(MmdArgs g) {
+    using TC = MmdTile;
+    using Loop = MainLoop<TC, true, true, VEC, VEC, false, CPG_MMD_SPLIT>;
     __shared__ float red[8];
+    const int z = blockIdx.z, N = g.N;
+    const int m0 = blockIdx.y * TC::BM, n0 = blockIdx.x * TC::BN;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x, tiles = gridDim.x * gridDim.y;
+    const bool sym = z < 2;                           // K11, K22: symmetric
+    const bool need_all = (z == 0 && g.P != nullptr); // P wants every element of K11
     float v[2] = {0.f, 0.f};
-    const size_t n2 = (size_t)N * N;
-    const float cf = 1.f / ((float)N * (float)(N - 1));
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n2; idx += (size_t)RED_BLOCKS * 256) {
-        const int i = idx / N, j = idx % N;
-        const float a_i = G11[(size_t)i * N + i], a_j = G11[(size_t)j * N + j];
-        const float b_i = G22[(size_t)i * N + i], b_j = G22[(size_t)j * N + j];
-        float k11, k22, k12, w11, w22, w12;  // the reference's diagonal distances are exactly 0
-        mmd_kern<KIND>((i == j) ? 0.f : fmaxf(a_i + a_j - 2.f * G11[idx], 0.f), inv_s2, s2, k11, w11);
-        mmd_kern<KIND>((i == j) ? 0.f : fmaxf(b_i + b_j - 2.f * G22[idx], 0.f), inv_s2, s2, k22, w22);
-        mmd_kern<KIND>(fmaxf(a_i + b_j - 2.f * G12[idx], 0.f), inv_s2, s2, k12, w12);
-        const float h = k11 + k22 - 2.f * k12;
-        v[0] += h;
-        if (i == j) v[1] += h;
-        if (P) {
-            const float coef = (i == j) ? cf * (1.f - (float)N) : cf;
-            P[idx] = 2.f * coef * w11;
-            Q[idx] = -2.f * coef * w12;
+    if (!(sym && !need_all && n0 + TC::BN - 1 < m0)) {   // workgroup-uniform
+        const float* A = z == 1 ? g.z2 : g.z1;
+        const float* Bm = z == 0 ? g.z1 : g.z2;
+        const float* na = z == 1 ? g.n2 : g.n1;
+        const float* nb = z == 0 ? g.n1 : g.n2;
+        f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        OpA a{A, g.D, m0, N, nullptr, 1.f, g.pairs};
+        OpB b{Bm, g.D, n0, N, 0, nullptr, 1.f, g.pairs};
+        Loop::run(a, b, g.D, acc);
+        const float cf = 1.f / ((float)N * (float)(N - 1));
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) {
+            const int j = n0 + acc_col<TC>(ni);
+            if (j >= N) continue;
+            const float bj = nb[j];
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = m0 + acc_row<TC>(mi, r);
+                    if (i >= N) continue;
+                    const bool diag = sym && i == j;
+                    float k, w;
+                    mmd_kern<KIND>(diag ? 0.f : fmaxf(na[i] + bj - 2.f * acc[mi][ni][r], 0.f), g.inv_s2, g.s2, k, w);
+                    const float wt = (sym && !need_all) ? (j > i ? 2.f : (j == i ? 1.f : 0.f)) : 1.f;
+                    v[0] += wt * k;
+                    if (i == j) v[1] += k;
+                    if (z != 1 && g.P) {
+                        const float coef = (i == j) ? cf * (1.f - (float)N) : cf;
+                        if (z == 0) g.P[(size_t)i * N + j] = 2.f * coef * w;
+                        else g.Q[(size_t)i * N + j] = -2.f * coef * w;
+                    }
+                }
         }
     }
     block_sum<2>(v, red);
     if (threadIdx.x == 0) {
-        part[blockIdx.x * 2] = v[0];
-        part[blockIdx.x * 2 + 1] = v[1];
+        g.part[((size_t)z * tiles + tile) * 2] = v[0];
+        g.part[((size_t)z * tiles + tile) * 2 + 1] = v[1];
     }
 }
-__global__ void mmd_full_final_kernel(const float* part, int N, float* out) {
-    __shared__ float red[8];
-    float v[2] = {0.f, 0.f};
-    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) {
-        v[0] += part[i * 2];
-        v[1] += part[i * 2 + 1];
-    }
-    block_sum<2>(v, red);
+// out[0] = (sum H - N tr H) / (N (N-1)),  H = K11 + K22 - 2 K12;  out[1] = sum H, out[2] = tr H.  One block, fixed order.
+__global__ void mmd_fused_final_kernel(const float* part, int tiles, int N, float* out) {
+    __shared__ float red[24];
+    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < tiles; i += 256)
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+            v[2 * z] += part[((size_t)z * tiles + i) * 2];
+            v[2 * z + 1] += part[((size_t)z * tiles + i) * 2 + 1];
+        }
+    block_sum<6>(v, red);
     if (threadIdx.x == 0) {
-        out[0] = (v[0] - (float)N * v[1]) / ((float)N * (float)(N - 1));
-        out[1] = v[0];
-        out[2] = v[1];
+        const float sum = (v[0] + v[2]) - 2.f * v[4], tr = (v[1] + v[3]) - 2.f * v[5];
+        out[0] = (sum - (float)N * tr) / ((float)N * (float)(N - 1));
+        out[1] = sum;
+        out[2] = tr;
     }
 }
-CPG_EXPORT size_t cpg_mmd_full_workspace(int N) { return ((size_t)3 * N * N + 2 * RED_BLOCKS) * sizeof(float) + 256; }
+static size_t mmd_tiles(int N) { return (size_t)cdiv(N, MmdTile::BM) * cdiv(N, MmdTile::BN); }
+CPG_EXPORT size_t cpg_mmd_full_workspace(int N) { return ((size_t)2 * N + 6 * mmd_tiles(N)) * sizeof(float) + 256; }
+
+template <bool VEC, int KIND>
+static void mmd_launch(const MmdArgs& g, hipStream_t s) {
+    const size_t smem = MainLoop<MmdTile, true, true, VEC, VEC, false, CPG_MMD_SPLIT>::smem_bytes();
+    hipLaunchKernelGGL((mmd_gram_fused_kernel<VEC, KIND>), dim3(cdiv(g.N, MmdTile::BN), cdiv(g.N, MmdTile::BM), 3), dim3(256), smem, s, g);
+}
 
 // z1,z2 [N,D].  out[0] = loss.  P,Q [N,N] optional (null when no gradient is needed).  workspace: cpg_mmd_full_workspace(N).
 // kernel: 0 gaussian, 1 laplace, 2 energy (cfg.losses.wae_mmd.kernel, cfg.py:250).
@@ -340,23 +406,23 @@ CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, 
     CPG_CHECK_ARG(kernel >= 0 && kernel <= 2);
     CPG_CHECK_ARG(workspace_bytes >= cpg_mmd_full_workspace(N));
     hipStream_t s = (hipStream_t)stream;
-    float* G11 = (float*)workspace;
-    float* G22 = G11 + (size_t)N * N;
-    float* G12 = G22 + (size_t)N * N;
-    float* part = G12 + (size_t)N * N;
-    int rc = cpg_gemm_nt(z1, D, nullptr, 1.f, z1, D, nullptr, G11, N, N, N, D, 0, s);
-    if (!rc) rc = cpg_gemm_nt(z2, D, nullptr, 1.f, z2, D, nullptr, G22, N, N, N, D, 0, s);
-    if (!rc) rc = cpg_gemm_nt(z1, D, nullptr, 1.f, z2, D, nullptr, G12, N, N, N, D, 0, s);
-    if (rc) return rc;
-    const float s2 = sigma * sigma;
-#define CPG_MMD_LAUNCH(KIND)                                                                                               \
-    hipLaunchKernelGGL(mmd_full_partial_kernel<KIND>, dim3(RED_BLOCKS), dim3(256), 0, s, G11, G22, G12, N, 1.f / s2, s2, part, \
-                       P, Q)
-    if (kernel == 0) CPG_MMD_LAUNCH(0);
-    else if (kernel == 1) CPG_MMD_LAUNCH(1);
-    else CPG_MMD_LAUNCH(2);
+    MmdArgs g;
+    g.z1 = z1; g.z2 = z2; g.N = N; g.D = D; g.P = P; g.Q = Q;
+    float* n1 = (float*)workspace;
+    g.n1 = n1; g.n2 = n1 + N; g.part = n1 + 2 * (size_t)N;
+    g.s2 = sigma * sigma;
+    g.inv_s2 = 1.f / g.s2;
+    hipLaunchKernelGGL(rownorm2_kernel, dim3(cdiv(2 * N, 4)), dim3(256), 0, s, z1, z2, N, D, n1, n1 + N);
+    const bool vec = D % 4 == 0 && aligned16(z1) && aligned16(z2);
+    g.pairs = D % 2 == 0 && (((uintptr_t)z1) & 7) == 0 && (((uintptr_t)z2) & 7) == 0;
+#define CPG_MMD_LAUNCH(KIND)                 \
+    if (vec) mmd_launch<true, KIND>(g, s);   \
+    else mmd_launch<false, KIND>(g, s)
+    if (kernel == 0) { CPG_MMD_LAUNCH(0); }
+    else if (kernel == 1) { CPG_MMD_LAUNCH(1); }
+    else { CPG_MMD_LAUNCH(2); }
 #undef CPG_MMD_LAUNCH
-    hipLaunchKernelGGL(mmd_full_final_kernel, dim3(1), dim3(256), 0, s, (const float*)part, N, out);
+    hipLaunchKernelGGL(mmd_fused_final_kernel, dim3(1), dim3(256), 0, s, (const float*)g.part, (int)mmd_tiles(N), N, out);
     CPG_LAUNCH_CHECK();
     return 0;
 }
