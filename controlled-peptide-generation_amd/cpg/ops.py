@@ -372,9 +372,9 @@ def gru_seq_bwd_chain(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dG, d
          _p(wT), _p(_chain_scratch(B, hs.device)), _stream())
 
 
-def gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT=None):
+def gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT=None, last_f=None, last_r=None):
     call("cpg_gru_biseq_bwd_chain", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-         _p(dG_f), _p(dG_r), _p(wT[0] if wT is not None else None), _p(wT[1] if wT is not None else None),
+         _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(wT[0] if wT is not None else None), _p(wT[1] if wT is not None else None),
          _p(_chain_scratch(B, hs_f.device)), _stream())
 
 
@@ -396,9 +396,13 @@ class GruSeqFn(Function):
     models/decoder.py:40-41,77).  Returns the state slab [(T+1),B,H] (layout in include/cpg_api.h)."""
 
     @staticmethod
-    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse, defer=False, step_rows=None):
-        """step_rows: optional device int32 [T] of live-row counts per step (length-sorted batch, see cpg_api.h)."""
+    def forward(ctx, tok, tab, rowc, dense, h0, w_hh, b_hh, T, reverse, defer=False, step_rows=None, tail=False):
+        """step_rows: optional device int32 [T] of live-row counts per step (length-sorted batch, see cpg_api.h).
+        tail (forward direction): return the step outputs only - slots 1..T as one [T,B,H] tensor - so that their gradient
+        arrives as it is consumed (time-aligned), not through autograd's slice backward (a slab-sized fill and a copy)."""
         dev = w_hh.device
+        ctx.tail = bool(tail)
+        assert not (tail and reverse)
         # deferred mode: the 80-GFLOP dW_hh product of this sequence runs on a side stream and is added straight into the
         # parameters' existing .grad buffers, overlapping with the rest of the backward pass (only with FusedAdamClip,
         # which joins before it reads the gradients)
@@ -440,7 +444,7 @@ class GruSeqFn(Function):
         ctx.dims = (T, B, H, bool(reverse))
         ctx.V = tab.shape[0] if tab is not None else 0
         ctx.has = (tab is not None, rowc is not None, dense is not None, h0 is not None)
-        return hs
+        return hs[1:] if tail else hs
 
     @staticmethod
     def backward(ctx, ghs):
@@ -451,7 +455,7 @@ class GruSeqFn(Function):
         BH = B * H
         flat = ghs.view(-1)
         # time-aligned gradients on the step outputs: slots 1..T (forward) / 0..T-1 (reverse)
-        dhs_ext = flat[BH:] if not reverse else flat[:T * BH]
+        dhs_ext = flat if ctx.tail else (flat[BH:] if not reverse else flat[:T * BH])
         has_tab, has_rowc, has_dense, has_h0 = ctx.has
         step_rows = ctx.step_rows
         # ragged batch: gradient rows of dead (t,row) pairs are not written but are read by the reductions below
@@ -476,7 +480,7 @@ class GruSeqFn(Function):
                     f.run(gi, lambda r0=r0, r1=r1: call(
                         "cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
                         _p(scratch), _p(dh0), r0, r1, _p(step_rows), None, _stream()))
-        if has_h0:
+        if has_h0 and not ctx.tail:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
@@ -515,7 +519,7 @@ class GruSeqFn(Function):
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
             ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2)
-        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None, None
+        return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None, None, None
 
 
 class GruBiSeqFn(Function):
@@ -523,8 +527,12 @@ class GruBiSeqFn(Function):
     work per launch amortises the fixed per-launch phases.  Returns (slab_fwd, slab_rev), layouts as GruSeqFn."""
 
     @staticmethod
-    def forward(ctx, tok, tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r, T):
+    def forward(ctx, tok, tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r, T, finals=False):
+        """finals: return only the two final states (forward slot T, reverse slot 0) - what a top encoder layer is read for.
+        Their gradients then enter the backward recurrence directly (dh_last), instead of through slab-sized zero tensors
+        that autograd's select/slice backward would allocate, fill and copy into (and every backward launch would read)."""
         dev = w_hh_f.device
+        ctx.finals = bool(finals)
         H = w_hh_f.shape[1]
         B = tok.shape[1] if tok is not None else dense_f.shape[1]
         cont = lambda t: t.contiguous() if t is not None else None
@@ -551,6 +559,8 @@ class GruBiSeqFn(Function):
         ctx.dims = (T, B, H)
         ctx.V = tab_f.shape[0] if tab_f is not None else 0
         ctx.has_tab, ctx.has_dense = tab_f is not None, dense_f is not None
+        if finals:
+            return hs_f[T], hs_r[0]
         return hs_f, hs_r
 
     @staticmethod
@@ -559,23 +569,29 @@ class GruBiSeqFn(Function):
         T, B, H = ctx.dims
         dev = hs_f.device
         BH = B * H
-        ext_f = g_hs_f.contiguous().view(-1)[BH:] if g_hs_f is not None else None      # slots 1..T
-        ext_r = g_hs_r.contiguous().view(-1)[:T * BH] if g_hs_r is not None else None  # slots 0..T-1
+        last_f = last_r = None
+        if ctx.finals:
+            ext_f = ext_r = None
+            last_f = g_hs_f.contiguous() if g_hs_f is not None else None
+            last_r = g_hs_r.contiguous() if g_hs_r is not None else None
+        else:
+            ext_f = g_hs_f.contiguous().view(-1)[BH:] if g_hs_f is not None else None      # slots 1..T
+            ext_r = g_hs_r.contiguous().view(-1)[:T * BH] if g_hs_r is not None else None  # slots 0..T-1
         dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
         if persistent_bwd_fits(T, B, H):
             with _prof("bwd_persist", 2, T=T, B=B, H=H, ndir=1):
-                gru_seq_bwd_persistent(T, B, H, False, wf, hs_f, gt_f, ext_f, None, dG_f, None)
-                gru_seq_bwd_persistent(T, B, H, True, wr, hs_r, gt_r, ext_r, None, dG_r, None)
+                gru_seq_bwd_persistent(T, B, H, False, wf, hs_f, gt_f, ext_f, last_f, dG_f, None)
+                gru_seq_bwd_persistent(T, B, H, True, wr, hs_r, gt_r, ext_r, last_r, dG_r, None)
         elif chain_bwd_fits(T, B, H):
             with _prof("bwd_chain", 1, T=T, B=B, H=H, ndir=2, steps=T):
-                gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT)
+                gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT, last_f, last_r)
         else:
             with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
                 call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                     _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+                     _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []
@@ -600,7 +616,7 @@ class GruBiSeqFn(Function):
             ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2) if ctx.has_dense else None
             outs.append((dtab, ddense, dw, db))
         (dtab_f, dd_f, dw_f, db_f), (dtab_r, dd_r, dw_r, db_r) = outs
-        return None, dtab_f, dtab_r, dd_f, dd_r, dw_f, db_f, dw_r, db_r, None
+        return None, dtab_f, dtab_r, dd_f, dd_r, dw_f, db_f, dw_r, db_r, None, None
 
 
 _pending_events = []

@@ -989,11 +989,13 @@ CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const
 }
 
 // BPTT of both directions in lock step (no initial-state gradient: the encoder starts from h0 = 0).
-// dhs_ext_* [T,B,H] time-aligned (null = zeros); dG_* [T,B,4H]; scratch_* [2,B,H].
+// dhs_ext_* [T,B,H] time-aligned (null = zeros); dh_last_* [B,H] gradient on the direction's final state (null = zeros);
+// dG_* [T,B,4H]; scratch_* [2,B,H].
 CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                                  const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                                 const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
-                                 float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream) {
+                                 const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
+                                 float* dG_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
+                                 float* w_hhT_scratch_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
     if (w_hhT_scratch_f && !gru_bwd_choice(B, H, 2, true).wt) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // exact-f32 tiles
@@ -1008,6 +1010,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
     const float* HS[2] = {hs_f, hs_r};
     const float* GT[2] = {gates_f, gates_r};
     const float* EX[2] = {dhs_ext_f, dhs_ext_r};
+    const float* LAST[2] = {dh_last_f, dh_last_r};
     float* DG[2] = {dG_f, dG_r};
     float* SC[2] = {scratch_f, scratch_r};
     int prev_t[2] = {-1, -1};
@@ -1035,7 +1038,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
                 a.z_next = nullptr;
             }
             a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
-            a.ext2 = nullptr;
+            a.ext2 = (p == T - 1) ? LAST[d] : nullptr;   // gradient on the direction's final state enters at its last step
             a.gates = GT[d] + (size_t)t * 4 * BH;
             a.h_prev = d ? HS[d] + (size_t)(t + 1) * BH : HS[d] + (size_t)t * BH;
             a.dH_out = SC[d] + (size_t)cur * BH;
@@ -1325,8 +1328,9 @@ CPG_EXPORT int cpg_gru_seq_bwd_chain(int T, int B, int H, int reverse, const flo
 // Both directions of a biGRU layer (arguments as cpg_gru_biseq_bwd) in one launch.
 CPG_EXPORT int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                                        const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                                       const float* dhs_ext_r, float* dG_f, float* dG_r, float* w_hhT_scratch_f,
-                                       float* w_hhT_scratch_r, void* sync_scratch, void* stream) {
+                                       const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
+                                       float* dG_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* sync_scratch,
+                                       void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r && sync_scratch);
     if (!cpg_gru_chain_bwd_covers(T, B, H)) {
         cpg_set_error("cpg_gru_biseq_bwd_chain: T=%d B=%d H=%d is not covered on this device", T, B, H);
@@ -1334,8 +1338,8 @@ CPG_EXPORT int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f,
     }
     GruChainArgs g;
     g.nd = 2; g.T = T; g.B = B; g.H = H;
-    g.d[0] = GruChainDir{w_hh_f, nullptr, hs_f, gates_f, dhs_ext_f, nullptr, dG_f, nullptr, 0};
-    g.d[1] = GruChainDir{w_hh_r, nullptr, hs_r, gates_r, dhs_ext_r, nullptr, dG_r, nullptr, 1};
+    g.d[0] = GruChainDir{w_hh_f, nullptr, hs_f, gates_f, dhs_ext_f, dh_last_f, dG_f, nullptr, 0};
+    g.d[1] = GruChainDir{w_hh_r, nullptr, hs_r, gates_r, dhs_ext_r, dh_last_r, dG_r, nullptr, 1};
     return chain_launch(g, sync_scratch, w_hhT_scratch_f, w_hhT_scratch_r, (hipStream_t)stream);
 }
 

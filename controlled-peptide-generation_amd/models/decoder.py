@@ -105,11 +105,11 @@ class GRUDecoder(nn.Module):
             rowc = rowc.index_select(0, perm)
             zc = zc.index_select(0, perm)
         if self.cell == 'gru':
-            slab = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True,
-                                      step_rows)
+            outs = ops.GruSeqFn.apply(tok, tab, rowc, None, zc, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False, True,
+                                      step_rows, True)                    # step outputs [T,B,H] (slots 1..T of the slab)
         else:
-            slab = ops.LstmSeqFn.apply(tok, tab, rowc, None, zc, None, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)
-        hs = slab[1:].reshape(T * B, self.h_dim)
+            outs = ops.LstmSeqFn.apply(tok, tab, rowc, None, zc, None, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)[1:]
+        hs = outs.reshape(T * B, self.h_dim)
         keep, scale = None, 1.0
         if out_keep is not None:
             keep = ops.transpose01_u8(out_keep.to(torch.uint8))          # [B,T,H] -> [T,B,H]

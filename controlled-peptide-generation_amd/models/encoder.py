@@ -42,7 +42,7 @@ class GRUEncoder(nn.Module):
 
     def _run(self, T, tok=None, emb_weight=None, dense_x=None):
         """Either (tok int32 [T,B], emb_weight) - token-table path - or dense_x [T,B,E] embeddings."""
-        slabs = None
+        slabs = finals = None
         dev = self.q_mu.weight.device
         for l in range(self.layers):
             pre = []
@@ -67,9 +67,12 @@ class GRUEncoder(nn.Module):
             if self.cell == 'gru' and self.biGRU and ops.OVERLAP:
                 # both directions share one launch per time step (GruBiSeqFn)
                 (tab_f, dense_f), (tab_r, dense_r) = pre
+                top = l == self.layers - 1   # the top layer is read for its two final states only
                 new = list(ops.GruBiSeqFn.apply(tok if l == 0 else None, tab_f, tab_r, dense_f, dense_r,
                                                 self._w("weight_hh", l, ""), self._w("bias_hh", l, ""),
-                                                self._w("weight_hh", l, "_reverse"), self._w("bias_hh", l, "_reverse"), T))
+                                                self._w("weight_hh", l, "_reverse"), self._w("bias_hh", l, "_reverse"), T, top))
+                if top:
+                    finals = new
                 slabs = new
                 continue
             for d, (sfx, rev) in enumerate(self._dirs()):
@@ -81,7 +84,8 @@ class GRUEncoder(nn.Module):
                     new.append(ops.LstmSeqFn.apply(tok if l == 0 else None, tab, None, dense, None, None, w_hh, b_hh, T, rev))
             slabs = new
         # final states of the top layer: forward slab slot T, reverse slab slot 0 (reference: cat(h[-2], h[-1]))
-        finals = [slabs[0][T]] + ([slabs[1][0]] if self.biGRU else [])
+        if finals is None:
+            finals = [slabs[0][T]] + ([slabs[1][0]] if self.biGRU else [])
         h = torch.cat(finals, 1) if len(finals) > 1 else finals[0]
         mu = ops.LinearFn.apply(h, self.q_mu.weight, self.q_mu.bias)
         logvar = ops.LinearFn.apply(h, self.q_logvar.weight, self.q_logvar.bias)

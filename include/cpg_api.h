@@ -115,9 +115,10 @@ CPG_API int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const fl
                               float* gates_r, void* stream);
 CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                               const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                              const float* dhs_ext_r, float* dG_f, float* dG_r, float* scratch_f, float* scratch_r,
-                              float* w_hhT_scratch_f, float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */,
-                              void* stream);
+                              const float* dhs_ext_r, const float* dh_last_f /* [B,H] gradient on the final state of the
+                              direction, or null */, const float* dh_last_r, float* dG_f, float* dG_r, float* scratch_f,
+                              float* scratch_r, float* w_hhT_scratch_f,
+                              float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */, void* stream);
 /* Persistent form: the WHOLE time loop of one direction in ONE launch (csrc/gru_persist.hip): each workgroup keeps the
  * W_hh rows of 16 hidden units in LDS (already split into bf16 planes) for 256 batch rows and the column-tile workgroups of
  * a row tile hand h_t to each other through the state slab (write-through stores + arrival counters), so nothing is
@@ -159,8 +160,9 @@ CPG_API int cpg_gru_seq_bwd_chain(int T, int B, int H, int reverse, const float*
                                   void* sync_scratch, void* stream);
 CPG_API int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                                     const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                                    const float* dhs_ext_r, float* dG_f, float* dG_r, float* w_hhT_scratch_f,
-                                    float* w_hhT_scratch_r, void* sync_scratch, void* stream);
+                                    const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
+                                    float* dG_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* sync_scratch,
+                                    void* stream);
 CPG_API int cpg_gru_chain_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
  * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.

@@ -42,7 +42,8 @@ def test_no_undeclared_exports(built):
 def test_workspace_queries_do_not_need_a_gpu(built):
     from cpg import lib
     L = lib()
-    assert L.dll.cpg_mmd_full_workspace(2048) >= 3 * 2048 * 2048 * 4
+    # row norms + per-tile partial sums only: the fused Gram kernel never materialises the three [N,N] matrices
+    assert 2 * 2048 * 4 <= L.dll.cpg_mmd_full_workspace(2048) < (1 << 20)
     assert L.dll.cpg_gru_wgrad_workspace(25, 2048, 512, 24) > 0
     assert L.dll.cpg_sumsq_workspace() > 0
 

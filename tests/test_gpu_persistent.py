@@ -227,19 +227,20 @@ def test_chain_backward_pair_matches_per_step_pair(B, H, T):
     hs_r, gt_r = _run(dr, B, H, T, True, False)
     g = torch.Generator().manual_seed(5)
     ext_f, ext_r = ((torch.randn(T, B, H, generator=g) * 0.1).to(dev) for _ in range(2))
+    last_f, last_r = ((torch.randn(B, H, generator=g) * 0.1).to(dev) for _ in range(2))   # gradients on the final states
     out = []
     for chain in (True, False):
         dG_f, dG_r = torch.zeros(T, B, 4 * H, device=dev), torch.zeros(T, B, 4 * H, device=dev)
         if chain:
             ops.gru_biseq_bwd_chain(T, B, H, df["w_hh"], dr["w_hh"], hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r,
-                                    torch.empty(2, H, 3 * H, device=dev))
+                                    torch.empty(2, H, 3 * H, device=dev), last_f, last_r)
             ops.check_persistent()
         else:
             sc = torch.empty(2, 2, B, H, device=dev)
             os.environ["CPG_GRU_BWD_WIDE"] = "32"
             try:
                 call("cpg_gru_biseq_bwd", T, B, H, _p(df["w_hh"]), _p(dr["w_hh"]), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r),
-                     _p(ext_f), _p(ext_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), None, None, _stream())
+                     _p(ext_f), _p(ext_r), _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), None, None, _stream())
             finally:
                 os.environ.pop("CPG_GRU_BWD_WIDE")
         torch.cuda.synchronize()

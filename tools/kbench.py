@@ -83,7 +83,7 @@ def main():
         ops.gru_biseq_bwd_chain(T, B, H, w_hh, w_hh, hs, hs, gates, gates, dhs, dhs, dG, dG2, wT2)
 
     def bwd2():
-        call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), _p(dG), _p(dG2),
+        call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), None, None, _p(dG), _p(dG2),
              _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), _stream())
 
     big_ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)  # large enough for any split the knobs select
