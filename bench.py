@@ -74,6 +74,17 @@ def family_roofline(family, dims, avg_us, launches):
     elif family == "wgrad_hh":
         kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), 2.0 * 3 * H * H * T * B
         split = 2 if kernel.endswith(", 1>") else 1
+    elif family == "bwd_chain":   # one launch for the whole recurrence (CPG_GRU_BWD_CHAIN=1); flops per step of the chain
+        tc = "TileCfg<64, 32, 32, 4, 1, 1, 256>, true, 1" if bf16 else "TileCfg<32, 32, 32, 2, 2, 1, 256>, false, 7"
+        kernel, split = "gru_seq_bwd_chain_kernel<%s>" % tc, (2 if bf16 else 0)
+        flops = dims.get("steps", T) * nd * 2.0 * B * 3 * H * H
+    elif family in ("lstm_fwd_step", "lstm_bwd_step"):   # LSTM extension: four gates
+        kind = 0 if family == "lstm_fwd_step" else 1
+        kernel, split = _cname("cpg_lstm_step_kernel_name", kind, B, H), L.cpg_lstm_step_kernel_is_split(kind, B, H)
+        flops = 2.0 * B * H * 4 * H
+    elif family == "lstm_wgrad_hh":
+        kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 4 * H, H), 2.0 * 4 * H * H * T * B
+        split = 2 if kernel.endswith(", 1>") else 1
     else:
         return None
     ach = flops / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0

@@ -681,16 +681,18 @@ class LstmSeqFn(Function):
         need0 = has_h0 or has_c0
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
         dc0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
-        call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
-             _p(dh0), _p(dc0), _stream())
+        with _prof("lstm_bwd_step", T + (1 if need0 else 0), T=T, B=B, H=H, ndir=1):
+            call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
+                 _p(dh0), _p(dc0), _stream())
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         dw_hh = torch.empty(4 * H, H, device=dev, dtype=torch.float32)
         db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
-        call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
-             ws.numel(), _stream())
+        with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+            call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
+                 ws.numel(), _stream())
         dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32) if has_tab else None
         drowc = torch.empty(B, 4 * H, device=dev, dtype=torch.float32) if has_rowc else None
         if has_tab or has_rowc:

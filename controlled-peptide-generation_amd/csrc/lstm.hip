@@ -203,15 +203,50 @@ using LB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using LB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 using LB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
+// tile choices of the step launches (shared by the launchers and the introspection entry point below)
+static int lstm_fwd_choice(int B, int H) { return B >= 64 ? 0 : ((B > 32 && (long)cdiv(B, 32) * cdiv(H, 32) < 1024) ? 1 : 2); }  // LF64S | LF64 | LF32
+static int lstm_bwd_choice(int B, int H) { return (long)cdiv(B, 32) * cdiv(H, 32) >= 1024 ? 0 : (B > 32 ? 1 : 2); }               // LB32N | LB64 | LB32
+
+template <class TC>
+static int lstm_tc_name(char* b, int n) {
+    return snprintf(b, n, "TileCfg<%d, %d, %d, %d, %d, %d, %d>", TC::BM, TC::BN, TC::BK, TC::WM, TC::WN, TC::NSEG, TC::NT);
+}
+// Launcher introspection for bench.py (as cpg_gru_step_kernel_name): the kernel an LSTM step launch runs, named as rocprofv3
+// prints it.  kind 0 forward, 1 backward.  cpg_lstm_step_kernel_is_split: 1 = six bf16 MFMAs on split operands, 0 = exact f32.
+CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int n) {
+    char tc[96];
+    const char* vec = H % 4 == 0 ? "true" : "false";
+    if (kind == 0) {
+        const int c = lstm_fwd_choice(B, H);
+        if (c == 0) lstm_tc_name<LF64S>(tc, sizeof tc);
+        else if (c == 1) lstm_tc_name<LF64>(tc, sizeof tc);
+        else lstm_tc_name<LF32>(tc, sizeof tc);
+        return snprintf(buf, n, "lstm_step_fwd_kernel<%s, %s>", tc, vec);
+    }
+    if (kind == 1) {
+        const int c = lstm_bwd_choice(B, H);
+        if (c == 0) lstm_tc_name<LB32N>(tc, sizeof tc);
+        else if (c == 1) lstm_tc_name<LB64>(tc, sizeof tc);
+        else lstm_tc_name<LB32>(tc, sizeof tc);
+        return snprintf(buf, n, "lstm_step_bwd_kernel<%s, %s>", tc, vec);
+    }
+    return 0;
+}
+CPG_EXPORT int cpg_lstm_step_kernel_is_split(int kind, int B, int H) {
+    if (kind == 0) return lstm_fwd_choice(B, H) != 2;   // 64-row tiles run the plane engine (LstmFwdLoop)
+    return 0;                                           // backward: exact-f32 MFMA
+}
+
 static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.h_prev) && aligned16(a.w_hh);
-    if (a.B >= 64) {  // measured at B=2048, H=512: 13.76 -> 13.56 ms per training step against 32x128 exact-f32 tiles
+    const int choice = lstm_fwd_choice(a.B, a.H);
+    if (choice == 0) {  // measured at B=2048, H=512: 13.76 -> 13.56 ms per training step against 32x128 exact-f32 tiles
         dim3 grid(cdiv(a.H, LF64S::BN / 4), cdiv(a.B, LF64S::BM));
         const size_t smem = LstmFwdLoop<LF64S, true>::smem_bytes();
         if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64S, true>), grid, dim3(256), smem, s, a);
         else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64S, false>), grid, dim3(256), smem, s, a);
-    } else if (a.B > 32 && (long)cdiv(a.B, 32) * cdiv(a.H, 32) < 1024) {
-        // exact-f32 engine: 32-row tiles once they give >= 1024 workgroups
+    } else if (choice == 1) {
+        // 32-row tiles once they give >= 1024 workgroups
         dim3 grid(cdiv(a.H, LF64::BN / 4), cdiv(a.B, LF64::BM));
         static bool done = false;
         const size_t smem = LstmFwdLoop<LF64, true>::smem_bytes();
@@ -234,12 +269,13 @@ static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
 
 static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
     const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
-    if ((long)cdiv(a.B, 32) * cdiv(a.H, 32) >= 1024) {
+    const int choice = lstm_bwd_choice(a.B, a.H);
+    if (choice == 0) {
         dim3 grid(cdiv(a.H, LB32N::BN), cdiv(a.B, LB32N::BM));
         const size_t smem = LB32N::smem_floats<true, false>() * sizeof(float);
         if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, true>), grid, dim3(256), smem, s, a);
         else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, false>), grid, dim3(256), smem, s, a);
-    } else if (a.B > 32) {
+    } else if (choice == 1) {
         dim3 grid(cdiv(a.H, LB64::BN), cdiv(a.B, LB64::BM));
         const size_t smem = LB64::smem_floats<true, false>() * sizeof(float);
         if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, true>), grid, dim3(256), smem, s, a);

@@ -184,6 +184,9 @@ CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32
 /* ---- LSTM (NOT in the reference, which is GRU-only - SURVEY F2; semantics = torch.nn.LSTM, gate row order i,f,g,o) --------
  * Same conventions as the GRU entry points; cs is the cell-state slab [(T+1),B,H] (c0 in slot 0 / T), gates [T,4,B,H] =
  * i,f,g,o, dG [T,B,4H] = pre-activation gradients (identical for the input and the hidden side). */
+/* Launcher introspection (as cpg_gru_step_kernel_name): kind 0 forward step, 1 backward step. */
+CPG_API int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int n);
+CPG_API int cpg_lstm_step_kernel_is_split(int kind, int B, int H);
 CPG_API int cpg_lstm_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                              const float* tab, const float* rowc, const float* dense, float* hs, float* cs, float* gates,
                              void* stream);
