@@ -303,21 +303,46 @@ def dedup_frame(frame, seen):
     return out, (kept if n_seen == 0 else torch.cat([seen, kept], 0))
 
 
+def _peptide_column(letters, n_res, itos):
+    """Residue rows (DEVICE uint8 [n, L] ids, int32 [n] counts) -> the 'A C D' peptide strings of
+    idx2sentences(..., print_special_tokens=False) as a pandas column.  The characters, the separating blanks and the
+    compaction into one flat byte buffer + offsets happen on the device; with pyarrow the column is built over that buffer
+    without creating a python string per row (176 k kept rows of a 1 M-proposal round: 1 ms instead of 50-130 ms), otherwise
+    by slicing one decoded string."""
+    import pandas as pd
+    n, L = letters.shape
+    lut = torch.zeros(256, dtype=torch.uint8)
+    for i in range(N_SPECIALS, len(itos)):
+        assert len(itos[i]) == 1, 'vectorised form needs one-letter residue tokens'
+        lut[i] = ord(itos[i])
+    dev = letters.device
+    buf = torch.full((n, 2 * L), ord(' '), dtype=torch.uint8, device=dev)
+    buf[:, 0::2] = lut.to(dev)[letters.long()]
+    lens = (2 * n_res.long() - 1).clamp_(min=0)
+    flat = buf[torch.arange(2 * L, device=dev)[None, :] < lens[:, None]].cpu().numpy()
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = torch.cumsum(lens, 0).cpu().numpy()
+    if os.environ.get('CPG_ARROW_STRINGS', '1') != '0' and off[-1] < 2 ** 31:
+        try:
+            import pyarrow as pa
+            arr = pa.StringArray.from_buffers(n, pa.py_buffer(off.astype(np.int32)), pa.py_buffer(flat))
+            return pd.Series(arr, dtype=pd.ArrowDtype(pa.string()))
+        except (ImportError, AttributeError):
+            pass
+    text, o = flat.tobytes().decode('ascii'), off.tolist()
+    return [text[o[i]:o[i + 1]] for i in range(n)]
+
+
 def frames_to_dataframe(frames, dataset):
     """The reference's sample table (peptide, z, accept_z, clfZ_*, accept) from the kept frames."""
     import pandas as pd
     if not frames:
         return pd.DataFrame(columns=['peptide', 'z', 'accept_z', 'accept'])
-    cat = {k: torch.cat([f[k] for f in frames], 0).cpu().numpy() for k in frames[0]}
-    # ids -> characters through the loader's vocabulary (one-letter residues), then one bytes.decode per kept row
-    itos = dataset.TEXT.vocab.itos
-    lut = np.zeros(256, np.uint8)
-    for i in range(N_SPECIALS, len(itos)):
-        assert len(itos[i]) == 1, 'vectorised form needs one-letter residue tokens'
-        lut[i] = ord(itos[i])
-    df = pd.DataFrame({'peptide': dataset.letters_to_peptides(lut[cat['letters']], cat['n_res']), 'z': list(cat['z']),
-                       'accept_z': cat['accept_z'].astype(bool),
-                       **{k: v for k, v in cat.items() if k not in ('letters', 'n_res', 'z', 'accept_z')}})
+    dev = {k: torch.cat([f[k] for f in frames], 0) for k in frames[0]}
+    peptide = _peptide_column(dev.pop('letters'), dev.pop('n_res'), dataset.TEXT.vocab.itos)
+    cat = {k: v.cpu().numpy() for k, v in dev.items()}
+    df = pd.DataFrame({'peptide': peptide, 'z': list(cat['z']), 'accept_z': cat['accept_z'].astype(bool),
+                       **{k: v for k, v in cat.items() if k not in ('z', 'accept_z')}})
     df = compute_modlamp(df)
     df['accept'] = df['accept_z']
     return df

@@ -148,3 +148,27 @@ def test_vectorised_peptide_strings_match_idx2sentences():
     ids[1] = 1
     ref = d.idx2sentences([[t for t in row if t >= 0] for row in ids], print_special_tokens=False)
     assert d.ids_to_peptides(ids) == ref and ref[0] == '' and ref[1] == ''
+
+
+def test_peptide_column_from_residue_rows_both_forms(monkeypatch):
+    """sample_pipeline._peptide_column (flat byte buffer + offsets; Arrow-backed column or sliced python strings) equals
+    idx2sentences(..., print_special_tokens=False) row for row, empty rows included."""
+    import torch
+    import sample_pipeline as sp
+    from cpg.synth import SyntheticPeptideLoader
+    d = SyntheticPeptideLoader(4, 25, 'cpu', size=10)
+    rs = np.random.RandomState(1)
+    ids = rs.randint(-1, 24, (700, 26))
+    ids[0] = -1
+    ids[1] = 1
+    ref = d.idx2sentences([[t for t in row if t >= 0] for row in ids], print_special_tokens=False)
+    letters, n_res = sp.residue_rows(torch.from_numpy(ids), d.n_vocab)
+    col = sp._peptide_column(letters, n_res, d.TEXT.vocab.itos)
+    assert list(col) == ref
+    monkeypatch.setenv('CPG_ARROW_STRINGS', '0')
+    col2 = sp._peptide_column(letters, n_res, d.TEXT.vocab.itos)
+    assert isinstance(col2, list) and col2 == ref
+    import pandas as pd
+    df = pd.DataFrame({'peptide': col})
+    assert df.peptide.str.replace(' ', '').tolist() == [r.replace(' ', '') for r in ref]
+    assert df.peptide.isin(ref[:5]).sum() >= 5 and len(df.peptide.drop_duplicates()) == len(set(ref))

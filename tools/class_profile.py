@@ -1,27 +1,45 @@
-"""CLaSS decode loops only (config A), for rocprofv3 --kernel-trace --stats."""
-import os, sys, time
-import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "controlled-peptide-generation_amd"))
-sys.path.insert(0, ROOT)
-from bench import model_kwargs
-from cpg import ops, decode as cdecode
-from models.model import RNN_VAE
+#!/usr/bin/env python3
+"""Stage times of one CLaSS round (sample_pipeline.run_rounds at bench.py's configs[3] setup) with a device sync after every
+stage - where the wall time outside the decode kernel goes."""
+import os
+import sys
+import time
 
-dev = torch.device("cuda:0")
-torch.manual_seed(1238)
-m = RNN_VAE(n_vocab=24, max_seq_len=25, **model_kwargs(100, 80)).to(dev)
-m.device = dev
-N = int(os.environ.get("N", 262144))
-mode = os.environ.get("MODE", "greedy")
-z = ops.rng_normal((N, 100), 99, 0, dev)
-c = torch.zeros(N, 2, device=dev); c[:, 1] = 1
-for it in range(3):
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "controlled-peptide-generation_amd"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+import sample_pipeline as sp  # noqa: E402
+
+dev = torch.device("cuda")
+m, Q, ds = bench.class_setup(dev)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+mode = sys.argv[2] if len(sys.argv) > 2 else "beam"
+sp.run_rounds(m, ds, Q, 65536, 10 ** 9, max_rounds=1, sample_mode=mode)
+
+
+def t(label, fn):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if mode == "greedy":
-        m.generate_sentences(N, z, c, sample_mode="greedy")
-    else:
-        cdecode.decode_beam_arrays(m.decoder, z, c, 25)
+    r = fn()
     torch.cuda.synchronize()
-    print(mode, N, f"{1e3*(time.perf_counter()-t0):.2f} ms")
+    print(f"{label:28s} {1e3 * (time.perf_counter() - t0):8.1f} ms")
+    return r
+
+
+for rep in range(2):
+    print("--- round", rep)
+    t0 = time.perf_counter()
+    z, probs, accum, acc = t("rejection_sample", lambda: Q.rejection_sample(N, return_device=True, shard=(0, 1)))
+    c = torch.zeros(z.shape[0], 2, device=dev)
+    c[:, 1] = 1.0
+    ids, evals = t("decode_ids_from_z", lambda: sp.decode_ids_from_z(z, c, m, mode))
+    letters, n_res = t("residue_rows", lambda: sp.residue_rows(ids, ds.n_vocab))
+    names = Q.score_names()
+    frame = {'letters': letters, 'n_res': n_res, 'z': z, 'accept_z': acc.to(torch.bool), names[0]: accum}
+    for i, nm in enumerate(names[1:]):
+        frame[nm] = probs[i]
+    frame, seen = t("dedup_frame", lambda: sp.dedup_frame(frame, None))
+    df = t("frames_to_dataframe", lambda: sp.frames_to_dataframe([frame], ds))
+    print(f"{'total':28s} {1e3 * (time.perf_counter() - t0):8.1f} ms   kept {len(df)} accepted {int(df['accept'].sum())}")
