@@ -61,6 +61,9 @@ def train_vae(cfgv, model, dataset, reduce_fn=None, world=1, rank=0):
         logging_it = it % cfgv.cheaplog_every == 0 or it % cfgv.expsvlog_every == 0
         inputs = dataset.next_batch('train_vae')
         t = train_step(cfgv, model, trainer, inputs.text, it)
+        if logging_it:
+            from cpg import ops
+            ops.check_persistent()   # a timed-out inter-workgroup wait of a persistent launch raises here (logging syncs anyway)
         if logging_it and rank == 0:
             from cpg.ops import latent_sums
             with torch.no_grad():
