@@ -22,6 +22,12 @@
 // One workgroup (4 waves, 1 per SIMD) per CU; the launch is persistent over tiles.
 #include "cpg_internal.h"
 
+// Diagnostic builds of the beam kernel (results wrong): 1 no product, 2 no cell, 4 no vocabulary projection, 8 no stage 1 (row
+// lists), 16 no stage 2 (sentence merge), 32 no re-gather
+#ifndef CPG_BEAM_ABLATE
+#define CPG_BEAM_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int RM = 64;  // decoder rows per workgroup tile
@@ -445,128 +451,186 @@ __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
 
         for (int step = 0; step < a.T; ++step) {
             f32x4 acc[MT][6];
-            gru_product<G, R, 0, MT>(ww, hx_l, acc);
-            gru_cell<G, R, 0, MT>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, hx_l, hy_l);
+            if (!(CPG_BEAM_ABLATE & 1)) gru_product<G, R, 0, MT>(ww, hx_l, acc);
+            else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+            }
+            if (!(CPG_BEAM_ABLATE & 2)) gru_cell<G, R, 0, MT>(ww, acc, H, tab_l, rowc_l, tok_l, rcrow_l, hx_l, hy_l);
             __syncthreads();
-            vocab_logits<G, R>(ww, hy_l, fc_l, logit_l);
+            if (!(CPG_BEAM_ABLATE & 4)) vocab_logits<G, R>(ww, hy_l, fc_l, logit_l);
             __syncthreads();
 
-            // ---- Beam.advance, stage 1: one lane per row: log_softmax, masks, the row's K best (ties: lower token first)
-            if (tid < RM) {
-                const int sl = tid / K, k = tid - sl * K;
-                if (sl < nsent && !done_l[sl] && (step > 0 || k == 0)) {
-                    const float* l = logit_l + tid * LGS;
-                    float m = -INFINITY;
-                    for (int v = 0; v < V; ++v) m = fmaxf(m, l[v]);
-                    float se = 0.f;
-                    for (int v = 0; v < V; ++v) se += expf(l[v] - m);
-                    const float lse = m + logf(se);
-                    const bool parent_eos = step > 0 && tok_l[tid] == a.eos;
-                    const float base = sc_l[tid];
-                    float bs[MAXK];
-                    int bv[MAXK];
+            // ---- Beam.advance, stage 1: FOUR lanes per row (all 256 threads): log_softmax over the row, each lane's own sorted
+            // K best of its quarter of the vocabulary (tokens q, q+4, ...), then a K-round merge across the quad.  Order of a
+            // row's list: score descending, ties lower token first (Beam.py's topk over the flattened scores).
+            // (One lane per row ran this as a serial chain of LDS reads, 24 expf and a data-dependent insertion on ONE wave while
+            // three waves idled: 45 % of the kernel - tools/ablate_beam.sh.)
+            if (!(CPG_BEAM_ABLATE & 8)) {
+                const int r1 = tid >> 2, q = tid & 3;
+                const int sl = r1 / K, kb = r1 - sl * K;
+                const bool act = sl < nsent && !done_l[min(sl, S - 1)] && (step > 0 || kb == 0);   // uniform within the quad
+                constexpr int VQ = 8;   // V <= 32
+                const float* l = logit_l + r1 * LGS;
+                float lv[VQ];
+                float m = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < VQ; ++i) {
+                    const int v = q + 4 * i;
+                    lv[i] = v < V ? l[v] : -INFINITY;
+                    m = fmaxf(m, lv[i]);
+                }
+                m = fmaxf(m, __shfl_xor(m, 1));
+                m = fmaxf(m, __shfl_xor(m, 2));
+                float se = 0.f;
+#pragma unroll
+                for (int i = 0; i < VQ; ++i)
+                    if (q + 4 * i < V) se += expf(lv[i] - m);
+                se += __shfl_xor(se, 1);
+                se += __shfl_xor(se, 2);
+                const float lse = m + logf(se);
+                const bool parent_eos = step > 0 && tok_l[r1] == a.eos;
+                const float base = sc_l[r1];
+                float bs[MAXK];
+                int bv[MAXK];
+#pragma unroll
+                for (int p = 0; p < MAXK; ++p) {
+                    bs[p] = -INFINITY;
+                    bv[p] = 0;
+                }
+#pragma unroll
+                for (int i = 0; i < VQ; ++i) {
+                    const int v = q + 4 * i;
+                    if (v >= V) continue;
+                    float lp = lv[i] - lse;
+                    if (step + 1 < a.min_length && v == a.eos) lp = -1e20f;
+                    if (v == a.bos) lp = -1e20f;
+                    float cs = step > 0 ? lp + base : lp;
+                    if (parent_eos) cs = -1e20f;
+                    int cc = v;
+                    bool carried = false;
 #pragma unroll
                     for (int p = 0; p < MAXK; ++p) {
-                        bs[p] = -INFINITY;
-                        bv[p] = 0;
-                    }
-                    float worst = -INFINITY;
-                    for (int v = 0; v < V; ++v) {
-                        float lp = l[v] - lse;
-                        if (step + 1 < a.min_length && v == a.eos) lp = -1e20f;
-                        if (v == a.bos) lp = -1e20f;
-                        float cs = step > 0 ? lp + base : lp;
-                        if (parent_eos) cs = -1e20f;
-                        if (!(cs > worst)) continue;
-                        int cc = v;
-                        bool carried = false;
-#pragma unroll
-                        for (int p = 0; p < MAXK; ++p) {
-                            if (p >= K) break;
-                            if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
-                                const float fs = bs[p];
-                                const int fv = bv[p];
-                                bs[p] = cs;
-                                bv[p] = cc;
-                                cs = fs;
-                                cc = fv;
-                                carried = true;
-                            }
+                        if (p >= K) break;
+                        if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
+                            const float fs = bs[p];
+                            const int fv = bv[p];
+                            bs[p] = cs;
+                            bv[p] = cc;
+                            cs = fs;
+                            cc = fv;
+                            carried = true;
                         }
-#pragma unroll
-                        for (int p = 0; p < MAXK; ++p)
-                            if (p == K - 1) worst = bs[p];
-                    }
-#pragma unroll
-                    for (int p = 0; p < MAXK; ++p) {
-                        cs_l[tid * MAXK + p] = bs[p];
-                        cv_l[tid * MAXK + p] = bv[p];
                     }
                 }
-            }
-            __syncthreads();
-
-            // ---- stage 2: one lane per sentence merges its rows' lists (ties: lower beam first = lower flat index)
-            int active = 0;
-            int new_tok[MAXK], new_org[MAXK];
-            float new_sc[MAXK];
-            bool advanced = false;
-            if (tid < nsent && !done_l[tid]) {
-                advanced = true;
-                const int sl = tid, kmax = step == 0 ? 1 : K;
-                int ptr[MAXK];
-#pragma unroll
-                for (int k = 0; k < MAXK; ++k) ptr[k] = 0;
-                int nf = nfin_l[sl];
 #pragma unroll
                 for (int sel = 0; sel < MAXK; ++sel) {
                     if (sel >= K) break;
-                    float best = -INFINITY;
-                    int bk = 0, bp = 0;
+                    float ws = bs[0];
+                    int wv = bv[0];
 #pragma unroll
-                    for (int k = 0; k < MAXK; ++k) {
-                        if (k >= kmax) break;
-                        if (ptr[k] < K) {
-                            const float x = cs_l[(sl * K + k) * MAXK + ptr[k]];
-                            if (x > best) {
-                                best = x;
-                                bk = k;
-                                bp = ptr[k];
-                            }
-                        }
+                    for (int d = 1; d <= 2; d <<= 1) {
+                        const float os = __shfl_xor(ws, d);
+                        const int ov = __shfl_xor(wv, d);
+                        const bool take = os > ws || (os == ws && ov < wv);
+                        ws = take ? os : ws;
+                        wv = take ? ov : wv;
                     }
+                    if (bs[0] == ws && bv[0] == wv) {   // this lane's head won (tokens are unique across the quad): pop it
 #pragma unroll
-                    for (int k = 0; k < MAXK; ++k)
-                        if (k == bk) ++ptr[k];
-                    const int tk = cv_l[(sl * K + bk) * MAXK + bp];
-                    new_sc[sel] = best;
-                    new_tok[sel] = tk;
-                    new_org[sel] = bk;
-                    if (tk == a.eos) ++nf;
+                        for (int p = 0; p + 1 < MAXK; ++p) {
+                            bs[p] = bs[p + 1];
+                            bv[p] = bv[p + 1];
+                        }
+                        bs[MAXK - 1] = -INFINITY;
+                        bv[MAXK - 1] = 0;
+                    }
+                    if (act && q == 0) {
+                        cs_l[r1 * MAXK + sel] = ws;
+                        cv_l[r1 * MAXK + sel] = wv;
+                    }
                 }
-                nfin_l[sl] = nf;
-                if (new_tok[0] == a.eos && nf >= a.n_best) done_l[sl] = 1; else active = 1;
             }
-            if (advanced) {  // stage 2 reads only the candidate lists: the per-row state can be replaced right away
-                const int sl = tid;
+            __syncthreads();
+
+            // ---- stage 2: EIGHT lanes per sentence, lane k holding beam row k's list: K rounds of an 8-lane arg-max
+            // (ties: lower beam first = lower flat index), the winner pops, lane `sel` keeps the sel-th selection and then
+            // installs it as the new state of row `sel` (stage 2 reads only the candidate lists: the per-row state can be
+            // replaced right away)
+            int active = 0;
+            if ((CPG_BEAM_ABLATE & 16) && tid < nsent) active = 1;
+            if (tid < 8 * S && !(CPG_BEAM_ABLATE & 16)) {
+                const int sl = tid >> 3, k8 = tid & 7;
+                const bool live = sl < nsent && !done_l[sl];   // uniform within the group of 8
+                const int kmax = step == 0 ? 1 : K;
+                float bs[MAXK];
+                int bv[MAXK];
 #pragma unroll
-                for (int k = 0; k < MAXK; ++k) {
-                    if (k >= K) break;
-                    const int row = sl * K + k;
-                    sc_l[row] = new_sc[k];
-                    tok_l[row] = new_tok[k];
-                    org_l[row] = sl * K + new_org[k];
-                    const size_t h = ((size_t)step * a.N + (s0 + sl)) * K + k;
-                    a.hist_tok[h] = new_tok[k];
-                    a.hist_prev[h] = new_org[k];
-                    a.hist_score[h] = new_sc[k];
+                for (int p = 0; p < MAXK; ++p) {
+                    const bool have = live && k8 < kmax && p < K;
+                    const int idx = (min(sl * K + k8, RM - 1)) * MAXK + p;
+                    bs[p] = have ? cs_l[idx] : -INFINITY;
+                    bv[p] = have ? cv_l[idx] : 0;
+                }
+                float my_sc = 0.f;
+                int my_tok = 0, my_org = 0, nf_add = 0, tok0 = 0;
+#pragma unroll
+                for (int sel = 0; sel < MAXK; ++sel) {
+                    if (sel >= K) break;
+                    float ws = bs[0];
+                    int wv = bv[0], wk = k8;
+#pragma unroll
+                    for (int d = 1; d <= 4; d <<= 1) {
+                        const float os = __shfl_xor(ws, d);
+                        const int ov = __shfl_xor(wv, d), ok = __shfl_xor(wk, d);
+                        const bool take = os > ws || (os == ws && ok < wk);
+                        ws = take ? os : ws;
+                        wv = take ? ov : wv;
+                        wk = take ? ok : wk;
+                    }
+                    if (k8 == wk) {
+#pragma unroll
+                        for (int p = 0; p + 1 < MAXK; ++p) {
+                            bs[p] = bs[p + 1];
+                            bv[p] = bv[p + 1];
+                        }
+                        bs[MAXK - 1] = -INFINITY;
+                        bv[MAXK - 1] = 0;
+                    }
+                    if (k8 == sel) {
+                        my_sc = ws;
+                        my_tok = wv;
+                        my_org = wk;
+                    }
+                    if (sel == 0) tok0 = wv;
+                    nf_add += wv == a.eos;
+                }
+                if (live) {
+                    const int nf = nfin_l[sl] + nf_add;   // every lane of the group reads the old count before lane 0 updates it
+                    if (k8 < K) {
+                        const int row = sl * K + k8;
+                        sc_l[row] = my_sc;
+                        tok_l[row] = my_tok;
+                        org_l[row] = sl * K + my_org;
+                        const size_t h = ((size_t)step * a.N + (s0 + sl)) * K + k8;
+                        a.hist_tok[h] = my_tok;
+                        a.hist_prev[h] = my_org;
+                        a.hist_score[h] = my_sc;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (k8 == 0) {
+                        nfin_l[sl] = nf;
+                        if (tok0 == a.eos && nf >= a.n_best) done_l[sl] = 1; else active = 1;
+                    }
                 }
             }
             const int nact = __syncthreads_count(active);
             if (nact == 0) break;  // every sentence of the tile is done (model.py:364-366)
 
             // ---- re-gather the hidden rows by back-pointer (model.py:387-404): hx[row] = hy[org[row]]
-            for (int i = tid; i < RM * (C::KP / 4); i += 256) {
+            for (int i = tid; i < RM * (C::KP / 4) && !(CPG_BEAM_ABLATE & 32); i += 256) {
                 const int r = i / (C::KP / 4), c = i - r * (C::KP / 4);
                 *reinterpret_cast<f32x4*>(&hx_l[r * C::LDH + 4 * c]) = *reinterpret_cast<const f32x4*>(&hy_l[org_l[r] * C::LDH + 4 * c]);
             }
