@@ -392,6 +392,18 @@ int launch_greedy(const GreedyArgs& a, int device_cus, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ beam
+// lane exchanges of the selection stages as DPP moves (one VALU instruction; __shfl_xor compiles to ds_bpermute_b32, an LDS
+// crossbar round trip per exchange in chains of 20-70 of them): 0xB1 = quad_perm [1,0,3,2] (lane ^ 1), 0x4E = quad_perm
+// [2,3,0,1] (lane ^ 2), 0x141 = row_half_mirror (lane i <-> 7 - i of each 8: pairs the two quads of a group of eight)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) {
+    return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true);
+}
+
 struct BeamArgs {
     DecoderWeights w;
     const float* h0;      // [N,H]  one row per sentence
@@ -482,14 +494,14 @@ __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
                     lv[i] = v < V ? l[v] : -INFINITY;
                     m = fmaxf(m, lv[i]);
                 }
-                m = fmaxf(m, __shfl_xor(m, 1));
-                m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, dpp_f<0xB1>(m));
+                m = fmaxf(m, dpp_f<0x4E>(m));
                 float se = 0.f;
 #pragma unroll
                 for (int i = 0; i < VQ; ++i)
                     if (q + 4 * i < V) se += expf(lv[i] - m);
-                se += __shfl_xor(se, 1);
-                se += __shfl_xor(se, 2);
+                se += dpp_f<0xB1>(se);
+                se += dpp_f<0x4E>(se);
                 const float lse = m + logf(se);
                 const bool parent_eos = step > 0 && tok_l[r1] == a.eos;
                 const float base = sc_l[r1];
@@ -530,10 +542,16 @@ __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
                     if (sel >= K) break;
                     float ws = bs[0];
                     int wv = bv[0];
-#pragma unroll
-                    for (int d = 1; d <= 2; d <<= 1) {
-                        const float os = __shfl_xor(ws, d);
-                        const int ov = __shfl_xor(wv, d);
+                    {
+                        const float os = dpp_f<0xB1>(ws);
+                        const int ov = dpp_i<0xB1>(wv);
+                        const bool take = os > ws || (os == ws && ov < wv);
+                        ws = take ? os : ws;
+                        wv = take ? ov : wv;
+                    }
+                    {
+                        const float os = dpp_f<0x4E>(ws);
+                        const int ov = dpp_i<0x4E>(wv);
                         const bool take = os > ws || (os == ws && ov < wv);
                         ws = take ? os : ws;
                         wv = take ? ov : wv;
@@ -581,15 +599,19 @@ __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
                     if (sel >= K) break;
                     float ws = bs[0];
                     int wv = bv[0], wk = k8;
-#pragma unroll
-                    for (int d = 1; d <= 4; d <<= 1) {
-                        const float os = __shfl_xor(ws, d);
-                        const int ov = __shfl_xor(wv, d), ok = __shfl_xor(wk, d);
-                        const bool take = os > ws || (os == ws && ok < wk);
-                        ws = take ? os : ws;
-                        wv = take ? ov : wv;
-                        wk = take ? ok : wk;
-                    }
+#define CPG_BEAM_MERGE8(CTRL)                                                  \
+    {                                                                          \
+        const float os = dpp_f<CTRL>(ws);                                      \
+        const int ov = dpp_i<CTRL>(wv), ok = dpp_i<CTRL>(wk);                  \
+        const bool take = os > ws || (os == ws && ok < wk);                    \
+        ws = take ? os : ws;                                                   \
+        wv = take ? ov : wv;                                                   \
+        wk = take ? ok : wk;                                                   \
+    }
+                    CPG_BEAM_MERGE8(0xB1)
+                    CPG_BEAM_MERGE8(0x4E)
+                    CPG_BEAM_MERGE8(0x141)
+#undef CPG_BEAM_MERGE8
                     if (k8 == wk) {
 #pragma unroll
                         for (int p = 0; p + 1 < MAXK; ++p) {
