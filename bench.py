@@ -387,7 +387,7 @@ def class_bench(dev, N=1000000, cpu=True):
              "decoder_evals": st["decoder_evals"], "decode_kernel_ms": round(kms, 2)}
         if kms > 0:
             ach = st["decoder_evals"] * EVAL_FLOPS / (kms * 1e-3) / 1e12
-            r["roofline"] = {"bound": "mfma", "kernel": "decode_beam_fused_kernel<6, 2>" if kw["sample_mode"] == "beam" else "decode_greedy_fused_kernel<6, 2>",
+            r["roofline"] = {"bound": "mfma", "kernel": _cname("cpg_decode_fused_kernel_name", 1 if kw["sample_mode"] == "beam" else 0, 102, 5),
                              "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                              "traffic": None, "avg_launch_us": round(kms * 1e3 / max(launches, 1), 1), "launches_timed": launches,
                              "flops_per_eval": EVAL_FLOPS, "pipe": "exact f32 MFMA, W_hh fragments in registers, state in LDS (csrc/decode_fused.hip); "

@@ -21,6 +21,7 @@
 //                and the hidden rows are re-gathered by back-pointer inside LDS.
 // One workgroup (4 waves, 1 per SIMD) per CU; the launch is persistent over tiles.
 #include "cpg_internal.h"
+#include <stdio.h>
 
 // Diagnostic builds of the beam kernel (results wrong): 1 no product, 2 no cell, 4 no vocabulary projection, 8 no stage 1 (row
 // lists), 16 no stage 2 (sentence merge), 32 no re-gather
@@ -414,11 +415,13 @@ struct BeamArgs {
     int N, T, K, n_best, min_length, bos, eos, S, ntiles;  // S = sentences per tile = RM / K
 };
 
-template <int G, int R>
+// KT: beam width as a compile-time constant (0 = a.K at run time): the selection stages are loops over K with K-dependent
+// bounds and divisions by K; the reference's default width 5 at its default decoder size gets its own instantiation.
+template <int G, int R, int KT = 0>
 __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
     using C = FusedCfg<G, R>;
     extern __shared__ float4 cpg_fused_smem[];
-    const int H = a.w.H, H3 = 3 * H, V = a.w.V, K = a.K, S = a.S;
+    const int H = a.w.H, H3 = 3 * H, V = a.w.V, K = KT ? KT : a.K, S = KT ? RM / KT : a.S;
     float* hx_l = reinterpret_cast<float*>(cpg_fused_smem);  // [RM][LDH] state the product reads (rows in beam order)
     float* hy_l = hx_l + RM * C::LDH;                         // [RM][LDH] state after the cell, before the re-gather
     float* fc_l = hy_l + RM * C::LDH;                         // [V][LDH]
@@ -670,7 +673,10 @@ size_t beam_lds_bytes(int ldh, int H, int V, int Vt, int K) {
 template <int G, int R>
 int launch_beam(const BeamArgs& a, int device_cus, hipStream_t s) {
     const size_t bytes = beam_lds_bytes(FusedCfg<G, R>::LDH, a.w.H, a.w.V, a.w.Vt, a.K);
-    auto kern = decode_beam_fused_kernel<G, R>;
+    auto kern = decode_beam_fused_kernel<G, R, 0>;
+    if constexpr (G == 6 && R == 2) {
+        if (a.K == 5) kern = decode_beam_fused_kernel<G, R, 5>;
+    }
     CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int grid = a.ntiles < device_cus ? a.ntiles : device_cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), bytes, s, a);
@@ -728,6 +734,17 @@ CPG_EXPORT int cpg_decode_greedy_fused(const float* h0, const float* rowc, const
     GreedyArgs a{{tab, w_hh, b_hh, fc_w, fc_b, H, V, Vt}, h0, rowc, ids, unfinished, N, T, ld_ids, start, pad, eos, cdiv(N, RM)};
     hipStream_t s = (hipStream_t)stream;
     CPG_FUSED_DISPATCH(launch_greedy, H, a, cus, s);
+}
+
+// Launcher introspection (bench.py labels the CLaSS roofline with it): the whole-loop decode kernel a launch with hidden size H
+// (and beam width K) runs, named as rocprofv3 prints it.  kind 0 greedy, 1 beam.  Returns the length written (0: not covered).
+CPG_EXPORT int cpg_decode_fused_kernel_name(int kind, int H, int K, char* buf, int n) {
+    if (H <= 0 || H > 128 || kind < 0 || kind > 1) return 0;
+    int g, r = 0;
+    if (fused_kp(H) == 104) { g = 6; r = 2; }
+    else g = H <= 32 ? 2 : H <= 64 ? 4 : H <= 96 ? 6 : 8;
+    if (kind == 0) return snprintf(buf, n, "decode_greedy_fused_kernel<%d, %d>", g, r);
+    return snprintf(buf, n, "decode_beam_fused_kernel<%d, %d, %d>", g, r, (g == 6 && r == 2 && K == 5) ? 5 : 0);
 }
 
 CPG_EXPORT size_t cpg_decode_beam_fused_lds_bytes(int H, int V, int Vt, int K) {

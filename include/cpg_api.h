@@ -236,6 +236,8 @@ CPG_API int cpg_decode_greedy_fused(const float* h0, const float* rowc, const fl
  * re-gather happen in LDS.  h0/rowc: one row per sentence.  hist_tok must be pre-filled with -1 (steps a finished
  * sentence is not advanced on keep it); hist_* [T,N,K] feed cpg_beam_hypotheses.  Same shape limits as the greedy one
  * plus K <= 8, K <= V; -3 if cpg_decode_beam_fused_lds_bytes exceeds the device's LDS per workgroup. */
+/* Launcher introspection: the whole-loop decode kernel a launch runs (kind 0 greedy, 1 beam), as rocprofv3 prints it. */
+CPG_API int cpg_decode_fused_kernel_name(int kind, int H, int K, char* buf, int n);
 CPG_API size_t cpg_decode_beam_fused_lds_bytes(int H, int V, int Vt, int K);
 CPG_API int cpg_decode_beam_fused(const float* h0, const float* rowc, const float* tab, int Vt, const float* w_hh,
                                   const float* b_hh, const float* fc_w, const float* fc_b, int N, int H, int V, int T, int K,
