@@ -91,6 +91,15 @@ constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
 constexpr int P_NC = 3 * P_CT;    // gate columns per workgroup
 constexpr int P_TBW = 16;         // words per row of the per-wave 16x16 transposition buffer
+// Phase offset between the two waves of a SIMD (waves w and w + P_WAVES/2 own different row tiles = independent chains): the
+// second set starts this many 10-ns ticks late, so that one wave's product phase (exchange loads, MFMAs) runs against the
+// other's epilogue phase (gate / state traffic, cell arithmetic) instead of both doing the same thing at the same time.
+#ifndef CPG_PERSIST_PHASE_FWD
+#define CPG_PERSIST_PHASE_FWD 0
+#endif
+#ifndef CPG_PERSIST_PHASE_BWD
+#define CPG_PERSIST_PHASE_BWD 0
+#endif
 #ifndef CPG_PERSIST_CNT_STRIDE
 #define CPG_PERSIST_CNT_STRIDE 64  // words between arrival counters: one 256-byte line each, so the adds and polls of different
                                    // row tiles do not queue on one memory channel
@@ -116,6 +125,12 @@ struct PFwdArgs {
                            // CUs of an XCD that read the same tile at the same time camped on a few L2 channels: 62.8 us/step.)
     int T, B, H, reverse, groups, S;  // S: words per plane row (H/2 data + pad so that S % 64 == 8)
 };
+
+__device__ __forceinline__ void phase_delay(int wave, unsigned ticks) {
+    if (ticks == 0 || wave < P_WAVES / 2) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -210,6 +225,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     const int rt = g * P_WAVES + wave;   // row tile of this wave
     const int row0 = rt * P_WROWS;
     if (row0 >= B) return;               // wave-uniform; nobody waits for a tile that does not exist
+    phase_delay(wave, CPG_PERSIST_PHASE_FWD);
     const int l15 = lane & 15, lq = lane >> 4;
     const int col = j0 + l15;            // hidden unit of this lane's accumulator elements
     const int srow = lane >> 2, scq = lane & 3;  // row-layout coordinates after acc_to_rows
@@ -470,6 +486,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist
     const int rt = g * P_WAVES + wave;
     const int row0 = rt * P_WROWS;
     if (row0 >= B) return;
+    phase_delay(wave, CPG_PERSIST_PHASE_BWD);
     const int l15 = lane & 15, lq = lane >> 4;
     const int srow = lane >> 2, scq = lane & 3;
     const size_t BH = (size_t)B * H;
