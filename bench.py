@@ -78,6 +78,8 @@ def family_roofline(family, dims, avg_us, launches):
         tc = "TileCfg<64, 32, 32, 4, 1, 1, 256>, true, 1" if bf16 else "TileCfg<32, 32, 32, 2, 2, 1, 256>, false, 7"
         kernel, split = "gru_seq_bwd_chain_kernel<%s>" % tc, (2 if bf16 else 0)
         flops = dims.get("steps", T) * nd * 2.0 * B * 3 * H * H
+    elif family == "lstm_fwd_persist":
+        kernel, split, flops = "lstm_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 4 * H
     elif family in ("lstm_fwd_step", "lstm_bwd_step"):   # LSTM extension: four gates
         kind = 0 if family == "lstm_fwd_step" else 1
         kernel, split = _cname("cpg_lstm_step_kernel_name", kind, B, H), L.cpg_lstm_step_kernel_is_split(kind, B, H)

@@ -378,9 +378,30 @@ def gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, d
          _p(_chain_scratch(B, hs_f.device)), _stream())
 
 
+def lstm_persistent_fits(B, H):
+    """Whole-sequence persistent LSTM forward kernel (csrc/lstm_persist.hip) covers this shape on this device."""
+    return bool(query("cpg_lstm_persistent_fits", int(B), int(H)))
+
+
+def lstm_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, cs, gates):
+    dev = hs.device
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, "lstm", (H, T))
+    sc = _persist_scratch.get(key)
+    if sc is None:
+        nb = query("cpg_lstm_persistent_scratch_bytes", T, B, H)
+        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word + slots
+    call("cpg_lstm_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
+         _p(hs), _p(cs), _p(gates), _p(sc), _stream())
+
+
 def check_persistent():
     """Raise if any in-kernel wait of a persistent launch has timed out since start-up (synchronises the streams used)."""
     for (_, _, B, _H, _T), sc in list(_persist_scratch.items()):
+        if _H == "lstm":
+            if query("cpg_lstm_persistent_status", B, _p(sc), _stream()) != 0:
+                raise CpgError("persistent LSTM kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
+                               "set CPG_LSTM_PERSIST=0 to use the per-step kernels")
+            continue
         if _H == "chain":
             if query("cpg_gru_chain_status", B, _p(sc), _stream()) != 0:
                 raise CpgError("one-launch BPTT: an inter-workgroup wait timed out (workgroups not co-resident?); "
@@ -657,9 +678,13 @@ class LstmSeqFn(Function):
         cs[slot0].zero_() if c0 is None else cs[slot0].copy_(c0)
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, c0, w_hh, b_hh))
         gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
-        with _prof("lstm_fwd_step", T, T=T, B=B, H=H, ndir=1):
-            call("cpg_lstm_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
-                 _p(hs), _p(cs), _p(gates), _stream())
+        if lstm_persistent_fits(B, H):
+            with _prof("lstm_fwd_persist", 1, T=T, B=B, H=H, ndir=1):
+                lstm_seq_fwd_persistent(T, B, H, reverse, w_hh_c, b_hh_c, tok, tab_c, rowc_c, dense_c, hs, cs, gates)
+        else:
+            with _prof("lstm_fwd_step", T, T=T, B=B, H=H, ndir=1):
+                call("cpg_lstm_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c), _p(dense_c),
+                     _p(hs), _p(cs), _p(gates), _stream())
         ctx.save_for_backward(tok, w_hh_c, hs, cs, gates)
         ctx.dims = (T, B, H, bool(reverse))
         ctx.V = tab.shape[0] if tab is not None else 0

@@ -184,6 +184,18 @@ CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32
 /* ---- LSTM (NOT in the reference, which is GRU-only - SURVEY F2; semantics = torch.nn.LSTM, gate row order i,f,g,o) --------
  * Same conventions as the GRU entry points; cs is the cell-state slab [(T+1),B,H] (c0 in slot 0 / T), gates [T,4,B,H] =
  * i,f,g,o, dG [T,B,4H] = pre-activation gradients (identical for the input and the hidden side). */
+/* Persistent form of cpg_lstm_seq_fwd (csrc/lstm_persist.hip): the whole time loop of one direction in ONE launch - a workgroup
+ * keeps the i,f,g,o rows of W_hh of 8 hidden units in LDS (split bf16 planes) for 512 batch rows, the column-tile workgroups of
+ * a row tile hand h_t to each other through per-step plane slots + arrival counters (as cpg_gru_seq_fwd_persistent).  Same
+ * arguments and results as cpg_lstm_seq_fwd.  cpg_lstm_persistent_fits: 1 when (B,H) is covered on this device
+ * (CPG_LSTM_PERSIST=0 disables); sync_scratch: cpg_lstm_persistent_scratch_bytes(T,B,H) bytes, zeroed by the caller when
+ * allocated; cpg_lstm_persistent_status reads its sticky error word (0 = no wait has timed out). */
+CPG_API int cpg_lstm_persistent_fits(int B, int H);
+CPG_API size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H);
+CPG_API int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
+                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
+                                        float* hs, float* cs, float* gates, void* sync_scratch, void* stream);
+CPG_API int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (as cpg_gru_step_kernel_name): kind 0 forward step, 1 backward step. */
 CPG_API int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int n);
 CPG_API int cpg_lstm_step_kernel_is_split(int kind, int B, int H);

@@ -154,3 +154,81 @@ def test_lstm_beam_and_greedy_vs_oracle():
     for i in range(N):
         for j in range(3):
             assert hyps[i][j] == [int(t) for t in ref[i][j]], (i, j)
+
+
+# ---- persistent whole-sequence LSTM forward kernel (csrc/lstm_persist.hip) against the per-step kernels
+def _lstm_inputs(B, H, T, V, seed, dense=False, rowc=True):
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device("cuda")
+    return dict(
+        w_hh=(torch.randn(4 * H, H, generator=g) / H ** 0.5).to(dev), b_hh=(torch.randn(4 * H, generator=g) * 0.1).to(dev),
+        tab=(torch.randn(V, 4 * H, generator=g) * 0.3).to(dev),
+        rowc=(torch.randn(B, 4 * H, generator=g) * 0.3).to(dev) if rowc else None,
+        dense=(torch.randn(T, B, 4 * H, generator=g) * 0.3).to(dev) if dense else None,
+        tok=torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev),
+        h0=(torch.randn(B, H, generator=g) * 0.5).to(dev), c0=(torch.randn(B, H, generator=g) * 0.5).to(dev))
+
+
+def _lstm_run(d, B, H, T, reverse, persistent):
+    from cpg import ops
+    from cpg.ops import _p, _stream, call
+    dev = torch.device("cuda")
+    hs, cs = torch.zeros(T + 1, B, H, device=dev), torch.zeros(T + 1, B, H, device=dev)
+    hs[T if reverse else 0] = d["h0"]
+    cs[T if reverse else 0] = d["c0"]
+    gates = torch.zeros(T, 4, B, H, device=dev)
+    if persistent:
+        assert ops.lstm_persistent_fits(B, H)
+        ops.lstm_seq_fwd_persistent(T, B, H, reverse, d["w_hh"], d["b_hh"], d["tok"], d["tab"], d["rowc"], d["dense"], hs, cs, gates)
+        ops.check_persistent()
+    else:
+        call("cpg_lstm_seq_fwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(d["b_hh"]), _p(d["tok"]), _p(d["tab"]), _p(d["rowc"]),
+             _p(d["dense"]), _p(hs), _p(cs), _p(gates), _stream())
+    torch.cuda.synchronize()
+    return hs, cs, gates
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,T,reverse,dense,rowc", [
+    (2048, 512, 25, False, False, True),    # bench decoder shape
+    (2048, 512, 25, True, False, False),    # bench encoder shape, reverse direction
+    (200, 96, 6, False, False, True),       # partial row tile, three k-blocks
+    (333, 128, 9, True, True, False),       # dense input term (upper layers), reverse
+    (64, 512, 50, False, False, True),
+    (1000, 256, 3, False, True, True),
+])
+def test_lstm_persistent_forward_matches_per_step(B, H, T, reverse, dense, rowc):
+    """State slabs (h, c) and saved gates of every step against the per-step kernels: same split products and cell formulas,
+    sums over k-blocks in the same order - agreement to f32 rounding of the six-term order (<= 5e-6 on O(1) values)."""
+    d = _lstm_inputs(B, H, T, 24, seed=B + H + T, dense=dense, rowc=rowc)
+    hp, cp, gp = _lstm_run(d, B, H, T, reverse, True)
+    hq, cq, gq = _lstm_run(d, B, H, T, reverse, False)
+    assert torch.isfinite(hp).all() and torch.isfinite(cp).all()
+    assert (hp - hq).abs().max().item() < 5e-6
+    assert (cp - cq).abs().max().item() < 2e-5
+    assert (gp - gq).abs().max().item() < 5e-6
+
+
+@pytest.mark.gpu
+def test_lstm_persistent_forward_vs_oracle_and_repeatable():
+    B, H, T, V = 130, 64, 7, 24
+    d = _lstm_inputs(B, H, T, V, seed=5)
+    hs, cs, gates = _lstm_run(d, B, H, T, False, True)
+    gi = (d["tab"].cpu().numpy()[d["tok"].cpu().numpy().T] + d["rowc"].cpu().numpy()[:, None, :]).astype(np.float32)   # [B,T,4H]
+    hs_ref, _, _, _ = olstm.lstm_seq_fwd(gi, d["h0"].cpu().numpy(), d["c0"].cpu().numpy(), d["w_hh"].cpu().numpy(), d["b_hh"].cpu().numpy())
+    np.testing.assert_allclose(hs[1:].permute(1, 0, 2).cpu().numpy(), hs_ref, atol=3e-6)
+    d2 = _lstm_inputs(2048, 512, 25, V, seed=2)
+    a = _lstm_run(d2, 2048, 512, 25, False, True)
+    for _ in range(2):
+        b = _lstm_run(d2, 2048, 512, 25, False, True)
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_lstm_persistent_limits_and_knob(monkeypatch):
+    from cpg import ops
+    assert ops.lstm_persistent_fits(2048, 512)
+    assert not ops.lstm_persistent_fits(2048, 100)     # H % 32 != 0
+    assert not ops.lstm_persistent_fits(8192, 512)     # 1024 workgroups
+    monkeypatch.setenv("CPG_LSTM_PERSIST", "0")
+    assert not ops.lstm_persistent_fits(2048, 512)
