@@ -27,8 +27,14 @@ constexpr int L_NC = 4 * L_CT;       // gate columns per workgroup: two MFMA blo
 constexpr int L_WAVES = 8;
 constexpr int L_WROWS = 64;          // rows per wave
 constexpr int L_MI = L_WROWS / 16;
-constexpr int L_HM = 2;              // row blocks per product pass (two passes per step)
-constexpr int L_DEPTH = 2;           // register ring over k-blocks
+#ifndef CPG_LSTM_PERSIST_HM
+#define CPG_LSTM_PERSIST_HM 2
+#endif
+#ifndef CPG_LSTM_PERSIST_DEPTH
+#define CPG_LSTM_PERSIST_DEPTH 2
+#endif
+constexpr int L_HM = CPG_LSTM_PERSIST_HM;        // row blocks per product pass (two passes per step)
+constexpr int L_DEPTH = CPG_LSTM_PERSIST_DEPTH;  // register ring over k-blocks
 constexpr int L_CNT_STRIDE = 64;     // words between arrival counters (one 256-byte line each)
 constexpr int L_TBW = 16;
 constexpr unsigned L_SPIN_LIMIT = 400000u;
