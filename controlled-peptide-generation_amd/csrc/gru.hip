@@ -401,6 +401,107 @@ using GB128W = TileCfg<128, 64, 32, 2, 2, 1>;
 using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab barriers (exact-f32 engine only)
 
+// ---- backward step with a direct-to-LDS main loop ("DL"): exact-f32 MFMA on 32 x 32 tiles like gru_step_bwd_kernel<GB32N>, but
+// both operands K-contiguous (dgh rows, W_hh^T rows) and staged by `global_load_lds_dwordx4` into a THREE-stage LDS ring, two
+// slabs ahead of the product: no staging registers, no ds_write pass, four ds_read_b128 per slab instead of two + eight dword
+// reads, and almost no VALU work in the slab loop (the exact-f32 MFMA shares its lanes with the VALU: every address / mask
+// instruction of the register-staged loop is paid in matrix-pipe time).  An LDS-DMA lane writes to
+// base + 16 * lane, so the image is unpadded ([row][32 floats]); bank conflicts of the fragment reads are avoided by a
+// source-side swizzle instead: lane (row, slot s) loads k-chunk s ^ f(row), f(row) = (row >> 1) & 7, and the reader of k-chunk q
+// of a row reads slot q ^ f(row).  Contraction order = the register-staged kernel's (k = 16h + 4q + j): bit-identical sums.
+// Covers dense launches with B % 32 == 0, H % 32 == 0 and 16-byte aligned operands; everything else runs gru_step_bwd_kernel.
+constexpr int DL_TILE_FLOATS = 32 * 32;            // one operand slab: 32 rows x 32 k
+constexpr int DL_STAGE_FLOATS = 2 * DL_TILE_FLOATS;  // A + B
+constexpr int DL_STAGES = 3;
+__device__ __forceinline__ void dl_issue(const float* ga, const float* gb, float* stage, int wave) {
+    // LDS destination: wave-uniform base (+ 16 bytes x lane added by the hardware)
+    __builtin_amdgcn_global_load_lds(ga, (__attribute__((address_space(3))) void*)(stage + wave * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(gb, (__attribute__((address_space(3))) void*)(stage + DL_TILE_FLOATS + wave * 256), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
+    using TC = GB32N;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const GruBwdArgs& g = pr.d[bz];
+    const int H = g.H, B = g.row1;
+    const int m0 = g.row0 + by * 32, j0 = bx * 32;
+    const size_t BH = (size_t)g.B * H;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const tb = cpg_smem + DL_STAGES * DL_STAGE_FLOATS + wave * 256;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    const int rb0 = m0 + wm * 16 + (lane >> 2), cb0 = j0 + wn * 16 + 4 * (lane & 3);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pre, sv[5];
+    auto load_ep = [&]() {
+        const size_t o = (size_t)rb0 * H + cb0;
+        f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+        if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
+        if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
+        pre = p;
+        if (g.gates) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+            sv[4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
+        }
+    };
+    if (g.dG_next) {
+        const int K = 3 * H, KT = K / 32;
+        // this thread's 16-byte piece of a slab: row = tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
+        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);
+        const float* ga = g.dG_next + (size_t)(m0 + srow) * 4 * H + 4 * sch;
+        const float* gb = g.w_hhT + (size_t)(j0 + srow) * K + 4 * sch;
+        // fragment addresses: row r of the wave's 16-row block, k-chunk q = 4h + lq  ->  slot q ^ f(r)
+        const int ra = wm * 16 + l15, rbn = wn * 16 + l15;
+        const int fa = (ra >> 1) & 7, fb = (rbn >> 1) & 7;
+        const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int phase = ((hb >> 3) + (hb >> 8)) & 3;
+        const int hook_kt = min(phase * g.ep_step, KT - 1);
+        dl_issue(ga, gb, cpg_smem, wave);
+        if (KT > 1) dl_issue(ga + 32, gb + 32, cpg_smem + DL_STAGE_FLOATS, wave);
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt == hook_kt) load_ep();
+            // slab kt has landed once at most the loads of slab kt+1 are outstanding; the barrier then makes every wave's
+            // piece visible and retires every wave's fragment reads of slab kt-1 (whose stage is refilled next)
+            if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < KT) dl_issue(ga + (kt + 2) * 32, gb + (kt + 2) * 32, cpg_smem + ((kt + 2) % DL_STAGES) * DL_STAGE_FLOATS, wave);
+            const float* As = cpg_smem + (kt % DL_STAGES) * DL_STAGE_FLOATS;
+            const float* Bs = As + DL_TILE_FLOATS;
+            f32x4 av[2], bv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                av[h] = *reinterpret_cast<const f32x4*>(As + ra * 32 + 4 * ((4 * h + lq) ^ fa));
+                bv[h] = *reinterpret_cast<const f32x4*>(Bs + rbn * 32 + 4 * ((4 * h + lq) ^ fb));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][j], bv[h][j], acc, 0, 0, 0);
+        }
+    } else {
+        load_ep();
+    }
+    const f32x4 dh = acc_block_to_rows(tb, acc, lane) + pre;
+    const size_t o = (size_t)rb0 * H + cb0;
+    *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+    if (!g.gates) return;
+    const f32x4 rg = sv[0], zg = sv[1], ng = sv[2], hn = sv[3], hp = sv[4];
+    const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+    const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+    const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
+    float* d = g.dG_out + (size_t)rb0 * 4 * H + cb0;
+    *reinterpret_cast<f32x4*>(d) = dr_pre;
+    *reinterpret_cast<f32x4*>(d + H) = dz_pre;
+    *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
+    *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+}
+
+
 template <class TC, int PREC>
 static void launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
@@ -560,6 +661,19 @@ static int bwd_ep_step(int H) {
     return (knob >= 0 ? knob : kt / 4) & ~1;
 }
 
+// The direct-to-LDS backward step (gru_step_bwd_dl_kernel) covers full 32 x 32 tiles; CPG_GRU_BWD_DL=0 keeps the
+// register-staged kernel.
+static bool bwd_dl_shape_ok(int row0, int row1, int H) {
+    const char* e = getenv("CPG_GRU_BWD_DL");
+    if (e && atoi(e) == 0) return false;
+    return row0 % 32 == 0 && (row1 - row0) % 32 == 0 && row1 > row0 && H % 32 == 0;
+}
+// W_hh^T is needed by the split-engine tiles and by the direct-to-LDS kernel
+static bool bwd_wants_wt(int rows, int H, int nd, int row0, bool dense) {
+    const BwdChoice c = gru_bwd_choice(rows, H, nd, true);
+    return c.wt || (dense && c.tile == BT_32x32 && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H));
+}
+
 static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     GruBwdPair pr = pr_in;
     for (int d = 0; d < 2; ++d) pr.d[d].ep_step = bwd_ep_step(pr.d[d].H);
@@ -575,8 +689,18 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
         if (pr.d[d].w_hhT) vec = vec && aligned16(pr.d[d].w_hhT);
     }
     const BwdChoice c = gru_bwd_choice(a.row1 - a.row0, a.H, nd, have_wt);
-    if (c.wt) launch_bwd_tile<true>(c.tile, pr, nd, vec, s);
-    else launch_bwd_tile<false>(c.tile, pr, nd, vec, s);
+    bool dense = true;
+    for (int d = 0; d < nd; ++d) dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
+    if (!c.wt && c.tile == BT_32x32 && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
+        // direct-to-LDS main loop (gru_step_bwd_dl_kernel): same tiles, same sums
+        dim3 grid(a.H / 32, (a.row1 - a.row0) / 32, nd);
+        const size_t smem = (size_t)(DL_STAGES * DL_STAGE_FLOATS + 4 * 256) * sizeof(float);
+        hipLaunchKernelGGL(gru_step_bwd_dl_kernel, grid, dim3(256), smem, s, pr);
+    } else if (c.wt) {
+        launch_bwd_tile<true>(c.tile, pr, nd, vec, s);
+    } else {
+        launch_bwd_tile<false>(c.tile, pr, nd, vec, s);
+    }
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -731,6 +855,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     }
     if (kind == 1) {
         const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
+        if (!c.wt && c.tile == BT_32x32 && vec && have_wt && bwd_dl_shape_ok(0, B, H)) return snprintf(buf, n, "gru_step_bwd_dl_kernel");
         switch (c.tile) {
             case BT_64x32: tc_name<GB64>(tc, sizeof tc); break;
             case BT_32x64: tc_name<GB32>(tc, sizeof tc); break;
@@ -801,7 +926,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
-    if (w_hhT_scratch && !gru_bwd_choice(row_end - row_begin, H, 1, true).wt) w_hhT_scratch = nullptr;  // exact-f32 tiles: W_hh as stored
+    if (w_hhT_scratch && !bwd_wants_wt(row_end - row_begin, H, 1, row_begin, step_rows == nullptr)) w_hhT_scratch = nullptr;  // W_hh as stored
     if (w_hhT_scratch) {
         int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream);
         if (rc) return rc;
@@ -998,7 +1123,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
                                  float* w_hhT_scratch_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
-    if (w_hhT_scratch_f && !gru_bwd_choice(B, H, 2, true).wt) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // exact-f32 tiles
+    if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 2, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
     if (w_hhT_scratch_f) {
         int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream);
         if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream);
