@@ -413,6 +413,7 @@ using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab b
 constexpr int DL_TILE_FLOATS = 32 * 32;            // one operand slab: 32 rows x 32 k
 constexpr int DL_STAGE_FLOATS = 2 * DL_TILE_FLOATS;  // A + B
 constexpr int DL_STAGES = 3;
+constexpr int DL_AHEAD = 2;                        // slabs in flight ahead of the product
 __device__ __forceinline__ void dl_issue(const float* ga, const float* gb, float* stage, int wave) {
     // LDS destination: wave-uniform base (+ 16 bytes x lane added by the hardware)
     __builtin_amdgcn_global_load_lds(ga, (__attribute__((address_space(3))) void*)(stage + wave * 256), 16, 0, 0);
@@ -460,29 +461,37 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
         const int hook_kt = min(phase * g.ep_step, KT - 1);
-        dl_issue(ga, gb, cpg_smem, wave);
-        if (KT > 1) dl_issue(ga + 32, gb + 32, cpg_smem + DL_STAGE_FLOATS, wave);
-        for (int kt = 0; kt < KT; ++kt) {
+        // fragment word offsets inside a stage (slab-invariant)
+        const int oa0 = ra * 32 + 4 * ((0 + lq) ^ fa), oa1 = ra * 32 + 4 * ((4 + lq) ^ fa);
+        const int ob0 = DL_TILE_FLOATS + rbn * 32 + 4 * ((0 + lq) ^ fb), ob1 = DL_TILE_FLOATS + rbn * 32 + 4 * ((4 + lq) ^ fb);
+        // one slab: slab kt has landed once at most the loads of slab kt+1 are outstanding; the barrier then makes every wave's
+        // piece visible and retires every wave's fragment reads of slab kt-1, whose stage is refilled right after it
+        auto slab = [&](int kt, const float* cur, float* refill) {
             if (kt == hook_kt) load_ep();
-            // slab kt has landed once at most the loads of slab kt+1 are outstanding; the barrier then makes every wave's
-            // piece visible and retires every wave's fragment reads of slab kt-1 (whose stage is refilled next)
             if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < KT) dl_issue(ga + (kt + 2) * 32, gb + (kt + 2) * 32, cpg_smem + ((kt + 2) % DL_STAGES) * DL_STAGE_FLOATS, wave);
-            const float* As = cpg_smem + (kt % DL_STAGES) * DL_STAGE_FLOATS;
-            const float* Bs = As + DL_TILE_FLOATS;
-            f32x4 av[2], bv[2];
+            if (kt + DL_AHEAD < KT) dl_issue(ga + (kt + DL_AHEAD) * 32, gb + (kt + DL_AHEAD) * 32, refill, wave);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cur + oa0), b0 = *reinterpret_cast<const f32x4*>(cur + ob0);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(cur + oa1), b1 = *reinterpret_cast<const f32x4*>(cur + ob1);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                av[h] = *reinterpret_cast<const f32x4*>(As + ra * 32 + 4 * ((4 * h + lq) ^ fa));
-                bv[h] = *reinterpret_cast<const f32x4*>(Bs + rbn * 32 + 4 * ((4 * h + lq) ^ fb));
-            }
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc, 0, 0, 0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][j], bv[h][j], acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc, 0, 0, 0);
+        };
+        float* const S0 = cpg_smem;
+        float* const S1 = cpg_smem + DL_STAGE_FLOATS;
+        float* const S2 = cpg_smem + 2 * DL_STAGE_FLOATS;
+        dl_issue(ga, gb, S0, wave);
+        if (KT > 1) dl_issue(ga + 32, gb + 32, S1, wave);
+        int kt = 0;
+        for (; kt + 3 <= KT; kt += 3) {   // three slabs per trip: the stage of every access is a compile-time offset
+            slab(kt, S0, S2);
+            slab(kt + 1, S1, S0);
+            slab(kt + 2, S2, S1);
         }
+        if (kt < KT) slab(kt, S0, S2);
+        if (kt + 1 < KT) slab(kt + 1, S1, S0);
     } else {
         load_ep();
     }
