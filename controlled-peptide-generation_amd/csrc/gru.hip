@@ -410,104 +410,138 @@ using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab b
 // source-side swizzle instead: lane (row, slot s) loads k-chunk s ^ f(row), f(row) = (row >> 1) & 7, and the reader of k-chunk q
 // of a row reads slot q ^ f(row).  Contraction order = the register-staged kernel's (k = 16h + 4q + j): bit-identical sums.
 // Covers dense launches with B % 32 == 0, H % 32 == 0 and 16-byte aligned operands; everything else runs gru_step_bwd_kernel.
-constexpr int DL_TILE_FLOATS = 32 * 32;            // one operand slab: 32 rows x 32 k
-constexpr int DL_STAGE_FLOATS = 2 * DL_TILE_FLOATS;  // A + B
-constexpr int DL_STAGES = 3;
-constexpr int DL_AHEAD = 2;                        // slabs in flight ahead of the product
-__device__ __forceinline__ void dl_issue(const float* ga, const float* gb, float* stage, int wave) {
-    // LDS destination: wave-uniform base (+ 16 bytes x lane added by the hardware)
-    __builtin_amdgcn_global_load_lds(ga, (__attribute__((address_space(3))) void*)(stage + wave * 256), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(gb, (__attribute__((address_space(3))) void*)(stage + DL_TILE_FLOATS + wave * 256), 16, 0, 0);
-}
-
+// BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16); NS LDS stages, NS - 1 slabs in flight
+template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
-    using TC = GB32N;
+    constexpr int DL_STAGES = NS, DL_AHEAD = NS - 1;
+    constexpr int MI = BM / 32, NI = BN / 32;
+    constexpr int AF = BM * 32, BF = BN * 32, SF = AF + BF;   // floats per operand slab / per stage
+    constexpr int LPS = MI + NI;                              // LDS-DMA instructions per thread and slab
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
     const GruBwdArgs& g = pr.d[bz];
-    const int H = g.H, B = g.row1;
-    const int m0 = g.row0 + by * 32, j0 = bx * 32;
+    const int H = g.H;
+    const int m0 = g.row0 + by * BM, j0 = bx * BN;
     const size_t BH = (size_t)g.B * H;
     extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const tb = cpg_smem + DL_STAGES * DL_STAGE_FLOATS + wave * 256;
+    float* const tb = cpg_smem + DL_STAGES * SF + wave * 256;
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
-    const int rb0 = m0 + wm * 16 + (lane >> 2), cb0 = j0 + wn * 16 + 4 * (lane & 3);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 pre, sv[5];
-    auto load_ep = [&]() {
-        const size_t o = (size_t)rb0 * H + cb0;
-        f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
-        if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
-        if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
-        pre = p;
-        if (g.gates) {
+    const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
+    f32x4 acc[MI][NI];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
-            sv[4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
-        }
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pre[MI][NI], sv[MI][NI][5];
+    auto load_ep = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
+                f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+                if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
+                if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
+                pre[mi][ni] = p;
+                if (g.gates) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[mi][ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                    sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
+                }
+            }
     };
     if (g.dG_next) {
         const int K = 3 * H, KT = K / 32;
-        // this thread's 16-byte piece of a slab: row = tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
-        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);
+        // this thread's 16-byte pieces of a slab: piece i covers row = 32 i + tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
+        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);   // f(32 i + r) = f(r)
         const float* ga = g.dG_next + (size_t)(m0 + srow) * 4 * H + 4 * sch;
         const float* gb = g.w_hhT + (size_t)(j0 + srow) * K + 4 * sch;
-        // fragment addresses: row r of the wave's 16-row block, k-chunk q = 4h + lq  ->  slot q ^ f(r)
-        const int ra = wm * 16 + l15, rbn = wn * 16 + l15;
-        const int fa = (ra >> 1) & 7, fb = (rbn >> 1) & 7;
+        const size_t ga32 = (size_t)32 * 4 * H, gb32 = (size_t)32 * K;
+        auto issue = [&](int kt, float* stage) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                __builtin_amdgcn_global_load_lds(ga + i * ga32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
+        };
+        // fragment word offsets inside a stage (slab-invariant): row r of block mi / ni, k-chunk q = 4h + lq -> slot q ^ f(r)
+        const int ra = wm * (BM / 2) + l15, rbn = wn * (BN / 2) + l15;
+        const int fa = (ra >> 1) & 7, fb = (rbn >> 1) & 7;   // f is the same for rows 16 apart
+        const int oa0 = ra * 32 + 4 * (lq ^ fa), oa1 = ra * 32 + 4 * ((4 + lq) ^ fa);
+        const int ob0 = AF + rbn * 32 + 4 * (lq ^ fb), ob1 = AF + rbn * 32 + 4 * ((4 + lq) ^ fb);
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
         const int hook_kt = min(phase * g.ep_step, KT - 1);
-        // fragment word offsets inside a stage (slab-invariant)
-        const int oa0 = ra * 32 + 4 * ((0 + lq) ^ fa), oa1 = ra * 32 + 4 * ((4 + lq) ^ fa);
-        const int ob0 = DL_TILE_FLOATS + rbn * 32 + 4 * ((0 + lq) ^ fb), ob1 = DL_TILE_FLOATS + rbn * 32 + 4 * ((4 + lq) ^ fb);
         // one slab: slab kt has landed once at most the loads of slab kt+1 are outstanding; the barrier then makes every wave's
         // piece visible and retires every wave's fragment reads of slab kt-1, whose stage is refilled right after it
         auto slab = [&](int kt, const float* cur, float* refill) {
             if (kt == hook_kt) load_ep();
-            if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // loads of the slabs kt+1 .. kt+AHEAD-1 may stay in flight (fewer near the end of the K range)
+            if (NS == 3) {   // the shipped form: one compare per slab
+                if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const int left = KT - 1 - kt;
+                if (left >= DL_AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (DL_AHEAD - 1)) : "memory");
+                else if (DL_AHEAD > 2 && left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * 2) : "memory");
+                else if (DL_AHEAD > 1 && left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            if (kt + DL_AHEAD < KT) dl_issue(ga + (kt + DL_AHEAD) * 32, gb + (kt + DL_AHEAD) * 32, refill, wave);
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(cur + oa0), b0 = *reinterpret_cast<const f32x4*>(cur + ob0);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(cur + oa1), b1 = *reinterpret_cast<const f32x4*>(cur + ob1);
+            if (kt + DL_AHEAD < KT) issue(kt + DL_AHEAD, refill);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc, 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                f32x4 av[MI], bv[NI];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc, 0, 0, 0);
+                for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(cur + (h ? oa1 : oa0) + mi * 512);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(cur + (h ? ob1 : ob0) + ni * 512);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            }
         };
-        float* const S0 = cpg_smem;
-        float* const S1 = cpg_smem + DL_STAGE_FLOATS;
-        float* const S2 = cpg_smem + 2 * DL_STAGE_FLOATS;
-        dl_issue(ga, gb, S0, wave);
-        if (KT > 1) dl_issue(ga + 32, gb + 32, S1, wave);
+#pragma unroll
+        for (int i = 0; i < DL_AHEAD; ++i)
+            if (i < KT) issue(i, cpg_smem + i * SF);
         int kt = 0;
-        for (; kt + 3 <= KT; kt += 3) {   // three slabs per trip: the stage of every access is a compile-time offset
-            slab(kt, S0, S2);
-            slab(kt + 1, S1, S0);
-            slab(kt + 2, S2, S1);
+        for (; kt + NS <= KT; kt += NS) {   // NS slabs per trip: the stage of every access is a compile-time offset
+#pragma unroll
+            for (int i = 0; i < NS; ++i) slab(kt + i, cpg_smem + i * SF, cpg_smem + ((i + NS - 1) % NS) * SF);
         }
-        if (kt < KT) slab(kt, S0, S2);
-        if (kt + 1 < KT) slab(kt + 1, S1, S0);
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i)
+            if (kt + i < KT) slab(kt + i, cpg_smem + i * SF, cpg_smem + ((i + NS - 1) % NS) * SF);
     } else {
         load_ep();
     }
-    const f32x4 dh = acc_block_to_rows(tb, acc, lane) + pre;
-    const size_t o = (size_t)rb0 * H + cb0;
-    *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
-    if (!g.gates) return;
-    const f32x4 rg = sv[0], zg = sv[1], ng = sv[2], hn = sv[3], hp = sv[4];
-    const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
-    const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
-    const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
-    float* d = g.dG_out + (size_t)rb0 * 4 * H + cb0;
-    *reinterpret_cast<f32x4*>(d) = dr_pre;
-    *reinterpret_cast<f32x4*>(d + H) = dz_pre;
-    *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
-    *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
+            const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
+            const size_t o = (size_t)row * H + col;
+            *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+            if (!g.gates) continue;
+            const f32x4 rg = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
+            const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+            const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+            const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
+            float* d = g.dG_out + (size_t)row * 4 * H + col;
+            *reinterpret_cast<f32x4*>(d) = dr_pre;
+            *reinterpret_cast<f32x4*>(d + H) = dz_pre;
+            *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
+            *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+        }
 }
 
 
@@ -683,6 +717,21 @@ static bool bwd_wants_wt(int rows, int H, int nd, int row0, bool dense) {
     return c.wt || (dense && c.tile == BT_32x32 && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H));
 }
 
+template <int BM, int BN, int NS>
+static void launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
+    const GruBwdArgs& a = pr.d[0];
+    dim3 grid(a.H / BN, (a.row1 - a.row0) / BM, nd);
+    const size_t smem = (size_t)(NS * (BM + BN) * 32 + 4 * 256) * sizeof(float);
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, NS>), grid, dim3(256), smem, s, pr);
+}
+
 static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     GruBwdPair pr = pr_in;
     for (int d = 0; d < 2; ++d) pr.d[d].ep_step = bwd_ep_step(pr.d[d].H);
@@ -701,10 +750,34 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     bool dense = true;
     for (int d = 0; d < nd; ++d) dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
     if (!c.wt && c.tile == BT_32x32 && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
-        // direct-to-LDS main loop (gru_step_bwd_dl_kernel): same tiles, same sums
-        dim3 grid(a.H / 32, (a.row1 - a.row0) / 32, nd);
-        const size_t smem = (size_t)(DL_STAGES * DL_STAGE_FLOATS + 4 * 256) * sizeof(float);
-        hipLaunchKernelGGL(gru_step_bwd_dl_kernel, grid, dim3(256), smem, s, pr);
+        // direct-to-LDS main loop (gru_step_bwd_dl_kernel): same sums whatever the tile
+        // Tile (tools/kbench.py, B=2048, H=512, us per launch; 32x32 / 64x32 / 32x64 / 64x64): single direction 38.9 / 35.5 /
+        // 35.0 / 38.2, paired directions 71.6 / 66.9 / 68.0 / 60.7 - larger tiles halve the operand traffic per MFMA, as long as
+        // at least two workgroups per CU remain.  CPG_GRU_BWD_DL_TILE / CPG_GRU_BWD_DL_STAGES (2 | 3 | 4: no effect) override.
+        const char* t = getenv("CPG_GRU_BWD_DL_TILE");
+        const char* st = getenv("CPG_GRU_BWD_DL_STAGES");
+        const int ns = st ? atoi(st) : 3;
+        const int rows = a.row1 - a.row0;
+        const bool r64 = rows % 64 == 0, h64 = a.H % 64 == 0;
+        const long wg64 = (long)(rows / 64) * (a.H / 64) * nd;   // 64 x 64 tiles of the launch
+        int bm = 32, bn = 32;
+        if (t) {
+            if (!strcmp(t, "64x64")) { bm = 64; bn = 64; }
+            else if (!strcmp(t, "64x32")) { bm = 64; }
+            else if (!strcmp(t, "32x64")) { bn = 64; }
+        } else if (r64 && h64 && wg64 >= 512) {
+            bm = bn = 64;
+        } else if (r64 && wg64 >= 256) {
+            bm = 64;
+        }
+        if (bm == 64 && !r64) bm = 32;
+        if (bn == 64 && !h64) bn = 32;
+#define CPG_DL_PICK(BM, BN) (ns == 4 ? launch_dl<BM, BN, 4>(pr, nd, s) : ns == 2 ? launch_dl<BM, BN, 2>(pr, nd, s) : launch_dl<BM, BN, 3>(pr, nd, s))
+        if (bm == 64 && bn == 64) CPG_DL_PICK(64, 64);
+        else if (bm == 64) CPG_DL_PICK(64, 32);
+        else if (bn == 64) CPG_DL_PICK(32, 64);
+        else CPG_DL_PICK(32, 32);
+#undef CPG_DL_PICK
     } else if (c.wt) {
         launch_bwd_tile<true>(c.tile, pr, nd, vec, s);
     } else {
@@ -864,7 +937,12 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     }
     if (kind == 1) {
         const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
-        if (!c.wt && c.tile == BT_32x32 && vec && have_wt && bwd_dl_shape_ok(0, B, H)) return snprintf(buf, n, "gru_step_bwd_dl_kernel");
+        if (!c.wt && c.tile == BT_32x32 && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
+            const bool r64 = B % 64 == 0, h64 = H % 64 == 0;
+            const long wg64 = (long)(B / 64) * (H / 64) * ndir;
+            const int bm = (r64 && h64 && wg64 >= 512) || (r64 && wg64 >= 256) ? 64 : 32, bn = (r64 && h64 && wg64 >= 512) ? 64 : 32;
+            return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3>", bm, bn);
+        }
         switch (c.tile) {
             case BT_64x32: tc_name<GB64>(tc, sizeof tc); break;
             case BT_32x64: tc_name<GB32>(tc, sizeof tc); break;
