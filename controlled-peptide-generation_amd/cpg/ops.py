@@ -123,6 +123,16 @@ def row_groups(B):
     return [(r, min(B, r + step)) for r in range(0, B, step)]
 
 
+def bwd_row_groups(B):
+    """Row groups of a BACKWARD recurrence (CPG_BWD_ROW_GROUPS, default 1): independent launch chains on side streams whose
+    fixed phases (launch ramp, epilogue traffic) can sit under the other chain's matrix phase."""
+    g = int(_os.environ.get("CPG_BWD_ROW_GROUPS", "0"))
+    if g <= 1 or B < 128:
+        return [(0, B)]
+    step = -(-(-(-B // 2)) // 64) * 64
+    return [(r, min(B, r + step)) for r in range(0, B, step)]
+
+
 class fork:
     """`with fork(device) as f: f.run(i, fn)` runs fn on side stream i after everything already queued on the current
     stream; leaving the block makes the current stream wait for all branches."""
@@ -484,7 +494,10 @@ class GruSeqFn(Function):
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         groups = row_groups(B)
-        wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # W_hh^T for the split-bf16 backward step kernels
+        if len(groups) == 1 and step_rows is None:
+            groups = bwd_row_groups(B)
+        wT = torch.empty(len(groups), H, 3 * H, device=dev, dtype=torch.float32)  # W_hh^T: split-bf16 / direct-to-LDS kernels
+        wT = wT[0] if len(groups) == 1 else wT
         if step_rows is None and len(groups) == 1 and persistent_bwd_fits(T, B, H):
             with _prof("bwd_persist", 1, T=T, B=B, H=H, ndir=1):
                 gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, None, dG, dh0)
@@ -500,7 +513,7 @@ class GruSeqFn(Function):
                 for gi, (r0, r1) in enumerate(groups):
                     f.run(gi, lambda r0=r0, r1=r1: call(
                         "cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                        _p(scratch), _p(dh0), r0, r1, _p(step_rows), None, _stream()))
+                        _p(scratch), _p(dh0), r0, r1, _p(step_rows), _p(wT[gi]), _stream()))
         if has_h0 and not ctx.tail:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
