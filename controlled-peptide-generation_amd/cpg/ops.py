@@ -720,8 +720,9 @@ class LstmSeqFn(Function):
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
         dc0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
         with _prof("lstm_bwd_step", T + (1 if need0 else 0), T=T, B=B, H=H, ndir=1):
+            wT = torch.empty(H, 4 * H, device=dev, dtype=torch.float32)   # W_hh^T for the direct-to-LDS step kernel
             call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
-                 _p(dh0), _p(dc0), _stream())
+                 _p(dh0), _p(dc0), _p(wT), _stream())
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))

@@ -738,3 +738,106 @@ __device__ __forceinline__ int acc_col(int ni) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     return (wave % TC::WN) * TC::WTN + ni * 16 + (lane & 15);
 }
+
+// 16x16 accumulator block (lane (u = l&15, rq = l>>4), reg -> row 4rq+reg, col u) -> one f32x4 per lane in row layout
+// (lane -> row l>>2, cols 4(l&3)..+3) through a 1 KB per-wave LDS buffer no other wave touches
+__device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int lane) {
+    const int u = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tb[(4 * rq + r) * 16 + u] = v[r];
+    return *reinterpret_cast<const f32x4*>(tb + (lane >> 2) * 16 + 4 * (lane & 3));
+}
+
+
+// ---- direct-to-LDS main loop for products with BOTH operands K-contiguous: acc[mi][ni] += A[rows, K] . B[cols, K]^T on the
+// exact-f32 MFMA, BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16).  Operands are staged by
+// `global_load_lds_dwordx4` into an NS-stage LDS ring, NS - 1 slabs ahead of the product: no staging registers, no ds_write
+// pass, one ds_read_b128 per fragment half, and almost no VALU work in the slab loop (the exact-f32 MFMA shares its lanes with
+// the VALU: every address / mask instruction of the register-staged loop is paid in matrix-pipe time).  An LDS-DMA lane writes
+// to base + 16 * lane, so the image is unpadded ([row][32 floats]); bank conflicts of the fragment reads are avoided by a
+// source-side swizzle instead: lane (row, slot s) loads k-chunk s ^ f(row), f(row) = (row >> 1) & 7, and the reader of k-chunk q
+// of a row reads slot q ^ f(row) (PMC: 1 % of the LDS cycles in conflicts).  Contraction order = MainLoop's permuted order
+// (k = 16h + 4q + j): sums are bit-identical to the register-staged exact-f32 kernels.
+// Requirements: full tiles (no bound masks), K % 32 == 0, 16-byte aligned rows (lda, ldb multiples of 4, aligned bases).
+// `hook` runs once ahead of slab hook_kt (the caller's own global loads; < 0: never).  smem: smem_floats() floats.
+template <int BM, int BN, int NS = 3>
+struct DlLoop {
+    static constexpr int MI = BM / 32, NI = BN / 32;
+    static constexpr int AF = BM * 32, BF = BN * 32, SF = AF + BF;   // floats per operand slab / per stage
+    static constexpr int LPS = MI + NI;                              // LDS-DMA instructions per thread and slab
+    static constexpr int AHEAD = NS - 1;
+    static constexpr size_t smem_floats() { return (size_t)NS * SF; }
+
+    template <class Hook>
+    __device__ static __forceinline__ void run(const float* A, size_t lda, const float* Bt, size_t ldb, int K, float* smem,
+                                               f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook) {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+        const int KT = K / 32;
+        // this thread's 16-byte pieces of a slab: piece i covers row = 32 i + tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
+        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);   // f(32 i + r) = f(r)
+        const float* ga = A + (size_t)srow * lda + 4 * sch;
+        const float* gb = Bt + (size_t)srow * ldb + 4 * sch;
+        const size_t ga32 = 32 * lda, gb32 = 32 * ldb;
+        auto issue = [&](int kt, float* stage) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                __builtin_amdgcn_global_load_lds(ga + i * ga32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
+        };
+        // fragment word offsets inside a stage (slab-invariant): row r of block mi / ni, k-chunk q = 4h + lq -> slot q ^ f(r)
+        const int ra = wm * (BM / 2) + l15, rbn = wn * (BN / 2) + l15;
+        const int fa = (ra >> 1) & 7, fb = (rbn >> 1) & 7;   // f is the same for rows 16 apart
+        const int oa0 = ra * 32 + 4 * (lq ^ fa), oa1 = ra * 32 + 4 * ((4 + lq) ^ fa);
+        const int ob0 = AF + rbn * 32 + 4 * (lq ^ fb), ob1 = AF + rbn * 32 + 4 * ((4 + lq) ^ fb);
+        // one slab: slab kt has landed once only the loads of the slabs after it are outstanding; the barrier then makes every
+        // wave's piece visible and retires every wave's fragment reads of slab kt-1, whose stage is refilled right after it
+        auto slab = [&](int kt, const float* cur, float* refill) {
+            if (kt == hook_kt) hook();
+            if (NS == 3) {   // the shipped form: one compare per slab
+                if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const int left = KT - 1 - kt;
+                if (left >= AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (AHEAD - 1)) : "memory");
+                else if (AHEAD > 2 && left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * 2) : "memory");
+                else if (AHEAD > 1 && left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + AHEAD < KT) issue(kt + AHEAD, refill);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 av[MI], bv[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(cur + (h ? oa1 : oa0) + mi * 512);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(cur + (h ? ob1 : ob0) + ni * 512);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i)
+            if (i < KT) issue(i, smem + i * SF);
+        int kt = 0;
+        for (; kt + NS <= KT; kt += NS) {   // NS slabs per trip: the stage of every access is a compile-time offset
+#pragma unroll
+            for (int i = 0; i < NS; ++i) slab(kt + i, smem + i * SF, smem + ((i + NS - 1) % NS) * SF);
+        }
+#pragma unroll
+        for (int i = 0; i < NS - 1; ++i)
+            if (kt + i < KT) slab(kt + i, smem + i * SF, smem + ((i + NS - 1) % NS) * SF);
+        // the last slab's fragment reads are done when its MFMAs have their operands; callers that reuse the LDS ring must
+        // place a barrier first
+    }
+};
+

@@ -180,15 +180,6 @@ template <class TC, bool VEC, bool WT, int PREC = 7>
 using BwdLoop = MainLoop<TC, true, WT, VEC, VEC, false,
                          (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && (WT || TC::BV % 2 == 0)) ? PREC : 0>;
 
-// 16x16 accumulator block (lane (u = l&15, rq = l>>4), reg -> row 4rq+reg, col u) -> one f32x4 per lane in row layout
-// (lane -> row l>>2, cols 4(l&3)..+3) through a 1 KB per-wave LDS buffer no other wave touches
-__device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int lane) {
-    const int u = lane & 15, rq = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tb[(4 * rq + r) * 16 + u] = v[r];
-    return *reinterpret_cast<const f32x4*>(tb + (lane >> 2) * 16 + 4 * (lane & 3));
-}
-
 template <class TC, bool VEC, bool WT, int PREC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
@@ -410,13 +401,11 @@ using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab b
 // source-side swizzle instead: lane (row, slot s) loads k-chunk s ^ f(row), f(row) = (row >> 1) & 7, and the reader of k-chunk q
 // of a row reads slot q ^ f(row).  Contraction order = the register-staged kernel's (k = 16h + 4q + j): bit-identical sums.
 // Covers dense launches with B % 32 == 0, H % 32 == 0 and 16-byte aligned operands; everything else runs gru_step_bwd_kernel.
-// BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16); NS LDS stages, NS - 1 slabs in flight
+// BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16); main loop: DlLoop (gemm_core.h)
 template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
-    constexpr int DL_STAGES = NS, DL_AHEAD = NS - 1;
-    constexpr int MI = BM / 32, NI = BN / 32;
-    constexpr int AF = BM * 32, BF = BN * 32, SF = AF + BF;   // floats per operand slab / per stage
-    constexpr int LPS = MI + NI;                              // LDS-DMA instructions per thread and slab
+    using DL = DlLoop<BM, BN, NS>;
+    constexpr int MI = DL::MI, NI = DL::NI;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
     const GruBwdArgs& g = pr.d[bz];
@@ -426,8 +415,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
     extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const tb = cpg_smem + DL_STAGES * SF + wave * 256;
-    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
+    const int wm = wave >> 1, wn = wave & 1;
     const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -454,72 +443,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             }
     };
     if (g.dG_next) {
-        const int K = 3 * H, KT = K / 32;
-        // this thread's 16-byte pieces of a slab: piece i covers row = 32 i + tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
-        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);   // f(32 i + r) = f(r)
-        const float* ga = g.dG_next + (size_t)(m0 + srow) * 4 * H + 4 * sch;
-        const float* gb = g.w_hhT + (size_t)(j0 + srow) * K + 4 * sch;
-        const size_t ga32 = (size_t)32 * 4 * H, gb32 = (size_t)32 * K;
-        auto issue = [&](int kt, float* stage) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                __builtin_amdgcn_global_load_lds(ga + i * ga32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
-        };
-        // fragment word offsets inside a stage (slab-invariant): row r of block mi / ni, k-chunk q = 4h + lq -> slot q ^ f(r)
-        const int ra = wm * (BM / 2) + l15, rbn = wn * (BN / 2) + l15;
-        const int fa = (ra >> 1) & 7, fb = (rbn >> 1) & 7;   // f is the same for rows 16 apart
-        const int oa0 = ra * 32 + 4 * (lq ^ fa), oa1 = ra * 32 + 4 * ((4 + lq) ^ fa);
-        const int ob0 = AF + rbn * 32 + 4 * (lq ^ fb), ob1 = AF + rbn * 32 + 4 * ((4 + lq) ^ fb);
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
-        const int hook_kt = min(phase * g.ep_step, KT - 1);
-        // one slab: slab kt has landed once at most the loads of slab kt+1 are outstanding; the barrier then makes every wave's
-        // piece visible and retires every wave's fragment reads of slab kt-1, whose stage is refilled right after it
-        auto slab = [&](int kt, const float* cur, float* refill) {
-            if (kt == hook_kt) load_ep();
-            // loads of the slabs kt+1 .. kt+AHEAD-1 may stay in flight (fewer near the end of the K range)
-            if (NS == 3) {   // the shipped form: one compare per slab
-                if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else {
-                const int left = KT - 1 - kt;
-                if (left >= DL_AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * (DL_AHEAD - 1)) : "memory");
-                else if (DL_AHEAD > 2 && left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS * 2) : "memory");
-                else if (DL_AHEAD > 1 && left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            if (kt + DL_AHEAD < KT) issue(kt + DL_AHEAD, refill);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 av[MI], bv[NI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(cur + (h ? oa1 : oa0) + mi * 512);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(cur + (h ? ob1 : ob0) + ni * 512);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < DL_AHEAD; ++i)
-            if (i < KT) issue(i, cpg_smem + i * SF);
-        int kt = 0;
-        for (; kt + NS <= KT; kt += NS) {   // NS slabs per trip: the stage of every access is a compile-time offset
-#pragma unroll
-            for (int i = 0; i < NS; ++i) slab(kt + i, cpg_smem + i * SF, cpg_smem + ((i + NS - 1) % NS) * SF);
-        }
-#pragma unroll
-        for (int i = 0; i < NS - 1; ++i)
-            if (kt + i < KT) slab(kt + i, cpg_smem + i * SF, cpg_smem + ((i + NS - 1) % NS) * SF);
+        DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
+                min(phase * g.ep_step, 3 * H / 32 - 1), load_ep);
     } else {
         load_ep();
     }
@@ -721,7 +648,7 @@ template <int BM, int BN, int NS>
 static void launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(a.H / BN, (a.row1 - a.row0) / BM, nd);
-    const size_t smem = (size_t)(NS * (BM + BN) * 32 + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, NS>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {

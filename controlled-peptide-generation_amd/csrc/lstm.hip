@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(LstmFwdArgs g) {
 struct LstmBwdArgs {
     const float* dG_next;  // [B,4H] of the step processed just before (s+1), null on the first launch
     const float* w_hh;     // [4H,H]
+    const float* w_hhT;    // [H,4H] = w_hh^T, or null (direct-to-LDS kernel only)
     const float* dC_next;  // [B,H] carried cell gradient dc_{s+1} * f_{s+1}, null on the first launch
     const float* ext;      // [B,H] external gradient on h_s
     const float* gates;    // [4,B,H] of step s; null on the closing launch (emits dh0 / dc0)
@@ -196,6 +197,80 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
     }
 }
 
+// Backward step with the direct-to-LDS main loop (DlLoop, gemm_core.h): dG_next [B,4H] . W_hh^T rows, both K-contiguous, exact-f32
+// MFMA, 16-byte row-layout epilogue.  Same sums as lstm_step_bwd_kernel (same contraction order); dense full tiles only.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdArgs g) {
+    using DL = DlLoop<BM, BN, 3>;
+    constexpr int MI = DL::MI, NI = DL::NI;
+    const int H = g.H;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = by * BM, j0 = bx * BN;
+    const size_t BH = (size_t)g.B * H;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pre[MI][NI], sv[MI][NI][7];
+    auto load_ep = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
+                const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+                pre[mi][ni] = g.ext ? *reinterpret_cast<const f32x4*>(g.ext + o) : zero;
+                sv[mi][ni][6] = g.dC_next ? *reinterpret_cast<const f32x4*>(g.dC_next + o) : zero;
+                if (g.gates) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[mi][ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                    sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(g.c_prev + o);
+                    sv[mi][ni][5] = *reinterpret_cast<const f32x4*>(g.c_cur + o);
+                }
+            }
+    };
+    if (g.dG_next) {
+        const int hb = blockIdx.x + gridDim.x * blockIdx.y;
+        const int phase = ((hb >> 3) + (hb >> 8)) & 3, KT = 4 * H / 32;
+        DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 4 * H, (size_t)4 * H, 4 * H, cpg_smem, acc,
+                min(phase * ((KT / 4) & ~1), KT - 1), load_ep);
+    } else {
+        load_ep();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
+            const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
+            const f32x4 dcn = sv[mi][ni][6];
+            if (!g.gates) {
+                *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+                *reinterpret_cast<f32x4*>(g.dC_out + o) = dcn;
+                continue;
+            }
+            const f32x4 ig = sv[mi][ni][0], fg = sv[mi][ni][1], gg = sv[mi][ni][2], og = sv[mi][ni][3], cpv = sv[mi][ni][4];
+            f32x4 tc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tc[e] = tanhf(sv[mi][ni][5][e]);
+            const f32x4 dc = dcn + dh * og * (1.f - tc * tc);
+            *reinterpret_cast<f32x4*>(g.dC_out + o) = dc * fg;
+            float* d = g.dG_out + (size_t)(rb0 + 16 * mi) * 4 * H + cb0 + 16 * ni;
+            *reinterpret_cast<f32x4*>(d) = dc * gg * ig * (1.f - ig);
+            *reinterpret_cast<f32x4*>(d + H) = dc * cpv * fg * (1.f - fg);
+            *reinterpret_cast<f32x4*>(d + 2 * H) = dc * ig * (1.f - gg * gg);
+            *reinterpret_cast<f32x4*>(d + 3 * H) = dh * tc * og * (1.f - og);
+        }
+}
+
 using LF64 = TileCfg<64, 128, 32, 2, 2, 4>;
 using LF32 = TileCfg<32, 128, 32, 2, 2, 4>;
 using LF64S = TileCfg<64, 64, 32, 4, 1, 4>;   // 64 rows x (4 gates x 16 units): 61 KB of bf16 planes, two workgroups per CU
@@ -203,6 +278,7 @@ using LB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using LB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 using LB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
+static bool lstm_dl_ok(int B, int H);
 // tile choices of the step launches (shared by the launchers and the introspection entry point below)
 static int lstm_fwd_choice(int B, int H) { return B >= 64 ? 0 : ((B > 32 && (long)cdiv(B, 32) * cdiv(H, 32) < 1024) ? 1 : 2); }  // LF64S | LF64 | LF32
 static int lstm_bwd_choice(int B, int H) { return (long)cdiv(B, 32) * cdiv(H, 32) >= 1024 ? 0 : (B > 32 ? 1 : 2); }               // LB32N | LB64 | LB32
@@ -224,6 +300,8 @@ CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int 
         return snprintf(buf, n, "lstm_step_fwd_kernel<%s, %s>", tc, vec);
     }
     if (kind == 1) {
+        if (lstm_dl_ok(B, H) && H % 4 == 0)
+            return snprintf(buf, n, "lstm_step_bwd_dl_kernel<64, %d>", (H % 64 == 0 && (long)(B / 64) * (H / 64) >= 512) ? 64 : 32);
         const int c = lstm_bwd_choice(B, H);
         if (c == 0) lstm_tc_name<LB32N>(tc, sizeof tc);
         else if (c == 1) lstm_tc_name<LB64>(tc, sizeof tc);
@@ -267,7 +345,53 @@ static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
     return 0;
 }
 
+// out[C,R] = w[R,C]^T
+__global__ void lstm_transpose_w_kernel(const float* w, int R, int C, float* out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[i][threadIdx.x] = w[(size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[(size_t)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+// direct-to-LDS backward step: dense full tiles, W_hh^T handed over.  CPG_LSTM_BWD_DL=0 keeps the register-staged kernel.
+static bool lstm_dl_ok(int B, int H) {
+    const char* e = getenv("CPG_LSTM_BWD_DL");
+    if (e && atoi(e) == 0) return false;
+    return B % 64 == 0 && H % 32 == 0;
+}
+template <int BM, int BN>
+static void lstm_launch_dl(const LstmBwdArgs& a, hipStream_t s) {
+    const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN>), dim3(a.H / BN, a.B / BM), dim3(256), smem, s, a);
+}
+
 static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
+    if (a.w_hhT && lstm_dl_ok(a.B, a.H)) {
+        const void* ptrs[] = {a.dG_next, a.w_hhT, a.dC_next, a.ext, a.gates, a.c_prev, a.c_cur, a.dH_out, a.dC_out, a.dG_out};
+        bool al = true;
+        for (const void* q : ptrs) al = al && (!q || aligned16(q));
+        if (al) {
+            // 64 x 64 tiles once they give two workgroups per CU, else 64 x 32 (as the GRU kernel: csrc/gru.hip)
+            if (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) >= 512) lstm_launch_dl<64, 64>(a, s);
+            else lstm_launch_dl<64, 32>(a, s);
+            CPG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
     const int choice = lstm_bwd_choice(a.B, a.H);
     if (choice == 0) {
@@ -321,9 +445,16 @@ CPG_EXPORT int cpg_lstm_step_fwd(int B, int H, const float* w_hh, const float* b
 // dhs_ext [T,B,H] (time-aligned, may be null); dG out [T,B,4H]; scratch [2,B,H] (carried cell gradient);
 // dh0, dc0 [B,H] (both or neither).
 CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
-                                const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, void* stream) {
+                                const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
+                                void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && cs && gates && dG && scratch && ((dh0 == nullptr) == (dc0 == nullptr)));
     const size_t BH = (size_t)B * H;
+    if (w_hhT_scratch && !lstm_dl_ok(B, H)) w_hhT_scratch = nullptr;
+    if (w_hhT_scratch) {   // W_hh^T [H,4H] once per sequence: the direct-to-LDS kernel wants both operands K-contiguous
+        hipLaunchKernelGGL(lstm_transpose_w_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, (hipStream_t)stream, w_hh,
+                           4 * H, H, w_hhT_scratch);
+        CPG_LAUNCH_CHECK();
+    }
     int prev_t = -1;
     for (int p = T - 1; p >= -1; --p) {
         if (p < 0 && !dh0) break;
@@ -333,6 +464,7 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
         a.B = B;
         a.H = H;
         a.w_hh = w_hh;
+        a.w_hhT = w_hhT_scratch;
         a.dG_next = prev_t >= 0 ? dG + (size_t)prev_t * B * 4 * H : nullptr;
         a.dC_next = prev_t >= 0 ? scratch + (size_t)(cur ^ 1) * BH : nullptr;
         if (p >= 0) {

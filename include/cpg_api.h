@@ -206,7 +206,9 @@ CPG_API int cpg_lstm_step_fwd(int B, int H, const float* w_hh, const float* b_hh
                               const float* rowc, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
                               void* stream);
 CPG_API int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
-                             const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, void* stream);
+                             const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0,
+                             float* w_hhT_scratch /* [H,4H] or null: receives W_hh^T for the direct-to-LDS step kernel */,
+                             void* stream);
 CPG_API int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
                               float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 CPG_API int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,

@@ -232,3 +232,31 @@ def test_lstm_persistent_limits_and_knob(monkeypatch):
     assert not ops.lstm_persistent_fits(8192, 512)     # 1024 workgroups
     monkeypatch.setenv("CPG_LSTM_PERSIST", "0")
     assert not ops.lstm_persistent_fits(2048, 512)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,T,reverse", [(128, 64, 5, False), (192, 96, 4, True), (2048, 512, 6, False)])
+def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reverse, monkeypatch):
+    """lstm_step_bwd_dl_kernel (global_load_lds ring, W_hh^T) against lstm_step_bwd_kernel: same products in the same contraction
+    order; the cell backward is written on 4-vectors there and on scalars here (fused-multiply-add contraction may differ): dG,
+    dh0, dc0 within 2e-6 of their scale."""
+    from cpg.ops import _p, _stream, call
+    dev = torch.device("cuda")
+    d = _lstm_inputs(B, H, T, 24, seed=B + H)
+    hs, cs, gates = _lstm_run(d, B, H, T, reverse, False)
+    g = torch.Generator().manual_seed(3)
+    dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
+    out = []
+    for dl in ("1", "0"):
+        monkeypatch.setenv("CPG_LSTM_BWD_DL", dl)
+        dG = torch.zeros(T, B, 4 * H, device=dev)
+        scr = torch.empty(2, B, H, device=dev)
+        dh0, dc0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+        wT = torch.empty(H, 4 * H, device=dev)
+        call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dhs), _p(dG), _p(scr), _p(dh0), _p(dc0),
+             _p(wT), _stream())
+        torch.cuda.synchronize()
+        out.append((dG, dh0, dc0))
+    for a, b in zip(*out):
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
