@@ -571,6 +571,7 @@ enum BwdTile { BT_64x32, BT_32x64, BT_64x64, BT_128x32, BT_128x64, BT_32x32, BT_
 struct BwdChoice {
     bool wt;
     BwdTile tile;
+    bool forced = false;   // a CPG_GRU_BWD_BM / _WIDE knob asked for this register-staged tile: the direct-to-LDS kernel stays out
 };
 static BwdChoice gru_bwd_choice(int rows, int H, int nd, bool have_wt) {
     const char* wide = getenv("CPG_GRU_BWD_WIDE");
@@ -586,14 +587,15 @@ static BwdChoice gru_bwd_choice(int rows, int H, int nd, bool have_wt) {
         const int bm = pick_bm(rows, cdiv(H, 32), "CPG_GRU_BWD_BM");
         // 32x32 tiles (>= 1024 workgroups) measured 51.4 us vs 53.7 us for 64x32 at B=2048,H=512; wider tiles lose badly (77 / 116 us)
         const bool small = !wide && !bmk && (long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024;
+        const bool forced = wide || bmk;
         if (small) return {false, BT_32x32};
-        if (wide && atoi(wide) == 64) return {false, BT_64x64};
-        if (wide && atoi(wide) == 128) return {false, BT_128x64};
-        if (wide && atoi(wide) == 32) return {false, BT_32x32};
-        if (wide && atoi(wide) == 3264) return {false, BT_32x32K64};
-        if (bm == 128) return {false, BT_128x32};
-        if (bm == 64) return {false, BT_64x32};
-        return {false, BT_32x64};
+        if (wide && atoi(wide) == 64) return {false, BT_64x64, true};
+        if (wide && atoi(wide) == 128) return {false, BT_128x64, true};
+        if (wide && atoi(wide) == 32) return {false, BT_32x32, true};
+        if (wide && atoi(wide) == 3264) return {false, BT_32x32K64, true};
+        if (bm == 128) return {false, BT_128x32, forced};
+        if (bm == 64) return {false, BT_64x32, forced};
+        return {false, BT_32x64, forced};
     }
     if (t) {
         if (!strcmp(t, "64x32")) return {true, BT_64x32};
@@ -641,7 +643,7 @@ static bool bwd_dl_shape_ok(int row0, int row1, int H) {
 // W_hh^T is needed by the split-engine tiles and by the direct-to-LDS kernel
 static bool bwd_wants_wt(int rows, int H, int nd, int row0, bool dense) {
     const BwdChoice c = gru_bwd_choice(rows, H, nd, true);
-    return c.wt || (dense && c.tile == BT_32x32 && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H));
+    return c.wt || (dense && !c.forced && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H));
 }
 
 template <int BM, int BN, int NS>
@@ -676,7 +678,7 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     const BwdChoice c = gru_bwd_choice(a.row1 - a.row0, a.H, nd, have_wt);
     bool dense = true;
     for (int d = 0; d < nd; ++d) dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
-    if (!c.wt && c.tile == BT_32x32 && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
+    if (!c.wt && !c.forced && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
         // direct-to-LDS main loop (gru_step_bwd_dl_kernel): same sums whatever the tile
         // Tile (tools/kbench.py, B=2048, H=512, us per launch; 32x32 / 64x32 / 32x64 / 64x64): single direction 38.9 / 35.5 /
         // 35.0 / 38.2, paired directions 71.6 / 66.9 / 68.0 / 60.7 - larger tiles halve the operand traffic per MFMA, as long as
@@ -864,7 +866,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     }
     if (kind == 1) {
         const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
-        if (!c.wt && c.tile == BT_32x32 && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
+        if (!c.wt && !c.forced && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
             const bool r64 = B % 64 == 0, h64 = H % 64 == 0;
             const long wg64 = (long)(B / 64) * (H / 64) * ndir;
             const int bm = (r64 && h64 && wg64 >= 512) || (r64 && wg64 >= 256) ? 64 : 32, bn = (r64 && h64 && wg64 >= 512) ? 64 : 32;
