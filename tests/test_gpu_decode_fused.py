@@ -126,11 +126,12 @@ def test_fused_limits_reported():
                  ops._stream())
 
 
-def test_dgi_reduce_one_pass_sums():
-    """cpg_gru_dgi_reduce: token-grouped sums + column sums of dG from the one-hot product vs float64 sums."""
+@pytest.mark.parametrize("Tn,B,H", [(7, 96, 20), (7, 96, 64), (25, 256, 128), (3, 32, 192)])
+def test_dgi_reduce_one_pass_sums(Tn, B, H):
+    """cpg_gru_dgi_reduce: token-grouped sums, column sums and sums over time of dG vs float64 sums - through the one-hot
+    product + over-time pass (H % 64 != 0) and through the fused single pass (dgi_fused_kernel: H % 64 == 0, B % 32 == 0)."""
     from cpg import ops
     rs = np.random.RandomState(0)
-    Tn, B, H = 7, 96, 20
     dG = rs.randn(Tn, B, 4 * H).astype(np.float32)
     tok = rs.randint(0, V, size=(Tn, B)).astype(np.int32)
     d = torch.device("cuda")
