@@ -1473,6 +1473,131 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_chain_kernel(GruChainArgs g) 
     }
 }
 
+// The same chain on the direct-to-LDS main loop (DlLoop, gemm_core.h; f32-grade mode): BM x BN tiles of 2 x 2 waves, W_hh^T
+// handed over.  `stagger`: row tiles with an odd index start that many 10-ns ticks late, so that the two workgroups a CU holds
+// (different row tiles = independent chains) run their product and their epilogue / hand-off phases against each other.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gru_seq_bwd_chain_dl_kernel(GruChainArgs g, unsigned stagger) {
+    using DL = DlLoop<BM, BN, 3>;
+    constexpr int MI = DL::MI, NI = DL::NI;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int H = g.H, B = g.B, T = g.T;
+    const int m0 = by * BM, j0 = bx * BN;
+    const size_t BH = (size_t)B * H;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
+    const unsigned peers = gridDim.x;
+    const int KT = 3 * H / 32;
+    const int hb = blockIdx.x + gridDim.x * blockIdx.y;
+    const int hook_kt = min((((hb >> 3) + (hb >> 8)) & 3) * g.ep_step, KT - 1);
+    f32x4 zdh[2][MI][NI];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) zdh[d][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool dead = false;
+    if (stagger && (by & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    for (int p = T - 1; p >= -1; --p) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            if (d >= g.nd) break;
+            const GruChainDir& D = g.d[d];
+            if (p < 0 && !D.dh0) continue;
+            unsigned* const cnt = g.cnt + ((size_t)d * gridDim.y + by) * CHAIN_CNT_STRIDE;
+            const int t = p < 0 ? -1 : (D.reverse ? T - 1 - p : p);
+            const int prev_t = (p == T - 1) ? -1 : (D.reverse ? T - 2 - p : p + 1);
+            const float* const gates = t >= 0 ? D.gates + (size_t)t * 4 * BH : nullptr;
+            const float* const h_prev = t >= 0 ? D.hs + (size_t)(D.reverse ? t + 1 : t) * BH : nullptr;
+            const float* const ext = (t >= 0 && D.ext) ? D.ext + (size_t)t * BH : nullptr;
+            const float* const ext2 = (p == T - 1) ? D.dh_last : nullptr;
+            f32x4 acc[MI][NI], pre[MI][NI], sv[MI][NI][5];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto load_ep = [&]() {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
+                        f32x4 q = zdh[d][mi][ni];
+                        if (ext) q += *reinterpret_cast<const f32x4*>(ext + o);
+                        if (ext2) q += *reinterpret_cast<const f32x4*>(ext2 + o);
+                        pre[mi][ni] = q;
+                        if (gates) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sv[mi][ni][k] = *reinterpret_cast<const f32x4*>(gates + k * BH + o);
+                            sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(h_prev + o);
+                        }
+                    }
+            };
+            if (prev_t >= 0) {
+                if (wave == 0) chain_wait(cnt, peers * (unsigned)(T - 1 - p), g.err, dead);
+                __syncthreads();
+                DL::run(D.dG + ((size_t)prev_t * B + m0) * 4 * H, (size_t)4 * H, D.w_hhT + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem,
+                        acc, hook_kt, load_ep);
+            } else {
+                load_ep();
+            }
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+                t >= 0 ? D.dG + (size_t)t * B * 4 * H : D.dG, 0, (unsigned)((size_t)B * 4 * H * sizeof(float)), 0x00020000);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
+                    const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
+                    if (t < 0) {
+                        *reinterpret_cast<f32x4*>(D.dh0 + (size_t)row * H + col) = dh;
+                        continue;
+                    }
+                    const f32x4 rgt = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
+                    const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+                    const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+                    const f32x4 dr_pre = dn_pre * hn * rgt * (1.f - rgt);
+                    zdh[d][mi][ni] = zg * dh;
+                    const unsigned o = (unsigned)(((size_t)row * 4 * H + col) * sizeof(float));
+                    const unsigned hb4 = (unsigned)(H * sizeof(float));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dr_pre), rg, o, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dz_pre), rg, o + hb4, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre * rgt), rg, o + 2 * hb4, 0, 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre), rg, o + 3 * hb4, 0, 16);
+                }
+            if (t >= 0 && p > 0 || (t >= 0 && D.dh0)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int chain_dl_resident_blocks() {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    const void* fn = reinterpret_cast<const void*>(gru_seq_bwd_chain_dl_kernel<BM, BN>);
+    const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
+    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t pr;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+    cached = per_cu * pr.multiProcessorCount;
+    return cached;
+}
+
 using GC32 = GB32N;   // exact-f32 product, 32 x 32 tiles: the f32-grade choice of the step kernels (gru_bwd_choice)
 using GC64 = GB64;    // bf16 compute mode: W_hh^T path, 64 x 32 tiles
 
@@ -1547,6 +1672,33 @@ static int chain_launch(GruChainArgs& g, void* sync_scratch, float* wT0, float* 
     g.err = g.cnt + chain_cnt_words(g.B);
     CPG_HIP(hipMemsetAsync(sync_scratch, 0, chain_cnt_words(g.B) * sizeof(unsigned), s));  // the error word is sticky
     g.ep_step = bwd_ep_step(g.H);
+    {   // direct-to-LDS form (f32-grade mode, full 64-row tiles, W_hh^T scratch handed over): CPG_GRU_BWD_CHAIN_DL=0 disables
+        const char* e = getenv("CPG_GRU_BWD_CHAIN_DL");
+        float* wt[2] = {wT0, wT1};
+        bool ok = !bf && !(e && atoi(e) == 0) && g.B % 64 == 0 && g.H % 32 == 0 && bwd_dl_shape_ok(0, g.B, g.H);
+        for (int d = 0; d < g.nd; ++d) ok = ok && wt[d] && aligned16(wt[d]);
+        const bool wide = false;   // 64 x 64 tiles leave one workgroup per CU at B=2048, H=512: nothing to run out of phase with
+        const long wgs = ok ? (long)(g.B / 64) * (g.H / (wide ? 64 : 32)) : 0;
+        if (ok && wgs <= (wide ? chain_dl_resident_blocks<64, 64>() : chain_dl_resident_blocks<64, 32>())) {
+            for (int d = 0; d < g.nd; ++d) {
+                int rc = transpose_w(g.d[d].w_hh, g.H, wt[d], s);
+                if (rc) return rc;
+                g.d[d].w_hhT = wt[d];
+            }
+            const char* st = getenv("CPG_GRU_BWD_CHAIN_STAGGER");   // 10-ns ticks; default: none
+            const unsigned stagger = st ? (unsigned)atoi(st) : 0u;
+            const dim3 grid2(g.H / (wide ? 64 : 32), g.B / 64, 1);
+            if (wide) {
+                const size_t smem = (DlLoop<64, 64, 3>::smem_floats() + 4 * 256) * sizeof(float);
+                hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 64>), grid2, dim3(256), smem, s, g, stagger);
+            } else {
+                const size_t smem = (DlLoop<64, 32, 3>::smem_floats() + 4 * 256) * sizeof(float);
+                hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 32>), grid2, dim3(256), smem, s, g, stagger);
+            }
+            CPG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const dim3 grid(cdiv(g.H, bn), nrt, 1);
     if (bf) {
         (void)chain_resident_blocks<GC64, true, 1>();  // sets the dynamic-LDS attribute once

@@ -105,7 +105,7 @@ def main():
             fp = timeit(fwdp, a.iters) / T if ops.persistent_fits(B, H) else float("nan")
             bp = timeit(bwdp, a.iters) / (T + 1) if ops.persistent_fits(B, H) else float("nan")
             b = timeit(bwd, a.iters) / (T + 1)
-            chain_ok = ops.chain_bwd_fits(T, B, H)
+            chain_ok = ops.chain_bwd_covers(T, B, H)
             bc = timeit(bwdc, a.iters) / (T + 1) if chain_ok else float("nan")
             bc2 = timeit(bwdc2, a.iters) / T if chain_ok else float("nan")
             b2 = timeit(bwd2, a.iters) / T
