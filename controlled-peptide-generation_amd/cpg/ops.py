@@ -944,7 +944,7 @@ class MmdFullFn(Function):
         need = z.requires_grad
         P = torch.empty(N, N, device=dev, dtype=torch.float32) if need else None
         Q = torch.empty(N, N, device=dev, dtype=torch.float32) if need else None
-        nb = query("cpg_mmd_full_workspace", N)
+        nb = query("cpg_mmd_full_workspace", N, D)
         ws = workspace(nb, dev)
         call("cpg_mmd_full_fwd", _p(z), _p(z_prior), N, D, float(sigma), int(kernel), _p(out), _p(P), _p(Q), _p(ws),
              ws.numel(), _stream())

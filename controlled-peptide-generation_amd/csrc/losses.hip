@@ -371,6 +371,81 @@ __global__ __launch_bounds__(256) void mmd_gram_fused_kernel(MmdArgs g) {
         g.part[((size_t)z * tiles + tile) * 2 + 1] = v[1];
     }
 }
+// ---- the same launch on the direct-to-LDS loop (gemm_core.h DlLoop, 64x64 tiles): needs K-contiguous operands whose row length
+// is a multiple of 32, so the row-norm pre-pass also writes zero-padded copies zp [2N, Dp] (8 MB at 2048 x 510, L2-resident);
+// the padding adds exact zeros to every dot product.  N % 64 == 0.
+using MmdDl = DlLoop<64, 64, 3>;
+__global__ void rownorm2_pad_kernel(const float* z1, const float* z2, int N, int D, int Dp, float* n1, float* n2, float* zp) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= 2 * N) return;
+    const float* r = (wave < N ? z1 : z2) + (size_t)(wave % N) * D;
+    float* o = zp + (size_t)wave * Dp;
+    float s = 0.f;
+    for (int k = lane; k < Dp; k += 64) {
+        const float x = k < D ? r[k] : 0.f;
+        o[k] = x;
+        s += x * x;
+    }
+    s = wave_sum(s);
+    if (lane == 0) (wave < N ? n1 : n2)[wave % N] = s;
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void mmd_gram_dl_kernel(MmdArgs g, const float* zp, int Dp) {
+    extern __shared__ float dl_smem[];
+    __shared__ float red[8];
+    const int z = blockIdx.z, N = g.N;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x, tiles = gridDim.x * gridDim.y;
+    const bool sym = z < 2;
+    const bool need_all = (z == 0 && g.P != nullptr);
+    float v[2] = {0.f, 0.f};
+    if (!(sym && !need_all && n0 + 63 < m0)) {   // workgroup-uniform
+        const float* A = zp + (size_t)(z == 1 ? N : 0) * Dp;
+        const float* Bm = zp + (size_t)(z == 0 ? 0 : N) * Dp;
+        const float* na = z == 1 ? g.n2 : g.n1;
+        const float* nb = z == 0 ? g.n1 : g.n2;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        MmdDl::run(A + (size_t)m0 * Dp, (size_t)Dp, Bm + (size_t)n0 * Dp, (size_t)Dp, Dp, dl_smem, acc, -1, [] {});
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+        const float cf = 1.f / ((float)N * (float)(N - 1));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int j = n0 + (wave & 1) * 32 + ni * 16 + l15;
+            const float bj = nb[j];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = m0 + (wave >> 1) * 32 + mi * 16 + 4 * lq + r;
+                    const bool diag = sym && i == j;
+                    float k, w;
+                    mmd_kern<KIND>(diag ? 0.f : fmaxf(na[i] + bj - 2.f * acc[mi][ni][r], 0.f), g.inv_s2, g.s2, k, w);
+                    const float wt = (sym && !need_all) ? (j > i ? 2.f : (j == i ? 1.f : 0.f)) : 1.f;
+                    v[0] += wt * k;
+                    if (i == j) v[1] += k;
+                    if (z != 1 && g.P) {
+                        const float coef = (i == j) ? cf * (1.f - (float)N) : cf;
+                        if (z == 0) g.P[(size_t)i * N + j] = 2.f * coef * w;
+                        else g.Q[(size_t)i * N + j] = -2.f * coef * w;
+                    }
+                }
+        }
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        g.part[((size_t)z * tiles + tile) * 2] = v[0];
+        g.part[((size_t)z * tiles + tile) * 2 + 1] = v[1];
+    }
+}
+static bool mmd_dl_ok(int N) {
+    static const int off = [] { const char* e = getenv("CPG_MMD_DL"); return e && atoi(e) == 0; }();
+    return !off && N % 64 == 0;
+}
+static int mmd_dp(int D) { return (D + 31) / 32 * 32; }
 // out[0] = (sum H - N tr H) / (N (N-1)),  H = K11 + K22 - 2 K12;  out[1] = sum H, out[2] = tr H.  One block, fixed order.
 __global__ void mmd_fused_final_kernel(const float* part, int tiles, int N, float* out) {
     __shared__ float red[24];
@@ -390,7 +465,11 @@ __global__ void mmd_fused_final_kernel(const float* part, int tiles, int N, floa
     }
 }
 static size_t mmd_tiles(int N) { return (size_t)cdiv(N, MmdTile::BM) * cdiv(N, MmdTile::BN); }
-CPG_EXPORT size_t cpg_mmd_full_workspace(int N) { return ((size_t)2 * N + 6 * mmd_tiles(N)) * sizeof(float) + 256; }
+static size_t mmd_tiles_max(int N) { return (size_t)cdiv(N, 64) * cdiv(N, 64); }
+// [n1 | n2 | per-tile partials | zero-padded operand copies for the direct-to-LDS form]
+CPG_EXPORT size_t cpg_mmd_full_workspace(int N, int D) {
+    return ((size_t)2 * N + 6 * mmd_tiles_max(N) + (size_t)2 * N * mmd_dp(D)) * sizeof(float) + 256;
+}
 
 template <bool VEC, int KIND>
 static void mmd_launch(const MmdArgs& g, hipStream_t s) {
@@ -404,7 +483,7 @@ CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, 
                                 float* Q, void* workspace, size_t workspace_bytes, void* stream) {
     CPG_CHECK_ARG(z1 && z2 && out && workspace && N > 1 && D > 0 && sigma > 0.f && ((P == nullptr) == (Q == nullptr)));
     CPG_CHECK_ARG(kernel >= 0 && kernel <= 2);
-    CPG_CHECK_ARG(workspace_bytes >= cpg_mmd_full_workspace(N));
+    CPG_CHECK_ARG(workspace_bytes >= cpg_mmd_full_workspace(N, D));
     hipStream_t s = (hipStream_t)stream;
     MmdArgs g;
     g.z1 = z1; g.z2 = z2; g.N = N; g.D = D; g.P = P; g.Q = Q;
@@ -412,6 +491,21 @@ CPG_EXPORT int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, 
     g.n1 = n1; g.n2 = n1 + N; g.part = n1 + 2 * (size_t)N;
     g.s2 = sigma * sigma;
     g.inv_s2 = 1.f / g.s2;
+    if (mmd_dl_ok(N)) {
+        const int Dp = mmd_dp(D);
+        float* zp = g.part + 6 * mmd_tiles_max(N);
+        zp += (64 - (((uintptr_t)zp >> 2) & 63)) & 63;   // 256-byte aligned rows
+        g.pairs = 0;
+        hipLaunchKernelGGL(rownorm2_pad_kernel, dim3(cdiv(2 * N, 4)), dim3(256), 0, s, z1, z2, N, D, Dp, n1, n1 + N, zp);
+        const size_t smem = MmdDl::smem_floats() * sizeof(float);
+        const dim3 grid(N / 64, N / 64, 3);
+        if (kernel == 0) hipLaunchKernelGGL(mmd_gram_dl_kernel<0>, grid, dim3(256), smem, s, g, (const float*)zp, Dp);
+        else if (kernel == 1) hipLaunchKernelGGL(mmd_gram_dl_kernel<1>, grid, dim3(256), smem, s, g, (const float*)zp, Dp);
+        else hipLaunchKernelGGL(mmd_gram_dl_kernel<2>, grid, dim3(256), smem, s, g, (const float*)zp, Dp);
+        hipLaunchKernelGGL(mmd_fused_final_kernel, dim3(1), dim3(256), 0, s, (const float*)g.part, (int)mmd_tiles_max(N), N, out);
+        CPG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(rownorm2_kernel, dim3(cdiv(2 * N, 4)), dim3(256), 0, s, z1, z2, N, D, n1, n1 + N);
     const bool vec = D % 4 == 0 && aligned16(z1) && aligned16(z2);
     g.pairs = D % 2 == 0 && (((uintptr_t)z1) & 7) == 0 && (((uintptr_t)z2) & 7) == 0;

@@ -300,7 +300,7 @@ CPG_API int cpg_rf_bwd(const float* raw, const float* rf_b, const float* diff, c
                        float sigma, int B_global, float* dpre, void* stream);
 /* mmd_full_kernel, losses.py:47-56,96-108 (incl. the `H - diag(H)` broadcast).
  * kernel: 0 "gaussian", 1 "laplace", 2 "energy" - compute_mmd_kernel, losses.py:102-107. */
-CPG_API size_t cpg_mmd_full_workspace(int N);
+CPG_API size_t cpg_mmd_full_workspace(int N, int D);
 CPG_API int cpg_mmd_full_fwd(const float* z1, const float* z2, int N, int D, float sigma, int kernel, float* out, float* P,
                              float* Q, void* workspace, size_t workspace_bytes, void* stream);
 CPG_API int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P, const float* Q, const float* gout, int N,

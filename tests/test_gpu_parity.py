@@ -108,13 +108,16 @@ def test_mmd_full_kernels_golden(golden, kernel):
     assert abs(loss.item() - ref_l) < 1e-4 * max(1.0, abs(ref_l))
     assert np.abs(z1.grad.cpu().numpy() - ref_g).max() < 1e-4 * np.abs(ref_g).max()
     rs = np.random.RandomState(5)
-    x, y = (0.5 * rs.randn(2048, 100) + 0.2).astype(np.float32), rs.randn(2048, 100).astype(np.float32)
-    ol, og = wae.mmd_full_kernel(x, y, 7.0, kernel)
-    z1 = cu(x).requires_grad_(True)
-    loss = losses.mmd_full_kernel(z1, cu(y), sigma=7.0, kernel=kernel)
-    loss.backward()
-    assert abs(loss.item() - float(ol)) < 1e-4 * max(1.0, abs(float(ol)))
-    assert np.abs(z1.grad.cpu().numpy() - og).max() < 1e-3 * np.abs(og).max()
+    # 2048 x 100 and 192 x 70 run the direct-to-LDS Gram kernel (N % 64 == 0; rows zero-padded to 128 / 96), 100 x 70 the
+    # register-staged one
+    for n, d in ((2048, 100), (192, 70), (100, 70)):
+        x, y = (0.5 * rs.randn(n, d) + 0.2).astype(np.float32), rs.randn(n, d).astype(np.float32)
+        ol, og = wae.mmd_full_kernel(x, y, 7.0, kernel)
+        z1 = cu(x).requires_grad_(True)
+        loss = losses.mmd_full_kernel(z1, cu(y), sigma=7.0, kernel=kernel)
+        loss.backward()
+        assert abs(loss.item() - float(ol)) < 1e-4 * max(1.0, abs(float(ol))), (n, d)
+        assert np.abs(z1.grad.cpu().numpy() - og).max() < 1e-3 * np.abs(og).max(), (n, d)
     with pytest.raises(ValueError):
         losses.mmd_full_kernel(z1, cu(y), sigma=7.0, kernel="cauchy")
 
