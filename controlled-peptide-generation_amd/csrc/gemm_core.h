@@ -760,7 +760,9 @@ __device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int
 // (k = 16h + 4q + j): sums are bit-identical to the register-staged exact-f32 kernels.
 // Requirements: full tiles (no bound masks), K % 32 == 0, 16-byte aligned rows (lda, ldb multiples of 4, aligned bases).
 // `hook` runs once ahead of slab hook_kt (the caller's own global loads; < 0: never).  smem: smem_floats() floats.
-template <int BM, int BN, int NS = 3>
+// PREC = 1 ("bf16 compute mode"): each lane's eight slab values per block row are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) after
+// the fragment read and ONE v_mfma_f32_16x16x32_bf16 per block consumes the slab - same LDS image and reads as PREC = 0.
+template <int BM, int BN, int NS = 3, int PREC = 0>
 struct DlLoop {
     static constexpr int MI = BM / 32, NI = BN / 32;
     static constexpr int AF = BM * 32, BF = BN * 32, SF = AF + BF;   // floats per operand slab / per stage
@@ -809,6 +811,24 @@ struct DlLoop {
             }
             __builtin_amdgcn_s_barrier();
             if (kt + AHEAD < KT) issue(kt + AHEAD, refill);
+            if constexpr (PREC == 1) {
+                cpg_bf16x8 fa[MI], fb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cur + oa0 + mi * 512), hi = *reinterpret_cast<const f32x4*>(cur + oa1 + mi * 512);
+                    fa[mi] = __builtin_bit_cast(cpg_bf16x8, make_uint4(cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(hi[0], hi[1]), cvt_pk_bf16(hi[2], hi[3])));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cur + ob0 + ni * 512), hi = *reinterpret_cast<const f32x4*>(cur + ob1 + ni * 512);
+                    fb[ni] = __builtin_bit_cast(cpg_bf16x8, make_uint4(cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(lo[2], lo[3]), cvt_pk_bf16(hi[0], hi[1]), cvt_pk_bf16(hi[2], hi[3])));
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x4 av[MI], bv[NI];
@@ -823,6 +843,7 @@ struct DlLoop {
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            }
             }
         };
 #pragma unroll

@@ -402,9 +402,10 @@ using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab b
 // of a row reads slot q ^ f(row).  Contraction order = the register-staged kernel's (k = 16h + 4q + j): bit-identical sums.
 // Covers dense launches with B % 32 == 0, H % 32 == 0 and 16-byte aligned operands; everything else runs gru_step_bwd_kernel.
 // BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16); main loop: DlLoop (gemm_core.h)
-template <int BM, int BN, int NS>
+// PREC 1: bf16 compute mode (operands rounded at the fragment read, one bf16 MFMA per block and slab)
+template <int BM, int BN, int NS, int PREC = 0>
 __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
-    using DL = DlLoop<BM, BN, NS>;
+    using DL = DlLoop<BM, BN, NS, PREC>;
     constexpr int MI = DL::MI, NI = DL::NI;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -646,19 +647,19 @@ static bool bwd_wants_wt(int rows, int H, int nd, int row0, bool dense) {
     return c.wt || (dense && !c.forced && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H));
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int PREC = 0>
 static void launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(a.H / BN, (a.row1 - a.row0) / BM, nd);
-    const size_t smem = (DlLoop<BM, BN, NS>::smem_floats() + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, NS, PREC>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, NS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             done = true;
         }
     }
-    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, NS>), grid, dim3(256), smem, s, pr);
+    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, NS, PREC>), grid, dim3(256), smem, s, pr);
 }
 
 static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
@@ -678,7 +679,9 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     const BwdChoice c = gru_bwd_choice(a.row1 - a.row0, a.H, nd, have_wt);
     bool dense = true;
     for (int d = 0; d < nd; ++d) dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
-    if (!c.wt && !c.forced && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
+    // bf16 compute mode: the direct-to-LDS kernel with PREC = 1 unless a split-engine tile was asked for (CPG_GRU_BWD_TILE)
+    const bool bf16_dl = c.wt && !c.forced && cpg_compute_mode_get() == 1 && !getenv("CPG_GRU_BWD_TILE");
+    if ((!c.wt || bf16_dl) && !c.forced && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
         // direct-to-LDS main loop (gru_step_bwd_dl_kernel): same sums whatever the tile
         // Tile (tools/kbench.py, B=2048, H=512, us per launch; 32x32 / 64x32 / 32x64 / 64x64): single direction 38.9 / 35.5 /
         // 35.0 / 38.2, paired directions 71.6 / 66.9 / 68.0 / 60.7 - larger tiles halve the operand traffic per MFMA, as long as
@@ -701,7 +704,9 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
         }
         if (bm == 64 && !r64) bm = 32;
         if (bn == 64 && !h64) bn = 32;
-#define CPG_DL_PICK(BM, BN) (ns == 4 ? launch_dl<BM, BN, 4>(pr, nd, s) : ns == 2 ? launch_dl<BM, BN, 2>(pr, nd, s) : launch_dl<BM, BN, 3>(pr, nd, s))
+#define CPG_DL_PICK(BM, BN)                                                                                              \
+    (bf16_dl ? launch_dl<BM, BN, 3, 1>(pr, nd, s)                                                                        \
+             : ns == 4 ? launch_dl<BM, BN, 4>(pr, nd, s) : ns == 2 ? launch_dl<BM, BN, 2>(pr, nd, s) : launch_dl<BM, BN, 3>(pr, nd, s))
         if (bm == 64 && bn == 64) CPG_DL_PICK(64, 64);
         else if (bm == 64) CPG_DL_PICK(64, 32);
         else if (bn == 64) CPG_DL_PICK(32, 64);
@@ -866,11 +871,12 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     }
     if (kind == 1) {
         const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
-        if (!c.wt && !c.forced && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
+        const bool bf16_dl = c.wt && !c.forced && cpg_compute_mode_get() == 1 && !getenv("CPG_GRU_BWD_TILE");
+        if ((!c.wt || bf16_dl) && !c.forced && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
             const bool r64 = B % 64 == 0, h64 = H % 64 == 0;
             const long wg64 = (long)(B / 64) * (H / 64) * ndir;
             const int bm = (r64 && h64 && wg64 >= 512) || (r64 && wg64 >= 256) ? 64 : 32, bn = (r64 && h64 && wg64 >= 512) ? 64 : 32;
-            return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3>", bm, bn);
+            return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3, %d>", bm, bn, bf16_dl ? 1 : 0);
         }
         switch (c.tile) {
             case BT_64x32: tc_name<GB64>(tc, sizeof tc); break;
@@ -1476,9 +1482,9 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_chain_kernel(GruChainArgs g) 
 // The same chain on the direct-to-LDS main loop (DlLoop, gemm_core.h; f32-grade mode): BM x BN tiles of 2 x 2 waves, W_hh^T
 // handed over.  `stagger`: row tiles with an odd index start that many 10-ns ticks late, so that the two workgroups a CU holds
 // (different row tiles = independent chains) run their product and their epilogue / hand-off phases against each other.
-template <int BM, int BN>
+template <int BM, int BN, int PREC = 0>
 __global__ __launch_bounds__(256) void gru_seq_bwd_chain_dl_kernel(GruChainArgs g, unsigned stagger) {
-    using DL = DlLoop<BM, BN, 3>;
+    using DL = DlLoop<BM, BN, 3, PREC>;
     constexpr int MI = DL::MI, NI = DL::NI;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -1583,11 +1589,11 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_chain_dl_kernel(GruChainArgs 
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PREC = 0>
 static int chain_dl_resident_blocks() {
     static int cached = -1;
     if (cached >= 0) return cached;
-    const void* fn = reinterpret_cast<const void*>(gru_seq_bwd_chain_dl_kernel<BM, BN>);
+    const void* fn = reinterpret_cast<const void*>(gru_seq_bwd_chain_dl_kernel<BM, BN, PREC>);
     const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     int per_cu = 0, dev = 0;
@@ -1672,29 +1678,26 @@ static int chain_launch(GruChainArgs& g, void* sync_scratch, float* wT0, float* 
     g.err = g.cnt + chain_cnt_words(g.B);
     CPG_HIP(hipMemsetAsync(sync_scratch, 0, chain_cnt_words(g.B) * sizeof(unsigned), s));  // the error word is sticky
     g.ep_step = bwd_ep_step(g.H);
-    {   // direct-to-LDS form (f32-grade mode, full 64-row tiles, W_hh^T scratch handed over): CPG_GRU_BWD_CHAIN_DL=0 disables
+    {   // direct-to-LDS form (either compute mode; full 64-row tiles, W_hh^T scratch handed over): CPG_GRU_BWD_CHAIN_DL=0 disables
         const char* e = getenv("CPG_GRU_BWD_CHAIN_DL");
         float* wt[2] = {wT0, wT1};
-        bool ok = !bf && !(e && atoi(e) == 0) && g.B % 64 == 0 && g.H % 32 == 0 && bwd_dl_shape_ok(0, g.B, g.H);
+        bool ok = !(e && atoi(e) == 0) && g.B % 64 == 0 && g.H % 32 == 0 && bwd_dl_shape_ok(0, g.B, g.H);
         for (int d = 0; d < g.nd; ++d) ok = ok && wt[d] && aligned16(wt[d]);
-        const bool wide = false;   // 64 x 64 tiles leave one workgroup per CU at B=2048, H=512: nothing to run out of phase with
-        const long wgs = ok ? (long)(g.B / 64) * (g.H / (wide ? 64 : 32)) : 0;
-        if (ok && wgs <= (wide ? chain_dl_resident_blocks<64, 64>() : chain_dl_resident_blocks<64, 32>())) {
-            for (int d = 0; d < g.nd; ++d) {
-                int rc = transpose_w(g.d[d].w_hh, g.H, wt[d], s);
-                if (rc) return rc;
-                g.d[d].w_hhT = wt[d];
-            }
+        // 64 x 32 tiles (64 x 64 leave one workgroup per CU at B=2048, H=512: nothing to run out of phase with)
+        const long wgs = ok ? (long)(g.B / 64) * (g.H / 32) : 0;
+        if (ok && wgs <= (bf ? chain_dl_resident_blocks<64, 32, 1>() : chain_dl_resident_blocks<64, 32>())) {
+            if (!bf)   // (the bf16 mode has transposed above)
+                for (int d = 0; d < g.nd; ++d) {
+                    int rc = transpose_w(g.d[d].w_hh, g.H, wt[d], s);
+                    if (rc) return rc;
+                    g.d[d].w_hhT = wt[d];
+                }
             const char* st = getenv("CPG_GRU_BWD_CHAIN_STAGGER");   // 10-ns ticks; default: none
             const unsigned stagger = st ? (unsigned)atoi(st) : 0u;
-            const dim3 grid2(g.H / (wide ? 64 : 32), g.B / 64, 1);
-            if (wide) {
-                const size_t smem = (DlLoop<64, 64, 3>::smem_floats() + 4 * 256) * sizeof(float);
-                hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 64>), grid2, dim3(256), smem, s, g, stagger);
-            } else {
-                const size_t smem = (DlLoop<64, 32, 3>::smem_floats() + 4 * 256) * sizeof(float);
-                hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 32>), grid2, dim3(256), smem, s, g, stagger);
-            }
+            const dim3 grid2(g.H / 32, g.B / 64, 1);
+            const size_t smem = (DlLoop<64, 32, 3>::smem_floats() + 4 * 256) * sizeof(float);
+            if (bf) hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 32, 1>), grid2, dim3(256), smem, s, g, stagger);
+            else hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 32>), grid2, dim3(256), smem, s, g, stagger);
             CPG_LAUNCH_CHECK();
             return 0;
         }
