@@ -1121,6 +1121,104 @@ static bool dgi_fused_ok(int T, int B, int H, int V, const float* dG, const int3
            ws_bytes >= dgi_fused_workspace(B, H, V);
 }
 
+// ---- the same three reductions with the token-grouped sums on the matrix cores: R[v][c] = sum_rows onehot[row][v] dG[row][c] is
+// a product with an exact operand (0 / 1), so the exact-f32 MFMA gives f32 sums without any operand split, the one-hot operand is
+// built in registers from the token ids (two compares per lane and k-step), and row V of the operand is all ones: the column
+// sums come out of the same product.  Workgroup = 64 dG columns x 128 batch rows x all T steps, four waves of 32 rows; a lane
+// owns four columns of the rows bw + 8 lq + ks (ks = k-step 0..7): one 16-byte load per k-step feeds the four column sets of
+// the product (block column n <-> dG column 4 n + j) and the lane's running sum over time (drowc, complete rows: no partials).
+// dG is read once, 1 KB per wave and k-step against 8 MFMAs: the matrix pipe can take ~9.8 TB/s of it, HBM delivers ~5.
+constexpr int DM_RW = 32, DM_ROWS = 4 * DM_RW, DM_VMAX = 31;
+template <bool ROWC>
+__global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const int32_t* tok, int T, int B, int H, int V, int lstm,
+                                                        float* part_tab, float* part_sum, float* drowc, int accumulate) {
+    __shared__ f32x4 dm_red[3][2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int C4 = 4 * H, col = blockIdx.x * 64 + 4 * l15;
+    const int bw = blockIdx.y * DM_ROWS + wave * DM_RW + 8 * lq;
+    const bool two = V + 1 > 16;   // token rows 16..31 of the one-hot operand in use
+    f32x4 acc[2][4], racc[8], x[8], xn[8];
+    int tk[8], tkn[8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) racc[ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int t, f32x4 (&xv)[8], int (&tv)[8]) {
+        const int4 t0 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw), t1 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw + 4);
+        tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
+        const float* base = dG + ((size_t)t * B + bw) * C4 + col;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xv[ks] = *reinterpret_cast<const f32x4*>(base + (size_t)ks * C4);
+    };
+    fetch(0, x, tk);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) fetch(t + 1, xn, tkn);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ROWC) racc[ks] += x[ks];
+            const float a0 = (tk[ks] == l15 || l15 == V) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, x[ks][j], acc[0][j], 0, 0, 0);
+            if (two) {
+                const float a1 = (tk[ks] == 16 + l15 || 16 + l15 == V) ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x[ks][j], acc[1][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            x[ks] = xn[ks];
+            tk[ks] = tkn[ks];
+        }
+    }
+    if (ROWC) {   // sums over time (the GRU's dhn block, columns [2H,3H) of dG, is not an input-side gradient)
+        const bool is_dgi = lstm || col < 2 * H || col >= 3 * H;
+        const int NC = lstm ? 4 * H : 3 * H, dcol = (lstm || col < 2 * H) ? col : col - H;
+        if (is_dgi) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                f32x4* o = reinterpret_cast<f32x4*>(drowc + (size_t)(bw + ks) * NC + dcol);
+                *o = accumulate ? *o + racc[ks] : racc[ks];
+            }
+        }
+    }
+    // waves 1..3 hand their block sums to wave 0, which adds them in a fixed order and writes the workgroup's partials
+    if (wave > 0) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dm_red[wave - 1][m][j][lane] = acc[m][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const size_t chunk = blockIdx.y;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m == 1 && !two) break;
+            f32x4 sacc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sacc[j] = ((acc[m][j] + dm_red[0][m][j][lane]) + dm_red[1][m][j][lane]) + dm_red[2][m][j][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = 16 * m + 4 * lq + r;
+                const f32x4 val = f32x4{sacc[0][r], sacc[1][r], sacc[2][r], sacc[3][r]};
+                if (v < V) *reinterpret_cast<f32x4*>(part_tab + (chunk * V + v) * C4 + col) = val;
+                else if (v == V) *reinterpret_cast<f32x4*>(part_sum + chunk * C4 + col) = val;
+            }
+        }
+    }
+}
+static size_t dgi_mfma_workspace(int B, int H, int V) { return (size_t)(B / DM_ROWS) * (V + 1) * 4 * H * sizeof(float); }
+// CPG_DGI_MFMA=0 disables.
+static bool dgi_mfma_ok(int B, int H, int V, const float* dG, const int32_t* tok, const float* drowc, size_t ws_bytes) {
+    const char* e = getenv("CPG_DGI_MFMA");
+    if (e && atoi(e) == 0) return false;
+    return tok && V > 0 && V <= DM_VMAX && H % 64 == 0 && B % DM_ROWS == 0 && aligned16(dG) && aligned16(tok) &&
+           (!drowc || aligned16(drowc)) && ws_bytes >= dgi_mfma_workspace(B, H, V);
+}
+
 // Input-side reductions of dgi = [dr_pre, dz_pre, dn_pre]:
 //   dtab[V,3H]  (+)= sum over (t,b) with tok[t,b]==v     (gradient of the token table; null to skip)
 //   drowc[B,3H] (+)= sum over t                          (gradient of the constant-over-time term; null to skip)
@@ -1130,6 +1228,21 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
     const int NC = lstm ? 4 * H : 3 * H;
     hipStream_t s = (hipStream_t)stream;
     const int rows = T * B;
+    if ((dtab || dsum) && dgi_mfma_ok(B, H, V, dG, tok, drowc, workspace_bytes)) {
+        CPG_CHECK_ARG(workspace);
+        const int chunks = B / DM_ROWS;
+        float* part_tab = (float*)workspace;
+        float* part_sum = part_tab + (size_t)chunks * V * 4 * H;
+        const dim3 grid(4 * H / 64, chunks);
+        if (drowc) hipLaunchKernelGGL(dgi_mfma_kernel<true>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
+        else hipLaunchKernelGGL(dgi_mfma_kernel<false>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
+        CPG_LAUNCH_CHECK();
+        const int m = V * NC > 4 * H ? V * NC : 4 * H;
+        hipLaunchKernelGGL(dgi_fused_final_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, (const float*)part_tab, (const float*)part_sum,
+                           chunks, H, V, lstm, dtab, dsum, accumulate);
+        CPG_LAUNCH_CHECK();
+        return 0;
+    }
     if ((dtab || dsum) && !(drowc && accumulate) && dgi_fused_ok(T, B, H, V, dG, tok, drowc, workspace_bytes)) {
         CPG_CHECK_ARG(workspace);
         const int chunks = B / DF_ROWS;

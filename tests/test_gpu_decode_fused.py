@@ -126,10 +126,11 @@ def test_fused_limits_reported():
                  ops._stream())
 
 
-@pytest.mark.parametrize("Tn,B,H", [(7, 96, 20), (7, 96, 64), (25, 256, 128), (3, 32, 192)])
+@pytest.mark.parametrize("Tn,B,H", [(7, 96, 20), (7, 96, 64), (25, 256, 128), (3, 32, 192), (9, 384, 64), (1, 128, 64)])
 def test_dgi_reduce_one_pass_sums(Tn, B, H):
     """cpg_gru_dgi_reduce: token-grouped sums, column sums and sums over time of dG vs float64 sums - through the one-hot
-    product + over-time pass (H % 64 != 0) and through the fused single pass (dgi_fused_kernel: H % 64 == 0, B % 32 == 0)."""
+    product + over-time pass (H % 64 != 0), the fused single pass (dgi_fused_kernel: H % 64 == 0, B % 32 == 0) and the
+    matrix-core single pass (dgi_mfma_kernel: H % 64 == 0, B % 128 == 0)."""
     from cpg import ops
     rs = np.random.RandomState(0)
     dG = rs.randn(Tn, B, 4 * H).astype(np.float32)
@@ -149,3 +150,31 @@ def test_dgi_reduce_one_pass_sums(Tn, B, H):
     np.testing.assert_allclose(dtab.cpu().numpy(), ref_tab, atol=1e-4)
     np.testing.assert_allclose(dsum.cpu().numpy(), flat.sum(0), atol=2e-4)
     np.testing.assert_allclose(drowc.cpu().numpy(), dgi.reshape(Tn, B, 3 * H).sum(0), atol=1e-4)
+
+
+@pytest.mark.parametrize("lstm", [0, 1])
+def test_dgi_reduce_matrix_core_pass_accumulates(lstm):
+    """dgi_mfma_kernel with accumulate = 1, with and without the over-time sums, GRU and LSTM gate layouts; ids >= V (none in
+    the reference's data) count in the column sums only."""
+    from cpg import ops
+    Tn, B, H = 6, 256, 64
+    NC = 4 * H if lstm else 3 * H
+    rs = np.random.RandomState(3)
+    dG = rs.randn(Tn, B, 4 * H).astype(np.float32)
+    tok = rs.randint(0, V + 2, size=(Tn, B)).astype(np.int32)
+    d = torch.device("cuda")
+    flat = dG.reshape(-1, 4 * H).astype(np.float64)
+    dgi = flat if lstm else np.concatenate([flat[:, :2 * H], flat[:, 3 * H:]], 1)
+    ref_tab = np.zeros((V + 2, NC))
+    np.add.at(ref_tab, tok.reshape(-1), dgi)
+    name = "cpg_lstm_dgi_reduce" if lstm else "cpg_gru_dgi_reduce"
+    ws = ops.workspace(ops.query("cpg_gru_wgrad_workspace", Tn, B, H, V), d)
+    dG_d, tok_d = cu(dG), cu(tok)
+    for with_rowc in (True, False):
+        dtab, dsum, drowc = torch.ones(V, NC, device=d), torch.full((4 * H,), 2.0, device=d), torch.full((B, NC), 3.0, device=d)
+        ops.call(name, Tn, B, H, ops._p(dG_d), ops._p(tok_d), V, ops._p(dtab), ops._p(dsum), ops._p(drowc) if with_rowc else None, 1,
+                 ops._p(ws), ws.numel(), ops._stream())
+        np.testing.assert_allclose(dtab.cpu().numpy(), 1.0 + ref_tab[:V], atol=1e-4)
+        np.testing.assert_allclose(dsum.cpu().numpy(), 2.0 + flat.sum(0), atol=2e-4)
+        if with_rowc:
+            np.testing.assert_allclose(drowc.cpu().numpy(), 3.0 + dgi.reshape(Tn, B, NC).sum(0), atol=1e-4)
