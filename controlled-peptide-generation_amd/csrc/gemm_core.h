@@ -109,6 +109,9 @@ __device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int& bz) {
     const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
     const int combos = gy * gz;
     if (combos % 8 != 0) {
+        // (Giving each XCD a contiguous 1/8 of the x-fastest tile sequence here as well was measured on the 4 x 6 x 10 grid of the
+        // dW_hh product: L2 misses drop 3x, the launch takes 583 us instead of 430 - the four workgroups that share an A panel
+        // then ask ONE L2 for the same lines at the same time.)
         bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
         return;
     }
