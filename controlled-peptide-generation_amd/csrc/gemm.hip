@@ -38,7 +38,7 @@ using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, 
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC>
 __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     int bx, by, bz;
-    xcd_tile_order(bx, by, bz);
+    xcd_tile_order<PREC == 1>(bx, by, bz);
     const int m0 = by * TC::BM, n0 = bx * TC::BN;
     int kb = 0, K = g.K;
     if (g.k_chunk > 0) {

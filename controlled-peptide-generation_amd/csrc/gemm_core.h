@@ -105,9 +105,20 @@ struct TileCfg {
 // XCD streams the WHOLE M-side operand (measured on the dW_hh product: FETCH_SIZE 1.29 GB raw vs 0.52 GB algorithmic).
 // Remapped order: the gx workgroups that share one (y,z) - the same M-side rows / K-chunk - run back to back on ONE XCD,
 // and each XCD owns a contiguous 1/8 of the (y,z) combinations.
+template <bool SEQ8 = false>
 __device__ __forceinline__ void xcd_tile_order(int& bx, int& by, int& bz) {
     const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
     const int combos = gy * gz;
+    if (SEQ8 && combos % 8 != 0 && (gx * combos) % 8 == 0) {
+        // each XCD takes a contiguous 1/8 of the x-fastest tile sequence (the bf16-mode dW_hh product, which is bound by its
+        // operand loads: 284 -> 249 us; see the note below for the f32-grade launch)
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int t = (lin & 7) * (gx * combos / 8) + (lin >> 3);
+        bx = t % gx;
+        by = (t / gx) % gy;
+        bz = (t / gx) / gy;
+        return;
+    }
     if (combos % 8 != 0) {
         // (Giving each XCD a contiguous 1/8 of the x-fastest tile sequence here as well was measured on the 4 x 6 x 10 grid of the
         // dW_hh product: L2 misses drop 3x, the launch takes 583 us instead of 430 - the four workgroups that share an A panel
