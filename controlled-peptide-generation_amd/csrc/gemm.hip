@@ -145,7 +145,7 @@ static int launch_tc_p(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
 // weight gradients stay f32-grade
 template <class TC, bool A_KC, bool B_KC>
 static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
-    if constexpr (!A_KC && !B_KC && TC::NT == 512) {
+    if constexpr (!A_KC && !B_KC && (TC::NT == 512 || (TC::BM == 128 && TC::BN == 128))) {
         if (cpg_compute_mode_get() == 1) return launch_tc_p<TC, A_KC, B_KC, 1>(g, zdim, vec, s);
     }
     return launch_tc_p<TC, A_KC, B_KC, 7>(g, zdim, vec, s);
@@ -279,11 +279,17 @@ static TnPlan tn_plan(int M, int N, int K) {
     const char* e = getenv("CPG_TN_SPLIT");  // tuning knob (tools/kbench.py)
     // Large products (the dW_hh product: M=3H, N=H, K=T*B): 256x128 tiles, ONE 512-thread workgroup per CU, split-K chosen
     // so that a single round of <= 256 workgroups covers the problem.
-    if (p.tile == TN_AUTO && M >= 512 && N >= 256 && K >= 8192 && M % 4 == 0 && N % 4 == 0) p.tile = TN_256x128;
+    // (bf16 compute mode: the single-buffered 128x128 tile, two workgroups per CU - 347 us against 365 at the dW_hh shape incl.
+    // the reductions; in f32-grade mode it is the slower one, 604 against 564)
+    if (p.tile == TN_AUTO && M >= 512 && N >= 256 && K >= 8192 && M % 4 == 0 && N % 4 == 0)
+        p.tile = (cpg_compute_mode_get() == 1 && M % 128 == 0 && N % 128 == 0) ? TN_128x128 : TN_256x128;
     long want;
     if (p.tile == TN_256x128) {
         const long tiles = (long)cdiv(M, 256) * cdiv(N, 128);
         want = 256 / tiles;
+    } else if (p.tile == TN_128x128) {   // single-buffered plane images: two workgroups per CU, one round
+        const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+        want = 512 / tiles;
     } else {
         // Two 128x64 workgroups are resident per CU (57 KB LDS each): aim at ~3 full rounds of 512 workgroups so the
         // last round is not half empty (measured at M=1536,N=512,K=51200: S=4 (384 WGs) 1356 us, S=16 (1536 WGs) 1084 us).
@@ -339,7 +345,7 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n) 
                      t == TN_128x32 ? "128, 32, 32, 4, 1, 1, 256" : "32, 128, 32, 1, 4, 1, 256";
     const bool vec = N % 4 == 0 && Kd % 4 == 0 && p.k_chunk % 4 == 0;
     return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false, %d>", tc, vec ? "true" : "false",
-                    (t == TN_256x128 && cpg_compute_mode_get() == 1) ? 1 : 7);
+                    ((t == TN_256x128 || t == TN_128x128) && cpg_compute_mode_get() == 1) ? 1 : 7);
 }
 CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
 

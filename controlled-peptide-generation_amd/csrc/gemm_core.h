@@ -228,8 +228,12 @@ struct MainLoop {
                   "0: exact f32; 7: f32-grade, three bf16 planes split at LDS-store time, six MFMAs; 1: bf16 compute mode, one plane, one MFMA");
     static_assert(SPLIT == 0 || BK == 32, "plane products are written for 32-deep slabs");
     static_assert(SPLIT == 0 || TRX || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
+    // SB ("single buffer", the 128 x 128 transposed-use tile on the plane engine): ONE LDS image per operand, two barriers per
+    // slab (product | conversion + store), so that TWO workgroups fit a CU (48 KB each) and run those phases against each other -
+    // the double-buffered 256 x 128 tile has one workgroup per CU whose eight waves all stall on the same loads.
+    static constexpr bool SB = SPLIT != 0 && !A_KC && !B_KC && TC::BM == 128 && TC::BN == 128;
     static constexpr size_t smem_bytes() {
-        return SPLIT != 0 ? (size_t)2 * (ASZ7 + BSZ7) * 4 : (size_t)2 * (ASZ + BSZ) * sizeof(float);
+        return SPLIT != 0 ? (size_t)(SB ? 1 : 2) * (ASZ7 + BSZ7) * 4 : (size_t)2 * (ASZ + BSZ) * sizeof(float);
     }
     // staging vector i of this thread -> (k row inside the slab, column quad) for an XC operand X columns wide
     template <int BX>
@@ -564,6 +568,22 @@ struct MainLoop {
         plan(a, b, pl);
         const int KT = (K + BK - 1) / BK;
         gload(a, b, pl, 0, K, st);
+        if constexpr (SB) {
+            uint32_t* const Bs = base + ASZ7;
+            sstore7(a, b, A0, Bs, st);
+            __syncthreads();
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt == hook_kt) hook();
+                if (kt + 1 < KT) gload(a, b, pl, (kt + 1) * BK, K, st);
+                slab7<false>(a, b, A0, Bs, A0, Bs, st, acc);
+                __syncthreads();
+                if (kt + 1 < KT) {
+                    sstore7(a, b, A0, Bs, st);
+                    __syncthreads();
+                }
+            }
+            return;
+        }
         sstore7(a, b, A0, B0, st);
         __syncthreads();
         for (int kt = 0; kt < KT; kt += 2) {
