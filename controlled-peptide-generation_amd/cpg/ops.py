@@ -275,9 +275,14 @@ class ZeroRowGradFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.clone()
-        g[ctx.row].zero_()
-        return g, None
+        key = (g.device, ctx.row)
+        idx = _ROW_IDX.get(key)
+        if idx is None:   # built once per process: a host -> device copy inside a step would stall the enqueue
+            idx = _ROW_IDX[key] = torch.tensor([ctx.row], device=g.device, dtype=torch.int64)
+        return g.index_fill(0, idx, 0.0), None
+
+
+_ROW_IDX = {}
 
 
 def tokens_prepare(ids, wd_mask=None):
@@ -840,6 +845,51 @@ class LatentTermFn(Function):
         return dmu, dlv, None, None
 
 
+class LatentTermsFn(Function):
+    """The three analytic latent penalties of a training step - kl_gaussianprior, kl_gaussian_sharedmu, logvar L1 (losses.py:8-15,
+    train_vae.py:33) - from ONE statistics pass, with one backward pass for whichever of them carry a gradient.  Values and
+    gradients are those of three LatentTermFn calls (same kernels, same division)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, b_global):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        scaled = latent_sums(mu, logvar)[:3] / b_global
+        ctx.save_for_backward(mu, logvar)
+        ctx.bg = b_global
+        return scaled[0], scaled[1], scaled[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        mu, logvar = ctx.saved_tensors
+        gs = [g.contiguous() if g is not None else None for g in (g0, g1, g2)]
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        call("cpg_latent_stats_bwd", _p(mu), _p(logvar), mu.numel(), ctx.bg, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(dmu), _p(dlv), 0,
+             _stream())
+        return dmu, dlv, None
+
+
+class WeightedSumFn(Function):
+    """sum_i w_i * term_i over up to four device scalars, python-float weights (train_vae.py:35-37), one launch forward and one
+    backward; products and sums rounded one by one, left to right, as the element-wise expression rounds them."""
+
+    @staticmethod
+    def forward(ctx, w, *terms):
+        assert 1 <= len(terms) <= 4 and len(w) == len(terms)
+        ts = [t.contiguous() for t in terms] + [None] * (4 - len(terms))
+        ws = [float(x) for x in w] + [0.0] * (4 - len(terms))
+        out = torch.empty(1, device=terms[0].device, dtype=torch.float32)
+        call("cpg_weighted_sum4", _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), ws[0], ws[1], ws[2], ws[3], _p(out), _stream())
+        ctx.w, ctx.n = ws, len(terms)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        o = torch.empty(4, device=g.device, dtype=torch.float32)
+        call("cpg_scale_fanout4", _p(g), ctx.w[0], ctx.w[1], ctx.w[2], ctx.w[3], _p(o), _stream())
+        return (None,) + tuple(o[i] for i in range(ctx.n))
+
+
 class ReconCEFn(Function):
     """losses.recon_dec (losses.py:18-31).  Returns (sum_nll, count) as device scalars; loss = sum/count is formed by
     the caller so a data-parallel run can all-reduce both first."""
@@ -865,10 +915,13 @@ class ReconLossFn(Function):
     def forward(ctx, logits, ids, count_override):
         logits, ids = logits.contiguous(), ids.contiguous()
         B, T, V = logits.shape
-        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        out = torch.empty(3, device=logits.device, dtype=torch.float32)
         ws = workspace(512 * 4, logits.device, tag=1)
-        call("cpg_recon_ce_fwd", _p(ids), _p(logits), B, T, V, PAD_IDX, _p(out), _p(ws), _stream())
-        count = out[1:2] if count_override is None else count_override.reshape(1).to(torch.float32)
+        call("cpg_recon_ce_loss_fwd", _p(ids), _p(logits), B, T, V, PAD_IDX, _p(out), _p(ws), _stream())
+        if count_override is None:   # the kernel's own sum / max(count, 1)
+            ctx.save_for_backward(logits, ids, out[1:2])
+            return out[2]
+        count = count_override.reshape(1).to(torch.float32)
         ctx.save_for_backward(logits, ids, count.contiguous())
         return out[0] / count.clamp(min=1.0)[0]
 

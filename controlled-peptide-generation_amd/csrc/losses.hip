@@ -73,6 +73,73 @@ CPG_EXPORT int cpg_recon_ce_fwd(const int64_t* ids, const float* logits, int B, 
     return 0;
 }
 
+// out[0], out[1] as cpg_recon_ce_fwd; out[2] = out[0] / max(out[1], 1): the loss itself, formed in the reduction's last block
+// (the same division the host-side wrapper issued as two more launches)
+__global__ void recon_ce_final3_kernel(const float* part, int blocks, float* out) {
+    __shared__ float red[8];
+    float v[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < blocks; i += 256) {
+        v[0] += part[2 * i];
+        v[1] += part[2 * i + 1];
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        out[0] = v[0];
+        out[1] = v[1];
+        out[2] = v[0] / fmaxf(v[1], 1.f);
+    }
+}
+CPG_EXPORT int cpg_recon_ce_loss_fwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, float* out,
+                                     float* workspace, void* stream) {
+    CPG_CHECK_ARG(ids && logits && out && workspace && B > 0 && T > 0 && V > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(recon_ce_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, ids, logits, B, T, V, pad, workspace);
+    hipLaunchKernelGGL(recon_ce_final3_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, RED_BLOCKS, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- loss = t0 + w1 t1 + w2 t2 + w3 t3 (train_vae.py:35-37) as ONE launch, and its gradient fan-out as one: the host-side
+// expression costs three multiplies, three adds and three backward multiplies of one element each.  Products and sums are
+// rounded one by one, left to right, exactly as the separate element-wise kernels round them.
+struct WSum4 {
+    const float* t[4];
+    float w[4];
+};
+__global__ void weighted_sum4_kernel(WSum4 a, float* out) {
+    float s = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!a.t[i]) continue;
+        const float p = a.w[i] == 1.f ? a.t[i][0] : __fmul_rn(a.w[i], a.t[i][0]);
+        s = any ? __fadd_rn(s, p) : p;
+        any = true;
+    }
+    out[0] = s;
+}
+__global__ void scale_fanout4_kernel(const float* g, WSum4 a, float* out) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = __fmul_rn(g[0], a.w[i]);
+}
+// out[0] = sum_i w_i * t_i[0] over the non-null terms (device scalars), in order
+CPG_EXPORT int cpg_weighted_sum4(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1,
+                                 float w2, float w3, float* out, void* stream) {
+    CPG_CHECK_ARG(out && (t0 || t1 || t2 || t3));
+    WSum4 a{{t0, t1, t2, t3}, {w0, w1, w2, w3}};
+    hipLaunchKernelGGL(weighted_sum4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// out[i] = g[0] * w_i, i = 0..3
+CPG_EXPORT int cpg_scale_fanout4(const float* g, float w0, float w1, float w2, float w3, float* out, void* stream) {
+    CPG_CHECK_ARG(g && out);
+    WSum4 a{{nullptr, nullptr, nullptr, nullptr}, {w0, w1, w2, w3}};
+    hipLaunchKernelGGL(scale_fanout4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, a, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 // dlogits = gout * (softmax - onehot) / count on valid rows, 0 elsewhere.  gout and count are device scalars (no host sync).
 __global__ void recon_ce_bwd_kernel(const int64_t* ids, const float* logits, int B, int T, int V, int pad, const float* gout,
                                     const float* count, float* dlogits) {

@@ -47,6 +47,12 @@ def logvar_l1(logvar):
     return ops.LatentTermFn.apply(torch.zeros_like(logvar), logvar, 2, logvar.size(0))
 
 
+def latent_terms(mu, logvar):
+    """(kl_gaussianprior, kl_gaussian_sharedmu, logvar_l1) of one (mu, logvar) pair from a single pass - what train_step uses;
+    each equals the stand-alone function's value and gradient."""
+    return ops.LatentTermsFn.apply(mu, logvar, mu.size(0))
+
+
 def recon_dec(sequences, logits):
     count = None
     if _dist["reduce"] is not None:

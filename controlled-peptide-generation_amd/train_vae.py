@@ -39,14 +39,14 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
     finally:
         model.decoder.ragged = ragged_before
     recon_loss = losses.recon_dec(text, dec_logits)
-    kl_loss = losses.kl_gaussianprior(z_mu, z_logvar)
+    kl_loss, z_logvar_KL_penalty, z_logvar_L1 = losses.latent_terms(z_mu, z_logvar)
     wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0])
     wae_mmdrf_loss = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=z_priors[1])
     z_regu_loss = {'kl': kl_loss, 'mmd': wae_mmd_loss, 'mmdrf': wae_mmdrf_loss}[cfgv.z_regu_loss]
-    z_logvar_L1 = losses.logvar_l1(z_logvar)
-    z_logvar_KL_penalty = losses.kl_gaussian_sharedmu(z_mu, z_logvar)
-    loss = recon_loss + beta * z_regu_loss + cfgv.lambda_logvar_L1 * z_logvar_L1 \
-        + cfgv.lambda_logvar_KL * z_logvar_KL_penalty
+    # loss = recon + beta * regu + lambda_L1 * L1 + lambda_KL * KLpenalty (train_vae.py:35-37), one launch
+    from cpg.ops import WeightedSumFn
+    loss = WeightedSumFn.apply((1.0, beta, cfgv.lambda_logvar_L1, cfgv.lambda_logvar_KL), recon_loss, z_regu_loss, z_logvar_L1,
+                               z_logvar_KL_penalty)
     trainer.zero_grad()
     loss.backward()
     trainer.step()

@@ -277,6 +277,15 @@ CPG_API int cpg_beam_hypotheses(const int32_t* hist_tok, const int32_t* hist_pre
  * workspace: 512 floats. */
 CPG_API int cpg_recon_ce_fwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, float* out,
                              float* workspace, void* stream);
+/* the same with the loss itself appended: out[2] = out[0] / max(out[1], 1) (F.cross_entropy(..., reduction='mean',
+ * ignore_index=PAD), losses.py:27-31).  out: 3 floats. */
+CPG_API int cpg_recon_ce_loss_fwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, float* out,
+                                  float* workspace, void* stream);
+/* train_vae.py:35-37, `loss = recon + beta*regu + l1w*L1 + klw*KLpen`: out[0] = sum_i w_i * t_i[0] over the non-null device
+ * scalars, products and sums rounded one by one, left to right; cpg_scale_fanout4: out[i] = g[0] * w_i (its gradient). */
+CPG_API int cpg_weighted_sum4(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1,
+                              float w2, float w3, float* out, void* stream);
+CPG_API int cpg_scale_fanout4(const float* g, float w0, float w1, float w2, float w3, float* out, void* stream);
 /* dlogits = gout[0] * (softmax - onehot) / count[0] on valid rows (gout, count: device scalars) */
 CPG_API int cpg_recon_ce_bwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, const float* gout,
                              const float* count, float* dlogits, void* stream);

@@ -248,3 +248,35 @@ def test_ragged_decoder_matches_dense_full_size():
     for k in res[0][2]:
         a, b = res[0][2][k], res[1][2][k]
         assert torch.allclose(a, b, atol=1e-6 + 1e-5 * a.abs().max().item()), k
+
+
+def test_fused_step_scalars_match_the_separate_forms():
+    """train_step's fused scalar glue: losses.latent_terms == the three stand-alone latent penalties (values and the summed
+    gradient, bit for bit - same kernels), WeightedSumFn == the element-wise `recon + beta*regu + l1w*L1 + klw*KL` of
+    train_vae.py:35-37 (bit for bit) with its gradient fan-out, and recon_dec's in-kernel mean == sum / count."""
+    import losses
+    from cpg import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mu = torch.randn(64, 30, device="cuda", generator=g)
+    lv = 0.3 * torch.randn(64, 30, device="cuda", generator=g)
+    w = (1.0, 1.37, 0.25, 1e-3)
+    grads = []
+    for fused in (False, True):
+        m, l = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+        if fused:
+            kl, klmu, l1 = losses.latent_terms(m, l)
+            tot = ops.WeightedSumFn.apply(w, kl * 1.0, klmu, l1, kl)
+        else:
+            kl, klmu, l1 = losses.kl_gaussianprior(m, l), losses.kl_gaussian_sharedmu(m, l), losses.logvar_l1(l)
+            tot = kl * 1.0 + w[1] * klmu + w[2] * l1 + w[3] * kl
+        tot.backward()
+        grads.append((kl.detach().clone(), klmu.detach().clone(), l1.detach().clone(), tot.detach().clone(), m.grad.clone(), l.grad.clone()))
+    for a, b in zip(grads[0][:4], grads[1][:4]):
+        assert torch.equal(a, b)
+    for a, b in zip(grads[0][4:], grads[1][4:]):   # one fused backward pass vs three passes summed by autograd
+        assert (a - b).abs().max().item() <= 1e-6 * a.abs().max().item()
+    ids = torch.randint(4, 24, (16, 9), device="cuda", generator=g)
+    ids[:, 6:] = ops.PAD_IDX
+    logits = torch.randn(16, 9, 24, device="cuda", generator=g)
+    out = ops.ReconCEFn.apply(logits, ids)
+    assert torch.equal(losses.recon_dec(ids, logits), out[0] / out[1].clamp(min=1.0))

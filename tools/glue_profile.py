@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Which torch (ATen) kernels one training step launches beside the library's own, grouped by the Python frame that issued them
-(torch.profiler with stacks).  Output: launches and device time per (aten op, source line) over 5 steps."""
+"""Which torch (ATen) ops one training step dispatches beside the library's own kernels, with the repo source line that issued
+them (TorchDispatchMode + traceback; ops issued from the autograd engine have no Python frame and are listed by their shapes)."""
 import collections
 import os
 import sys
+import traceback
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,7 +16,7 @@ import losses  # noqa: E402
 import train_vae as tv  # noqa: E402
 from cpg.synth import synth_ids  # noqa: E402
 from models.model import RNN_VAE  # noqa: E402
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 dev = torch.device("cuda")
 T, V, B, Hh = 25, 24, 2048, 512
@@ -31,30 +32,34 @@ cfgv = cfg.Bunch(lr=1e-3, clip_grad=5.0, z_regu_loss='mmdrf', lambda_logvar_L1=0
                  beta=cfg.Bunch(start=cfg.Bunch(val=1.0, iter=0), end=cfg.Bunch(val=2.0, iter=40000)))
 trainer = tv.make_optimizer(cfgv, model, None, 1)
 ids = synth_ids(B, T, V, torch.Generator().manual_seed(1)).to(dev)
-for _ in range(5):
+for _ in range(3):
     tv.train_step(cfgv, model, trainer, ids, 10)
 torch.cuda.synchronize()
-N = 5
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    for _ in range(N):
-        tv.train_step(cfgv, model, trainer, ids, 10)
-    torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or not ev.kernels:
-        continue
-    frame = "?"
-    for fr in ev.stack:
-        if "controlled-peptide-generation_amd" in fr or "/tools/" in fr:
-            frame = fr.split("controlled-peptide-generation_amd/")[-1]
-            break
-    if frame == "?" and ev.stack:
-        frame = "autograd engine / " + ev.stack[0][-60:]
-    k = (ev.name, frame)
-    agg[k][0] += len(ev.kernels)
-    agg[k][1] += sum(kk.duration for kk in ev.kernels)
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-tot = sum(v[1] for _, v in rows)
-print("torch kernels per step: %.1f launches, %.1f us" % (sum(v[0] for _, v in rows) / N, tot / N))
-for (name, frame), (n, us) in rows[:40]:
-    print("%5.1f x  %7.1f us/step  %-28s %s" % (n / N, us / N, name, frame))
+
+SKIP = ("aten.view", "aten.detach", "aten.t.", "aten.transpose", "aten.slice", "aten.select", "aten.as_strided", "aten.expand",
+        "aten.unsqueeze", "aten.squeeze", "aten._unsafe_view", "aten.alias", "aten.permute", "aten.empty", "aten.narrow",
+        "aten.reshape", "aten.unbind", "aten.split", "aten.chunk", "aten.is_", "aten.sym_", "aten.stride", "aten.size",
+        "aten._local_scalar_dense", "aten.lift_fresh", "aten.new_empty", "aten.resize_", "aten.set_")
+log = collections.Counter()
+
+
+class Mode(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            frame = "autograd engine"
+            for fr in reversed(traceback.extract_stack()):
+                if "controlled-peptide-generation_amd" in fr.filename and "tools/" not in fr.filename:
+                    frame = "%s:%d %s" % (fr.filename.split("controlled-peptide-generation_amd/")[-1], fr.lineno, fr.name)
+                    break
+            shapes = ",".join(str(tuple(a.shape)) for a in args if isinstance(a, torch.Tensor))
+            log[(name, frame, shapes)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Mode():
+    tv.train_step(cfgv, model, trainer, ids, 10)
+torch.cuda.synchronize()
+for (name, frame, shapes), n in sorted(log.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+    print("%2d x %-34s %-60s %s" % (n, name, frame, shapes))
+print("total dispatched ops:", sum(log.values()))
