@@ -402,6 +402,9 @@ using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab b
 // of a row reads slot q ^ f(row).  Contraction order = the register-staged kernel's (k = 16h + 4q + j): bit-identical sums.
 // Covers dense launches with B % 32 == 0, H % 32 == 0 and 16-byte aligned operands; everything else runs gru_step_bwd_kernel.
 // BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16); main loop: DlLoop (gemm_core.h)
+#ifndef CPG_DL_ABLATE
+#define CPG_DL_ABLATE 0   // diagnostic builds (tools/variant_build.sh): 1 no epilogue loads, 2 no stores, 4 no main loop
+#endif
 // PREC 1: bf16 compute mode (operands rounded at the fragment read, one bf16 MFMA per block and slab)
 template <int BM, int BN, int NS, int PREC = 0>
 __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
@@ -432,6 +435,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             for (int ni = 0; ni < NI; ++ni) {
                 const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
                 f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (CPG_DL_ABLATE & 1) {   // diagnostic build: no epilogue-operand loads (results wrong)
+                    pre[mi][ni] = p;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) sv[mi][ni][q] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+                    continue;
+                }
                 if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
                 if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
                 if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
                 }
             }
     };
-    if (g.dG_next) {
+    if (g.dG_next && !(CPG_DL_ABLATE & 4)) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
         DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
@@ -458,6 +467,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
             const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
             const size_t o = (size_t)row * H + col;
+            if ((CPG_DL_ABLATE & 2) && dh[0] != 12345.f) continue;   // diagnostic build: no result stores
             *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
             if (!g.gates) continue;
             const f32x4 rg = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
