@@ -807,7 +807,9 @@ struct DlLoop {
     template <class Hook>
     __device__ static __forceinline__ void run(const float* A, size_t lda, const float* Bt, size_t ldb, int K, float* smem,
                                                f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook) {
-        const int tid = threadIdx.x, lane = tid & 63;
+        // (a 512-thread workgroup runs two of these loops side by side - its two 256-thread halves, each on its own ring and its
+        // own half of K: gru_step_bwd_dl2_kernel; the slab barrier is the workgroup's)
+        const int tid = threadIdx.x & 255, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
         const int KT = K / 32;

@@ -483,6 +483,91 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
 }
 
 
+// ---- the same step for launches that have only ~256 tiles of 64 x 64 (one direction at B=2048, H=512): ONE 512-thread
+// workgroup per tile whose two 256-thread halves each run the direct-to-LDS loop over HALF of K on their own LDS ring (the
+// operand traffic per MFMA of the 64 x 64 tile with the eight waves per CU of two 64 x 32 workgroups), then swap partial
+// blocks through LDS so that each half finishes - adds, cell backward, stores - one 16-row block row of every wave tile.
+// The two half sums are added once (a + b): NOT the slab-by-slab order of the other kernels, equal to them within f32 rounding.
+template <int PREC>
+__global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
+    using DL = DlLoop<64, 64, 3, PREC>;
+    constexpr int NI = DL::NI;
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const GruBwdArgs& g = pr.d[bz];
+    const int H = g.H;
+    const int m0 = g.row0 + by * 64, j0 = bx * 64;
+    const size_t BH = (size_t)g.B * H;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave8 >> 2, wave = wave8 & 3;
+    float* const ring = cpg_smem + kg * DL::smem_floats();
+    float* const tb = cpg_smem + 2 * DL::smem_floats() + wave8 * 256;
+    const int wm = wave >> 1, wn = wave & 1;
+    // after the swap this wave owns block row kg of its wave tile
+    const int rb = m0 + wm * 32 + 16 * kg + (lane >> 2), cb0 = j0 + wn * 32 + 4 * (lane & 3);
+    f32x4 acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pre[NI], sv[NI][5];
+    auto load_ep = [&]() {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const size_t o = (size_t)rb * H + cb0 + 16 * ni;
+            f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+            if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
+            if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
+            pre[ni] = p;
+            if (g.gates) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sv[ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                sv[ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
+            }
+        }
+    };
+    f32x4 mine[NI];
+    if (g.dG_next) {
+        const int Kh = 3 * H / 2;
+        const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int phase = ((hb >> 3) + (hb >> 8)) & 3;
+        DL::run(g.dG_next + (size_t)m0 * 4 * H + kg * Kh, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H + kg * Kh, (size_t)3 * H, Kh,
+                ring, acc, min(phase * (g.ep_step / 2), Kh / 32 - 1), load_ep);
+        __syncthreads();   // every fragment read of the rings is done: their first 16 KB carry the swap
+        f32x4* const xb = reinterpret_cast<f32x4*>(cpg_smem);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) xb[(((1 - kg) * 4 + wave) * NI + ni) * 64 + lane] = kg ? acc[0][ni] : acc[1][ni];
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mine[ni] = (kg ? acc[1][ni] : acc[0][ni]) + xb[((kg * 4 + wave) * NI + ni) * 64 + lane];
+    } else {
+        load_ep();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mine[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const f32x4 dh = acc_block_to_rows(tb, mine[ni], lane) + pre[ni];
+        const int col = cb0 + 16 * ni;
+        const size_t o = (size_t)rb * H + col;
+        *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+        if (!g.gates) continue;
+        const f32x4 rg = sv[ni][0], zg = sv[ni][1], ng = sv[ni][2], hn = sv[ni][3], hp = sv[ni][4];
+        const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+        const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
+        const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
+        float* d = g.dG_out + (size_t)rb * 4 * H + col;
+        *reinterpret_cast<f32x4*>(d) = dr_pre;
+        *reinterpret_cast<f32x4*>(d + H) = dz_pre;
+        *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
+        *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+    }
+}
+
+
 template <class TC, int PREC>
 static void launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
@@ -672,6 +757,32 @@ static void launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
     hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, NS, PREC>), grid, dim3(256), smem, s, pr);
 }
 
+template <int PREC>
+static void launch_dl2(const GruBwdPair& pr, int nd, hipStream_t s) {
+    const GruBwdArgs& a = pr.d[0];
+    dim3 grid(a.H / 64, (a.row1 - a.row0) / 64, nd);
+    const size_t smem = (2 * DlLoop<64, 64, 3, PREC>::smem_floats() + 8 * 256) * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_dl2_kernel<PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        done = true;
+    }
+    hipLaunchKernelGGL((gru_step_bwd_dl2_kernel<PREC>), grid, dim3(512), smem, s, pr);
+}
+// 64 x 64 tiles, two K-halves per workgroup: launches with 128 <= tiles < 512 (fewer than two 64 x 64 workgroups per CU, the
+// decoder's single direction at B=2048, H=512) IN THE bf16 COMPUTE MODE - measured at that shape, us per launch against the
+// 64 x 32 direct-to-LDS kernel: bf16 mode 21.1 vs 24.7, f32-grade 38.9 vs 37.1 (its main loop is matrix-pipe-bound either way
+// and the eight-wave barrier costs more than the halved operand traffic returns).  CPG_GRU_BWD_DL2=0 disables, =1 forces it
+// for any full-tile shape in either mode.
+static bool bwd_dl2_wanted(int rows, int H, int nd, bool bf16) {
+    const char* e = getenv("CPG_GRU_BWD_DL2");
+    if (e && atoi(e) == 0) return false;
+    if (rows % 64 != 0 || H % 64 != 0) return false;
+    if (e && atoi(e) == 1) return true;
+    const long wg64 = (long)(rows / 64) * (H / 64) * nd;
+    return bf16 && wg64 >= 128 && wg64 < 512;
+}
+
 static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     GruBwdPair pr = pr_in;
     for (int d = 0; d < 2; ++d) pr.d[d].ep_step = bwd_ep_step(pr.d[d].H);
@@ -702,6 +813,12 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
         const int rows = a.row1 - a.row0;
         const bool r64 = rows % 64 == 0, h64 = a.H % 64 == 0;
         const long wg64 = (long)(rows / 64) * (a.H / 64) * nd;   // 64 x 64 tiles of the launch
+        if (!t && !st && bwd_dl2_wanted(rows, a.H, nd, bf16_dl)) {
+            if (bf16_dl) launch_dl2<1>(pr, nd, s);
+            else launch_dl2<0>(pr, nd, s);
+            CPG_LAUNCH_CHECK();
+            return 0;
+        }
         int bm = 32, bn = 32;
         if (t) {
             if (!strcmp(t, "64x64")) { bm = 64; bn = 64; }
@@ -883,6 +1000,8 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
         const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
         const bool bf16_dl = c.wt && !c.forced && cpg_compute_mode_get() == 1 && !getenv("CPG_GRU_BWD_TILE");
         if ((!c.wt || bf16_dl) && !c.forced && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
+            if (!getenv("CPG_GRU_BWD_DL_TILE") && !getenv("CPG_GRU_BWD_DL_STAGES") && bwd_dl2_wanted(B, H, ndir, bf16_dl))
+                return snprintf(buf, n, "gru_step_bwd_dl2_kernel<%d>", bf16_dl ? 1 : 0);
             const bool r64 = B % 64 == 0, h64 = H % 64 == 0;
             const long wg64 = (long)(B / 64) * (H / 64) * ndir;
             const int bm = (r64 && h64 && wg64 >= 512) || (r64 && wg64 >= 256) ? 64 : 32, bn = (r64 && h64 && wg64 >= 512) ? 64 : 32;

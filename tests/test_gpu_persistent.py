@@ -301,3 +301,42 @@ def test_chain_backward_bf16_mode_matches_per_step_bf16():
     dG_f, _, _ = _run_chain(d, B, H, T, False, True, seed=3, dh_last=True)      # f32-grade result: bf16 mode is close, not equal
     assert not torch.equal(dG_f, dG_c)
     assert (dG_f - dG_c).abs().max().item() < 2e-2 * dG_f.abs().max().item()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,T", [(256, 128, 6), (128, 192, 4)])
+def test_backward_two_k_halves_workgroup_matches_the_plain_direct_to_lds_kernel(B, H, T, mode):
+    """gru_step_bwd_dl2_kernel (512 threads, two K-halves, partial blocks swapped through LDS; CPG_GRU_BWD_DL2=1 forces it) against
+    gru_step_bwd_dl_kernel (=0): the same products with one extra reassociation (half sums added once), forward and reverse."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call
+    dev = torch.device("cuda")
+    d = _inputs(B, H, T, 24, seed=41)
+    ops.set_compute_mode(mode)
+    saved = os.environ.get("CPG_GRU_BWD_DL2")
+    try:
+        for reverse in (0, 1):
+            hs, gates = _run(d, B, H, T, bool(reverse), False)
+            g = torch.Generator().manual_seed(7)
+            dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
+            last = (torch.randn(B, H, generator=g) * 0.1).to(dev)
+            res = []
+            for knob in ("0", "1"):
+                os.environ["CPG_GRU_BWD_DL2"] = knob
+                dG, dh0 = torch.zeros(T, B, 4 * H, device=dev), torch.zeros(B, H, device=dev)
+                scr, wT = torch.empty(2, B, H, device=dev), torch.empty(H, 3 * H, device=dev)
+                call("cpg_gru_seq_bwd", T, B, H, reverse, _p(d["w_hh"]), _p(hs), _p(gates), _p(dhs), _p(last), _p(dG), _p(scr), _p(dh0),
+                     0, B, None, _p(wT), _stream())
+                torch.cuda.synchronize()
+                res.append((dG, dh0))
+            # bf16 mode: a last-bit difference in dG can flip the bf16 rounding of the next step's operand (2^-9 of one term)
+            tol = 2e-6 if mode == "f32" else 1e-3
+            for a, b in zip(res[0], res[1]):
+                assert not torch.equal(a, torch.zeros_like(a))
+                assert (a - b).abs().max().item() <= tol * max(1.0, a.abs().max().item())
+    finally:
+        ops.set_compute_mode("f32")
+        if saved is None:
+            os.environ.pop("CPG_GRU_BWD_DL2", None)
+        else:
+            os.environ["CPG_GRU_BWD_DL2"] = saved
