@@ -66,3 +66,31 @@ CPG_EXPORT int cpg_lr_score_accept(const float* z, int n, int D, const double* c
     CPG_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- residue rows of decoded ids (the compaction idx2sentences(..., print_special_tokens=False) does per row in python,
+// data_processing/dataset.py:285-300 via sample_pipeline.py:129-139): ids int16 [n, L] (< first_residue = special or padding) ->
+// letters uint8 [n, L] (the ids >= first_residue of the row, left-aligned, zero-filled) and their count.  One thread per row,
+// 2 L bytes in and L bytes out per row: HBM-bound and tiny (the tensor-op form - int64 cast, cumsum, scatter - took 20 ms per
+// million rows).
+__global__ void residue_rows_kernel(const int16_t* ids, size_t n, int L, int first_residue, uint8_t* letters, int32_t* counts) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int16_t* r = ids + row * L;
+    uint8_t* o = letters + row * L;
+    int k = 0;
+    for (int j = 0; j < L; ++j) {
+        const int v = r[j];
+        if (v >= first_residue) o[k++] = (uint8_t)v;
+    }
+    counts[row] = k;
+    for (; k < L; ++k) o[k] = 0;
+}
+CPG_EXPORT int cpg_residue_rows(const int16_t* ids, size_t n, int L, int first_residue, uint8_t* letters, int32_t* counts,
+                                void* stream) {
+    CPG_CHECK_ARG(ids && letters && counts && n > 0 && L > 0 && first_residue >= 0);
+    hipLaunchKernelGGL(residue_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids, n, L,
+                       first_residue, letters, counts);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}

@@ -228,6 +228,14 @@ def residue_rows(ids, n_vocab):
     stripped, left-aligned, zero-filled; counts int32 [n]).  The compaction idx2sentences(..., print_special_tokens=False)
     does per row in python, as three tensor ops on the device the decode left the ids on.  Two rows give the same peptide
     string iff their letter rows are equal."""
+    if ids.is_cuda and ids.shape[0] > 0:   # one pass on the device (cpg_residue_rows); the tensor-op form below serves host arrays
+        from cpg import ops
+        ids16 = ids.to(torch.int16).contiguous()
+        letters = torch.empty(ids16.shape, dtype=torch.uint8, device=ids.device)
+        counts = torch.empty(ids16.shape[0], dtype=torch.int32, device=ids.device)
+        ops.call("cpg_residue_rows", ops._p(ids16), ids16.shape[0], ids16.shape[1], N_SPECIALS, ops._p(letters), ops._p(counts),
+                 ops._stream())
+        return letters, counts
     ids = ids.to(torch.int64)
     keep = ids >= N_SPECIALS
     pos = torch.cumsum(keep, 1) - 1

@@ -330,6 +330,12 @@ CPG_API int cpg_lr_score_accept(const float* z, int n, int D, const double* coef
                                 const int32_t* target, int A, const double* uniforms, double* probs, double* accum,
                                 uint8_t* accepted, void* stream);
 
+/* Residue rows of decoded ids: what dataset.idx2sentences(..., print_special_tokens=False) keeps of each row
+ * (data_processing/dataset.py:285-300, called from sample_pipeline.py:129-139), as arrays.  ids int16 [n, L] (ids below
+ * first_residue - the 4 specials, or -1 padding - are dropped); letters uint8 [n, L] left-aligned, zero-filled; counts [n]. */
+CPG_API int cpg_residue_rows(const int16_t* ids, size_t n, int L, int first_residue, uint8_t* letters, int32_t* counts,
+                             void* stream);
+
 /* ---- CNN classifier forward (ADJACENT row, inference only): models/classifier.py:39-60 ------------------------------
  * pooled[B, nconv*F] = max_p relu(bias + sum_dw tab[dw][ids[b,p+dw]]) for filters of widths min_width..min_width+nconv-1;
  * tabs = per layer [w][V][F] tables emb @ W[:,0,dw,:]^T (cpg_linear_fwd), layers back to back; bias [nconv,F]. */

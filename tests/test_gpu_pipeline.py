@@ -428,3 +428,20 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["unit"] == "seq/s" and c["value"] > 0 and c["cores"] >= 1 and len(c["cases"]) == 3
     k = d["class"]
     assert k["unit"] == "accepted-samples/s" and k["value"] > 0 and k["roofline"]["kernel"] and k["cpu_baseline"]["value"] > 0
+
+
+def test_residue_rows_device_kernel_equals_the_tensor_op_form():
+    """cpg_residue_rows (device ids) vs the cumsum / scatter form (host ids): letters and counts equal, for rows that are all
+    padding, all specials, full of residues, and random mixes; int16 / int32 / int64 ids."""
+    import sample_pipeline as sp
+    rs = np.random.RandomState(4)
+    ids = rs.randint(-1, 24, size=(1000, 26)).astype(np.int64)
+    ids[0] = -1
+    ids[1] = 3
+    ids[2] = 7
+    ids[3, ::2] = 1
+    ref_l, ref_n = sp.residue_rows(torch.from_numpy(ids), 24)
+    for dt in (torch.int16, torch.int32, torch.int64):
+        l, n = sp.residue_rows(torch.from_numpy(ids).to(dt).cuda(), 24)
+        assert l.dtype == torch.uint8 and n.dtype == torch.int32
+        assert torch.equal(l.cpu(), ref_l) and torch.equal(n.cpu(), ref_n)
