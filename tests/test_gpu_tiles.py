@@ -211,3 +211,25 @@ def test_other_seq_len_vs_oracle():
         m, P, ids, rnd = _random_case(192, T, 24, 100, 80, 1, seed=seed)
         _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
         _check_greedy_vs_oracle(m, P, 256, T, seed=seed + 100)
+
+
+def test_minimal_seq_len_vs_oracle(monkeypatch):
+    """The shortest sequences the path can be given: T = 1 (only <start>: every target is PAD), 2, 3, with rows of every live
+    length, at B = 5 (one partial row tile) and B = 64 - losses and gradients against the oracle."""
+    import cpg.synth as synth
+
+    def tiny_ids(B, T, V, gen):   # <start>=2, <eos>=3, <pad>=1, residues from 4
+        ids = torch.full((B, T), 1, dtype=torch.int64)
+        ids[:, 0] = 2
+        for b in range(B):
+            n = 1 + (b % T)
+            for j in range(1, n):
+                ids[b, j] = 4 + (7 * b + j) % (V - 4)
+            if n < T:
+                ids[b, n] = 3
+        return ids
+    monkeypatch.setattr(synth, "synth_ids", tiny_ids)
+    for T in (1, 2, 3):
+        for B in (5, 64):
+            m, P, ids, rnd = _random_case(B, T, 24, 100, 80, 1, seed=30 + T)
+            _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
