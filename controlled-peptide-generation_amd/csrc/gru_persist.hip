@@ -79,8 +79,8 @@ constexpr int P_CT = 16;          // hidden units per workgroup
 #define CPG_PERSIST_DEFER 0       // 1: the f32 state / gate stores of step p are issued after the wait of step p+1
 #endif
 #ifndef CPG_PERSIST_DEPTH
-#define CPG_PERSIST_DEPTH 2
-#endif
+#define CPG_PERSIST_DEPTH 3       // k-blocks of the state operand in flight per wave (8 waves: f32-grade 21.8 / 21.7 / 22.0 us per step at
+#endif                            // depth 2 / 3 / 4; bf16 mode 10.5 / 10.0 / 10.1)
 constexpr int P_DEPTH = CPG_PERSIST_DEPTH;
 #ifndef CPG_PERSIST_BWD_DEPTH
 #define CPG_PERSIST_BWD_DEPTH 4   // the backward k-block is a third of the forward's work: deeper ring for the same latency cover
