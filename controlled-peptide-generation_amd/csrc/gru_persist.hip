@@ -39,7 +39,9 @@
 #define CPG_PERSIST_ROTATE 0
 #endif
 #ifndef CPG_PERSIST_PLAIN_LOADS
-#define CPG_PERSIST_PLAIN_LOADS 1   // 1: exchange slots are never reused inside a launch and are read with plain (L1/L2-allocating) loads
+#define CPG_PERSIST_PLAIN_LOADS 0   // 1: exchange slots are never reused inside a launch and are read with plain (L1/L2-allocating) loads;
+                                    // 0: two-slot ring read with sc1 loads (always served behind the L2).  With the arrival counters on
+                                    // their own lines the sc1 form is the faster one: 19.7 vs 21.9 us per step (f32-grade, B=2048, H=512)
 #endif
 // Diagnostic builds only (results wrong by construction): 1 no waits, 2 A operand loaded once per step, 4 no MFMAs,
 // 8 no cell transcendental math, 16 no gate stores, 32 no publish drain (vmcnt) before the arrival
