@@ -33,13 +33,30 @@ HBM_PEAK_GBS = 8000.0
 # tools/pmc_summary.py --json): counters cannot be collected from inside this script, so the per-kernel means of the
 # committed profile are looked up BY THE KERNEL NAME THE LAUNCHER REPORTS - a tile-policy change yields null, not a stale
 # number.  (2*FETCH + WRITE)*1024: the gfx950 read-side correction of MI355X_MICROARCH.md, HBM section.
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, sorted by name): what a PMC profile must have been taken from for its
+    per-kernel byte counts to describe the kernels this run launches (the GPU box has no .git, so not a commit id)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile - only when that profile was taken from THESE kernel
+    sources (its "_csrc_sha256_16" stamp equals csrc_fingerprint()); otherwise null."""
     try:
         d = json.load(open(PMC_JSON))
     except (OSError, ValueError):
+        return None
+    if d.get("_csrc_sha256_16") != csrc_fingerprint():
         return None
     r = d.get(kernel)
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
@@ -159,6 +176,247 @@ def note(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    p = sk.getsockname()[1]
+    sk.close()
+    return p
+
+
+def spawn_command(gpus, argv, port):
+    """The launch line the driver uses for N > 1 (one rank per GPU over RCCL), built here when bench.py is started WITHOUT it."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def maybe_self_spawn(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself as N ranks through
+    torch.distributed.run (same arguments).  With fewer visible GPUs than ranks (a 1-GPU box) the ranks share devices:
+    RCCL refuses two ranks on one device, so the collectives run on gloo and the line says so - a functional run of the
+    N > 1 code path, not a scaling measurement."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.dist_selftest or ngpu < args.gpus:
+        env["CPG_DIST_BACKEND"] = "gloo"
+    if 0 < ngpu < args.gpus:
+        env["CPG_SHARED_DEVICE"] = "1"   # persistent kernels need every CU of the device to themselves: off when ranks share it
+        env["CPG_GRU_PERSIST"] = env["CPG_LSTM_PERSIST"] = "0"
+    cmd = spawn_command(args.gpus, sys.argv[1:], _free_port())
+    note("self-spawn: " + " ".join(cmd[1:8]) + " ...")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_count_per_step(step_fn):
+    """Kernel launches of ONE training step (torch.profiler device-activity records; None when the profiler is unavailable or
+    switched off with CPG_BENCH_NO_TORCH_PROFILER=1, e.g. under rocprofv3)."""
+    if os.environ.get("CPG_BENCH_NO_TORCH_PROFILER"):
+        return None
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step_fn()
+            torch.cuda.synchronize()
+        n = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and not e.name.lower().startswith(("memcpy", "memset")))
+        return n or None
+    except Exception as e:   # noqa: BLE001 - a diagnostic count must never fail the bench
+        note(f"launch count unavailable: {e!r}")
+        return None
+
+
+def rccl_probe(dev, grad_numel, backend, world, iters=20):
+    """Times the two collectives of the path on their real payloads: the SUM all-reduce of a flat f32 gradient buffer of the
+    model's size, and the all-gather of one CLaSS round's rows (cpg.dist.allgather_rows on a [65536/world, 26] int16 + f32
+    frame).  HIP events on the current stream; RCCL enqueues on its own stream and the process group makes the current
+    stream wait for it (work.wait()), so the events bracket the collective."""
+    import torch.distributed as tdist
+    from cpg import dist as cdist
+    on_gpu = backend == "nccl"
+    buf = torch.zeros(grad_numel, device=dev if on_gpu else "cpu", dtype=torch.float32)
+    rows = torch.zeros(65536 // world, 26 + 100, device=dev if on_gpu else "cpu", dtype=torch.float32)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        if on_gpu:
+            torch.cuda.synchronize()
+        tdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        if on_gpu:
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    ar = timed(lambda: tdist.all_reduce(buf))
+    ag = timed(lambda: cdist.allgather_rows(rows))
+    nbytes = grad_numel * 4
+    return {"backend": backend, "ranks": world, "allreduce_ms": round(ar, 4), "allreduce_bytes": nbytes,
+            "allreduce_busbw_GBs": round(2.0 * (world - 1) / world * nbytes / (ar * 1e-3) / 1e9, 2),
+            "allgather_ms": round(ag, 4), "allgather_rows_per_rank": rows.shape[0], "allgather_row_bytes": rows.shape[1] * 4,
+            "shared_device": bool(os.environ.get("CPG_SHARED_DEVICE")),
+            "overlap": "gradient buckets (decoder, encoder heads) are all-reduced while the encoder BPTT still runs (cpg.optim)"}
+
+
+def dist_selftest(args):
+    """CPU-only check of the N > 1 launcher and the collectives plumbing (tests/test_dist_gloo.py runs it with 2 ranks):
+    no GPU work at all, prints one JSON line with the `rccl` object measured over gloo."""
+    import torch.distributed as tdist
+    from cpg import dist as cdist
+    world, rank, local = cdist.init(backend="gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    probe = rccl_probe(None, 1 << 16, "gloo", world, iters=3) if world > 1 else None
+    if world > 1:
+        tdist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "dist", "n_gpus": world, "rccl": probe}))
+
+
+def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len, steps, warmup, min_sustain_s=0.0):
+    """One timed WAE-training leg: builds the model at the given dimensions, W untimed steps, EXACTLY `steps` timed steps
+    bracketed by barrier + synchronize, max over ranks.  Returns the numbers of the leg (rank 0 builds the roofline rows).
+    min_sustain_s > 0: afterwards the same step keeps running until that much wall time has passed (`sustained`): the timed
+    region of the default K=20 is 0.14 s, too short for an SMI sampler to see the GPU busy."""
+    import cfg
+    import losses
+    from cpg import dist as cdist
+    from cpg import ops
+    from cpg.synth import synth_ids
+    from models.model import RNN_VAE
+    import train_vae as tv
+
+    ops.set_compute_mode(dtype)
+    T, V, B, Hh = seq_len, 24, batch, hidden
+    Z, E, R = Hh - 2, 150, 500
+    torch.manual_seed(1238)
+    model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh, enc_layers=enc_layers, cell=args.cell)).to(dev)
+    model.device = dev
+    losses.rf.clear()
+    losses._rf_basis(torch.zeros(1, Z, device=dev), R, False)          # same basis on every rank (same seed)
+    model.use_device_rng(1238 + 7919 * rank)                            # rank-distinct draws
+    losses.set_prior_sampler(lambda z: model._randn(z.shape[0], z.shape[1]))
+    cdist.broadcast_params(model.parameters())
+    reduce_fn = cdist.allreduce_sum if world > 1 else None
+    losses.set_distributed(reduce_fn, world, gather_fn=cdist.allgather_equal, rank=rank)
+    cfgv = cfg.Bunch(lr=1e-3, clip_grad=5.0, z_regu_loss='mmdrf', lambda_logvar_L1=0.0, lambda_logvar_KL=1e-3,
+                     beta=cfg.Bunch(start=cfg.Bunch(val=1.0, iter=0), end=cfg.Bunch(val=2.0, iter=40000)))
+    trainer = tv.make_optimizer(cfgv, model, reduce_fn, world)
+    g = torch.Generator().manual_seed(1238 + rank)
+    pool = [synth_ids(B, T, V, g).to(dev) for _ in range(8)]
+
+    def step(it):
+        return tv.train_step(cfgv, model, trainer, pool[it % len(pool)], it)
+
+    for it in range(warmup):
+        step(it)
+    torch.cuda.synchronize()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    t0 = time.perf_counter()
+    for it in range(steps):
+        out = step(warmup + it)
+    t_enqueued = time.perf_counter() - t0   # host time to enqueue the K steps (no host sync inside a step)
+    torch.cuda.synchronize()
+    cdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        cdist.allreduce_max(tmax)
+    dt = float(tmax.item())
+    loss_val = float(out["L_vae"].item())
+    assert np.isfinite(loss_val), "non-finite loss in the timed region"
+    ops.check_persistent()
+    ms = dt / steps * 1e3
+    res = {"value": round(B * world * steps / dt, 1), "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+           "loss_last_step": round(loss_val, 4), "host_enqueue_ms_per_step": round(t_enqueued / steps * 1e3, 3),
+           "grad_numel": trainer.flat_g.numel(), "launches_per_step": launch_count_per_step(lambda: step(warmup + steps))}
+    if min_sustain_s > 0:
+        # same step, same model, until min_sustain_s of wall time: per-step time over ALL of these iterations
+        it, n = warmup + steps + 1, 0
+        torch.cuda.synchronize()
+        cdist.barrier()
+        ts = time.perf_counter()
+        chunk = max(steps, 10)
+        while True:
+            for _ in range(chunk):
+                step(it)
+                it += 1
+            n += chunk
+            torch.cuda.synchronize()
+            go = torch.tensor([1.0 if time.perf_counter() - ts < min_sustain_s else 0.0], device=dev)
+            if world > 1:
+                cdist.allreduce_max(go)          # every rank runs the same number of chunks
+            if go.item() == 0.0:
+                break
+        cdist.barrier()
+        ds = time.perf_counter() - ts
+        res["sustained"] = {"steps": n, "wall_s": round(ds, 3), "ms_per_step": round(ds / n * 1e3, 3),
+                            "value": round(B * world * n / ds, 1)}
+        ops.check_persistent()
+    if rank == 0:
+        # kernel families of the step, timed with HIP events on their launch streams inside the timed region (cpg.ops._prof);
+        # the roofline object carries the family with the largest share of the step, the others follow in `extra`
+        fams = {}
+        for fam, e0, e1, launches, dims in prof:
+            key = (fam, dims["B"], dims["H"], dims["ndir"], dims["T"])
+            f = fams.setdefault(key, {"ms": 0.0, "launches": 0, "dims": dims, "family": fam})
+            f["ms"] += e0.elapsed_time(e1)
+            f["launches"] += launches
+        rows = []
+        for f in fams.values():
+            avg_us = f["ms"] * 1e3 / max(f["launches"], 1)
+            r = family_roofline(f["family"], f["dims"], avg_us, f["launches"])
+            if r is None:
+                continue
+            r["family"] = f["family"] + ("_pair" if f["dims"]["ndir"] == 2 else "")
+            r["ms_per_step"] = round(f["ms"] / steps, 3)
+            r["share_of_step"] = round(f["ms"] / steps / ms, 4)
+            rows.append(r)
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        by_kernel = {}
+        for r in rows:   # single-direction and paired launches of one kernel: rank kernels by their summed share
+            by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0.0) + r["ms_per_step"]
+        top_kernel = max(by_kernel, key=by_kernel.get) if by_kernel else None
+        roofline = next((r for r in rows if r["kernel"] == top_kernel),
+                        {"bound": "mfma", "kernel": None, "achieved": 0.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 0.0, "traffic": None})
+        roofline = dict(roofline)
+        roofline["kernel_ms_per_step_all_launch_shapes"] = round(by_kernel.get(top_kernel, 0.0), 3)
+        gates = 3 if args.cell == "gru" else 4
+        step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
+        res.update(roofline=roofline, kernel_families=[r for r in rows if r["kernel"] != top_kernel or r["family"] != roofline.get("family")],
+                   executed_step_tflops_per_gpu=round(step_tflops, 2),
+                   executed_step_frac_of_f32_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4))
+    del trainer, model, pool
+    losses.set_distributed(None, 1)
+    ops.set_compute_mode('f32')
+    torch.cuda.empty_cache()
+    return res
+
+
+def workload_text(args, dtype, Hh, enc_layers, B, T):
+    Z = Hh - 2
+    cfg_tag = ("BASELINE.json configs[1]" if (Hh, T, enc_layers, B) == (512, 25, 1, 2048)
+               else "BASELINE.json configs[4] dimensions, GRU cells, 1-layer decoder as in the reference"
+               if (Hh, T, enc_layers) == (1024, 50, 2) else "non-default dimensions")
+    return (f"WAE train step ({cfg_tag}): biGRU encoder h={Hh} {enc_layers} layer, z={Z}, GRU decoder "
+            f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; "
+            + ("GRU cell = the reference's cell, parity pinned (the reference has no LSTM; --cell lstm runs "
+               "the LSTM extension)" if args.cell == "gru" else
+               "LSTM cell (extension, torch.nn.LSTM semantics; parity unpinned against the GRU-only reference)")
+            + (", f32 storage; recurrent products on the MFMA units in f32-grade forms (exact-f32 MFMA, or six bf16 MFMAs on 3-way "
+               "split operands)" if dtype == "f32" else
+               ", bf16 mode: recurrent products with bf16-rounded operands (one bf16 MFMA per block, f32 accumulation), saved gates / "
+               "gate gradients stored as bf16, f32 state slabs and master weights (NOT the parity path: agreement figures in profiles/)"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,12 +429,19 @@ def main():
     ap.add_argument("--cell", default="gru", choices=["gru", "lstm"], help="gru = the reference's cell (parity pinned); lstm = extension")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = f32-grade products (the parity path, the headline line); bf16 = bf16 recurrent products "
-                         "(cfg.hw.dtype='bf16': one bf16 MFMA per block, f32 accumulate / storage / master weights)")
+                         "(cfg.hw.dtype='bf16': one bf16 MFMA per block, f32 accumulate / master weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-class", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip extra.bf16_mode / extra.config_c / the sustained region")
+    ap.add_argument("--sustain-s", type=float, default=2.5, help="wall seconds of the sustained region after the K timed steps")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="host seconds per cpu_baseline case (bounded sample)")
-    ap.add_argument("--class-proposals", type=int, default=1000000, help="z proposals of the CLaSS leg (BASELINE.json configs[3]: 1 M)")
+    ap.add_argument("--class-proposals", type=int, default=1000000, help="z proposals of the CLaSS leg (BASELINE.json configs[3]: 1 M in total, sharded over the ranks)")
+    ap.add_argument("--dist-selftest", action="store_true", help="CPU-only check of the N>1 launcher + collectives (gloo); no GPU work")
     args = ap.parse_args()
+
+    maybe_self_spawn(args)
+    if args.dist_selftest:
+        return dist_selftest(args)
 
     from cpg import dist as cdist
     world, rank, local = cdist.init()
@@ -185,134 +450,70 @@ def main():
     local = cdist.local_device(local)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = torch.distributed.get_backend() if world > 1 else None
 
-    import cfg
-    import losses
-    from cpg import ops
-    from cpg.synth import synth_ids
-    from models.model import RNN_VAE
-    import train_vae as tv
-
-    ops.set_compute_mode(args.dtype)
-    T, V, B, Hh = args.seq_len, 24, args.batch, args.hidden
-    Z, E, R = Hh - 2, 150, 500
-    torch.manual_seed(1238)
-    model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh, enc_layers=args.enc_layers, cell=args.cell)).to(dev)
-    model.device = dev
-    losses.rf.clear()
-    losses._rf_basis(torch.zeros(1, Z, device=dev), R, False)          # same basis on every rank (same seed)
-    model.use_device_rng(1238 + 7919 * rank)                            # rank-distinct draws
-    losses.set_prior_sampler(lambda z: model._randn(z.shape[0], z.shape[1]))
-    cdist.broadcast_params(model.parameters())
-    reduce_fn = cdist.allreduce_sum if world > 1 else None
+    T, B, Hh = args.seq_len, args.batch, args.hidden
+    note("headline leg")
+    head = train_leg(args, dev, rank, world, args.dtype, Hh, args.enc_layers, B, T, args.steps, args.warmup,
+                     0.0 if args.no_extra_legs else args.sustain_s)
+    extra = {}
+    default_shape = (Hh, T, args.enc_layers, B, args.dtype, args.cell) == (512, 25, 1, 2048, "f32", "gru")
+    if default_shape and not args.no_extra_legs:
+        note("bf16-mode leg")
+        r = train_leg(args, dev, rank, world, "bf16", Hh, args.enc_layers, B, T, args.steps, args.warmup)
+        if rank == 0:
+            extra["bf16_mode"] = {"workload": workload_text(args, "bf16", Hh, args.enc_layers, B, T), "value": r["value"], "unit": "seq/s",
+                                  "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "roofline": r["roofline"],
+                                  "kernel_families": r["kernel_families"], "launches_per_step": r["launches_per_step"]}
+        note("config-C leg")
+        cB, cK, cW = 256, max(3, min(args.steps, 6)), 2
+        r = train_leg(args, dev, rank, world, "f32", 1024, 2, cB, 50, cK, cW)
+        if rank == 0:
+            extra["config_c"] = {"workload": workload_text(args, "f32", 1024, 2, cB, 50), "value": r["value"], "unit": "seq/s",
+                                 "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "roofline": r["roofline"],
+                                 "kernel_families": r["kernel_families"], "launches_per_step": r["launches_per_step"]}
+    rccl = None
     if world > 1:
-        losses.set_distributed(cdist.allreduce_sum, world)
-    cfgv = cfg.Bunch(lr=1e-3, clip_grad=5.0, z_regu_loss='mmdrf', lambda_logvar_L1=0.0, lambda_logvar_KL=1e-3,
-                     beta=cfg.Bunch(start=cfg.Bunch(val=1.0, iter=0), end=cfg.Bunch(val=2.0, iter=40000)))
-    trainer = tv.make_optimizer(cfgv, model, reduce_fn, world)
-    g = torch.Generator().manual_seed(1238 + rank)
-    pool = [synth_ids(B, T, V, g).to(dev) for _ in range(8)]
-
-    def step(it):
-        return tv.train_step(cfgv, model, trainer, pool[it % len(pool)], it)
-
-    note("warm-up")
-    for it in range(args.warmup):
-        step(it)
-    torch.cuda.synchronize()
-    cdist.barrier()
-    torch.cuda.synchronize()
-    ops.PROFILE = []
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        out = step(args.warmup + it)
-    t_enqueued = time.perf_counter() - t0   # host time to enqueue the K steps (no host sync inside a step)
-    torch.cuda.synchronize()
-    cdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    loss_val = float(out["L_vae"].item())
-    assert np.isfinite(loss_val), "non-finite loss in the timed region"
+        note("collectives probe")
+        rccl = rccl_probe(dev, head["grad_numel"], backend, world)
+    cls = None
+    if not args.no_class:
+        note("CLaSS leg")
+        cls = class_bench(dev, N=args.class_proposals, cpu=(world == 1 and not args.no_cpu_baseline), rank=rank, world=world)
     if rank != 0:
+        cdist.barrier()
         return
-    note(f"timed region done: {dt / args.steps * 1e3:.3f} ms/step")
-    ms = dt / args.steps * 1e3
-    seq_per_s = B * world * args.steps / dt
-
-    # kernel families of the step, timed with HIP events on their launch streams inside the timed region (cpg.ops._prof);
-    # the roofline object carries the family with the largest share of the step, the others follow in `extra`
-    fams = {}
-    for fam, e0, e1, launches, dims in prof:
-        key = (fam, dims["B"], dims["H"], dims["ndir"], dims["T"])
-        f = fams.setdefault(key, {"ms": 0.0, "launches": 0, "dims": dims, "family": fam})
-        f["ms"] += e0.elapsed_time(e1)
-        f["launches"] += launches
-    rows = []
-    for f in fams.values():
-        avg_us = f["ms"] * 1e3 / max(f["launches"], 1)
-        r = family_roofline(f["family"], f["dims"], avg_us, f["launches"])
-        if r is None:
-            continue
-        r["family"] = f["family"] + ("_pair" if f["dims"]["ndir"] == 2 else "")
-        r["ms_per_step"] = round(f["ms"] / args.steps, 3)
-        r["share_of_step"] = round(f["ms"] / args.steps / ms, 4)
-        rows.append(r)
-    rows.sort(key=lambda r: -r["ms_per_step"])
-    by_kernel = {}
-    for r in rows:   # single-direction and paired launches of one kernel: rank kernels by their summed share
-        by_kernel[r["kernel"]] = by_kernel.get(r["kernel"], 0.0) + r["ms_per_step"]
-    top_kernel = max(by_kernel, key=by_kernel.get) if by_kernel else None
-    roofline = next((r for r in rows if r["kernel"] == top_kernel), {"bound": "mfma", "kernel": None, "achieved": 0.0,
-                                                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": 0.0,
-                                                                     "traffic": None})
-    roofline = dict(roofline)
-    roofline["kernel_ms_per_step_all_launch_shapes"] = round(by_kernel.get(top_kernel, 0.0), 3)
-    gates = 3 if args.cell == "gru" else 4
-    step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
-    extra = {"loss_last_step": round(loss_val, 4), "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3), "executed_step_tflops_per_gpu": round(step_tflops, 2),
-             "executed_step_frac_of_f32_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-             "kernel_families": [r for r in rows if r is not roofline]}
-    ops.check_persistent()
-
-    cfg_tag = ("BASELINE.json configs[1]" if (Hh, T, args.enc_layers, B) == (512, 25, 1, 2048)
-               else "BASELINE.json configs[4] dimensions, GRU cells, 1-layer decoder as in the reference"
-               if (Hh, T, args.enc_layers) == (1024, 50, 2) else "non-default dimensions")
+    note(f"timed region: {head['ms_per_step']:.3f} ms/step")
+    extra.update({k: head[k] for k in ("loss_last_step", "host_enqueue_ms_per_step", "executed_step_tflops_per_gpu",
+                                       "executed_step_frac_of_f32_peak", "launches_per_step")})
+    if "sustained" in head:
+        extra["sustained"] = head["sustained"]
+    extra["kernel_families"] = head["kernel_families"]
     line = {
-        "metric": "peptide-seq/s per WAE training step", "value": round(seq_per_s, 1), "unit": "seq/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "metric": "peptide-seq/s per WAE training step", "value": head["value"], "unit": "seq/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"WAE train step ({cfg_tag}): biGRU encoder h={Hh} {args.enc_layers} layer, z={Z}, GRU decoder "
-                               f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; "
-                               + ("GRU cell = the reference's cell, parity pinned (the reference has no LSTM; --cell lstm runs "
-                                  "the LSTM extension)" if args.cell == "gru" else
-                                  "LSTM cell (extension, torch.nn.LSTM semantics; parity unpinned against the GRU-only reference)")
-                               + (", f32 storage; recurrent products on the MFMA units in f32-grade forms (exact-f32 MFMA, or six bf16 MFMAs on 3-way "
-                                  "split operands)" if args.dtype == "f32" else
-                                  ", bf16 compute mode: recurrent products with bf16-rounded operands, one bf16 MFMA per block, f32 accumulation, "
-                                  "f32 storage and master weights (NOT the parity path: agreement figures in profiles/)"),
+        "config": {"workload": workload_text(args, args.dtype, Hh, args.enc_layers, B, T),
                    "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
-        "roofline": roofline, "extra": extra,
+        "roofline": head["roofline"], "extra": extra,
     }
+    if rccl is not None:
+        line["rccl"] = rccl
     if world == 1 and not args.no_cpu_baseline:
         # ATen's CPU GRU forks/joins its thread pool at every time step: on the box's 256 hardware threads the step got SLOWER
         # than on 8 (minutes per step); 32 threads is about the best these shapes get.  Stated in the output.
         threads = min(32, os.cpu_count() or 1)
         note("cpu baseline (torch-CPU restatement)")
-        cases = cpu_baseline(T, V, threads, args.cpu_budget_s)
+        cases = cpu_baseline(T, 24, threads, args.cpu_budget_s)
         line["cpu_baseline"] = {"value": cases[0]["seq_per_s"], "unit": "seq/s", "cores": threads, "kind": "port",
                                 "sample": f"oracle/torch_ref.py (torch-CPU restatement of train_vae.py's step on ATen CPU kernels: the "
                                           f"backend the reference runs on), torch.set_num_threads({threads}); {cases[0]['case']}: median of "
                                           f"{cases[0]['steps']} steps after 1 warm-up ({cases[0]['s_per_step']} s/step)",
                                 "cases": cases}
-    if world == 1 and not args.no_class:
-        note("CLaSS leg")
-        line["class"] = class_bench(dev, N=args.class_proposals, cpu=not args.no_cpu_baseline)
-    print(json.dumps(line))
+    if cls is not None:
+        line["class"] = cls
+    print(json.dumps(line), flush=True)
+    cdist.barrier()
 
 
 def class_setup(dev, Z=100, K=100, seed=1238):
@@ -342,6 +543,8 @@ def class_cpu_baseline(m, Q, n_score=1000000, n_decode=1024):
     rs = np.random.RandomState(0)
     z = rs.randn(n_score, m.z_dim).astype(np.float32)
     coef, icpt, tgt = (t.cpu().numpy() for t in Q._dev_clf)
+    from threadpoolctl import threadpool_limits
+    limit = threadpool_limits(limits=1)     # "cores": 1 - the oracle is a scalar port; keep numpy's BLAS from threading the LR product
     t0 = time.perf_counter()
     probs, accum, acc = ocs.rejection_mask(z, [(coef[i:i + 1], icpt[i:i + 1], int(tgt[i])) for i in range(len(tgt))], rs.rand(n_score))
     t_score = time.perf_counter() - t0
@@ -350,36 +553,47 @@ def class_cpu_baseline(m, Q, n_score=1000000, n_decode=1024):
     t0 = time.perf_counter()
     hyps, _ = odec.beam(P, z[:n_decode], c, 25, beam_size=5, n_best=3)
     t_dec = time.perf_counter() - t0
+    limit.restore_original_limits()
     steps = sum(len(h[0]) - 1 for h in hyps)
     z_per_s = 1.0 / (t_score / n_score + t_dec / n_decode)     # reference behaviour: every proposal is decoded
-    return {"value": round(z_per_s * float(acc.mean()), 1), "unit": "accepted-samples/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"numpy oracle (oracle/class_sampler.py + oracle/decode.py): LR scoring + accept of {n_score} z ({t_score:.2f} s), "
+    return {"value": round(z_per_s * float(acc.mean()), 1), "unit": "accepted-samples/s", "cores": 1, "kind": "port",
+            "sample": f"single-threaded numpy oracle (oracle/class_sampler.py + oracle/decode.py): LR scoring + accept of {n_score} z ({t_score:.2f} s), "
                       f"beam-5 / n-best-3 decode of {n_decode} z ({t_dec:.1f} s, {5 * steps / t_dec:.0f} decoder row-step evals/s); "
                       f"every proposal decoded, as sample_pipeline.py:129-139 does",
             "z_per_s": round(z_per_s, 1), "decoder_evals_per_s": round(5 * steps / t_dec, 1)}
 
 
-def class_bench(dev, N=1000000, cpu=True):
-    """BASELINE.json configs[3] on one GPU: ONE sampling round of 1 M proposals through sample_pipeline.run_rounds - device
-    GMM draw, LR scoring + accept test, beam-5 / n-best-3 decode (the reference decodes EVERY proposal), residue rows,
-    de-duplication, the final pandas table - wall-clock, plus the accepted-only and greedy variants of the same round."""
+def class_bench(dev, N=1000000, cpu=True, rank=0, world=1):
+    """BASELINE.json configs[3]: ONE sampling round of N proposals IN TOTAL through sample_pipeline.run_rounds - device GMM draw,
+    LR scoring + accept test, beam-5 / n-best-3 decode (the reference decodes EVERY proposal), residue rows, de-duplication,
+    the final pandas table - wall-clock, plus the accepted-only and greedy variants of the same round.  With world > 1 the
+    round's rows are sharded over the ranks (N / world each, counter-based streams: the union is the single-rank round), every
+    rank decodes its rows, the rows are all-gathered over RCCL and de-duplicated identically on every rank: strong scaling."""
     import logging
     import sample_pipeline as sp
+    from cpg import dist as cdist
     from cpg import ops
     logging.getLogger('GenerationAPI').setLevel(logging.WARNING)
     m, Q, ds = class_setup(dev)
+    N = N // (4 * world) * (4 * world)
     EVAL_FLOPS = 2.0 * 3 * 102 * (252 + 102) + 2.0 * 102 * 24    # one decoder row-step (SURVEY 8d: 221.5 kFLOP at config A)
     out = {}
-    sp.run_rounds(m, ds, Q, 65536, 10 ** 9, max_rounds=1, sample_mode='beam')          # warm-up (code load, allocator)
+    sp.run_rounds(m, ds, Q, 65536 // (4 * world) * (4 * world), 10 ** 9, max_rounds=1, sample_mode='beam')   # warm-up (code load, allocator)
     for tag, kw in (("beam5_all", dict(sample_mode='beam')), ("beam5_accepted_only", dict(sample_mode='beam', decode_accepted_only=True)),
                     ("greedy_all", dict(sample_mode='greedy'))):
         torch.cuda.synchronize()
+        cdist.barrier()
         note("CLaSS variant " + tag)
         ops.PROFILE = []
         t0 = time.perf_counter()
         df, st = sp.run_rounds(m, ds, Q, N, 10 ** 9, max_rounds=1, return_stats=True, **kw)
         torch.cuda.synchronize()
+        cdist.barrier()
         dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            cdist.allreduce_max(tmax)
+            dt = float(tmax.item())
         prof, ops.PROFILE = ops.PROFILE, None
         kms = sum(e0.elapsed_time(e1) for _, e0, e1, _, _ in prof)
         launches = sum(l for _, _, _, l, _ in prof)
@@ -388,19 +602,20 @@ def class_bench(dev, N=1000000, cpu=True):
              "proposals_per_s": round(st["proposed"] / dt, 1), "decoder_evals_per_s": round(st["decoder_evals"] / dt, 1),
              "decoder_evals": st["decoder_evals"], "decode_kernel_ms": round(kms, 2)}
         if kms > 0:
-            ach = st["decoder_evals"] * EVAL_FLOPS / (kms * 1e-3) / 1e12
+            ach = st["decoder_evals"] / world * EVAL_FLOPS / (kms * 1e-3) / 1e12     # this rank's kernel time, this rank's share of the evals
             r["roofline"] = {"bound": "mfma", "kernel": _cname("cpg_decode_fused_kernel_name", 1 if kw["sample_mode"] == "beam" else 0, 102, 5),
                              "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                              "traffic": None, "avg_launch_us": round(kms * 1e3 / max(launches, 1), 1), "launches_timed": launches,
                              "flops_per_eval": EVAL_FLOPS, "pipe": "exact f32 MFMA, W_hh fragments in registers, state in LDS (csrc/decode_fused.hip); "
-                             "algorithmic flops = live row-steps x (dense W_ih + W_hh + fc)"}
+                             "algorithmic flops = live row-steps x (dense W_ih + W_hh + fc); per-GPU rate (rank 0's kernels)"}
         out[tag] = r
     head = out["beam5_all"]
-    res = {"workload": f"BASELINE.json configs[3] on 1 GPU: {N} z proposals (synthetic GMM K=100), 2 LR heads, reference defaults "
-                       f"z=100 / decoder h=102 / V=24 / T=25, beam-5 decode of every proposal through sample_pipeline.run_rounds",
-           "metric": "CLaSS accepted-samples/s", "value": head["accepted_per_s"], "unit": "accepted-samples/s",
-           "decoder_evals_per_s": head["decoder_evals_per_s"], "roofline": head.get("roofline"), "variants": out}
-    if cpu:
+    res = {"workload": f"BASELINE.json configs[3] on {world} GPU(s): {N} z proposals in total ({N // world} per GPU; synthetic GMM K=100), 2 LR heads, "
+                       f"reference defaults z=100 / decoder h=102 / V=24 / T=25, c ~ Cat(.5,.5) per proposal, beam-5 decode of every proposal through "
+                       f"sample_pipeline.run_rounds" + ("; rows all-gathered across the ranks and de-duplicated on the gathered set" if world > 1 else ""),
+           "metric": "CLaSS accepted-samples/s", "value": head["accepted_per_s"], "unit": "accepted-samples/s", "n_gpus": world,
+           "scaling": "strong", "decoder_evals_per_s": head["decoder_evals_per_s"], "roofline": head.get("roofline"), "variants": out}
+    if cpu and rank == 0:
         note("CLaSS cpu baseline")
         res["cpu_baseline"] = class_cpu_baseline(m, Q)
     return res

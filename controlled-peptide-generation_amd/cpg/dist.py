@@ -42,6 +42,21 @@ def allreduce_sum(t):
     return t
 
 
+def is_initialized():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_sum_async(t):
+    """Non-blocking SUM all-reduce; the returned Work's .wait() makes the current stream (RCCL) / the host (gloo) wait."""
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def allreduce_max(t):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 def broadcast_params(params, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         for p in params:
@@ -51,6 +66,15 @@ def broadcast_params(params, src=0):
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def allgather_equal(t):
+    """All-gather of equal-sized row blocks -> [world*b, ...] in rank order (global batch of the full-kernel MMD)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t.contiguous())
+    return torch.cat(outs, 0)
 
 
 def allgather_rows(t):

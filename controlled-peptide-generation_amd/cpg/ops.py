@@ -171,11 +171,72 @@ def _rowmajor(t):
 
 
 # ----------------------------------------------------------------------------------------------- dense
+DIRECT_GRAD = False   # only inside backward_scope (FusedAdamClip.backward): see _grad_buf
+DEFER_WGRAD = False   # only inside backward_scope: the decoder's dW_hh product runs on a side stream (GruSeqFn)
+BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
+
+
+class backward_scope:
+    """`with backward_scope(boundary_cb): loss.backward()` - the fused-optimiser form of the backward pass: weight-gradient
+    kernels accumulate straight into the parameters' existing .grad buffers (the Functions then return None for those
+    inputs), the decoder's dW_hh product runs on a side stream, gradient-bucket boundaries fire `boundary_cb(tag)`.  Leaving
+    the scope joins the side stream and restores plain autograd semantics (every Function returns its gradients), so
+    torch.autograd.grad, parameter hooks and any other optimiser see standard behaviour outside it."""
+
+    def __init__(self, boundary_cb=None):
+        self.cb = boundary_cb
+
+    def __enter__(self):
+        global DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB
+        self.prev = (DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB)
+        DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB = True, True, self.cb
+        return self
+
+    def __exit__(self, *exc):
+        global DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB
+        DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB = self.prev
+        join_deferred()
+        return False
+
+
+class GradBoundaryFn(Function):
+    """Identity on its tensor inputs.  Its backward runs once the gradients of ALL of them are complete - i.e. after every
+    backward node downstream of the boundary has been enqueued - and then fires BOUNDARY_CB(tag): the optimiser starts the
+    all-reduce of the gradient bucket that became final there while the rest of the backward pass still runs."""
+
+    @staticmethod
+    def forward(ctx, tag, *ts):
+        ctx.tag = tag
+        return tuple(t.view_as(t) for t in ts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if BOUNDARY_CB is not None:
+            BOUNDARY_CB(ctx.tag)
+        return (None,) + gs
+
+
+def grad_boundary(tag, *ts):
+    """Mark a gradient-bucket boundary on tensors that require grad (no-op on the others and outside training)."""
+    if not torch.is_grad_enabled():
+        return ts if len(ts) > 1 else ts[0]
+    idx = [i for i, t in enumerate(ts) if t is not None and t.requires_grad]
+    if idx:
+        outs = GradBoundaryFn.apply(tag, *[ts[i] for i in idx])
+        ts = list(ts)
+        for i, o in zip(idx, outs):
+            ts[i] = o
+    return tuple(ts) if len(ts) > 1 else ts[0]
+
+
 def _grad_buf(p):
-    """The existing gradient buffer of a LEAF parameter, or None.  autograd would add a returned gradient into it with one
-    elementwise kernel per parameter (AccumulateGrad: ~30 `add` launches per training step here); the weight-gradient
-    kernels accumulate straight into it instead (their `accumulate` flag) and the Function returns None for that input."""
-    if p is None or not p.is_leaf or not p.requires_grad:
+    """The existing gradient buffer of a LEAF parameter, or None.  Inside backward_scope only (FusedAdamClip.backward): autograd
+    would add a returned gradient into .grad with one elementwise kernel per parameter (AccumulateGrad: ~30 `add` launches per
+    training step here); the weight-gradient kernels accumulate straight into it instead (their `accumulate` flag) and the
+    Function returns None for that input.  Never for a parameter with hooks, never outside the scope."""
+    if not DIRECT_GRAD or p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
         return None
     g = p.grad
     if g is None or not g.is_contiguous() or g.dtype != torch.float32 or g.shape != p.shape:
@@ -442,8 +503,7 @@ class GruSeqFn(Function):
         # deferred mode: the 80-GFLOP dW_hh product of this sequence runs on a side stream and is added straight into the
         # parameters' existing .grad buffers, overlapping with the rest of the backward pass (only with FusedAdamClip,
         # which joins before it reads the gradients)
-        ctx.defer = (w_hh, b_hh) if (defer and DEFER_WGRAD and OVERLAP and w_hh.grad is not None and b_hh.grad is not None
-                                     and w_hh.is_leaf and b_hh.is_leaf) else None
+        ctx.defer_req = (w_hh, b_hh) if defer else None
         H = w_hh.shape[1]
         B = tok.shape[1] if tok is not None else (rowc.shape[0] if rowc is not None else dense.shape[1])
         w_hh_c, b_hh_c = w_hh.contiguous(), b_hh.contiguous()
@@ -533,7 +593,9 @@ class GruSeqFn(Function):
         dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
         db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
         db_arg = None if has_tab else _p(db_hh)
-        if ctx.defer is not None:
+        dl = ctx.defer_req
+        defer = dl if (dl is not None and DEFER_WGRAD and OVERLAP and _grad_buf(dl[0]) is not None and _grad_buf(dl[1]) is not None) else None
+        if defer is not None:
             side = side_streams(dev)[2]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -541,8 +603,8 @@ class GruSeqFn(Function):
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                     call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws2), ws2.numel(),
                          _stream())
-                ctx.defer[0].grad.add_(dw_hh)
-                ctx.defer[1].grad.add_(db_hh)
+                defer[0].grad.add_(dw_hh)
+                defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
             # the accumulation into .grad runs on the side stream: make the stream that called backward() wait for it when
             # the backward pass ends, so ANY reader of .grad after loss.backward() (clip_grad_norm_, another optimiser, a
@@ -659,7 +721,6 @@ class GruBiSeqFn(Function):
 
 
 _pending_events = []
-DEFER_WGRAD = False  # set by FusedAdamClip: w_hh/b_hh gradients of flagged sequences are accumulated on a side stream
 
 
 def join_deferred():
@@ -980,6 +1041,21 @@ class MmdRfFn(Function):
         call("cpg_rf_bwd", _p(raw1), _p(rf_b), _p(diff), _p(g), B, R, ctx.sigma, ctx.bg, _p(dpre), _stream())
         dz = linear_raw(dpre, rf_w, None)  # dpre [B,R] @ rf_w^T ([Z,R] rows) -> [B,Z]
         return dz, None, None, None, None, None, None, None
+
+
+class AllGatherRowsFn(Function):
+    """Equal-shard row all-gather with the data-parallel backward: every rank evaluates the same global loss, rank r keeps the
+    gradient rows of its own shard - pre-scaled by world, because the later gradient all-reduce is a SUM / world."""
+
+    @staticmethod
+    def forward(ctx, x, gather_fn, rank, world):
+        ctx.rows, ctx.rank, ctx.world = x.shape[0], int(rank), int(world)
+        return gather_fn(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        r0 = ctx.rank * ctx.rows
+        return g[r0:r0 + ctx.rows] * float(ctx.world), None, None, None
 
 
 MMD_KERNELS = {"gaussian": 0, "laplace": 1, "energy": 2}  # compute_mmd_kernel, losses.py:102-107

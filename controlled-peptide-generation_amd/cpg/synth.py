@@ -26,6 +26,28 @@ def synth_ids(B, T, V=24, generator=None, device="cpu"):
     return ids.to(device)
 
 
+HYDROPHOBIC = "AFILMVWY"
+ATTR_NAMES = ('amp', 'tox', 'sol', 'anticancer', 'antihyper', 'hormone')   # column order of cfg.attributes (cfg.py amp dataset)
+
+
+def synth_labels(ids, generator=None, p_na=0.2):
+    """int64 [N, 6] attribute labels in the reference's convention (1 pos / 0 neg / -1 'na'; column order = cfg.attributes) for
+    synthetic peptides, as DETERMINISTIC functions of the sequence so that the latent classifiers of the CLaSS pipeline have
+    something to learn: amp = net charge (#K + #R - #D - #E) >= 1, tox = hydrophobic fraction (AFILMVWY) >= 0.45.  A random
+    p_na of the amp / tox entries is unlabelled (-1) like most of the reference's corpus; the other four columns are all -1."""
+    ids = ids.cpu()
+    stoi = {a: i + len(SPECIALS) for i, a in enumerate(AMINO)}
+    cnt = lambda letters: sum((ids == stoi[a]).sum(1) for a in letters)
+    n_res = (ids >= len(SPECIALS)).sum(1).clamp(min=1)
+    amp = (cnt("KR") - cnt("DE") >= 1).long()
+    tox = (cnt(HYDROPHOBIC).float() / n_res.float() >= 0.45).long()
+    lab = torch.full((ids.shape[0], len(ATTR_NAMES)), -1, dtype=torch.int64)
+    lab[:, 0], lab[:, 1] = amp, tox
+    na = torch.rand(ids.shape[0], 2, generator=generator) < p_na
+    lab[:, :2][na] = -1
+    return lab
+
+
 class _Vocab:
     def __init__(self):
         self.itos = SPECIALS + AMINO
@@ -48,8 +70,26 @@ class SyntheticPeptideLoader:
         self.TEXT = _Text()
         self.n_vocab = len(self.TEXT.vocab.itos)
         g = torch.Generator().manual_seed(seed)
-        self.pool = synth_ids(size, max_seq_len, self.n_vocab, g).to(device)
+        pool = synth_ids(size, max_seq_len, self.n_vocab, g)
+        self.labels = synth_labels(pool, g)                       # [size, n_attr], reference convention 1 / 0 / -1
+        # split column like the reference's csv (`split=train|val|test`): 80 / 10 / 10 by position
+        self.split = np.array(['train'] * size, dtype=object)
+        self.split[int(0.8 * size):int(0.9 * size)] = 'val'
+        self.split[int(0.9 * size):] = 'test'
+        self.pool = pool.to(device)
         self.gen = torch.Generator().manual_seed(seed + 1000 * (rank + 1))
+
+    def subset(self, split=None, query=None):
+        """(ids, labels) of the pool rows in `split` ('train' | 'val' | 'test' | comma list | None = all) whose labels match
+        `query` {attr: value} - the role of AttributeDataset.get_subset_iterators in the reference (dataset.py), for the encode
+        passes of build_index.py / sample_pipeline.get_encodings_from_dataloader."""
+        sel = np.ones(len(self.split), bool)
+        if split is not None:
+            sel &= np.isin(self.split, [t.strip() for t in split.split(',')])
+        for attr, val in (query or {}).items():
+            sel &= (self.labels[:, ATTR_NAMES.index(attr)] == val).numpy()
+        idx = torch.from_numpy(np.nonzero(sel)[0])
+        return self.pool[idx.to(self.pool.device)], self.labels[idx]
 
     def print_stats(self):
         print('SyntheticPeptideLoader: {} sequences, vocab {}, max_seq_len {}'.format(self.pool.shape[0], self.n_vocab, self.T))

@@ -92,7 +92,10 @@ constexpr int P_WAVES = CPG_PERSIST_WAVES;
 constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
 constexpr int P_NC = 3 * P_CT;    // gate columns per workgroup
-constexpr int P_TBW = 16;         // words per row of the per-wave 16x16 transposition buffer
+#ifndef CPG_PERSIST_TBW
+#define CPG_PERSIST_TBW 16
+#endif
+constexpr int P_TBW = CPG_PERSIST_TBW;  // words per row of the per-wave 16x16 transposition buffer
 // Phase offset between the two waves of a SIMD (waves w and w + P_WAVES/2 own different row tiles = independent chains): the
 // second set starts this many 10-ns ticks late, so that one wave's product phase (exchange loads, MFMAs) runs against the
 // other's epilogue phase (gate / state traffic, cell arithmetic) instead of both doing the same thing at the same time.

@@ -16,6 +16,25 @@ import torch
 from cpg import class_sampler, ops
 
 
+def prior_logpdf(z):
+    """log N(z; 0, I) of one point (reference density_modeling.py:11-14)."""
+    import math
+    return -0.5 * z.shape[0] * math.log(math.tau) - 0.5 * float((z.double() ** 2).sum())
+
+
+def evaluate_nll(q, points):
+    """(NLL under Q, NLL under the prior) per point, each point perturbed by ONE shared normal draw along its posterior
+    standard deviations as the reference does (density_modeling.py:118-128: `torch.randn(1).item()`); host-side diagnostic."""
+    mu, lv = points
+    N = mu.shape[0]
+    llq = llp = 0.0
+    for s in range(N):
+        z = mu[s] + (0.5 * lv[s]).exp() * torch.randn(1).item()
+        llq += q.logpdf(z)
+        llp += prior_logpdf(z)
+    return -llq / N, -llp / N
+
+
 class RejSampleBase:
     rng = 'numpy'
     device = torch.device('cuda')

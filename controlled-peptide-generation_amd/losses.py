@@ -16,13 +16,15 @@ import cfg  # cfg.losses.wae_mmd is read at call time, like the reference (losse
 from cpg import ops
 
 rf = {}
-_dist = {"reduce": None, "world": 1}
+_dist = {"reduce": None, "world": 1, "gather": None, "rank": 0}
 _prior_sampler = {"fn": None}
 
 
-def set_distributed(reduce_fn, world):
-    """reduce_fn(tensor) must SUM-all-reduce in place across ranks (e.g. torch.distributed.all_reduce)."""
-    _dist["reduce"], _dist["world"] = reduce_fn, int(world)
+def set_distributed(reduce_fn, world, gather_fn=None, rank=0):
+    """reduce_fn(tensor) must SUM-all-reduce in place across ranks (e.g. torch.distributed.all_reduce).  gather_fn(tensor
+    [b,D]) -> [world*b, D] (rank order, equal shards) is needed only for the full-kernel MMD AS THE REGULARISER under data
+    parallelism: that term couples every pair of rows of the global batch, so z is all-gathered (mmd_full_kernel_global)."""
+    _dist["reduce"], _dist["world"], _dist["gather"], _dist["rank"] = reduce_fn, int(world), gather_fn, int(rank)
 
 
 def set_prior_sampler(fn):
@@ -66,11 +68,20 @@ def recon_dec(sequences, logits):
     return ops.ReconLossFn.apply(logits, sequences, count)
 
 
-def wae_mmd_gaussianprior(z, method='full_kernel', z_prior=None):
+def wae_mmd_gaussianprior(z, method='full_kernel', z_prior=None, global_batch=False):
+    """global_batch (data parallel, full kernel only): evaluate the term on the all-gathered global batch - exact, at the
+    price of world^2 times the rank-local Gram work - instead of on this rank's shard (what a logged-only value gets)."""
     if z_prior is None:
         z_prior = _randn_like(z)
     cfgm = cfg.losses.wae_mmd
     if method == 'full_kernel':
+        if global_batch and _dist["world"] > 1:
+            if _dist["gather"] is None:
+                raise RuntimeError("full-kernel MMD over the global batch needs losses.set_distributed(..., gather_fn=, rank=)")
+            zg = ops.AllGatherRowsFn.apply(z, _dist["gather"], _dist["rank"], _dist["world"])
+            with torch.no_grad():
+                zpg = _dist["gather"](z_prior.contiguous())
+            return mmd_full_kernel(zg, zpg, sigma=cfgm.sigma, kernel=cfgm.kernel)
         return mmd_full_kernel(z, z_prior, sigma=cfgm.sigma, kernel=cfgm.kernel)
     return mmd_rf(z, z_prior, **cfgm)
 

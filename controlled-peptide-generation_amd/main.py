@@ -76,7 +76,7 @@ def _build_model(n_vocab, device, rank, world):
     cdist.broadcast_params(model.parameters())
     reduce_fn = cdist.allreduce_sum if world > 1 else None
     if reduce_fn is not None:
-        losses.set_distributed(reduce_fn, world)
+        losses.set_distributed(reduce_fn, world, gather_fn=cdist.allgather_equal, rank=rank)
     return model, reduce_fn
 
 
@@ -111,6 +111,14 @@ def run(argv=None):
             with torch.no_grad():
                 samples, _, _ = model.generate_sentences(cfg.evals.sample_size, sample_mode='categorical')
             utils.write_gen_samples(dataset.idx2sentences(samples.cpu(), False), cfg.vae.gen_samples_path)
+            if cfg.hw.dump_states:
+                # the encode pass the reference runs offline (vis/scripts/build_index.py:93-118, "run static_eval first"):
+                # states_<split>_<n_iter> under savepath is what sample_pipeline.py fits Q_xi(z) and the z-space classifiers on
+                from sample_pipeline import dump_encodings
+                for split in ('train', 'val', 'test'):
+                    ids, labels = dataset.subset(split)
+                    fn = dump_encodings(model, ids, labels, split, cfg.savepath, cfg.vae.n_iter)
+                    log.info('encodings of {} {} sequences -> {}'.format(ids.shape[0], split, fn))
     if lead:
         log.info('saving result.json and vae_result.json at {}'.format(cfg.savepath))
         tb_json_logger.export_to_json(os.path.join(cfg.savepath, 'result.json'))

@@ -72,11 +72,15 @@ class GRUDecoder(nn.Module):
     def init_hidden(self, z, c):
         return torch.cat([z, c], dim=1)
 
-    def _tables(self, zc):
+    def _emb_w(self):
+        return ops.ZeroRowGradFn.apply(self.emb.weight, self.emb.padding_idx) if self.emb.padding_idx is not None \
+            else self.emb.weight
+
+    def _tables(self, zc, emb_w=None):
         E = self.emb.weight.shape[1]
         w_ih = self.rnn.weight_ih_l0
-        emb_w = ops.ZeroRowGradFn.apply(self.emb.weight, self.emb.padding_idx) if self.emb.padding_idx is not None \
-            else self.emb.weight
+        if emb_w is None:
+            emb_w = self._emb_w()
         tab = ops.LinearFn.apply(emb_w, w_ih[:, :E], self.rnn.bias_ih_l0)   # [V,3H]
         rowc = ops.LinearFn.apply(zc, w_ih[:, E:], None)                    # [B,3H]
         return tab, rowc
@@ -89,7 +93,10 @@ class GRUDecoder(nn.Module):
         if wd_mask is None:
             wd_mask = self.word_dropout.sample_mask(x)
         tok = ops.tokens_prepare(x, wd_mask)
-        tab, rowc = self._tables(zc)
+        # gradient-bucket boundary: once the gradients of [z;c] and of the embedding rows the decoder reads are complete, every
+        # gradient of the decoder's own parameters has been enqueued (cpg.optim starts their all-reduce there)
+        zc, emb_w = ops.grad_boundary('decoder', zc, self._emb_w())
+        tab, rowc = self._tables(zc, emb_w)
         ragged = self.ragged and self.cell == 'gru' and torch.is_grad_enabled()
         perm = inv = step_rows = None
         if ragged:

@@ -87,6 +87,7 @@ class GRUEncoder(nn.Module):
         if finals is None:
             finals = [slabs[0][T]] + ([slabs[1][0]] if self.biGRU else [])
         h = torch.cat(finals, 1) if len(finals) > 1 else finals[0]
+        h = ops.grad_boundary('encoder_heads', h)   # gradient-bucket boundary: the two heads' gradients are final behind it
         mu = ops.LinearFn.apply(h, self.q_mu.weight, self.q_mu.bias)
         logvar = ops.LinearFn.apply(h, self.q_logvar.weight, self.q_logvar.bias)
         return mu, logvar

@@ -4,8 +4,9 @@ Round structure and stop rule are the reference's: rounds of `n_samples_per_roun
 decode -> drop duplicates within the round and against earlier rounds -> stop once `n_samples_acc` accepted peptides
 exist (:299-322).  Differences, all documented in DESIGN.md:
   * decode mode is selectable ('beam' with beam_size 5 as the reference's decode_from_z :129-139, or 'greedy');
-  * `decode_accepted_only=True` classifies first and decodes only accepted z - per-z independent, so the accepted
-    peptides are identical, but c must then be passed explicitly (the reference draws c per 1024-chunk, SURVEY F10);
+  * `decode_accepted_only=True` classifies first and decodes only accepted z with c fixed to [0,1] (the reference draws
+    c ~ Cat(.5,.5) for every proposal, per 1024-chunk; the default array round draws it per proposal from the
+    round's counter stream and reports it as column `c`);
   * encodings come from `states_<split>_<iter>.npz` (same field names as the reference's h5: src, z, mu, logvar, label,
     split) or are computed on the fly; modlamp descriptors (H, uH, charge) need modlamp, which is not installed: columns
     are filled when it is importable, skipped otherwise;
@@ -141,15 +142,65 @@ def dump_encodings(model, ids, labels, split, savepath, n_iter, batch=4096, fmt=
     return fn
 
 
-def build_clfZ(zpos_mu, zneg_mu):
-    """Logistic regression between attr=1 and attr=0 encodings (reference :169-192); host-side, one-off."""
+def get_encodings_from_dataloader(query, split, model, dataloader, batch=4096):
+    """mu, logvar of the loader's sequences in `split` matching `query`, encoded now (reference :45-70: the same
+    `model(batch.text, q_c='classifier', sample_z='max')` pass, no states file needed)."""
+    ids, _ = dataloader.subset(split, query)
+    LOG.info('Start encoding {} samples from dataset'.format(ids.shape[0]))
+    mus, lvs = [], []
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            for chunk in torch.split(ids, batch):
+                (mu, lv), _, _ = model(chunk.to(model.device), q_c='classifier', sample_z='max')
+                mus.append(mu.double().cpu()), lvs.append(lv.double().cpu())
+    finally:
+        model.train(was_training)
+    return torch.cat(mus, 0), torch.cat(lvs, 0)
+
+
+def get_encodings(query, split, model=None, dataloader=None):
+    if model is not None and dataloader is not None:
+        return get_encodings_from_dataloader(query, split, model, dataloader)
+    return get_encodings_from_states(query, split)
+
+
+def fitQ_and_test(QClass, QKwargs, Q_select={}, negative_select={}, model=None, dataloader=None, n_eval=256):
+    """Fit Q_xi^a(z) on the encodings selected by `Q_select` and report its cross-entropy on training and held-out encodings next
+    to the prior's (reference :95-126).  The NLL estimate walks over at most n_eval points per set (the reference walks over all
+    of them in python; the figure is a diagnostic)."""
+    from collections import OrderedDict
+    from density_modeling import evaluate_nll
+    if model is not None and dataloader is not None:
+        mu, logvar = get_encodings_from_dataloader(Q_select, 'train,val', model, dataloader)
+    else:
+        mu, logvar = get_encodings_from_states(query=Q_select, split='train')
+    Q = QClass(mu, logvar, **QKwargs)
+    LOG.info('Fitted {}  {} on selection {}'.format(QClass.__name__, str(QKwargs), str(Q_select)))
+    metrics = OrderedDict()
+    for name, split in (('a,tr', 'train'), ('a,hld', 'test')):
+        pts = get_encodings(Q_select, split, model, dataloader)
+        if pts[0].shape[0]:
+            metrics[name] = evaluate_nll(Q, (pts[0][:n_eval], pts[1][:n_eval]))
+    return Q, metrics
+
+
+def build_clfZ(attr, zneg_mu=None, model=None, dataloader=None):
+    """Logistic regression between attr=1 and attr=0 encodings of the training split (reference :169-192: labels -1 / 0 / 1 =
+    na / neg / pos); host-side, one-off.  build_clfZ(zpos_mu, zneg_mu) with two tensors fits on given encodings."""
     from sklearn.linear_model import LogisticRegression
+    if isinstance(attr, str):
+        zpos_mu = get_encodings({attr: 1}, 'train', model, dataloader)[0]
+        zneg_mu = get_encodings({attr: 0}, 'train', model, dataloader)[0]
+    else:
+        zpos_mu, attr = attr, '<given encodings>'
     X = torch.cat([zpos_mu, zneg_mu], 0).numpy()
     Y = np.concatenate([np.ones(zpos_mu.shape[0]), np.zeros(zneg_mu.shape[0])])
     clf = LogisticRegression(solver='lbfgs', max_iter=200)
     clf.fit(X, Y)
-    LOG.info('Fitted LogReg classifier in z-space: {} pos, {} neg. train accuracy={:.5f}'.format(
-        zpos_mu.shape[0], zneg_mu.shape[0], clf.score(X, Y)))
+    LOG.info('Fitted LogReg classifier in z-space, on attr={}.'.format(attr))
+    LOG.info('num samples: {} pos, {} neg. train accuracy={:.5f}'.format(zpos_mu.shape[0], zneg_mu.shape[0], clf.score(X, Y)))
     return clf
 
 
@@ -258,10 +309,22 @@ def sample_round_arrays(model, dataset, Q, n_samples, sample_mode='beam', decode
         ids, evals = torch.full((0, T + 1), -1, dtype=torch.int16, device=z.device), 0
     else:
         c = torch.zeros(z.shape[0], 2, device=z.device)
-        c[:, 1] = 1.0
+        if decode_accepted_only:
+            c[:, 1] = 1.0      # documented difference: the accepted-only form fixes c = [0,1] (module docstring)
+        else:
+            # decode_from_z -> generate_sentences(z) with c=None: c ~ Cat(.5,.5) per proposal (reference models/model.py:121-126,
+            # 208-209; it draws per 1024-chunk with numpy).  One Bernoulli per ROW of the round's counter stream, so a rank's
+            # shard carries exactly the c's those rows have in the single-rank round.
+            rank, world = shard
+            row0 = rank * (n_samples // world) if world > 1 else 0
+            seed, off = Q._next_philox(n_samples)
+            from cpg import ops
+            bit = ops.rng_bernoulli((z.shape[0],), 0.5, seed, off + row0 // 4, z.device).long()
+            c.scatter_(1, bit.unsqueeze(1), 1.0)
         ids, evals = decode_ids_from_z(z, c, model, sample_mode)
     letters, n_res = residue_rows(ids, dataset.n_vocab)
     frame = {'letters': letters, 'n_res': n_res, 'z': z, 'accept_z': acc.to(torch.bool), names[0]: accum}
+    frame['c'] = c.argmax(1).to(torch.uint8) if z.shape[0] else torch.zeros(0, dtype=torch.uint8, device=z.device)
     for i, nm in enumerate(names[1:]):
         frame[nm] = probs[i]
     return frame, dict(proposed=n_prop, decoded=int(z.shape[0]), decoder_evals=evals)
@@ -403,73 +466,101 @@ def run_rounds(model, dataset, Q, n_samples_per_round, n_samples_acc, max_rounds
     return (samples, stats) if return_stats else samples
 
 
+def _write_table(table, stem):
+    table.drop(columns='z').to_csv(stem + '.csv', index_label='idx')
+    table.to_pickle(stem + '.pkl')
+
+
 def save_samples(samples, basedir, fn_prefix):
-    out = os.path.join(basedir, fn_prefix) + '_{}'.format(datetime.datetime.now().isoformat().split('T')[0])
+    """The reference's output set (:149-160): <prefix>_<date>.plain.txt / .csv / .pkl with every kept sample, and
+    <prefix>_<date>.accepted.<n>.csv / .pkl with the accepted ones (csv without the z column)."""
+    stem = '{}_{}'.format(os.path.join(basedir, fn_prefix), datetime.date.today().isoformat())
     os.makedirs(basedir, exist_ok=True)
-    with open(out + '.plain.txt', 'w') as fh:
+    with open(stem + '.plain.txt', 'w') as fh:
         fh.write(samples['peptide'].to_string(index=False))
-    samples.drop(columns='z').to_csv(out + '.csv', index_label='idx')
-    samples.to_pickle(out + '.pkl')
-    acc = samples[samples.accept.astype(bool)]
-    acc.drop(columns='z').to_csv('{}.accepted.{}.csv'.format(out, len(acc)), index_label='idx')
-    acc.to_pickle('{}.accepted.{}.pkl'.format(out, len(acc)))
-    LOG.info('Sample lists written to {}.*'.format(out))
+    _write_table(samples, stem)
+    LOG.info('Full sample list written to {}.pkl/csv'.format(stem))
+    accepted = samples[samples['accept'].astype(bool)]
+    acc_stem = '{}.accepted.{}'.format(stem, len(accepted))
+    _write_table(accepted, acc_stem)
+    LOG.info('Accepted sample list written to {}.pkl/csv'.format(acc_stem))
+    return stem
 
 
 def main(args):
+    """Reference main :236-324: load the trained model + vocabulary of the run (api.get_model_and_vocab_path /
+    load_trained_model - a missing or mismatched checkpoint is an error), fit Q_xi^a(z) and the amp / tox z-space classifiers
+    on the dumped states (main.py --phase 1 writes them) or straight from the loader (--Q_from_full_dataloader 1), sample in
+    rounds until n_samples_acc accepted peptides exist, write the sample lists."""
+    import json
+    from api import Vocab, get_model_and_vocab_path, get_result_for_model, load_trained_model
     from cpg import dist as cdist
+    from cpg import ops
     from cpg.synth import SyntheticPeptideLoader
-    from models.model import RNN_VAE
     world, rank, local = cdist.init()   # one process per GPU (torch.distributed.run); world 1 = plain run
     torch.cuda.set_device(cdist.local_device(local))
     device = torch.device('cuda', cdist.local_device(local))
+    model_path, vocab_path, _ = get_model_and_vocab_path()
+    LOG.info('Load model, vocab, dataloader.')
+    vocab = Vocab(vocab_path)
+    model = load_trained_model(model_path, vocab.size(), device=device)
+    LOG.info('Loaded model succesfully.')
     torch.manual_seed(cfg.seed)
     np.random.seed(cfg.seed)
     dataset = SyntheticPeptideLoader(cfg.vae.batch_size, cfg.max_seq_len, device, size=cfg.hw.synthetic_size, seed=cfg.seed)
-    model = RNN_VAE(n_vocab=dataset.n_vocab, max_seq_len=cfg.max_seq_len, **cfg.model).to(device)
-    model.device = device
-    ckpt = cfg.vae.chkpt_path.format(cfg.vae.n_iter)
-    # the reference fails hard on a missing / mismatched checkpoint (api.py:91-94 torch.load): sampling from a randomly
-    # initialised decoder would silently write garbage "accepted" peptides
-    if not os.path.exists(ckpt):
-        raise FileNotFoundError('trained model checkpoint {} not found (run main.py --phase 1 first)'.format(ckpt))
-    from api import load_state_dict_checked
-    load_state_dict_checked(model, torch.load(ckpt, map_location=device))
-    LOG.info('Loaded model from ' + ckpt)
-    model.eval()
-    for k in Q_KWARGS:
+    assert dataset.n_vocab == vocab.size(), 'vocab.dict of the run does not match the loader'
+    LOG.info('Model metrics: {}'.format(get_result_for_model(model_path, print_results=False)))
+    LOG.info('Fit attribute-conditioned marginal posterior Q_xi^a(z)')
+    qkw = dict(Q_KWARGS)
+    for k in qkw:
         if hasattr(args, 'Q_' + k):
-            Q_KWARGS[k] = getattr(args, 'Q_' + k)
-    query = {'amp': 1} if args.Q_select_amppos else {}
-    mu, logvar = get_encodings_from_states(query=query, split='train')
-    Q = Q_CLASS(mu, logvar, **Q_KWARGS)
-    z_clfs = {a: build_clfZ(get_encodings_from_states({a: 1}, 'train')[0], get_encodings_from_states({a: 0}, 'train')[0])
-              for a in ['amp', 'tox']}
+            qkw[k] = getattr(args, 'Q_' + k)
+    select, negative = ({'amp': 1}, {'amp': 0}) if getattr(args, 'Q_select_amppos', 0) else ({}, {})
+    live = bool(getattr(args, 'Q_from_full_dataloader', 0))
+    Q, q_metrics = fitQ_and_test(Q_CLASS, qkw, select, negative, model if live else None, dataset if live else None)
+    Q.device = device
+    Q._upload()
+    LOG.info('Q Fit metrics: ')
+    print(json.dumps(q_metrics, indent=4))
+    z_clfs = {attr: build_clfZ(attr, model=model if live else None, dataloader=dataset if live else None) for attr in ['amp', 'tox']}
     Q.init_attr_classifiers(z_clfs, clf_targets={'amp': 1, 'tox': 0})
-    if world > 1 or args.device_rng:
+    if world > 1 or getattr(args, 'device_rng', False):
         Q.rng = 'device'   # counter-based streams: rounds shard by rows across the ranks
-    samples = run_rounds(model, dataset, Q, args.n_samples_per_round, args.n_samples_acc, sample_mode=args.sample_mode,
-                         decode_accepted_only=args.decode_accepted_only)
+    samples = run_rounds(model, dataset, Q, args.n_samples_per_round, args.n_samples_acc, sample_mode=getattr(args, 'sample_mode', 'beam'),
+                         decode_accepted_only=getattr(args, 'decode_accepted_only', False))
+    ops.check_persistent()
     if rank == 0:
         save_samples(samples, cfg.savepath, args.samples_outfn_prefix)
+    return samples
 
 
-if __name__ == "__main__":
+def build_parser():
     parser = argparse.ArgumentParser(argument_default=argparse.SUPPRESS, description='Override config float & string values')
     cfg._cfg_import_export(parser, cfg, mode='fill_parser')
     parser.add_argument('--QClass', default='mogQ')
     parser.add_argument('--Q_n_components', type=int, default=100)
     parser.add_argument('--Q_covariance_type', default='diag')
+    parser.add_argument('--Q_select_amppos', type=int, default=0)
+    parser.add_argument('--Q_from_full_dataloader', type=int, default=0)
     parser.add_argument('--n_samples_per_round', type=int, default=5000)
     parser.add_argument('--n_samples_acc', type=int, default=100)
     parser.add_argument('--samples_outfn_prefix', default='samples')
-    parser.add_argument('--Q_select_amppos', type=int, default=0)
     parser.add_argument('--sample_mode', default='beam')
     parser.add_argument('--decode_accepted_only', action='store_true', default=False)
     parser.add_argument('--device_rng', action='store_true', default=False,
                         help="draw proposals with the on-device counter streams (always on with more than one rank)")
-    a = parser.parse_args()
+    return parser
+
+
+def run(argv=None):
+    """`python sample_pipeline.py [--<cfg.key> value] [--Q_* ...]`: parse, apply the cfg overrides like main.py, sample."""
+    a = build_parser().parse_args(argv)
     cfg._override_config(a, cfg)
     cfg._update_cfg()
     cfg._print(cfg)
-    main(a)
+    return main(a)
+
+
+if __name__ == "__main__":
+    LOG.info("Sample pipeline. Fit Q_xi(z), Sample from it, score samples.")
+    run()

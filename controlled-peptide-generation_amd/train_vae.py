@@ -20,17 +20,22 @@ from models.mutils import save_model
 from tb_json_logger import log_value
 
 
-def make_optimizer(cfgv, model, reduce_fn=None, world=1):
-    return FusedAdamClip(model.vae_params(), lr=cfgv.lr, max_norm=cfgv.clip_grad, reduce_fn=reduce_fn, world=world)
+def make_optimizer(cfgv, model, reduce_fn=None, world=1, async_reduce_fn=None):
+    """Gradient buckets in the order the backward pass completes them (models.model marks the boundaries): the decoder's own
+    parameters, then the encoder heads; the shared embedding and the encoder recurrence are final only at the very end."""
+    emb = model.word_emb.weight
+    buckets = [('decoder', [p for p in model.decoder.parameters() if p is not emb]),
+               ('encoder_heads', list(model.encoder.q_mu.parameters()) + list(model.encoder.q_logvar.parameters()))]
+    if async_reduce_fn is None and world > 1:
+        from cpg import dist as cdist
+        async_reduce_fn = cdist.allreduce_sum_async if cdist.is_initialized() else None
+    return FusedAdamClip(model.vae_params(), lr=cfgv.lr, max_norm=cfgv.clip_grad, reduce_fn=reduce_fn, world=world, buckets=buckets,
+                         async_reduce_fn=async_reduce_fn)
 
 
 def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
     """One full iteration.  Returns a dict of device scalars (no host sync)."""
     beta = utils.anneal(cfgv.beta, it)
-    if cfgv.z_regu_loss == 'mmd' and trainer.world > 1:
-        # the full-kernel MMD couples every pair of rows of the GLOBAL batch; ranks only hold their shard, so its gradient
-        # would not equal the single-device one (the logged-only value under 'mmdrf' / 'kl' stays rank-local, SURVEY 8e)
-        raise NotImplementedError("z_regu_loss='mmd' is not data-parallel exact; use 'mmdrf' (the default) with world > 1")
     # the trainer consumes the logits only through recon_dec (pad targets ignored): the decoder may skip dead rows
     ragged_before = model.decoder.ragged
     model.decoder.ragged = bool(cfg.hw.ragged_decoder)
@@ -40,7 +45,10 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
         model.decoder.ragged = ragged_before
     recon_loss = losses.recon_dec(text, dec_logits)
     kl_loss, z_logvar_KL_penalty, z_logvar_L1 = losses.latent_terms(z_mu, z_logvar)
-    wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0])
+    # the full-kernel MMD couples every pair of rows of the GLOBAL batch: as the regulariser it is evaluated on the all-gathered
+    # batch (exact under data parallelism); as a logged-only value it stays rank-local
+    wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0],
+                                                global_batch=(cfgv.z_regu_loss == 'mmd' and trainer.world > 1))
     wae_mmdrf_loss = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=z_priors[1])
     z_regu_loss = {'kl': kl_loss, 'mmd': wae_mmd_loss, 'mmdrf': wae_mmdrf_loss}[cfgv.z_regu_loss]
     # loss = recon + beta * regu + lambda_L1 * L1 + lambda_KL * KLpenalty (train_vae.py:35-37), one launch
@@ -48,7 +56,7 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
     loss = WeightedSumFn.apply((1.0, beta, cfgv.lambda_logvar_L1, cfgv.lambda_logvar_KL), recon_loss, z_regu_loss, z_logvar_L1,
                                z_logvar_KL_penalty)
     trainer.zero_grad()
-    loss.backward()
+    trainer.backward(loss)
     trainer.step()
     return dict(z_mu=z_mu, z_logvar=z_logvar, z_logvar_L1=z_logvar_L1, z_logvar_KL_penalty=z_logvar_KL_penalty, L_vae=loss,
                 L_vae_recon=recon_loss, L_vae_kl=kl_loss, L_wae_mmd=wae_mmd_loss, L_wae_mmdrf=wae_mmdrf_loss, beta=beta)

@@ -161,3 +161,18 @@ def test_class_rounds_sharded_equal_single_rank():
     pep, acc, _, st = one
     assert len(set(pep)) == len(pep) and sum(acc) >= 40
     assert st['rounds'] == two[0][3]['rounds'] and st['kept'] == len(pep)
+
+
+def test_bench_self_spawns_ranks_without_world_size():
+    """`python bench.py --gpus 2` started WITHOUT torch.distributed.run (the form the driver uses for N=1) re-executes itself as
+    two ranks; --dist-selftest keeps the run on the CPU (gloo) and returns the `rccl` object of the collectives probe."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["rccl"]["allreduce_ms"] > 0 and line["rccl"]["allgather_ms"] > 0

@@ -115,8 +115,10 @@ def test_array_round_vs_oracle_and_sharding(golden, mode):
     frame = {k: v.cpu().numpy() for k, v in frame.items()}
     assert st['proposed'] == n and st['decoded'] == n and st['decoder_evals'] > 0
     z = frame['z']
+    # c ~ Cat(.5,.5) per proposal as in generate_sentences(z, c=None) (reference models/model.py:121-126): both classes drawn
+    assert 0.3 < frame['c'].mean() < 0.7
     c = np.zeros((n, 2), np.float32)
-    c[:, 1] = 1
+    c[np.arange(n), frame['c']] = 1
     if mode == "greedy":
         ids = odec.greedy(P, z, c, 25)
         assert st['decoder_evals'] <= n * 25
@@ -223,6 +225,65 @@ def test_main_tiny_phase1_plumbing(tmp_path, monkeypatch):
     tb_json_logger.reset()
     losses.rf.clear()
     losses.set_prior_sampler(None)
+
+
+def test_cli_chain_main_then_sample_pipeline(tmp_path, monkeypatch):
+    """The reference's two-command workflow end to end on the device: `main.py --tiny 1 --phase 1` (training + the encode pass
+    that writes states_<split>_<n_iter>, vis/scripts/build_index.py:93-118) and then `sample_pipeline.py` on that run directory
+    (reference :236-324): checkpoint + vocab.dict found through api.get_model_and_vocab_path, Q_xi(z) fitted on the dumped
+    train encodings, amp / tox z-space classifiers fitted on the dumped labels (build_clfZ :169-192), rounds until n_samples_acc
+    accepted peptides, the five output files of save_samples (:149-160)."""
+    import glob
+    import importlib
+    import pandas as pd
+    import cfg
+    importlib.reload(cfg)
+    import tb_json_logger
+    tb_json_logger.reset()
+    import losses
+    losses.rf.clear()
+    monkeypatch.chdir(tmp_path)
+    import main
+    import sample_pipeline as sp
+    common = ['--tiny', '1', '--phase', '1', '--runname', 'chain', '--hw.synthetic_size', '2048']
+    try:
+        main.run(common)
+        d = tmp_path / 'output' / 'chain'
+        for split, n in (('train', 1638), ('val', 205), ('test', 205)):
+            fn = sp._states_path(split, str(d), 100)
+            assert os.path.exists(fn), fn
+            mu, lv = sp.get_encodings_from_states({}, split, savepath=str(d), n_iter=100)
+            assert mu.shape == (n, cfg.model.z_dim) and torch.isfinite(mu).all() and torch.isfinite(lv).all()
+        pos, _ = sp.get_encodings_from_states({'amp': 1}, 'train', savepath=str(d), n_iter=100)
+        neg, _ = sp.get_encodings_from_states({'amp': 0}, 'train', savepath=str(d), n_iter=100)
+        assert pos.shape[0] > 100 and neg.shape[0] > 100                      # the loader carries attribute labels
+        importlib.reload(cfg)
+        samples = sp.run(common + ['--Q_n_components', '8', '--n_samples_per_round', '512', '--n_samples_acc', '20',
+                                   '--samples_outfn_prefix', 'smp'])
+        assert samples['accept'].sum() >= 20 and not samples['peptide'].duplicated().any()
+        stem = glob.glob(str(d / 'smp_*.plain.txt'))
+        assert len(stem) == 1
+        stem = stem[0][:-len('.plain.txt')]
+        full = pd.read_csv(stem + '.csv')
+        assert len(full) == len(samples) and 'z' not in full.columns and {'peptide', 'accept_z', 'accept', 'clfZ_prob_accum',
+                                                                         'clfZ_amp=1', 'clfZ_tox=0'} <= set(full.columns)
+        acc_csv = glob.glob(stem + '.accepted.*.csv')
+        assert len(acc_csv) == 1
+        n_acc = int(acc_csv[0].split('.accepted.')[1].split('.')[0])
+        assert n_acc == int(samples['accept'].sum()) >= 20 and len(pd.read_csv(acc_csv[0])) == n_acc
+        acc_pkl = pd.read_pickle('{}.accepted.{}.pkl'.format(stem, n_acc))
+        assert len(acc_pkl) == n_acc and len(acc_pkl['z'].iloc[0]) == cfg.model.z_dim and os.path.exists(stem + '.pkl')
+        assert len(open(stem + '.plain.txt').read().strip().split('\n')) == len(samples)
+        # the live-encoding variant (reference --Q_from_full_dataloader) needs no states files
+        importlib.reload(cfg)
+        s2 = sp.run(common + ['--Q_n_components', '4', '--n_samples_per_round', '256', '--n_samples_acc', '5',
+                              '--samples_outfn_prefix', 'live', '--Q_from_full_dataloader', '1', '--Q_select_amppos', '1'])
+        assert s2['accept'].sum() >= 5
+    finally:
+        importlib.reload(cfg)
+        tb_json_logger.reset()
+        losses.rf.clear()
+        losses.set_prior_sampler(None)
 
 
 def test_full_size_properties():
