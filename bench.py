@@ -80,8 +80,6 @@ def family_roofline(family, dims, avg_us, launches):
     bf16 = L.cpg_get_compute_mode() == 1
     if family == "fwd_persist":
         kernel, split, flops = "gru_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 3 * H
-    elif family == "bwd_persist":
-        kernel, split, flops = "gru_seq_bwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * 3 * H * H
     elif family == "fwd_step":
         kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0)
         flops = nd * 2.0 * B * H * 3 * H
@@ -91,10 +89,6 @@ def family_roofline(family, dims, avg_us, launches):
     elif family == "wgrad_hh":
         kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), 2.0 * 3 * H * H * T * B
         split = 2 if kernel.endswith(", 1>") else 1
-    elif family == "bwd_chain":   # one launch for the whole recurrence (CPG_GRU_BWD_CHAIN=1); flops per step of the chain
-        tc = "TileCfg<64, 32, 32, 4, 1, 1, 256>, true, 1" if bf16 else "TileCfg<32, 32, 32, 2, 2, 1, 256>, false, 7"
-        kernel, split = "gru_seq_bwd_chain_kernel<%s>" % tc, (2 if bf16 else 0)
-        flops = dims.get("steps", T) * nd * 2.0 * B * 3 * H * H
     elif family == "lstm_fwd_persist":
         kernel, split, flops = "lstm_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 4 * H
     elif family in ("lstm_fwd_step", "lstm_bwd_step"):   # LSTM extension: four gates
@@ -204,8 +198,7 @@ def maybe_self_spawn(args):
     if args.dist_selftest or ngpu < args.gpus:
         env["CPG_DIST_BACKEND"] = "gloo"
     if 0 < ngpu < args.gpus:
-        env["CPG_SHARED_DEVICE"] = "1"   # persistent kernels need every CU of the device to themselves: off when ranks share it
-        env["CPG_GRU_PERSIST"] = env["CPG_LSTM_PERSIST"] = "0"
+        env["CPG_SHARED_DEVICE"] = "1"   # persistent kernels need every CU of the device to themselves: cpg.ops switches them off
     cmd = spawn_command(args.gpus, sys.argv[1:], _free_port())
     note("self-spawn: " + " ".join(cmd[1:8]) + " ...")
     sys.exit(subprocess.call(cmd, env=env))

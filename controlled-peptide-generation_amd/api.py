@@ -78,6 +78,8 @@ def encode_sequence(model, vocab, sequence, sample_q='max'):
     """One (string) sequence -> z: the posterior mean ('max') or sample_q draws from the posterior, [sample_q, z_dim]."""
     with torch.no_grad():
         mu, logvar = model.forward_encoder(vocab.to_ix(sequence).to(model.device))
+        from cpg import ops
+        ops.check_persistent()   # interactive call: a host sync is fine, a silently wrong encoding is not
         if sample_q == 'max':
             return mu
         return torch.cat([model.sample_z(mu, logvar) for _ in range(sample_q)], dim=0)

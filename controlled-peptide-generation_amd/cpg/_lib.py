@@ -51,6 +51,12 @@ def parse_header(path=HEADER):
     return out
 
 
+def abi_version():
+    """CPG_ABI_VERSION of csrc/cpg_internal.h: what cpg_version() of a library built from these sources returns."""
+    m = re.search(r"#define\s+CPG_ABI_VERSION\s+(\d+)", open(os.path.join(CSRC, "cpg_internal.h")).read())
+    return int(m.group(1))
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP source for gfx950 into the in-tree libcpg_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
@@ -94,6 +100,11 @@ class _Lib:
             fn.restype = ret
             fn.argtypes = [a for a, _ in args]
         self.dll.cpg_last_error.restype = ctypes.c_char_p
+        want = abi_version()
+        got = self.dll.cpg_version()
+        if got != want:   # a stale build (or a CPG_LIB_PATH diagnostic library of another revision): its signatures may differ
+            raise LibraryMissing(f"{LIB_PATH} reports ABI version {got}, the sources declare {want}: rebuild it "
+                                 "(`python __graft_entry__.py build`)")
 
     def last_error(self):
         return (self.dll.cpg_last_error() or b"").decode()

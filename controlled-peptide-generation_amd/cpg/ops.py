@@ -52,6 +52,37 @@ def get_compute_mode():
     return 'bf16' if query("cpg_get_compute_mode") == 1 else 'f32'
 
 
+def set_option(name, value=None):
+    """Launch-policy option of the library (KNOBS.md): cpg_set_option.  value None / '' = back to the built-in policy."""
+    call("cpg_set_option", name.encode(), None if value is None else str(value).encode())
+
+
+def get_option(name):
+    buf = ctypes.create_string_buffer(32)
+    rc = query("cpg_get_option", name.encode(), buf, 32)
+    if rc < 0:
+        raise CpgError("unknown option " + name)
+    return buf.value.decode() if rc == 1 else None
+
+
+class options:
+    """`with options(gru_bwd_tile='64x32', tn_split=4): ...` - set for the block, restored afterwards (tests, A/B timing)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.prev = {k: get_option(k) for k in self.kv}
+        for k, v in self.kv.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
+
+
 _ws_cache = {}
 PROFILE = None  # set to a list by bench.py to collect (family, start_event, end_event, launches, dims) records
 
@@ -108,29 +139,6 @@ def _alloc_guard(*tensors):
         for t in tensors:
             if t is not None:
                 t.record_stream(main)
-
-
-def row_groups(B):
-    """Split the batch rows of one recurrent sequence into independent launch chains (one per side stream).  Rows are
-    independent recurrences, so the chains need no synchronisation with each other; running them on separate streams lets
-    one group's matrix phase overlap another group's load/epilogue phases instead of the whole batch moving in lockstep."""
-    g = int(_os.environ.get("CPG_ROW_GROUPS", "0"))
-    if g <= 0:
-        g = 1  # measured on MI355X at B=2048,H=512: 2 groups 13.78 ms/step vs 13.62 with one chain (no gain) -> off
-    g = max(1, min(g, 2, B // 64 if B >= 64 else 1))
-    step = -(-B // g)
-    step = -(-step // 64) * 64
-    return [(r, min(B, r + step)) for r in range(0, B, step)]
-
-
-def bwd_row_groups(B):
-    """Row groups of a BACKWARD recurrence (CPG_BWD_ROW_GROUPS, default 1): independent launch chains on side streams whose
-    fixed phases (launch ramp, epilogue traffic) can sit under the other chain's matrix phase."""
-    g = int(_os.environ.get("CPG_BWD_ROW_GROUPS", "0"))
-    if g <= 1 or B < 128:
-        return [(0, B)]
-    step = -(-(-(-B // 2)) // 64) * 64
-    return [(r, min(B, r + step)) for r in range(0, B, step)]
 
 
 class fork:
@@ -386,106 +394,69 @@ def transpose01_u8(x):
 
 
 # ----------------------------------------------------------------------------------------------- GRU
-_persist_scratch = {}
+_persist_scratch = {}   # (kind, device, stream, B, H) -> [scratch tensor, T it was sized for, pinned error word, copy event]
+import os as _os2
+SHARED_DEVICE = bool(_os2.environ.get("CPG_SHARED_DEVICE"))   # ranks share this GPU: persistent kernels cannot own every CU
 
 
 def persistent_fits(B, H):
-    """Whole-sequence persistent kernels (csrc/gru_persist.hip) cover this shape on this device."""
-    return bool(query("cpg_gru_persistent_fits", int(B), int(H)))
-
-
-def _persist_sync_scratch(T, B, H, dev):
-    nb = query("cpg_gru_persistent_scratch_bytes", T, B, H)
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, H, T)
-    sc = _persist_scratch.get(key)
-    if sc is None:
-        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word
-    return sc
-
-
-def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, gates):
-    sc = _persist_sync_scratch(T, B, H, hs.device)
-    call("cpg_gru_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
-         _p(hs), _p(gates), _p(sc), _stream())
-
-
-def persistent_bwd_fits(T, B, H):
-    return bool(query("cpg_gru_persistent_bwd_fits", int(T), int(B), int(H)))
-
-
-def gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dG, dh0):
-    dev = hs.device
-    nb = query("cpg_gru_persistent_bwd_scratch_bytes", T, B, H)
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, H, -T)
-    sc = _persist_scratch.get(key)
-    if sc is None:
-        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)
-    call("cpg_gru_seq_bwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), _p(dh_last), _p(dG),
-         _p(dh0), _p(sc), _stream())
-
-
-def chain_bwd_fits(T, B, H):
-    """Launch policy of the one-launch BPTT (csrc/gru.hip, cpg_gru_*_bwd_chain): off unless CPG_GRU_BWD_CHAIN=1."""
-    return bool(query("cpg_gru_chain_bwd_fits", int(T), int(B), int(H)))
-
-
-def chain_bwd_covers(T, B, H):
-    """The one-launch BPTT covers this shape on this device (every workgroup co-resident)."""
-    return bool(query("cpg_gru_chain_bwd_covers", int(T), int(B), int(H)))
-
-
-def _chain_scratch(B, dev):
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, "chain", 0)
-    sc = _persist_scratch.get(key)
-    if sc is None:
-        nb = query("cpg_gru_chain_scratch_bytes", B)
-        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word
-    return sc
-
-
-def gru_seq_bwd_chain(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dG, dh0, wT=None):
-    call("cpg_gru_seq_bwd_chain", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), _p(dh_last), _p(dG), _p(dh0),
-         _p(wT), _p(_chain_scratch(B, hs.device)), _stream())
-
-
-def gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT=None, last_f=None, last_r=None):
-    call("cpg_gru_biseq_bwd_chain", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-         _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(wT[0] if wT is not None else None), _p(wT[1] if wT is not None else None),
-         _p(_chain_scratch(B, hs_f.device)), _stream())
+    """The whole-sequence persistent forward kernel (csrc/gru_persist.hip) covers this shape on this device."""
+    return not SHARED_DEVICE and bool(query("cpg_gru_persistent_fits", int(B), int(H)))
 
 
 def lstm_persistent_fits(B, H):
     """Whole-sequence persistent LSTM forward kernel (csrc/lstm_persist.hip) covers this shape on this device."""
-    return bool(query("cpg_lstm_persistent_fits", int(B), int(H)))
+    return not SHARED_DEVICE and bool(query("cpg_lstm_persistent_fits", int(B), int(H)))
+
+
+def _persist_entry(kind, T, B, H, dev):
+    """Scratch of the persistent launches on the current stream: ONE buffer per (kind, device, stream, B, H), grown to the largest
+    T seen; with it a pinned copy of its sticky error word, refreshed asynchronously behind every launch."""
+    key = (kind, dev.index, torch.cuda.current_stream().cuda_stream, B, H)
+    ent = _persist_scratch.get(key)
+    if ent is None or ent[1] < T:
+        nb = query("cpg_gru_persistent_scratch_bytes" if kind == "gru" else "cpg_lstm_persistent_scratch_bytes", T, B, H)
+        ent = _persist_scratch[key] = [torch.zeros(nb, dtype=torch.uint8, device=dev), T,     # counters + sticky error word + slots
+                                       torch.zeros(4, dtype=torch.uint8).pin_memory(), None]
+    elif ent[3] is not None and ent[3].query() and ent[2].view(torch.int32).item() != 0:
+        _persist_failed(kind)      # a PREVIOUS launch on this scratch timed out: seen here without any synchronisation
+    return ent
+
+
+def _persist_after_launch(kind, ent, B):
+    off = query("cpg_gru_persistent_err_offset" if kind == "gru" else "cpg_lstm_persistent_err_offset", B)
+    ent[2].copy_(ent[0][off:off + 4], non_blocking=True)
+    ent[3] = torch.cuda.current_stream().record_event()
+
+
+def _persist_failed(kind):
+    raise CpgError("persistent %s kernel: an inter-workgroup wait timed out (its workgroups were not co-resident: another process "
+                   "or kernel held CUs); outputs of that launch are NaN-poisoned.  cpg.ops.set_option('%s_persist', 0) selects the "
+                   "per-step kernels" % (kind.upper(), kind))
+
+
+def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, gates):
+    ent = _persist_entry("gru", T, B, H, hs.device)
+    call("cpg_gru_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
+         _p(hs), _p(gates), _p(ent[0]), _stream())
+    _persist_after_launch("gru", ent, B)
 
 
 def lstm_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, cs, gates):
-    dev = hs.device
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, B, "lstm", (H, T))
-    sc = _persist_scratch.get(key)
-    if sc is None:
-        nb = query("cpg_lstm_persistent_scratch_bytes", T, B, H)
-        sc = _persist_scratch[key] = torch.zeros(nb, dtype=torch.uint8, device=dev)  # counters + sticky error word + slots
+    ent = _persist_entry("lstm", T, B, H, hs.device)
     call("cpg_lstm_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
-         _p(hs), _p(cs), _p(gates), _p(sc), _stream())
+         _p(hs), _p(cs), _p(gates), _p(ent[0]), _stream())
+    _persist_after_launch("lstm", ent, B)
 
 
 def check_persistent():
-    """Raise if any in-kernel wait of a persistent launch has timed out since start-up (synchronises the streams used)."""
-    for (_, _, B, _H, _T), sc in list(_persist_scratch.items()):
-        if _H == "lstm":
-            if query("cpg_lstm_persistent_status", B, _p(sc), _stream()) != 0:
-                raise CpgError("persistent LSTM kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
-                               "set CPG_LSTM_PERSIST=0 to use the per-step kernels")
-            continue
-        if _H == "chain":
-            if query("cpg_gru_chain_status", B, _p(sc), _stream()) != 0:
-                raise CpgError("one-launch BPTT: an inter-workgroup wait timed out (workgroups not co-resident?); "
-                               "set CPG_GRU_BWD_CHAIN=0 to use the per-step kernels")
-            continue
-        if query("cpg_gru_persistent_status", B, _p(sc), _stream()) != 0:
-            raise CpgError("persistent GRU kernel: an inter-workgroup wait timed out (workgroups not co-resident?); "
-                           "set CPG_GRU_PERSIST=0 to use the per-step kernels")
+    """Raise if any in-kernel wait of a persistent launch has timed out (waits for the pending error-word copies: call it where
+    a host synchronisation is acceptable - logging iterations, the end of an inference entry point, bench, tests)."""
+    for (kind, *_), ent in list(_persist_scratch.items()):
+        if ent[3] is not None:
+            ent[3].synchronize()
+            if ent[2].view(torch.int32).item() != 0:
+                _persist_failed(kind)
 
 
 class GruSeqFn(Function):
@@ -521,20 +492,13 @@ class GruSeqFn(Function):
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, w_hh, b_hh))
         gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
         _alloc_guard(hs, gates)
-        groups = row_groups(B)
-        if step_rows is None and len(groups) == 1 and persistent_fits(B, H):
+        if step_rows is None and persistent_fits(B, H):
             with _prof("fwd_persist", 1, T=T, B=B, H=H, ndir=1):
                 gru_seq_fwd_persistent(T, B, H, reverse, w_hh_c, b_hh_c, tok, tab_c, rowc_c, dense_c, hs, gates)
-        elif len(groups) == 1:
+        else:
             with _prof("fwd_step", T, T=T, B=B, H=H, ndir=1):
                 call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
                      _p(dense_c), _p(hs), _p(gates), 0, B, _p(step_rows), _stream())
-        else:
-            with fork(dev) as f:
-                for gi, (r0, r1) in enumerate(groups):
-                    f.run(gi, lambda r0=r0, r1=r1: call(
-                        "cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
-                        _p(dense_c), _p(hs), _p(gates), r0, r1, _p(step_rows), _stream()))
         ctx.save_for_backward(tok, w_hh_c, hs, gates)
         ctx.step_rows = step_rows
         ctx.dims = (T, B, H, bool(reverse))
@@ -558,27 +522,10 @@ class GruSeqFn(Function):
         dG = (torch.zeros if step_rows is not None else torch.empty)(T, B, 4 * H, device=dev, dtype=torch.float32)
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
-        groups = row_groups(B)
-        if len(groups) == 1 and step_rows is None:
-            groups = bwd_row_groups(B)
-        wT = torch.empty(len(groups), H, 3 * H, device=dev, dtype=torch.float32)  # W_hh^T: split-bf16 / direct-to-LDS kernels
-        wT = wT[0] if len(groups) == 1 else wT
-        if step_rows is None and len(groups) == 1 and persistent_bwd_fits(T, B, H):
-            with _prof("bwd_persist", 1, T=T, B=B, H=H, ndir=1):
-                gru_seq_bwd_persistent(T, B, H, reverse, w_hh, hs, gates, dhs_ext, None, dG, dh0)
-        elif step_rows is None and len(groups) == 1 and chain_bwd_fits(T, B, H):
-            with _prof("bwd_chain", 1, T=T, B=B, H=H, ndir=1, steps=T + (1 if has_h0 else 0)):
-                gru_seq_bwd_chain(T, B, H, reverse, w_hh, hs, gates, dhs_ext, None, dG, dh0, wT)
-        elif len(groups) == 1:
-            with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
-                call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                     _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
-        else:
-            with fork(dev) as f:
-                for gi, (r0, r1) in enumerate(groups):
-                    f.run(gi, lambda r0=r0, r1=r1: call(
-                        "cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                        _p(scratch), _p(dh0), r0, r1, _p(step_rows), _p(wT[gi]), _stream()))
+        wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # receives W_hh^T for the direct-to-LDS step kernel
+        with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
+            call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
+                 _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
         if has_h0 and not ctx.tail:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -682,17 +629,9 @@ class GruBiSeqFn(Function):
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
-        if persistent_bwd_fits(T, B, H):
-            with _prof("bwd_persist", 2, T=T, B=B, H=H, ndir=1):
-                gru_seq_bwd_persistent(T, B, H, False, wf, hs_f, gt_f, ext_f, last_f, dG_f, None)
-                gru_seq_bwd_persistent(T, B, H, True, wr, hs_r, gt_r, ext_r, last_r, dG_r, None)
-        elif chain_bwd_fits(T, B, H):
-            with _prof("bwd_chain", 1, T=T, B=B, H=H, ndir=2, steps=T):
-                gru_biseq_bwd_chain(T, B, H, wf, wr, hs_f, hs_r, gt_f, gt_r, ext_f, ext_r, dG_f, dG_r, wT, last_f, last_r)
-        else:
-            with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
-                call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                     _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+        with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
+            call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []

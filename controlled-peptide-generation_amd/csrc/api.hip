@@ -1,6 +1,8 @@
-// Library-wide plumbing of libcpg_hip.so: version, thread-local error text, small layout kernels.
+// Library-wide plumbing of libcpg_hip.so: version, thread-local error text, the option table, small layout kernels.
 #include <stdarg.h>
-#include "cpg_common.h"
+#include <stdlib.h>
+#include <mutex>
+#include "cpg_internal.h"
 
 static thread_local char g_err[512] = "";
 
@@ -12,11 +14,100 @@ void cpg_set_error(const char* fmt, ...) {
 }
 
 CPG_EXPORT const char* cpg_last_error(void) { return g_err; }
-CPG_EXPORT int cpg_version(void) { return 100; }  // 0.1.0
+CPG_EXPORT int cpg_version(void) { return CPG_ABI_VERSION; }
+
+// ---- option table: the launch policy's tuning knobs, ONE process-wide struct.  Filled once, on first use, from the
+// environment (CPG_<NAME IN CAPITALS>), afterwards changed only through cpg_set_option: no launch path calls getenv.
+static const char* const g_opt_names[OPT__COUNT] = {
+    "gru_persist", "lstm_persist", "gru_fwd_bm", "gru_bwd_dl", "gru_bwd_tile", "gru_bwd_dl2", "gru_bwd_stagger", "lstm_bwd_dl",
+    "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl"};
+static CpgOptVal g_opts[OPT__COUNT];
+static std::once_flag g_opts_once;
+
+static void opt_assign(CpgOptVal& v, const char* text) {
+    v.set = text && text[0];
+    v.i = v.set ? atol(text) : 0;
+    snprintf(v.s, sizeof(v.s), "%s", v.set ? text : "");
+}
+
+static void opts_from_env() {
+    for (int o = 0; o < OPT__COUNT; ++o) {
+        char key[48] = "CPG_";
+        size_t k = 4;
+        for (const char* c = g_opt_names[o]; *c && k + 1 < sizeof(key); ++c) key[k++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        key[k] = 0;
+        opt_assign(g_opts[o], getenv(key));
+    }
+}
+
+const CpgOptVal& cpg_opt(CpgOpt o) {
+    std::call_once(g_opts_once, opts_from_env);
+    return g_opts[o];
+}
+
+static int opt_index(const char* name) {
+    for (int o = 0; name && o < OPT__COUNT; ++o)
+        if (!strcmp(name, g_opt_names[o])) return o;
+    return -1;
+}
+
+// value: decimal number or short token ("64x32"); null / "" = back to the built-in policy
+CPG_EXPORT int cpg_set_option(const char* name, const char* value) {
+    const int o = opt_index(name);
+    if (o < 0) {
+        cpg_set_error("cpg_set_option: unknown option '%s'", name ? name : "(null)");
+        return -2;
+    }
+    std::call_once(g_opts_once, opts_from_env);
+    opt_assign(g_opts[o], value);
+    return 0;
+}
+
+// Copies the option's current text ("" when unset) into buf; returns 1 when set, 0 when unset, -2 for an unknown name.
+CPG_EXPORT int cpg_get_option(const char* name, char* buf, int n) {
+    const int o = opt_index(name);
+    if (o < 0) return -2;
+    const CpgOptVal& v = cpg_opt((CpgOpt)o);
+    if (buf && n > 0) snprintf(buf, (size_t)n, "%s", v.s);
+    return v.set ? 1 : 0;
+}
+
+// Per-device facts the launchers need (CU count), cached per device index.
+int cpg_device_cus() {
+    static int cus[64];
+    static std::once_flag once[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    std::call_once(once[dev], [dev] {
+        hipDeviceProp_t pr;
+        cus[dev] = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 0;
+    });
+    return cus[dev];
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); the return code is the caller's to check.
+int cpg_allow_big_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static struct { const void* k; int dev; int bytes; } seen[512];
+    static int nseen = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i].k == kernel && seen[i].dev == dev && seen[i].bytes >= bytes) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        cpg_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", bytes, hipGetErrorString(e));
+        return (int)e;
+    }
+    if (nseen < 512) seen[nseen++] = {kernel, dev, bytes};
+    return 0;
+}
 
 // Compute mode of the recurrent products (forward / backward step products and dW_hh = dG^T h): 0 = f32-grade (default:
 // exact-f32 MFMA or six bf16 MFMAs on 3-way split operands), 1 = bf16 (operands rounded to bf16 when staged, ONE bf16 MFMA
-// per block, f32 accumulation; BASELINE.json configs[1]/[4] "bf16").  Process-wide, read at launch time.
+// per block, f32 accumulation; BASELINE.json configs[1]/[4] "bf16").  Process-wide like the option table, read at launch time.
 static int g_compute_mode = 0;
 int cpg_compute_mode_get() { return g_compute_mode; }
 CPG_EXPORT int cpg_set_compute_mode(int mode) {

@@ -7,6 +7,12 @@
 
 #define CPG_EXPORT extern "C" __attribute__((visibility("default")))
 
+// Ablation macros compile phases of a kernel out (results WRONG by construction: "where does the time go" builds).  They are
+// honoured in diagnostic builds only (tools/variant_build.sh passes -DCPG_DIAG); the product library cannot be built with them.
+#if !defined(CPG_DIAG) && (defined(CPG_ABLATE) || defined(CPG_DL_ABLATE) || defined(CPG_PERSIST_ABLATE) || defined(CPG_BEAM_ABLATE))
+#error "CPG_*_ABLATE needs -DCPG_DIAG: these macros build kernels whose results are wrong by construction"
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- error plumbing -------------------------------------------------------------------------

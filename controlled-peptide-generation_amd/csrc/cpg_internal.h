@@ -22,3 +22,33 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
 
 // 0 = f32-grade products, 1 = bf16 recurrent products (cpg_set_compute_mode, api.hip)
 int cpg_compute_mode_get();
+
+// ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
+#define CPG_ABI_VERSION 300
+
+// ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
+// cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).
+enum CpgOpt {
+    OPT_GRU_PERSIST,      // 0: per-step launches instead of the whole-sequence persistent forward
+    OPT_LSTM_PERSIST,     // same for the LSTM extension
+    OPT_GRU_FWD_BM,       // 32 | 64 | 128: row-tile height of the per-step forward kernel
+    OPT_GRU_BWD_DL,       // 0: register-staged exact-f32 backward step instead of the direct-to-LDS loop
+    OPT_GRU_BWD_TILE,     // "32x32" | "64x32" | "32x64" | "64x64": tile of the backward step
+    OPT_GRU_BWD_DL2,      // 0 never / 1 whenever tiles are full: the 512-thread two-K-halves backward step
+    OPT_GRU_BWD_STAGGER,  // slabs between the staggered epilogue-operand fetches of the register-staged backward step
+    OPT_LSTM_BWD_DL,      // 0: register-staged LSTM backward step
+    OPT_TN_TILE,          // tile of the dW (transposed-use) products, e.g. "256x128"
+    OPT_TN_SPLIT,         // split-K factor of those products
+    OPT_GEMM_TILE,        // tile of the nn.Linear-shaped products
+    OPT_DGI_MODE,         // input-side reductions: "mfma" (default) | "fused" | "gemm"
+    OPT_MMD_DL,           // 0: register-staged Gram launch of the full-kernel MMD
+    OPT__COUNT
+};
+struct CpgOptVal {
+    bool set;
+    long i;       // atol of the text
+    char s[24];   // the text
+};
+const CpgOptVal& cpg_opt(CpgOpt o);
+int cpg_device_cus();                                   // CUs of the current device (cached per device)
+int cpg_allow_big_lds(const void* kernel, int bytes);   // opt a kernel into > 64 KB dynamic LDS, once per (kernel, device)

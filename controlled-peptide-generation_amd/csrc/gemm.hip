@@ -120,14 +120,12 @@ static int launch_tc_p(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
     const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false, PREC>::smem_bytes();
     const bool masks = g.a_mask || g.b_mask;
     if (smem > 64 * 1024) {  // more than the default dynamic-LDS limit: opt in once per instantiation
-        static bool done = false;
-        if (!done) {
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, true, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, true, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, false, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            done = true;
-        }
+        const void* ks[4] = {reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, true, PREC>),
+                             reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false, PREC>),
+                             reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, true, PREC>),
+                             reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, false, PREC>)};
+        const int rc = cpg_allow_big_lds(ks[(vec ? 0 : 2) + (masks ? 0 : 1)], (int)smem);
+        if (rc) return rc;
     }
     if (vec && masks)
         hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true, PREC>), grid, dim3(TC::NT), smem, s, g);
@@ -162,15 +160,20 @@ using T128x128 = TileCfg<128, 128, 32, 2, 2, 1>;
 // 512-thread workgroup (two waves per SIMD from ONE workgroup), each wave a 64x64 block: the dW_hh product.  One such
 // workgroup per CU (150 KB of split-plane LDS images); operand traffic per MAC is 2/3 of the 128x64 tile's.
 using T256x128 = TileCfg<256, 128, 32, 4, 2, 1, 512>;
+// 192 x 128: the dW_hh product (M = 3H = 1536, N = H = 512) is then 8 x 4 = 32 tiles per K-chunk, i.e. with split-K 8 ONE
+// K-chunk per XCD (xcd_tile_order: 32 workgroups = the XCD's 32 CUs) - every A / B panel row is fetched into exactly one L2.
+using T192x128 = TileCfg<192, 128, 32, 4, 2, 1, 512>;
 
-enum TnTile { TN_AUTO = 0, TN_256x128, TN_128x128, TN_128x64, TN_64x64, TN_128x32, TN_32x128 };
+enum TnTile { TN_AUTO = 0, TN_256x128, TN_192x128, TN_128x128, TN_128x64, TN_64x64, TN_128x32, TN_32x128 };
 
-// CPG_TN_TILE forces the tile of the transposed-use (dW = dY^T X) products: tools/kbench.py and tests/test_gpu_tiles.py
+// Option tn_tile forces the tile of the transposed-use (dW = dY^T X) products: tools/kb.py and tests/test_gpu_tiles.py
 // (every instantiation against the golden vectors).
 static TnTile tn_tile_knob() {
-    const char* e = getenv("CPG_TN_TILE");
-    if (!e) return TN_AUTO;
+    const CpgOptVal& o = cpg_opt(OPT_TN_TILE);
+    if (!o.set) return TN_AUTO;
+    const char* e = o.s;
     if (!strcmp(e, "256x128")) return TN_256x128;
+    if (!strcmp(e, "192x128")) return TN_192x128;
     if (!strcmp(e, "128x128")) return TN_128x128;
     if (!strcmp(e, "128x64")) return TN_128x64;
     if (!strcmp(e, "64x64")) return TN_64x64;
@@ -194,6 +197,7 @@ static int launch_gemm(const GemmArgs& g_in, int zdim, hipStream_t s, TnTile for
     if constexpr (!A_KC && !B_KC) {
         switch (force) {
             case TN_256x128: return launch_tc<T256x128, A_KC, B_KC>(g, zdim, vec, s);
+            case TN_192x128: return launch_tc<T192x128, A_KC, B_KC>(g, zdim, vec, s);
             case TN_128x128: return launch_tc<T128x128, A_KC, B_KC>(g, zdim, vec, s);
             case TN_128x64: return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
             case TN_64x64: return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
@@ -202,8 +206,9 @@ static int launch_gemm(const GemmArgs& g_in, int zdim, hipStream_t s, TnTile for
             default: break;
         }
     }
-    if constexpr (A_KC) {  // nn.Linear forward / input-gradient products (exact-f32 engine): CPG_GEMM_TILE forces a tile
-        if (const char* e = getenv("CPG_GEMM_TILE")) {
+    if constexpr (A_KC) {  // nn.Linear forward / input-gradient products (exact-f32 engine): option gemm_tile forces a tile
+        if (const CpgOptVal& o = cpg_opt(OPT_GEMM_TILE); o.set) {
+            const char* e = o.s;
             if (!strcmp(e, "128x64")) return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);
             if (!strcmp(e, "64x64")) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
             if (!strcmp(e, "64x32")) return launch_tc<T64x32, A_KC, B_KC>(g, zdim, vec, s);
@@ -276,7 +281,7 @@ struct TnPlan {
 };
 static TnPlan tn_plan(int M, int N, int K) {
     TnPlan p{tn_tile_knob(), 1, 0};
-    const char* e = getenv("CPG_TN_SPLIT");  // tuning knob (tools/kbench.py)
+    const CpgOptVal& split = cpg_opt(OPT_TN_SPLIT);
     // Large products (the dW_hh product: M=3H, N=H, K=T*B): 256x128 tiles, ONE 512-thread workgroup per CU, split-K chosen
     // so that a single round of <= 256 workgroups covers the problem.
     // (bf16 compute mode: the single-buffered 128x128 tile, two workgroups per CU - 347 us against 365 at the dW_hh shape incl.
@@ -287,6 +292,9 @@ static TnPlan tn_plan(int M, int N, int K) {
     if (p.tile == TN_256x128) {
         const long tiles = (long)cdiv(M, 256) * cdiv(N, 128);
         want = 256 / tiles;
+    } else if (p.tile == TN_192x128) {
+        const long tiles = (long)cdiv(M, 192) * cdiv(N, 128);
+        want = 256 / tiles;
     } else if (p.tile == TN_128x128) {   // single-buffered plane images: two workgroups per CU, one round
         const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
         want = 512 / tiles;
@@ -296,11 +304,11 @@ static TnPlan tn_plan(int M, int N, int K) {
         const long tiles = (long)cdiv(M, 128) * cdiv(N, 64);
         want = (1536 + tiles - 1) / tiles;
     }
-    if (e && atoi(e) > 0) want = atoi(e);
+    if (split.set && split.i > 0) want = split.i;
     if (want < 1) want = 1;
     long maxs = K / 512;  // at least 16 slabs per workgroup: shorter chunks are all prologue (measured: K=2048 split 16 ways
     if (maxs < 1) maxs = 1;  // ran a 3.2 GFLOP product in 0.46 ms)
-    if (!(e && atoi(e) > 0) && want > maxs) want = maxs;
+    if (!(split.set && split.i > 0) && want > maxs) want = maxs;
     if (want > 64) want = 64;
     p.k_chunk = cdiv(cdiv(K, (int)want), 32) * 32;
     p.S = cdiv(K, p.k_chunk);
@@ -340,12 +348,12 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n) 
         else if (Kd <= 32) t = TN_128x32;
         else t = ((long)cdiv(N, 128) * cdiv(Kd, 64) * p.S < 256) ? TN_64x64 : TN_128x64;
     }
-    const char* tc = t == TN_256x128 ? "256, 128, 32, 4, 2, 1, 512" : t == TN_128x128 ? "128, 128, 32, 2, 2, 1, 256" :
+    const char* tc = t == TN_256x128 ? "256, 128, 32, 4, 2, 1, 512" : t == TN_192x128 ? "192, 128, 32, 4, 2, 1, 512" : t == TN_128x128 ? "128, 128, 32, 2, 2, 1, 256" :
                      t == TN_128x64 ? "128, 64, 32, 2, 2, 1, 256" : t == TN_64x64 ? "64, 64, 32, 2, 2, 1, 256" :
                      t == TN_128x32 ? "128, 32, 32, 4, 1, 1, 256" : "32, 128, 32, 1, 4, 1, 256";
     const bool vec = N % 4 == 0 && Kd % 4 == 0 && p.k_chunk % 4 == 0;
     return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false, %d>", tc, vec ? "true" : "false",
-                    ((t == TN_256x128 || t == TN_128x128) && cpg_compute_mode_get() == 1) ? 1 : 7);
+                    ((t == TN_256x128 || t == TN_192x128 || t == TN_128x128) && cpg_compute_mode_get() == 1) ? 1 : 7);
 }
 CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
 

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
 struct GruBwdArgs {
     const float* dG_next;  // [B,4H] of the step processed just before this one (s+1), null on the first launch
     const float* w_hh;     // [3H,H]
-    const float* w_hhT;    // [H,3H] = w_hh^T (the split-bf16 engine wants both operands K-contiguous), or null: exact-f32 path
+    const float* w_hhT;    // [H,3H] = w_hh^T for the direct-to-LDS kernel (both operands K-contiguous), or null
     const float* dH_next;  // [B,H] total gradient of h_{s+1}, null on the first launch
     const float* z_next;   // [B,H] z gate of step s+1
     const float* ext;      // [B,H] external gradient on h_s (time-aligned slice) or null
@@ -167,20 +167,13 @@ struct GruBwdPair {
     GruBwdArgs d[2];
 };
 
-// dgh . W_hh of the backward step, two forms:
-//   WT = false  W_hh [3H,H] as stored is the transposed-use (XC) operand.  Its split staging works on k-row pairs (tiles at
-//               least 64 columns wide); narrower tiles run the exact-f32 MFMA (v_mfma_f32_16x16x4_f32), whose issue slots
-//               are shared with every VALU instruction of the epilogue / staging code.
-//   WT = true   the caller hands over W_hh^T [H,3H] (one 3 MB transpose per sequence): both operands are K-contiguous, so
-//               every tile shape runs on the split-bf16 engine (six bf16 MFMAs on operands split when the slab is stored).
-#ifndef CPG_STEP_BWD_SPLIT
-#define CPG_STEP_BWD_SPLIT 7
-#endif
-template <class TC, bool VEC, bool WT, int PREC = 7>
-using BwdLoop = MainLoop<TC, true, WT, VEC, VEC, false,
-                         (CPG_STEP_BWD_SPLIT == 7 && TC::BK == 32 && (WT || TC::BV % 2 == 0)) ? PREC : 0>;
+// dgh . W_hh of the register-staged backward step: W_hh [3H,H] as stored is the transposed-use (XC) operand.  Its split
+// staging works on k-row pairs (tiles at least 64 columns wide: six bf16 MFMAs on operands split when the slab is stored);
+// narrower tiles run the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).  Full tiles of dense batches run gru_step_bwd_dl_kernel.
+template <class TC, bool VEC>
+using BwdLoop = MainLoop<TC, true, false, VEC, VEC, false, (TC::BK == 32 && TC::BV % 2 == 0) ? 7 : 0>;
 
-template <class TC, bool VEC, bool WT, int PREC>
+template <class TC, bool VEC>
 __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -202,7 +195,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
         // layout (one dword per lane, 64 B per row segment), which is what a step launch is bound by
         extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float* const tb = cpg_smem + BwdLoop<TC, VEC, WT, PREC>::smem_bytes() / sizeof(float) + wave * 256;
+        float* const tb = cpg_smem + BwdLoop<TC, VEC>::smem_bytes() / sizeof(float) + wave * 256;
         const int rb0 = m0 + (wave / TC::WN) * TC::WTM + (lane >> 2), cb0 = j0 + (wave % TC::WN) * TC::WTN + 4 * (lane & 3);
         f32x4 pre[TC::MI][TC::NI], sv[TC::MI][TC::NI][5];
         // The epilogue operands (36 B per element: saved gates, h_prev, z*dH of step s+1, external gradients) are fetched
@@ -229,10 +222,10 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
         };
         if (g.dG_next) {
             OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
-            OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
+            OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
             const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);  // dispatch order: XCD = hb % 8
             const int phase = ((hb >> 3) + (hb >> 8)) & 3, last = ((3 * H + TC::BK - 1) / TC::BK - 1) & ~1;
-            BwdLoop<TC, VEC, WT, PREC>::run(a, b, 3 * H, acc, min(phase * g.ep_step, last), load_ep);
+            BwdLoop<TC, VEC>::run(a, b, 3 * H, acc, min(phase * g.ep_step, last), load_ep);
         } else {
             load_ep();
         }
@@ -288,8 +281,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     }
     if (g.dG_next) {
         OpA a{g.dG_next, 4 * H, m0, Bn, nullptr, 1.f};  // rows past Bn read as zero
-        OpB b{WT ? g.w_hhT : g.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
-        BwdLoop<TC, VEC, WT, PREC>::run(a, b, 3 * H, acc);
+        OpB b{g.w_hh, H, j0, H, 0, nullptr, 1.f};
+        BwdLoop<TC, VEC>::run(a, b, 3 * H, acc);
     }
 #pragma unroll
     for (int ni = 0; ni < TC::NI; ++ni) {
@@ -319,78 +312,13 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
     }
 }
 
-// ---- split form of the forward step: plain product gh = h_prev W_hh^T (gemm.hip) + this memory-bound cell kernel.
-// Two row groups alternate the two kernels on two streams, so one group's cell kernel (HBM traffic, few registers)
-// co-runs with the other group's product (MFMA): the lockstep "everybody loads / everybody multiplies / everybody stores"
-// of the fused kernel is broken up at the price of writing and re-reading gh (24 MB per step at B=2048,H=512).
-__global__ void gru_cell_fwd_kernel(const float* gh, const float* b_hh, const int32_t* tok, const float* tab, const float* rowc,
-                                    const float* dense, const float* h_prev, float* h_out, float* gates, int B, int H,
-                                    int row0, int row1) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = row0 + blockIdx.y;
-    if (j >= H || row >= row1) return;
-    float gi_r = 0.f, gi_z = 0.f, gi_n = 0.f;
-    if (tok) {
-        const float* t = tab + (size_t)tok[row] * 3 * H;
-        gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
-    }
-    if (rowc) {
-        const float* t = rowc + (size_t)row * 3 * H;
-        gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
-    }
-    if (dense) {
-        const float* t = dense + (size_t)row * 3 * H;
-        gi_r += t[j]; gi_z += t[H + j]; gi_n += t[2 * H + j];
-    }
-    const float* g3 = gh + (size_t)row * 3 * H;
-    const float hn = g3[2 * H + j] + b_hh[2 * H + j];
-    const float rg = sigmoidf_(gi_r + (g3[j] + b_hh[j]));
-    const float zg = sigmoidf_(gi_z + (g3[H + j] + b_hh[H + j]));
-    const float ng = tanhf(gi_n + rg * hn);
-    const size_t o = (size_t)row * H + j;
-    h_out[o] = (1.f - zg) * ng + zg * h_prev[o];
-    if (gates) {
-        const size_t BH = (size_t)B * H;
-        __builtin_nontemporal_store(rg, gates + o);
-        __builtin_nontemporal_store(zg, gates + BH + o);
-        __builtin_nontemporal_store(ng, gates + 2 * BH + o);
-        __builtin_nontemporal_store(hn, gates + 3 * BH + o);
-    }
-}
-
-// Experimental entry point (tools/kbench3.py): same contract as cpg_gru_seq_fwd plus a gh scratch [B,3H].
-CPG_EXPORT int cpg_gru_seq_fwd_split(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
-                                     const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                                     float* gh, int row_begin, int row_end, void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && gh && 0 <= row_begin && row_begin < row_end && row_end <= B);
-    const size_t BH = (size_t)B * H;
-    hipStream_t s = (hipStream_t)stream;
-    const int rows = row_end - row_begin;
-    for (int p = 0; p < T; ++p) {
-        const int t = reverse ? T - 1 - p : p;
-        const float* h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
-        float* h_out = reverse ? hs + (size_t)t * BH : hs + (size_t)(t + 1) * BH;
-        int rc = cpg_gemm_nt(h_prev + (size_t)row_begin * H, H, nullptr, 1.f, w_hh, H, nullptr, gh + (size_t)row_begin * 3 * H,
-                             3 * H, rows, 3 * H, H, 0, s);
-        if (rc) return rc;
-        hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, s, (const float*)gh, b_hh,
-                           tok ? tok + (size_t)t * B : nullptr, tab, rowc, dense ? dense + (size_t)t * B * 3 * H : nullptr,
-                           h_prev, h_out, gates ? gates + (size_t)t * 4 * BH : nullptr, B, H, row_begin, row_end);
-        CPG_LAUNCH_CHECK();
-    }
-    return 0;
-}
-
 using GF128 = TileCfg<128, 96, 32, 2, 2, 3>;
 using GF64 = TileCfg<64, 96, 32, 2, 2, 3>;
 using GF32 = TileCfg<32, 96, 32, 2, 2, 3>;
-using GB128 = TileCfg<128, 32, 32, 4, 1, 1>;
+// register-staged backward step (every shape the direct-to-LDS kernel does not cover: partial tiles, ragged batches, H % 32 != 0)
 using GB64 = TileCfg<64, 32, 32, 4, 1, 1>;
 using GB32 = TileCfg<32, 64, 32, 2, 2, 1>;
-using GB64W = TileCfg<64, 64, 32, 2, 2, 1>;    // wider N tile: 4 MFMAs per k-step per wave instead of 2
-using GB128W = TileCfg<128, 64, 32, 2, 2, 1>;
 using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
-using GB32K = TileCfg<32, 32, 64, 2, 2, 1>;    // 64-deep slabs: half the slab barriers (exact-f32 engine only)
 
 // ---- backward step with a direct-to-LDS main loop ("DL"): exact-f32 MFMA on 32 x 32 tiles like gru_step_bwd_kernel<GB32N>, but
 // both operands K-contiguous (dgh rows, W_hh^T rows) and staged by `global_load_lds_dwordx4` into a THREE-stage LDS ring, two
@@ -569,87 +497,62 @@ __global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
 
 
 template <class TC, int PREC>
-static void launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
+static int launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN / 3), cdiv(a.row1 - a.row0, TC::BM), nd);
     const size_t smem = FwdLoop<TC, true, PREC>::smem_bytes();
-    if (smem > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per instantiation
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, true, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, false, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done = true;
-        }
+    const void* k = vec ? reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, true, PREC>)
+                        : reinterpret_cast<const void*>(gru_step_fwd_kernel<TC, false, PREC>);
+    if (smem > 64 * 1024) {  // above the default dynamic-LDS limit: opt in once per (instantiation, device)
+        const int rc = cpg_allow_big_lds(k, (int)smem);
+        if (rc) return rc;
     }
     if (vec)
         hipLaunchKernelGGL((gru_step_fwd_kernel<TC, true, PREC>), grid, dim3(256), smem, s, pr);
     else
         hipLaunchKernelGGL((gru_step_fwd_kernel<TC, false, PREC>), grid, dim3(256), smem, s, pr);
+    return 0;
 }
 
 template <class TC>
-static void launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
-    if (cpg_compute_mode_get() == 1) launch_fwd_p<TC, 1>(pr, nd, vec, s);
-    else launch_fwd_p<TC, 7>(pr, nd, vec, s);
+static int launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
+    return cpg_compute_mode_get() == 1 ? launch_fwd_p<TC, 1>(pr, nd, vec, s) : launch_fwd_p<TC, 7>(pr, nd, vec, s);
 }
 
-template <class TC, bool WT, int PREC>
-static void launch_bwd_p(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
+template <class TC>
+static int launch_bwd(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(cdiv(a.H, TC::BN), cdiv(a.row1 - a.row0, TC::BM), nd);
-    const size_t smem = BwdLoop<TC, true, WT, PREC>::smem_bytes() + 4 * 256 * sizeof(float);  // + per-wave transposition buffers
+    const size_t smem = BwdLoop<TC, true>::smem_bytes() + 4 * 256 * sizeof(float);  // + per-wave transposition buffers
     if (smem > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true, WT, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false, WT, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done = true;
-        }
+        const void* k = vec ? reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, true>)
+                            : reinterpret_cast<const void*>(gru_step_bwd_kernel<TC, false>);
+        const int rc = cpg_allow_big_lds(k, (int)smem);
+        if (rc) return rc;
     }
     if (vec)
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true, WT, PREC>), grid, dim3(256), smem, s, pr);
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, true>), grid, dim3(256), smem, s, pr);
     else
-        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false, WT, PREC>), grid, dim3(256), smem, s, pr);
+        hipLaunchKernelGGL((gru_step_bwd_kernel<TC, false>), grid, dim3(256), smem, s, pr);
+    return 0;
 }
 
-template <class TC, bool WT>
-static void launch_bwd(const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
-    // bf16 compute mode exists on the W_hh^T (both operands K-contiguous) path only
-    if (WT && cpg_compute_mode_get() == 1) launch_bwd_p<TC, WT, WT ? 1 : 7>(pr, nd, vec, s);
-    else launch_bwd_p<TC, WT, 7>(pr, nd, vec, s);
-}
-
-// pick the row-tile height so that the launch has at least ~256 workgroups when the problem allows it
-// (CPG_GRU_FWD_BM / CPG_GRU_BWD_BM force 128|64|32: tuning knobs for tools/kbench.py)
-static int pick_bm(int B, int ntile_n, const char* knob) {
-    const char* e = getenv(knob);
-    if (e) {
-        const int v = atoi(e);
-        if (v == 128 || v == 64 || v == 32) return v;
-    }
-    // measured on MI355X (tools/kbench.py, B=2048 H=512): 64-row tiles (2 workgroups per CU) beat 128-row tiles by
-    // 20-25 % - the second resident workgroup covers the other's staging waits and epilogue traffic
-    if ((long)cdiv(B, 64) * ntile_n >= 256 || B > 32) return 64;
-    return 32;
-}
-
+// Row-tile height of the per-step forward kernel (option gru_fwd_bm = 32 | 64 | 128 forces).  Measured on MI355X at B=2048,
+// H=512: 64-row tiles (2 workgroups per CU) beat 128-row tiles by 20-25 % - the second resident workgroup covers the other's
+// staging waits and epilogue traffic; 32-row tiles lose on the split engine (every row tile converts the whole W_hh slab).
 static int fwd_bm_choice(int rows, int H, int nd) {
-    int bm = pick_bm(rows, cdiv(H, 32), "CPG_GRU_FWD_BM");
-    if (CPG_STEP_FWD_SPLIT != 7 && bm == 64 && !getenv("CPG_GRU_FWD_BM") && (long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024) bm = 32;
-    return bm;
+    const CpgOptVal& o = cpg_opt(OPT_GRU_FWD_BM);
+    if (o.set && (o.i == 128 || o.i == 64 || o.i == 32)) return (int)o.i;
+    return ((long)cdiv(rows, 64) * cdiv(H, 32) >= 256 || rows > 32) ? 64 : 32;
 }
 
 static int gru_fwd_launch(const GruFwdPair& pr, int nd, hipStream_t s) {
     const GruFwdArgs& a = pr.d[0];
     bool vec = a.H % 4 == 0;
     for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].h_prev) && aligned16(pr.d[d].w_hh);
-    // exact-f32 engine: 32-row tiles (4 resident workgroups per CU) measured 43.5 us vs 46.9 us for 64-row tiles at
-    // B=2048,H=512.  Split-bf16 engine: 64-row tiles 37.1 us vs 50.8 us for 32-row tiles (every row tile converts the
-    // whole W_hh slab again, and the slab barrier is paid twice as often per MFMA).
     const int bm = fwd_bm_choice(a.row1 - a.row0, a.H, nd);
-    if (bm == 128) launch_fwd<GF128>(pr, nd, vec, s);
-    else if (bm == 64) launch_fwd<GF64>(pr, nd, vec, s);
-    else launch_fwd<GF32>(pr, nd, vec, s);
+    const int rc = bm == 128 ? launch_fwd<GF128>(pr, nd, vec, s) : bm == 64 ? launch_fwd<GF64>(pr, nd, vec, s) : launch_fwd<GF32>(pr, nd, vec, s);
+    if (rc) return rc;
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -661,189 +564,146 @@ int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
     return gru_fwd_launch(pr, 1, s);
 }
 
-// Tile of a backward-step launch.  Exact-f32 path (no W_hh^T handed over, or one of the CPG_GRU_BWD_BM / CPG_GRU_BWD_WIDE
-// knobs set): the round-1 policy.  Split path: CPG_GRU_BWD_TILE = 64x32 | 32x64 | 64x64 | 128x32 | 128x64 | 32x32 forces.
-enum BwdTile { BT_64x32, BT_32x64, BT_64x64, BT_128x32, BT_128x64, BT_32x32, BT_32x32K64 };
-struct BwdChoice {
-    bool wt;
-    BwdTile tile;
-    bool forced = false;   // a CPG_GRU_BWD_BM / _WIDE knob asked for this register-staged tile: the direct-to-LDS kernel stays out
+// ---- backward-step launch policy.  Option gru_bwd_tile ("32x32" | "64x32" | "32x64" | "64x64") forces the tile of either
+// kernel; gru_bwd_dl = 0 keeps the register-staged kernel; gru_bwd_dl2 = 0 / 1 disables / forces the two-K-halves form.
+struct BwdTile {
+    int bm, bn;
 };
-static BwdChoice gru_bwd_choice(int rows, int H, int nd, bool have_wt) {
-    const char* wide = getenv("CPG_GRU_BWD_WIDE");
-    const char* bmk = getenv("CPG_GRU_BWD_BM");
-    const char* exact = getenv("CPG_GRU_BWD_EXACT");
-    const char* t = getenv("CPG_GRU_BWD_TILE");
-    // Measured on MI355X (tools/kbench.py, B=2048, H=512, us per step): exact-f32 32x32 tiles 48.1; split-bf16 engine with
-    // W_hh^T: 64x32 52.9, 32x32 52.9, 32x64 65.3, 64x64 68.0, 128x32 73.7, 128x64 93.5.  The launch is bound by its fixed
-    // prologue / epilogue traffic and slab-loop latency, not by the matrix pipe (PMC: MFMA busy 16 %), so the cheaper
-    // product does not pay for the extra staging conversions: the split path runs only when CPG_GRU_BWD_TILE asks for it.
-    const bool bf16 = cpg_compute_mode_get() == 1 && have_wt && !wide && !bmk && !(exact && atoi(exact));
-    if (!bf16 && (!have_wt || wide || bmk || !t || (exact && atoi(exact)))) {
-        const int bm = pick_bm(rows, cdiv(H, 32), "CPG_GRU_BWD_BM");
-        // 32x32 tiles (>= 1024 workgroups) measured 51.4 us vs 53.7 us for 64x32 at B=2048,H=512; wider tiles lose badly (77 / 116 us)
-        const bool small = !wide && !bmk && (long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024;
-        const bool forced = wide || bmk;
-        if (small) return {false, BT_32x32};
-        if (wide && atoi(wide) == 64) return {false, BT_64x64, true};
-        if (wide && atoi(wide) == 128) return {false, BT_128x64, true};
-        if (wide && atoi(wide) == 32) return {false, BT_32x32, true};
-        if (wide && atoi(wide) == 3264) return {false, BT_32x32K64, true};
-        if (bm == 128) return {false, BT_128x32, forced};
-        if (bm == 64) return {false, BT_64x32, forced};
-        return {false, BT_32x64, forced};
-    }
-    if (t) {
-        if (!strcmp(t, "64x32")) return {true, BT_64x32};
-        if (!strcmp(t, "32x64")) return {true, BT_32x64};
-        if (!strcmp(t, "64x64")) return {true, BT_64x64};
-        if (!strcmp(t, "128x32")) return {true, BT_128x32};
-        if (!strcmp(t, "128x64")) return {true, BT_128x64};
-        if (!strcmp(t, "32x32")) return {true, BT_32x32};
-    }
-    if (rows <= 32) return {true, BT_32x64};
-    return {true, BT_64x32};
+static bool parse_tile(const CpgOptVal& o, BwdTile& t) {
+    if (!o.set) return false;
+    int bm = 0, bn = 0;
+    if (sscanf(o.s, "%dx%d", &bm, &bn) != 2) return false;
+    if ((bm != 32 && bm != 64) || (bn != 32 && bn != 64)) return false;
+    t = {bm, bn};
+    return true;
 }
 
-template <bool WT>
-static void launch_bwd_tile(BwdTile t, const GruBwdPair& pr, int nd, bool vec, hipStream_t s) {
-    switch (t) {
-        case BT_64x32: launch_bwd<GB64, WT>(pr, nd, vec, s); break;
-        case BT_32x64: launch_bwd<GB32, WT>(pr, nd, vec, s); break;
-        case BT_64x64: launch_bwd<GB64W, WT>(pr, nd, vec, s); break;
-        case BT_128x32: launch_bwd<GB128, WT>(pr, nd, vec, s); break;
-        case BT_128x64: launch_bwd<GB128W, WT>(pr, nd, vec, s); break;
-        case BT_32x32: launch_bwd<GB32N, WT>(pr, nd, vec, s); break;
-        case BT_32x32K64:
-            if (!WT) launch_bwd_p<GB32K, false, 7>(pr, nd, vec, s);
-            break;
-    }
+// Register-staged exact-f32 kernel: 32 x 32 tiles when they give >= 1024 workgroups (measured 51.4 us against 53.7 for 64 x 32 at
+// B=2048, H=512), 64-row tiles for big batches otherwise, 32 x 64 for small ones.
+static BwdTile staged_tile(int rows, int H, int nd) {
+    BwdTile t;
+    if (parse_tile(cpg_opt(OPT_GRU_BWD_TILE), t) && !(t.bm == 64 && t.bn == 64)) return t;
+    if ((long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024) return {32, 32};
+    return ((long)cdiv(rows, 64) * cdiv(H, 32) >= 256 || rows > 32) ? BwdTile{64, 32} : BwdTile{32, 64};
 }
 
-// Slab spacing of the staggered epilogue-operand fetch: a quarter of the slab count by default (the four workgroups a CU
-// holds fetch ahead of slabs 0, KT/4, KT/2, 3KT/4);  CPG_GRU_BWD_STAGGER=<slabs> overrides, 0 = all ahead of slab 0.
+// Slab spacing of the staggered epilogue-operand fetch of the register-staged kernel: a quarter of the slab count by default
+// (the four workgroups a CU holds fetch ahead of slabs 0, KT/4, KT/2, 3KT/4); option gru_bwd_stagger overrides, 0 = all ahead.
 static int bwd_ep_step(int H) {
-    const char* e = getenv("CPG_GRU_BWD_STAGGER");  // read per launch, like the tile knobs (A/B sweeps inside one process)
-    const int knob = e ? atoi(e) : -1;
+    const CpgOptVal& o = cpg_opt(OPT_GRU_BWD_STAGGER);
     const int kt = cdiv(3 * H, 32);
-    return (knob >= 0 ? knob : kt / 4) & ~1;
+    return (int)(o.set && o.i >= 0 ? o.i : kt / 4) & ~1;
 }
 
-// The direct-to-LDS backward step (gru_step_bwd_dl_kernel) covers full 32 x 32 tiles; CPG_GRU_BWD_DL=0 keeps the
-// register-staged kernel.
+// The direct-to-LDS backward step (gru_step_bwd_dl_kernel) covers full 32 x 32 tiles of dense batches.
 static bool bwd_dl_shape_ok(int row0, int row1, int H) {
-    const char* e = getenv("CPG_GRU_BWD_DL");
-    if (e && atoi(e) == 0) return false;
+    const CpgOptVal& o = cpg_opt(OPT_GRU_BWD_DL);
+    if (o.set && o.i == 0) return false;
     return row0 % 32 == 0 && (row1 - row0) % 32 == 0 && row1 > row0 && H % 32 == 0;
 }
-// W_hh^T is needed by the split-engine tiles and by the direct-to-LDS kernel
-static bool bwd_wants_wt(int rows, int H, int nd, int row0, bool dense) {
-    const BwdChoice c = gru_bwd_choice(rows, H, nd, true);
-    return c.wt || (dense && !c.forced && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H));
-}
+// W_hh^T is needed by the direct-to-LDS kernel only
+static bool bwd_wants_wt(int rows, int H, int row0, bool dense) { return dense && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H); }
 
-template <int BM, int BN, int NS, int PREC = 0>
-static void launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
+template <int BM, int BN, int PREC>
+static int launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(a.H / BN, (a.row1 - a.row0) / BM, nd);
-    const size_t smem = (DlLoop<BM, BN, NS, PREC>::smem_floats() + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, 3, PREC>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, NS, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done = true;
-        }
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, 3, PREC>), (int)smem);
+        if (rc) return rc;
     }
-    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, NS, PREC>), grid, dim3(256), smem, s, pr);
+    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, 3, PREC>), grid, dim3(256), smem, s, pr);
+    return 0;
 }
 
 template <int PREC>
-static void launch_dl2(const GruBwdPair& pr, int nd, hipStream_t s) {
+static int launch_dl2(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(a.H / 64, (a.row1 - a.row0) / 64, nd);
     const size_t smem = (2 * DlLoop<64, 64, 3, PREC>::smem_floats() + 8 * 256) * sizeof(float);
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_step_bwd_dl2_kernel<PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        done = true;
-    }
+    const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gru_step_bwd_dl2_kernel<PREC>), (int)smem);
+    if (rc) return rc;
     hipLaunchKernelGGL((gru_step_bwd_dl2_kernel<PREC>), grid, dim3(512), smem, s, pr);
+    return 0;
 }
 // 64 x 64 tiles, two K-halves per workgroup: launches with 128 <= tiles < 512 (fewer than two 64 x 64 workgroups per CU, the
 // decoder's single direction at B=2048, H=512) IN THE bf16 COMPUTE MODE - measured at that shape, us per launch against the
 // 64 x 32 direct-to-LDS kernel: bf16 mode 21.1 vs 24.7, f32-grade 38.9 vs 37.1 (its main loop is matrix-pipe-bound either way
-// and the eight-wave barrier costs more than the halved operand traffic returns).  CPG_GRU_BWD_DL2=0 disables, =1 forces it
-// for any full-tile shape in either mode.
+// and the eight-wave barrier costs more than the halved operand traffic returns).
 static bool bwd_dl2_wanted(int rows, int H, int nd, bool bf16) {
-    const char* e = getenv("CPG_GRU_BWD_DL2");
-    if (e && atoi(e) == 0) return false;
+    const CpgOptVal& o = cpg_opt(OPT_GRU_BWD_DL2);
+    if (o.set && o.i == 0) return false;
     if (rows % 64 != 0 || H % 64 != 0) return false;
-    if (e && atoi(e) == 1) return true;
+    if (o.set && o.i == 1) return true;
     const long wg64 = (long)(rows / 64) * (H / 64) * nd;
     return bf16 && wg64 >= 128 && wg64 < 512;
+}
+
+// Tile of the direct-to-LDS kernel (tools/kb.py, B=2048, H=512, us per launch; 32x32 / 64x32 / 32x64 / 64x64): single direction
+// 38.9 / 35.5 / 35.0 / 38.2, paired directions 71.6 / 66.9 / 68.0 / 60.7 - larger tiles halve the operand traffic per MFMA, as
+// long as at least two workgroups per CU remain.
+static BwdTile dl_tile(int rows, int H, int nd) {
+    const bool r64 = rows % 64 == 0, h64 = H % 64 == 0;
+    const long wg64 = (long)(rows / 64) * (H / 64) * nd;   // 64 x 64 tiles of the launch
+    BwdTile t{32, 32};
+    if (!parse_tile(cpg_opt(OPT_GRU_BWD_TILE), t)) {
+        if (r64 && h64 && wg64 >= 512) t = {64, 64};
+        else if (r64 && wg64 >= 256) t = {64, 32};
+    }
+    if (t.bm == 64 && !r64) t.bm = 32;
+    if (t.bn == 64 && !h64) t.bn = 32;
+    return t;
+}
+
+enum BwdKernelKind { BK_STAGED, BK_DL, BK_DL2 };
+struct BwdPlan {
+    BwdKernelKind kind;
+    BwdTile tile;
+    bool bf16;
+};
+static BwdPlan bwd_plan(int rows, int H, int nd, int row0, bool vec, bool have_wt, bool dense) {
+    const bool bf16 = cpg_compute_mode_get() == 1;
+    if (vec && have_wt && dense && bwd_dl_shape_ok(row0, row0 + rows, H)) {
+        if (!cpg_opt(OPT_GRU_BWD_TILE).set && bwd_dl2_wanted(rows, H, nd, bf16)) return {BK_DL2, {64, 64}, bf16};
+        return {BK_DL, dl_tile(rows, H, nd), bf16};
+    }
+    return {BK_STAGED, staged_tile(rows, H, nd), false};   // exact f32 in either compute mode
 }
 
 static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     GruBwdPair pr = pr_in;
     for (int d = 0; d < 2; ++d) pr.d[d].ep_step = bwd_ep_step(pr.d[d].H);
     const GruBwdArgs& a = pr.d[0];
-    bool vec = a.H % 4 == 0, have_wt = true;
+    bool vec = a.H % 4 == 0, have_wt = true, dense = true;
     for (int d = 0; d < nd; ++d) {
         vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
         // the row-layout epilogue moves four columns per lane: every state / gate / gradient base 16-byte aligned
         const void* ptrs[] = {pr.d[d].dH_next, pr.d[d].z_next, pr.d[d].ext, pr.d[d].ext2, pr.d[d].gates, pr.d[d].h_prev,
                               pr.d[d].dH_out, pr.d[d].dG_out};
         for (const void* q : ptrs) vec = vec && (!q || aligned16(q));
-        have_wt = have_wt && pr.d[d].w_hhT != nullptr;
-        if (pr.d[d].w_hhT) vec = vec && aligned16(pr.d[d].w_hhT);
+        have_wt = have_wt && pr.d[d].w_hhT != nullptr && aligned16(pr.d[d].w_hhT);
+        dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
     }
-    const BwdChoice c = gru_bwd_choice(a.row1 - a.row0, a.H, nd, have_wt);
-    bool dense = true;
-    for (int d = 0; d < nd; ++d) dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
-    // bf16 compute mode: the direct-to-LDS kernel with PREC = 1 unless a split-engine tile was asked for (CPG_GRU_BWD_TILE)
-    const bool bf16_dl = c.wt && !c.forced && cpg_compute_mode_get() == 1 && !getenv("CPG_GRU_BWD_TILE");
-    if ((!c.wt || bf16_dl) && !c.forced && vec && have_wt && dense && bwd_dl_shape_ok(a.row0, a.row1, a.H)) {
-        // direct-to-LDS main loop (gru_step_bwd_dl_kernel): same sums whatever the tile
-        // Tile (tools/kbench.py, B=2048, H=512, us per launch; 32x32 / 64x32 / 32x64 / 64x64): single direction 38.9 / 35.5 /
-        // 35.0 / 38.2, paired directions 71.6 / 66.9 / 68.0 / 60.7 - larger tiles halve the operand traffic per MFMA, as long as
-        // at least two workgroups per CU remain.  CPG_GRU_BWD_DL_TILE / CPG_GRU_BWD_DL_STAGES (2 | 3 | 4: no effect) override.
-        const char* t = getenv("CPG_GRU_BWD_DL_TILE");
-        const char* st = getenv("CPG_GRU_BWD_DL_STAGES");
-        const int ns = st ? atoi(st) : 3;
-        const int rows = a.row1 - a.row0;
-        const bool r64 = rows % 64 == 0, h64 = a.H % 64 == 0;
-        const long wg64 = (long)(rows / 64) * (a.H / 64) * nd;   // 64 x 64 tiles of the launch
-        if (!t && !st && bwd_dl2_wanted(rows, a.H, nd, bf16_dl)) {
-            if (bf16_dl) launch_dl2<1>(pr, nd, s);
-            else launch_dl2<0>(pr, nd, s);
-            CPG_LAUNCH_CHECK();
-            return 0;
-        }
-        int bm = 32, bn = 32;
-        if (t) {
-            if (!strcmp(t, "64x64")) { bm = 64; bn = 64; }
-            else if (!strcmp(t, "64x32")) { bm = 64; }
-            else if (!strcmp(t, "32x64")) { bn = 64; }
-        } else if (r64 && h64 && wg64 >= 512) {
-            bm = bn = 64;
-        } else if (r64 && wg64 >= 256) {
-            bm = 64;
-        }
-        if (bm == 64 && !r64) bm = 32;
-        if (bn == 64 && !h64) bn = 32;
-#define CPG_DL_PICK(BM, BN)                                                                                              \
-    (bf16_dl ? launch_dl<BM, BN, 3, 1>(pr, nd, s)                                                                        \
-             : ns == 4 ? launch_dl<BM, BN, 4>(pr, nd, s) : ns == 2 ? launch_dl<BM, BN, 2>(pr, nd, s) : launch_dl<BM, BN, 3>(pr, nd, s))
-        if (bm == 64 && bn == 64) CPG_DL_PICK(64, 64);
-        else if (bm == 64) CPG_DL_PICK(64, 32);
-        else if (bn == 64) CPG_DL_PICK(32, 64);
-        else CPG_DL_PICK(32, 32);
+    const BwdPlan pl = bwd_plan(a.row1 - a.row0, a.H, nd, a.row0, vec, have_wt, dense);
+    int rc = 0;
+    if (pl.kind == BK_DL2) {
+        rc = pl.bf16 ? launch_dl2<1>(pr, nd, s) : launch_dl2<0>(pr, nd, s);
+    } else if (pl.kind == BK_DL) {
+#define CPG_DL_PICK(BM, BN) (pl.bf16 ? launch_dl<BM, BN, 1>(pr, nd, s) : launch_dl<BM, BN, 0>(pr, nd, s))
+        if (pl.tile.bm == 64 && pl.tile.bn == 64) rc = CPG_DL_PICK(64, 64);
+        else if (pl.tile.bm == 64) rc = CPG_DL_PICK(64, 32);
+        else if (pl.tile.bn == 64) rc = CPG_DL_PICK(32, 64);
+        else rc = CPG_DL_PICK(32, 32);
 #undef CPG_DL_PICK
-    } else if (c.wt) {
-        launch_bwd_tile<true>(c.tile, pr, nd, vec, s);
+    } else if (pl.tile.bm == 64) {
+        rc = launch_bwd<GB64>(pr, nd, vec, s);
+    } else if (pl.tile.bn == 64) {
+        rc = launch_bwd<GB32>(pr, nd, vec, s);
     } else {
-        launch_bwd_tile<false>(c.tile, pr, nd, vec, s);
+        rc = launch_bwd<GB32N>(pr, nd, vec, s);
     }
+    if (rc) return rc;
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -997,38 +857,24 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
         return snprintf(buf, n, "gru_step_fwd_kernel<%s, %s, %d>", tc, vec ? "true" : "false", cpg_compute_mode_get() == 1 ? 1 : 7);
     }
     if (kind == 1) {
-        const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
-        const bool bf16_dl = c.wt && !c.forced && cpg_compute_mode_get() == 1 && !getenv("CPG_GRU_BWD_TILE");
-        if ((!c.wt || bf16_dl) && !c.forced && vec && have_wt && bwd_dl_shape_ok(0, B, H)) {
-            if (!getenv("CPG_GRU_BWD_DL_TILE") && !getenv("CPG_GRU_BWD_DL_STAGES") && bwd_dl2_wanted(B, H, ndir, bf16_dl))
-                return snprintf(buf, n, "gru_step_bwd_dl2_kernel<%d>", bf16_dl ? 1 : 0);
-            const bool r64 = B % 64 == 0, h64 = H % 64 == 0;
-            const long wg64 = (long)(B / 64) * (H / 64) * ndir;
-            const int bm = (r64 && h64 && wg64 >= 512) || (r64 && wg64 >= 256) ? 64 : 32, bn = (r64 && h64 && wg64 >= 512) ? 64 : 32;
-            return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3, %d>", bm, bn, bf16_dl ? 1 : 0);
-        }
-        switch (c.tile) {
-            case BT_64x32: tc_name<GB64>(tc, sizeof tc); break;
-            case BT_32x64: tc_name<GB32>(tc, sizeof tc); break;
-            case BT_64x64: tc_name<GB64W>(tc, sizeof tc); break;
-            case BT_128x32: tc_name<GB128>(tc, sizeof tc); break;
-            case BT_128x64: tc_name<GB128W>(tc, sizeof tc); break;
-            case BT_32x32: tc_name<GB32N>(tc, sizeof tc); break;
-            case BT_32x32K64: tc_name<GB32K>(tc, sizeof tc); break;
-        }
-        return snprintf(buf, n, "gru_step_bwd_kernel<%s, %s, %s, %d>", tc, vec ? "true" : "false", c.wt ? "true" : "false",
-                        (c.wt && cpg_compute_mode_get() == 1) ? 1 : 7);
+        const BwdPlan pl = bwd_plan(B, H, ndir, 0, vec, have_wt != 0, true);
+        if (pl.kind == BK_DL2) return snprintf(buf, n, "gru_step_bwd_dl2_kernel<%d>", pl.bf16 ? 1 : 0);
+        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3, %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : 0);
+        if (pl.tile.bm == 64) tc_name<GB64>(tc, sizeof tc);
+        else if (pl.tile.bn == 64) tc_name<GB32>(tc, sizeof tc);
+        else tc_name<GB32N>(tc, sizeof tc);
+        return snprintf(buf, n, "gru_step_bwd_kernel<%s, %s>", tc, vec ? "true" : "false");
     }
     return 0;
 }
 
-// 1 when the named step kernel runs its product on the split-bf16 engine (six bf16 MFMAs per block), 0: exact-f32 MFMA.
-// (2: one bf16 MFMA per block - the bf16 compute mode)
+// Product form of the named step kernel: 0 exact-f32 MFMA, 1 split-bf16 engine (six bf16 MFMAs per block), 2 one bf16 MFMA
+// per block (bf16 compute mode).
 CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt) {
-    if (kind == 0) return CPG_STEP_FWD_SPLIT == 7 ? (cpg_compute_mode_get() == 1 ? 2 : 1) : 0;
-    const BwdChoice c = gru_bwd_choice(B, H, ndir, have_wt != 0);
-    if (c.wt) return CPG_STEP_BWD_SPLIT == 7 ? (cpg_compute_mode_get() == 1 ? 2 : 1) : 0;
-    return CPG_STEP_BWD_SPLIT == 7 && (c.tile == BT_64x64 || c.tile == BT_128x64 || c.tile == BT_32x64);  // XC pairs: BV even
+    if (kind == 0) return cpg_compute_mode_get() == 1 ? 2 : 1;
+    const BwdPlan pl = bwd_plan(B, H, ndir, 0, H % 4 == 0, have_wt != 0, true);
+    if (pl.kind != BK_STAGED) return pl.bf16 ? 2 : 0;
+    return pl.tile.bn == 64 ? 1 : 0;   // XC k-row pairs: 64-column tiles run the split engine
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
@@ -1077,7 +923,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
-    if (w_hhT_scratch && !bwd_wants_wt(row_end - row_begin, H, 1, row_begin, step_rows == nullptr)) w_hhT_scratch = nullptr;  // W_hh as stored
+    if (w_hhT_scratch && !bwd_wants_wt(row_end - row_begin, H, row_begin, step_rows == nullptr)) w_hhT_scratch = nullptr;  // W_hh as stored
     if (w_hhT_scratch) {
         int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream);
         if (rc) return rc;
@@ -1153,73 +999,7 @@ CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* d
     return cpg_colsum(dG, 4 * H, T * B, 3 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// ---- one pass over dG for all three input-side reductions (token-grouped sums, column sums, sums over time).
-// Workgroup = (256 dG columns, 32 batch rows over ALL T steps), two waves; wave r owns the 16 rows b0 + 2 i + r.  A lane owns
-// four columns and keeps, in registers, (a) the running sum over time of each of its 16 rows (= the drowc rows, complete - no
-// partials) and (b) one accumulator per token (V <= 24): a row's token is the same for every lane of the wave, so
-// `table[token] += x` is a wave-uniform switch over compile-time register indices - no LDS, no atomics, fixed order.
-// Per workgroup one [V][256] partial of the token table and one [256] partial of the column sums go out;
-// dgi_fused_final_kernel adds the B/32 partials in a fixed order.  dG is read ONCE at HBM rate (the one-hot product + the
-// over-time pass read it twice, 107 + 54 us per sequence at B=2048, H=512; read-modify-write of an LDS table took 211 us,
-// LDS float atomics 583).
-constexpr int DF_ROWS = 32, DF_COLS = 256, DF_VMAX = 24;
-#define CPG_DF_CASE(k) case k: tacc[k] += xv; break;
-__global__ __launch_bounds__(128) void dgi_fused_kernel(const float* dG, const int32_t* tok, int T, int B, int H, int V, int lstm,
-                                                        float* part_tab, float* part_sum, float* drowc) {
-    extern __shared__ __attribute__((aligned(16))) float df_tab[];   // [V + 1][256]: wave 1's table and column sums
-    const int tid = threadIdx.x, c = tid & 63, r = tid >> 6;
-    const int col = blockIdx.x * DF_COLS + 4 * c, b0 = blockIdx.y * DF_ROWS;
-    const int C4 = 4 * H;
-    f32x4 acc[16], tacc[DF_VMAX];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < DF_VMAX; ++k) tacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < T; ++t) {
-        const float* base = dG + ((size_t)t * B + b0 + r) * C4 + col;
-        const int32_t* tk = tok + (size_t)t * B + b0 + r;
-        f32x4 x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const f32x4*>(base + (size_t)2 * i * C4);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const f32x4 xv = x[i];
-            acc[i] += xv;
-            switch (__builtin_amdgcn_readfirstlane(tk[2 * i])) {   // wave-uniform: a scalar branch
-                CPG_DF_CASE(0) CPG_DF_CASE(1) CPG_DF_CASE(2) CPG_DF_CASE(3) CPG_DF_CASE(4) CPG_DF_CASE(5) CPG_DF_CASE(6) CPG_DF_CASE(7)
-                CPG_DF_CASE(8) CPG_DF_CASE(9) CPG_DF_CASE(10) CPG_DF_CASE(11) CPG_DF_CASE(12) CPG_DF_CASE(13) CPG_DF_CASE(14)
-                CPG_DF_CASE(15) CPG_DF_CASE(16) CPG_DF_CASE(17) CPG_DF_CASE(18) CPG_DF_CASE(19) CPG_DF_CASE(20) CPG_DF_CASE(21)
-                CPG_DF_CASE(22) CPG_DF_CASE(23)
-                default: break;
-            }
-        }
-    }
-    // sums over time: drowc[b][dgi column] (the GRU's dhn block, columns [2H,3H) of dG, is not an input-side gradient)
-    f32x4 tot = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool is_dgi = lstm || col < 2 * H || col >= 3 * H;
-    const int NC = lstm ? 4 * H : 3 * H, dcol = (lstm || col < 2 * H) ? col : col - H;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        tot += acc[i];
-        if (drowc && is_dgi) *reinterpret_cast<f32x4*>(drowc + (size_t)(b0 + 2 * i + r) * NC + dcol) = acc[i];
-    }
-    // wave 1 hands its table and its column sums to wave 0 through LDS; wave 0 adds and writes the workgroup's partials
-    if (r == 1) {
-#pragma unroll
-        for (int k = 0; k < DF_VMAX; ++k) *reinterpret_cast<f32x4*>(df_tab + k * DF_COLS + 4 * c) = tacc[k];
-        *reinterpret_cast<f32x4*>(df_tab + DF_VMAX * DF_COLS + 4 * c) = tot;
-    }
-    __syncthreads();
-    if (r == 0) {
-        const size_t chunk = blockIdx.y;
-        *reinterpret_cast<f32x4*>(part_sum + chunk * C4 + col) = tot + *reinterpret_cast<const f32x4*>(df_tab + DF_VMAX * DF_COLS + 4 * c);
-#pragma unroll
-        for (int k = 0; k < DF_VMAX; ++k)
-            if (k < V) *reinterpret_cast<f32x4*>(part_tab + (chunk * V + k) * C4 + col) = tacc[k] + *reinterpret_cast<const f32x4*>(df_tab + k * DF_COLS + 4 * c);
-    }
-}
-#undef CPG_DF_CASE
-// dtab[v][c] (+)= sum over chunks of part_tab[chunk][v][dG column of c];  dsum[c4] (+)= sum over chunks of part_sum[chunk][c4]
+// final reduction of the per-chunk partials of dgi_mfma_kernel (B/DM_ROWS chunks, fixed order)
 __global__ void dgi_fused_final_kernel(const float* part_tab, const float* part_sum, int chunks, int H, int V, int lstm, float* dtab,
                                        float* dsum, int accumulate) {
     const int NC = lstm ? 4 * H : 3 * H, C4 = 4 * H;
@@ -1238,19 +1018,7 @@ __global__ void dgi_fused_final_kernel(const float* part_tab, const float* part_
         dsum[i] = accumulate ? dsum[i] + s : s;
     }
 }
-static size_t dgi_fused_workspace(int B, int H, int V) { return (size_t)(B / DF_ROWS) * (V + 1) * 4 * H * sizeof(float); }
-// Measured at B=2048, H=512, T=25 (per sequence): fused pass 146 + 20 us against one-hot product 139 us (+ 54 us for the
-// over-time sums when drowc is wanted): it pays only when all three reductions are asked for (the decoder: 193 -> 166 us).
-// CPG_DGI_FUSED=0 never, =1 whenever the shape allows.
-static bool dgi_fused_ok(int T, int B, int H, int V, const float* dG, const int32_t* tok, const float* drowc, size_t ws_bytes) {
-    const char* e = getenv("CPG_DGI_FUSED");
-    if (e && atoi(e) == 0) return false;
-    if (!(e && atoi(e) == 1) && !drowc) return false;
-    return tok && V > 0 && V <= DF_VMAX && H % 64 == 0 && B % DF_ROWS == 0 && aligned16(dG) && (!drowc || aligned16(drowc)) &&
-           ws_bytes >= dgi_fused_workspace(B, H, V);
-}
-
-// ---- the same three reductions with the token-grouped sums on the matrix cores: R[v][c] = sum_rows onehot[row][v] dG[row][c] is
+// ---- the three input-side reductions (token-grouped sums, column sums, sums over time) with the token-grouped sums on the matrix cores: R[v][c] = sum_rows onehot[row][v] dG[row][c] is
 // a product with an exact operand (0 / 1), so the exact-f32 MFMA gives f32 sums without any operand split, the one-hot operand is
 // built in registers from the token ids (two compares per lane and k-step), and row V of the operand is all ones: the column
 // sums come out of the same product.  Workgroup = 64 dG columns x 128 batch rows x all T steps, four waves of 32 rows; a lane
@@ -1340,10 +1108,10 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
     }
 }
 static size_t dgi_mfma_workspace(int B, int H, int V) { return (size_t)(B / DM_ROWS) * (V + 1) * 4 * H * sizeof(float); }
-// CPG_DGI_MFMA=0 disables.
+// option dgi_mode = "gemm" keeps the one-hot product + over-time pass (the form of every other shape).
 static bool dgi_mfma_ok(int B, int H, int V, const float* dG, const int32_t* tok, const float* drowc, size_t ws_bytes) {
-    const char* e = getenv("CPG_DGI_MFMA");
-    if (e && atoi(e) == 0) return false;
+    const CpgOptVal& o = cpg_opt(OPT_DGI_MODE);
+    if (o.set && !strcmp(o.s, "gemm")) return false;
     return tok && V > 0 && V <= DM_VMAX && H % 64 == 0 && B % DM_ROWS == 0 && aligned16(dG) && aligned16(tok) &&
            (!drowc || aligned16(drowc)) && ws_bytes >= dgi_mfma_workspace(B, H, V);
 }
@@ -1365,21 +1133,6 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
         const dim3 grid(4 * H / 64, chunks);
         if (drowc) hipLaunchKernelGGL(dgi_mfma_kernel<true>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
         else hipLaunchKernelGGL(dgi_mfma_kernel<false>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
-        CPG_LAUNCH_CHECK();
-        const int m = V * NC > 4 * H ? V * NC : 4 * H;
-        hipLaunchKernelGGL(dgi_fused_final_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, (const float*)part_tab, (const float*)part_sum,
-                           chunks, H, V, lstm, dtab, dsum, accumulate);
-        CPG_LAUNCH_CHECK();
-        return 0;
-    }
-    if ((dtab || dsum) && !(drowc && accumulate) && dgi_fused_ok(T, B, H, V, dG, tok, drowc, workspace_bytes)) {
-        CPG_CHECK_ARG(workspace);
-        const int chunks = B / DF_ROWS;
-        float* part_tab = (float*)workspace;
-        float* part_sum = part_tab + (size_t)chunks * V * 4 * H;
-        const size_t smem = (size_t)(DF_VMAX + 1) * DF_COLS * sizeof(float);
-        hipLaunchKernelGGL(dgi_fused_kernel, dim3(4 * H / DF_COLS, chunks), dim3(128), smem, s, dG, tok, T, B, H, V, lstm, part_tab,
-                           part_sum, drowc);
         CPG_LAUNCH_CHECK();
         const int m = V * NC > 4 * H ? V * NC : 4 * H;
         hipLaunchKernelGGL(dgi_fused_final_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, (const float*)part_tab, (const float*)part_sum,
@@ -1499,7 +1252,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
                                  float* w_hhT_scratch_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
-    if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 2, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
+    if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
     if (w_hhT_scratch_f) {
         int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream);
         if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream);
@@ -1552,452 +1305,3 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------ BPTT as ONE launch ("chain")
-// The per-step backward launches are rounds of 1024 workgroups in lock step: all of them fetch their 36 B / element of
-// epilogue operands, then all of them multiply, then all of them store - the HBM phases and the matrix phase of a launch never
-// overlap, and every launch pays its ramp and its drain (18 us of a 48 us launch at B=2048, H=512: DESIGN.md 9).  Here the
-// same tiles run the WHOLE time loop: workgroup (row tile m, column tile j) needs, for step s, the dgh rows of tile m of step
-// s+1 - written by the column-tile workgroups of ITS row tile only - so the hand-off is an arrival counter per row tile
-// (write-through stores, vmcnt(0), one relaxed agent-scope add per wave; consumers poll relaxed and then read addresses that
-// were never read before in this launch: the placement-independent pattern of csrc/gru_persist.hip), not a grid barrier.
-// Row tiles are independent recurrences and drift apart, so a CU's four workgroups are in different phases; z (.) dH of the
-// workgroup's own elements stays in registers across steps (no dH round trip).  W_hh is not stationary (it is the L2-resident
-// operand it is for the step kernels).  Both directions of a biGRU layer run in the same workgroups, alternating, so the wait
-// for one direction's peers sits under the other direction's product.
-// Needs every workgroup co-resident (cpg_gru_chain_bwd_fits checks the occupancy); waits are bounded (sticky error word).
-struct GruChainDir {
-    const float* w_hh;     // [3H,H]
-    const float* w_hhT;    // [H,3H] or null (WT kernels)
-    const float* hs;       // [(T+1),B,H]
-    const float* gates;    // [T,4,B,H]
-    const float* ext;      // [T,B,H] time-aligned external gradient, or null
-    const float* dh_last;  // [B,H] gradient on the final state, or null
-    float* dG;             // [T,B,4H]
-    float* dh0;            // [B,H] or null
-    int reverse;
-};
-struct GruChainArgs {
-    GruChainDir d[2];
-    unsigned* cnt;  // [nd][row tiles][64 words] arrival counters (first word of each group), zeroed before the launch
-    unsigned* err;  // sticky error word
-    int nd, T, B, H, ep_step;
-};
-
-// Diagnostic builds (tools/ablate_chain.sh; results WRONG by construction): 1 no waits, 2 plain instead of write-through stores,
-// 4 no vmcnt(0) drain ahead of the arrival, 8 no dG stores, 16 no arrivals
-#ifndef CPG_CHAIN_ABLATE
-#define CPG_CHAIN_ABLATE 0
-#endif
-typedef unsigned chain_u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned CHAIN_SPIN_LIMIT = 400000u;
-constexpr int CHAIN_CNT_STRIDE = 64;  // words between arrival counters
-
-__device__ __forceinline__ void chain_wait(unsigned* p, unsigned target, unsigned* err, bool& dead) {
-    if (dead) return;
-    unsigned spins = 0;
-    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > CHAIN_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dead = true;
-            return;
-        }
-    }
-    asm volatile("" ::: "memory");
-}
-
-template <class TC, bool WT, int PREC>
-__global__ __launch_bounds__(256) void gru_seq_bwd_chain_kernel(GruChainArgs g) {
-    using Loop = BwdLoop<TC, true, WT, PREC>;
-    int bx, by, bz;
-    xcd_tile_order(bx, by, bz);
-    const int H = g.H, B = g.B, T = g.T;
-    const int m0 = by * TC::BM, j0 = bx * TC::BN;
-    const size_t BH = (size_t)B * H;
-    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* const tb = cpg_smem + Loop::smem_bytes() / sizeof(float) + wave * 256;
-    const int rb0 = m0 + (wave / TC::WN) * TC::WTM + (lane >> 2), cb0 = j0 + (wave % TC::WN) * TC::WTN + 4 * (lane & 3);
-    const unsigned peers = gridDim.x;  // arrivals per row tile, direction and step: one per column-tile workgroup
-    const int hb = blockIdx.x + gridDim.x * blockIdx.y;
-    const int phase = ((hb >> 3) + (hb >> 8)) & 3, last = ((3 * H + TC::BK - 1) / TC::BK - 1) & ~1;
-    const int hook_kt = min(phase * g.ep_step, last);
-    f32x4 zdh[2][TC::MI][TC::NI];  // z_{s+1} (.) dH_{s+1} of this lane's own elements, per direction
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TC::NI; ++ni) zdh[d][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool dead = false;
-
-    for (int p = T - 1; p >= -1; --p) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            if (d >= g.nd) break;
-            const GruChainDir& D = g.d[d];
-            if (p < 0 && !D.dh0) continue;
-            // a counter per (direction, row tile), each in its own 256 bytes: arrivals and polls of different row tiles do not
-            // queue on one memory channel (4096 adds per step on two adjacent lines cost 90 us per step)
-            unsigned* const cnt = g.cnt + ((size_t)d * gridDim.y + by) * CHAIN_CNT_STRIDE;
-            const int t = p < 0 ? -1 : (D.reverse ? T - 1 - p : p);
-            const int prev_t = (p == T - 1) ? -1 : (D.reverse ? T - 2 - p : p + 1);
-            const float* const gates = t >= 0 ? D.gates + (size_t)t * 4 * BH : nullptr;
-            const float* const h_prev = t >= 0 ? D.hs + (size_t)(D.reverse ? t + 1 : t) * BH : nullptr;
-            const float* const ext = (t >= 0 && D.ext) ? D.ext + (size_t)t * BH : nullptr;
-            const float* const ext2 = (p == T - 1) ? D.dh_last : nullptr;
-
-            f32x4 acc[TC::MI][TC::NI], pre[TC::MI][TC::NI], sv[TC::MI][TC::NI][5];
-#pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto load_ep = [&]() {
-#pragma unroll
-                for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TC::NI; ++ni) {
-                        const int row = rb0 + mi * 16, col = cb0 + ni * 16;
-                        const size_t o = (size_t)((row < B) ? row : 0) * H + ((col < H) ? col : 0);
-                        f32x4 q = zdh[d][mi][ni];   // exact zero on the first step: same sums as the step kernels
-                        if (ext) q += *reinterpret_cast<const f32x4*>(ext + o);
-                        if (ext2) q += *reinterpret_cast<const f32x4*>(ext2 + o);
-                        pre[mi][ni] = q;
-                        if (gates) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) sv[mi][ni][k] = *reinterpret_cast<const f32x4*>(gates + k * BH + o);
-                            sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(h_prev + o);
-                        }
-                    }
-            };
-            if (prev_t >= 0) {
-                // one wave polls for the workgroup (the others sit in the barrier: no polling traffic from them)
-                if (!(CPG_CHAIN_ABLATE & 1)) {
-                    if (wave == 0) chain_wait(cnt, peers * (unsigned)(T - 1 - p), g.err, dead);
-                    __syncthreads();
-                }
-                OpA a{D.dG + (size_t)prev_t * B * 4 * H, 4 * H, m0, B, nullptr, 1.f};
-                OpB b{WT ? D.w_hhT : D.w_hh, WT ? 3 * H : H, j0, H, 0, nullptr, 1.f};
-                Loop::run(a, b, 3 * H, acc, hook_kt, load_ep);
-            } else {
-                load_ep();
-            }
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-                t >= 0 ? D.dG + (size_t)t * B * 4 * H : D.dG, 0, (unsigned)((size_t)B * 4 * H * sizeof(float)), 0x00020000);
-#pragma unroll
-            for (int mi = 0; mi < TC::MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC::NI; ++ni) {
-                    const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
-                    const int row = rb0 + mi * 16, col = cb0 + ni * 16;
-                    if (row >= B || col >= H) continue;
-                    if (t < 0) {
-                        *reinterpret_cast<f32x4*>(D.dh0 + (size_t)row * H + col) = dh;
-                        continue;
-                    }
-                    const f32x4 rgt = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
-                    const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
-                    const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
-                    const f32x4 dr_pre = dn_pre * hn * rgt * (1.f - rgt);
-                    zdh[d][mi][ni] = zg * dh;
-                    const unsigned o = (unsigned)(((size_t)row * 4 * H + col) * sizeof(float));
-                    const unsigned hb4 = (unsigned)(H * sizeof(float));
-                    // write-through (sc1): the consumers of these rows run on other CUs and read them after the arrival below
-                    constexpr int AUX = (CPG_CHAIN_ABLATE & 2) ? 0 : 16;
-                    if (CPG_CHAIN_ABLATE & 8) continue;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dr_pre), rg, o, 0, AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dz_pre), rg, o + hb4, 0, AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre * rgt), rg, o + 2 * hb4, 0, AUX);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre), rg, o + 3 * hb4, 0, AUX);
-                }
-            if (t >= 0 && p > 0 || (t >= 0 && D.dh0)) {  // somebody will wait for this step
-                // every wave drains its stores, then ONE arrival for the workgroup
-                if (!(CPG_CHAIN_ABLATE & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0 && !(CPG_CHAIN_ABLATE & 16))
-                    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-// The same chain on the direct-to-LDS main loop (DlLoop, gemm_core.h; f32-grade mode): BM x BN tiles of 2 x 2 waves, W_hh^T
-// handed over.  `stagger`: row tiles with an odd index start that many 10-ns ticks late, so that the two workgroups a CU holds
-// (different row tiles = independent chains) run their product and their epilogue / hand-off phases against each other.
-template <int BM, int BN, int PREC = 0>
-__global__ __launch_bounds__(256) void gru_seq_bwd_chain_dl_kernel(GruChainArgs g, unsigned stagger) {
-    using DL = DlLoop<BM, BN, 3, PREC>;
-    constexpr int MI = DL::MI, NI = DL::NI;
-    int bx, by, bz;
-    xcd_tile_order(bx, by, bz);
-    const int H = g.H, B = g.B, T = g.T;
-    const int m0 = by * BM, j0 = bx * BN;
-    const size_t BH = (size_t)B * H;
-    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
-    const unsigned peers = gridDim.x;
-    const int KT = 3 * H / 32;
-    const int hb = blockIdx.x + gridDim.x * blockIdx.y;
-    const int hook_kt = min((((hb >> 3) + (hb >> 8)) & 3) * g.ep_step, KT - 1);
-    f32x4 zdh[2][MI][NI];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) zdh[d][mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool dead = false;
-    if (stagger && (by & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < stagger) __builtin_amdgcn_s_sleep(8);
-    }
-    for (int p = T - 1; p >= -1; --p) {
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            if (d >= g.nd) break;
-            const GruChainDir& D = g.d[d];
-            if (p < 0 && !D.dh0) continue;
-            unsigned* const cnt = g.cnt + ((size_t)d * gridDim.y + by) * CHAIN_CNT_STRIDE;
-            const int t = p < 0 ? -1 : (D.reverse ? T - 1 - p : p);
-            const int prev_t = (p == T - 1) ? -1 : (D.reverse ? T - 2 - p : p + 1);
-            const float* const gates = t >= 0 ? D.gates + (size_t)t * 4 * BH : nullptr;
-            const float* const h_prev = t >= 0 ? D.hs + (size_t)(D.reverse ? t + 1 : t) * BH : nullptr;
-            const float* const ext = (t >= 0 && D.ext) ? D.ext + (size_t)t * BH : nullptr;
-            const float* const ext2 = (p == T - 1) ? D.dh_last : nullptr;
-            f32x4 acc[MI][NI], pre[MI][NI], sv[MI][NI][5];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto load_ep = [&]() {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
-                        f32x4 q = zdh[d][mi][ni];
-                        if (ext) q += *reinterpret_cast<const f32x4*>(ext + o);
-                        if (ext2) q += *reinterpret_cast<const f32x4*>(ext2 + o);
-                        pre[mi][ni] = q;
-                        if (gates) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) sv[mi][ni][k] = *reinterpret_cast<const f32x4*>(gates + k * BH + o);
-                            sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(h_prev + o);
-                        }
-                    }
-            };
-            if (prev_t >= 0) {
-                if (wave == 0) chain_wait(cnt, peers * (unsigned)(T - 1 - p), g.err, dead);
-                __syncthreads();
-                DL::run(D.dG + ((size_t)prev_t * B + m0) * 4 * H, (size_t)4 * H, D.w_hhT + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem,
-                        acc, hook_kt, load_ep);
-            } else {
-                load_ep();
-            }
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-                t >= 0 ? D.dG + (size_t)t * B * 4 * H : D.dG, 0, (unsigned)((size_t)B * 4 * H * sizeof(float)), 0x00020000);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const f32x4 dh = acc_block_to_rows(tb, acc[mi][ni], lane) + pre[mi][ni];
-                    const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
-                    if (t < 0) {
-                        *reinterpret_cast<f32x4*>(D.dh0 + (size_t)row * H + col) = dh;
-                        continue;
-                    }
-                    const f32x4 rgt = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
-                    const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
-                    const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
-                    const f32x4 dr_pre = dn_pre * hn * rgt * (1.f - rgt);
-                    zdh[d][mi][ni] = zg * dh;
-                    const unsigned o = (unsigned)(((size_t)row * 4 * H + col) * sizeof(float));
-                    const unsigned hb4 = (unsigned)(H * sizeof(float));
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dr_pre), rg, o, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dz_pre), rg, o + hb4, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre * rgt), rg, o + 2 * hb4, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(chain_u32x4, dn_pre), rg, o + 3 * hb4, 0, 16);
-                }
-            if (t >= 0 && p > 0 || (t >= 0 && D.dh0)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
-template <int BM, int BN, int PREC = 0>
-static int chain_dl_resident_blocks() {
-    static int cached = -1;
-    if (cached >= 0) return cached;
-    const void* fn = reinterpret_cast<const void*>(gru_seq_bwd_chain_dl_kernel<BM, BN, PREC>);
-    const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t pr;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem) != hipSuccess) return 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-    cached = per_cu * pr.multiProcessorCount;
-    return cached;
-}
-
-using GC32 = GB32N;   // exact-f32 product, 32 x 32 tiles: the f32-grade choice of the step kernels (gru_bwd_choice)
-using GC64 = GB64;    // bf16 compute mode: W_hh^T path, 64 x 32 tiles
-
-template <class TC, bool WT, int PREC>
-static size_t chain_smem() { return BwdLoop<TC, true, WT, PREC>::smem_bytes() + 4 * 256 * sizeof(float); }
-
-template <class TC, bool WT, int PREC>
-static int chain_resident_blocks() {  // workgroups of this kernel the device holds at once
-    static int cached = -1;
-    if (cached >= 0) return cached;
-    const void* fn = reinterpret_cast<const void*>(gru_seq_bwd_chain_kernel<TC, WT, PREC>);
-    const size_t smem = chain_smem<TC, WT, PREC>();
-    if (smem > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t pr;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, smem) != hipSuccess) return 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-    cached = per_cu * pr.multiProcessorCount;
-    return cached;
-}
-
-static bool chain_bf16() { return cpg_compute_mode_get() == 1; }
-
-// 1 when the one-launch BPTT covers (T, B, H) on this device: 16-byte row layout (H % 4 == 0), one dG step slice addressable
-// through a 32-bit buffer range, every workgroup co-resident.
-CPG_EXPORT int cpg_gru_chain_bwd_covers(int T, int B, int H) {
-    if (T <= 0 || B <= 0 || H < 4 || H % 4 != 0) return 0;
-    if ((size_t)B * 4 * H * sizeof(float) >= ((size_t)1 << 32)) return 0;
-    const bool bf = chain_bf16();
-    const long wgs = bf ? (long)cdiv(H, GC64::BN) * cdiv(B, GC64::BM) : (long)cdiv(H, GC32::BN) * cdiv(B, GC32::BM);
-    const int cap = bf ? chain_resident_blocks<GC64, true, 1>() : chain_resident_blocks<GC32, false, 7>();
-    return wgs <= cap;
-}
-// Policy: measured on MI355X at B=2048, H=512 the one-launch form takes 46-48 us per step (pairs 87) against 46.6-48 (pairs
-// 84) for the per-step launches - the step is bound by what a workgroup does, not by the launch boundaries -
-// so it runs only when CPG_GRU_BWD_CHAIN=1 asks for it.
-CPG_EXPORT int cpg_gru_chain_bwd_fits(int T, int B, int H) {
-    const char* e = getenv("CPG_GRU_BWD_CHAIN");
-    if (!e || atoi(e) == 0) return 0;
-    return cpg_gru_chain_bwd_covers(T, B, H);
-}
-
-// counters [2 directions][row tiles of 32][256 bytes] + the sticky error word
-static size_t chain_cnt_words(int B) { return (size_t)2 * cdiv(B, 32) * CHAIN_CNT_STRIDE; }
-CPG_EXPORT size_t cpg_gru_chain_scratch_bytes(int B) { return (chain_cnt_words(B) + CHAIN_CNT_STRIDE) * sizeof(unsigned); }
-
-static int chain_launch(GruChainArgs& g, void* sync_scratch, float* wT0, float* wT1, hipStream_t s) {
-    const bool bf = chain_bf16();
-    const int bm = bf ? GC64::BM : GC32::BM, bn = bf ? GC64::BN : GC32::BN;
-    const int nrt = cdiv(g.B, bm);
-    for (int d = 0; d < g.nd; ++d) {
-        const void* ptrs[] = {g.d[d].w_hh, g.d[d].hs, g.d[d].gates, g.d[d].ext, g.d[d].dh_last, g.d[d].dG, g.d[d].dh0};
-        for (const void* q : ptrs)
-            if (q && !aligned16(q)) {
-                cpg_set_error("cpg_gru_*_bwd_chain: operands must be 16-byte aligned");
-                return -2;
-            }
-    }
-    if (bf) {
-        float* wt[2] = {wT0, wT1};
-        for (int d = 0; d < g.nd; ++d) {
-            if (!wt[d]) {
-                cpg_set_error("cpg_gru_*_bwd_chain: the bf16 compute mode needs the W_hh^T scratch");
-                return -2;
-            }
-            int rc = transpose_w(g.d[d].w_hh, g.H, wt[d], s);
-            if (rc) return rc;
-            g.d[d].w_hhT = wt[d];
-        }
-    }
-    g.cnt = (unsigned*)sync_scratch;
-    g.err = g.cnt + chain_cnt_words(g.B);
-    CPG_HIP(hipMemsetAsync(sync_scratch, 0, chain_cnt_words(g.B) * sizeof(unsigned), s));  // the error word is sticky
-    g.ep_step = bwd_ep_step(g.H);
-    {   // direct-to-LDS form (either compute mode; full 64-row tiles, W_hh^T scratch handed over): CPG_GRU_BWD_CHAIN_DL=0 disables
-        const char* e = getenv("CPG_GRU_BWD_CHAIN_DL");
-        float* wt[2] = {wT0, wT1};
-        bool ok = !(e && atoi(e) == 0) && g.B % 64 == 0 && g.H % 32 == 0 && bwd_dl_shape_ok(0, g.B, g.H);
-        for (int d = 0; d < g.nd; ++d) ok = ok && wt[d] && aligned16(wt[d]);
-        // 64 x 32 tiles (64 x 64 leave one workgroup per CU at B=2048, H=512: nothing to run out of phase with)
-        const long wgs = ok ? (long)(g.B / 64) * (g.H / 32) : 0;
-        if (ok && wgs <= (bf ? chain_dl_resident_blocks<64, 32, 1>() : chain_dl_resident_blocks<64, 32>())) {
-            if (!bf)   // (the bf16 mode has transposed above)
-                for (int d = 0; d < g.nd; ++d) {
-                    int rc = transpose_w(g.d[d].w_hh, g.H, wt[d], s);
-                    if (rc) return rc;
-                    g.d[d].w_hhT = wt[d];
-                }
-            const char* st = getenv("CPG_GRU_BWD_CHAIN_STAGGER");   // 10-ns ticks; default: none
-            const unsigned stagger = st ? (unsigned)atoi(st) : 0u;
-            const dim3 grid2(g.H / 32, g.B / 64, 1);
-            const size_t smem = (DlLoop<64, 32, 3>::smem_floats() + 4 * 256) * sizeof(float);
-            if (bf) hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 32, 1>), grid2, dim3(256), smem, s, g, stagger);
-            else hipLaunchKernelGGL((gru_seq_bwd_chain_dl_kernel<64, 32>), grid2, dim3(256), smem, s, g, stagger);
-            CPG_LAUNCH_CHECK();
-            return 0;
-        }
-    }
-    const dim3 grid(cdiv(g.H, bn), nrt, 1);
-    if (bf) {
-        (void)chain_resident_blocks<GC64, true, 1>();  // sets the dynamic-LDS attribute once
-        const size_t smem = chain_smem<GC64, true, 1>();
-        hipLaunchKernelGGL((gru_seq_bwd_chain_kernel<GC64, true, 1>), grid, dim3(256), smem, s, g);
-    } else {
-        (void)chain_resident_blocks<GC32, false, 7>();
-        const size_t smem = chain_smem<GC32, false, 7>();
-        hipLaunchKernelGGL((gru_seq_bwd_chain_kernel<GC32, false, 7>), grid, dim3(256), smem, s, g);
-    }
-    CPG_LAUNCH_CHECK();
-    return 0;
-}
-
-// Arguments and results as cpg_gru_seq_bwd over all rows of a dense batch; sync_scratch: cpg_gru_chain_scratch_bytes(B) bytes,
-// zeroed by the caller when allocated.  w_hhT_scratch [H,3H]: needed in the bf16 compute mode only.
-CPG_EXPORT int cpg_gru_seq_bwd_chain(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
-                                     const float* dhs_ext, const float* dh_last, float* dG, float* dh0, float* w_hhT_scratch,
-                                     void* sync_scratch, void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && sync_scratch);
-    if (!cpg_gru_chain_bwd_covers(T, B, H)) {
-        cpg_set_error("cpg_gru_seq_bwd_chain: T=%d B=%d H=%d is not covered on this device", T, B, H);
-        return -5;
-    }
-    GruChainArgs g;
-    g.nd = 1; g.T = T; g.B = B; g.H = H;
-    g.d[0] = GruChainDir{w_hh, nullptr, hs, gates, dhs_ext, dh_last, dG, dh0, reverse};
-    g.d[1] = g.d[0];
-    return chain_launch(g, sync_scratch, w_hhT_scratch, nullptr, (hipStream_t)stream);
-}
-
-// Both directions of a biGRU layer (arguments as cpg_gru_biseq_bwd) in one launch.
-CPG_EXPORT int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
-                                       const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                                       const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
-                                       float* dG_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* sync_scratch,
-                                       void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r && sync_scratch);
-    if (!cpg_gru_chain_bwd_covers(T, B, H)) {
-        cpg_set_error("cpg_gru_biseq_bwd_chain: T=%d B=%d H=%d is not covered on this device", T, B, H);
-        return -5;
-    }
-    GruChainArgs g;
-    g.nd = 2; g.T = T; g.B = B; g.H = H;
-    g.d[0] = GruChainDir{w_hh_f, nullptr, hs_f, gates_f, dhs_ext_f, dh_last_f, dG_f, nullptr, 0};
-    g.d[1] = GruChainDir{w_hh_r, nullptr, hs_r, gates_r, dhs_ext_r, dh_last_r, dG_r, nullptr, 1};
-    return chain_launch(g, sync_scratch, w_hhT_scratch_f, w_hhT_scratch_r, (hipStream_t)stream);
-}
-
-// 0 = no wait has timed out since the scratch was zeroed (synchronises the stream)
-CPG_EXPORT int cpg_gru_chain_status(int B, const void* sync_scratch, void* stream) {
-    CPG_CHECK_ARG(sync_scratch && B > 0);
-    unsigned v = 0;
-    CPG_HIP(hipMemcpyAsync(&v, (const unsigned*)sync_scratch + chain_cnt_words(B), sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    CPG_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return (int)v;
-}

@@ -28,6 +28,8 @@
 #include "gemm_core.h"
 #include "cpg_internal.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 #ifndef CPG_PERSIST_ACQUIRE
 #define CPG_PERSIST_ACQUIRE 0
@@ -51,6 +53,23 @@
 
 #ifndef CPG_PERSIST_FAST_CELL
 #define CPG_PERSIST_FAST_CELL 0
+#endif
+// Diagnostic builds only (-DCPG_DIAG -DCPG_PERSIST_TRACE=1, tools/persist_trace.py): every wave writes 8 time stamps (10-ns
+// ticks) per step into a trace area behind the exchange slots - where a step's time goes, wave by wave.
+#ifndef CPG_PERSIST_TRACE
+#define CPG_PERSIST_TRACE 0
+#endif
+#if CPG_PERSIST_TRACE && !defined(CPG_DIAG)
+#error "CPG_PERSIST_TRACE needs -DCPG_DIAG"
+#endif
+#if CPG_PERSIST_TRACE
+#define P_STAMP(i)                                                                                                       \
+    do {                                                                                                                 \
+        const unsigned long long t__ = __builtin_amdgcn_s_memrealtime();                                                 \
+        if (lane == 0) a.trace[(((size_t)blockIdx.x * P_WAVES + wave) * T + p) * 8 + (i)] = t__;                         \
+    } while (0)
+#else
+#define P_STAMP(i) do {} while (0)
 #endif
 
 namespace {
@@ -84,10 +103,6 @@ constexpr int P_CT = 16;          // hidden units per workgroup
 #define CPG_PERSIST_DEPTH 3       // k-blocks of the state operand in flight per wave (8 waves: f32-grade 21.8 / 21.7 / 22.0 us per step at
 #endif                            // depth 2 / 3 / 4; bf16 mode 10.5 / 10.0 / 10.1)
 constexpr int P_DEPTH = CPG_PERSIST_DEPTH;
-#ifndef CPG_PERSIST_BWD_DEPTH
-#define CPG_PERSIST_BWD_DEPTH 4   // the backward k-block is a third of the forward's work: deeper ring for the same latency cover
-#endif
-constexpr int PB_DEPTH = CPG_PERSIST_BWD_DEPTH;
 constexpr int P_WAVES = CPG_PERSIST_WAVES;
 constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
@@ -101,9 +116,6 @@ constexpr int P_TBW = CPG_PERSIST_TBW;  // words per row of the per-wave 16x16 t
 // other's epilogue phase (gate / state traffic, cell arithmetic) instead of both doing the same thing at the same time.
 #ifndef CPG_PERSIST_PHASE_FWD
 #define CPG_PERSIST_PHASE_FWD 0
-#endif
-#ifndef CPG_PERSIST_PHASE_BWD
-#define CPG_PERSIST_PHASE_BWD 0
 #endif
 #ifndef CPG_PERSIST_CNT_STRIDE
 #define CPG_PERSIST_CNT_STRIDE 64  // words between arrival counters: one 256-byte line each, so the adds and polls of different
@@ -129,6 +141,9 @@ struct PFwdArgs {
                            // A-fragment load (16 rows x 32 k of one plane) is ONE contiguous KB.  (With rows H apart the 32
                            // CUs of an XCD that read the same tile at the same time camped on a few L2 channels: 62.8 us/step.)
     int T, B, H, reverse, groups, S;  // S: words per plane row (H/2 data + pad so that S % 64 == 8)
+#if CPG_PERSIST_TRACE
+    unsigned long long* trace;        // [workgroups][waves][T][8]
+#endif
 };
 
 __device__ __forceinline__ void phase_delay(int wave, unsigned ticks) {
@@ -141,8 +156,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-// Wait until *p >= target (relaxed agent-scope polls: every lane reads the same word).  Bounded: on timeout the error
-// word is set and the wave carries on with whatever is in memory - the run is wrong, but it ends.
+// Wait until *p >= target (relaxed agent-scope polls: every lane reads the same word).  Bounded: on timeout the sticky error
+// word is set and the wave is `dead`: it stops waiting, and everything it stores from then on is NaN (state slab, saved
+// gates, exchange planes), so the failure reaches the loss / the decoded ids instead of passing as plausible numbers.
 __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, bool& dead) {
     if (dead) return false;
     unsigned spins = 0;
@@ -312,6 +328,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         const unsigned in_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p : (p & 1)) * 3u * plane_bytes;
         const unsigned out_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p + 1 : ((p + 1) & 1)) * 3u * plane_bytes;
 
+        P_STAMP(0);
         // input-side pre-activations of this step: independent of the recurrence, fetched before the wait
         float gi[P_MI][4][3];
 #pragma unroll
@@ -332,6 +349,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             }
 
         if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, dead);
+        P_STAMP(1);
         if (CPG_PERSIST_DEFER) flush();
 #if CPG_PERSIST_ACQUIRE
         // plain (L2-allocating) loads behind ONE agent-scope acquire: the 32 column-tile workgroups of a row tile read the
@@ -398,9 +416,11 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 if (kb + d < KB) {
                     if (kb + d + P_DEPTH - 1 < KB && !(CPG_PERSIST_ABLATE & 2)) load(buf[(d + P_DEPTH - 1) % P_DEPTH], kb + d + P_DEPTH - 1);
                     compute(buf[d], kb + d);
+                    if (kb + d == 0) P_STAMP(2);
                 }
             }
         }
+        P_STAMP(3);
 
         // ---- cell (same formulas and association as gru_step_fwd_kernel)
 #pragma unroll
@@ -418,8 +438,10 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 ng[mi][r] = p_tanh(gi[mi][r][2] + rg[mi][r] * hn[mi][r]);
                 }
                 hprev[mi][r] = (1.f - zg[mi][r]) * ng[mi][r] + zg[mi][r] * hprev[mi][r];
+                if (dead) hprev[mi][r] = rg[mi][r] = __builtin_nanf("");   // a timed-out wait: make the damage visible
             }
 
+        P_STAMP(4);
         // ---- publish h_t (split planes, write-through), drain, one arrival per wave; the f32 slab goes out behind it
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi) {
@@ -430,194 +452,13 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                              out_off + (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P_STAMP(5);
         if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_tt = tt;
         if (!CPG_PERSIST_DEFER) flush();
+        P_STAMP(6);
     }
     if (CPG_PERSIST_DEFER) flush();
-}
-
-// ------------------------------------------------------------------------------------------------ backward (BPTT)
-// The same decomposition for the backward recurrence  dH_s = ext_s + z_{s+1} (.) dH_{s+1} + dgh_{s+1} W_hh  (csrc/gru.hip,
-// gru_step_bwd_kernel): a workgroup owns 16 hidden units j for 256 rows and keeps W_hh[:, j]^T - all 3H contraction rows for
-// its 16 output columns - in LDS as bf16 planes (16 x 3H x 6 B = 147 KB at H = 512).  What the column-tile workgroups of a
-// row tile exchange per step is dgh = (dr_pre, dz_pre, d(W_hn h + b_hn)) [rows, 3H], already split, in per-step slots
-// laid out [k-block][row][32 k]; z (.) dH of the wave's own elements stays in registers.  The cell backward runs in ROW
-// layout (one transposition of the 16x16 accumulator tile per row block, then 16-byte loads of the saved gates / h_prev /
-// external gradient and 16-byte stores of dG).  Same formulas, same product order as the per-step kernels.
-struct PBwdArgs {
-    const float* w_hh;      // [3H,H]
-    const float* hs;        // [(T+1),B,H] state slab of the forward pass
-    const float* gates;     // [T,4,B,H]
-    const float* dhs_ext;   // [T,B,H] time-aligned gradients on the step outputs, or null
-    const float* dh_last;   // [B,H] gradient on the final state, or null
-    float* dG;              // [T,B,4H]
-    float* dh0;             // [B,H] gradient of the initial state, or null
-    unsigned* cnt;
-    unsigned* err;
-    uint16_t* xch;          // [T slots][3 planes][3H/32 k-blocks][B][32] bf16
-    int T, B, H, reverse, groups, S;   // S: words per plane row (3H/2 data + pad, S % 64 == 8)
-};
-
-// row-layout tile (lane -> row l>>2, 4 columns) of one of the three dgh components -> exchange planes
-template <int NP>
-__global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_bwd_persist_kernel(PBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t psm[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.x % a.groups, ct = blockIdx.x / a.groups;
-    const int H = a.H, B = a.B, T = a.T, S = a.S;
-    const int j0 = ct * P_CT;
-    const int NCT = H / P_CT, KB = 3 * H / 32;
-    const int PLW = P_CT * S;
-    uint32_t* const planes = psm;
-    float* const tb = reinterpret_cast<float*>(psm + NP * PLW) + wave * (16 * P_TBW);
-
-    // ---- W_hh[:, j0..j0+16)^T -> bf16 planes in LDS, once per sequence: plane[n = local column][k pair]
-    for (int idx = tid; idx < P_CT * (3 * H / 2); idx += P_WAVES * 64) {
-        const int kp = idx / P_CT, n = idx - kp * P_CT;   // consecutive threads -> consecutive columns of one k row
-        const float v0 = a.w_hh[(size_t)(2 * kp) * H + j0 + n], v1 = a.w_hh[(size_t)(2 * kp + 1) * H + j0 + n];
-        uint32_t w0, w1 = 0, w2 = 0;
-        if (NP == 3) split3_pair(v0, v1, w0, w1, w2);
-        else w0 = cvt_pk_bf16(v0, v1);
-        planes[n * S + kp] = w0;
-        if (NP == 3) {
-            planes[PLW + n * S + kp] = w1;
-            planes[2 * PLW + n * S + kp] = w2;
-        }
-    }
-    __syncthreads();
-
-    const int rt = g * P_WAVES + wave;
-    const int row0 = rt * P_WROWS;
-    if (row0 >= B) return;
-    phase_delay(wave, CPG_PERSIST_PHASE_BWD);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int srow = lane >> 2, scq = lane & 3;
-    const size_t BH = (size_t)B * H;
-    const unsigned plane_bytes = (unsigned)(BH * 3 * 2), kb_bytes = (unsigned)B * 64u;   // one plane of dgh [B,3H] bf16
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xch, (unsigned)T * 3u * plane_bytes);
-    bool dead = false;
-
-    int aoff[P_MI];
-#pragma unroll
-    for (int mi = 0; mi < P_MI; ++mi) aoff[mi] = min(row0 + 16 * mi + l15, B - 1) * 64 + 16 * lq;
-    const uint32_t* const bbase = planes + l15 * S + 4 * lq;
-
-    f32x4 zdh[P_MI];   // z_{s+1} (.) dH_{s+1} of this wave's own elements, row layout
-#pragma unroll
-    for (int mi = 0; mi < P_MI; ++mi) zdh[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // processing index p runs T-1 .. 0 (and one closing product for dh0); time t of index p: forward p, reverse T-1-p
-    for (int p = T - 1; p >= (a.dh0 ? -1 : 0); --p) {
-        const bool closing = p < 0;
-        const int t = closing ? 0 : (a.reverse ? T - 1 - p : p);
-        const int step = T - 1 - p;            // 0 for the first processed step; slot `step` receives this step's dgh
-
-        // operands of the cell backward that do not depend on the recurrence: fetched before the wait (row layout, 16 B)
-        f32x4 sv[P_MI][5], ext[P_MI];
-#pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi) {
-            const int row = min(row0 + 16 * mi + srow, B - 1);
-            const size_t o = (size_t)row * H + j0 + 4 * scq;
-            f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!closing) {
-                const float* gb = a.gates + (size_t)t * 4 * BH + o;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sv[mi][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gb + q * BH));
-                sv[mi][4] = *reinterpret_cast<const f32x4*>(a.hs + (size_t)(a.reverse ? t + 1 : t) * BH + o);   // h_prev
-                if (a.dhs_ext) e = *reinterpret_cast<const f32x4*>(a.dhs_ext + (size_t)t * BH + o);
-                if (a.dh_last && step == 0) e += *reinterpret_cast<const f32x4*>(a.dh_last + o);
-            }
-            ext[mi] = e;
-        }
-
-        f32x4 acc[P_MI];
-#pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (step > 0) {
-            if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * step), a.err, dead);
-            const unsigned in_off = (unsigned)(step - 1) * 3u * plane_bytes;
-            u32x4 buf[PB_DEPTH][P_MI][NP];
-            const int rot = CPG_PERSIST_ROTATE ? (ct * KB) / NCT : 0;   // see the forward kernel: spread the readers over the L2 channels
-            auto load = [&](u32x4 (&b)[P_MI][NP], int kbi) {
-                int kb = kbi + rot;
-                kb = kb >= KB ? kb - KB : kb;
-                if ((CPG_PERSIST_ABLATE & 2) && kbi >= PB_DEPTH) return;
-#pragma unroll
-                for (int mi = 0; mi < P_MI; ++mi)
-#pragma unroll
-                    for (int pl = 0; pl < NP; ++pl)
-                        b[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes, 0);
-            };
-            auto compute = [&](const u32x4 (&b)[P_MI][NP], int kbi) {
-                int kb = kbi + rot;
-                kb = kb >= KB ? kb - KB : kb;
-                cpg_bf16x8 fb[NP];
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) fb[pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + kb * 16);
-                constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-                if (CPG_PERSIST_ABLATE & 4) {
-#pragma unroll
-                    for (int mi = 0; mi < P_MI; ++mi) acc[mi] += __builtin_bit_cast(f32x4, b[mi][0]) * __builtin_bit_cast(f32x4, fb[0]);
-                    return;
-                }
-#pragma unroll
-                for (int tm = (NP == 3 ? 0 : 5); tm < 6; ++tm)
-#pragma unroll
-                    for (int mi = 0; mi < P_MI; ++mi)
-                        acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, b[mi][NP == 3 ? TA[tm] : 0]),
-                                                                          fb[NP == 3 ? TB[tm] : 0], acc[mi], 0, 0, 0);
-            };
-#pragma unroll
-            for (int d = 0; d < PB_DEPTH - 1; ++d)
-                if (d < KB) load(buf[d], d);
-            for (int kb = 0; kb < KB; kb += PB_DEPTH) {
-#pragma unroll
-                for (int d = 0; d < PB_DEPTH; ++d) {
-                    if (kb + d < KB) {
-                        if (kb + d + PB_DEPTH - 1 < KB) load(buf[(d + PB_DEPTH - 1) % PB_DEPTH], kb + d + PB_DEPTH - 1);
-                        compute(buf[d], kb + d);
-                    }
-                }
-            }
-        }
-
-        // ---- dH_s and the cell backward, row layout
-        const unsigned out_off = (unsigned)step * 3u * plane_bytes;
-#pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi) {
-            float av[4] = {acc[mi][0], acc[mi][1], acc[mi][2], acc[mi][3]};
-            const f32x4 dh = acc_to_rows(tb, av, lane) + (zdh[mi] + ext[mi]);   // association of gru_step_bwd_kernel: acc + pre
-            const int row = row0 + 16 * mi + srow;
-            const bool ok = row < B;
-            if (closing) {
-                if (ok) *reinterpret_cast<f32x4*>(a.dh0 + (size_t)row * H + j0 + 4 * scq) = dh;
-                continue;
-            }
-            const f32x4 rg = sv[mi][0], zg = sv[mi][1], ng = sv[mi][2], hn = sv[mi][3], hp = sv[mi][4];
-            const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
-            const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
-            const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
-            const f32x4 dhn = dn_pre * rg;
-            zdh[mi] = zg * dh;
-            const int voff = row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2;
-            const unsigned kb0 = (unsigned)(j0 >> 5) * kb_bytes, kbH = (unsigned)(H / 32) * kb_bytes;
-            publish_rows<NP>(dr_pre, rx, voff, plane_bytes, out_off + kb0, ok, lane);
-            publish_rows<NP>(dz_pre, rx, voff, plane_bytes, out_off + kb0 + kbH, ok, lane);
-            publish_rows<NP>(dhn, rx, voff, plane_bytes, out_off + kb0 + 2 * kbH, ok, lane);
-            if (ok && !(CPG_PERSIST_ABLATE & 16)) {
-                float* d = a.dG + ((size_t)t * B + row) * 4 * H + j0 + 4 * scq;
-                *reinterpret_cast<f32x4*>(d) = dr_pre;
-                *reinterpret_cast<f32x4*>(d + H) = dz_pre;
-                *reinterpret_cast<f32x4*>(d + 2 * H) = dhn;
-                *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
-            }
-        }
-        if (closing) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 int plane_stride_words(int H) {
@@ -628,31 +469,40 @@ int plane_stride_words(int H) {
 
 size_t fwd_lds_bytes(int H, int np = 3) { return ((size_t)np * P_NC * plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
 
-int device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-        cus = pr.multiProcessorCount;
-    }
-    return cus;
-}
-
 }  // namespace
 
-// 1 when the persistent kernels cover a [B rows, H hidden] sequence on this device: one workgroup (16 hidden units x 256
-// rows) per CU, all of them co-resident.  CPG_GRU_PERSIST=0 disables the path (per-step launches), =1 is the default.
+// Workgroups of the persistent kernel the CURRENT device holds at once with `lds` bytes of dynamic LDS each, as the occupancy
+// API reports it (registers, LDS, waves) - not an assumption about one workgroup per CU.
+template <int NP>
+static long resident_workgroups(size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<int, size_t>, long> cache;   // (device, LDS bytes) -> workgroups
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, lds});
+    if (it != cache.end()) return it->second;
+    const void* k = reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<NP>);
+    if (cpg_allow_big_lds(k, 160 * 1024) != 0) return 0;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_seq_fwd_persist_kernel<NP>, P_WAVES * 64, lds) != hipSuccess) return 0;
+    return cache[{dev, lds}] = (long)per_cu * cpg_device_cus();
+}
+
+// 1 when the persistent kernel covers a [B rows, H hidden] sequence on this device: every workgroup (16 hidden units x 256
+// rows) co-resident by the occupancy API's count.  Option gru_persist = 0 disables the path (per-step launches).  The caller
+// must own the device: a second process (ranks sharing a GPU) or a concurrent kernel holding CUs breaks co-residency - the
+// host side switches the path off in that case (CPG_SHARED_DEVICE), and a wait that times out poisons the outputs with NaN.
 CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
-    const char* e = getenv("CPG_GRU_PERSIST");
-    if (e && atoi(e) == 0) return 0;
+    const CpgOptVal& o = cpg_opt(OPT_GRU_PERSIST);
+    if (o.set && o.i == 0) return 0;
     if (B <= 0 || H < 32 || H % 32 != 0) return 0;
     if (fwd_lds_bytes(H) > 160 * 1024) return 0;
     if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
     const int groups = cdiv(cdiv(B, P_WROWS), P_WAVES);
     const long wgs = (long)groups * (H / P_CT);
-    const int cus = device_cus();
-    return cus > 0 && wgs <= cus;
+    const long fit = cpg_compute_mode_get() == 1 ? resident_workgroups<1>(fwd_lds_bytes(H, 1)) : resident_workgroups<3>(fwd_lds_bytes(H, 3));
+    return wgs <= fit;
 }
 
 static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_CNT_STRIDE; }
@@ -660,7 +510,11 @@ static size_t sync_words(int B) { return (cnt_words(B) + 16 + 63) / 64 * 64; }  
 
 CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
     // + one exchange slot of three bf16 planes per step (+ the initial state): slots are never reused inside a launch
-    return sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
+    size_t n = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
+#if CPG_PERSIST_TRACE
+    n = (n + 255) / 256 * 256 + (size_t)cdiv(cdiv(B, P_WROWS), P_WAVES) * (H / P_CT) * P_WAVES * T * 8 * sizeof(unsigned long long);
+#endif
+    return n;
 }
 
 // Whole forward sequence in one launch; arguments as cpg_gru_seq_fwd (all rows).  sync_scratch: device memory of
@@ -687,12 +541,13 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(nrt, P_WAVES);
     a.S = plane_stride_words(H);
-    static bool attr = false;
-    if (!attr) {
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
+#if CPG_PERSIST_TRACE
+    {
+        const size_t base = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
+        a.trace = (unsigned long long*)((char*)sync_scratch + (base + 255) / 256 * 256);
     }
+#endif
+    // (the > 64 KB dynamic-LDS opt-in happened in cpg_gru_persistent_fits -> resident_workgroups, per device)
     if (cpg_compute_mode_get() == 1)
         hipLaunchKernelGGL(gru_seq_fwd_persist_kernel<1>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), fwd_lds_bytes(H, 1), s, a);
     else
@@ -700,6 +555,10 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     CPG_LAUNCH_CHECK();
     return 0;
 }
+
+// Byte offset of the sticky error word inside sync_scratch: the host copies it asynchronously to pinned memory behind every
+// launch and looks at the previous copy on the next call (no synchronisation on the hot path).
+CPG_EXPORT size_t cpg_gru_persistent_err_offset(int B) { return cnt_words(B) * sizeof(unsigned); }
 
 // Error word of the last persistent launch that used this scratch (synchronises the stream): 0 = every wait completed.
 CPG_EXPORT int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream) {
@@ -710,70 +569,3 @@ CPG_EXPORT int cpg_gru_persistent_status(int B, const void* sync_scratch, void* 
     return (int)v;
 }
 
-static int bwd_plane_stride_words(int H) {
-    int s = 3 * H / 2;
-    while (s % 64 != 8) ++s;
-    return s;
-}
-static size_t bwd_lds_bytes(int H, int np = 3) { return ((size_t)np * P_CT * bwd_plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
-
-static int bwd_shape_fits(int T, int B, int H) {
-    if (B <= 0 || H < 32 || H % 32 != 0 || T <= 0) return 0;
-    if (fwd_lds_bytes(H) > 160 * 1024 || bwd_lds_bytes(H) > 160 * 1024) return 0;
-    if ((size_t)T * B * 3 * H * 6 > (size_t)3 << 30) return 0;   // exchange slots sit in one 32-bit buffer range
-    const int groups = cdiv(cdiv(B, P_WROWS), P_WAVES);
-    const int cus = device_cus();
-    return cus > 0 && (long)groups * (H / P_CT) <= cus;
-}
-
-// Policy: 1 when the launcher should use the persistent backward for (T,B,H).
-// OFF unless CPG_GRU_PERSIST_BWD=1: measured 83-95 us per step at B=2048, H=512 against 48.9 for the per-step kernel - the
-// exchanged operand dgh is 3x the forward's (590 MB of plane reads per step over all workgroups) and those reads run at the
-// fabric rate (~7 TB/s chip-wide) whatever the store / load cache policy.  Parity-tested either way
-// (cpg_gru_seq_bwd_persistent itself only checks the shape).
-CPG_EXPORT int cpg_gru_persistent_bwd_fits(int T, int B, int H) {
-    const char* e = getenv("CPG_GRU_PERSIST_BWD");
-    if (!e || atoi(e) == 0) return 0;
-    const char* p = getenv("CPG_GRU_PERSIST");
-    if (p && atoi(p) == 0) return 0;
-    return bwd_shape_fits(T, B, H);
-}
-
-CPG_EXPORT size_t cpg_gru_persistent_bwd_scratch_bytes(int T, int B, int H) {
-    return sync_words(B) * sizeof(unsigned) + (size_t)T * 3 * B * 3 * H * sizeof(uint16_t);
-}
-
-// Whole BPTT of one direction in one launch; arguments as cpg_gru_seq_bwd over all rows (dense batches).  sync_scratch:
-// cpg_gru_persistent_bwd_scratch_bytes(T,B,H) bytes, zeroed by the caller once.
-CPG_EXPORT int cpg_gru_seq_bwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
-                                          const float* dhs_ext, const float* dh_last, float* dG, float* dh0, void* sync_scratch,
-                                          void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && sync_scratch);
-    if (!bwd_shape_fits(T, B, H)) {
-        cpg_set_error("cpg_gru_seq_bwd_persistent: T=%d B=%d H=%d does not fit the persistent kernel on this device", T, B, H);
-        return -5;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    const int nrt = cdiv(B, P_WROWS);
-    CPG_HIP(hipMemsetAsync(sync_scratch, 0, cnt_words(B) * sizeof(unsigned), s));
-    PBwdArgs a;
-    a.w_hh = w_hh; a.hs = hs; a.gates = gates; a.dhs_ext = dhs_ext; a.dh_last = dh_last; a.dG = dG; a.dh0 = dh0;
-    a.cnt = (unsigned*)sync_scratch;
-    a.err = a.cnt + cnt_words(B);
-    a.xch = (uint16_t*)(a.cnt + sync_words(B));
-    a.T = T; a.B = B; a.H = H; a.reverse = reverse;
-    a.groups = cdiv(nrt, P_WAVES);
-    a.S = bwd_plane_stride_words(H);
-    static bool attr = false;
-    if (!attr) {
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_persist_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_seq_bwd_persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
-    if (cpg_compute_mode_get() == 1)
-        hipLaunchKernelGGL(gru_seq_bwd_persist_kernel<1>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), bwd_lds_bytes(H, 1), s, a);
-    else
-        hipLaunchKernelGGL(gru_seq_bwd_persist_kernel<3>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), bwd_lds_bytes(H, 3), s, a);
-    CPG_LAUNCH_CHECK();
-    return 0;
-}

@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void mmd_gram_dl_kernel(MmdArgs g, const float
     }
 }
 static bool mmd_dl_ok(int N) {
-    static const int off = [] { const char* e = getenv("CPG_MMD_DL"); return e && atoi(e) == 0; }();
+    const CpgOptVal& o = cpg_opt(OPT_MMD_DL);
+    const bool off = o.set && o.i == 0;
     return !off && N % 64 == 0;
 }
 static int mmd_dp(int D) { return (D + 31) / 32 * 32; }

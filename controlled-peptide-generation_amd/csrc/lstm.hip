@@ -326,13 +326,10 @@ static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
     } else if (choice == 1) {
         // 32-row tiles once they give >= 1024 workgroups
         dim3 grid(cdiv(a.H, LF64::BN / 4), cdiv(a.B, LF64::BM));
-        static bool done = false;
         const size_t smem = LstmFwdLoop<LF64, true>::smem_bytes();
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<LF64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_fwd_kernel<LF64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done = true;
-        }
+        const int rc = cpg_allow_big_lds(vec ? reinterpret_cast<const void*>(lstm_step_fwd_kernel<LF64, true>)
+                                             : reinterpret_cast<const void*>(lstm_step_fwd_kernel<LF64, false>), (int)smem);
+        if (rc) return rc;
         if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, true>), grid, dim3(256), smem, s, a);
         else hipLaunchKernelGGL((lstm_step_fwd_kernel<LF64, false>), grid, dim3(256), smem, s, a);
     } else {
@@ -360,23 +357,21 @@ __global__ void lstm_transpose_w_kernel(const float* w, int R, int C, float* out
     }
 }
 
-// direct-to-LDS backward step: dense full tiles, W_hh^T handed over.  CPG_LSTM_BWD_DL=0 keeps the register-staged kernel.
+// direct-to-LDS backward step: dense full tiles, W_hh^T handed over.  Option lstm_bwd_dl = 0 keeps the register-staged kernel.
 static bool lstm_dl_ok(int B, int H) {
-    const char* e = getenv("CPG_LSTM_BWD_DL");
-    if (e && atoi(e) == 0) return false;
+    const CpgOptVal& o = cpg_opt(OPT_LSTM_BWD_DL);
+    if (o.set && o.i == 0) return false;
     return B % 64 == 0 && H % 32 == 0;
 }
 template <int BM, int BN>
-static void lstm_launch_dl(const LstmBwdArgs& a, hipStream_t s) {
+static int lstm_launch_dl(const LstmBwdArgs& a, hipStream_t s) {
     const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            done = true;
-        }
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN>), (int)smem);
+        if (rc) return rc;
     }
     hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN>), dim3(a.H / BN, a.B / BM), dim3(256), smem, s, a);
+    return 0;
 }
 
 static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
@@ -386,8 +381,8 @@ static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
         for (const void* q : ptrs) al = al && (!q || aligned16(q));
         if (al) {
             // 64 x 64 tiles once they give two workgroups per CU, else 64 x 32 (as the GRU kernel: csrc/gru.hip)
-            if (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) >= 512) lstm_launch_dl<64, 64>(a, s);
-            else lstm_launch_dl<64, 32>(a, s);
+            const int rc = (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) >= 512) ? lstm_launch_dl<64, 64>(a, s) : lstm_launch_dl<64, 32>(a, s);
+            if (rc) return rc;
             CPG_LAUNCH_CHECK();
             return 0;
         }

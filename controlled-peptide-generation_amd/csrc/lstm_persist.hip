@@ -326,32 +326,27 @@ int l_plane_stride_words(int H) {
     return s;
 }
 size_t l_lds_bytes(int H, int np) { return ((size_t)np * L_NC * l_plane_stride_words(H) + L_WAVES * 16 * L_TBW) * 4; }
-int l_device_cus() {
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
-        cus = pr.multiProcessorCount;
-    }
-    return cus;
-}
 size_t l_cnt_words(int B) { return (size_t)cdiv(B, L_WROWS) * L_CNT_STRIDE; }
 size_t l_sync_words(int B) { return (l_cnt_words(B) + 16 + 63) / 64 * 64; }
 
 }  // namespace
 
 // 1 when the persistent LSTM forward kernel covers [B rows, H hidden] on this device (one workgroup of 8 hidden units x 512
-// rows per CU, all co-resident).  CPG_LSTM_PERSIST=0 disables the path (per-step launches).
+// rows per CU, all co-resident).  Option lstm_persist = 0 disables the path (per-step launches).
 CPG_EXPORT int cpg_lstm_persistent_fits(int B, int H) {
-    const char* e = getenv("CPG_LSTM_PERSIST");
-    if (e && atoi(e) == 0) return 0;
+    const CpgOptVal& o = cpg_opt(OPT_LSTM_PERSIST);
+    if (o.set && o.i == 0) return 0;
     if (B <= 0 || H < 32 || H % 32 != 0) return 0;
     if (l_lds_bytes(H, cpg_compute_mode_get() == 1 ? 1 : 3) > 160 * 1024) return 0;
     if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
     const long wgs = (long)cdiv(cdiv(B, L_WROWS), L_WAVES) * (H / L_CT);
-    const int cus = l_device_cus();
-    return cus > 0 && wgs <= cus;
+    const bool bf = cpg_compute_mode_get() == 1;
+    const void* k = bf ? reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<1>) : reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<3>);
+    if (cpg_allow_big_lds(k, 160 * 1024) != 0) return 0;
+    int per_cu = 0;   // co-residency by the occupancy API's count, not by assumption
+    const hipError_t e = bf ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_fwd_persist_kernel<1>, L_WAVES * 64, l_lds_bytes(H, 1))
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_fwd_persist_kernel<3>, L_WAVES * 64, l_lds_bytes(H, 3));
+    return e == hipSuccess && wgs <= (long)per_cu * cpg_device_cus();
 }
 
 CPG_EXPORT size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H) {
@@ -382,17 +377,13 @@ CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, con
     a.S = l_plane_stride_words(H);
     const bool bf = cpg_compute_mode_get() == 1;
     const size_t lds = l_lds_bytes(H, bf ? 1 : 3);
-    static bool attr_done = false;
-    if (!attr_done) {
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        CPG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
     if (bf) hipLaunchKernelGGL(lstm_seq_fwd_persist_kernel<1>, dim3(a.groups * (H / L_CT)), dim3(L_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(lstm_seq_fwd_persist_kernel<3>, dim3(a.groups * (H / L_CT)), dim3(L_WAVES * 64), lds, s, a);
     CPG_LAUNCH_CHECK();
     return 0;
 }
+
+CPG_EXPORT size_t cpg_lstm_persistent_err_offset(int B) { return l_cnt_words(B) * sizeof(unsigned); }
 
 CPG_EXPORT int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* stream) {
     unsigned v = 0;

@@ -120,6 +120,8 @@ def dump_encodings(model, ids, labels, split, savepath, n_iter, batch=4096, fmt=
             zs.append(z.cpu()), mus.append(mu.cpu()), lvs.append(lv.cpu())
     finally:
         model.train(was_training)
+    from cpg import ops
+    ops.check_persistent()   # the encoder's persistent launches: a timed-out wait must not end up in a states file
     f16 = lambda ts: torch.cat(ts).numpy().astype(np.float16)
     fields = dict(src=ids.cpu().numpy().astype(np.int64), z=f16(zs), mu=f16(mus), logvar=f16(lvs),
                   label=np.asarray(labels).astype(np.int64).reshape(ids.shape[0], -1),
@@ -157,6 +159,8 @@ def get_encodings_from_dataloader(query, split, model, dataloader, batch=4096):
                 mus.append(mu.double().cpu()), lvs.append(lv.double().cpu())
     finally:
         model.train(was_training)
+    from cpg import ops
+    ops.check_persistent()
     return torch.cat(mus, 0), torch.cat(lvs, 0)
 
 

@@ -15,7 +15,10 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; 0 = default stream);
  *   - dense arrays are row-major f32 unless stated; `ld*` = leading dimension in elements;
  *   - all randomness is an input (or comes from the explicit cpg_rng_* counter-based streams);
- *   - no global mutable state; re-entrant across streams; one process per GPU.
+ *   - process-wide state is exactly two things, both set through this ABI: the compute mode (cpg_set_compute_mode) and
+ *     the option table of launch-policy knobs (cpg_set_option; initialised ONCE from CPG_<NAME> environment variables -
+ *     no launch path reads the environment); everything else is re-entrant across streams; one process per GPU;
+ *   - cpg_version() changes whenever a signature below changes: a binding must refuse a library whose version differs.
  *   - reductions use a fixed two-stage partition: results are run-to-run deterministic.
  */
 #ifndef CPG_API_H
@@ -34,6 +37,12 @@ extern "C" {
 CPG_API const char* cpg_last_error(void);
 CPG_API int cpg_version(void);
 CPG_API int cpg_device_count(void);
+/* Launch-policy options ("gru_persist", "gru_fwd_bm", "gru_bwd_dl", "gru_bwd_tile", "gru_bwd_dl2", "gru_bwd_stagger",
+ * "lstm_persist", "lstm_bwd_dl", "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl"; KNOBS.md).  value: a decimal
+ * number or a short token such as "64x32"; null or "" returns the option to the built-in policy.  Unknown name: -2. */
+CPG_API int cpg_set_option(const char* name, const char* value);
+/* copies the option's text ("" when unset) into buf; returns 1 when set, 0 when unset, -2 for an unknown name */
+CPG_API int cpg_get_option(const char* name, char* buf, int n);
 
 /* ---- layout ----------------------------------------------------------------------------------------------- */
 /* ids int64 [B,T] (loader layout, data_processing/dataset.py:242-244) -> tok int32 [T,B] time-major; applies
@@ -78,9 +87,7 @@ CPG_API int cpg_get_compute_mode(void);
  * State slab hs [(T+1),B,H]: forward direction hs[0]=h0 (caller fills), h_t -> hs[t+1];
  *                            reverse direction hs[T]=h0 (caller fills), h_t -> hs[t].
  * gates [T,4,B,H] receives r,z,n and (W_hn h + b_hn) per step for the backward pass (null for inference).
- * Batch rows are independent recurrences: a call covers rows [row_begin,row_end) of the B-row problem (0,B for all),
- * so a caller may run row groups as separate launch chains on separate streams (their MFMA and memory phases then
- * overlap instead of running in lockstep). */
+ * Batch rows are independent recurrences: a call covers rows [row_begin,row_end) of the B-row problem (0,B for all). */
 /* step_rows (optional, DEVICE int32 [T], may be null): only rows < step_rows[t] are live at time t.  For length-sorted
  * teacher-forced batches: once all remaining targets of a row are <pad> (losses.py:27 ignores them) its state is never
  * needed again, so the tail of the batch drops out step by step.  The counts are read by the kernels (no host sync);
@@ -88,11 +95,6 @@ CPG_API int cpg_get_compute_mode(void);
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
                             int row_begin, int row_end, const int32_t* step_rows, void* stream);
-/* split form of the same sequence (plain product + memory-bound cell kernel per step; gh scratch [B,3H]) - lets two
- * row groups on two streams overlap one group's cell traffic with the other group's product */
-CPG_API int cpg_gru_seq_fwd_split(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
-                                  const int32_t* tok, const float* tab, const float* rowc, const float* dense, float* hs,
-                                  float* gates, float* gh, int row_begin, int row_end, void* stream);
 /* one decode step = GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) */
 CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                              const float* rowc, const float* h_prev, float* h_out, void* stream);
@@ -100,8 +102,8 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
  * dh_last [B,H]: gradient on the final state (may be null); dG out [T,B,4H] = (dr_pre, dz_pre, d(W_hn h+b_hn), dn_pre):
  * columns 0..3H are the hidden-side gate gradients, columns {0..2H, 3H..4H} the input-side ones;
  * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip).
- * w_hhT_scratch [H,3H] (optional): receives W_hh^T once per call, which puts the dgh . W_hh product of every step on the
- * split-bf16 MFMA engine (both operands K-contiguous); null keeps the exact-f32 MFMA kernels. */
+ * w_hhT_scratch [H,3H] (optional): receives W_hh^T once per call for the direct-to-LDS step kernel (both operands
+ * K-contiguous; full 32 x 32 tiles of dense batches); null keeps the register-staged kernel for every shape. */
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
                             int row_begin, int row_end, const int32_t* step_rows /* as in cpg_gru_seq_fwd; dG rows of dead
@@ -123,47 +125,20 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
  * W_hh rows of 16 hidden units in LDS (already split into bf16 planes) for 256 batch rows and the column-tile workgroups of
  * a row tile hand h_t to each other through the state slab (write-through stores + arrival counters), so nothing is
  * re-staged, re-launched or re-gathered per step.  Same arguments and results as cpg_gru_seq_fwd over all rows.
- * cpg_gru_persistent_fits: 1 when (B,H) is covered on this device (H % 32 == 0, H <= 512, one workgroup per CU co-resident;
- * CPG_GRU_PERSIST=0 disables).  sync_scratch: cpg_gru_persistent_scratch_bytes(T,B,H) bytes of device memory, zeroed by
- * the caller once (arrival counters, re-zeroed by every call, a sticky error word, one bf16-plane exchange slot per step).  cpg_gru_persistent_status synchronises the
- * stream and returns the error word (0 = every in-kernel wait of every launch on this scratch completed).
+ * cpg_gru_persistent_fits: 1 when (B,H) is covered on this device (H % 32 == 0, the plane slice fits the LDS, every
+ * workgroup co-resident by hipOccupancyMaxActiveBlocksPerMultiprocessor's count; option gru_persist = 0 disables).
+ * sync_scratch: cpg_gru_persistent_scratch_bytes(T,B,H) bytes of device memory, zeroed by the caller once (arrival counters,
+ * re-zeroed by every call, a sticky error word at byte cpg_gru_persistent_err_offset(B), the bf16-plane exchange slots).
+ * A wait that times out (workgroups not co-resident: another process or kernel holds CUs) sets the error word and NaN-poisons
+ * everything the wave stores afterwards.  cpg_gru_persistent_status synchronises the stream and returns the error word.
  * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident. */
 CPG_API int cpg_gru_persistent_fits(int B, int H);
 CPG_API size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H);
+CPG_API size_t cpg_gru_persistent_err_offset(int B);
 CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                        float* hs, float* gates, void* sync_scratch, void* stream);
 CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream);
-/* Persistent BPTT: the whole backward recurrence of one direction in one launch (same decomposition; what the column-tile
- * workgroups exchange per step is dgh [rows,3H], already split).  Arguments and results as cpg_gru_seq_bwd over all rows of a
- * dense batch (no step_rows).  sync_scratch: cpg_gru_persistent_bwd_scratch_bytes(T,B,H) bytes, zeroed by the caller once;
- * cpg_gru_persistent_status reads its error word too. */
-CPG_API int cpg_gru_persistent_bwd_fits(int T, int B, int H);
-CPG_API size_t cpg_gru_persistent_bwd_scratch_bytes(int T, int B, int H);
-CPG_API int cpg_gru_seq_bwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
-                                       const float* dhs_ext, const float* dh_last, float* dG, float* dh0, void* sync_scratch,
-                                       void* stream);
-/* BPTT as ONE launch without a stationary operand ("chain", csrc/gru.hip): the tiles of the per-step backward kernel run the
- * whole time loop; the column-tile workgroups of a row tile hand dgh rows to each other through dG itself (write-through
- * stores + one arrival counter per row tile), z (.) dH stays in registers, both directions of a biGRU layer alternate inside
- * the same workgroups.  Arguments and results as cpg_gru_seq_bwd / cpg_gru_biseq_bwd over all rows of a dense batch (no
- * step_rows); results are bit-identical to the per-step launches on the same tiles.  cpg_gru_chain_bwd_covers: 1 when every
- * workgroup is co-resident on this device; cpg_gru_chain_bwd_fits: the launch policy on top of it (measured no faster than the
- * per-step launches, so only with CPG_GRU_BWD_CHAIN=1).  sync_scratch: cpg_gru_chain_scratch_bytes(B) bytes, zeroed by
- * the caller when allocated; cpg_gru_chain_status reads its sticky error word (0 = no wait has timed out).
- * w_hhT_scratch [H,3H] per direction: used in the bf16 compute mode only (may be null otherwise). */
-CPG_API int cpg_gru_chain_bwd_covers(int T, int B, int H);
-CPG_API int cpg_gru_chain_bwd_fits(int T, int B, int H);
-CPG_API size_t cpg_gru_chain_scratch_bytes(int B);
-CPG_API int cpg_gru_seq_bwd_chain(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
-                                  const float* dhs_ext, const float* dh_last, float* dG, float* dh0, float* w_hhT_scratch,
-                                  void* sync_scratch, void* stream);
-CPG_API int cpg_gru_biseq_bwd_chain(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
-                                    const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                                    const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
-                                    float* dG_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* sync_scratch,
-                                    void* stream);
-CPG_API int cpg_gru_chain_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
  * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.
  * kind 0 forward step, 1 backward step; ndir 1 | 2 (paired biGRU launches); have_wt: W_hh^T handed to the backward. */
@@ -188,13 +163,14 @@ CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32
  * keeps the i,f,g,o rows of W_hh of 8 hidden units in LDS (split bf16 planes) for 512 batch rows, the column-tile workgroups of
  * a row tile hand h_t to each other through per-step plane slots + arrival counters (as cpg_gru_seq_fwd_persistent).  Same
  * arguments and results as cpg_lstm_seq_fwd.  cpg_lstm_persistent_fits: 1 when (B,H) is covered on this device
- * (CPG_LSTM_PERSIST=0 disables); sync_scratch: cpg_lstm_persistent_scratch_bytes(T,B,H) bytes, zeroed by the caller when
+ * (option lstm_persist = 0 disables); sync_scratch: cpg_lstm_persistent_scratch_bytes(T,B,H) bytes, zeroed by the caller when
  * allocated; cpg_lstm_persistent_status reads its sticky error word (0 = no wait has timed out). */
 CPG_API int cpg_lstm_persistent_fits(int B, int H);
 CPG_API size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H);
 CPG_API int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                         const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                         float* hs, float* cs, float* gates, void* sync_scratch, void* stream);
+CPG_API size_t cpg_lstm_persistent_err_offset(int B);
 CPG_API int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (as cpg_gru_step_kernel_name): kind 0 forward step, 1 backward step. */
 CPG_API int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int n);

@@ -168,9 +168,10 @@ def reset_rf():
 
 
 # ------------------------------------------------------------------ forward / loss / grad vectors
-def model_vectors(name, seed, B, N_greedy, N_beam, z_regu_variants, **kw):
+def model_vectors(name, seed, B, N_greedy, N_beam, z_regu_variants, model=None, **kw):
     out = {}
-    model = build(seed, **kw)
+    if model is None:
+        model = build(seed, **kw)
     out.update(np_state(model))
     gen = torch.Generator().manual_seed(seed)
     ids = synth_ids(B, T, V, gen)
@@ -400,6 +401,42 @@ def train_vectors(name, seed, B, n_iter, clip, z_regu, **kw):
     out["beta_end_iter"] = np.int64(4)
     np.savez_compressed(os.path.join(OUT, f"train_{name}.npz"), **out)
     print(f"train_{name}.npz: {len(out)} arrays; logged it0 = {logged[0]}")
+
+
+def trained_vectors(name, seed, B_train, n_iter, **kw):
+    """The same vectors as model_vectors, for a model that the REFERENCE's own train_vae.train_vae has trained for n_iter
+    iterations first (Adam lr 1e-3, clip 5.0, z_regu 'mmdrf', beta 1 -> 2: cfg.py defaults) on synthetic peptides: gates move
+    away from their default-init regime (|W_hh| grows, r / z saturate on the <pad> tail), logit margins open up."""
+    model = build(seed, **kw)
+    gen = torch.Generator().manual_seed(seed + 5)
+    pool = synth_ids(64 * B_train, T, V, gen)
+
+    class PoolDataset:
+        def next_batch(self, nm):
+            return FakeBatch(pool[torch.randint(0, pool.shape[0], (B_train,), generator=gen)])
+
+        def idx2sentence(self, s):
+            return ""
+    cfgv = rcfg.Bunch(
+        lr=1e-3, s_iter=0, n_iter=n_iter,
+        beta=rcfg.Bunch(start=rcfg.Bunch(val=1.0, iter=0), end=rcfg.Bunch(val=2.0, iter=n_iter)),
+        lambda_logvar_L1=0.0, lambda_logvar_KL=1e-3, z_regu_loss='mmdrf',
+        cheaplog_every=10 ** 9, expsvlog_every=10 ** 9, clip_grad=5.0, chkpt_path="/tmp/x_{}.pt")
+    logged = {}
+    rtrain.log_value = lambda k, v, it: logged.setdefault(it, {}).__setitem__(k, float(v))
+    reset_rf()
+    torch.manual_seed(seed + 7)
+    np.random.seed(seed + 7)
+    w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    rtrain.train_vae(cfgv, model, PoolDataset())
+    moved = {k: float((model.state_dict()[k] - w0[k]).abs().max()) for k in ("decoder.rnn.weight_hh_l0", "encoder.rnn.weight_hh_l0")}
+    print(f"trained {n_iter} reference iterations; it0 recon {logged[0]['train_L_vae_recon']:.4f}; max |dW_hh| {moved}")
+    model_vectors(name, seed, B=16, N_greedy=256, N_beam=16, z_regu_variants=["mmdrf"], model=model)
+
+
+if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "trained":
+    torch.set_num_threads(4)
+    trained_vectors("A_200", 1238, B_train=32, n_iter=200, **model_kwargs(z_dim=100, enc_h=80))
 
 
 # ------------------------------------------------------------------ CLaSS rejection sampling (G10)

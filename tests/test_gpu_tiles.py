@@ -3,8 +3,8 @@ launcher picks at BASELINE.json's sizes against the oracle.
 
 The golden batches are small (B <= 16), so left alone the launcher only ever picks its small-problem tiles for them; the
 benchmark shapes (B=2048, H=512 / H=1024, T=50) select different template instantiations.  Part 1 forces each instantiation
-through the launch-time knobs (CPG_GRU_FWD_BM, CPG_GRU_BWD_BM, CPG_GRU_BWD_WIDE, CPG_TN_TILE) and repeats the golden
-checks; part 2 runs the real sizes - where the launcher itself chooses - against the numpy oracle (oracle/wae.py,
+through the library's launch-policy options (cpg_set_option: gru_fwd_bm, gru_bwd_tile, gru_bwd_dl, tn_tile, ...) and repeats
+the golden checks; part 2 runs the real sizes - where the launcher itself chooses - against the numpy oracle (oracle/wae.py,
 oracle/decode.py) on seeded inputs.  Bars: losses 1e-4, gradients 2e-6 + 1e-4 max|g|, greedy ids bit-exact.
 """
 import os
@@ -18,8 +18,7 @@ from helpers import (check_decoder_teacher_forced_golden, check_encoder_golden, 
 
 pytestmark = pytest.mark.gpu
 MODELS = ["A", "micro", "enc2"]
-KNOBS = ("CPG_GRU_FWD_BM", "CPG_GRU_BWD_BM", "CPG_GRU_BWD_WIDE", "CPG_GRU_BWD_TILE", "CPG_TN_TILE", "CPG_TN_SPLIT",
-         "CPG_GRU_BWD_CHAIN", "CPG_GRU_BWD_STAGGER")
+KNOBS = ("gru_fwd_bm", "gru_bwd_tile", "gru_bwd_dl", "gru_bwd_dl2", "gru_bwd_stagger", "tn_tile", "tn_split", "gemm_tile", "dgi_mode")
 
 
 @pytest.fixture(autouse=True)
@@ -30,20 +29,19 @@ def _need_gpu():
 
 @pytest.fixture
 def knobs():
-    """Set launch-time tile knobs (read with getenv by the launchers at every call) and restore them afterwards."""
-    saved = {k: os.environ.get(k) for k in KNOBS}
+    """Set launch-policy options of the library (cpg_set_option) for one test and return them to the built-in policy afterwards."""
+    from cpg import ops
+    touched = []
 
     def set_(**kw):
         for k, v in kw.items():
             assert k in KNOBS, k
-            os.environ[k] = str(v)
+            ops.set_option(k, v)
+            touched.append(k)
     yield set_
     torch.cuda.synchronize()
-    for k, v in saved.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    for k in touched:
+        ops.set_option(k, None)
 
 
 # ------------------------------------------------------------------------------------------------ part 1: forced tiles
@@ -51,24 +49,23 @@ def knobs():
 @pytest.mark.parametrize("name", MODELS)
 def test_forward_tiles_golden(golden, knobs, name, bm):
     """gru_step_fwd_kernel<GF32|GF64|GF128> (GF64 is the bench's forward instantiation)."""
-    knobs(CPG_GRU_FWD_BM=bm)
+    knobs(gru_fwd_bm=bm)
     g = golden("model_" + name)
     check_encoder_golden(g)
     check_decoder_teacher_forced_golden(g)
 
 
-BWD_VARIANTS = [dict(CPG_GRU_BWD_BM=32), dict(CPG_GRU_BWD_BM=64), dict(CPG_GRU_BWD_BM=128),
-                dict(CPG_GRU_BWD_WIDE=32), dict(CPG_GRU_BWD_WIDE=64), dict(CPG_GRU_BWD_WIDE=128)] + \
-               [dict(CPG_GRU_BWD_TILE=t) for t in ("64x32", "32x64", "64x64", "128x32", "128x64", "32x32")] + \
-               [dict(CPG_GRU_BWD_WIDE=3264), dict(CPG_GRU_BWD_STAGGER=0), dict(CPG_GRU_BWD_STAGGER=2), dict(CPG_GRU_BWD_CHAIN=1)]
+BWD_VARIANTS = [dict(gru_bwd_tile=t) for t in ("32x32", "64x32", "32x64")] + \
+               [dict(gru_bwd_tile="32x32", gru_bwd_stagger=0), dict(gru_bwd_tile="64x32", gru_bwd_stagger=2), dict(dgi_mode="gemm")]
 
 
-@pytest.mark.parametrize("variant", BWD_VARIANTS, ids=lambda v: "-".join(f"{k[12:]}{x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", BWD_VARIANTS, ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()))
 @pytest.mark.parametrize("name", MODELS)
 def test_backward_tiles_golden(golden, knobs, name, variant):
-    """gru_step_bwd_kernel<GB32|GB64|GB128|GB32N|GB64W|GB128W> on the exact-f32 path (BM / WIDE knobs; GB32N = 32x32 tiles
-    is the bench's) and on the split-bf16 path with W_hh^T handed over (TILE knob); 64-deep slabs (WIDE=3264); the staggered
-    epilogue-operand fetch at other spacings; the one-launch BPTT (CHAIN=1: whole model through cpg_gru_*_bwd_chain)."""
+    """gru_step_bwd_kernel<GB32N | GB64 | GB32> - the register-staged backward step every golden shape runs (H = 80 / 102 / 16:
+    no full 32 x 32 tiles) - on each of its tiles (32 x 64 runs the split-bf16 engine, the others the exact-f32 MFMA), the
+    staggered epilogue-operand fetch at other spacings, and the one-hot-product form of the input-side reductions.  The
+    direct-to-LDS kernels' tiles are pinned to this kernel bit for bit in tests/test_gpu_persistent.py."""
     knobs(**variant)
     check_losses_and_grads_golden(golden("model_" + name))
 
@@ -79,12 +76,12 @@ def test_backward_tiles_golden(golden, knobs, name, variant):
 def test_wgrad_tiles_golden(golden, knobs, name, tile, split):
     """dW = dY^T X products (the dW_hh product and every nn.Linear weight gradient): each tile shape, with and without
     split-K (256x128 split-K, 512-thread workgroups, is the bench's dW_hh instantiation)."""
-    knobs(CPG_TN_TILE=tile, CPG_TN_SPLIT=split)
+    knobs(tn_tile=tile, tn_split=split)
     check_losses_and_grads_golden(golden("model_" + name))
 
 
-@pytest.mark.parametrize("variant", [dict(CPG_GRU_FWD_BM=64, CPG_GRU_BWD_WIDE=32, CPG_TN_TILE="128x64", CPG_TN_SPLIT=4),
-                                     dict(CPG_GRU_FWD_BM=128, CPG_GRU_BWD_BM=128, CPG_TN_TILE="128x128")],
+@pytest.mark.parametrize("variant", [dict(gru_fwd_bm=64, gru_bwd_tile="32x32", tn_tile="128x64", tn_split=4),
+                                     dict(gru_fwd_bm=128, gru_bwd_tile="64x32", tn_tile="128x128")],
                          ids=["bench-tiles", "large-tiles"])
 @pytest.mark.parametrize("name", ["micro_clip", "A_clip"])
 def test_train_trajectory_forced_tiles(golden, knobs, name, variant):
@@ -113,12 +110,32 @@ def _random_case(B, T, V, Z, He, enc_layers, seed):
     return m, P, ids, rnd
 
 
-def _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", beta=1.5, lam_l1=0.1, lam_kl=1e-3):
+CONDITION_REPORT = []
+
+
+def _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", beta=1.5, lam_l1=0.1, lam_kl=1e-3, f64=False, tag=""):
+    """f64: evaluate the oracle with float64 parameters, inputs and intermediates (oracle.precision) - the arbiter where the
+    float32 rounding of the restatement itself would be comparable to the deviation under test.  The float32 restatement (the
+    reference's own arithmetic) is evaluated as well: where IT departs from the float64 value by more than a bar - a recurrence
+    driven into its chaotic regime amplifies rounding differences by orders of magnitude - the HIP path is held to four times
+    that departure instead (`slack`, per quantity; recorded in gpurun_out/condition_report.json)."""
     import losses
+    import oracle
     from helpers import set_losses_cfg
     from oracle import wae
     set_losses_cfg()
-    terms, G, aux = wae.train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, regu)
+    slack = {}
+    if f64:
+        with oracle.precision(np.float64):
+            terms, G, aux = wae.train_loss_and_grads(oracle.as_f64(P), ids, oracle.as_f64(rnd), beta, lam_l1, lam_kl, regu)
+        t32, G32, a32 = wae.train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, regu)
+        slack = {k: 4.0 * float(np.abs(a32[k] - aux[k]).max()) for k in ("mu", "logits", "dz")}
+        slack.update({k: 4.0 * abs(float(t32[k]) - float(terms[k])) for k in terms})
+        slack.update({"g." + k: 4.0 * float(np.abs(G32[k] - G[k]).max()) for k in G})
+        CONDITION_REPORT.append(dict(test=tag, f32_restatement_vs_f64={k: slack[k] / 4.0 for k in ("mu", "logits", "dz", "total")}))
+        _write_report("condition_report.json", CONDITION_REPORT)
+    else:
+        terms, G, aux = wae.train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, regu)
     losses.rf.clear()
     losses.rf['gaussian'] = (cu(rnd["rf_w"]), cu(rnd["rf_b"]))
     idt = cu(ids)
@@ -136,42 +153,69 @@ def _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", beta=1.5, lam_l1=0.1, la
     torch.cuda.synchronize()
     for name, got in (("recon", recon), ("kl", kl), ("mmd", mmd), ("mmdrf", mmdrf), ("klmu", klmu), ("total", loss)):
         ref = float(terms[name])
-        assert abs(got.item() - ref) < 1e-4 * max(1.0, abs(ref)), (name, got.item(), ref)
-    assert abs(l1.item() - float(terms["l1"])) < 1e-4 * max(1.0, abs(float(terms["l1"])))
-    np.testing.assert_allclose(mu.detach().cpu().numpy(), aux["mu"], atol=2e-5)
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), aux["logits"], atol=1e-4)
+        assert abs(got.item() - ref) < 1e-4 * max(1.0, abs(ref)) + slack.get(name, 0.0), (name, got.item(), ref)
+    assert abs(l1.item() - float(terms["l1"])) < 1e-4 * max(1.0, abs(float(terms["l1"]))) + slack.get("l1", 0.0)
+    np.testing.assert_allclose(mu.detach().cpu().numpy(), aux["mu"], atol=2e-5 + slack.get("mu", 0.0), rtol=0)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), aux["logits"], atol=1e-4 + slack.get("logits", 0.0), rtol=0)
     ref = aux["dz"]
-    np.testing.assert_allclose(z.grad.cpu().numpy(), ref, atol=2e-6 + 1e-4 * np.abs(ref).max(), rtol=0)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), ref, atol=2e-6 + 1e-4 * np.abs(ref).max() + slack.get("dz", 0.0), rtol=0)
     for k, prm in m.named_parameters():
         if k.startswith("classifier") or k == "decoder.emb.weight":
             continue
         ref, got = G[k], prm.grad.cpu().numpy()
-        np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+        np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max() + slack.get("g." + k, 0.0), rtol=0, err_msg=k)
 
 
-def _check_greedy_vs_oracle(m, P, N, T, seed):
+TIE_REPORT = []   # (test, rows decoded, rows that differ at an f32 tie of the oracle's own logits): written to gpurun_out/
+
+
+def _check_greedy_vs_oracle(m, P, N, T, seed, f64=False, tag=""):
     """Token ids bit-exact against the oracle; a row may only differ from the step on at which the ORACLE's own top-2 logit
-    margin is below 1e-5 (an f32 tie: either argmax is a correct evaluation) - and such rows must be rare."""
+    margin is below 1e-5 (an f32 tie: either argmax is a correct evaluation) - and such rows must be rare.  With f64 the float32
+    restatement decodes too: rows on which IT already departs from the float64 ids are ill-conditioned (not a property of the
+    HIP path) and are left out, the rest must match the float64 ids.  Counts are recorded (gpurun_out/greedy_tie_report.json)."""
+    import oracle
     from oracle import decode
     rs = np.random.RandomState(seed)
     Z = m.z_dim
     z = rs.randn(N, Z).astype(np.float32)
     c = np.zeros((N, 2), np.float32)
     c[np.arange(N), rs.randint(0, 2, N)] = 1
-    ref, ref_logits = decode.greedy(P, z, c, T, return_logits=True)
+    keep = np.ones(N, bool)
+    if f64:
+        with oracle.precision(np.float64):
+            ref, ref_logits = decode.greedy(oracle.as_f64(P), z.astype(np.float64), c.astype(np.float64), T, return_logits=True)
+        ref32 = decode.greedy(P, z, c, T)
+        w32 = min(ref.shape[1], ref32.shape[1])
+        keep = ~((ref[:, :w32] != ref32[:, :w32]).any(1)) if ref.shape[1] == ref32.shape[1] else ~((ref[:, :w32] != ref32[:, :w32]).any(1))
+    else:
+        ref, ref_logits = decode.greedy(P, z, c, T, return_logits=True)
     ids, _, _ = m.generate_sentences(N, cu(z), cu(c), sample_mode='greedy')
     got = ids.cpu().numpy()
     assert got.shape[1] <= T + 1 and ref.shape[1] <= T + 1
     w = min(got.shape[1], ref.shape[1])
     ties = 0
-    for i in np.nonzero((got[:, :w] != ref[:, :w]).any(1))[0]:
+    for i in np.nonzero((got[:, :w] != ref[:, :w]).any(1) & keep)[0]:
         s = int(np.nonzero(got[i, :w] != ref[i, :w])[0][0]) - 1    # decode step that produced the first differing column
         top2 = np.sort(ref_logits[i, s])[-2:]
         assert top2[1] - top2[0] < 1e-5, (i, s, got[i], ref[i], top2)
         ties += 1
+    TIE_REPORT.append(dict(test=tag or "greedy", rows=int(N), T=int(T), ties=int(ties), ill_conditioned_rows=int((~keep).sum())))
+    _write_report("greedy_tie_report.json", TIE_REPORT)
     assert ties <= max(1, N // 256), ties
+    assert (~keep).sum() <= N // 4, "the float32 restatement itself departs from float64 on more than a quarter of the rows"
     if ties == 0:
-        assert np.array_equal(got, ref)
+        assert np.array_equal(got[keep][:, :w], ref[keep][:, :w])
+
+
+def _write_report(name, rows):
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        json.dump(rows, open(os.path.join(d, name), "w"), indent=1)
+    except OSError:
+        pass
 
 
 def test_config_b_step_vs_oracle():
@@ -179,16 +223,36 @@ def test_config_b_step_vs_oracle():
     picks the bench's instantiations (64-row split-bf16 forward tiles, exact-f32 32x32 backward tiles, 128x64 split-K dW)."""
     m, P, ids, rnd = _random_case(2048, 25, 24, 510, 512, 1, seed=11)
     _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
-    _check_greedy_vs_oracle(m, P, 512, 25, seed=12)
+    _check_greedy_vs_oracle(m, P, 512, 25, seed=12, tag="config B")
 
 
-def test_config_b_step_one_launch_bptt_vs_oracle(knobs):
-    """The same step with both backward recurrences (decoder, encoder pair) as one-launch chains (CPG_GRU_BWD_CHAIN=1)."""
-    knobs(CPG_GRU_BWD_CHAIN=1)
-    m, P, ids, rnd = _random_case(1024, 25, 24, 510, 512, 1, seed=21)
-    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
-    from cpg import ops
-    ops.check_persistent()
+def _scale_recurrent(m, P, scale):
+    """Multiply every GRU weight matrix (W_ih, W_hh of encoder and decoder) by `scale`, in the model and in the oracle's dict."""
+    with torch.no_grad():
+        for k, prm in m.named_parameters():
+            if ".rnn.weight_" in k:
+                prm.mul_(scale)
+                P[k] = (P[k] * np.float32(scale)).astype(np.float32)
+
+
+@pytest.mark.parametrize("scale", [4.0, 8.0])
+def test_config_b_saturated_gates_vs_f64_oracle(scale):
+    """Adversarial regime for the f32-grade product forms (six-term bf16 splits, whose error scales with operand magnitude): every
+    GRU weight x4 / x8 at configs[1] dimensions - r, z saturate, |h| -> 1, pre-activations of O(10..100) - against the oracle run in
+    float64.  Same bars as everywhere: losses / logits 1e-4, gradients 2e-6 + 1e-4 max|g|, greedy ids bit-exact (ties reported).
+    At x8 the recurrence is chaotic: the reference's own float32 arithmetic departs from float64 by ~1e-4 in mu and ~3e-4 in the
+    logits (measured on the restatement), so every bar carries the `slack` term of _check_step_vs_oracle there."""
+    m, P, ids, rnd = _random_case(2048, 25, 24, 510, 512, 1, seed=int(40 + scale))
+    _scale_recurrent(m, P, scale)
+    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", f64=True, tag=f"config B, GRU weights x{scale:g}")
+    _check_greedy_vs_oracle(m, P, 512, 25, seed=int(50 + scale), f64=True, tag=f"config B, GRU weights x{scale:g}")
+
+
+def test_config_b_long_sequence_vs_f64_oracle():
+    """T = 50 at configs[1] width (h = 512), B = 512: twice the recurrence depth of the bench shape, float64 oracle."""
+    m, P, ids, rnd = _random_case(512, 50, 24, 510, 512, 1, seed=61)
+    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", f64=True, tag="config B, T=50")
+    _check_greedy_vs_oracle(m, P, 512, 50, seed=62, f64=True, tag="config B, T=50")
 
 
 def test_config_b_full_mmd_regulariser_vs_oracle():
@@ -202,7 +266,7 @@ def test_config_c_step_vs_oracle():
     (models/encoder.py:27,46-47), z=1022, decoder h=1024 (1 layer: models/model.py:283-284), T=50; B=256."""
     m, P, ids, rnd = _random_case(256, 50, 24, 1022, 1024, 2, seed=17)
     _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
-    _check_greedy_vs_oracle(m, P, 128, 50, seed=18)
+    _check_greedy_vs_oracle(m, P, 128, 50, seed=18, tag="config C")
 
 
 def test_other_seq_len_vs_oracle():

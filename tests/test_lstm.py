@@ -225,18 +225,18 @@ def test_lstm_persistent_forward_vs_oracle_and_repeatable():
 
 
 @pytest.mark.gpu
-def test_lstm_persistent_limits_and_knob(monkeypatch):
+def test_lstm_persistent_limits_and_option():
     from cpg import ops
     assert ops.lstm_persistent_fits(2048, 512)
     assert not ops.lstm_persistent_fits(2048, 100)     # H % 32 != 0
     assert not ops.lstm_persistent_fits(8192, 512)     # 1024 workgroups
-    monkeypatch.setenv("CPG_LSTM_PERSIST", "0")
-    assert not ops.lstm_persistent_fits(2048, 512)
+    with ops.options(lstm_persist=0):
+        assert not ops.lstm_persistent_fits(2048, 512)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,T,reverse", [(128, 64, 5, False), (192, 96, 4, True), (2048, 512, 6, False)])
-def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reverse, monkeypatch):
+def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reverse):
     """lstm_step_bwd_dl_kernel (global_load_lds ring, W_hh^T) against lstm_step_bwd_kernel: same products in the same contraction
     order; the cell backward is written on 4-vectors there and on scalars here (fused-multiply-add contraction may differ): dG,
     dh0, dc0 within 2e-6 of their scale."""
@@ -247,8 +247,9 @@ def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reve
     g = torch.Generator().manual_seed(3)
     dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
     out = []
-    for dl in ("1", "0"):
-        monkeypatch.setenv("CPG_LSTM_BWD_DL", dl)
+    from cpg import ops
+    for dl in (1, 0):
+        ops.set_option("lstm_bwd_dl", dl)
         dG = torch.zeros(T, B, 4 * H, device=dev)
         scr = torch.empty(2, B, H, device=dev)
         dh0, dc0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
@@ -257,6 +258,7 @@ def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reve
              _p(wT), _stream())
         torch.cuda.synchronize()
         out.append((dG, dh0, dc0))
+    ops.set_option("lstm_bwd_dl", None)
     for a, b in zip(*out):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())

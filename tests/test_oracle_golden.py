@@ -5,7 +5,7 @@ import pytest
 from conftest import weights_of
 from oracle import wae, decode, optim, class_sampler
 
-MODELS = ["A", "micro", "enc2"]
+MODELS = ["A", "micro", "enc2", "A_200"]   # A_200: config A after 200 reference train_vae iterations
 
 
 def rnd_of(g):

@@ -35,7 +35,13 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--only", default="fwdp,fwd,bwd,bwd2,wgrad")
     ap.add_argument("--tag", default=os.path.basename(os.environ.get("CPG_LIB_PATH", "default")))
+    ap.add_argument("--opt", action="append", default=[], help="name=value launch-policy option (cpg_set_option), repeatable")
     a = ap.parse_args()
+    for kv in a.opt:
+        k, v = kv.split("=")
+        ops.set_option(k, v)
+    if a.opt:
+        a.tag += " " + ",".join(a.opt)
     dev = torch.device("cuda")
     ops.set_compute_mode(a.dtype)
     B, H, T, V = a.B, a.H, a.T, a.V

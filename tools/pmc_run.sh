@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (counters only, with --kernel-trace; never combined with other trace domains) over one command.
-#   bash tools/pmc_run.sh OUTDIR -- python tools/kbench.py --iters 2
+#   bash tools/pmc_run.sh OUTDIR -- python tools/kb.py --iters 2
 # Passes follow the SQ (8) / TCC (4: FETCH_SIZE costs 3, WRITE_SIZE 2) / GRBM (2) slot limits of MI355X_MICROARCH.md.
 set -e
 OUT=$1; shift; shift
