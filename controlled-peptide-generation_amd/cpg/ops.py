@@ -399,9 +399,16 @@ import os as _os2
 SHARED_DEVICE = bool(_os2.environ.get("CPG_SHARED_DEVICE"))   # ranks share this GPU: persistent kernels cannot own every CU
 
 
+def persistent_rows(H):
+    """Batch rows ONE launch of the whole-sequence persistent forward kernel (csrc/gru_persist.hip) covers at width H on this
+    device; 0 when the width is not covered (or the path is off)."""
+    return 0 if SHARED_DEVICE else int(query("cpg_gru_persistent_rows", int(H)))
+
+
 def persistent_fits(B, H):
-    """The whole-sequence persistent forward kernel (csrc/gru_persist.hip) covers this shape on this device."""
-    return not SHARED_DEVICE and bool(query("cpg_gru_persistent_fits", int(B), int(H)))
+    """The persistent forward path covers this shape: in one launch, or - rows being independent recurrences - in consecutive
+    launches over row ranges when the batch is wider than one launch holds."""
+    return B > 0 and persistent_rows(H) >= 256 and B * H * 6 * 64 <= (3 << 30)
 
 
 def lstm_persistent_fits(B, H):
@@ -411,22 +418,17 @@ def lstm_persistent_fits(B, H):
 
 def _persist_entry(kind, T, B, H, dev):
     """Scratch of the persistent launches on the current stream: ONE buffer per (kind, device, stream, B, H), grown to the largest
-    T seen; with it a pinned copy of its sticky error word, refreshed asynchronously behind every launch."""
+    T seen; with it a pinned, host-mapped error word that a timed-out wave sets directly - looked at here, before the next launch
+    on this scratch, without any stream operation."""
     key = (kind, dev.index, torch.cuda.current_stream().cuda_stream, B, H)
     ent = _persist_scratch.get(key)
     if ent is None or ent[1] < T:
         nb = query("cpg_gru_persistent_scratch_bytes" if kind == "gru" else "cpg_lstm_persistent_scratch_bytes", T, B, H)
-        ent = _persist_scratch[key] = [torch.zeros(nb, dtype=torch.uint8, device=dev), T,     # counters + sticky error word + slots
-                                       torch.zeros(4, dtype=torch.uint8).pin_memory(), None]
-    elif ent[3] is not None and ent[3].query() and ent[2].view(torch.int32).item() != 0:
-        _persist_failed(kind)      # a PREVIOUS launch on this scratch timed out: seen here without any synchronisation
+        host = ent[2] if ent is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+        ent = _persist_scratch[key] = [torch.zeros(nb, dtype=torch.uint8, device=dev), T, host]   # counters + error word + slots
+    if ent[2][0] != 0:
+        _persist_failed(kind)      # an EARLIER launch on this scratch timed out
     return ent
-
-
-def _persist_after_launch(kind, ent, B):
-    off = query("cpg_gru_persistent_err_offset" if kind == "gru" else "cpg_lstm_persistent_err_offset", B)
-    ent[2].copy_(ent[0][off:off + 4], non_blocking=True)
-    ent[3] = torch.cuda.current_stream().record_event()
 
 
 def _persist_failed(kind):
@@ -437,26 +439,27 @@ def _persist_failed(kind):
 
 def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, gates):
     ent = _persist_entry("gru", T, B, H, hs.device)
-    call("cpg_gru_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
-         _p(hs), _p(gates), _p(ent[0]), _stream())
-    _persist_after_launch("gru", ent, B)
+    rows = persistent_rows(H)
+    for r0 in range(0, B, rows):     # one launch when the batch fits, else row ranges back to back on this stream
+        call("cpg_gru_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
+             _p(hs), _p(gates), r0, min(B, r0 + rows), _p(ent[0]), ctypes.c_void_p(ent[2].data_ptr()), _stream())
 
 
 def lstm_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, cs, gates):
     ent = _persist_entry("lstm", T, B, H, hs.device)
     call("cpg_lstm_seq_fwd_persistent", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(dense),
-         _p(hs), _p(cs), _p(gates), _p(ent[0]), _stream())
-    _persist_after_launch("lstm", ent, B)
+         _p(hs), _p(cs), _p(gates), _p(ent[0]), ctypes.c_void_p(ent[2].data_ptr()), _stream())
 
 
 def check_persistent():
-    """Raise if any in-kernel wait of a persistent launch has timed out (waits for the pending error-word copies: call it where
-    a host synchronisation is acceptable - logging iterations, the end of an inference entry point, bench, tests)."""
+    """Raise if any in-kernel wait of a persistent launch has timed out.  Synchronises the device first, so that launches still
+    running are covered: call it where a host synchronisation is acceptable (logging iterations, the end of an inference entry
+    point, bench, tests); the hot path itself only glances at the host-mapped error words between launches."""
+    if _persist_scratch:
+        torch.cuda.synchronize()
     for (kind, *_), ent in list(_persist_scratch.items()):
-        if ent[3] is not None:
-            ent[3].synchronize()
-            if ent[2].view(torch.int32).item() != 0:
-                _persist_failed(kind)
+        if ent[2][0] != 0:
+            _persist_failed(kind)
 
 
 class GruSeqFn(Function):

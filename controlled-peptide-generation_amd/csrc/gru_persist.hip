@@ -7,9 +7,12 @@
 // launch ramp, two dependent gather latencies before its epilogue and a store tail after it.
 //
 // Decomposition (rows are independent recurrences; columns need the whole previous state):
-//   * a workgroup owns CT = 16 hidden units (the r, z, n rows of W_hh for them: 48 x H) for a group of 256 batch rows and
-//     keeps that W_hh slice in LDS for the whole sequence, ALREADY split into three bf16 planes (48 x H x 6 B = 147 KB at
-//     H = 512: the reason for CT = 16 and for one workgroup per CU);
+//   * a workgroup owns CT hidden units (the r, z, n rows of W_hh for them: 3 CT x H) for a group of 256 batch rows and
+//     keeps that W_hh slice in LDS for the whole sequence, ALREADY split into three bf16 planes.  CT = 16 (three 16-column
+//     MFMA blocks, one per gate: 48 x H x 6 B = 147 KB at H = 512, the reason for one workgroup per CU) up to H = 512;
+//     CT = 8 for 512 < H <= 1024 (24 x H x 6 B = 147 KB at H = 1024; BASELINE.json configs[4] width): TWO column blocks,
+//     [r | z] and [n | n again], the half-rows of a 16-lane group swap r / z with one DPP rotate (row_ror:8) and the lower
+//     half runs the cell - the matrix pipe then works at 3/4 efficiency (24 useful of 32 columns);
 //   * each of its 8 waves (two per SIMD: one wave's cell arithmetic and waits run under the other's MFMAs) owns 32 of the
 //     rows.  The state operand goes global -> registers -> MFMA A fragments directly: every element is used by exactly one
 //     wave of the workgroup, so nothing is shared through LDS and the time loop has NO workgroup barrier; the per-row
@@ -91,7 +94,6 @@ __device__ __forceinline__ float p_tanh(float x) {
 #endif
 }
 
-constexpr int P_CT = 16;          // hidden units per workgroup
 #ifndef CPG_PERSIST_WAVES
 #define CPG_PERSIST_WAVES 8       // two waves per SIMD: one wave's cell arithmetic, stores and waits run under the other's MFMAs
                                   // (21.8 us per step against 26.8 with 4 - once the arrival counters sit on separate lines)
@@ -106,7 +108,6 @@ constexpr int P_DEPTH = CPG_PERSIST_DEPTH;
 constexpr int P_WAVES = CPG_PERSIST_WAVES;
 constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
-constexpr int P_NC = 3 * P_CT;    // gate columns per workgroup
 #ifndef CPG_PERSIST_TBW
 #define CPG_PERSIST_TBW 16
 #endif
@@ -137,10 +138,12 @@ struct PFwdArgs {
     float* gates;          // [T,4,B,H] or null
     unsigned* cnt;         // [row tiles] arrival counters (zeroed before the launch)
     unsigned* err;         // sticky error word
+    unsigned* err_host;    // the same word in host-mapped (pinned) memory, or null: the host sees a timeout without any copy
     uint16_t* xch;         // [2 slots][3 planes][H/32 k-blocks][B][32] bf16: the state as the consumers want it - a wave's
                            // A-fragment load (16 rows x 32 k of one plane) is ONE contiguous KB.  (With rows H apart the 32
                            // CUs of an XCD that read the same tile at the same time camped on a few L2 channels: 62.8 us/step.)
     int T, B, H, reverse, groups, S;  // S: words per plane row (H/2 data + pad so that S % 64 == 8)
+    int row0, row1;                   // rows [row0, row1) of the B-row problem are this launch's
 #if CPG_PERSIST_TRACE
     unsigned long long* trace;        // [workgroups][waves][T][8]
 #endif
@@ -159,13 +162,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 // Wait until *p >= target (relaxed agent-scope polls: every lane reads the same word).  Bounded: on timeout the sticky error
 // word is set and the wave is `dead`: it stops waiting, and everything it stores from then on is NaN (state slab, saved
 // gates, exchange planes), so the failure reaches the loss / the decoded ids instead of passing as plausible numbers.
-__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, bool& dead) {
+__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* err_host, bool& dead) {
     if (dead) return false;
     unsigned spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > P_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((threadIdx.x & 63) == 0) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (err_host) __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             dead = true;
             return false;
         }
@@ -188,13 +194,18 @@ __device__ __forceinline__ float lane_xor1(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
 }
 
+// value of lane (l + 8) % 16 of the same 16-lane row: DPP row_ror:8
+__device__ __forceinline__ float row_ror8(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
+}
+
 // Row-layout tile (lane -> row l>>2, 4 columns) -> three bf16 planes in the exchange slot: even lanes collect their odd
 // neighbour's four columns and store 8 columns = 16 bytes per plane, write-through.
 template <int NP>
 __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffer_rsrc_t rx, int voff, unsigned plane_bytes,
                                              unsigned slot_off, bool ok, int lane) {
     const float n0 = lane_xor1(v[0]), n1 = lane_xor1(v[1]), n2 = lane_xor1(v[2]), n3 = lane_xor1(v[3]);
-    if ((lane & 1) == 0 && ok) {
+    if ((lane & 1) == 0 && ok) {   // ok also carries the column bound of narrow (CT = 8) tiles
         uint32_t w0[4], w1[4], w2[4];
         if (NP == 3) {
             split3_pair(v[0], v[1], w0[0], w1[0], w2[0]);
@@ -215,23 +226,28 @@ __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffe
 }
 
 // NP: planes of the split - 3 = f32-grade (six MFMAs per block), 1 = bf16 compute mode (cpg_set_compute_mode(1))
-template <int NP>
+// CT: hidden units per workgroup - 16 (one MFMA column block per gate) or 8 (blocks [r | z] and [n | n], see the header)
+template <int NP, int CT>
 __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
+    constexpr int NC = 3 * CT;              // gate columns (LDS plane rows) of the workgroup
+    constexpr int NB = CT == 16 ? 3 : 2;    // MFMA column blocks
+    static_assert(CT == 16 || CT == 8, "16 units: one block per gate; 8 units: [r|z] and [n|n]");
     extern __shared__ __attribute__((aligned(16))) uint32_t psm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x % a.groups, ct = blockIdx.x / a.groups;
     const int H = a.H, B = a.B, T = a.T, S = a.S;
-    const int j0 = ct * P_CT;
-    const int NCT = H / P_CT, KB = H / 32;
-    const int PLW = P_NC * S;
+    const int Bend = a.row1;                // this launch covers rows [row_begin, row_end) of the B-row problem
+    const int j0 = ct * CT;
+    const int NCT = H / CT, KB = H / 32;
+    const int PLW = NC * S;
     uint32_t* const planes = psm;
     float* const tb = reinterpret_cast<float*>(psm + NP * PLW) + wave * (16 * P_TBW);
 
-    // ---- W_hh slice -> three bf16 planes in LDS, once per sequence: plane[c = gate*16 + u][k pair]
-    for (int idx = tid; idx < P_NC * (H / 2); idx += P_WAVES * 64) {
+    // ---- W_hh slice -> three bf16 planes in LDS, once per sequence: plane[c = gate*CT + u][k pair]
+    for (int idx = tid; idx < NC * (H / 2); idx += P_WAVES * 64) {
         const int c = idx / (H / 2), kp = idx - c * (H / 2);
-        const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c >> 4) * H + j0 + (c & 15))) * H + 2 * kp);
+        const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c / CT) * H + j0 + (c % CT))) * H + 2 * kp);
         uint32_t w0, w1 = 0, w2 = 0;
         if (NP == 3) split3_pair(v.x, v.y, w0, w1, w2);
         else w0 = cvt_pk_bf16(v.x, v.y);
@@ -243,37 +259,48 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     }
     __syncthreads();
 
-    const int rt = g * P_WAVES + wave;   // row tile of this wave
-    const int row0 = rt * P_WROWS;
-    if (row0 >= B) return;               // wave-uniform; nobody waits for a tile that does not exist
+    const int rt = g * P_WAVES + wave;   // row tile of this wave (counted from row_begin)
+    const int row0 = a.row0 + rt * P_WROWS;
+    if (row0 >= Bend) return;            // wave-uniform; nobody waits for a tile that does not exist
     phase_delay(wave, CPG_PERSIST_PHASE_FWD);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int col = j0 + l15;            // hidden unit of this lane's accumulator elements
     const int srow = lane >> 2, scq = lane & 3;  // row-layout coordinates after acc_to_rows
+    const int hcol = j0 + (l15 & (CT - 1));      // hidden unit of this lane's accumulator elements
+    const bool cvalid = 4 * scq < CT;            // row layout: this lane's four columns belong to the tile
+    // column of the 3H gate axis that block b's accumulator of this lane belongs to
+    int gcol[NB];
+    if constexpr (CT == 16) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gcol[b] = b * H + hcol;
+    } else {
+        gcol[0] = (l15 >> 3) * H + hcol;   // lower half-row: r of unit l15, upper half-row: z of unit l15 - 8
+        gcol[1] = 2 * H + hcol;            // n (both half-rows multiply the same eight W_hn rows; the upper copy is unused)
+    }
 
     const unsigned plane_bytes = (unsigned)((size_t)B * H * 2), kb_bytes = (unsigned)B * 64u;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xch, (unsigned)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3u * plane_bytes);
     bool dead = false;
 
     // per-lane constants of the epilogue: row of accumulator element (mi, reg), clamped for the loads
-    float rc[P_MI][4][3], hprev[P_MI][4];
+    float rc[P_MI][4][NB], hprev[P_MI][4];
     const size_t slot0 = (size_t)(a.reverse ? T : 0) * B * H;
-    float bh[3];
+    float bh[NB];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) bh[q] = a.b_hh[q * H + col];
+    for (int b = 0; b < NB; ++b) bh[b] = a.b_hh[gcol[b]];
 #pragma unroll
     for (int mi = 0; mi < P_MI; ++mi) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = min(row0 + 16 * mi + 4 * lq + r, B - 1);
+            const int row = min(row0 + 16 * mi + 4 * lq + r, Bend - 1);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) rc[mi][r][q] = a.rowc ? a.rowc[(size_t)row * 3 * H + q * H + col] : 0.f;
-            hprev[mi][r] = a.hs[slot0 + (size_t)row * H + col];
+            for (int b = 0; b < NB; ++b) rc[mi][r][b] = a.rowc ? a.rowc[(size_t)row * 3 * H + gcol[b]] : 0.f;
+            hprev[mi][r] = a.hs[slot0 + (size_t)row * H + hcol];
         }
         // h0 enters the exchange like any step's output: slot 0, arrival #1
         const int row = row0 + 16 * mi + srow;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.hs + slot0 + (size_t)min(row, B - 1) * H + j0 + 4 * scq);
-        publish_rows<NP>(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.hs + slot0 + (size_t)min(row, Bend - 1) * H + j0 + (cvalid ? 4 * scq : 0));
+        publish_rows<NP>(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes,
+                         row < Bend && 4 * (scq & ~1) < CT, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -281,8 +308,11 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     // A-operand addressing: lane (l15, lq) of row block mi reads 8 consecutive k of row row0 + 16 mi + l15 (16 bytes of a plane)
     int aoff[P_MI];
 #pragma unroll
-    for (int mi = 0; mi < P_MI; ++mi) aoff[mi] = min(row0 + 16 * mi + l15, B - 1) * 64 + 16 * lq;
-    const uint32_t* const bbase = planes + l15 * S + 4 * lq;
+    for (int mi = 0; mi < P_MI; ++mi) aoff[mi] = min(row0 + 16 * mi + l15, Bend - 1) * 64 + 16 * lq;
+    // B fragments: block b, lane l15 -> plane row; CT = 8: block 1 wraps (both half-rows read the eight n rows)
+    const uint32_t* bbase[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bbase[b] = planes + (CT == 16 ? 16 * b + l15 : (b == 0 ? l15 : 16 + (l15 & 7))) * S + 4 * lq;
 
     // saved-for-backward gates and the f32 state of the last finished step (not part of the hand-off)
     float rg[P_MI][4], zg[P_MI][4], ng[P_MI][4], hn[P_MI][4];
@@ -294,7 +324,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi) {
             const int row = row0 + 16 * mi + srow;
-            if (row < B) *reinterpret_cast<f32x4*>(hout + (size_t)row * H + j0 + 4 * scq) = hrow[mi];
+            if (row < Bend && cvalid) *reinterpret_cast<f32x4*>(hout + (size_t)row * H + j0 + 4 * scq) = hrow[mi];
         }
         if (a.gates && !(CPG_PERSIST_ABLATE & 16)) {
             const size_t BH = (size_t)B * H;
@@ -306,7 +336,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 const f32x4 v1 = acc_to_rows(tb, zg[mi], lane);
                 const f32x4 v2 = acc_to_rows(tb, ng[mi], lane);
                 const f32x4 v3 = acc_to_rows(tb, hn[mi], lane);
-                if (row < B) {
+                if (row < Bend && cvalid) {
                     float* d = gbase + (size_t)row * H + j0 + 4 * scq;
                     __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(d));
                     __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(d + BH));
@@ -320,82 +350,93 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 
     for (int p = 0; p < T; ++p) {
         const int tt = a.reverse ? T - 1 - p : p;
-        // Exchange slot of step p's input / output.  One slot PER STEP (never reused inside the launch): an address is written
-        // once, write-through, and first read only after its row tile's arrival counter says every producer is done - so no
-        // cache anywhere can hold a stale copy of it, and the loads may be plain ones that allocate in L2: of the 32 column-
-        // tile workgroups that read the same planes all but the first hit the XCD's L2.  (sc1 loads of a two-slot ring were
-        // served at the fabric rate: 197 MB per step, 25 us - the bound of that form.)
+        // Exchange slot of step p's input / output: a two-slot ring read with sc1 loads (CPG_PERSIST_PLAIN_LOADS = 1: one slot
+        // PER STEP, written once, write-through, first read only after its row tile's arrival counter says every producer is
+        // done - no cache can hold a stale copy - and read with plain loads that allocate in L2).
         const unsigned in_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p : (p & 1)) * 3u * plane_bytes;
         const unsigned out_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p + 1 : ((p + 1) & 1)) * 3u * plane_bytes;
 
         P_STAMP(0);
-        // input-side pre-activations of this step: independent of the recurrence, fetched before the wait
-        float gi[P_MI][4][3];
+        // input-side pre-activations of this step: independent of the recurrence, fetched before the wait.  The (uniform) tests
+        // for the two optional sources sit OUTSIDE the element loops: each source's 8 x NB gathers form one clause of loads
+        float gi[P_MI][4][NB];
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = min(row0 + 16 * mi + 4 * lq + r, B - 1);
-                float x0 = rc[mi][r][0], x1 = rc[mi][r][1], x2 = rc[mi][r][2];
-                if (a.tok) {
-                    const float* t = a.tab + (size_t)a.tok[(size_t)tt * B + row] * 3 * H + col;
-                    x0 += t[0]; x1 += t[H]; x2 += t[2 * H];
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) gi[mi][r][b] = rc[mi][r][b];
+        if (a.tok) {
+            int tk[P_MI][4];
+#pragma unroll
+            for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tk[mi][r] = a.tok[(size_t)tt * B + min(row0 + 16 * mi + 4 * lq + r, Bend - 1)];
+#pragma unroll
+            for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* t = a.tab + (size_t)tk[mi][r] * 3 * H;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) gi[mi][r][b] += t[gcol[b]];
                 }
-                if (a.dense) {
-                    const float* t = a.dense + ((size_t)tt * B + row) * 3 * H + col;
-                    x0 += t[0]; x1 += t[H]; x2 += t[2 * H];
+        }
+        if (a.dense) {
+#pragma unroll
+            for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* t = a.dense + ((size_t)tt * B + min(row0 + 16 * mi + 4 * lq + r, Bend - 1)) * 3 * H;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) gi[mi][r][b] += t[gcol[b]];
                 }
-                gi[mi][r][0] = x0; gi[mi][r][1] = x1; gi[mi][r][2] = x2;
-            }
+        }
 
-        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, dead);
+        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
         P_STAMP(1);
         if (CPG_PERSIST_DEFER) flush();
 #if CPG_PERSIST_ACQUIRE
-        // plain (L2-allocating) loads behind ONE agent-scope acquire: the 32 column-tile workgroups of a row tile read the
-        // same planes, so all but the first reader hit the XCD's L2 (sc1 loads are served at the fabric rate: 60 us/step)
+        // plain (L2-allocating) loads behind ONE agent-scope acquire
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
 
-        // ---- recurrent product: acc[mi][gate] = h_prev[32 rows, H] . W_hh[gate rows of 16 units, H]^T
-        f32x4 acc[P_MI][3];
+        // ---- recurrent product: acc[mi][b] = h_prev[32 rows, H] . (block b's 16 rows of the W_hh slice)^T
+        f32x4 acc[P_MI][NB];
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < NB; ++b) acc[mi][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 buf[P_DEPTH][P_MI][NP];  // register ring: the loads of k-block kb + P_DEPTH - 1 are in flight while kb is multiplied
-        // The 32 column-tile workgroups of a row tile read the SAME planes at about the same time; walking the k-blocks in the
-        // same order they all hit one L2 channel at a time (measured: ~1 TB/s per XCD instead of 4 - the 25 us floor of the
-        // first form).  Each column tile therefore starts at its own k-block and wraps around: sums over k-blocks in a
-        // rotated order (deterministic per column tile; results equal the per-step kernel's up to f32 summation order).
+        // CPG_PERSIST_ROTATE: each column tile starts at its own k-block and wraps around (spreads the 32 readers of a plane
+        // over the L2 channels; sums over k-blocks in a rotated, per-column-tile deterministic order)
         const int rot = CPG_PERSIST_ROTATE ? (ct * KB) / NCT : 0;
-        auto load = [&](u32x4 (&b)[P_MI][NP], int kbi) {
+        auto load = [&](u32x4 (&bf)[P_MI][NP], int kbi) {
             int kb = kbi + rot;
             kb = kb >= KB ? kb - KB : kb;
 #pragma unroll
             for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    b[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes,
-                                                                      (CPG_PERSIST_ACQUIRE || CPG_PERSIST_PLAIN_LOADS) ? 0 : 16);
+                    bf[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes,
+                                                                       (CPG_PERSIST_ACQUIRE || CPG_PERSIST_PLAIN_LOADS) ? 0 : 16);
         };
-        auto compute = [&](const u32x4 (&buf)[P_MI][NP], int kbi) {
+        auto compute = [&](const u32x4 (&bf)[P_MI][NP], int kbi) {
             int kb = kbi + rot;
             kb = kb >= KB ? kb - KB : kb;
-            cpg_bf16x8 fb[3][NP];
+            cpg_bf16x8 fb[NB][NP];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    fb[q][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + q * 16 * S + kb * 16);
+                    fb[b][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase[b] + pl * PLW + kb * 16);
             if (CPG_PERSIST_ABLATE & 4) {
 #pragma unroll
                 for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) acc[mi][q] += __builtin_bit_cast(f32x4, buf[mi][0]) * __builtin_bit_cast(f32x4, fb[q][0]);
+                    for (int b = 0; b < NB; ++b) acc[mi][b] += __builtin_bit_cast(f32x4, bf[mi][0]) * __builtin_bit_cast(f32x4, fb[b][0]);
                 return;
             }
-            // six products per block in the per-step kernel's order, walked TERM BY TERM over the 3 P_MI independent
+            // six products per block in the per-step kernel's order, walked TERM BY TERM over the NB P_MI independent
             // accumulators: a dependent MFMA waits for its predecessor to leave the pipe, independent ones issue back to back
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -403,9 +444,9 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 #pragma unroll
                 for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        acc[mi][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, buf[mi][NP == 3 ? TA[t] : 0]),
-                                                                             fb[q][NP == 3 ? TB[t] : 0], acc[mi][q], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b)
+                        acc[mi][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, bf[mi][NP == 3 ? TA[t] : 0]),
+                                                                             fb[b][NP == 3 ? TB[t] : 0], acc[mi][b], 0, 0, 0);
         };
 #pragma unroll
         for (int d = 0; d < P_DEPTH - 1; ++d)
@@ -427,19 +468,35 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                hn[mi][r] = acc[mi][2][r] + bh[2];
-                if (CPG_PERSIST_ABLATE & 8) {
-                    rg[mi][r] = gi[mi][r][0] + (acc[mi][0][r] + bh[0]);
-                    zg[mi][r] = gi[mi][r][1] + (acc[mi][1][r] + bh[1]);
-                    ng[mi][r] = gi[mi][r][2] + rg[mi][r] * hn[mi][r];
+                float pr, pz, pn;     // r / z pre-activations, and gi_n
+                if constexpr (CT == 16) {
+                    pr = gi[mi][r][0] + (acc[mi][0][r] + bh[0]);
+                    pz = gi[mi][r][1] + (acc[mi][1][r] + bh[1]);
+                    pn = gi[mi][r][2];
+                    hn[mi][r] = acc[mi][2][r] + bh[2];
                 } else {
-                rg[mi][r] = p_sigmoid(gi[mi][r][0] + (acc[mi][0][r] + bh[0]));
-                zg[mi][r] = p_sigmoid(gi[mi][r][1] + (acc[mi][1][r] + bh[1]));
-                ng[mi][r] = p_tanh(gi[mi][r][2] + rg[mi][r] * hn[mi][r]);
+                    pr = gi[mi][r][0] + (acc[mi][0][r] + bh[0]);   // lower half-row: r, upper half-row: z
+                    pz = 0.f;
+                    pn = gi[mi][r][1];
+                    hn[mi][r] = acc[mi][1][r] + bh[1];
+                }
+                if (CPG_PERSIST_ABLATE & 8) {
+                    rg[mi][r] = pr;
+                    zg[mi][r] = CT == 16 ? pz : row_ror8(pr);
+                    ng[mi][r] = pn + rg[mi][r] * hn[mi][r];
+                } else {
+                    rg[mi][r] = p_sigmoid(pr);
+                    zg[mi][r] = CT == 16 ? p_sigmoid(pz) : row_ror8(rg[mi][r]);   // CT = 8: the upper half-row's sigmoid IS z
+                    ng[mi][r] = p_tanh(pn + rg[mi][r] * hn[mi][r]);
                 }
                 hprev[mi][r] = (1.f - zg[mi][r]) * ng[mi][r] + zg[mi][r] * hprev[mi][r];
-                if (dead) hprev[mi][r] = rg[mi][r] = __builtin_nanf("");   // a timed-out wait: make the damage visible
             }
+        if (__builtin_amdgcn_readfirstlane((int)dead)) {   // a timed-out wait (wave-uniform): make the damage visible
+#pragma unroll
+            for (int mi = 0; mi < P_MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hprev[mi][r] = rg[mi][r] = __builtin_nanf("");
+        }
 
         P_STAMP(4);
         // ---- publish h_t (split planes, write-through), drain, one arrival per wave; the f32 slab goes out behind it
@@ -449,7 +506,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             const int row = row0 + 16 * mi + srow;
             if (p + 1 < T)
                 publish_rows<NP>(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
-                             out_off + (unsigned)(j0 >> 5) * kb_bytes, row < B, lane);
+                                 out_off + (unsigned)(j0 >> 5) * kb_bytes, row < Bend && 4 * (scq & ~1) < CT, lane);
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         P_STAMP(5);
@@ -467,13 +524,21 @@ int plane_stride_words(int H) {
     return s;
 }
 
-size_t fwd_lds_bytes(int H, int np = 3) { return ((size_t)np * P_NC * plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
+size_t fwd_lds_bytes(int H, int ct, int np) { return ((size_t)np * 3 * ct * plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
+
+// hidden units per workgroup for width H: 16 while the 48 x H plane slice fits the LDS, else 8 (24 x H), else 0 (not covered)
+int pick_ct(int H, int np) {
+    if (H < 32 || H % 32 != 0) return 0;
+    if (fwd_lds_bytes(H, 16, np) <= 160 * 1024) return 16;
+    if (fwd_lds_bytes(H, 8, np) <= 160 * 1024) return 8;
+    return 0;
+}
 
 }  // namespace
 
 // Workgroups of the persistent kernel the CURRENT device holds at once with `lds` bytes of dynamic LDS each, as the occupancy
 // API reports it (registers, LDS, waves) - not an assumption about one workgroup per CU.
-template <int NP>
+template <int NP, int CT>
 static long resident_workgroups(size_t lds) {
     static std::mutex mu;
     static std::map<std::pair<int, size_t>, long> cache;   // (device, LDS bytes) -> workgroups
@@ -482,63 +547,77 @@ static long resident_workgroups(size_t lds) {
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find({dev, lds});
     if (it != cache.end()) return it->second;
-    const void* k = reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<NP>);
+    const void* k = reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<NP, CT>);
     if (cpg_allow_big_lds(k, 160 * 1024) != 0) return 0;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_seq_fwd_persist_kernel<NP>, P_WAVES * 64, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_seq_fwd_persist_kernel<NP, CT>, P_WAVES * 64, lds) != hipSuccess) return 0;
     return cache[{dev, lds}] = (long)per_cu * cpg_device_cus();
 }
 
-// 1 when the persistent kernel covers a [B rows, H hidden] sequence on this device: every workgroup (16 hidden units x 256
-// rows) co-resident by the occupancy API's count.  Option gru_persist = 0 disables the path (per-step launches).  The caller
-// must own the device: a second process (ranks sharing a GPU) or a concurrent kernel holding CUs breaks co-residency - the
-// host side switches the path off in that case (CPG_SHARED_DEVICE), and a wait that times out poisons the outputs with NaN.
-CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
+// Batch rows ONE persistent launch covers at width H on this device (0: width not covered): every workgroup (CT hidden
+// units x 256 rows) co-resident by the occupancy API's count.  Wider batches run as consecutive launches over row ranges
+// (rows are independent recurrences).  Option gru_persist = 0 disables the path (per-step launches).  The caller must own
+// the device: a second process (ranks sharing a GPU) or a concurrent kernel holding CUs breaks co-residency - the host side
+// switches the path off in that case (CPG_SHARED_DEVICE), and a wait that times out poisons the outputs with NaN.
+CPG_EXPORT int cpg_gru_persistent_rows(int H) {
     const CpgOptVal& o = cpg_opt(OPT_GRU_PERSIST);
     if (o.set && o.i == 0) return 0;
-    if (B <= 0 || H < 32 || H % 32 != 0) return 0;
-    if (fwd_lds_bytes(H) > 160 * 1024) return 0;
+    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const int ct = pick_ct(H, np);
+    if (ct == 0) return 0;
+    const size_t lds = fwd_lds_bytes(H, ct, np);
+    const long fit = np == 1 ? (ct == 16 ? resident_workgroups<1, 16>(lds) : resident_workgroups<1, 8>(lds))
+                             : (ct == 16 ? resident_workgroups<3, 16>(lds) : resident_workgroups<3, 8>(lds));
+    const long groups = fit / (H / ct);          // row groups of 256 rows (8 waves x 32 rows)
+    return (int)(groups * P_WAVES * P_WROWS);
+}
+
+// 1 when ONE launch covers a [B rows, H hidden] sequence
+CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
+    if (B <= 0) return 0;
     if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
-    const int groups = cdiv(cdiv(B, P_WROWS), P_WAVES);
-    const long wgs = (long)groups * (H / P_CT);
-    const long fit = cpg_compute_mode_get() == 1 ? resident_workgroups<1>(fwd_lds_bytes(H, 1)) : resident_workgroups<3>(fwd_lds_bytes(H, 3));
-    return wgs <= fit;
+    return B <= cpg_gru_persistent_rows(H);
 }
 
 static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_CNT_STRIDE; }
 static size_t sync_words(int B) { return (cnt_words(B) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
 
 CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
-    // + one exchange slot of three bf16 planes per step (+ the initial state): slots are never reused inside a launch
+    // counters + error word, then the exchange slots: three bf16 planes of the state, two slots (a slot per step + the initial
+    // state with CPG_PERSIST_PLAIN_LOADS)
     size_t n = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
 #if CPG_PERSIST_TRACE
-    n = (n + 255) / 256 * 256 + (size_t)cdiv(cdiv(B, P_WROWS), P_WAVES) * (H / P_CT) * P_WAVES * T * 8 * sizeof(unsigned long long);
+    n = (n + 255) / 256 * 256 + (size_t)cdiv(cdiv(B, P_WROWS), P_WAVES) * (H / 8) * P_WAVES * T * 8 * sizeof(unsigned long long);
 #endif
     return n;
 }
 
-// Whole forward sequence in one launch; arguments as cpg_gru_seq_fwd (all rows).  sync_scratch: device memory of
-// cpg_gru_persistent_scratch_bytes(T,B,H) bytes, ZEROED BY THE CALLER when allocated: arrival counters (re-zeroed here on the
-// stream before every launch), a sticky error word (set by a wave whose wait timed out, never cleared here) and the two
-// exchange slots.
+// Whole forward sequence of rows [row_begin, row_end) in one launch; other arguments as cpg_gru_seq_fwd.  sync_scratch:
+// device memory of cpg_gru_persistent_scratch_bytes(T,B,H) bytes, ZEROED BY THE CALLER when allocated: arrival counters
+// (re-zeroed here on the stream before every launch), a sticky error word (set by a wave whose wait timed out, never cleared
+// here) and the exchange slots.
 CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                           const int32_t* tok, const float* tab, const float* rowc, const float* dense,
-                                          float* hs, float* gates, void* sync_scratch, void* stream) {
+                                          float* hs, float* gates, int row_begin, int row_end, void* sync_scratch, void* err_host, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && sync_scratch);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
-    if (!cpg_gru_persistent_fits(B, H)) {
-        cpg_set_error("cpg_gru_seq_fwd_persistent: B=%d H=%d does not fit the persistent kernel on this device", B, H);
+    CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
+    const int rows = row_end - row_begin;
+    if (rows > cpg_gru_persistent_rows(H) || (size_t)B * H * 6 * 64 > (size_t)3 << 30) {
+        cpg_set_error("cpg_gru_seq_fwd_persistent: %d rows of B=%d at H=%d do not fit one persistent launch on this device", rows, B, H);
         return -5;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int nrt = cdiv(B, P_WROWS);
+    const int nrt = cdiv(rows, P_WROWS);
     CPG_HIP(hipMemsetAsync(sync_scratch, 0, cnt_words(B) * sizeof(unsigned), s));  // counters only: the error word is sticky
     PFwdArgs a;
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.gates = gates;
     a.cnt = (unsigned*)sync_scratch;
     a.err = a.cnt + cnt_words(B);
+    a.err_host = (unsigned*)err_host;
     a.xch = (uint16_t*)(a.cnt + sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
+    a.row0 = row_begin; a.row1 = row_end;
     a.groups = cdiv(nrt, P_WAVES);
     a.S = plane_stride_words(H);
 #if CPG_PERSIST_TRACE
@@ -547,17 +626,28 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
         a.trace = (unsigned long long*)((char*)sync_scratch + (base + 255) / 256 * 256);
     }
 #endif
-    // (the > 64 KB dynamic-LDS opt-in happened in cpg_gru_persistent_fits -> resident_workgroups, per device)
-    if (cpg_compute_mode_get() == 1)
-        hipLaunchKernelGGL(gru_seq_fwd_persist_kernel<1>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), fwd_lds_bytes(H, 1), s, a);
-    else
-        hipLaunchKernelGGL(gru_seq_fwd_persist_kernel<3>, dim3(a.groups * (H / P_CT)), dim3(P_WAVES * 64), fwd_lds_bytes(H, 3), s, a);
+    // (the > 64 KB dynamic-LDS opt-in happened in cpg_gru_persistent_rows -> resident_workgroups, per device)
+    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const int ct = pick_ct(H, np);
+    const dim3 grid(a.groups * (H / ct)), block(P_WAVES * 64);
+    const size_t lds = fwd_lds_bytes(H, ct, np);
+    if (np == 1 && ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<1, 16>), grid, block, lds, s, a);
+    else if (np == 1) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<1, 8>), grid, block, lds, s, a);
+    else if (ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<3, 16>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<3, 8>), grid, block, lds, s, a);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 
-// Byte offset of the sticky error word inside sync_scratch: the host copies it asynchronously to pinned memory behind every
-// launch and looks at the previous copy on the next call (no synchronisation on the hot path).
+// Name of the kernel a persistent launch at width H runs, as rocprofv3 prints it (bench.py's roofline object)
+CPG_EXPORT int cpg_gru_persistent_kernel_name(int H, char* buf, int n) {
+    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    return snprintf(buf, n, "gru_seq_fwd_persist_kernel<%d, %d>", np, pick_ct(H, np));
+}
+
+// Byte offset of the sticky error word inside sync_scratch (tests plant a value there).  On the hot path the host does not
+// read it: a wave that times out also sets err_host (pinned, host-mapped memory handed to the launch), which the host looks at
+// without any stream operation.
 CPG_EXPORT size_t cpg_gru_persistent_err_offset(int B) { return cnt_words(B) * sizeof(unsigned); }
 
 // Error word of the last persistent launch that used this scratch (synchronises the stream): 0 = every wait completed.

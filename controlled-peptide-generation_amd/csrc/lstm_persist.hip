@@ -53,17 +53,21 @@ struct LFwdArgs {
     float* gates;          // [T,4,B,H] or null
     unsigned* cnt;
     unsigned* err;
+    unsigned* err_host;   // host-mapped copy of the sticky error word, or null
     uint16_t* xch;         // [(T+1) slots][3 planes][H/32 k-blocks][B][32] bf16
     int T, B, H, reverse, groups, S;
 };
 
-__device__ __forceinline__ bool l_wait_ge(unsigned* p, unsigned target, unsigned* err, bool& dead) {
+__device__ __forceinline__ bool l_wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* err_host, bool& dead) {
     if (dead) return false;
     unsigned spins = 0;
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > L_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((threadIdx.x & 63) == 0) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (err_host) __hip_atomic_store(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             dead = true;
             return false;
         }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
                 for (int q = 0; q < 4; ++q) gi[mi][e][q] = x[q];
             }
 
-        l_wait_ge(a.cnt + rt * L_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, dead);
+        l_wait_ge(a.cnt + rt * L_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
 
         // ---- two passes over the wave's 64 rows (32 rows = 2 row blocks each): product, then the cell of those rows.  (One pass
         // over all four row blocks needs 96 registers of operand ring + 32 of accumulators next to the 72 of per-row constants:
@@ -358,7 +362,7 @@ CPG_EXPORT size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H) {
 // word is sticky, cpg_lstm_persistent_status reads it).
 CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                            const int32_t* tok, const float* tab, const float* rowc, const float* dense,
-                                           float* hs, float* cs, float* gates, void* sync_scratch, void* stream) {
+                                           float* hs, float* cs, float* gates, void* sync_scratch, void* err_host, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && cs && sync_scratch);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     if (!cpg_lstm_persistent_fits(B, H)) {
@@ -371,6 +375,7 @@ CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, con
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.cs = cs; a.gates = gates;
     a.cnt = (unsigned*)sync_scratch;
     a.err = a.cnt + l_cnt_words(B);
+    a.err_host = (unsigned*)err_host;
     a.xch = (uint16_t*)(a.cnt + l_sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(cdiv(B, L_WROWS), L_WAVES);

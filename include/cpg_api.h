@@ -129,15 +129,22 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
  * workgroup co-resident by hipOccupancyMaxActiveBlocksPerMultiprocessor's count; option gru_persist = 0 disables).
  * sync_scratch: cpg_gru_persistent_scratch_bytes(T,B,H) bytes of device memory, zeroed by the caller once (arrival counters,
  * re-zeroed by every call, a sticky error word at byte cpg_gru_persistent_err_offset(B), the bf16-plane exchange slots).
- * A wait that times out (workgroups not co-resident: another process or kernel holds CUs) sets the error word and NaN-poisons
- * everything the wave stores afterwards.  cpg_gru_persistent_status synchronises the stream and returns the error word.
+ * A wait that times out (workgroups not co-resident: another process or kernel holds CUs) sets the error word - and
+ * *err_host, so the host notices without a copy or a synchronisation - and NaN-poisons everything the wave stores afterwards.
+ * cpg_gru_persistent_status synchronises the stream and returns the error word.
  * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident. */
 CPG_API int cpg_gru_persistent_fits(int B, int H);
+/* batch rows one launch covers at width H on this device (0: width not covered; 16 hidden units per workgroup up to H = 512,
+ * 8 up to H = 1024); wider batches run as consecutive launches over row ranges [row_begin, row_end) */
+CPG_API int cpg_gru_persistent_rows(int H);
 CPG_API size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H);
 CPG_API size_t cpg_gru_persistent_err_offset(int B);
 CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
-                                       float* hs, float* gates, void* sync_scratch, void* stream);
+                                       float* hs, float* gates, int row_begin, int row_end, void* sync_scratch,
+                                       void* err_host /* pinned, host-mapped uint32 that a timed-out wave also sets; may be null */,
+                                       void* stream);
+CPG_API int cpg_gru_persistent_kernel_name(int H, char* buf, int n);
 CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
  * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.
@@ -169,7 +176,7 @@ CPG_API int cpg_lstm_persistent_fits(int B, int H);
 CPG_API size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H);
 CPG_API int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                         const int32_t* tok, const float* tab, const float* rowc, const float* dense,
-                                        float* hs, float* cs, float* gates, void* sync_scratch, void* stream);
+                                        float* hs, float* cs, float* gates, void* sync_scratch, void* err_host, void* stream);
 CPG_API size_t cpg_lstm_persistent_err_offset(int B);
 CPG_API int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (as cpg_gru_step_kernel_name): kind 0 forward step, 1 backward step. */

@@ -51,6 +51,10 @@ def _run(d, B, H, T, reverse, persistent):
     (333, 128, 9, True, True, False),       # dense input term (upper encoder layers), ragged last tile
     (64, 512, 50, False, False, True),      # one row tile, T = 50
     (1000, 256, 12, False, True, True),
+    (256, 1024, 6, False, False, True),     # configs[4] width: 8 hidden units per workgroup ([r|z], [n|n] column blocks)
+    (300, 768, 5, True, True, False),       # H = 768 also takes the 8-unit form; partial row tile, dense input term
+    (1100, 1024, 4, False, False, True),    # wider than one launch holds at H = 1024 (512 rows): consecutive row ranges
+    (4096, 512, 3, True, False, False),     # the same at H = 512 (2048 rows per launch)
 ])
 def test_persistent_forward_matches_per_step(B, H, T, reverse, dense, rowc):
     """Same split, same MFMA order, same cell formulas as the per-step kernel with 64-row split tiles: results agree to
@@ -88,30 +92,30 @@ def test_option_disables_persistent_path_and_limits():
     from cpg import ops
     with ops.options(gru_persist=0):
         assert not ops.persistent_fits(2048, 512)
-    assert ops.persistent_fits(2048, 512)
+    assert ops.persistent_fits(2048, 512) and ops.persistent_rows(512) == 2048     # 16 units x 256 rows per CU, 256 CUs
+    assert ops.persistent_rows(1024) == 512 and ops.persistent_rows(768) >= 512  # 8 units per workgroup
+    assert ops.persistent_fits(8192, 512)        # four launches over row ranges
     assert not ops.persistent_fits(2048, 102)    # H % 32 != 0
-    assert not ops.persistent_fits(8192, 512)    # more workgroups than the occupancy API says are co-resident
+    assert not ops.persistent_fits(256, 2048)    # the 24 x H plane slice does not fit the LDS
+    assert ops.query("cpg_gru_persistent_fits", 2048, 512) == 1 and ops.query("cpg_gru_persistent_fits", 4096, 512) == 0   # ONE launch
     with pytest.raises(ops.CpgError):
         ops.set_option("no_such_option", 1)
 
 
 def test_persistent_timeout_is_loud():
-    """The sticky error word reaches the host WITHOUT a synchronisation on the hot path: the copy queued behind a launch is
-    looked at on the next call that uses the scratch, and check_persistent() raises on it."""
+    """A timed-out wave sets the sticky error word in the scratch AND a host-mapped copy: the host sees it without a copy or a
+    synchronisation - at the next launch on that scratch, and in check_persistent()."""
     from cpg import ops
     B, H, T = 256, 64, 3
     d = _inputs(B, H, T, 24, seed=3)
     _run(d, B, H, T, False, True)
     key = next(k for k in ops._persist_scratch if k[0] == "gru" and k[3:] == (B, H))
     ent = ops._persist_scratch[key]
-    off = ops.query("cpg_gru_persistent_err_offset", B)
+    assert ent[2].is_pinned() and ent[2][0] == 0
     try:
-        ent[0][off:off + 4].copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))   # what a timed-out wave leaves behind
-        ent[2].copy_(ent[0][off:off + 4], non_blocking=True)
-        ent[3] = torch.cuda.current_stream().record_event()
-        torch.cuda.synchronize()
+        ent[2][0] = 1                                  # what a timed-out wave writes through the host-mapped pointer
         with pytest.raises(ops.CpgError, match="timed out"):
-            _run(d, B, H, T, False, True)              # noticed at the next launch on this scratch
+            _run(d, B, H, T, False, True)              # noticed before the next launch on this scratch
         with pytest.raises(ops.CpgError, match="timed out"):
             ops.check_persistent()
     finally:
