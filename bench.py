@@ -79,7 +79,7 @@ def family_roofline(family, dims, avg_us, launches):
     L = lib().dll
     bf16 = L.cpg_get_compute_mode() == 1
     if family == "fwd_persist":
-        kernel, split, flops = "gru_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 3 * H
+        kernel, split, flops = _cname("cpg_gru_persistent_kernel_name", H), (2 if bf16 else 1), T * 2.0 * B * H * 3 * H
     elif family == "fwd_step":
         kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0)
         flops = nd * 2.0 * B * H * 3 * H
@@ -269,7 +269,7 @@ def dist_selftest(args):
         print(json.dumps({"selftest": "dist", "n_gpus": world, "rccl": probe}))
 
 
-def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len, steps, warmup, min_sustain_s=0.0):
+def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len, steps, warmup, min_sustain_s=0.0, graph=False, z_dim=None):
     """One timed WAE-training leg: builds the model at the given dimensions, W untimed steps, EXACTLY `steps` timed steps
     bracketed by barrier + synchronize, max over ranks.  Returns the numbers of the leg (rank 0 builds the roofline rows).
     min_sustain_s > 0: afterwards the same step keeps running until that much wall time has passed (`sustained`): the timed
@@ -284,7 +284,7 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
 
     ops.set_compute_mode(dtype)
     T, V, B, Hh = seq_len, 24, batch, hidden
-    Z, E, R = Hh - 2, 150, 500
+    Z, E, R = (Hh - 2 if z_dim is None else z_dim), 150, 500
     torch.manual_seed(1238)
     model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh, enc_layers=enc_layers, cell=args.cell)).to(dev)
     model.device = dev
@@ -301,10 +301,14 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
     g = torch.Generator().manual_seed(1238 + rank)
     pool = [synth_ids(B, T, V, g).to(dev) for _ in range(8)]
 
+    graphed = tv.GraphedTrainStep(cfgv, model, trainer) if graph else None   # first calls eager, then capture, then replays
+
     def step(it):
+        if graphed is not None:
+            return graphed(pool[it % len(pool)], it)
         return tv.train_step(cfgv, model, trainer, pool[it % len(pool)], it)
 
-    for it in range(warmup):
+    for it in range(max(warmup, 5) if graph else warmup):
         step(it)
     torch.cuda.synchronize()
     cdist.barrier()
@@ -329,7 +333,8 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
     ms = dt / steps * 1e3
     res = {"value": round(B * world * steps / dt, 1), "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
            "loss_last_step": round(loss_val, 4), "host_enqueue_ms_per_step": round(t_enqueued / steps * 1e3, 3),
-           "grad_numel": trainer.flat_g.numel(), "launches_per_step": launch_count_per_step(lambda: step(warmup + steps))}
+           "grad_numel": trainer.flat_g.numel(),
+           "launches_per_step": None if graph else launch_count_per_step(lambda: step(warmup + steps))}
     if min_sustain_s > 0:
         # same step, same model, until min_sustain_s of wall time: per-step time over ALL of these iterations
         it, n = warmup + steps + 1, 0
@@ -458,6 +463,20 @@ def main():
             extra["bf16_mode"] = {"workload": workload_text(args, "bf16", Hh, args.enc_layers, B, T), "value": r["value"], "unit": "seq/s",
                                   "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "roofline": r["roofline"],
                                   "kernel_families": r["kernel_families"], "launches_per_step": r["launches_per_step"]}
+        if world == 1:
+            note("graph-replay legs")
+            r = train_leg(args, dev, rank, world, "f32", Hh, args.enc_layers, B, T, args.steps, args.warmup, graph=True)
+            extra["graph_replay"] = {"what": "the same step replayed from ONE captured hipGraph (train_vae.GraphedTrainStep; cfg.hw.graph)",
+                                     "value": r["value"], "unit": "seq/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                                     "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "graph_launches_per_step": 1,
+                                     "host_side_launches_per_step": 3}
+            # the reference's own defaults (config A: enc h=80, z=100, decoder h=102) at its default batch of 32: host-bound eagerly
+            ra = {}
+            for tag, gflag in (("eager", False), ("graph", True)):
+                rr = train_leg(args, dev, rank, world, "f32", 80, 1, 32, 25, 200, 20, graph=gflag, z_dim=100)
+                ra[tag] = {"value": rr["value"], "ms_per_step": rr["ms_per_step"], "host_enqueue_ms_per_step": rr["host_enqueue_ms_per_step"]}
+            extra["config_a_batch32"] = {"workload": "reference defaults (cfg.py:262-274: biGRU encoder h=80, z=100, GRU decoder h=102), batch 32, "
+                                                     "seq_len 25, f32-grade; 200 timed steps", "unit": "seq/s", **ra}
         note("config-C leg")
         cB, cK, cW = 256, max(3, min(args.steps, 6)), 2
         r = train_leg(args, dev, rank, world, "f32", 1024, 2, cB, 50, cK, cW)

@@ -201,6 +201,8 @@ hw = _bunchify(dict(
     world_size=1,         # data-parallel ranks (set by the launcher from WORLD_SIZE)
     synthetic_data=True,  # random-vocab peptide batches (the reference's curated CSVs are not reproducible)
     synthetic_size=20000,
+    graph=False,          # replay the training step from ONE captured hipGraph (train_vae.GraphedTrainStep): pays when the host
+                          # enqueue bounds the step (small batches); single rank, device_rng, dense decoder batches
     dump_states=True,     # main.py --phase 1 ends with the encode pass (states_<split>_<n_iter>: what sample_pipeline.py reads)
     dtype='f32',          # 'f32': f32-grade recurrent products (the parity path) | 'bf16': bf16 recurrent products - operands
                           # rounded to bf16, one bf16 MFMA per block, f32 accumulation / storage / master weights

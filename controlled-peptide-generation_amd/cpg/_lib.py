@@ -18,7 +18,7 @@ class LibraryMissing(RuntimeError):
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
-    "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64, "void": None,
+    "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "void": None,
 }
 
 

@@ -132,7 +132,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
                 u = uniforms[i]
             elif rng is not None:
                 seed, off = rng.next(2 * N)
-                u = ops.rng_uniform((N,), seed, off, dev, dtype=torch.float64)
+                u = ops.rng_uniform((N,), seed, off, dev, dtype=torch.float64, base=rng.base_for(dev))
             else:
                 u = torch.rand(N, dtype=torch.float64).to(dev)
             call("cpg_categorical_select", _p(logits), N, V, float(temp), _p(u.contiguous()), _p(finished), _p(ids), max_len + 1,

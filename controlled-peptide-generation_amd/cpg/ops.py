@@ -877,19 +877,26 @@ class WeightedSumFn(Function):
 
     @staticmethod
     def forward(ctx, w, *terms):
-        assert 1 <= len(terms) <= 4 and len(w) == len(terms)
+        """w: python floats, or a device float32 tensor [4] read by the kernels (captured training steps: the host rewrites it
+        between graph replays)."""
+        assert 1 <= len(terms) <= 4
         ts = [t.contiguous() for t in terms] + [None] * (4 - len(terms))
-        ws = [float(x) for x in w] + [0.0] * (4 - len(terms))
+        if isinstance(w, torch.Tensor):
+            assert w.is_cuda and w.dtype == torch.float32 and w.numel() == 4 and w.is_contiguous()
+            ws, wdev = [0.0] * 4, w
+        else:
+            assert len(w) == len(terms)
+            ws, wdev = [float(x) for x in w] + [0.0] * (4 - len(terms)), None
         out = torch.empty(1, device=terms[0].device, dtype=torch.float32)
-        call("cpg_weighted_sum4", _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), ws[0], ws[1], ws[2], ws[3], _p(out), _stream())
-        ctx.w, ctx.n = ws, len(terms)
+        call("cpg_weighted_sum4", _p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), ws[0], ws[1], ws[2], ws[3], _p(wdev), _p(out), _stream())
+        ctx.w, ctx.wdev, ctx.n = ws, wdev, len(terms)
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         o = torch.empty(4, device=g.device, dtype=torch.float32)
-        call("cpg_scale_fanout4", _p(g), ctx.w[0], ctx.w[1], ctx.w[2], ctx.w[3], _p(o), _stream())
+        call("cpg_scale_fanout4", _p(g), ctx.w[0], ctx.w[1], ctx.w[2], ctx.w[3], _p(ctx.wdev), _p(o), _stream())
         return (None,) + tuple(o[i] for i in range(ctx.n))
 
 
@@ -1036,20 +1043,63 @@ class MmdFullFn(Function):
 
 
 # ----------------------------------------------------------------------------------------------- random streams
-def rng_normal(shape, seed, offset, device):
+def rng_normal(shape, seed, offset, device, base=None):
+    """base: optional device int64[1] added to `offset` on the device (DeviceRng: hipGraph-replayable training steps)."""
     out = torch.empty(shape, device=device, dtype=torch.float32)
-    call("cpg_rng_normal", _p(out), out.numel(), int(seed), int(offset), _stream())
+    call("cpg_rng_normal", _p(out), out.numel(), int(seed), int(offset), _p(base), _stream())
     return out
 
 
-def rng_uniform(shape, seed, offset, device, dtype=torch.float32):
+def rng_uniform(shape, seed, offset, device, dtype=torch.float32, base=None):
     out = torch.empty(shape, device=device, dtype=dtype)
     name = "cpg_rng_uniform_f64" if dtype == torch.float64 else "cpg_rng_uniform"
-    call(name, _p(out), out.numel(), int(seed), int(offset), _stream())
+    call(name, _p(out), out.numel(), int(seed), int(offset), _p(base), _stream())
     return out
 
 
-def rng_bernoulli(shape, p_one, seed, offset, device):
+def rng_bernoulli(shape, p_one, seed, offset, device, base=None):
     out = torch.empty(shape, device=device, dtype=torch.uint8)
-    call("cpg_rng_bernoulli_u8", _p(out), out.numel(), float(p_one), int(seed), int(offset), _stream())
+    call("cpg_rng_bernoulli_u8", _p(out), out.numel(), float(p_one), int(seed), int(offset), _p(base), _stream())
     return out
+
+
+class DeviceRng:
+    """Counter-based device streams of one model (Philox4x32-10, cpg_rng_*): every draw takes the next counter range.  The
+    counter is split in two: a host-side offset RELATIVE to the current training step and a device-side base that `end_step()`
+    advances by the step's total - the launches of a step captured into a hipGraph carry the same relative offsets at every
+    replay and still draw fresh numbers, because the base they add lives in device memory."""
+
+    def __init__(self, seed, device=None):
+        self.seed, self.offset, self.device = int(seed), 0, device
+        self.base = None
+
+    def base_for(self, device):
+        if self.base is None:
+            self.base = torch.zeros(1, dtype=torch.int64, device=device)
+        return self.base
+
+    def next(self, n):
+        """(seed, offset) of a fresh n-element range, relative to the device base (pass base=self.base to ops.rng_*)."""
+        off = self.offset
+        self.offset += (int(n) + 3) // 4 + 1
+        return self.seed, off
+
+    def normal(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        seed, off = self.next(n)
+        return rng_normal(shape, seed, off, device, self.base_for(device))
+
+    def bernoulli(self, shape, p_one, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        seed, off = self.next(n)
+        return rng_bernoulli(shape, p_one, seed, off, device, self.base_for(device))
+
+    def end_step(self):
+        """Close the current step: the device base moves past everything drawn since the last call, offsets restart at 0."""
+        if self.base is not None and self.offset:
+            call("cpg_counter_add_u64", _p(self.base), int(self.offset), _stream())
+        self.offset = 0

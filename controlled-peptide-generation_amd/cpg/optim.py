@@ -77,7 +77,8 @@ class FusedAdamClip:
         self._inflight, self._reduced = [], set()
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
         self.reduce_fn, self.world = reduce_fn, int(world)
-        self.steps = [0] * len(self.order)
+        self.iter_dev = torch.zeros(1, device=dev, dtype=torch.int32)   # completed optimiser iterations, ON THE DEVICE: the Adam
+        self.iters = 0                                                   # step numbers are formed there (graph-replayable steps)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.ws = torch.empty(ops.query("cpg_sumsq_workspace") // 4, device=dev, dtype=torch.float32)
 
@@ -149,20 +150,21 @@ class FusedAdamClip:
             sumsq = self.sumsq
         b1, b2 = self.betas
 
-        def adam(off, k, step, coef_pow):
+        def adam(off, k, step_add, step_mult, coef_pow):
+            # step number = step_mult * iter_dev + step_add, formed on the device
             call("cpg_adam_step", _p(self.flat_p[off:]), _p(self.flat_g[off:]), _p(self.m[off:]), _p(self.v[off:]), k,
-                 float(self.lr), float(b1), float(b2), float(self.eps), int(step), _p(sumsq),
-                 float(self.max_norm if self.max_norm is not None else 0.0), int(coef_pow), float(gscale), _stream())
+                 float(self.lr), float(b1), float(b2), float(self.eps), int(step_add), _p(sumsq),
+                 float(self.max_norm if self.max_norm is not None else 0.0), int(coef_pow), float(gscale),
+                 _p(self.iter_dev), int(step_mult), _stream())
 
         i = 0
-        while i < len(self.order) and self.mult[i] > 1:
+        while i < len(self.order) and self.mult[i] > 1:     # a parameter listed mult times: mult consecutive Adam steps
             off, k = self.segs[i]
-            for _ in range(self.mult[i]):
-                self.steps[i] += 1
-                adam(off, k, self.steps[i], self.mult[i])
+            for j in range(self.mult[i]):
+                adam(off, k, j + 1, self.mult[i], self.mult[i])
             i += 1
         if i < len(self.order):
             off = self.segs[i][0]
-            for j in range(i, len(self.order)):
-                self.steps[j] += 1
-            adam(off, n - off, self.steps[i], 1)
+            adam(off, n - off, 1, 1, 1)
+        call("cpg_counter_add_i32", _p(self.iter_dev), 1, _stream())
+        self.iters += 1

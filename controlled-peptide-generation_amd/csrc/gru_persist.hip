@@ -62,6 +62,7 @@
 #ifndef CPG_PERSIST_TRACE
 #define CPG_PERSIST_TRACE 0
 #endif
+
 #if CPG_PERSIST_TRACE && !defined(CPG_DIAG)
 #error "CPG_PERSIST_TRACE needs -DCPG_DIAG"
 #endif
@@ -357,8 +358,9 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         const unsigned out_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p + 1 : ((p + 1) & 1)) * 3u * plane_bytes;
 
         P_STAMP(0);
-        // input-side pre-activations of this step: independent of the recurrence, fetched before the wait.  The (uniform) tests
-        // for the two optional sources sit OUTSIDE the element loops: each source's 8 x NB gathers form one clause of loads
+        // input-side pre-activations of this step: independent of the recurrence, fetched before the wait.  (Hoisting the
+        // source tests out of the element loops - one clause of 8 token loads, then one of 8 x NB gathers - was built and measured:
+        // faster in a synthetic micro-benchmark, 75-100 us per sequence SLOWER inside the training step; not kept.)
         float gi[P_MI][4][NB];
 #pragma unroll
         for (int mi = 0; mi < P_MI; ++mi)
@@ -366,31 +368,22 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) gi[mi][r][b] = rc[mi][r][b];
-        if (a.tok) {
-            int tk[P_MI][4];
 #pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi)
+        for (int mi = 0; mi < P_MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tk[mi][r] = a.tok[(size_t)tt * B + min(row0 + 16 * mi + 4 * lq + r, Bend - 1)];
-#pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float* t = a.tab + (size_t)tk[mi][r] * 3 * H;
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(row0 + 16 * mi + 4 * lq + r, Bend - 1);
+                if (a.tok) {
+                    const float* t = a.tab + (size_t)a.tok[(size_t)tt * B + row] * 3 * H;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) gi[mi][r][b] += t[gcol[b]];
                 }
-        }
-        if (a.dense) {
-#pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float* t = a.dense + ((size_t)tt * B + min(row0 + 16 * mi + 4 * lq + r, Bend - 1)) * 3 * H;
+                if (a.dense) {
+                    const float* t = a.dense + ((size_t)tt * B + row) * 3 * H;
 #pragma unroll
                     for (int b = 0; b < NB; ++b) gi[mi][r][b] += t[gcol[b]];
                 }
-        }
+            }
 
         if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
         P_STAMP(1);
@@ -465,7 +458,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 
         // ---- cell (same formulas and association as gru_step_fwd_kernel)
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi)
+        for (int mi = 0; mi < P_MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pr, pz, pn;     // r / z pre-activations, and gi_n
@@ -491,13 +484,11 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 }
                 hprev[mi][r] = (1.f - zg[mi][r]) * ng[mi][r] + zg[mi][r] * hprev[mi][r];
             }
-        if (__builtin_amdgcn_readfirstlane((int)dead)) {   // a timed-out wait (wave-uniform): make the damage visible
-#pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi)
+            if (__builtin_amdgcn_readfirstlane((int)dead)) {   // a timed-out wait (wave-uniform): make the damage visible
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hprev[mi][r] = rg[mi][r] = __builtin_nanf("");
+            }
         }
-
         P_STAMP(4);
         // ---- publish h_t (split planes, write-through), drain, one arrival per wave; the f32 slab goes out behind it
 #pragma unroll

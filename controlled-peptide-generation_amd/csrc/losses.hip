@@ -106,36 +106,39 @@ struct WSum4 {
     const float* t[4];
     float w[4];
 };
-__global__ void weighted_sum4_kernel(WSum4 a, float* out) {
+__global__ void weighted_sum4_kernel(WSum4 a, const float* wdev, float* out) {
     float s = 0.f;
     bool any = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (!a.t[i]) continue;
-        const float p = a.w[i] == 1.f ? a.t[i][0] : __fmul_rn(a.w[i], a.t[i][0]);
+        const float w = wdev ? wdev[i] : a.w[i];
+        const float p = w == 1.f ? a.t[i][0] : __fmul_rn(w, a.t[i][0]);
         s = any ? __fadd_rn(s, p) : p;
         any = true;
     }
     out[0] = s;
 }
-__global__ void scale_fanout4_kernel(const float* g, WSum4 a, float* out) {
+__global__ void scale_fanout4_kernel(const float* g, WSum4 a, const float* wdev, float* out) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = __fmul_rn(g[0], a.w[i]);
+    for (int i = 0; i < 4; ++i) out[i] = __fmul_rn(g[0], wdev ? wdev[i] : a.w[i]);
 }
-// out[0] = sum_i w_i * t_i[0] over the non-null terms (device scalars), in order
+// out[0] = sum_i w_i * t_i[0] over the non-null terms (device scalars), in order.  wdev (optional, device float[4]) replaces
+// the host weights: a captured training step reads the annealed beta from memory the host updates between replays.
 CPG_EXPORT int cpg_weighted_sum4(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1,
-                                 float w2, float w3, float* out, void* stream) {
+                                 float w2, float w3, const float* wdev, float* out, void* stream) {
     CPG_CHECK_ARG(out && (t0 || t1 || t2 || t3));
     WSum4 a{{t0, t1, t2, t3}, {w0, w1, w2, w3}};
-    hipLaunchKernelGGL(weighted_sum4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, out);
+    hipLaunchKernelGGL(weighted_sum4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, wdev, out);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 // out[i] = g[0] * w_i, i = 0..3
-CPG_EXPORT int cpg_scale_fanout4(const float* g, float w0, float w1, float w2, float w3, float* out, void* stream) {
+CPG_EXPORT int cpg_scale_fanout4(const float* g, float w0, float w1, float w2, float w3, const float* wdev, float* out,
+                                 void* stream) {
     CPG_CHECK_ARG(g && out);
     WSum4 a{{nullptr, nullptr, nullptr, nullptr}, {w0, w1, w2, w3}};
-    hipLaunchKernelGGL(scale_fanout4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, a, out);
+    hipLaunchKernelGGL(scale_fanout4_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, a, wdev, out);
     CPG_LAUNCH_CHECK();
     return 0;
 }

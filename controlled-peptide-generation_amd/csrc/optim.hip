@@ -43,7 +43,18 @@ CPG_EXPORT int cpg_sumsq(const float* x, size_t n, float mult, int accumulate, f
 
 __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                                  float eps, float bc1, float bc2_sqrt, const float* sumsq, float max_norm, int coef_pow,
-                                 float gscale) {
+                                 float gscale, int step, const int32_t* iter, int step_mult) {
+    __shared__ float s_bc[2];
+    if (iter) {   // step number formed on the device (captured training steps): the bias corrections once per block, in double
+        if (threadIdx.x == 0) {
+            const double st = (double)(step_mult * iter[0] + step);
+            s_bc[0] = (float)(1.0 - pow((double)b1, st));
+            s_bc[1] = (float)sqrt(1.0 - pow((double)b2, st));
+        }
+        __syncthreads();
+        bc1 = s_bc[0];
+        bc2_sqrt = s_bc[1];
+    }
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float coef = 1.f;
@@ -61,16 +72,17 @@ __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, s
     p[i] = p[i] - (lr / bc1) * (mi / denom);
 }
 
-// One Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad) of p[0..n) with step number `step` (1-based).
+// One Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad) of p[0..n) with step number `step` (1-based) - or,
+// with `iter` (device int32, completed optimiser iterations), step number step_mult * iter[0] + step formed on the device.
 // gscale multiplies the raw gradient first (1/world_size after a SUM all-reduce).  sumsq may be null (no clipping).
 CPG_EXPORT int cpg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                              float eps, int step, const float* sumsq, float max_norm, int coef_pow, float gscale,
-                             void* stream) {
+                             const int32_t* iter, int step_mult, void* stream) {
     CPG_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && coef_pow >= 1);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), sumsq, max_norm, coef_pow, gscale);
+                       lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), sumsq, max_norm, coef_pow, gscale, step, iter, step_mult);
     CPG_LAUNCH_CHECK();
     return 0;
 }

@@ -35,8 +35,7 @@ class WordDropout(nn.Module):
 
     def sample_mask(self, x):
         if self.rng is not None:
-            seed, off = self.rng.next(x.numel())
-            return ops.rng_bernoulli(tuple(x.shape), self.p, seed, off, x.device)
+            return self.rng.bernoulli(tuple(x.shape), self.p, x.device)
         m = np.random.binomial(1, p=self.p, size=tuple(x.size())).astype('uint8')  # reference's generator & call order
         return torch.from_numpy(m).to(x.device)
 
@@ -134,9 +133,7 @@ class GRUDecoder(nn.Module):
 
     def _sample_keep(self, shape, device):
         if self.rng is not None:
-            n = shape[0] * shape[1] * shape[2]
-            seed, off = self.rng.next(n)
-            return ops.rng_bernoulli(shape, 1.0 - self.p_out, seed, off, device)
+            return self.rng.bernoulli(shape, 1.0 - self.p_out, device)
         return (torch.rand(shape, device=device) >= self.p_out).to(torch.uint8)
 
     def forward_sample(self, sampleSoft, sampleHard, z, c, h):

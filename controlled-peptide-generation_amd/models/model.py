@@ -30,16 +30,7 @@ HARD_MODES = ('categorical', 'greedy', 'beam')
 SOFT_MODES = ('gumbel_soft', 'gumbel_ST', 'greedy_softmax', 'categorical_softmax', 'none_softmax')
 
 
-class DeviceRng:
-    """(seed, running offset) for the Philox streams of cpg_rng_*; one instance per model so every draw is distinct."""
-
-    def __init__(self, seed):
-        self.seed, self.offset = int(seed), 0
-
-    def next(self, n):
-        off = self.offset
-        self.offset += (int(n) + 3) // 4 + 1
-        return self.seed, off
+DeviceRng = ops.DeviceRng   # (seed, step-relative offset, device base): see cpg.ops
 
 
 class RNN_VAE(nn.Module):
@@ -82,8 +73,7 @@ class RNN_VAE(nn.Module):
 
     def _randn(self, n, d):
         if self.rng is not None:
-            seed, off = self.rng.next(n * d)
-            return ops.rng_normal((n, d), seed, off, self.device)
+            return self.rng.normal((n, d), self.device)
         return torch.randn(n, d).to(self.device)
 
     # ------------------------------------------------------------------ parameter groups (model.py:75-94)
@@ -123,8 +113,7 @@ class RNN_VAE(nn.Module):
     def sample_c_prior(self, mbsize):
         """c ~ Cat([.5,.5]) one-hot [mbsize, 2]."""
         if self.rng is not None:
-            seed, off = self.rng.next(mbsize)
-            bit = ops.rng_bernoulli((mbsize,), 0.5, seed, off, self.device).long()
+            bit = self.rng.bernoulli((mbsize,), 0.5, self.device).long()
             c = torch.zeros(mbsize, 2, device=self.device)
             c.scatter_(1, bit.unsqueeze(1), 1.0)
             return c

@@ -33,8 +33,10 @@ def make_optimizer(cfgv, model, reduce_fn=None, world=1, async_reduce_fn=None):
                          async_reduce_fn=async_reduce_fn)
 
 
-def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
-    """One full iteration.  Returns a dict of device scalars (no host sync)."""
+def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None), weights_dev=None):
+    """One full iteration.  Returns a dict of device scalars (no host sync).  weights_dev (optional, device float[4] =
+    (1, beta, lambda_L1, lambda_KL)): the loss weights are read from that tensor by the kernels instead of being launch arguments -
+    what a captured step needs (GraphedTrainStep rewrites it between replays)."""
     beta = utils.anneal(cfgv.beta, it)
     # the trainer consumes the logits only through recon_dec (pad targets ignored): the decoder may skip dead rows
     ragged_before = model.decoder.ragged
@@ -53,22 +55,84 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None)):
     z_regu_loss = {'kl': kl_loss, 'mmd': wae_mmd_loss, 'mmdrf': wae_mmdrf_loss}[cfgv.z_regu_loss]
     # loss = recon + beta * regu + lambda_L1 * L1 + lambda_KL * KLpenalty (train_vae.py:35-37), one launch
     from cpg.ops import WeightedSumFn
-    loss = WeightedSumFn.apply((1.0, beta, cfgv.lambda_logvar_L1, cfgv.lambda_logvar_KL), recon_loss, z_regu_loss, z_logvar_L1,
-                               z_logvar_KL_penalty)
+    weights = weights_dev if weights_dev is not None else (1.0, beta, cfgv.lambda_logvar_L1, cfgv.lambda_logvar_KL)
+    loss = WeightedSumFn.apply(weights, recon_loss, z_regu_loss, z_logvar_L1, z_logvar_KL_penalty)
     trainer.zero_grad()
     trainer.backward(loss)
     trainer.step()
+    if model.rng is not None:
+        model.rng.end_step()     # the device-side Philox base moves past this step's draws; host offsets restart at 0
     return dict(z_mu=z_mu, z_logvar=z_logvar, z_logvar_L1=z_logvar_L1, z_logvar_KL_penalty=z_logvar_KL_penalty, L_vae=loss,
                 L_vae_recon=recon_loss, L_vae_kl=kl_loss, L_wae_mmd=wae_mmd_loss, L_wae_mmdrf=wae_mmdrf_loss, beta=beta)
+
+
+class GraphedTrainStep:
+    """train_step captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed: ~185 launches become one graph launch, the
+    host's work per step shrinks to a batch copy, one fill and the replay (what small configurations - the reference's default
+    batch of 32 - are bound by).  What makes a replay a NEW step although its launch arguments are frozen:
+      * the batch lives in a static buffer that is overwritten before every replay;
+      * the Philox offsets of every random draw are relative to a device-side base that the step itself advances (DeviceRng);
+      * Adam's step number is formed on the device from an iteration counter the step increments (FusedAdamClip.iter_dev);
+      * the annealed beta is read from device memory (`weights`), rewritten by a fill launch before the replay.
+    Needs model.use_device_rng(...) (host generators cannot be captured) and a single rank (collectives stay eager)."""
+
+    def __init__(self, cfgv, model, trainer, warmup=3):
+        assert model.rng is not None, "a captured step needs the device random streams (model.use_device_rng)"
+        assert trainer.world == 1, "captured steps are single-rank (the gradient all-reduce stays eager)"
+        self.cfgv, self.model, self.trainer, self.warmup = cfgv, model, trainer, int(warmup)
+        self.text = self.weights = self.graph = self.out = None
+        self.calls = 0
+
+    def _eager(self, it):
+        self.weights[1:2].fill_(float(utils.anneal(self.cfgv.beta, it)))
+        return train_step(self.cfgv, self.model, self.trainer, self.text, it, weights_dev=self.weights)
+
+    def __call__(self, text, it):
+        """Iteration `it` on batch `text`.  The first `warmup` calls run eagerly ON THE CAPTURE STREAM (stream-keyed workspaces,
+        persistent-kernel scratch, side streams and LDS opt-ins then exist before the capture: allocating pinned memory or querying
+        occupancy inside a capture is not allowed); the next call captures the step - a capture records, it does not execute -
+        and every call from then on is one graph replay."""
+        if self.text is None:
+            dev = text.device
+            self.text = text.clone()
+            self.weights = torch.tensor([1.0, 0.0, float(self.cfgv.lambda_logvar_L1), float(self.cfgv.lambda_logvar_KL)], device=dev)
+            self.stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        if self.graph is None:
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.text.copy_(text, non_blocking=True)
+                if self.calls < self.warmup:
+                    out = self._eager(it)
+                    cur.wait_stream(self.stream)
+                    self.calls += 1
+                    return out
+            cur.wait_stream(self.stream)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                # recorded, not run: the replay below is this iteration.  (No beta fill in here: it would be frozen into the graph.)
+                self.out = train_step(self.cfgv, self.model, self.trainer, self.text, it, weights_dev=self.weights)
+        else:
+            self.text.copy_(text, non_blocking=True)
+        self.weights[1:2].fill_(float(utils.anneal(self.cfgv.beta, it)))
+        self.graph.replay()
+        self.calls += 1
+        out = dict(self.out)
+        out['beta'] = utils.anneal(self.cfgv.beta, it)
+        return out
 
 
 def train_vae(cfgv, model, dataset, reduce_fn=None, world=1, rank=0):
     print('Training base vae ...')
     trainer = make_optimizer(cfgv, model, reduce_fn, world)
+    # cfg.hw.graph: replay the step from one captured hipGraph (single rank, device random streams, dense decoder batches)
+    graphed = GraphedTrainStep(cfgv, model, trainer) if (cfg.hw.graph and world == 1 and model.rng is not None
+                                                        and not cfg.hw.ragged_decoder) else None
     for it in range(cfgv.s_iter, cfgv.s_iter + cfgv.n_iter + 1):
         logging_it = it % cfgv.cheaplog_every == 0 or it % cfgv.expsvlog_every == 0
         inputs = dataset.next_batch('train_vae')
-        t = train_step(cfgv, model, trainer, inputs.text, it)
+        t = graphed(inputs.text, it) if graphed is not None else train_step(cfgv, model, trainer, inputs.text, it)
         if logging_it:
             from cpg import ops
             ops.check_persistent()   # a timed-out inter-workgroup wait of a persistent launch raises here (logging syncs anyway)
@@ -87,6 +151,8 @@ def train_vae(cfgv, model, dataset, reduce_fn=None, world=1, rank=0):
                   'Grad_norm: {:.4e} '.format(it, vals['L_vae'], vals['L_vae_recon'], vals['L_vae_kl'], vals['L_wae_mmd'],
                                               trainer.grad_norm().item()))
             log_sent, _, _ = model.generate_sentences(1, sample_mode='categorical')
+            if model.rng is not None:
+                model.rng.end_step()     # draws made outside a training step: move the device base past them as well
             print('Sample (cat T=1.0): "{}"'.format(dataset.idx2sentence(log_sent.squeeze())))
             sys.stdout.flush()
         if it % cfgv.expsvlog_every == 0 and it > 0 and rank == 0:

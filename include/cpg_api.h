@@ -266,9 +266,11 @@ CPG_API int cpg_recon_ce_loss_fwd(const int64_t* ids, const float* logits, int B
                                   float* workspace, void* stream);
 /* train_vae.py:35-37, `loss = recon + beta*regu + l1w*L1 + klw*KLpen`: out[0] = sum_i w_i * t_i[0] over the non-null device
  * scalars, products and sums rounded one by one, left to right; cpg_scale_fanout4: out[i] = g[0] * w_i (its gradient). */
+/* wdev (optional, device float[4]) replaces w0..w3: a captured (hipGraph) training step reads the annealed beta from memory. */
 CPG_API int cpg_weighted_sum4(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1,
-                              float w2, float w3, float* out, void* stream);
-CPG_API int cpg_scale_fanout4(const float* g, float w0, float w1, float w2, float w3, float* out, void* stream);
+                              float w2, float w3, const float* wdev, float* out, void* stream);
+CPG_API int cpg_scale_fanout4(const float* g, float w0, float w1, float w2, float w3, const float* wdev, float* out,
+                              void* stream);
 /* dlogits = gout[0] * (softmax - onehot) / count[0] on valid rows (gout, count: device scalars) */
 CPG_API int cpg_recon_ce_bwd(const int64_t* ids, const float* logits, int B, int T, int V, int pad, const float* gout,
                              const float* count, float* dlogits, void* stream);
@@ -302,9 +304,10 @@ CPG_API int cpg_mmd_full_bwd(const float* z1, const float* z2, const float* P, c
 /* ---- optimiser: clip_grad_norm_ + Adam, train_vae.py:15,39-42 ---------------------------------------------------- */
 CPG_API size_t cpg_sumsq_workspace(void);
 CPG_API int cpg_sumsq(const float* x, size_t n, float mult, int accumulate, float* out, float* workspace, void* stream);
+/* iter (optional, device int32): the step number is step_mult * iter[0] + step, formed on the device (captured steps) */
 CPG_API int cpg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                           float eps, int step, const float* sumsq, float max_norm, int coef_pow, float gscale,
-                          void* stream);
+                          const int32_t* iter, int step_mult, void* stream);
 
 /* ---- CLaSS sampler: density_modeling.py:43-60,79-80 (sklearn GaussianMixture.sample / LogisticRegression) ---------- */
 CPG_API int cpg_gmm_sample(const double* means, const double* covars, const int32_t* comp, const double* normals, int n,
@@ -326,10 +329,16 @@ CPG_API int cpg_cnn_classifier_pool(const int64_t* ids, int B, int T, int V, int
                                     const float* tabs, const float* bias, float* pooled, void* stream);
 
 /* ---- counter-based random streams (Philox4x32-10) for callers that do not inject the draws ----------------------- */
-CPG_API int cpg_rng_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
-CPG_API int cpg_rng_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
-CPG_API int cpg_rng_uniform_f64(double* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
-CPG_API int cpg_rng_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint64_t seed, uint64_t offset, void* stream);
+/* base (optional, device uint64): added to `offset` on the device.  A training step replayed from a hipGraph keeps host-side
+ * offsets relative to the step and advances *base once per step with cpg_counter_add_u64. */
+CPG_API int cpg_rng_normal(float* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* base, void* stream);
+CPG_API int cpg_rng_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* base, void* stream);
+CPG_API int cpg_rng_uniform_f64(double* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* base, void* stream);
+CPG_API int cpg_rng_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint64_t seed, uint64_t offset, const uint64_t* base,
+                                 void* stream);
+/* device-side step counters of a captured training step: *p += by (one thread) */
+CPG_API int cpg_counter_add_u64(uint64_t* p, uint64_t by, void* stream);
+CPG_API int cpg_counter_add_i32(int32_t* p, int32_t by, void* stream);
 
 #ifdef __cplusplus
 }

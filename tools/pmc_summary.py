@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--match", action="append", default=[])
     ap.add_argument("--json")
     ap.add_argument("--skip-first", type=int, default=0, help="ignore the first N dispatches of every kernel (warm-up)")
+    ap.add_argument("--stamp-csrc", action="store_true",
+                    help="store bench.csrc_fingerprint() as \"_csrc_sha256_16\": bench.py reports traffic from a profile only when "
+                         "it was taken from the kernel sources it runs")
     a = ap.parse_args()
     files = []
     for p in a.paths:
@@ -74,6 +77,10 @@ def main():
         for c, v in row.items():
             print(f"    {c:32s} {v:16.1f}")
     if a.json:
+        if a.stamp_csrc:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            out["_csrc_sha256_16"] = bench.csrc_fingerprint()
         with open(a.json, "w") as fh:
             json.dump(out, fh, indent=1, sort_keys=True)
 

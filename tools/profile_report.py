@@ -8,7 +8,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 out = os.path.join(root, "profiles")
@@ -34,11 +34,12 @@ for r in rows[lo:hi]:
     agg[k][0] += 1
     agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(v[1] for v in agg.values())
-md = [f"# Round 2 profile ({tag}), 1x MI355X", "",
+md = [f"# Round {int(tag[1:3])} profile ({tag}), 1x MI355X", "",
       "Regenerate: `bash tools/profile_round.sh %s` on the GPU box, then `python tools/profile_report.py %s` (this file, "
       "`%s_kernel_stats.csv`, `%s_pmc.json`)." % (tag, tag, tag, tag), "",
-      "Command profiled: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5` "
-      "(default flags: training leg + CPU baseline leg + CLaSS leg).", "",
+      "Command profiled: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 "
+      "--no-extra-legs` (headline training leg + CPU baseline leg + CLaSS leg; the default command adds the bf16-mode and "
+      "config-C legs and a sustained region, whose launches would mix into the per-step table).", "",
       "Bench line of the profiled run (the profiler costs a few %):", "", "```", json.dumps(line), "```", "",
       f"## Training leg: kernels of the {nsteps} timed steps (kernels on the side stream overlap in time)", "",
       "| kernel | launches / step | avg us | ms / step | % of kernel time |", "|---|---|---|---|---|"]
@@ -63,8 +64,9 @@ md += ["", "## PMC readings of the recurrent kernels (separate passes: tools/pmc
        "MI355X_MICROARCH.md HBM section).  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8).", "",
        "| kernel | avg us | FETCH KB | WRITE KB | traffic MB | MFMA busy | VALU insts / wave | LDS bank-conflict share | wave-cycles waiting |",
        "|---|---|---|---|---|---|---|---|---|"]
+pmc = {k: v for k, v in pmc.items() if not k.startswith("_")}
 for k, r in sorted(pmc.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].get("dispatches", 0)):
-    if not any(t in k for t in ("gru_", "gemm_kernel<TileCfg<256", "lstm_")) or "FETCH_SIZE" not in r:
+    if not any(t in k for t in ("gru_", "gemm_kernel<TileCfg<256", "gemm_kernel<TileCfg<192", "lstm_")) or "FETCH_SIZE" not in r:
         continue
     busy = r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1024 * r.get("GRBM_GUI_ACTIVE", 1) / 8, 1)
     md.append(f"| `{k[:110]}` | {r.get('avg_us', 0):.1f} | {r['FETCH_SIZE']:.0f} | {r.get('WRITE_SIZE', 0):.0f} | "
