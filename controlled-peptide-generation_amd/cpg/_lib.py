@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, "include", "cpg_api.h")
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("CPG_LIB_PATH", os.path.join(PKG_DIR, "libcpg_hip.so"))  # override: diagnostic builds only
-SOURCES = ["api.hip", "gemm.hip", "gru.hip", "gru_persist.hip", "lstm.hip", "lstm_persist.hip", "decode.hip", "decode_fused.hip", "losses.hip", "optim.hip", "rng.hip", "class.hip", "classifier.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gru.hip", "gru_persist.hip", "lstm.hip", "lstm_persist.hip", "decode.hip", "decode_fused.hip", "losses.hip", "optim.hip", "rng.hip", "class.hip", "classifier.hip", "comm.hip"]
 
 
 class LibraryMissing(RuntimeError):
@@ -80,7 +80,7 @@ def build_library(force=False, verbose=False):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)

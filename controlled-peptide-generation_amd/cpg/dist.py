@@ -36,8 +36,89 @@ def local_device(local_rank):
     return local_rank % n if n else 0
 
 
+class LibComm:
+    """The library's own RCCL communicator (include/cpg_api.h: cpg_comm_*, cpg_allreduce_f32, cpg_allgatherv): collectives are
+    plain launches on a HIP stream of the caller's choice - no process-group stream, no Work objects.  The 128-byte unique id
+    travels over the torch.distributed group that is up anyway (any backend).  Opt-in: CPG_COMM=lib (default: torch.distributed)."""
+
+    def __init__(self, rank, world):
+        import ctypes
+        from . import ops
+        self.rank, self.world = rank, world
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            ops.call("cpg_comm_unique_id", buf)
+            idt = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            idt = idt.to(dev)
+            dist.broadcast(idt, 0)
+            idt = idt.cpu()
+        self._comm = ctypes.c_void_p()
+        ops.call("cpg_comm_init", ctypes.c_char_p(bytes(idt.numpy().tobytes())), rank, world, ctypes.byref(self._comm))
+
+    def allreduce_sum(self, t):
+        """In-place SUM on the CURRENT stream (asynchronous to the host)."""
+        from . import ops
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        ops.call("cpg_allreduce_f32", self._comm, ops._p(t), t.numel(), ops._stream())
+        return t
+
+    def allreduce_sum_async(self, t):
+        self.allreduce_sum(t)
+        return _StreamWork(torch.cuda.current_stream().record_event())
+
+    def allgather_rows(self, t):
+        """Variable number of rows per rank -> all rows in rank order (counts first, then one grouped set of broadcasts)."""
+        import ctypes
+        from . import ops
+        t = t.contiguous()
+        row_bytes = t[0:1].numel() * t.element_size() if t.dim() > 1 else t.element_size()
+        mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        allc = torch.zeros(self.world, dtype=torch.int64, device=t.device)
+        eight = (ctypes.c_size_t * self.world)(*([8] * self.world))
+        ops.call("cpg_allgatherv", self._comm, ops._p(mine), eight, self.rank, self.world, ops._p(allc), ops._stream())
+        rows = [int(x) for x in allc.cpu()]
+        out = torch.empty((sum(rows),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        counts = (ctypes.c_size_t * self.world)(*[r * row_bytes for r in rows])
+        if out.numel():
+            ops.call("cpg_allgatherv", self._comm, ops._p(t) if t.numel() else None, counts, self.rank, self.world, ops._p(out), ops._stream())
+        return out
+
+    def close(self):
+        from . import ops
+        if self._comm:
+            ops.call("cpg_comm_destroy", self._comm)
+            self._comm = None
+
+
+class _StreamWork:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+_lib_comm = None
+
+
+def lib_comm():
+    """The LibComm of this process when CPG_COMM=lib asked for it (created on first use, after init()), else None."""
+    global _lib_comm
+    if _lib_comm is None and os.environ.get("CPG_COMM") == "lib" and torch.cuda.is_available():
+        world, rank, _ = env_world()
+        if world == 1 or dist.is_initialized():
+            _lib_comm = LibComm(rank, world)
+    return _lib_comm
+
+
 def allreduce_sum(t):
     if dist.is_initialized() and dist.get_world_size() > 1:
+        c = lib_comm()
+        if c is not None and t.is_cuda and t.dtype == torch.float32:
+            return c.allreduce_sum(t)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -48,6 +129,9 @@ def is_initialized():
 
 def allreduce_sum_async(t):
     """Non-blocking SUM all-reduce; the returned Work's .wait() makes the current stream (RCCL) / the host (gloo) wait."""
+    c = lib_comm()
+    if c is not None and t.is_cuda and t.dtype == torch.float32:
+        return c.allreduce_sum_async(t)
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 

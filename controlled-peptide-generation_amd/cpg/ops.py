@@ -1042,6 +1042,39 @@ class MmdFullFn(Function):
         return dz, None, None, None
 
 
+# ----------------------------------------------------------------------------------------------- CNN classifier
+class CnnPoolFn(Function):
+    """ReLU + max-over-positions of the token-table form of the classifier's convolutions (models/classifier.py:49-53):
+    pooled [B, nconv*F] from ids [B,T], tabs [sum_w * V, F] (emb @ W_l[:, dw, :]^T per layer and tap) and bias [nconv, F].
+    Backward: the gradient of each pooled feature goes to the position its maximum came from - to the bias and to the table rows
+    that position read (cpg_cnn_classifier_pool_bwd); the tables' own gradients then reach the embedding and the filters."""
+
+    @staticmethod
+    def forward(ctx, ids, tabs, bias, V, min_w):
+        ids, tabs, bias = ids.contiguous(), tabs.contiguous(), bias.contiguous()
+        B, T = ids.shape
+        nconv, F_ = bias.shape
+        pooled = torch.empty(B, nconv * F_, device=ids.device, dtype=torch.float32)
+        need = tabs.requires_grad or bias.requires_grad
+        argpos = torch.empty(B, nconv * F_, device=ids.device, dtype=torch.int16) if need else None
+        call("cpg_cnn_classifier_pool", _p(ids), B, T, int(V), F_, int(min_w), nconv, _p(tabs), _p(bias), _p(pooled), _p(argpos),
+             _stream())
+        ctx.save_for_backward(ids, argpos)
+        ctx.dims = (B, T, int(V), F_, int(min_w), nconv, tabs.shape[0])
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        ids, argpos = ctx.saved_tensors
+        B, T, V, F_, min_w, nconv, rows = ctx.dims
+        dpooled = dpooled.contiguous()
+        dtabs = torch.empty(rows, F_, device=ids.device, dtype=torch.float32)
+        dbias = torch.empty(nconv, F_, device=ids.device, dtype=torch.float32)
+        call("cpg_cnn_classifier_pool_bwd", _p(ids), _p(argpos), _p(dpooled), B, T, V, F_, min_w, nconv, _p(dtabs), _p(dbias),
+             _stream())
+        return None, dtabs, dbias, None, None
+
+
 # ----------------------------------------------------------------------------------------------- random streams
 def rng_normal(shape, seed, offset, device, base=None):
     """base: optional device int64[1] added to `offset` on the device (DeviceRng: hipGraph-replayable training steps)."""

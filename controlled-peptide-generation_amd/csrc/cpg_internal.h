@@ -24,7 +24,7 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
 int cpg_compute_mode_get();
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 303
+#define CPG_ABI_VERSION 305
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).

@@ -3,9 +3,10 @@
 Counterpart of the reference's models/classifier.py:15-60.  The reference constructs it inside RNN_VAE but never
 trains it; it is reached only through q_c='classifier'.  The torch modules below are parameter containers
 (same checkpoint keys `classifier.conv_layers.{0,1,2}.*`, `classifier.fc.1.*`, same RNG consumption at construction).
-  * token inputs (`forward_tokens`, used by RNN_VAE.forward_classifier for id batches): HIP path, inference only - the
-    convolutions collapse to token-table look-ups (csrc/classifier.hip), pinned to the reference by
-    tests/golden/classifier_A.npz;
+  * token inputs (`forward_tokens`, used by RNN_VAE.forward_classifier for id batches): HIP path, forward and backward - the
+    convolutions collapse to token-table look-ups (csrc/classifier.hip), logits and gradients (of the classifier's own
+    parameters, of the embedding, and of the reconstruction loss through c = softmax(classifier(x))) pinned to the reference's
+    autograd by tests/golden/classifier_A.npz;
   * embedding / soft inputs (`forward`): plain torch, kept for completeness, no claim.
 """
 import torch
@@ -27,9 +28,9 @@ class CNNClassifier(nn.Module):
         self.conv_layers = nn.ModuleList([nn.Conv2d(1, num_filters, (w, emb_dim)) for w in widths])
         self.fc = nn.Sequential(nn.Dropout(dropout), nn.Linear(num_filters * len(widths), 2))
 
-    @torch.no_grad()
     def forward_tokens(self, ids, emb_weight):
-        """ids int64 [mbsize, seq_len] -> class logits [mbsize, 2] (eval-mode semantics: no dropout; no gradient)."""
+        """ids int64 [mbsize, seq_len] -> class logits [mbsize, 2]; differentiable in the classifier's parameters and in
+        emb_weight (the reference's q_c='classifier' path keeps this gradient, models/model.py:186-188)."""
         from cpg import ops
         B, T = ids.shape
         V, E = emb_weight.shape
@@ -37,21 +38,18 @@ class CNNClassifier(nn.Module):
         widths = [c.kernel_size[0] for c in self.conv_layers]
         assert widths == list(range(widths[0], widths[0] + len(widths))), 'consecutive filter widths expected'
         assert T >= widths[-1], 'Current classifier arch needs at least seqlen {}'.format(widths[-1])
-        tabs = torch.empty(sum(widths) * V, F_, device=ids.device, dtype=torch.float32)
-        row = 0
+        tabs = []
         for conv in self.conv_layers:
             w = conv.kernel_size[0]
             wmat = conv.weight.view(F_, w * E)                      # [F, w*E]: filter tap dw occupies columns dw*E..(dw+1)*E
             for dw in range(w):
-                ops.linear_raw(emb_weight, wmat[:, dw * E:(dw + 1) * E], None, out=tabs[row:row + V])
-                row += V
-        bias = torch.stack([c.bias for c in self.conv_layers]).contiguous()
-        pooled = torch.empty(B, len(widths) * F_, device=ids.device, dtype=torch.float32)
-        ops.call("cpg_cnn_classifier_pool", ops._p(ids.contiguous()), B, T, V, F_, widths[0], len(widths), ops._p(tabs),
-                 ops._p(bias), ops._p(pooled), ops._stream())
+                tabs.append(ops.LinearFn.apply(emb_weight, wmat[:, dw * E:(dw + 1) * E], None))    # [V, F]
+        tabs = torch.cat(tabs, 0)                                    # [sum_w * V, F]: layers and taps back to back
+        bias = torch.stack([c.bias for c in self.conv_layers])
+        pooled = ops.CnnPoolFn.apply(ids, tabs, bias, V, widths[0])
         if self.training and self.fc[0].p > 0:
             pooled = F.dropout(pooled, self.fc[0].p, True)
-        return ops.linear_raw(pooled, self.fc[1].weight, self.fc[1].bias)
+        return ops.LinearFn.apply(pooled, self.fc[1].weight, self.fc[1].bias)
 
     def forward(self, x):
         """x: embeddings [mbsize, seq_len, emb_dim] -> class logits [mbsize, 2]."""

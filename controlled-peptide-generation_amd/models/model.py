@@ -123,10 +123,10 @@ class RNN_VAE(nn.Module):
         return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep)
 
     def forward_classifier(self, inputs):
-        """Token inputs run the inference-only HIP path (no autograd tape: with q_c='classifier' the reference would let
-        gradients reach word_emb through c; it never trains that way - SURVEY F11 - and neither path is trained here)."""
+        """Token inputs run the HIP path (token-table convolutions), differentiable like the reference's: with q_c='classifier'
+        gradients reach the classifier and word_emb through c (models/model.py:135-144,186-188)."""
         if inputs.dim() == 2:
-            return self.classifier.forward_tokens(inputs, self.word_emb.weight)
+            return self.classifier.forward_tokens(inputs, self._emb_weight())
         else:
             from models.mutils import soft_embed
             x = soft_embed(self.word_emb, inputs)

@@ -322,11 +322,30 @@ CPG_API int cpg_lr_score_accept(const float* z, int n, int D, const double* coef
 CPG_API int cpg_residue_rows(const int16_t* ids, size_t n, int L, int first_residue, uint8_t* letters, int32_t* counts,
                              void* stream);
 
-/* ---- CNN classifier forward (ADJACENT row, inference only): models/classifier.py:39-60 ------------------------------
+/* ---- CNN classifier (ADJACENT row): models/classifier.py:39-60, reached through q_c='classifier' (models/model.py:186-188) ----
  * pooled[B, nconv*F] = max_p relu(bias + sum_dw tab[dw][ids[b,p+dw]]) for filters of widths min_width..min_width+nconv-1;
- * tabs = per layer [w][V][F] tables emb @ W[:,0,dw,:]^T (cpg_linear_fwd), layers back to back; bias [nconv,F]. */
+ * tabs = per layer [w][V][F] tables emb @ W[:,0,dw,:]^T (cpg_linear_fwd), layers back to back; bias [nconv,F].
+ * argpos (optional, int16 [B, nconv*F]): position each maximum came from (-1: ReLU flat) - what the backward needs.
+ * _bwd: dtabs (same layout as tabs) and dbias from dpooled; deterministic (batch walked in order per (layer, filter)). */
 CPG_API int cpg_cnn_classifier_pool(const int64_t* ids, int B, int T, int V, int F, int min_width, int nconv,
-                                    const float* tabs, const float* bias, float* pooled, void* stream);
+                                    const float* tabs, const float* bias, float* pooled, int16_t* argpos, void* stream);
+CPG_API int cpg_cnn_classifier_pool_bwd(const int64_t* ids, const int16_t* argpos, const float* dpooled, int B, int T, int V,
+                                        int F, int min_width, int nconv, float* dtabs, float* dbias, void* stream);
+
+/* ---- RCCL collectives of the path (the reference is single-device: new) -----------------------------------
+ * In-process communicator, one process per GPU.  librccl is bound at run time (the copy a PyTorch process has already loaded
+ * is reused); cpg_comm_available() == 0 when it cannot be.  Launcher: rank 0 -> cpg_comm_unique_id(id[128]) -> ship the
+ * bytes to every rank -> all ranks cpg_comm_init(id, rank, world, &comm) (collective).
+ * cpg_allreduce_f32: in-place SUM of the flat gradient buffer (train_vae.py's step under data parallelism), asynchronous on
+ * `stream` - issue it on a side stream to overlap with the rest of the backward pass.
+ * cpg_allgatherv: rank r contributes counts[r] BYTES (counts: host array, identical on every rank); recv gets them back to back
+ * in rank order - the accepted / decoded rows of a CLaSS sampling round (sample_pipeline.py:299-322 on sharded rounds). */
+CPG_API int cpg_comm_available(void);
+CPG_API int cpg_comm_unique_id(void* id128);
+CPG_API int cpg_comm_init(const void* id128, int rank, int world, void** comm);
+CPG_API int cpg_comm_destroy(void* comm);
+CPG_API int cpg_allreduce_f32(void* comm, float* buf, size_t n, void* stream);
+CPG_API int cpg_allgatherv(void* comm, const void* send, const size_t* counts, int rank, int world, void* recv, void* stream);
 
 /* ---- counter-based random streams (Philox4x32-10) for callers that do not inject the draws ----------------------- */
 /* base (optional, device uint64): added to `offset` on the device.  A training step replayed from a hipGraph keeps host-side

@@ -517,6 +517,32 @@ def classifier_vectors(name="A", seed=1238, B=16, **kw):
     out = {"w." + k: v.detach().numpy().copy() for k, v in model.state_dict().items()
            if k.startswith("classifier") or k == "word_emb.weight"}
     out.update(ids=ids.numpy(), logits=logits.numpy(), c_softmax=c.numpy())
+    # ---- gradients (the reference never trains the classifier, SURVEY F11, but its autograd defines them):
+    # (i) of sum(logits * gl) wrt the classifier's parameters and the embedding table, eval mode (no dropout);
+    gen2 = torch.Generator().manual_seed(seed + 43)
+    gl = torch.randn(B, 2, generator=gen2)
+    model.zero_grad()
+    (model.forward_classifier(ids) * gl).sum().backward()
+    out["gl"] = gl.numpy()
+    for k, prm in model.named_parameters():
+        if (k.startswith("classifier") or k == "word_emb.weight") and prm.grad is not None:
+            out["gcls." + k] = prm.grad.numpy().copy()
+    # (ii) of the reconstruction loss through c = softmax(classifier(x)) (models/model.py:186-188, q_c='classifier'), z = mu,
+    # eval mode, the word-dropout mask captured: what reaches the classifier's parameters comes through c alone
+    model.zero_grad()
+    np.random.seed(seed + 47)
+    cap = Capture()
+    with cap.on():
+        (mu, logvar), (z, c), dec = model(ids, q_c='classifier', sample_z='max')
+    loss = rlosses.recon_dec(ids, dec)
+    loss.backward()
+    out["qc.wd_mask"] = cap.take('binomial').astype(np.uint8)
+    out["qc.loss"] = np.float32(loss.item())
+    for k, prm in model.named_parameters():
+        if k.startswith("classifier") and prm.grad is not None:
+            out["gqc." + k] = prm.grad.numpy().copy()
+    out["gqc.word_emb.weight"] = model.word_emb.weight.grad.numpy().copy()
+    out.update({"wfull." + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
     np.savez_compressed(os.path.join(OUT, f"classifier_{name}.npz"), **out)
     print(f"classifier_{name}.npz written")
 

@@ -192,9 +192,45 @@ def test_cnn_classifier_forward_golden(golden):
     m.eval()
     ids = cu(g["ids"])
     logits = m.forward_classifier(ids)
-    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=1e-4)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], atol=1e-4)
     (mu, lv), (z, c), dec = m(ids, q_c='classifier', sample_z='max')
-    np.testing.assert_allclose(c.cpu().numpy(), g["c_softmax"], atol=1e-4)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), g["c_softmax"], atol=1e-4)
+
+
+def test_cnn_classifier_backward_golden(golden):
+    """Gradients of the classifier path against the reference's autograd (tests/golden/classifier_A.npz): (i) of sum(logits * gl)
+    wrt every classifier parameter and the embedding table (max-pool routing + token-table gradient kernel); (ii) of the
+    reconstruction loss through c = softmax(classifier(x)) with q_c='classifier' (models/model.py:186-188): what reaches the
+    classifier's parameters there comes through c alone."""
+    import losses
+    g = golden("classifier_A")
+    m = build_model(weights_of(g, prefix="wfull."))
+    m.eval()
+    ids = cu(g["ids"])
+    m.zero_grad()
+    logits = m.forward_classifier(ids)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), g["logits"], atol=1e-4)
+    (logits * cu(g["gl"])).sum().backward()
+    names = dict(m.named_parameters())
+    checked = 0
+    for k in g:
+        if not k.startswith("gcls."):
+            continue
+        ref, got = g[k], names[k[5:]].grad.cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+        checked += 1
+    assert checked == 9 and np.abs(g["gcls.classifier.conv_layers.1.weight"]).max() > 0
+    m.zero_grad()
+    (mu, lv), (z, c), dec = m(ids, q_c='classifier', sample_z='max', rnd=dict(wd_mask=cu(g["qc.wd_mask"])))
+    loss = losses.recon_dec(ids, dec)
+    assert abs(loss.item() - float(g["qc.loss"])) < 1e-4
+    loss.backward()
+    for k in g:
+        if not k.startswith("gqc."):
+            continue
+        ref, got = g[k], names[k[4:]].grad.cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+    assert np.abs(g["gqc.classifier.fc.1.weight"]).max() > 0
 
 
 @pytest.mark.parametrize("n_best", [1, 3, 5])

@@ -50,6 +50,21 @@ tr = tv.make_optimizer(cfgv, m, lambda x: dist.all_reduce(x), 1)
 ids = synth_ids(128, 25, 24, torch.Generator().manual_seed(1)).cuda()
 out = tv.train_step(cfgv, m, tr, ids, 0)
 assert torch.isfinite(out["L_vae"]).item()
+# the library's own communicator (cpg_comm_*, cpg_allreduce_f32, cpg_allgatherv) at world 1: librccl bound at run time (the copy
+# torch has loaded), id exchange, collectives as plain stream launches
+from cpg import ops
+assert ops.query("cpg_comm_available") == 1
+c = cdist.LibComm(0, 1)
+g = torch.arange(1 << 18, device="cuda", dtype=torch.float32)
+c.allreduce_sum(g)
+rows = torch.randn(37, 5, device="cuda")
+got = c.allgather_rows(rows)
+work = c.allreduce_sum_async(g)
+work.wait()
+torch.cuda.synchronize()
+assert torch.equal(g, torch.arange(1 << 18, device="cuda", dtype=torch.float32)) and torch.equal(got, rows)
+assert c.allgather_rows(rows[:0]).shape == (0, 5)
+c.close()
 dist.destroy_process_group()
 print("RCCL_OK")
 '''

@@ -53,7 +53,11 @@ def test_oracle_lstm_matches_torch(reverse):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,T,H,V,reverse", [(7, 6, 12, 9, False), (70, 5, 36, 24, True), (130, 4, 64, 24, False)])
+@pytest.mark.parametrize("B,T,H,V,reverse", [(7, 6, 12, 9, False), (70, 5, 36, 24, True), (130, 4, 64, 24, False),
+                                             # BASELINE.json configs[1] size ("hidden=512 1-layer LSTM, batch=2048, seq_len<=25"): here the
+                                             # launcher itself picks the persistent forward, the direct-to-LDS backward step and the
+                                             # 256 x 128 split-K dW tiles - against oracle/lstm.py (itself pinned to torch.nn.LSTM)
+                                             (2048, 25, 512, 24, False), (2048, 25, 512, 24, True)])
 def test_hip_lstm_sequence_matches_oracle(B, T, H, V, reverse):
     from cpg import ops
     if not torch.cuda.is_available():
@@ -68,8 +72,11 @@ def test_hip_lstm_sequence_matches_oracle(B, T, H, V, reverse):
     dslab = (rs.randn(T + 1, B, H) * 0.3).astype(np.float32)
     cu = lambda a: torch.from_numpy(a).cuda()
     tt = {k: cu(v).requires_grad_() for k, v in dict(tab=tab, rowc=rowc, h0=h0, c0=c0, w_hh=w_hh, b_hh=b_hh).items()}
+    if H == 512:
+        assert ops.lstm_persistent_fits(B, H)
     slab = ops.LstmSeqFn.apply(cu(tok), tt["tab"], tt["rowc"], None, tt["h0"], tt["c0"], tt["w_hh"], tt["b_hh"], T, reverse)
     slab.backward(cu(dslab))
+    ops.check_persistent()
     gi = (tab[tok] + rowc[None]).transpose(1, 0, 2)  # [B,T,4H]
     hs, _, _, caches = olstm.lstm_seq_fwd(gi, h0, c0, w_hh, b_hh, reverse)
     got = slab.detach().cpu().numpy()
