@@ -62,6 +62,14 @@
 #ifndef CPG_PERSIST_TRACE
 #define CPG_PERSIST_TRACE 0
 #endif
+// Row tiles per wave.  1: a wave owns ONE 32-row tile (one arrival counter, one chain of steps).  2: the wave's 32 rows are TWO
+// 16-row tiles with their own arrival counters, processed one after the other inside every step: while the wave works on tile B,
+// the 32 producers of tile A finish and arrive - the wait for the slowest of them (6 of 19.6 us per step in the one-tile form,
+// tools/persist_trace.py) runs under useful work instead of idling the wave.  Same registers (the tiles share them), twice the
+// B-fragment LDS reads and counter traffic.
+#ifndef CPG_PERSIST_SUBTILES
+#define CPG_PERSIST_SUBTILES 1
+#endif
 
 #if CPG_PERSIST_TRACE && !defined(CPG_DIAG)
 #error "CPG_PERSIST_TRACE needs -DCPG_DIAG"
@@ -109,6 +117,10 @@ constexpr int P_DEPTH = CPG_PERSIST_DEPTH;
 constexpr int P_WAVES = CPG_PERSIST_WAVES;
 constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
+constexpr int P_SUB = CPG_PERSIST_SUBTILES;          // row tiles per wave
+constexpr int P_MIS = P_MI / P_SUB;                  // 16-row blocks per row tile
+static_assert(P_MI % P_SUB == 0 && P_MIS >= 1, "row tiles per wave must divide the wave's row blocks");
+static_assert(P_SUB == 1 || !CPG_PERSIST_DEFER, "deferred gate stores are a one-tile-per-wave form");
 #ifndef CPG_PERSIST_TBW
 #define CPG_PERSIST_TBW 16
 #endif
@@ -304,7 +316,13 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                          row < Bend && 4 * (scq & ~1) < CT, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // row tile s of this wave: rows [row0 + 16 s P_MIS, ...); a tile that starts past the end does not exist (nobody waits for it)
+    unsigned* const cnt0 = a.cnt + (size_t)rt * P_SUB * P_CNT_STRIDE;
+    if (lane == 0) {
+#pragma unroll
+        for (int sb = 0; sb < P_SUB; ++sb)
+            if (row0 + 16 * sb * P_MIS < Bend) __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // A-operand addressing: lane (l15, lq) of row block mi reads 8 consecutive k of row row0 + 16 mi + l15 (16 bytes of a plane)
     int aoff[P_MI];
@@ -319,11 +337,11 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     float rg[P_MI][4], zg[P_MI][4], ng[P_MI][4], hn[P_MI][4];
     f32x4 hrow[P_MI];
     int pend_tt = -1;
-    auto flush = [&]() {
+    auto flush = [&](int mi0, int mi1) {
         if (pend_tt < 0) return;
         float* const hout = a.hs + (size_t)(a.reverse ? pend_tt : pend_tt + 1) * B * H;
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi) {
+        for (int mi = mi0; mi < mi1; ++mi) {
             const int row = row0 + 16 * mi + srow;
             if (row < Bend && cvalid) *reinterpret_cast<f32x4*>(hout + (size_t)row * H + j0 + 4 * scq) = hrow[mi];
         }
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             const size_t BH = (size_t)B * H;
             float* const gbase = a.gates + (size_t)pend_tt * 4 * BH;
 #pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi) {
+            for (int mi = mi0; mi < mi1; ++mi) {
                 const int row = row0 + 16 * mi + srow;
                 const f32x4 v0 = acc_to_rows(tb, rg[mi], lane);
                 const f32x4 v1 = acc_to_rows(tb, zg[mi], lane);
@@ -357,19 +375,24 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         const unsigned in_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p : (p & 1)) * 3u * plane_bytes;
         const unsigned out_off = (unsigned)(CPG_PERSIST_PLAIN_LOADS ? p + 1 : ((p + 1) & 1)) * 3u * plane_bytes;
 
-        P_STAMP(0);
+#pragma unroll
+        for (int sb = 0; sb < P_SUB; ++sb) {
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int MI0 = sb * P_MIS, MI1 = MI0 + P_MIS;
+        if (row0 + 16 * MI0 >= Bend) continue;      // wave-uniform: this row tile does not exist
+        if (sb == 0) P_STAMP(0);
         // input-side pre-activations of this step: independent of the recurrence, fetched before the wait.  (Hoisting the
         // source tests out of the element loops - one clause of 8 token loads, then one of 8 x NB gathers - was built and measured:
         // faster in a synthetic micro-benchmark, 75-100 us per sequence SLOWER inside the training step; not kept.)
-        float gi[P_MI][4][NB];
+        float gi[P_MI][4][NB];   // (only rows MI0..MI1 of the arrays below are live in this phase)
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi)
+        for (int mi = MI0; mi < MI1; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) gi[mi][r][b] = rc[mi][r][b];
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi)
+        for (int mi = MI0; mi < MI1; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = min(row0 + 16 * mi + 4 * lq + r, Bend - 1);
@@ -385,9 +408,9 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 }
             }
 
-        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(a.cnt + rt * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
-        P_STAMP(1);
-        if (CPG_PERSIST_DEFER) flush();
+        if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(cnt0 + sb * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
+        if (sb == 0) P_STAMP(1);
+        if (CPG_PERSIST_DEFER) flush(MI0, MI1);
 #if CPG_PERSIST_ACQUIRE
         // plain (L2-allocating) loads behind ONE agent-scope acquire
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -396,7 +419,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         // ---- recurrent product: acc[mi][b] = h_prev[32 rows, H] . (block b's 16 rows of the W_hh slice)^T
         f32x4 acc[P_MI][NB];
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi)
+        for (int mi = MI0; mi < MI1; ++mi)
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[mi][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 buf[P_DEPTH][P_MI][NP];  // register ring: the loads of k-block kb + P_DEPTH - 1 are in flight while kb is multiplied
@@ -407,7 +430,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             int kb = kbi + rot;
             kb = kb >= KB ? kb - KB : kb;
 #pragma unroll
-            for (int mi = 0; mi < P_MI; ++mi)
+            for (int mi = MI0; mi < MI1; ++mi)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     bf[mi][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[mi], in_off + pl * plane_bytes + kb * kb_bytes,
@@ -424,7 +447,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                     fb[b][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase[b] + pl * PLW + kb * 16);
             if (CPG_PERSIST_ABLATE & 4) {
 #pragma unroll
-                for (int mi = 0; mi < P_MI; ++mi)
+                for (int mi = MI0; mi < MI1; ++mi)
 #pragma unroll
                     for (int b = 0; b < NB; ++b) acc[mi][b] += __builtin_bit_cast(f32x4, bf[mi][0]) * __builtin_bit_cast(f32x4, fb[b][0]);
                 return;
@@ -435,7 +458,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
 #pragma unroll
             for (int t = (NP == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
-                for (int mi = 0; mi < P_MI; ++mi)
+                for (int mi = MI0; mi < MI1; ++mi)
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
                         acc[mi][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, bf[mi][NP == 3 ? TA[t] : 0]),
@@ -450,15 +473,15 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 if (kb + d < KB) {
                     if (kb + d + P_DEPTH - 1 < KB && !(CPG_PERSIST_ABLATE & 2)) load(buf[(d + P_DEPTH - 1) % P_DEPTH], kb + d + P_DEPTH - 1);
                     compute(buf[d], kb + d);
-                    if (kb + d == 0) P_STAMP(2);
+                    if (kb + d == 0) if (sb == 0) P_STAMP(2);
                 }
             }
         }
-        P_STAMP(3);
+        if (sb == 0) P_STAMP(3);
 
         // ---- cell (same formulas and association as gru_step_fwd_kernel)
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi) {
+        for (int mi = MI0; mi < MI1; ++mi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pr, pz, pn;     // r / z pre-activations, and gi_n
@@ -489,10 +512,10 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 for (int r = 0; r < 4; ++r) hprev[mi][r] = rg[mi][r] = __builtin_nanf("");
             }
         }
-        P_STAMP(4);
+        if (sb == 0) P_STAMP(4);
         // ---- publish h_t (split planes, write-through), drain, one arrival per wave; the f32 slab goes out behind it
 #pragma unroll
-        for (int mi = 0; mi < P_MI; ++mi) {
+        for (int mi = MI0; mi < MI1; ++mi) {
             hrow[mi] = acc_to_rows(tb, hprev[mi], lane);
             const int row = row0 + 16 * mi + srow;
             if (p + 1 < T)
@@ -500,13 +523,14 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                                  out_off + (unsigned)(j0 >> 5) * kb_bytes, row < Bend && 4 * (scq & ~1) < CT, lane);
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        P_STAMP(5);
-        if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sb == 0) P_STAMP(5);
+        if (lane == 0) __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_tt = tt;
-        if (!CPG_PERSIST_DEFER) flush();
-        P_STAMP(6);
+        if (!CPG_PERSIST_DEFER) flush(MI0, MI1);
+        if (sb == 0) P_STAMP(6);
+        }   // row tiles of the wave
     }
-    if (CPG_PERSIST_DEFER) flush();
+    if (CPG_PERSIST_DEFER) flush(0, P_MI);
 }
 
 int plane_stride_words(int H) {
@@ -570,7 +594,7 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
     return B <= cpg_gru_persistent_rows(H);
 }
 
-static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_CNT_STRIDE; }
+static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_SUB * P_CNT_STRIDE; }
 static size_t sync_words(int B) { return (cnt_words(B) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
 
 CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {

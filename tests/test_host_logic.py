@@ -172,3 +172,66 @@ def test_peptide_column_from_residue_rows_both_forms(monkeypatch):
     df = pd.DataFrame({'peptide': col})
     assert df.peptide.str.replace(' ', '').tolist() == [r.replace(' ', '') for r in ref]
     assert df.peptide.isin(ref[:5]).sum() >= 5 and len(df.peptide.drop_duplicates()) == len(set(ref))
+
+
+def test_synthetic_loader_labels_splits_and_subsets():
+    """The loader carries what the CLaSS pipeline needs from the reference's AttributeDataLoader: attribute labels in its
+    1 / 0 / -1 convention (deterministic functions of the sequence, a share unlabelled), a split column, label-query subsets."""
+    from cpg.synth import ATTR_NAMES, SyntheticPeptideLoader, synth_labels
+    d = SyntheticPeptideLoader(4, 25, 'cpu', size=2000, seed=3)
+    assert d.labels.shape == (2000, len(ATTR_NAMES)) and set(np.unique(d.labels[:, :2].numpy())) == {-1, 0, 1}
+    assert (d.labels[:, 2:] == -1).all()
+    assert list(np.unique(d.split)) == ['test', 'train', 'val'] and (d.split == 'train').sum() == 1600
+    again = synth_labels(d.pool, torch.Generator().manual_seed(0), p_na=0.0)
+    lab = d.labels[:, :2]
+    assert ((lab == -1) | (lab == again[:, :2])).all()                       # labelled entries ARE the rule; the rest is 'na'
+    stoi = d.TEXT.vocab.stoi
+    charge = sum((d.pool == stoi[a]).sum(1) for a in "KR") - sum((d.pool == stoi[a]).sum(1) for a in "DE")
+    assert torch.equal(again[:, 0], (charge >= 1).long())
+    ids, labels = d.subset('train', {'amp': 1})
+    assert 100 < ids.shape[0] < 1600 and (labels[:, 0] == 1).all()
+    ids2, _ = d.subset('train,val', {'amp': 1, 'tox': 0})
+    assert 0 < ids2.shape[0] and d.subset(None)[0].shape[0] == 2000
+
+
+def test_save_samples_writes_the_reference_file_set(tmp_path):
+    """sample_pipeline.save_samples (reference :149-160): <prefix>_<date>.plain.txt / .csv / .pkl and .accepted.<n>.csv / .pkl."""
+    import datetime
+    import pandas as pd
+    import sample_pipeline as sp
+    df = pd.DataFrame({'peptide': ['A C', 'D E F', 'G'], 'z': [np.zeros(3, np.float32)] * 3, 'accept_z': [True, False, True],
+                       'clfZ_prob_accum': [0.9, 0.1, 0.8], 'accept': [True, False, True]})
+    stem = sp.save_samples(df, str(tmp_path), 'smp')
+    assert stem.endswith('smp_' + datetime.date.today().isoformat())
+    full = pd.read_csv(stem + '.csv')
+    assert list(full.columns)[0] == 'idx' and 'z' not in full.columns and len(full) == 3
+    acc = pd.read_csv(stem + '.accepted.2.csv')
+    assert list(acc['peptide']) == ['A C', 'G']
+    assert len(pd.read_pickle(stem + '.pkl')) == 3 and len(pd.read_pickle(stem + '.accepted.2.pkl')['z'].iloc[0]) == 3
+    assert open(stem + '.plain.txt').read().split('\n')[1].strip() == 'D E F'
+
+
+def test_oracle_precision_context_is_scoped():
+    import oracle
+    from oracle import decode, gru, optim, wae
+    assert gru.F32 is np.float32
+    with oracle.precision(np.float64):
+        assert all(m.F32 is np.float64 for m in (gru, wae, decode, optim))
+        x = gru.sigmoid(np.array([0.25], np.float64))
+        assert x.dtype == np.float64
+    assert all(m.F32 is np.float32 for m in (gru, wae, decode, optim))
+    t = oracle.as_f64({'a': np.zeros(2, np.float32), 'b': np.zeros(2, np.uint8)})
+    assert t['a'].dtype == np.float64 and t['b'].dtype == np.uint8
+
+
+def test_evaluate_nll_and_prior_logpdf():
+    """density_modeling.evaluate_nll / prior_logpdf (reference :11-14,118-128) on a stand-in density: the standard normal itself."""
+    import math
+    import density_modeling as dm
+
+    class StdNormal:
+        def logpdf(self, z):
+            return dm.prior_logpdf(z)
+    mu, lv = torch.zeros(50, 4, dtype=torch.float64), torch.full((50, 4), -30.0, dtype=torch.float64)
+    nq, npr = dm.evaluate_nll(StdNormal(), (mu, lv))
+    assert abs(nq - npr) < 1e-12 and abs(nq - 0.5 * 4 * math.log(math.tau)) < 1e-6

@@ -76,6 +76,12 @@ for k, r in sorted(pmc.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].g
               f"{100 * r.get('SQ_WAIT_ANY', 0) / max(r.get('SQ_WAVE_CYCLES', 1), 1):.0f} % |")
 os.makedirs(out, exist_ok=True)
 open(os.path.join(out, f"{tag}_bench_n1_summary.md"), "w").write("\n".join(md) + "\n")
+# launches per step of the profiled (eager) step go into the PMC json next to its source fingerprint: bench.py quotes them from there
+pj = os.path.join(src, tag + "_pmc.json")
+d = json.load(open(pj))
+d["_launches_per_step"] = round(sum(v[0] for v in agg.values()) / nsteps, 1)
+d["_torch_glue_launches_per_step"] = round(sum(v[0] for k, v in agg.items() if k.startswith('at::') or k.startswith('__amd')) / nsteps, 1)
+json.dump(d, open(pj, "w"), indent=1, sort_keys=True)
 for a, b in ((f"{tag}_kernel_stats.csv", f"{tag}_bench_n1_kernel_stats.csv"), (f"{tag}_pmc.json", f"{tag}_pmc.json"),
              ("bench_line.json", f"{tag}_bench_line.json"), ("bench_line_bf16.json", f"{tag}_bench_line_bf16.json")):
     p = os.path.join(src, a)
