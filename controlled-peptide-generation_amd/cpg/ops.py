@@ -437,7 +437,20 @@ def _persist_failed(kind):
                    "per-step kernels" % (kind.upper(), kind))
 
 
+def gates_dtype(B, H, ragged=False):
+    """Element type of a GRU sequence's saved gates [T,4,B,H]: bf16 in the bf16 compute mode on dense batches that the
+    direct-to-LDS backward step covers (cpg_gru_gates_bf16: the BPTT epilogue is HBM-bound there), f32 otherwise."""
+    return torch.bfloat16 if query("cpg_gru_gates_bf16", B, H, int(bool(ragged))) == 1 else torch.float32
+
+
+def _check_gates(gates, B, H, ragged=False):
+    if gates is not None and gates.dtype != gates_dtype(B, H, ragged):
+        raise CpgError("saved gates are %s but the library now expects %s: compute mode / options changed between the forward "
+                       "and the backward pass of a sequence" % (gates.dtype, gates_dtype(B, H, ragged)))
+
+
 def gru_seq_fwd_persistent(T, B, H, reverse, w_hh, b_hh, tok, tab, rowc, dense, hs, gates):
+    _check_gates(gates, B, H)
     ent = _persist_entry("gru", T, B, H, hs.device)
     rows = persistent_rows(H)
     for r0 in range(0, B, rows):     # one launch when the batch fits, else row ranges back to back on this stream
@@ -493,7 +506,7 @@ class GruSeqFn(Function):
         else:
             hs[slot0].copy_(h0)
         need_grad = any(t is not None and t.requires_grad for t in (tab, rowc, dense, h0, w_hh, b_hh))
-        gates = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        gates = torch.empty(T, 4, B, H, device=dev, dtype=gates_dtype(B, H, step_rows is not None)) if need_grad else None
         _alloc_guard(hs, gates)
         if step_rows is None and persistent_fits(B, H):
             with _prof("fwd_persist", 1, T=T, B=B, H=H, ndir=1):
@@ -526,6 +539,7 @@ class GruSeqFn(Function):
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # receives W_hh^T for the direct-to-LDS step kernel
+        _check_gates(gates, B, H, step_rows is not None)
         with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
             call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
                  _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
@@ -594,8 +608,8 @@ class GruBiSeqFn(Function):
         hs_f[0].zero_()
         hs_r[T].zero_()
         need_grad = any(t is not None and t.requires_grad for t in (tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r))
-        g_f = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
-        g_r = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        g_f = torch.empty(T, 4, B, H, device=dev, dtype=gates_dtype(B, H)) if need_grad else None
+        g_r = torch.empty(T, 4, B, H, device=dev, dtype=gates_dtype(B, H)) if need_grad else None
         if persistent_fits(B, H):
             # two persistent launches back to back on ONE stream (each needs all of its workgroups co-resident)
             with _prof("fwd_persist", 2, T=T, B=B, H=H, ndir=1):
@@ -632,6 +646,7 @@ class GruBiSeqFn(Function):
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
+        _check_gates(gt_f, B, H)
         with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
             call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
                  _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())

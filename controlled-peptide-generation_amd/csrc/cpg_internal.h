@@ -22,9 +22,11 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
 
 // 0 = f32-grade products, 1 = bf16 recurrent products (cpg_set_compute_mode, api.hip)
 int cpg_compute_mode_get();
+// saved gates of a GRU sequence stored as bf16 (gru.hip): bf16 compute mode, dense batches on shapes the direct-to-LDS backward covers
+bool cpg_gru_store_bf16(int B, int H, bool dense);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 305
+#define CPG_ABI_VERSION 306
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).
@@ -42,6 +44,7 @@ enum CpgOpt {
     OPT_GEMM_TILE,        // tile of the nn.Linear-shaped products
     OPT_DGI_MODE,         // input-side reductions: "mfma" (default) | "fused" | "gemm"
     OPT_MMD_DL,           // 0: register-staged Gram launch of the full-kernel MMD
+    OPT_BF16_STORE,       // 0: f32 saved gates in the bf16 compute mode too (default there: bf16, see cpg_gru_gates_bf16)
     OPT__COUNT
 };
 struct CpgOptVal {

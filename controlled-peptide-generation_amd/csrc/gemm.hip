@@ -106,12 +106,21 @@ __global__ void colsum_partial_kernel(const float* X, int ld, int M, int N, int 
                                                               red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// out[n] = sum over chunks of part[chunk][n]; 64 columns x 16 chunk lanes per block (fixed order: deterministic).
 __global__ void colsum_final_kernel(const float* part, int chunks, int N, float* out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[16][64];
+    const int n = blockIdx.x * 64 + threadIdx.x, ty = threadIdx.y;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int c = ty; c < chunks; c += 16) s += part[(size_t)c * N + n];
+    red[ty][threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][threadIdx.x];
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
 
 template <class TC, bool A_KC, bool B_KC, int PREC>
@@ -362,10 +371,19 @@ size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
     return (size_t)N * Kd * p.S * sizeof(float) + 256;
 }
 
-int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+// Row chunks of the column sum: 256-row chunks (at most 96) for wide matrices; narrow ones (few 64-column blocks) get more,
+// shorter chunks so that the partial pass still launches ~1024 workgroups.
+static int colsum_chunks(int M, int N) {
     int chunks = cdiv(M, 256);
     if (chunks > 96) chunks = 96;
+    const int want = cdiv(1024, cdiv(N, 64)), most = cdiv(M, 16);
+    if (chunks < want) chunks = want < most ? want : most;
     if (chunks < 1) chunks = 1;
+    return chunks;
+}
+
+int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+    const int chunks = colsum_chunks(M, N);
     if ((size_t)chunks * N * sizeof(float) > ws_bytes) {
         cpg_set_error("cpg_colsum: workspace too small (%zu < %zu)", ws_bytes, (size_t)chunks * N * sizeof(float));
         return -3;
@@ -373,17 +391,12 @@ int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate,
     const int rows = cdiv(M, chunks);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), chunks), dim3(64, 4), 0, s, X, ld, M, N, rows, ws);
     CPG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, chunks, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(64, 16), 0, s, ws, chunks, N, out, accumulate);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 
-size_t cpg_colsum_workspace(int M, int N) {
-    int chunks = cdiv(M, 256);
-    if (chunks > 96) chunks = 96;
-    if (chunks < 1) chunks = 1;
-    return (size_t)chunks * N * sizeof(float);
-}
+size_t cpg_colsum_workspace(int M, int N) { return (size_t)colsum_chunks(M, N) * N * sizeof(float); }
 
 // ------------------------------------------------------------------------------------------ C ABI
 CPG_EXPORT int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,

@@ -174,6 +174,7 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+__device__ __forceinline__ uint16_t bf16_bits(float x) { return (uint16_t)(cvt_pk_bf16(x, 0.f) & 0xffffu); }   // RNE
 __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
     w0 = cvt_pk_bf16(lo, hi);
     const float l1 = lo - __uint_as_float(w0 << 16), h1 = hi - __uint_as_float(w0 & 0xffff0000u);

@@ -21,6 +21,8 @@
 #define CPG_FWD_PREFETCH 0   // measured: fetching the epilogue operands ahead of the MFMA loop costs registers (occupancy) for no gain
 #endif
 
+typedef uint32_t pk_u32x2 __attribute__((ext_vector_type(2)));
+
 struct GruFwdArgs {
     const float* h_prev;
     const float* w_hh;
@@ -30,7 +32,8 @@ struct GruFwdArgs {
     const float* rowc;   // [B,3H]
     const float* dense;  // [B,3H] of this step
     float* h_out;        // [B,H]
-    float* gates;        // [4,B,H] of this step (r,z,n,hn), or null
+    float* gates;        // [4,B,H] of this step (r,z,n,hn), or null; bf16 elements when gates_bf16 (bf16 compute mode only)
+    int gates_bf16;
     int B, H;
     int row0, row1;      // this launch covers batch rows [row0,row1): rows are independent recurrences, so row groups
                          // can run as separate launch chains on separate streams, out of phase with each other
@@ -134,6 +137,13 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
                 const float ng = tanhf(gi[jb][mi][r][2] + rg * hn);
                 const size_t o = (size_t)row * H + j;
                 g.h_out[o] = (1.f - zg) * ng + zg * hp[jb][mi][r];
+                if constexpr (PREC == 1) {
+                    if (g.gates && g.gates_bf16) {   // bf16 compute mode: the four saved values of an element as one 8-byte group
+                        __builtin_nontemporal_store(pk_u32x2{cvt_pk_bf16(rg, zg), cvt_pk_bf16(ng, hn)},
+                                                    reinterpret_cast<pk_u32x2*>(reinterpret_cast<uint16_t*>(g.gates) + 4 * o));
+                        continue;
+                    }
+                }
                 if (g.gates) {  // written once, read once by the backward pass much later: keep them out of the L2
                     __builtin_nontemporal_store(rg, g.gates + o);
                     __builtin_nontemporal_store(zg, g.gates + BH + o);
@@ -148,19 +158,20 @@ struct GruBwdArgs {
     const float* dG_next;  // [B,4H] of the step processed just before this one (s+1), null on the first launch
     const float* w_hh;     // [3H,H]
     const float* w_hhT;    // [H,3H] = w_hh^T for the direct-to-LDS kernel (both operands K-contiguous), or null
-    const float* dH_next;  // [B,H] total gradient of h_{s+1}, null on the first launch
-    const float* z_next;   // [B,H] z gate of step s+1
+    const float* dH_next;  // [B,H] z_{s+1} .* (total gradient of h_{s+1}): what step s+1's launch left in dH_out; null on the first launch
     const float* ext;      // [B,H] external gradient on h_s (time-aligned slice) or null
     const float* ext2;     // [B,H] second external gradient (final-state gradient on the first launch) or null
     const float* gates;    // [4,B,H] of step s; null on the closing launch that only emits dh0
     const float* h_prev;   // [B,H] h_{s-1}
-    float* dH_out;         // [B,H] total gradient of h_s (closing launch: dh0)
+    float* dH_out;         // [B,H] z_s .* (total gradient of h_s): the carry term of step s-1, pre-multiplied here where z_s is in
+                           // registers anyway (one operand stream less per step); closing launch (no gates): dh0 itself
     float* dG_out;         // [B,4H]
     int B, H;
     int row0, row1;
     const int32_t* nrows;       // device scalar or null: rows live at step s (see GruFwdArgs)
-    const int32_t* nrows_next;  // rows live at step s+1: beyond them dG_next / dH_next / z_next were never written
+    const int32_t* nrows_next;  // rows live at step s+1: beyond them dG_next / dH_next were never written
     int ep_step;                // (even) slab spacing of the staggered epilogue-operand fetch; 0: every workgroup ahead of slab 0
+    int gates_bf16;             // gates hold bf16 elements (bf16 compute mode, direct-to-LDS kernels only)
 };
 
 struct GruBwdPair {
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
                     const int row = rb0 + mi * 16, col = cb0 + ni * 16;
                     const size_t o = (size_t)((row < B) ? row : 0) * H + ((col < H) ? col : 0);
                     f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (g.dH_next && row < Bn) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+                    if (g.dH_next && row < Bn) p += *reinterpret_cast<const f32x4*>(g.dH_next + o);
                     if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
                     if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
                     pre[mi][ni] = p;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
                 const int row = rb0 + mi * 16, col = cb0 + ni * 16;
                 if (row >= B || col >= H) continue;
                 const size_t o = (size_t)row * H + col;
-                *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+                *reinterpret_cast<f32x4*>(g.dH_out + o) = g.gates ? dh * sv[mi][ni][1] : dh;
                 if (!g.gates) continue;
                 const f32x4 rg = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
                 const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 const size_t o = (size_t)((row < B) ? row : 0) * H + jc;
                 float p = 0.f;
-                if (g.dH_next && row < Bn) p += g.z_next[o] * g.dH_next[o];
+                if (g.dH_next && row < Bn) p += g.dH_next[o];
                 if (g.ext) p += g.ext[o];
                 if (g.ext2) p += g.ext2[o];
                 pre[ni][mi][r] = p;
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(GruBwdPair pr) {
                 if (row >= B) continue;
                 const size_t o = (size_t)row * H + j;
                 const float dh = acc[mi][ni][r] + pre[ni][mi][r];
-                g.dH_out[o] = dh;
+                g.dH_out[o] = g.gates ? dh * sv[ni][mi][r][1] : dh;
                 if (!g.gates) continue;
                 const float rg = sv[ni][mi][r][0], zg = sv[ni][mi][r][1], ng = sv[ni][mi][r][2], hn = sv[ni][mi][r][3];
                 const float hp = sv[ni][mi][r][4];
@@ -333,6 +344,28 @@ using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 #ifndef CPG_DL_ABLATE
 #define CPG_DL_ABLATE 0   // diagnostic builds (tools/variant_build.sh): 1 no epilogue loads, 2 no stores, 4 no main loop
 #endif
+// Saved gates r, z, n, hn of four consecutive elements (offset o of a [B,H] plane) for the direct-to-LDS backward kernels.
+// f32: four planes [4][B,H], one 16-byte load each.  bf16 (PREC 1 = bf16 compute mode only, gates_bf16): [B,H][4] bf16 - the four
+// values of an element are one 8-byte group, so a lane's four elements are 32 contiguous bytes: two loads instead of four.
+template <int PREC>
+__device__ __forceinline__ void ld_gates4(const float* gates, size_t BH, size_t o, int bf, f32x4* sv) {
+    if constexpr (PREC == 1) {
+        if (bf) {
+            const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(gates) + 4 * o);
+            const uint4 w0 = p[0], w1 = p[1];   // (r|z, n|hn) of elements 0,1 and 2,3
+            auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+            auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); };
+            sv[0] = f32x4{lo(w0.x), lo(w0.z), lo(w1.x), lo(w1.z)};
+            sv[1] = f32x4{hi(w0.x), hi(w0.z), hi(w1.x), hi(w1.z)};
+            sv[2] = f32x4{lo(w0.y), lo(w0.w), lo(w1.y), lo(w1.w)};
+            sv[3] = f32x4{hi(w0.y), hi(w0.w), hi(w1.y), hi(w1.w)};
+            return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const f32x4*>(gates + q * BH + o);
+}
+
 // PREC 1: bf16 compute mode (operands rounded at the fragment read, one bf16 MFMA per block and slab)
 template <int BM, int BN, int NS, int PREC = 0>
 __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
@@ -369,13 +402,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
                     for (int q = 0; q < 5; ++q) sv[mi][ni][q] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
                     continue;
                 }
-                if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+                if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.dH_next + o);
                 if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
                 if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
                 pre[mi][ni] = p;
                 if (g.gates) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sv[mi][ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                    ld_gates4<PREC>(g.gates, BH, o, g.gates_bf16, sv[mi][ni]);
                     sv[mi][ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
                 }
             }
@@ -396,7 +428,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
             const size_t o = (size_t)row * H + col;
             if ((CPG_DL_ABLATE & 2) && dh[0] != 12345.f) continue;   // diagnostic build: no result stores
-            *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+            *reinterpret_cast<f32x4*>(g.dH_out + o) = g.gates ? dh * sv[mi][ni][1] : dh;
             if (!g.gates) continue;
             const f32x4 rg = sv[mi][ni][0], zg = sv[mi][ni][1], ng = sv[mi][ni][2], hn = sv[mi][ni][3], hp = sv[mi][ni][4];
             const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
@@ -446,13 +478,12 @@ __global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
         for (int ni = 0; ni < NI; ++ni) {
             const size_t o = (size_t)rb * H + cb0 + 16 * ni;
             f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.z_next + o) * *reinterpret_cast<const f32x4*>(g.dH_next + o);
+            if (g.dH_next) p += *reinterpret_cast<const f32x4*>(g.dH_next + o);
             if (g.ext) p += *reinterpret_cast<const f32x4*>(g.ext + o);
             if (g.ext2) p += *reinterpret_cast<const f32x4*>(g.ext2 + o);
             pre[ni] = p;
             if (g.gates) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sv[ni][q] = *reinterpret_cast<const f32x4*>(g.gates + q * BH + o);
+                ld_gates4<PREC>(g.gates, BH, o, g.gates_bf16, sv[ni]);
                 sv[ni][4] = *reinterpret_cast<const f32x4*>(g.h_prev + o);
             }
         }
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
         const f32x4 dh = acc_block_to_rows(tb, mine[ni], lane) + pre[ni];
         const int col = cb0 + 16 * ni;
         const size_t o = (size_t)rb * H + col;
-        *reinterpret_cast<f32x4*>(g.dH_out + o) = dh;
+        *reinterpret_cast<f32x4*>(g.dH_out + o) = g.gates ? dh * sv[ni][1] : dh;
         if (!g.gates) continue;
         const f32x4 rg = sv[ni][0], zg = sv[ni][1], ng = sv[ni][2], hn = sv[ni][3], hp = sv[ni][4];
         const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
@@ -656,6 +687,19 @@ static BwdTile dl_tile(int rows, int H, int nd) {
     return t;
 }
 
+// Saved gates stored as bf16: bf16 compute mode (option bf16_store = 0 keeps f32), and only where every backward step of the sequence
+// runs a direct-to-LDS kernel (dense batch, shape covered) - the register-staged kernels read f32 gates.
+bool cpg_gru_store_bf16(int B, int H, bool dense) {
+    if (cpg_compute_mode_get() != 1) return false;
+    const CpgOptVal& o = cpg_opt(OPT_BF16_STORE);
+    if (o.set && o.i == 0) return false;
+    return dense && H % 4 == 0 && bwd_dl_shape_ok(0, B, H);
+}
+// element e of a saved-gates buffer
+static inline float* gate_at(const float* gates, size_t e, bool bf) {
+    return const_cast<float*>(bf ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(gates) + e) : gates + e);
+}
+
 enum BwdKernelKind { BK_STAGED, BK_DL, BK_DL2 };
 struct BwdPlan {
     BwdKernelKind kind;
@@ -679,13 +723,18 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     for (int d = 0; d < nd; ++d) {
         vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
         // the row-layout epilogue moves four columns per lane: every state / gate / gradient base 16-byte aligned
-        const void* ptrs[] = {pr.d[d].dH_next, pr.d[d].z_next, pr.d[d].ext, pr.d[d].ext2, pr.d[d].gates, pr.d[d].h_prev,
+        const void* ptrs[] = {pr.d[d].dH_next, pr.d[d].ext, pr.d[d].ext2, pr.d[d].gates, pr.d[d].h_prev,
                               pr.d[d].dH_out, pr.d[d].dG_out};
         for (const void* q : ptrs) vec = vec && (!q || aligned16(q));
         have_wt = have_wt && pr.d[d].w_hhT != nullptr && aligned16(pr.d[d].w_hhT);
         dense = dense && !pr.d[d].nrows && !pr.d[d].nrows_next;
     }
     const BwdPlan pl = bwd_plan(a.row1 - a.row0, a.H, nd, a.row0, vec, have_wt, dense);
+    if (a.gates_bf16 && (pl.kind == BK_STAGED || !pl.bf16)) {
+        cpg_set_error("gru backward: gates saved as bf16 need the bf16 compute mode and the direct-to-LDS step (transposed-weight "
+                      "scratch, aligned operands, option gru_bwd_dl unchanged since the forward pass)");
+        return -4;
+    }
     int rc = 0;
     if (pl.kind == BK_DL2) {
         rc = pl.bf16 ? launch_dl2<1>(pr, nd, s) : launch_dl2<0>(pr, nd, s);
@@ -878,12 +927,18 @@ CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, in
 }
 
 // ------------------------------------------------------------------------------------------ C ABI
+// 1 when the saved gates of a [T,4,B,H] GRU sequence are bf16 elements (half the buffer): bf16 compute mode, dense batch (no
+// step_rows), shape covered by the direct-to-LDS backward step.  The caller sizes / types the gates buffer by this answer and keeps
+// the compute mode and options unchanged between the forward and the backward pass of a sequence (the backward refuses otherwise).
+CPG_EXPORT int cpg_gru_gates_bf16(int B, int H, int ragged) { return cpg_gru_store_bf16(B, H, !ragged) ? 1 : 0; }
+
 CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                                const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
                                int row_begin, int row_end, const int32_t* step_rows, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && 0 <= row_begin && row_begin < row_end && row_end <= B);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     const size_t BH = (size_t)B * H;
+    const bool gbf = gates && cpg_gru_store_bf16(B, H, step_rows == nullptr);
     for (int p = 0; p < T; ++p) {
         const int t = reverse ? T - 1 - p : p;
         GruFwdArgs a;
@@ -895,7 +950,8 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
         a.tab = tab;
         a.rowc = rowc;
         a.dense = dense ? dense + (size_t)t * B * 3 * H : nullptr;
-        a.gates = gates ? gates + (size_t)t * 4 * BH : nullptr;
+        a.gates = gates ? gate_at(gates, (size_t)t * 4 * BH, gbf) : nullptr;
+        a.gates_bf16 = gbf;
         a.B = B;
         a.H = H;
         a.row0 = row_begin;
@@ -911,7 +967,7 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
 CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                                 const float* rowc, const float* h_prev, float* h_out, void* stream) {
     CPG_CHECK_ARG(B > 0 && H > 0 && w_hh && b_hh && h_prev && h_out && h_prev != h_out);
-    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, B, H, 0, B, nullptr};
+    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, 0, B, H, 0, B, nullptr};
     return cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
 }
 
@@ -928,6 +984,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream);
         if (rc) return rc;
     }
+    const bool gbf = cpg_gru_store_bf16(B, H, step_rows == nullptr);
     int prev_t = -1;
     for (int p = T - 1; p >= -1; --p) {  // p = processing index of the step whose dH we form; p=-1 closes with dh0
         if (p < 0 && !dh0) break;
@@ -941,20 +998,19 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         a.w_hhT = w_hhT_scratch;
         a.nrows = (step_rows && t >= 0) ? step_rows + t : nullptr;
         a.nrows_next = (step_rows && prev_t >= 0) ? step_rows + prev_t : nullptr;
+        a.gates_bf16 = gbf;
         const int cur = (p + 2) & 1;
         if (prev_t >= 0) {
             a.dG_next = dG + (size_t)prev_t * B * 4 * H;
             a.dH_next = dH_scratch + (size_t)(cur ^ 1) * BH;
-            a.z_next = gates + (size_t)prev_t * 4 * BH + BH;
         } else {
             a.dG_next = nullptr;
             a.dH_next = nullptr;
-            a.z_next = nullptr;
         }
         a.ext2 = (p == T - 1) ? dh_last : nullptr;
         if (p >= 0) {
             a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
-            a.gates = gates + (size_t)t * 4 * BH;
+            a.gates = gate_at(gates, (size_t)t * 4 * BH, gbf);
             a.h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
             a.dH_out = dH_scratch + (size_t)cur * BH;
             a.dG_out = dG + (size_t)t * B * 4 * H;
@@ -1215,7 +1271,9 @@ static void fill_fwd(GruFwdArgs& a, int t, int T, int B, int H, int reverse, con
     a.tab = tab;
     a.rowc = nullptr;
     a.dense = dense ? dense + (size_t)t * B * 3 * H : nullptr;
-    a.gates = gates ? gates + (size_t)t * 4 * BH : nullptr;
+    const bool gbf = gates && cpg_gru_store_bf16(B, H, true);
+    a.gates = gates ? gate_at(gates, (size_t)t * 4 * BH, gbf) : nullptr;
+    a.gates_bf16 = gbf;
     a.B = B;
     a.H = H;
     a.row0 = 0;
@@ -1267,6 +1325,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
     const float* LAST[2] = {dh_last_f, dh_last_r};
     float* DG[2] = {dG_f, dG_r};
     float* SC[2] = {scratch_f, scratch_r};
+    const bool gbf = cpg_gru_store_bf16(B, H, true);
     int prev_t[2] = {-1, -1};
     for (int p = T - 1; p >= 0; --p) {
         GruBwdPair pr;
@@ -1276,6 +1335,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             GruBwdArgs& a = pr.d[d];
             a.nrows = nullptr;
             a.nrows_next = nullptr;
+            a.gates_bf16 = gbf;
             a.B = B;
             a.H = H;
             a.row0 = 0;
@@ -1285,15 +1345,13 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             if (prev_t[d] >= 0) {
                 a.dG_next = DG[d] + (size_t)prev_t[d] * B * 4 * H;
                 a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;
-                a.z_next = GT[d] + (size_t)prev_t[d] * 4 * BH + BH;
             } else {
                 a.dG_next = nullptr;
                 a.dH_next = nullptr;
-                a.z_next = nullptr;
-            }
+                }
             a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
             a.ext2 = (p == T - 1) ? LAST[d] : nullptr;   // gradient on the direction's final state enters at its last step
-            a.gates = GT[d] + (size_t)t * 4 * BH;
+            a.gates = gate_at(GT[d], (size_t)t * 4 * BH, gbf);
             a.h_prev = d ? HS[d] + (size_t)(t + 1) * BH : HS[d] + (size_t)t * BH;
             a.dH_out = SC[d] + (size_t)cur * BH;
             a.dG_out = DG[d] + (size_t)t * B * 4 * H;

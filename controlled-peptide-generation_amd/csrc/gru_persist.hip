@@ -148,7 +148,8 @@ struct PFwdArgs {
     const float* rowc;     // [B,3H] or null
     const float* dense;    // [T,B,3H] or null
     float* hs;             // [(T+1),B,H]
-    float* gates;          // [T,4,B,H] or null
+    float* gates;          // [T,4,B,H] or null; bf16 elements when gates_bf16 (NP = 1 only)
+    int gates_bf16;
     unsigned* cnt;         // [row tiles] arrival counters (zeroed before the launch)
     unsigned* err;         // sticky error word
     unsigned* err_host;    // the same word in host-mapped (pinned) memory, or null: the host sees a timeout without any copy
@@ -240,6 +241,8 @@ __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffe
 
 // NP: planes of the split - 3 = f32-grade (six MFMAs per block), 1 = bf16 compute mode (cpg_set_compute_mode(1))
 // CT: hidden units per workgroup - 16 (one MFMA column block per gate) or 8 (blocks [r | z] and [n | n], see the header)
+typedef uint32_t pk_u32x4 __attribute__((ext_vector_type(4)));
+
 template <int NP, int CT>
 __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
     constexpr int NC = 3 * CT;              // gate columns (LDS plane rows) of the workgroup
@@ -355,6 +358,19 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
                 const f32x4 v1 = acc_to_rows(tb, zg[mi], lane);
                 const f32x4 v2 = acc_to_rows(tb, ng[mi], lane);
                 const f32x4 v3 = acc_to_rows(tb, hn[mi], lane);
+                if constexpr (NP == 1) {
+                    if (a.gates_bf16) {   // bf16 compute mode: [B,H][4] bf16, (r,z,n,hn) of an element adjacent - 32 contiguous bytes per lane
+                        if (row < Bend && cvalid) {
+                            pk_u32x4* d = reinterpret_cast<pk_u32x4*>(reinterpret_cast<uint16_t*>(a.gates) +
+                                                                      4 * ((size_t)pend_tt * BH + (size_t)row * H + j0 + 4 * scq));
+                            __builtin_nontemporal_store(pk_u32x4{cvt_pk_bf16(v0[0], v1[0]), cvt_pk_bf16(v2[0], v3[0]),
+                                                                 cvt_pk_bf16(v0[1], v1[1]), cvt_pk_bf16(v2[1], v3[1])}, d);
+                            __builtin_nontemporal_store(pk_u32x4{cvt_pk_bf16(v0[2], v1[2]), cvt_pk_bf16(v2[2], v3[2]),
+                                                                 cvt_pk_bf16(v0[3], v1[3]), cvt_pk_bf16(v2[3], v3[3])}, d + 1);
+                        }
+                        continue;
+                    }
+                }
                 if (row < Bend && cvalid) {
                     float* d = gbase + (size_t)row * H + j0 + 4 * scq;
                     __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(d));
@@ -627,6 +643,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     CPG_HIP(hipMemsetAsync(sync_scratch, 0, cnt_words(B) * sizeof(unsigned), s));  // counters only: the error word is sticky
     PFwdArgs a;
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.gates = gates;
+    a.gates_bf16 = gates && cpg_gru_store_bf16(B, H, true);
     a.cnt = (unsigned*)sync_scratch;
     a.err = a.cnt + cnt_words(B);
     a.err_host = (unsigned*)err_host;

@@ -86,12 +86,17 @@ CPG_API int cpg_get_compute_mode(void);
  *     dense[t,b,:]       arbitrary per-step term (upper encoder layers)    ([T,B,3H])
  * State slab hs [(T+1),B,H]: forward direction hs[0]=h0 (caller fills), h_t -> hs[t+1];
  *                            reverse direction hs[T]=h0 (caller fills), h_t -> hs[t].
- * gates [T,4,B,H] receives r,z,n and (W_hn h + b_hn) per step for the backward pass (null for inference).
+ * gates [T,4,B,H] receives r,z,n and (W_hn h + b_hn) per step for the backward pass (null for inference): f32 elements, or
+ * bf16 elements laid out [T,B,H,4] (the four values of an element adjacent; a buffer of half the bytes behind the same pointer
+ * type) when cpg_gru_gates_bf16(B, H, ragged) answers 1 - the bf16 compute mode on dense batches the direct-to-LDS backward step
+ * covers.  Ask once per sequence, allocate accordingly,
+ * and keep compute mode / options unchanged until its backward pass has been enqueued (which refuses a mismatch it can see).
  * Batch rows are independent recurrences: a call covers rows [row_begin,row_end) of the B-row problem (0,B for all). */
 /* step_rows (optional, DEVICE int32 [T], may be null): only rows < step_rows[t] are live at time t.  For length-sorted
  * teacher-forced batches: once all remaining targets of a row are <pad> (losses.py:27 ignores them) its state is never
  * needed again, so the tail of the batch drops out step by step.  The counts are read by the kernels (no host sync);
  * state / gate slots of dead (t,row) pairs are left untouched - hand in zeroed slabs if they are read elsewhere. */
+CPG_API int cpg_gru_gates_bf16(int B, int H, int ragged /* step_rows given */);
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
                             int row_begin, int row_end, const int32_t* step_rows, void* stream);

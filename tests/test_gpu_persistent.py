@@ -32,7 +32,7 @@ def _run(d, B, H, T, reverse, persistent):
     dev = torch.device("cuda")
     hs = torch.zeros(T + 1, B, H, device=dev)
     hs[T if reverse else 0] = d["h0"]
-    gates = torch.zeros(T, 4, B, H, device=dev)
+    gates = torch.zeros(T, 4, B, H, device=dev, dtype=ops.gates_dtype(B, H))
     if persistent:
         assert ops.persistent_fits(B, H)
         ops.gru_seq_fwd_persistent(T, B, H, reverse, d["w_hh"], d["b_hh"], d["tok"], d["tab"], d["rowc"], d["dense"], hs, gates)
@@ -204,5 +204,46 @@ def test_backward_two_k_halves_workgroup_matches_the_plain_direct_to_lds_kernel(
             for a, b in zip(res[0], res[1]):
                 assert not torch.equal(a, torch.zeros_like(a))
                 assert (a - b).abs().max().item() <= tol * max(1.0, a.abs().max().item())
+    finally:
+        ops.set_compute_mode("f32")
+
+
+# ---- bf16 compute mode: saved gates stored as bf16
+@pytest.mark.parametrize("B,H,T", [(256, 128, 6), (2048, 512, 5)])
+def test_bf16_mode_saves_gates_as_bf16(B, H, T):
+    """In the bf16 compute mode the saved gates of a dense sequence are bf16 (cpg_gru_gates_bf16): the persistent and the per-step
+    forward write the same values (RNE of their f32 gates), the direct-to-LDS backward on them stays within bf16 rounding of the
+    backward on f32 gates (option bf16_store = 0), and a sequence saved one way is refused by a backward expecting the other."""
+    from cpg import ops
+    d = _inputs(B, H, T, 24, seed=77)
+    ops.set_compute_mode("bf16")
+    try:
+        assert ops.gates_dtype(B, H) == torch.bfloat16 and ops.gates_dtype(B, H, ragged=True) == torch.float32
+        assert ops.gates_dtype(130, 80) == torch.float32            # shape the direct-to-LDS backward does not cover
+        hs_p, g_p = _run(d, B, H, T, False, True)
+        hs_s, g_s = _run(d, B, H, T, False, False)
+        assert g_p.dtype == torch.bfloat16 and g_p.shape == (T, 4, B, H)
+        with ops.options(bf16_store=0):
+            assert ops.gates_dtype(B, H) == torch.float32
+            hs_f, g_f = _run(d, B, H, T, False, True)
+        assert torch.equal(hs_p, hs_f)                              # the state does not depend on how the gates are stored
+        # layout of the bf16 form: [T,B,H,4] - (r,z,n,hn) of an element adjacent; values = RNE of the f32 gates [T,4,B,H]
+        assert torch.equal(g_p.view(T, B, H, 4), g_f.permute(0, 2, 3, 1).to(torch.bfloat16))
+        assert (g_p.float() - g_s.float()).abs().max().item() <= 2 ** -7   # per-step kernel: same values up to its own last bits
+        g = torch.Generator().manual_seed(5)
+        dhs = (torch.randn(T, B, H, generator=g) * 0.1).cuda()
+        last = (torch.randn(B, H, generator=g) * 0.1).cuda()
+        dG_b, dh0_b = _bwd(d, B, H, T, False, hs_p, g_p, dhs, last)
+        with ops.options(bf16_store=0):
+            dG_f, dh0_f = _bwd(d, B, H, T, False, hs_f, g_f, dhs, last)
+            with pytest.raises(ops.CpgError):                       # bf16 gates handed to a backward that expects f32: refused where visible
+                ops._check_gates(g_p, B, H)
+        scale = dG_f.abs().max().item()
+        assert scale > 0 and (dG_b - dG_f).abs().max().item() <= 2e-2 * scale
+        rel = ((dG_b - dG_f).norm() / dG_f.norm()).item()
+        assert rel <= 1e-2, rel
+        assert (dh0_b - dh0_f).abs().max().item() <= 2e-2 * max(1e-6, dh0_f.abs().max().item())
+        with pytest.raises(ops.CpgError, match="bf16"):             # no transposed-weight scratch -> register-staged kernel: refused
+            _bwd(d, B, H, T, False, hs_p, g_p, dhs, last, with_wT=False)
     finally:
         ops.set_compute_mode("f32")

@@ -53,7 +53,7 @@ def main():
     tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
     hs = torch.zeros(T + 1, B, H, device=dev)
     hs[0] = torch.randn(B, H, generator=g).to(dev)
-    gates = torch.empty(T, 4, B, H, device=dev)
+    gates = torch.empty(T, 4, B, H, device=dev, dtype=ops.gates_dtype(B, H))
     dhs = torch.randn(T, B, H, generator=g).to(dev) * 0.1
     dG, dG2 = torch.empty(T, B, 4 * H, device=dev), torch.empty(T, B, 4 * H, device=dev)
     scr, sc2 = torch.empty(2, B, H, device=dev), torch.empty(2, 2, B, H, device=dev)
