@@ -300,6 +300,47 @@ class LinearFn(Function):
         return dx, dw, db
 
 
+class LinearColsFn(Function):
+    """y = x W[:, c0:c1]^T + b on a column block of a LEAF weight: the two halves of nn.GRU's W_ih at models/decoder.py:70-77 (token
+    table from the embedding columns, row constant from the [z;c] columns).  Slicing the parameter in autograd instead costs, per
+    slice and step, a parameter-sized fill and a copy (SliceBackward) plus the add that joins the two; here the weight-gradient
+    product writes its block of the parameter's gradient in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, c0, c1):
+        ctx.save_for_backward(x, w)
+        ctx.cols = (int(c0), int(c1))
+        ctx.has_b = b is not None
+        ctx.leaves = (w, b)
+        return linear_raw(x, w[:, c0:c1], b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        c0, c1 = ctx.cols
+        dy, lddy = _rowmajor(dy)
+        xx, ldx = _rowmajor(x)
+        ww, ldw = _rowmajor(w)
+        M, K = xx.shape
+        N = ww.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+            call("cpg_linear_bwd_input", _p(dy), lddy, _p(ww[:, c0:c1]), ldw, _p(dx), K, M, N, K, 0, _stream())
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            gw, gb = _grad_buf(ctx.leaves[0]), _grad_buf(ctx.leaves[1])
+            direct = gw is not None and (not ctx.has_b or gb is not None)
+            dw = gw if direct else torch.zeros_like(ww)
+            db = (gb if direct else torch.empty(N, device=dy.device, dtype=torch.float32)) if ctx.has_b else None
+            nb = query("cpg_linear_bwd_weight_workspace", M, N, K)
+            ws = workspace(nb, dy.device)
+            call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw[:, c0:c1]), dw.stride(0), _p(db), M, N, K, int(direct),
+                 _p(ws), ws.numel(), _stream())
+            if direct:
+                dw = db = None
+        return dx, dw, db, None, None
+
+
 class Linear2Fn(Function):
     """y = x1 W[:, :K1]^T + x2 W[:, K1:]^T + b  (input projection of an upper biGRU layer: its input is the
     concatenation of the lower layer's two directions, which are two separate state slabs here)."""
@@ -554,32 +595,34 @@ class GruSeqFn(Function):
         if has_tab or has_rowc:
             call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(),
                  _stream())
-        dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
-        db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
-        db_arg = None if has_tab else _p(db_hh)
         dl = ctx.defer_req
         defer = dl if (dl is not None and DEFER_WGRAD and OVERLAP and _grad_buf(dl[0]) is not None and _grad_buf(dl[1]) is not None) else None
         if defer is not None:
+            db_hh = dsum[:3 * H] if has_tab else None
             side = side_streams(dev)[2]
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 ws2 = workspace(nb, dev)
-                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                    call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws2), ws2.numel(),
-                         _stream())
-                defer[0].grad.add_(dw_hh)
-                defer[1].grad.add_(db_hh)
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):   # accumulated straight into the parameters' gradient buffers
+                    call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
+                         None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _stream())
+                if has_tab:
+                    defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
             # the accumulation into .grad runs on the side stream: make the stream that called backward() wait for it when
             # the backward pass ends, so ANY reader of .grad after loss.backward() (clip_grad_norm_, another optimiser, a
             # test) sees the finished gradient - not only FusedAdamClip, which joins explicitly
             torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
-            for t in (dG, hs, dw_hh, db_hh):
-                t.record_stream(side)
+            for t in (dG, hs, db_hh):
+                if t is not None:
+                    t.record_stream(side)
             dw_hh = db_hh = None
         else:
+            dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
+            db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
             with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), db_arg, 0, _p(ws), ws.numel(), _stream())
+                call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
+                     ws.numel(), _stream())
         ddense = None
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)

@@ -80,13 +80,14 @@ class GRUDecoder(nn.Module):
         w_ih = self.rnn.weight_ih_l0
         if emb_w is None:
             emb_w = self._emb_w()
-        tab = ops.LinearFn.apply(emb_w, w_ih[:, :E], self.rnn.bias_ih_l0)   # [V,3H]
-        rowc = ops.LinearFn.apply(zc, w_ih[:, E:], None)                    # [B,3H]
+        tab = ops.LinearColsFn.apply(emb_w, w_ih, self.rnn.bias_ih_l0, 0, E)        # [V,3H]
+        rowc = ops.LinearColsFn.apply(zc, w_ih, None, E, w_ih.shape[1])            # [B,3H]
         return tab, rowc
 
-    def forward(self, x, z, c, wd_mask=None, out_keep=None):
+    def forward(self, x, z, c, wd_mask=None, out_keep=None, emb_w=None):
         """Teacher forcing.  x ids [B,T]; returns logits [B,T,V].
-        wd_mask uint8 [B,T] / out_keep uint8 [B,T,H] inject the two dropout masks (otherwise sampled here)."""
+        wd_mask uint8 [B,T] / out_keep uint8 [B,T,H] inject the two dropout masks (otherwise sampled here).
+        emb_w: the pad-masked embedding matrix shared with the step's other consumers (RNN_VAE.forward), or None."""
         B, T = x.shape
         zc = self.init_hidden(z, c)
         if wd_mask is None:
@@ -94,7 +95,7 @@ class GRUDecoder(nn.Module):
         tok = ops.tokens_prepare(x, wd_mask)
         # gradient-bucket boundary: once the gradients of [z;c] and of the embedding rows the decoder reads are complete, every
         # gradient of the decoder's own parameters has been enqueued (cpg.optim starts their all-reduce there)
-        zc, emb_w = ops.grad_boundary('decoder', zc, self._emb_w())
+        zc, emb_w = ops.grad_boundary('decoder', zc, self._emb_w() if emb_w is None else emb_w)
         tab, rowc = self._tables(zc, emb_w)
         ragged = self.ragged and self.cell == 'gru' and torch.is_grad_enabled()
         perm = inv = step_rows = None

@@ -95,10 +95,12 @@ class RNN_VAE(nn.Module):
     def _emb_weight(self):
         return ops.ZeroRowGradFn.apply(self.word_emb.weight, PAD_IDX)
 
-    def forward_encoder(self, inputs):
-        """ids [mbsize, seq_len] -> (mu, logvar);  soft inputs [mbsize, seq_len, n_vocab] go through soft_embed."""
+    def forward_encoder(self, inputs, emb_w=None):
+        """ids [mbsize, seq_len] -> (mu, logvar);  soft inputs [mbsize, seq_len, n_vocab] go through soft_embed.
+        emb_w: the embedding matrix as this step's graph sees it (_emb_weight()), when the caller shares one between the
+        encoder, the decoder and the classifier - one pad-row mask and one accumulation per step instead of one per consumer."""
         if inputs.dim() == 2:
-            return self.encoder.forward_tokens(inputs, self._emb_weight())
+            return self.encoder.forward_tokens(inputs, self._emb_weight() if emb_w is None else emb_w)
         from models.mutils import soft_embed
         return self.encoder(soft_embed(self.word_emb, inputs))
 
@@ -119,14 +121,14 @@ class RNN_VAE(nn.Module):
             return c
         return torch.from_numpy(np.random.multinomial(1, [0.5, 0.5], mbsize).astype('float32')).to(self.device)
 
-    def forward_decoder(self, inputs, z, c, wd_mask=None, out_keep=None):
-        return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep)
+    def forward_decoder(self, inputs, z, c, wd_mask=None, out_keep=None, emb_w=None):
+        return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep, emb_w=emb_w)
 
-    def forward_classifier(self, inputs):
+    def forward_classifier(self, inputs, emb_w=None):
         """Token inputs run the HIP path (token-table convolutions), differentiable like the reference's: with q_c='classifier'
         gradients reach the classifier and word_emb through c (models/model.py:135-144,186-188)."""
         if inputs.dim() == 2:
-            return self.classifier.forward_tokens(inputs, self._emb_weight())
+            return self.classifier.forward_tokens(inputs, self._emb_weight() if emb_w is None else emb_w)
         else:
             from models.mutils import soft_embed
             x = soft_embed(self.word_emb, inputs)
@@ -136,7 +138,8 @@ class RNN_VAE(nn.Module):
         """-> ((mu, logvar), (z, c), dec_logits [mbsize, seq_len, n_vocab])"""
         rnd = rnd or {}
         mbsize = sequences.size(0)
-        mu, logvar = self.forward_encoder(sequences)
+        emb_w = self._emb_weight() if sequences.dim() == 2 else None
+        mu, logvar = self.forward_encoder(sequences, emb_w)
         assert mu.size(0) == logvar.size(0) == mbsize
         if sample_z == 'max':
             z = mu
@@ -151,10 +154,10 @@ class RNN_VAE(nn.Module):
         elif q_c == 'prior':
             c = self.sample_c_prior(mbsize)
         elif q_c == 'classifier':
-            c = torch.softmax(self.forward_classifier(sequences), dim=1)
+            c = torch.softmax(self.forward_classifier(sequences, emb_w), dim=1)
         else:
             raise ValueError("q_c is not labels, prior, or classifier")
-        dec_logits = self.forward_decoder(sequences, z, c, wd_mask=rnd.get('wd_mask'), out_keep=rnd.get('out_mask'))
+        dec_logits = self.forward_decoder(sequences, z, c, wd_mask=rnd.get('wd_mask'), out_keep=rnd.get('out_mask'), emb_w=emb_w)
         return (mu, logvar), (z, c), dec_logits
 
     # ------------------------------------------------------------------ generation

@@ -41,24 +41,22 @@ def main():
     for i in range(5):
         step(batches[i % len(batches)], i)
     torch.cuda.synchronize()
-    n = 3
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        for i in range(n):
-            step(batches[i % len(batches)], 5 + i)
+    n = 1
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        step(batches[0], 5)
         torch.cuda.synchronize()
-    rows = collections.Counter()
-    for ev in prof.events():
-        if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU]
+    nodes = [e for e in evs if e.name.startswith("autograd::engine::evaluate_function")]
+    out = []
+    for ev in evs:
+        if not ev.name.startswith("aten::") or not ev.kernels:
             continue
-        if not ev.name.startswith("aten::"):
-            continue
-        frame = "?"
-        st = [f for f in (ev.stack or []) if "site-packages" not in f and "dist-packages" not in f and "<built-in" not in f]
-        if st:
-            frame = " < ".join(x.replace(ROOT + "/", "").replace("controlled-peptide-generation_amd/", "") for x in st[:3])
-        rows[(ev.name, frame, ",".join(sorted({k.name[:60] for k in ev.kernels})))] += len(ev.kernels)
-    for (name, frame, kern), c in sorted(rows.items(), key=lambda kv: -kv[1]):
-        print(f"{c / n:6.1f}  {name:18s} {kern[:50]:50s} {frame}")
+        t = ev.time_range.start
+        node = next((nd.name.split(": ")[-1] for nd in nodes if nd.time_range.start <= t <= nd.time_range.end), "forward")
+        out.append((t, ev.name, [tuple(x) for x in (ev.input_shapes or []) if x], node, len(ev.kernels)))
+    t_prev_node = None
+    for t, name, shapes, node, k in sorted(out):
+        print(f"{name:18s} x{k} {str(shapes)[:70]:70s} in {node}")
 
 
 if __name__ == "__main__":
