@@ -232,6 +232,9 @@ static int launch_gemm(const GemmArgs& g_in, int zdim, hipStream_t s, TnTile for
     const long tiles128 = (long)cdiv(g.M, 128) * cdiv(g.N, 64) * zdim;
     // tools/gbench.py on MI355X: below two 128x64 tiles per CU, and for very short contractions (the launch is all epilogue),
     // 64x64 tiles are 20-25 % faster (rowc product 50 -> 40 us, d logits -> d out at K=24 55 -> 41 us)
+    // tools/lin_sweep.py: fewer than two 64x64 tiles per CU AND a long contraction (the launch is one latency chain of >= 32 slabs
+    // per workgroup) - 64x32 tiles double the workgroups: [z;c] input gradient 76.6 -> 59.4 us, encoder heads 32.7 -> 28.4
+    if (A_KC && g.K >= 1024 && (long)cdiv(g.M, 64) * cdiv(g.N, 64) * zdim < 512) return launch_tc<T64x32, A_KC, B_KC>(g, zdim, vec, s);
     if (A_KC && (tiles128 < 512 || g.K <= 64)) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
     if (tiles128 < 256) return launch_tc<T64x64, A_KC, B_KC>(g, zdim, vec, s);
     return launch_tc<T128x64, A_KC, B_KC>(g, zdim, vec, s);

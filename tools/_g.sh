@@ -1,9 +1,3 @@
-one() {
-  (cd $1 && python bench.py --steps 40 --warmup 10 --no-extra-legs --no-cpu-baseline --no-class 2>/dev/null | python -c "
-import sys, json
-d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$2', d['value'], d['ms_per_step'])")
-}
-for i in 1 2 3; do
-  one $GRAFT_REPO_ROOT new
-  one $GRAFT_REPO_ROOT/build_variants/prev prev
-done
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_tiles.py -q -x -m gpu 2>&1 | tail -3
+bash tools/insitu.sh 2>&1 | tail -5
+bash tools/insitu.sh 2>&1 | tail -5
