@@ -23,21 +23,28 @@ def anneal(cfgan, it):
     return interpolate(cfgan.start.val, cfgan.end.val, cfgan.start.iter, cfgan.end.iter, it)
 
 
-def write_gen_samples(samples, fn, c_lab=None):
+def _open_for_write(fn, encoding=None):
     check_dir_exists(fn)
-    with open(fn, 'w+') as f:
-        if c_lab is not None:
-            assert c_lab.nelement() == len(samples), 'sizes dont match'
-            print("Saving %d samples with labels" % len(samples))
-            f.writelines('label: {}\n{}\n'.format(y, s) for y, s in zip(c_lab, samples))
+    return open(fn, 'w', encoding=encoding)
+
+
+def write_gen_samples(samples, fn, c_lab=None):
+    """vae_gen.txt format (what the reference's utils.py:17-31 writes and its evals read back): one sample per line, or - with
+    labels - a `label: <y>` line ahead of each sample."""
+    n = len(samples)
+    if c_lab is not None and c_lab.nelement() != n:
+        raise AssertionError('sizes dont match')
+    with _open_for_write(fn) as out:
+        if c_lab is None:
+            out.write(''.join(s + '\n' for s in samples))
         else:
-            print("Saving %d samples without labels" % len(samples))
-            f.write('\n'.join(samples) + '\n')
+            for y, s in zip(c_lab, samples):
+                out.write('label: {}\n'.format(y) + s + '\n')   # format(): a 0-dim tensor prints as its number
+    print('Saving %d samples %s labels' % (n, 'without' if c_lab is None else 'with'))
 
 
 def save_vocab(vocab, fn):
-    check_dir_exists(fn)
-    with codecs.open(fn, "w", "utf-8") as f:
-        for word, ix in vocab.stoi.items():
-            f.write(word + " " + str(ix) + "\n")
+    """vocab.dict format (utils.py:42-47): `<token> <index>` per line, UTF-8, in the vocabulary's own order."""
+    with _open_for_write(fn, encoding='utf-8') as out:
+        out.writelines('%s %d\n' % (tok, ix) for tok, ix in vocab.stoi.items())
     print('Saved vocab to ' + fn)

@@ -235,3 +235,21 @@ def test_evaluate_nll_and_prior_logpdf():
     mu, lv = torch.zeros(50, 4, dtype=torch.float64), torch.full((50, 4), -30.0, dtype=torch.float64)
     nq, npr = dm.evaluate_nll(StdNormal(), (mu, lv))
     assert abs(nq - npr) < 1e-12 and abs(nq - 0.5 * 4 * math.log(math.tau)) < 1e-6
+
+
+def test_sample_and_vocab_writers_keep_the_reference_file_formats(tmp_path):
+    """vae_gen.txt and vocab.dict as the reference's utils.py:17-31,42-47 writes them (they are read back by its evals / api.py)."""
+    import collections
+    import torch
+    import utils
+    fn = str(tmp_path / "sub" / "gen.txt")
+    utils.write_gen_samples(["A C D", "K L"], fn)
+    assert open(fn).read() == "A C D\nK L\n"
+    utils.write_gen_samples(["A C D", "K L"], fn, c_lab=torch.tensor([1, 0]))
+    assert open(fn).read() == "label: 1\nA C D\nlabel: 0\nK L\n"
+    with pytest.raises(AssertionError):
+        utils.write_gen_samples(["A"], fn, c_lab=torch.tensor([1, 0]))
+    Vocab = collections.namedtuple("Vocab", "stoi")
+    vf = str(tmp_path / "vocab.dict")
+    utils.save_vocab(Vocab(collections.OrderedDict([("<unk>", 0), ("<pad>", 1), ("A", 4)])), vf)
+    assert open(vf, encoding="utf-8").read() == "<unk> 0\n<pad> 1\nA 4\n"

@@ -57,7 +57,10 @@ def test_oracle_lstm_matches_torch(reverse):
                                              # BASELINE.json configs[1] size ("hidden=512 1-layer LSTM, batch=2048, seq_len<=25"): here the
                                              # launcher itself picks the persistent forward, the direct-to-LDS backward step and the
                                              # 256 x 128 split-K dW tiles - against oracle/lstm.py (itself pinned to torch.nn.LSTM)
-                                             (2048, 25, 512, 24, False), (2048, 25, 512, 24, True)])
+                                             (2048, 25, 512, 24, False), (2048, 25, 512, 24, True),
+                                             # BASELINE.json configs[4] width and length (hidden=1024, seq_len<=50): per-step
+                                             # forward kernels (the LSTM slice of that width does not fit a CU's LDS)
+                                             (128, 50, 1024, 24, False), (128, 50, 1024, 24, True)])
 def test_hip_lstm_sequence_matches_oracle(B, T, H, V, reverse):
     from cpg import ops
     if not torch.cuda.is_available():
