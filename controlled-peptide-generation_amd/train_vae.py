@@ -15,7 +15,6 @@ import torch
 import losses
 import cfg
 import utils
-from cpg import ops
 from cpg.optim import FusedAdamClip
 from models.mutils import save_model
 from tb_json_logger import log_value
@@ -50,21 +49,8 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None), 
     kl_loss, z_logvar_KL_penalty, z_logvar_L1 = losses.latent_terms(z_mu, z_logvar)
     # the full-kernel MMD couples every pair of rows of the GLOBAL batch: as the regulariser it is evaluated on the all-gathered
     # batch (exact under data parallelism); as a logged-only value it stays rank-local
-    mmd_done = None
-    if cfgv.z_regu_loss != 'mmd' and ops.OVERLAP and z.is_cuda:
-        # logged-only value (no gradient, nothing downstream reads it): its Gram launch - the one matrix-pipe-bound kernel of the
-        # loss section - runs on a side stream beside the memory- and latency-bound launches around it (latent terms, random
-        # features, the loss backward, the vocabulary projection's backward) and is joined at the end of the step
-        side, cur = ops.side_streams(z.device)[1], torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            wae_mmd_loss = losses.wae_mmd_gaussianprior(z.detach(), method='full_kernel', z_prior=z_priors[0])
-            mmd_done = side.record_event()
-        z.record_stream(side)
-        wae_mmd_loss.record_stream(cur)
-    else:
-        wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0],
-                                                    global_batch=(cfgv.z_regu_loss == 'mmd' and trainer.world > 1))
+    wae_mmd_loss = losses.wae_mmd_gaussianprior(z, method='full_kernel', z_prior=z_priors[0],
+                                                global_batch=(cfgv.z_regu_loss == 'mmd' and trainer.world > 1))
     wae_mmdrf_loss = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=z_priors[1])
     z_regu_loss = {'kl': kl_loss, 'mmd': wae_mmd_loss, 'mmdrf': wae_mmdrf_loss}[cfgv.z_regu_loss]
     # loss = recon + beta * regu + lambda_L1 * L1 + lambda_KL * KLpenalty (train_vae.py:35-37), one launch
@@ -76,8 +62,6 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None), 
     trainer.step()
     if model.rng is not None:
         model.rng.end_step()     # the device-side Philox base moves past this step's draws; host offsets restart at 0
-    if mmd_done is not None:
-        torch.cuda.current_stream().wait_event(mmd_done)
     return dict(z_mu=z_mu, z_logvar=z_logvar, z_logvar_L1=z_logvar_L1, z_logvar_KL_penalty=z_logvar_KL_penalty, L_vae=loss,
                 L_vae_recon=recon_loss, L_vae_kl=kl_loss, L_wae_mmd=wae_mmd_loss, L_wae_mmdrf=wae_mmdrf_loss, beta=beta)
 
