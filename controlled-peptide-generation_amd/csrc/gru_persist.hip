@@ -53,6 +53,9 @@
 #ifndef CPG_PERSIST_ABLATE
 #define CPG_PERSIST_ABLATE 0
 #endif
+#ifndef CPG_PERSIST_XCD_FAST
+#define CPG_PERSIST_XCD_FAST 1   // 0: always the placement-independent write-through hand-off
+#endif
 
 #ifndef CPG_PERSIST_FAST_CELL
 #define CPG_PERSIST_FAST_CELL 0
@@ -136,6 +139,7 @@ constexpr int P_TBW = CPG_PERSIST_TBW;  // words per row of the per-wave 16x16 t
                                    // row tiles do not queue on one memory channel
 #endif
 constexpr int P_CNT_STRIDE = CPG_PERSIST_CNT_STRIDE;
+constexpr size_t P_XCC_WORDS = 1024;   // XCD table: >= row groups x column tiles of one launch (8 x 128); its last word records the path taken
 constexpr unsigned P_SPIN_LIMIT = 400000u;  // ~0.2 s of polling before a wave gives up (sets the error word)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -158,6 +162,7 @@ struct PFwdArgs {
                            // CUs of an XCD that read the same tile at the same time camped on a few L2 channels: 62.8 us/step.)
     int T, B, H, reverse, groups, S;  // S: words per plane row (H/2 data + pad so that S % 64 == 8)
     int row0, row1;                   // rows [row0, row1) of the B-row problem are this launch's
+    unsigned* xcc;                    // [groups][column tiles]: XCC id + 1 of every workgroup of this launch (same-XCD check)
 #if CPG_PERSIST_TRACE
     unsigned long long* trace;        // [workgroups][waves][T][8]
 #endif
@@ -215,7 +220,7 @@ __device__ __forceinline__ float row_ror8(float x) {
 
 // Row-layout tile (lane -> row l>>2, 4 columns) -> three bf16 planes in the exchange slot: even lanes collect their odd
 // neighbour's four columns and store 8 columns = 16 bytes per plane, write-through.
-template <int NP>
+template <int NP, bool PLAIN = false>
 __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffer_rsrc_t rx, int voff, unsigned plane_bytes,
                                              unsigned slot_off, bool ok, int lane) {
     const float n0 = lane_xor1(v[0]), n1 = lane_xor1(v[1]), n2 = lane_xor1(v[2]), n3 = lane_xor1(v[3]);
@@ -230,7 +235,7 @@ __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffe
             w0[0] = cvt_pk_bf16(v[0], v[1]); w0[1] = cvt_pk_bf16(v[2], v[3]);
             w0[2] = cvt_pk_bf16(n0, n1); w0[3] = cvt_pk_bf16(n2, n3);
         }
-        constexpr int AUX = CPG_PERSIST_PLAIN_STORES ? 0 : 16;   // 16 = sc1: write-through
+        constexpr int AUX = (CPG_PERSIST_PLAIN_STORES || PLAIN) ? 0 : 16;   // 16 = sc1: write-through; 0: the line stays in this XCD's L2
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w0[1], w0[2], w0[3]}, rx, voff, slot_off, AUX);
         if (NP == 3) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, slot_off + plane_bytes, AUX);
@@ -318,6 +323,9 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         publish_rows<NP>(v, rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes, (unsigned)(j0 >> 5) * kb_bytes,
                          row < Bend && 4 * (scq & ~1) < CT, lane);
     }
+    // Same-XCD fast path (see the time loop): every workgroup posts the id of the XCD it runs on before its first arrival
+    const unsigned my_xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) + 1u;   // HW_REG_XCC_ID[3:0] + 1
+    if (lane == 0) __hip_atomic_store(a.xcc + (size_t)g * NCT + ct, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // row tile s of this wave: rows [row0 + 16 s P_MIS, ...); a tile that starts past the end does not exist (nobody waits for it)
     unsigned* const cnt0 = a.cnt + (size_t)rt * P_SUB * P_CNT_STRIDE;
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         pend_tt = -1;
     };
 
+    bool fast = false;   // wave-uniform: set after the first wait when the row tile's producers share this XCD
     for (int p = 0; p < T; ++p) {
         const int tt = a.reverse ? T - 1 - p : p;
         // Exchange slot of step p's input / output: a two-slot ring read with sc1 loads (CPG_PERSIST_PLAIN_LOADS = 1: one slot
@@ -425,6 +434,18 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             }
 
         if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(cnt0 + sb * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
+        if (CPG_PERSIST_XCD_FAST && p == 0 && sb == 0 && !dead) {
+            // All NCT producers of this row tile have arrived once, so all of them have posted their XCD.  If every one of them
+            // sits on THIS XCD they share one L2, and from here on the hand-off stays inside it: plain stores (the lines stay in
+            // the L2; an sc1 store writes through and drops them, and the readers then fetch at the cross-XCD rate) and L2-local
+            // arrival adds (an agent-scope add executes memory-side) - both still read with sc1 loads, which bypass the CU's L1
+            // only.  Measured per launch, NOT assumed from blockIdx: any other placement keeps the write-through protocol.
+            bool same = true;
+            for (int c = lane; c < NCT; c += 64)
+                same = same && __hip_atomic_load(a.xcc + (size_t)g * NCT + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc;
+            fast = __builtin_amdgcn_ballot_w64(!same) == 0;
+            if (blockIdx.x == 0 && wave == 0 && lane == 0) a.xcc[P_XCC_WORDS - 1] = fast ? 1u : 2u;   // for tests / diagnostics
+        }
         if (sb == 0) P_STAMP(1);
         if (CPG_PERSIST_DEFER) flush(MI0, MI1);
 #if CPG_PERSIST_ACQUIRE
@@ -534,13 +555,21 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         for (int mi = MI0; mi < MI1; ++mi) {
             hrow[mi] = acc_to_rows(tb, hprev[mi], lane);
             const int row = row0 + 16 * mi + srow;
-            if (p + 1 < T)
-                publish_rows<NP>(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
-                                 out_off + (unsigned)(j0 >> 5) * kb_bytes, row < Bend && 4 * (scq & ~1) < CT, lane);
+            if (p + 1 < T) {
+                if (fast)
+                    publish_rows<NP, true>(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
+                                           out_off + (unsigned)(j0 >> 5) * kb_bytes, row < Bend && 4 * (scq & ~1) < CT, lane);
+                else
+                    publish_rows<NP, false>(hrow[mi], rx, row * 64 + ((j0 & 31) + 4 * (scq & ~1)) * 2, plane_bytes,
+                                            out_off + (unsigned)(j0 >> 5) * kb_bytes, row < Bend && 4 * (scq & ~1) < CT, lane);
+            }
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (sb == 0) P_STAMP(5);
-        if (lane == 0) __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            if (fast) __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executes in the L2
+            else __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         pend_tt = tt;
         if (!CPG_PERSIST_DEFER) flush(MI0, MI1);
         if (sb == 0) P_STAMP(6);
@@ -611,7 +640,11 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
 }
 
 static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_SUB * P_CNT_STRIDE; }
-static size_t sync_words(int B) { return (cnt_words(B) + 16 + 63) / 64 * 64; }  // counters + error word, 256-byte multiple
+static size_t sync_words(int B) { return (cnt_words(B) + 16 + P_XCC_WORDS + 63) / 64 * 64; }  // counters + error word + XCD table, 256-byte multiple
+
+// Byte offset, inside the scratch, of a word the last launch set to 1 (its first row tile's producers shared one XCD: the hand-off
+// stayed inside that L2) or 2 (write-through hand-off).  Diagnostics only.
+CPG_EXPORT size_t cpg_gru_persistent_path_offset(int B) { return (cnt_words(B) + 16 + P_XCC_WORDS - 1) * sizeof(unsigned); }
 
 CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
     // counters + error word, then the exchange slots: three bf16 planes of the state, two slots (a slot per step + the initial
@@ -646,6 +679,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     a.gates_bf16 = gates && cpg_gru_store_bf16(B, H, true);
     a.cnt = (unsigned*)sync_scratch;
     a.err = a.cnt + cnt_words(B);
+    a.xcc = a.err + 16;
     a.err_host = (unsigned*)err_host;
     a.xch = (uint16_t*)(a.cnt + sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;

@@ -137,13 +137,18 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
  * A wait that times out (workgroups not co-resident: another process or kernel holds CUs) sets the error word - and
  * *err_host, so the host notices without a copy or a synchronisation - and NaN-poisons everything the wave stores afterwards.
  * cpg_gru_persistent_status synchronises the stream and returns the error word.
- * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident. */
+ * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident.
+ * Hand-off flavour: every workgroup posts the XCD it runs on (HW_REG_XCC_ID); a row tile whose producers all sit on one XCD keeps
+ * its hand-off inside that L2 from the first step on (plain stores, L2-local arrival adds), any other placement keeps the
+ * write-through protocol.  Decided per launch from what the hardware reports, never from blockIdx; the word at byte
+ * cpg_gru_persistent_path_offset(B) of the scratch records the last launch's choice (1 same-XCD, 2 write-through). */
 CPG_API int cpg_gru_persistent_fits(int B, int H);
 /* batch rows one launch covers at width H on this device (0: width not covered; 16 hidden units per workgroup up to H = 512,
  * 8 up to H = 1024); wider batches run as consecutive launches over row ranges [row_begin, row_end) */
 CPG_API int cpg_gru_persistent_rows(int H);
 CPG_API size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H);
 CPG_API size_t cpg_gru_persistent_err_offset(int B);
+CPG_API size_t cpg_gru_persistent_path_offset(int B);
 CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                        const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                        float* hs, float* gates, int row_begin, int row_end, void* sync_scratch,

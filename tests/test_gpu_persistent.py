@@ -6,6 +6,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(autouse=True)
@@ -247,3 +248,26 @@ def test_bf16_mode_saves_gates_as_bf16(B, H, T):
             _bwd(d, B, H, T, False, hs_p, g_p, dhs, last, with_wT=False)
     finally:
         ops.set_compute_mode("f32")
+
+
+def test_handoff_flavour_follows_the_reported_placement():
+    """The persistent forward picks its hand-off per launch from the XCD ids the workgroups report: at B=2048, H=512 (one row group
+    per XCD under the observed round-robin dispatch) the same-XCD form, at a shape whose six workgroups land on six XCDs the
+    write-through form - either way the results are the per-step kernels' (asserted above for every shape); here the recorded
+    choice is read back and must be one of the two, and is written to gpurun_out/ for the record."""
+    import json
+    import os
+    from cpg import ops
+    seen = {}
+    for B, H, T in ((2048, 512, 4), (200, 96, 3)):
+        d = _inputs(B, H, T, 24, seed=11)
+        hs_p, _ = _run(d, B, H, T, False, True)
+        hs_s, _ = _run(d, B, H, T, False, False)
+        assert (hs_p - hs_s).abs().max().item() < 5e-6
+        ent = next(v for k, v in ops._persist_scratch.items() if k[0] == "gru" and k[3:] == (B, H))
+        off = ops.query("cpg_gru_persistent_path_offset", B)
+        word = int(ent[0][off:off + 4].view(torch.int32).item())
+        assert word in (1, 2), word
+        seen[f"B{B}_H{H}"] = {1: "same-XCD (L2-local hand-off)", 2: "write-through"}[word]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(seen, open(os.path.join(ROOT, "gpurun_out", "persist_handoff_report.json"), "w"), indent=1)

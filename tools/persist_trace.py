@@ -30,7 +30,8 @@ torch.cuda.synchronize()
 ent = next(v for k, v in ops._persist_scratch.items() if k[0] == "gru")
 nwg = (B // 256) * (H // 16)
 n = nwg * W * T * 8
-tr = ent[0][-n * 8:].view(torch.int64).cpu().numpy().reshape(nwg, W, T, 8).astype(np.float64) * 0.01   # us
+area = (B // 256) * (H // 8) * W * T * 8 * 8                 # bytes of the trace area (sized for 8-unit column tiles)
+tr = ent[0][-area:][:n * 8].view(torch.int64).cpu().numpy().reshape(nwg, W, T, 8).astype(np.float64) * 0.01   # us
 t0 = tr[:, :, :, 0].min()
 names = ["wait", "first-kb", "mfma-loop", "cell", "publish+drain", "arrive+stores"]
 steps = slice(5, 22)
@@ -50,3 +51,41 @@ for wg in (0, 1, 8, 255):
 arr = tr[:, :, steps, 5].reshape(H // 16, B // 256, W, -1)     # block b: g = b % groups, ct = b // groups
 spread = arr.max(0) - arr.min(0)
 print(f"arrival spread across the 32 producers of a row tile: mean {spread.mean():.2f} us, p90 {np.percentile(spread, 90):.2f}")
+# is the lateness of a producer systematic (same workgroup late at every step) or noise?
+late = arr - arr.mean(0, keepdims=True)                       # [ct, g, wave, step]
+sysm = late.mean(3)                                           # per producer, over steps
+print(f"lateness of a producer vs its row tile's mean arrival: systematic part (mean over steps) std {sysm.std():.2f} us, "
+      f"range {sysm.min():.2f} .. {sysm.max():.2f}; residual (step-to-step) std {(late - sysm[..., None]).std():.2f} us")
+print("systematic lateness by column tile (mean over row groups / waves):", np.round(sysm.mean((1, 2)), 2).tolist())
+print("systematic lateness by wave index (mean over column tiles / row groups):", np.round(sysm.mean((0, 1)), 2).tolist())
+print("systematic lateness by row group:", np.round(sysm.mean((0, 2)), 2).tolist())
+last = arr.argmax(0)                                          # which ct is last, [g, wave, step]
+print("how often each column tile is the LAST arriver (of %d tile-steps):" % last.size, np.bincount(last.ravel(), minlength=H // 16).tolist())
+# step-top skew: how far apart do the 32 consumers of a row tile START a step (stamp 0)?
+top = tr[:, :, steps, 0].reshape(H // 16, B // 256, W, -1)
+print(f"step-top spread across the 32 workgroups of a row tile: mean {(top.max(0) - top.min(0)).mean():.2f} us")
+# wait-done (stamp 1) minus the last arrival of the previous step's producers = visibility latency of the counter
+prev_last = arr.max(0)[:, :, :-1]                              # last arrival for step p   [g, wave, step-1]
+seen = tr[:, :, steps, 1].reshape(H // 16, B // 256, W, -1)[:, :, :, 1:]   # wait done at step p+1 per consumer
+vis = seen - prev_last[None]
+print(f"wait-done minus last arrival (counter visibility + poll granularity): mean {vis.mean():.2f} us, p10 {np.percentile(vis, 10):.2f}, p90 {np.percentile(vis, 90):.2f}")
+waiting = top[:, :, :, 1:] < prev_last[None]                   # consumer was already polling when the last producer arrived
+print(f"consumers already waiting at the last arrival: {waiting.mean() * 100:.0f} %; their delay from last arrival to wait-done: "
+      f"mean {vis[waiting].mean():.2f} us, p10 {np.percentile(vis[waiting], 10):.2f}, p50 {np.percentile(vis[waiting], 50):.2f}, p90 {np.percentile(vis[waiting], 90):.2f}")
+dd = d.reshape(H // 16, B // 256, W, -1, 6)
+slow = np.zeros(H // 16, bool)
+slow[[6, 7, 22, 23]] = True
+for i, nm in enumerate(names):
+    print(f"  {nm:16s} slow tiles {dd[slow][..., i].mean():6.2f}   other tiles {dd[~slow][..., i].mean():6.2f}")
+pp = np.diff(tr[:, :, steps, 0], axis=2).reshape(H // 16, B // 256, W, -1)
+print("step period by column tile:", np.round(pp.mean((1, 2, 3)), 2).tolist())
+# busy time (step top of wait-done .. arrival) by column tile: what a tile needs when it does not wait
+busy = (tr[:, :, steps, 5] - tr[:, :, steps, 1]).reshape(H // 16, B // 256, W, -1)
+print("wait-done -> arrival (own work) by column tile:", np.round(busy.mean((1, 2, 3)), 2).tolist())
+print("own work by row group (XCD):", np.round(busy.mean((0, 2, 3)), 2).tolist())
+print("own work by wave:", np.round(busy.mean((0, 1, 3)), 2).tolist())
+pw = np.diff(tr[:, :, :, 0], axis=2)                           # all steps
+print("step period by wave index (all steps):", np.round(pw.mean((0, 2)), 2).tolist())
+end = tr[:, :, T - 1, 6] - t0
+print("chain end (last step's stores issued) by wave index, us from the first stamp: mean", np.round(end.mean(0), 1).tolist(), " max", np.round(end.max(0), 1).tolist())
+print("step period by wave over steps 0-7 / 8-15 / 16-23:", [np.round(pw[:, :, a:a + 8].mean((0, 2)), 2).tolist() for a in (0, 8, 16)])
