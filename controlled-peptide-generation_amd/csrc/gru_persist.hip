@@ -434,12 +434,14 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             }
 
         if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(cnt0 + sb * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
-        if (CPG_PERSIST_XCD_FAST && p == 0 && sb == 0 && !dead) {
+        if (CPG_PERSIST_XCD_FAST && NP == 3 && p == 0 && sb == 0 && !dead) {
             // All NCT producers of this row tile have arrived once, so all of them have posted their XCD.  If every one of them
-            // sits on THIS XCD they share one L2, and from here on the hand-off stays inside it: plain stores (the lines stay in
-            // the L2; an sc1 store writes through and drops them, and the readers then fetch at the cross-XCD rate) and L2-local
-            // arrival adds (an agent-scope add executes memory-side) - both still read with sc1 loads, which bypass the CU's L1
-            // only.  Measured per launch, NOT assumed from blockIdx: any other placement keeps the write-through protocol.
+            // sits on THIS XCD they share one L2, and from here on the tile's planes are published with PLAIN stores: the lines stay
+            // in that L2 (an sc1 store writes through and drops them, and the readers then fetch at the cross-XCD rate) and are
+            // still read with sc1 loads, which bypass the CU's L1 only.  Measured per launch, NOT assumed from blockIdx: any other
+            // placement keeps the write-through stores.  f32-grade (three planes) only: with the single plane of the bf16 mode the
+            // plain stores are 9 % SLOWER (273 against 251 us per sequence).  L2-local (workgroup-scope) arrival adds were
+            // measured too: no effect in either mode, not used.
             bool same = true;
             for (int c = lane; c < NCT; c += 64)
                 same = same && __hip_atomic_load(a.xcc + (size_t)g * NCT + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_xcc;
@@ -566,10 +568,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         }
         if (!(CPG_PERSIST_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (sb == 0) P_STAMP(5);
-        if (lane == 0) {
-            if (fast) __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executes in the L2
-            else __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (lane == 0) __hip_atomic_fetch_add(cnt0 + sb * P_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend_tt = tt;
         if (!CPG_PERSIST_DEFER) flush(MI0, MI1);
         if (sb == 0) P_STAMP(6);

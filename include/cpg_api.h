@@ -138,10 +138,10 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
  * *err_host, so the host notices without a copy or a synchronisation - and NaN-poisons everything the wave stores afterwards.
  * cpg_gru_persistent_status synchronises the stream and returns the error word.
  * Do not run two persistent launches concurrently on different streams: each needs all of its workgroups resident.
- * Hand-off flavour: every workgroup posts the XCD it runs on (HW_REG_XCC_ID); a row tile whose producers all sit on one XCD keeps
- * its hand-off inside that L2 from the first step on (plain stores, L2-local arrival adds), any other placement keeps the
- * write-through protocol.  Decided per launch from what the hardware reports, never from blockIdx; the word at byte
- * cpg_gru_persistent_path_offset(B) of the scratch records the last launch's choice (1 same-XCD, 2 write-through). */
+ * Hand-off flavour (f32-grade mode): every workgroup posts the XCD it runs on (HW_REG_XCC_ID); a row tile whose producers all sit
+ * on one XCD publishes its planes with plain stores from the first step on (the lines stay in that L2), any other placement keeps
+ * the write-through stores.  Decided per launch from what the hardware reports, never from blockIdx; the word at byte
+ * cpg_gru_persistent_path_offset(B) of the scratch records the last such launch's choice (1 same-XCD, 2 write-through). */
 CPG_API int cpg_gru_persistent_fits(int B, int H);
 /* batch rows one launch covers at width H on this device (0: width not covered; 16 hidden units per workgroup up to H = 512,
  * 8 up to H = 1024); wider batches run as consecutive launches over row ranges [row_begin, row_end) */
