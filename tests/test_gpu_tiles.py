@@ -297,3 +297,27 @@ def test_minimal_seq_len_vs_oracle(monkeypatch):
         for B in (5, 64):
             m, P, ids, rnd = _random_case(B, T, 24, 100, 80, 1, seed=30 + T)
             _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,ld", [(51200, 24, 24), (2048, 510, 510), (24, 1536, 1536), (7, 3, 5), (300, 1000, 1024), (51200, 2048, 2048), (1, 70, 70)])
+def test_column_sums_every_chunking(M, N, ld):
+    """cpg_colsum_f32 (bias gradients): the row-chunk count follows the shape - many short chunks for narrow matrices, 256-row
+    chunks for wide ones - with the workspace sized by cpg_colsum_workspace_bytes; against a float64 sum, with and without
+    accumulation into the output."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, ld, generator=g).to(dev)
+    ref = x[:, :N].double().sum(0)
+    nb = ops.query("cpg_colsum_workspace_bytes", M, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out = torch.full((N,), 3.0, device=dev)
+    call("cpg_colsum_f32", _p(x), ld, M, N, _p(out), 0, _p(ws), nb, _stream())
+    tol = 1e-6 * max(1.0, float(x[:, :N].abs().double().sum(0).max()))
+    assert (out.double() - ref).abs().max().item() <= tol
+    call("cpg_colsum_f32", _p(x), ld, M, N, _p(out), 1, _p(ws), nb, _stream())
+    assert (out.double() - 2 * ref).abs().max().item() <= 2 * tol
+    with pytest.raises(ops.CpgError):
+        call("cpg_colsum_f32", _p(x), ld, M, N, _p(out), 0, _p(ws), 8, _stream())     # workspace too small: refused
