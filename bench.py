@@ -423,8 +423,8 @@ def workload_text(args, dtype, Hh, enc_layers, B, T):
                "LSTM cell (extension, torch.nn.LSTM semantics; parity unpinned against the GRU-only reference)")
             + (", f32 storage; recurrent products on the MFMA units in f32-grade forms (exact-f32 MFMA, or six bf16 MFMAs on 3-way "
                "split operands)" if dtype == "f32" else
-               ", bf16 mode: recurrent products with bf16-rounded operands (one bf16 MFMA per block, f32 accumulation), saved gates / "
-               "gate gradients stored as bf16, f32 state slabs and master weights (NOT the parity path: agreement figures in profiles/)"))
+               ", bf16 mode: recurrent products with bf16-rounded operands (one bf16 MFMA per block, f32 accumulation), saved gates "
+               "stored as bf16; gate gradients, state slabs and master weights f32 (NOT the parity path: agreement figures in profiles/)"))
 
 
 def main():
