@@ -36,60 +36,92 @@ def local_device(local_rank):
     return local_rank % n if n else 0
 
 
+class _CApi:
+    """The library's RCCL entry points as LibComm drives them (include/cpg_api.h: cpg_comm_*, cpg_allreduce_f32, cpg_allgatherv).
+    Kept behind this small object so that tests can run LibComm's host logic - id exchange, row counts, empty ranks - at
+    world > 1 over a stand-in that speaks the same contract on CPU tensors (tests/test_dist_gloo.py)."""
+
+    def unique_id(self):
+        import ctypes
+        from . import ops
+        buf = ctypes.create_string_buffer(128)
+        ops.call("cpg_comm_unique_id", buf)
+        return bytes(buf.raw)
+
+    def init(self, uid, rank, world):
+        import ctypes
+        from . import ops
+        comm = ctypes.c_void_p()
+        ops.call("cpg_comm_init", ctypes.c_char_p(uid), rank, world, ctypes.byref(comm))
+        return comm
+
+    def allreduce_f32(self, comm, t):
+        from . import ops
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        ops.call("cpg_allreduce_f32", comm, ops._p(t), t.numel(), ops._stream())
+
+    def allgatherv(self, comm, send, counts, rank, world, out):
+        """counts: bytes contributed by every rank - IDENTICAL on every rank (the C entry point's contract); send may be None
+        when this rank's count is 0."""
+        import ctypes
+        from . import ops
+        arr = (ctypes.c_size_t * world)(*[int(c) for c in counts])
+        ops.call("cpg_allgatherv", comm, ops._p(send) if send is not None else None, arr, rank, world, ops._p(out), ops._stream())
+
+    def destroy(self, comm):
+        from . import ops
+        ops.call("cpg_comm_destroy", comm)
+
+    def record(self):
+        return torch.cuda.current_stream().record_event()
+
+
 class LibComm:
     """The library's own RCCL communicator (include/cpg_api.h: cpg_comm_*, cpg_allreduce_f32, cpg_allgatherv): collectives are
     plain launches on a HIP stream of the caller's choice - no process-group stream, no Work objects.  The 128-byte unique id
     travels over the torch.distributed group that is up anyway (any backend).  Opt-in: CPG_COMM=lib (default: torch.distributed)."""
 
-    def __init__(self, rank, world):
-        import ctypes
-        from . import ops
+    def __init__(self, rank, world, api=None):
         self.rank, self.world = rank, world
+        self.api = api if api is not None else _CApi()
         idt = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            ops.call("cpg_comm_unique_id", buf)
-            idt = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            idt = torch.frombuffer(bytearray(self.api.unique_id()), dtype=torch.uint8).clone()
         if world > 1:
             dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
             idt = idt.to(dev)
             dist.broadcast(idt, 0)
             idt = idt.cpu()
-        self._comm = ctypes.c_void_p()
-        ops.call("cpg_comm_init", ctypes.c_char_p(bytes(idt.numpy().tobytes())), rank, world, ctypes.byref(self._comm))
+        self._comm = self.api.init(bytes(idt.numpy().tobytes()), rank, world)
 
     def allreduce_sum(self, t):
         """In-place SUM on the CURRENT stream (asynchronous to the host)."""
-        from . import ops
-        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-        ops.call("cpg_allreduce_f32", self._comm, ops._p(t), t.numel(), ops._stream())
+        self.api.allreduce_f32(self._comm, t)
         return t
 
     def allreduce_sum_async(self, t):
         self.allreduce_sum(t)
-        return _StreamWork(torch.cuda.current_stream().record_event())
+        return _StreamWork(self.api.record())
 
     def allgather_rows(self, t):
-        """Variable number of rows per rank -> all rows in rank order (counts first, then one grouped set of broadcasts)."""
-        import ctypes
-        from . import ops
+        """Variable number of rows per rank -> all rows in rank order (counts first, then one grouped set of broadcasts).
+        A rank may contribute ZERO rows (no accepted CLaSS proposal in its shard): the row size comes from the trailing shape,
+        never from the local row count, so every rank hands cpg_allgatherv the same byte table (round-3 advisor finding)."""
+        import math
         t = t.contiguous()
-        row_bytes = t[0:1].numel() * t.element_size() if t.dim() > 1 else t.element_size()
+        row_bytes = math.prod(t.shape[1:]) * t.element_size()
         mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
         allc = torch.zeros(self.world, dtype=torch.int64, device=t.device)
-        eight = (ctypes.c_size_t * self.world)(*([8] * self.world))
-        ops.call("cpg_allgatherv", self._comm, ops._p(mine), eight, self.rank, self.world, ops._p(allc), ops._stream())
+        self.api.allgatherv(self._comm, mine, [8] * self.world, self.rank, self.world, allc)
         rows = [int(x) for x in allc.cpu()]
         out = torch.empty((sum(rows),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        counts = (ctypes.c_size_t * self.world)(*[r * row_bytes for r in rows])
         if out.numel():
-            ops.call("cpg_allgatherv", self._comm, ops._p(t) if t.numel() else None, counts, self.rank, self.world, ops._p(out), ops._stream())
+            self.api.allgatherv(self._comm, t if t.numel() else None, [r * row_bytes for r in rows], self.rank, self.world, out)
         return out
 
     def close(self):
-        from . import ops
         if self._comm:
-            ops.call("cpg_comm_destroy", self._comm)
+            self.api.destroy(self._comm)
             self._comm = None
 
 
@@ -98,7 +130,8 @@ class _StreamWork:
         self.ev = ev
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self.ev)
+        if self.ev is not None:
+            torch.cuda.current_stream().wait_event(self.ev)
 
 
 _lib_comm = None

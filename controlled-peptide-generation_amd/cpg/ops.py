@@ -108,11 +108,25 @@ class _prof:
         return False
 
 
+GRAPH_CAPTURED = False   # set by train_vae.GraphedTrainStep: a hipGraph now holds raw pointers into the caches below
+_retired = []            # buffers superseded AFTER a capture: kept alive, a replay still writes to them
+
+
+def _retire(old):
+    """A cached scratch buffer is being replaced by a larger one.  Once a training step has been captured into a hipGraph the
+    graph's kernel nodes carry the OLD buffer's address (the side-stream workspaces included: side_streams() is shared by eager
+    and captured code), so dropping the last reference would hand that memory back to the caching allocator while every replay
+    still writes to it.  Superseded buffers are therefore parked here for the life of the process (round-3 advisor finding)."""
+    if GRAPH_CAPTURED and old is not None:
+        _retired.append(old)
+
+
 def workspace(nbytes, device, tag=0):
     """Stream-keyed scratch buffer (grown on demand, reused across calls: launches on one stream are ordered)."""
     key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        _retire(buf)
         buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -207,19 +221,33 @@ class backward_scope:
         return False
 
 
+_boundary_pending = {}   # tag -> boundaries of that tag registered by forward passes and not yet reached by a backward pass
+
+
+def reset_boundaries():
+    """Forget boundaries registered by forward passes that were never differentiated (FusedAdamClip.step calls this)."""
+    _boundary_pending.clear()
+
+
 class GradBoundaryFn(Function):
     """Identity on its tensor inputs.  Its backward runs once the gradients of ALL of them are complete - i.e. after every
     backward node downstream of the boundary has been enqueued - and then fires BOUNDARY_CB(tag): the optimiser starts the
-    all-reduce of the gradient bucket that became final there while the rest of the backward pass still runs."""
+    all-reduce of the gradient bucket that became final there while the rest of the backward pass still runs.
+    A module may run more than once in the graph being differentiated (the decoder of a multi-decode loss): every forward
+    registers its boundary, and the callback fires only when the LAST registered boundary of the tag has been reached - the
+    bucket's gradients are not final before that (round-3 advisor finding)."""
 
     @staticmethod
     def forward(ctx, tag, *ts):
         ctx.tag = tag
+        _boundary_pending[tag] = _boundary_pending.get(tag, 0) + 1
         return tuple(t.view_as(t) for t in ts)
 
     @staticmethod
     def backward(ctx, *gs):
-        if BOUNDARY_CB is not None:
+        left = _boundary_pending.get(ctx.tag, 1) - 1
+        _boundary_pending[ctx.tag] = max(left, 0)
+        if BOUNDARY_CB is not None and left <= 0:
             BOUNDARY_CB(ctx.tag)
         return (None,) + gs
 
@@ -466,6 +494,7 @@ def _persist_entry(kind, T, B, H, dev):
     if ent is None or ent[1] < T:
         nb = query("cpg_gru_persistent_scratch_bytes" if kind == "gru" else "cpg_lstm_persistent_scratch_bytes", T, B, H)
         host = ent[2] if ent is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+        _retire(ent[0] if ent is not None else None)
         ent = _persist_scratch[key] = [torch.zeros(nb, dtype=torch.uint8, device=dev), T, host]   # counters + error word + slots
     if ent[2][0] != 0:
         _persist_failed(kind)      # an EARLIER launch on this scratch timed out
@@ -725,6 +754,8 @@ _pending_events = []
 
 def join_deferred():
     """Make the current stream wait for every deferred weight-gradient accumulation (called by the optimiser)."""
+    if not _pending_events:
+        return
     cur = torch.cuda.current_stream()
     while _pending_events:
         cur.wait_event(_pending_events.pop())

@@ -20,6 +20,81 @@ from . import ops
 from .ops import _p, _stream, call
 
 
+class BucketReducer:
+    """When and how the slices of ONE flat gradient buffer are SUM-all-reduced across data-parallel ranks.  Pure host logic (no
+    kernels: FusedAdamClip owns those), so it is the same object on the GPU - where the collectives are RCCL launches issued
+    from a side stream - and in the CPU tests, where gloo carries them at world 2 and 8 (tests/test_dist_gloo.py).
+
+    bucket_range: tag -> [start, end) of the flat buffer, laid out at its END in the order the backward pass completes them;
+    [0, tail_end) is everything else (final only when the backward pass ends).  `on_boundary(tag)` - called from inside the
+    backward pass when the bucket's gradients are final (cpg.ops.GradBoundaryFn) - starts its asynchronous all-reduce;
+    `finish()` reduces what was not started and waits for everything in flight."""
+
+    def __init__(self, flat_g, bucket_range, tail_end, reduce_fn=None, async_reduce_fn=None, world=1):
+        self.flat_g, self.bucket_range, self.tail_end = flat_g, dict(bucket_range), int(tail_end)
+        self.reduce_fn, self.async_reduce_fn, self.world = reduce_fn, async_reduce_fn, int(world)
+        self.inflight, self.reduced = [], set()
+
+    @property
+    def overlapped(self):
+        return self.async_reduce_fn is not None and self.world > 1 and bool(self.bucket_range)
+
+    def reset(self):
+        self.inflight, self.reduced = [], set()
+
+    def on_boundary(self, tag):
+        rng = self.bucket_range.get(tag)
+        if rng is None or tag in self.reduced:
+            return
+        self.reduced.add(tag)
+        g = self.flat_g[rng[0]:rng[1]]
+        if not self.flat_g.is_cuda:                      # CPU (tests over gloo): no streams, the Work object is the handle
+            self.inflight.append((self.async_reduce_fn(g), None))
+            return
+        main = torch.cuda.current_stream()
+        side = ops.side_streams(self.flat_g.device)[2]   # the deferred dW_hh accumulation of this bucket is queued there
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            work = self.async_reduce_fn(g)
+        self.inflight.append((work, side))
+
+    def finish(self):
+        """SUM over ranks of whatever has not been reduced yet, then wait for the bucket reductions started in backward()."""
+        if self.reduce_fn is None and self.async_reduce_fn is None:
+            return
+        sync = self.reduce_fn if self.reduce_fn is not None else (lambda t: self.async_reduce_fn(t).wait())
+        if not self.reduced:
+            sync(self.flat_g)
+        else:
+            if self.tail_end > 0:
+                sync(self.flat_g[:self.tail_end])
+            for tag, (a, b) in self.bucket_range.items():
+                if tag not in self.reduced:
+                    sync(self.flat_g[a:b])
+        for work, side in self.inflight:
+            if side is None:
+                work.wait()
+                continue
+            with torch.cuda.stream(side):
+                work.wait()                                   # the issuing stream waits for the collective ...
+            torch.cuda.current_stream().wait_stream(side)     # ... and the optimiser's stream for the issuing stream
+        self.reset()
+
+
+def bucket_layout(sizes, order_tags, pad):
+    """Offsets of parameters laid out in `order_tags` order (one tag or None per parameter, bucketed ones last and grouped):
+    -> (offsets, {tag: (start, end)}, tail_end, total).  Host arithmetic shared by FusedAdamClip and the CPU tests."""
+    offs, off, rng = [], 0, {}
+    for k, tag in zip(sizes, order_tags):
+        offs.append(off)
+        if tag is not None:
+            a, _ = rng.get(tag, (off, off))
+            rng[tag] = (a, off + pad(k))
+        off += pad(k)
+    tail_end = min([r[0] for r in rng.values()], default=off)
+    return offs, rng, tail_end, off
+
+
 class FusedAdamClip:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=None, reduce_fn=None, world=1, buckets=None,
                  async_reduce_fn=None):
@@ -67,65 +142,36 @@ class FusedAdamClip:
             off += pad(k)
         self.n_dup = sum(k for (o, k), mm in zip(self.segs, self.mult) if mm > 1)
         # bucket tag -> [start, end) of the flat buffers (padded segment boundaries); everything before the first bucket is the tail
-        self.bucket_range, pos = {}, {id(p): i for i, p in enumerate(self.order)}
-        for tag, grp in bucketed:
-            if grp:
-                i0, i1 = pos[id(grp[0])], pos[id(grp[-1])]
-                self.bucket_range[tag] = (self.segs[i0][0], self.segs[i1][0] + pad(self.segs[i1][1]))
-        self.tail_end = min([r[0] for r in self.bucket_range.values()], default=n)
-        self.async_reduce_fn = async_reduce_fn
-        self._inflight, self._reduced = [], set()
+        _, self.bucket_range, self.tail_end, total = bucket_layout([p.numel() for p in self.order],
+                                                                   [in_bucket.get(id(p)) for p in self.order], pad)
+        assert total == n
+        self.reducer = BucketReducer(self.flat_g, self.bucket_range, self.tail_end, reduce_fn, async_reduce_fn, world)
         self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
-        self.reduce_fn, self.world = reduce_fn, int(world)
-        self.iter_dev = torch.zeros(1, device=dev, dtype=torch.int32)   # completed optimiser iterations, ON THE DEVICE: the Adam
-        self.iters = 0                                                   # step numbers are formed there (graph-replayable steps)
+        self.world = int(world)
+        # completed optimiser iterations, ON THE DEVICE: the Adam step numbers are formed there, so that a step captured into a
+        # hipGraph advances them at every replay (there is deliberately no host-side counter: it would stop under replay)
+        self.iter_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.ws = torch.empty(ops.query("cpg_sumsq_workspace") // 4, device=dev, dtype=torch.float32)
+
+    @property
+    def _reduced(self):          # tags whose all-reduce was started from a gradient boundary of the current backward pass
+        return self.reducer.reduced
 
     def zero_grad(self):
         ops.join_deferred()
         self.flat_g.zero_()
-        self._inflight, self._reduced = [], set()
+        self.reducer.reset()
 
     def backward(self, loss):
         """loss.backward() in the fused form (cpg.ops.backward_scope): direct accumulation into the flat gradient buffer, the
         decoder's dW_hh on the side stream, bucket all-reduces started from the gradient boundaries."""
-        cb = self._on_boundary if (self.async_reduce_fn is not None and self.world > 1 and self.bucket_range) else None
+        cb = self.reducer.on_boundary if self.reducer.overlapped else None
         with ops.backward_scope(cb):
             loss.backward()
 
-    def _on_boundary(self, tag):
-        rng = self.bucket_range.get(tag)
-        if rng is None or tag in self._reduced:
-            return
-        self._reduced.add(tag)
-        dev = self.flat_g.device
-        main = torch.cuda.current_stream()
-        side = ops.side_streams(dev)[2]      # the deferred dW_hh accumulation of this bucket is queued there
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            work = self.async_reduce_fn(self.flat_g[rng[0]:rng[1]])
-        self._inflight.append((work, side))
-
     def _finish_reduce(self):
-        """SUM over ranks of whatever has not been reduced yet, then wait for the bucket reductions started in backward()."""
-        if self.reduce_fn is None and self.async_reduce_fn is None:
-            return
-        sync = self.reduce_fn if self.reduce_fn is not None else (lambda t: self.async_reduce_fn(t).wait())
-        if not self._reduced:
-            sync(self.flat_g)
-        else:
-            if self.tail_end > 0:
-                sync(self.flat_g[:self.tail_end])
-            for tag, (a, b) in self.bucket_range.items():
-                if tag not in self._reduced:
-                    sync(self.flat_g[a:b])
-        cur = torch.cuda.current_stream()
-        for work, side in self._inflight:
-            with torch.cuda.stream(side):
-                work.wait()                  # the issuing stream waits for the collective ...
-            cur.wait_stream(side)            # ... and the optimiser's stream for the issuing stream
-        self._inflight, self._reduced = [], set()
+        self.reducer.finish()
 
     def grad_norm(self):
         """Pre-clip total norm as clip_grad_norm_ would return it (duplicates counted by multiplicity); device scalar."""
@@ -167,4 +213,4 @@ class FusedAdamClip:
             off = self.segs[i][0]
             adam(off, n - off, 1, 1, 1)
         call("cpg_counter_add_i32", _p(self.iter_dev), 1, _stream())
-        self.iters += 1
+        ops.reset_boundaries()   # boundaries of forward passes that were never differentiated do not leak into the next step

@@ -23,6 +23,7 @@ static const char* const g_opt_names[OPT__COUNT] = {
     "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl", "bf16_store"};
 static CpgOptVal g_opts[OPT__COUNT];
 static std::once_flag g_opts_once;
+static std::mutex g_opts_mu;   // cpg_set_option may run on one thread while launch paths on another (autograd's backward thread) read
 
 static void opt_assign(CpgOptVal& v, const char* text) {
     v.set = text && text[0];
@@ -40,8 +41,12 @@ static void opts_from_env() {
     }
 }
 
-const CpgOptVal& cpg_opt(CpgOpt o) {
+// Returns a COPY taken under the table's mutex: a reader never sees a half-written entry (flag, number and text of one
+// cpg_set_option call arrive together).  Options must still not be CHANGED between the forward and the backward pass of a
+// sequence where they select a storage format (bf16_store): the Python binding checks the saved gates' dtype for that.
+CpgOptVal cpg_opt(CpgOpt o) {
     std::call_once(g_opts_once, opts_from_env);
+    std::lock_guard<std::mutex> lk(g_opts_mu);
     return g_opts[o];
 }
 
@@ -59,7 +64,10 @@ CPG_EXPORT int cpg_set_option(const char* name, const char* value) {
         return -2;
     }
     std::call_once(g_opts_once, opts_from_env);
-    opt_assign(g_opts[o], value);
+    CpgOptVal v;
+    opt_assign(v, value);
+    std::lock_guard<std::mutex> lk(g_opts_mu);
+    g_opts[o] = v;
     return 0;
 }
 
@@ -67,7 +75,7 @@ CPG_EXPORT int cpg_set_option(const char* name, const char* value) {
 CPG_EXPORT int cpg_get_option(const char* name, char* buf, int n) {
     const int o = opt_index(name);
     if (o < 0) return -2;
-    const CpgOptVal& v = cpg_opt((CpgOpt)o);
+    const CpgOptVal v = cpg_opt((CpgOpt)o);
     if (buf && n > 0) snprintf(buf, (size_t)n, "%s", v.s);
     return v.set ? 1 : 0;
 }

@@ -52,6 +52,6 @@ struct CpgOptVal {
     long i;       // atol of the text
     char s[24];   // the text
 };
-const CpgOptVal& cpg_opt(CpgOpt o);
+CpgOptVal cpg_opt(CpgOpt o);   // a copy, taken under the table's mutex (api.hip)
 int cpg_device_cus();                                   // CUs of the current device (cached per device)
 int cpg_allow_big_lds(const void* kernel, int bytes);   // opt a kernel into > 64 KB dynamic LDS, once per (kernel, device)

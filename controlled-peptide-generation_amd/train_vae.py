@@ -110,6 +110,8 @@ class GraphedTrainStep:
             cur.wait_stream(self.stream)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
+            from cpg import ops as _ops
+            _ops.GRAPH_CAPTURED = True   # scratch buffers the graph points into must outlive any later growth (cpg.ops._retire)
             with torch.cuda.graph(self.graph, stream=self.stream):
                 # recorded, not run: the replay below is this iteration.  (No beta fill in here: it would be frozen into the graph.)
                 self.out = train_step(self.cfgv, self.model, self.trainer, self.text, it, weights_dev=self.weights)
@@ -127,8 +129,16 @@ def train_vae(cfgv, model, dataset, reduce_fn=None, world=1, rank=0):
     print('Training base vae ...')
     trainer = make_optimizer(cfgv, model, reduce_fn, world)
     # cfg.hw.graph: replay the step from one captured hipGraph (single rank, device random streams, dense decoder batches)
-    graphed = GraphedTrainStep(cfgv, model, trainer) if (cfg.hw.graph and world == 1 and model.rng is not None
-                                                        and not cfg.hw.ragged_decoder) else None
+    graphed = None
+    if cfg.hw.graph:
+        unmet = [why for cond, why in ((world == 1, 'more than one rank (the gradient all-reduce stays eager)'),
+                                       (model.rng is not None, 'host random generators (needs model.use_device_rng)'),
+                                       (not cfg.hw.ragged_decoder, 'cfg.hw.ragged_decoder (per-step live-row counts change per batch)'))
+                 if not cond]
+        if unmet:
+            print('WARNING: cfg.hw.graph requested but NOT applied - eager steps instead: ' + '; '.join(unmet), file=sys.stderr)
+        else:
+            graphed = GraphedTrainStep(cfgv, model, trainer)
     for it in range(cfgv.s_iter, cfgv.s_iter + cfgv.n_iter + 1):
         logging_it = it % cfgv.cheaplog_every == 0 or it % cfgv.expsvlog_every == 0
         inputs = dataset.next_batch('train_vae')
