@@ -17,10 +17,23 @@ from . import ops
 from .ops import _p, _stream, call, PAD_IDX, START_IDX, EOS_IDX
 
 
-def _fc(decoder, h, logits):
-    fc = decoder.fc[1]
-    N, H = h.shape
-    call("cpg_vocab_fc_fwd", _p(h), None, 1.0, _p(fc.weight), _p(fc.bias), _p(logits), N, H, logits.shape[1], _stream())
+def _fc(decoder, h, logits, sz=None, keep=None):
+    """logits of one step: GRUDecoder.project (skip connections, out-dropout of a train-mode decode, vocabulary projection)."""
+    decoder.project(h, sz, keep, logits=logits)
+
+
+def _plain(decoder):
+    """The whole-loop kernels cover the plain decode step only: no skip connections, no live out-dropout (train-mode sampling)."""
+    return not getattr(decoder, "skip_connetions", False) and not (decoder.training and decoder.p_out > 0)
+
+
+def _step_keep(decoder, out_keep, i, rows, dev):
+    """Out-dropout mask of step i: the injected one, else the decoder's own draw when it is in train mode, else None."""
+    if out_keep is not None:
+        k = out_keep[i] if i < out_keep.shape[0] else None
+        assert k is None or tuple(k.shape) == (rows, decoder.h_dim)
+        return k.contiguous() if k is not None else decoder.step_keep(rows, dev)
+    return decoder.step_keep(rows, dev)
 
 
 LDS_PER_WORKGROUP = 160 * 1024  # gfx950
@@ -90,9 +103,10 @@ def _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length, prepend_st
 
 @torch.no_grad()
 def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=False, min_length=1, uniforms=None,
-                prepend_start_idx=True):
+                prepend_start_idx=True, out_keep=None):
     """ids int64 [N, 1+steps] (column 0 = <start>), steps <= max_len.
-    uniforms (categorical only): device f64 [max_len, N], the draw of every step (row t feeds step t)."""
+    uniforms (categorical only): device f64 [max_len, N], the draw of every step (row t feeds step t).
+    out_keep: uint8 [steps,N,H] out-dropout masks of a train-mode decode to inject (models/model.py:216-221)."""
     rng = getattr(decoder, "rng", None)
     N = z.shape[0]
     dev = z.device
@@ -102,8 +116,10 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
     V = decoder.fc[1].weight.shape[0]
     lstm = getattr(decoder, "cell", "gru") == "lstm"
-    if mode == "greedy" and not lstm and not prevent_empty and fused_greedy_fits(zc.shape[1], V, tab.shape[0]):
+    if (mode == "greedy" and not lstm and not prevent_empty and out_keep is None and _plain(decoder)
+            and fused_greedy_fits(zc.shape[1], V, tab.shape[0])):
         return _decode_greedy_fused(decoder, zc, tab, rowc, max_len, min_length, prepend_start_idx)
+    sz = decoder.skip_term(zc)
     h_a, h_b = zc.clone(), torch.empty_like(zc)
     if lstm:
         c_a, c_b = torch.zeros_like(zc), torch.empty_like(zc)
@@ -120,7 +136,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
             c_a, c_b = c_b, c_a
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
-        _fc(decoder, h_b, logits)
+        _fc(decoder, h_b, logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         pe = 1 if (prevent_empty and i == 0) else 0
         if mode == "greedy":
             call("cpg_greedy_select", _p(logits), N, V, _p(finished), _p(ids), max_len + 1, i + 1, _p(tok), PAD_IDX,
@@ -144,7 +160,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
 
 
 @torch.no_grad()
-def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_length=1):
+def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_length=1, out_keep=None):
     """RNN_VAE.sample_G soft modes (models/model.py:337-359): 'none_softmax' | 'greedy_softmax' | 'categorical_softmax'.
     Every step feeds the previous softmax row back through the embedding (mutils.soft_embed); W_ih[:, :E] . (soft @ emb)
     = soft @ (emb W_e^T), a [N,V]x[V,3H] product, enters the fused step kernel as its dense input term.
@@ -166,6 +182,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
     w_soft = ops.LinearFn.apply(rnn.weight_ih_l0[:, :E].contiguous(), decoder.emb.weight, None).contiguous()   # [3H,V]
     hs = torch.empty(2, N, H, device=dev, dtype=torch.float32)
     hs[0].copy_(zc)
+    sz = decoder.skip_term(zc)
     logits = torch.empty(N, V, device=dev, dtype=torch.float32)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
     finished = torch.zeros(N, device=dev, dtype=torch.bool)
@@ -180,7 +197,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
             dense = ops.LinearFn.apply(soft, w_soft, rnn.bias_ih_l0).contiguous()
             call("cpg_gru_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
                  _p(hs), None, 0, N, None, _stream())
-        _fc(decoder, hs[1], logits)
+        _fc(decoder, hs[1], logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         soft = torch.softmax(logits / temp, dim=1)
         if mode == "greedy_softmax":
             t = torch.argmax(logits, 1)
@@ -216,7 +233,7 @@ def _first_all_finished(ids):
 
 
 @torch.no_grad()
-def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
+def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1, out_keep=None):
     """Runs the device beam search; returns device tensors (tok, prev, score) each [T,N,K] (tok = -1 where a sentence
     had already finished): the recorded history cpg_beam_hypotheses walks back."""
     lstm = getattr(decoder, "cell", "gru") == "lstm"   # extension (torch.nn.LSTM semantics, h0 = [z;c], c0 = 0): per-step path
@@ -226,8 +243,11 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
     zc1 = decoder.init_hidden(z, c).contiguous()
     tab, rowc1 = decoder._tables(zc1)
     tab = tab.contiguous()
-    if not lstm and fused_beam_fits(zc1.shape[1], decoder.fc[1].weight.shape[0], tab.shape[0], K):
+    if (not lstm and out_keep is None and _plain(decoder)
+            and fused_beam_fits(zc1.shape[1], decoder.fc[1].weight.shape[0], tab.shape[0], K)):
         return _decode_beam_fused(decoder, zc1, tab, rowc1.contiguous(), max_len, K, n_best, min_length)
+    sz1 = decoder.skip_term(zc1)
+    sz = sz1.repeat(K, 1).contiguous() if sz1 is not None else None
     rowc = rowc1.repeat(K, 1).contiguous()            # beam-major rows: row = k*N + i (model.py:262-263)
     h_a = zc1.repeat(K, 1).contiguous()
     h_b = torch.empty_like(h_a)
@@ -257,7 +277,7 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
-        _fc(decoder, h_b, logits)
+        _fc(decoder, h_b, logits, sz, _step_keep(decoder, out_keep, i, K * N, dev))
         call("cpg_beam_select", _p(logits), N, V, K, i, n_best, min_length, START_IDX, EOS_IDX, _p(scores), _p(last_tok),
              _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active), _p(h_b),
              _p(h_a), H, _stream())
@@ -270,11 +290,11 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1)
 
 
 @torch.no_grad()
-def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1, device_out=False):
+def decode_beam_arrays(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1, device_out=False, out_keep=None):
     """Beam search + hypothesis walk-back, all on device.  Returns (hyps int32 [N,n_best,T+1] padded with -1,
     lengths [N,n_best] incl. the leading <start>, scores [N,n_best]) as numpy arrays, or as device tensors (device_out)."""
     global LAST_BEAM_STEPS
-    tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length)
+    tok, prev, score = decode_beam_raw(decoder, z, c, max_len, beam_size, n_best, min_length, out_keep=out_keep)
     T, N, K = tok.shape
     LAST_BEAM_STEPS = int((tok[:, :, 0] >= 0).sum().item())   # steps each sentence advanced before its beam was done
     hyps = torch.empty(N, n_best, T + 1, device=tok.device, dtype=torch.int32)
@@ -319,7 +339,7 @@ def beam_hypotheses(tok, prev, score, n_best):
     return hyps, tl + 1, out_scores
 
 
-def decode_beam(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1):
+def decode_beam(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1, out_keep=None):
     """Reference-format result: list over sentences of n_best hypotheses, each a list of ints incl. leading <start>."""
-    hyps, lens, _ = decode_beam_arrays(decoder, z, c, max_len, beam_size, n_best, min_length)
+    hyps, lens, _ = decode_beam_arrays(decoder, z, c, max_len, beam_size, n_best, min_length, out_keep=out_keep)
     return [[hyps[i, j, :lens[i, j]].tolist() for j in range(n_best)] for i in range(hyps.shape[0])]

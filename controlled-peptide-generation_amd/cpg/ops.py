@@ -403,6 +403,89 @@ class Linear2Fn(Function):
         return dxs[0], dxs[1], dw, db
 
 
+class MaskedLinear2Fn(Function):
+    """y = (x1 .* keep1*scale) W[:, :K1]^T (+ (x2 .* keep2*scale) W[:, K1:]^T) + b: nn.Dropout in front of the input projection of an
+    upper encoder layer - nn.GRU(dropout=p_dropout) drops the (concatenated) output of every layer but the last in train mode
+    (models/encoder.py:25-30).  x1 / x2 are the lower layer's two state slabs (x2, keep2 None for a unidirectional encoder); the
+    keep masks are uint8 0/1 with their x's shape - injected by the caller or drawn from the model's streams."""
+
+    @staticmethod
+    def forward(ctx, x1, keep1, x2, keep2, scale, w, b):
+        xs = [(x1.contiguous(), keep1.contiguous())] + ([(x2.contiguous(), keep2.contiguous())] if x2 is not None else [])
+        M, N = xs[0][0].shape[0], w.shape[0]
+        y = torch.empty(M, N, device=w.device, dtype=torch.float32)
+        k0 = 0
+        for i, (x, keep) in enumerate(xs):
+            assert keep.dtype == torch.uint8 and keep.shape == x.shape
+            kk = x.shape[1]
+            call("cpg_linear_masked_fwd", _p(x), kk, _p(keep), float(scale), _p(w[:, k0:]), w.stride(0), _p(b) if i == 0 else None,
+                 _p(y), N, M, N, kk, int(i > 0), _stream())
+            k0 += kk
+        ctx.save_for_backward(w, *[t for pair in xs for t in pair])
+        ctx.scale, ctx.two, ctx.has_b = float(scale), x2 is not None, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w, *rest = ctx.saved_tensors
+        xs = [(rest[0], rest[1])] + ([(rest[2], rest[3])] if ctx.two else [])
+        dy, lddy = _rowmajor(dy)
+        M, N = dy.shape
+        dw = torch.empty_like(w)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if ctx.has_b else None
+        dxs, k0 = [], 0
+        for i, (x, keep) in enumerate(xs):
+            kk = x.shape[1]
+            dx = torch.empty(M, kk, device=dy.device, dtype=torch.float32)
+            call("cpg_linear_masked_bwd_input", _p(dy), lddy, _p(w[:, k0:]), w.stride(0), _p(keep), ctx.scale, _p(dx), kk, M, N, kk,
+                 _stream())
+            nb = query("cpg_linear_bwd_weight_workspace", M, N, kk)
+            ws = workspace(nb, dy.device)
+            call("cpg_linear_masked_bwd_weight", _p(dy), lddy, _p(x), kk, _p(keep), ctx.scale, _p(dw[:, k0:]), dw.stride(0),
+                 _p(db) if i == 0 else None, M, N, kk, 0, _p(ws), ws.numel(), _stream())
+            dxs.append(dx)
+            k0 += kk
+        return dxs[0], None, (dxs[1] if ctx.two else None), None, None, dw, db
+
+
+class SkipAddFn(Function):
+    """y[t*B + b] = x[t*B + b] Wx^T + sz[b]: the decoder's skip connection rnn_out := skip_weight_x(rnn_out) + skip_weight_z([z;c])
+    (models/decoder.py:48-51,80-81,103-105; both bias-free) with sz = skip_weight_z([z;c]) formed once per row by the caller - the
+    second term is constant over time.  x [T*B,H] time-major step outputs, sz [B,H].  Backward: dx = dy Wx, dWx = dy^T x,
+    dsz = the sum of dy over time (column sums of dy viewed as [T, B*H])."""
+
+    @staticmethod
+    def forward(ctx, x, w, sz, T):
+        x, sz = x.contiguous(), sz.contiguous()
+        B, H = sz.shape
+        assert x.shape == (T * B, H)
+        y = sz.unsqueeze(0).expand(T, B, H).contiguous().view(T * B, H)    # data movement; the product accumulates onto it
+        linear_raw(x, w, None, out=y, accumulate=True)
+        ctx.save_for_backward(x, w)
+        ctx.dims, ctx.leaf = (T, B, H), w
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        T, B, H = ctx.dims
+        dy = dy.contiguous()
+        dev = dy.device
+        dx = torch.empty(T * B, H, device=dev, dtype=torch.float32)
+        call("cpg_linear_bwd_input", _p(dy), H, _p(w), w.stride(0), _p(dx), H, T * B, H, H, 0, _stream())
+        gw = _grad_buf(ctx.leaf)
+        dw = gw if gw is not None else torch.empty(H, H, device=dev, dtype=torch.float32)
+        nb = query("cpg_linear_bwd_weight_workspace", T * B, H, H)
+        ws = workspace(nb, dev)
+        call("cpg_linear_bwd_weight", _p(dy), H, _p(x), H, _p(dw), H, None, T * B, H, H, int(gw is not None), _p(ws), ws.numel(),
+             _stream())
+        dsz = torch.empty(B, H, device=dev, dtype=torch.float32)
+        nb = query("cpg_colsum_workspace_bytes", T, B * H)
+        ws = workspace(nb, dev)
+        call("cpg_colsum_f32", _p(dy), B * H, T, B * H, _p(dsz), 0, _p(ws), ws.numel(), _stream())
+        return dx, (None if gw is not None else dw), dsz, None
+
+
 class ZeroRowGradFn(Function):
     """Identity whose backward zeroes one row: nn.Embedding(padding_idx=PAD) gives <pad> no gradient (models/model.py:47)."""
 

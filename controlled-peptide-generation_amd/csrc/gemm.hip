@@ -431,6 +431,33 @@ CPG_EXPORT int cpg_linear_bwd_weight(const float* dY, int lddy, const float* X, 
     return rc;
 }
 
+// nn.Dropout in front of nn.Linear: the inter-layer dropout of nn.GRU(dropout=p_dropout) (models/encoder.py:25-30: the output of
+// every encoder layer but the last, in train mode) feeding the next layer's W_ih product.  keep: uint8 0/1 with X's indexing.
+CPG_EXPORT int cpg_linear_masked_fwd(const float* X, int ldx, const uint8_t* keep, float scale, const float* W, int ldw,
+                                     const float* bias, float* Y, int ldy, int M, int N, int K, int accumulate, void* stream) {
+    CPG_CHECK_ARG(X && keep && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
+    return cpg_gemm_nt(X, ldx, keep, scale, W, ldw, bias, Y, ldy, M, N, K, accumulate, (hipStream_t)stream);
+}
+
+// dX[M,K] = (dY[M,N] W[N,K]) .* keep*scale   (keep with dX's indexing)
+CPG_EXPORT int cpg_linear_masked_bwd_input(const float* dY, int lddy, const float* W, int ldw, const uint8_t* keep, float scale,
+                                           float* dX, int lddx, int M, int N, int K, void* stream) {
+    CPG_CHECK_ARG(dY && W && keep && dX && M > 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K);
+    return cpg_gemm_nn(dY, lddy, W, ldw, dX, lddx, M, K, N, 0, keep, scale, (hipStream_t)stream);
+}
+
+// dW[N,K] (+)= dY[M,N]^T (X .* keep*scale)[M,K] ; db[N] (+)= column sums of dY (db may be null); workspace as cpg_linear_bwd_weight
+CPG_EXPORT int cpg_linear_masked_bwd_weight(const float* dY, int lddy, const float* X, int ldx, const uint8_t* keep, float scale,
+                                            float* dW, int lddw, float* db, int M, int N, int K, int accumulate, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(dY && X && keep && dW && M > 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K);
+    int rc = cpg_gemm_tn(dY, lddy, X, ldx, keep, scale, dW, lddw, M, N, K, accumulate, (float*)workspace, workspace_bytes,
+                         (hipStream_t)stream);
+    if (rc) return rc;
+    if (db) rc = cpg_colsum(dY, lddy, M, N, db, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    return rc;
+}
+
 CPG_EXPORT size_t cpg_colsum_workspace_bytes(int M, int N) { return cpg_colsum_workspace(M, N) + 256; }
 
 // out[N] (+)= column sums of X[M,N] (bias gradients; fixed two-stage partition)

@@ -59,8 +59,9 @@ class GRUDecoder(nn.Module):
         self.p_out = p_out_dropout
         self.h_dim = h_dim
         self.skip_connetions = skip_connetions
-        if skip_connetions:
-            raise NotImplementedError('skip connections are off by default (cfg.py:281) and not on the MI355X path')
+        if skip_connetions:   # models/decoder.py:48-51: two bias-free [h_dim,h_dim] maps (same construction order = same init stream)
+            self.skip_weight_x = nn.Linear(h_dim, h_dim, bias=False)
+            self.skip_weight_z = nn.Linear(h_dim, h_dim, bias=False)
         self.rng = None
         # Length-sorted ("ragged") teacher forcing: rows are visited longest first and a row leaves the recurrence once all
         # its remaining targets are <pad> (those positions carry no loss and no gradient, losses.py:27).  The logits of
@@ -117,6 +118,10 @@ class GRUDecoder(nn.Module):
         else:
             outs = ops.LstmSeqFn.apply(tok, tab, rowc, None, zc, None, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)[1:]
         hs = outs.reshape(T * B, self.h_dim)
+        if self.skip_connetions:
+            # rnn_out := skip_weight_x(rnn_out) + skip_weight_z([z;c]) (models/decoder.py:80-81); the second term is constant over time
+            sz = ops.LinearFn.apply(zc, self.skip_weight_z.weight, None)
+            hs = ops.SkipAddFn.apply(hs, self.skip_weight_x.weight, sz, T)
         keep, scale = None, 1.0
         if out_keep is not None:
             keep = ops.transpose01_u8(out_keep.to(torch.uint8))          # [B,T,H] -> [T,B,H]
@@ -160,10 +165,37 @@ class GRUDecoder(nn.Module):
             else:
                 tok = sampleHard.to(torch.int32).contiguous()
                 ops.gru_step(tok, tab, rowc, h_prev, h_new, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
-            fc = self.fc[1]
-            keep, scale = None, 1.0
-            if self.training and self.p_out > 0:
-                keep = self._sample_keep((1,) + tuple(h_new.shape), h_new.device)[0]
-                scale = 1.0 / (1.0 - self.p_out)
-            logits = ops.VocabFcFn.apply(h_new, keep, scale, fc.weight, fc.bias)
+            logits = self.project(h_new, self.skip_term(zc))
         return logits, h_new.unsqueeze(0)
+
+    def skip_term(self, zc):
+        """skip_weight_z([z;c]) [N,H] of a decode (constant over its steps), or None without skip connections.  Inference only."""
+        if not self.skip_connetions:
+            return None
+        return ops.linear_raw(zc.contiguous(), self.skip_weight_z.weight, None)
+
+    def step_keep(self, rows, device):
+        """Out-dropout keep mask [rows,H] of ONE decode step when the module is in train mode (the reference's nn.Dropout(p_out) in
+        front of the vocabulary projection is live in forward_sample whenever the model has not been put in eval mode:
+        generate_sentences(eval_mode=False), models/model.py:216-221), else None."""
+        if not (self.training and self.p_out > 0):
+            return None
+        return self._sample_keep((rows, self.h_dim), device)
+
+    def project(self, h, sz=None, keep='sample', logits=None):
+        """The tail of GRUDecoder.forward_sample (models/decoder.py:101-108) for step outputs h [N,H]: skip connections when the
+        model has them (output := skip_weight_x(output) + skip_weight_z([z;c]); sz = skip_term(zc)), out-dropout when in train mode
+        (keep: uint8 [N,H] to inject, None for none, 'sample' = step_keep), vocabulary projection -> logits [N,V].  No tape."""
+        out = h
+        if self.skip_connetions:
+            out = ops.linear_raw(h, self.skip_weight_x.weight, None, out=sz.clone(), accumulate=True)
+        if isinstance(keep, str):
+            keep = self.step_keep(h.shape[0], h.device)
+        scale = 1.0 / (1.0 - self.p_out) if (keep is not None and self.p_out > 0) else 1.0
+        fc = self.fc[1]
+        N, H = out.shape
+        if logits is None:
+            logits = torch.empty(N, fc.weight.shape[0], device=h.device, dtype=torch.float32)
+        ops.call("cpg_vocab_fc_fwd", ops._p(out), ops._p(keep), float(scale), ops._p(fc.weight), ops._p(fc.bias), ops._p(logits), N, H,
+                 logits.shape[1], ops._stream())
+        return logits

@@ -31,8 +31,26 @@ class GRUEncoder(nn.Module):
         self.h_dim, self.layers, self.p_dropout = h_dim, layers, p_dropout
         self.q_mu = nn.Linear(self.biGRU_factor * h_dim, z_dim)
         self.q_logvar = nn.Linear(self.biGRU_factor * h_dim, z_dim)
-        if p_dropout > 0 and layers > 1:
-            raise NotImplementedError('inter-layer GRU dropout is not on the MI355X path (reference default p_dropout=0.0)')
+        self.rng = None   # DeviceRng set by RNN_VAE.use_device_rng: the inter-layer dropout masks then come from the device streams
+
+    def _layer_keep(self, l, T, B, enc_keep, dev):
+        """Keep masks (uint8, time-major [T*B, h_dim] per direction) of the dropout IN FRONT OF layer l >= 1, or None.
+        nn.GRU(dropout=p_dropout) (models/encoder.py:25-30) drops the concatenated output of every layer but the last while the
+        module is in train mode.  enc_keep: injected masks - [B,T,dirs*h_dim] for a 2-layer encoder, [layers-1,B,T,dirs*h_dim]
+        in general (parity tests replay the reference's draw); otherwise drawn here (device stream, or torch's generator)."""
+        if l == 0 or self.p_dropout <= 0 or not (self.training or enc_keep is not None):
+            return None
+        D = self.biGRU_factor * self.h_dim
+        if enc_keep is not None:
+            k = enc_keep if enc_keep.dim() == 3 else enc_keep[l - 1]
+            assert tuple(k.shape) == (B, T, D), (tuple(k.shape), (B, T, D))
+            k = ops.transpose01_u8(k.to(torch.uint8))                         # [B,T,D] -> [T,B,D]
+        elif self.rng is not None:
+            k = self.rng.bernoulli((T, B, D), 1.0 - self.p_dropout, dev)
+        else:
+            k = (torch.rand(T, B, D, device=dev) >= self.p_dropout).to(torch.uint8)
+        k = k.view(T * B, D)
+        return [k[:, d * self.h_dim:(d + 1) * self.h_dim].contiguous() for d in range(self.biGRU_factor)]
 
     def _dirs(self):
         return [("", False), ("_reverse", True)] if self.biGRU else [("", False)]
@@ -40,12 +58,14 @@ class GRUEncoder(nn.Module):
     def _w(self, name, layer, sfx):
         return getattr(self.rnn, f"{name}_l{layer}{sfx}")
 
-    def _run(self, T, tok=None, emb_weight=None, dense_x=None):
+    def _run(self, T, tok=None, emb_weight=None, dense_x=None, enc_keep=None):
         """Either (tok int32 [T,B], emb_weight) - token-table path - or dense_x [T,B,E] embeddings."""
         slabs = finals = None
         dev = self.q_mu.weight.device
         for l in range(self.layers):
             pre = []
+            keeps = self._layer_keep(l, T, (tok.shape[1] if tok is not None else dense_x.shape[1]), enc_keep, dev)
+            scale = 1.0 / (1.0 - self.p_dropout) if keeps is not None else 1.0
             for sfx, rev in self._dirs():
                 w_ih, b_ih = self._w("weight_ih", l, sfx), self._w("bias_ih", l, sfx)
                 tab = dense = None
@@ -57,8 +77,11 @@ class GRUEncoder(nn.Module):
                 else:
                     B = slabs[0].shape[1]
                     xf = slabs[0][1:].reshape(T * B, -1)            # forward direction: h_t at slot t+1
-                    if self.biGRU:
-                        xb = slabs[1][:T].reshape(T * B, -1)        # reverse direction: h_t at slot t
+                    xb = slabs[1][:T].reshape(T * B, -1) if self.biGRU else None   # reverse direction: h_t at slot t
+                    if keeps is not None:                           # inter-layer dropout fused into the projection's operand load
+                        dense = ops.MaskedLinear2Fn.apply(xf, keeps[0], xb, keeps[1] if self.biGRU else None, scale, w_ih,
+                                                          b_ih).view(T, B, -1)
+                    elif self.biGRU:
                         dense = ops.Linear2Fn.apply(xf, xb, w_ih, b_ih).view(T, B, -1)
                     else:
                         dense = ops.LinearFn.apply(xf, w_ih, b_ih).view(T, B, -1)
@@ -92,12 +115,13 @@ class GRUEncoder(nn.Module):
         logvar = ops.LinearFn.apply(h, self.q_logvar.weight, self.q_logvar.bias)
         return mu, logvar
 
-    def forward_tokens(self, ids, emb_weight):
-        """ids int64 [B,T]: fused path, W_ih emb[tok] is a V-row lookup table (never a [B,T,E] GEMM)."""
+    def forward_tokens(self, ids, emb_weight, enc_keep=None):
+        """ids int64 [B,T]: fused path, W_ih emb[tok] is a V-row lookup table (never a [B,T,E] GEMM).
+        enc_keep: inter-layer dropout masks to inject (_layer_keep)."""
         tok = ops.tokens_prepare(ids)
-        return self._run(ids.shape[1], tok=tok, emb_weight=emb_weight)
+        return self._run(ids.shape[1], tok=tok, emb_weight=emb_weight, enc_keep=enc_keep)
 
-    def forward(self, x):
+    def forward(self, x, enc_keep=None):
         """x: embeddings [mbsize, seq_len, emb_dim] (reference signature; used for soft inputs)."""
         T = x.shape[1]
-        return self._run(T, dense_x=x.transpose(0, 1).contiguous())
+        return self._run(T, dense_x=x.transpose(0, 1).contiguous(), enc_keep=enc_keep)

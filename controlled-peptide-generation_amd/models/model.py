@@ -7,7 +7,7 @@ work unchanged, with the same state-dict keys and the same default initialisatio
 kernels of libcpg_hip.so through cpg.ops / cpg.decode; torch modules below are parameter containers.
 
 Differences that are deliberate and documented:
-  * `forward` accepts optional keyword `rnd=dict(eps=, c=, wd_mask=, out_mask=)` to inject the step's random draws
+  * `forward` accepts optional keyword `rnd=dict(eps=, c=, wd_mask=, out_mask=, enc_keep=)` to inject the step's random draws
     (the reference mixes torch and numpy generators, SURVEY F8; parity tests inject its captured draws);
   * `.device` defaults to cuda (as in the reference, model.py:41) and stays an assignable attribute (api.py:96);
   * flows (flow>0) are not on this path and raise; the soft sampling modes run forward only (no autograd tape:
@@ -69,6 +69,7 @@ class RNN_VAE(nn.Module):
         self.rng = DeviceRng(seed)
         self.decoder.rng = self.rng
         self.decoder.word_dropout.rng = self.rng
+        self.encoder.rng = self.rng
         return self
 
     def _randn(self, n, d):
@@ -95,14 +96,15 @@ class RNN_VAE(nn.Module):
     def _emb_weight(self):
         return ops.ZeroRowGradFn.apply(self.word_emb.weight, PAD_IDX)
 
-    def forward_encoder(self, inputs, emb_w=None):
+    def forward_encoder(self, inputs, emb_w=None, enc_keep=None):
         """ids [mbsize, seq_len] -> (mu, logvar);  soft inputs [mbsize, seq_len, n_vocab] go through soft_embed.
         emb_w: the embedding matrix as this step's graph sees it (_emb_weight()), when the caller shares one between the
-        encoder, the decoder and the classifier - one pad-row mask and one accumulation per step instead of one per consumer."""
+        encoder, the decoder and the classifier - one pad-row mask and one accumulation per step instead of one per consumer.
+        enc_keep: inter-layer dropout masks of a multi-layer encoder to inject (GRUEncoder._layer_keep; parity tests)."""
         if inputs.dim() == 2:
-            return self.encoder.forward_tokens(inputs, self._emb_weight() if emb_w is None else emb_w)
+            return self.encoder.forward_tokens(inputs, self._emb_weight() if emb_w is None else emb_w, enc_keep=enc_keep)
         from models.mutils import soft_embed
-        return self.encoder(soft_embed(self.word_emb, inputs))
+        return self.encoder(soft_embed(self.word_emb, inputs), enc_keep=enc_keep)
 
     def sample_z(self, mu, logvar, eps=None):
         if eps is None:
@@ -139,7 +141,7 @@ class RNN_VAE(nn.Module):
         rnd = rnd or {}
         mbsize = sequences.size(0)
         emb_w = self._emb_weight() if sequences.dim() == 2 else None
-        mu, logvar = self.forward_encoder(sequences, emb_w)
+        mu, logvar = self.forward_encoder(sequences, emb_w, enc_keep=rnd.get('enc_keep'))
         assert mu.size(0) == logvar.size(0) == mbsize
         if sample_z == 'max':
             z = mu
@@ -174,8 +176,12 @@ class RNN_VAE(nn.Module):
         return sentences, z, c.argmax(dim=1)
 
     def sample_G(self, mbsize, z, c, sample_mode='categorical', temp=1.0, gumbel_temp=1.0, prepend_start_idx=True,
-                 prevent_empty=False, min_length=1, beam_size=5, n_best=3, uniforms=None):
-        """uniforms (extra, categorical only): f64 [MAX_SEQ_LEN, mbsize] draws to inject (parity tests)."""
+                 prevent_empty=False, min_length=1, beam_size=5, n_best=3, uniforms=None, out_keep=None):
+        """uniforms (extra, categorical only): f64 [MAX_SEQ_LEN, mbsize] draws to inject (parity tests).
+        out_keep (extra): uint8 [steps, rows, h_dim] out-dropout masks of a TRAIN-mode decode to inject (rows = mbsize, or
+        beam_size * mbsize beam-major for 'beam').  Called in train mode - generate_sentences(eval_mode=False),
+        models/model.py:216-221 - the decoder's nn.Dropout(p_out) is live in every step, exactly as in the reference; the
+        masks are drawn per step from the model's streams unless injected."""
         if sample_mode in ('gumbel_soft', 'gumbel_ST'):
             raise NotImplementedError('gumbel_soft / gumbel_ST are placeholders in the reference too (models/model.py:330-336 '
                                       'leaves sampleSoftIx unset and fails)')
@@ -185,15 +191,13 @@ class RNN_VAE(nn.Module):
         assert mbsize == z.size(0) == c.size(0), 'oops sizes dont match {} {} {}'.format(mbsize, z.size(0), c.size(0))
         z, c = z.to(self.device).float(), c.to(self.device).float()
         if sample_mode == 'beam':
-            return cdecode.decode_beam(self.decoder, z, c, self.MAX_SEQ_LEN, beam_size, n_best, min_length)
-        if self.training and self.decoder.p_out > 0:
-            raise NotImplementedError('sampling with out-dropout active (eval_mode=False) is not on the MI355X path')
+            return cdecode.decode_beam(self.decoder, z, c, self.MAX_SEQ_LEN, beam_size, n_best, min_length, out_keep=out_keep)
         if sample_mode in SOFT_MODES:
             assert not prevent_empty, 'cant prevent_empty when soft sampling'
             ids, soft = cdecode.decode_soft(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
-                                            min_length=min_length)
+                                            min_length=min_length, out_keep=out_keep)
             return (ids, soft) if prepend_start_idx else (ids[:, 1:], soft[:, 1:])
         ids = cdecode.decode_hard(self.decoder, z, c, self.MAX_SEQ_LEN, mode=sample_mode, temp=temp,
                                   prevent_empty=prevent_empty, min_length=min_length, uniforms=uniforms,
-                                  prepend_start_idx=prepend_start_idx)
+                                  prepend_start_idx=prepend_start_idx, out_keep=out_keep)
         return ids if prepend_start_idx else ids[:, 1:]

@@ -65,6 +65,17 @@ CPG_API size_t cpg_linear_bwd_weight_workspace(int M, int N, int K);
 CPG_API int cpg_linear_bwd_weight(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
                                   int M, int N, int K, int accumulate, void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* nn.Dropout in front of nn.Linear - the inter-layer dropout of nn.GRU(dropout=p_dropout) at models/encoder.py:25-30 (train
+ * mode, every layer's output but the last) feeding the next layer's W_ih product.  keep: uint8 0/1, indexed like the f32 array
+ * it multiplies (X forward / weight gradient, dX for the input gradient); the mask itself is an input (or a cpg_rng_bernoulli_u8 draw).
+ *   Y[M,N] (+)= (X .* keep*scale)[M,K] W[N,K]^T + bias[N] ;  dX = (dY W) .* keep*scale ;  dW (+)= dY^T (X .* keep*scale) */
+CPG_API int cpg_linear_masked_fwd(const float* X, int ldx, const uint8_t* keep, float scale, const float* W, int ldw,
+                                  const float* bias, float* Y, int ldy, int M, int N, int K, int accumulate, void* stream);
+CPG_API int cpg_linear_masked_bwd_input(const float* dY, int lddy, const float* W, int ldw, const uint8_t* keep, float scale,
+                                        float* dX, int lddx, int M, int N, int K, void* stream);
+CPG_API int cpg_linear_masked_bwd_weight(const float* dY, int lddy, const float* X, int ldx, const uint8_t* keep, float scale,
+                                         float* dW, int lddw, float* db, int M, int N, int K, int accumulate, void* workspace,
+                                         size_t workspace_bytes, void* stream);
 CPG_API size_t cpg_colsum_workspace_bytes(int M, int N);
 /* out[N] (+)= column sums of X[M,N] */
 CPG_API int cpg_colsum_f32(const float* X, int ld, int M, int N, float* out, int accumulate, void* workspace,

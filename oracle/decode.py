@@ -11,12 +11,20 @@ from .gru import gru_cell_fwd, F32
 UNK, PAD, START, EOS = 0, 1, 2, 3
 
 
-def decoder_step(P, tok, zc, h):
-    """logits [N,V], h' [N,H] for current tokens tok [N] (eval mode: no dropout)."""
+def decoder_step(P, tok, zc, h, keep=None, p_out=0.3):
+    """logits [N,V], h' [N,H] for current tokens tok [N] (GRUDecoder.forward_sample, models/decoder.py:86-109).
+    Skip connections when the model has them (:103-105): output := skip_weight_x(output) + skip_weight_z([z;c]).
+    keep (optional 0/1 [N,H]): the out-dropout mask of a step sampled in TRAIN mode (generate_sentences(eval_mode=False),
+    models/model.py:216-221: nn.Dropout(p_out) in front of the vocabulary projection is then live); eval mode: None."""
     x = np.concatenate([P["word_emb.weight"][tok], zc], 1).astype(F32)
     gi = (x @ P["decoder.rnn.weight_ih_l0"].T + P["decoder.rnn.bias_ih_l0"]).astype(F32)
     h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
-    logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
+    out = h
+    if "decoder.skip_weight_x.weight" in P:
+        out = ((h @ P["decoder.skip_weight_x.weight"].T).astype(F32) + (zc @ P["decoder.skip_weight_z.weight"].T).astype(F32)).astype(F32)
+    if keep is not None:
+        out = (out * (keep.astype(F32) * F32(1.0 / (1.0 - p_out)))).astype(F32)
+    logits = (out @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
     return logits, h
 
 
@@ -30,8 +38,9 @@ def lstm_decoder_step(P, tok, zc, h, cst):
     return logits, h, cst
 
 
-def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=False):
-    """ids [N, 1+steps] int64 with column 0 = START; steps <= max_len (stops once every row has emitted EOS)."""
+def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=False, out_keep=None, p_out=0.3):
+    """ids [N, 1+steps] int64 with column 0 = START; steps <= max_len (stops once every row has emitted EOS).
+    out_keep (optional [steps,N,H]): per-step out-dropout masks of a train-mode decode (decoder_step)."""
     N = z.shape[0]
     zc = np.concatenate([z, c], 1).astype(F32)
     h = zc.copy()
@@ -39,7 +48,7 @@ def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=Fa
     finished = np.zeros(N, bool)
     cols, all_logits = [tok], []
     for i in range(max_len):
-        logits, h = decoder_step(P, tok, zc, h)
+        logits, h = decoder_step(P, tok, zc, h, None if out_keep is None else out_keep[i], p_out)
         if prevent_empty and i == 0:
             neg = F32(-2.0) * np.abs(logits.min())
             logits[:, [PAD, START, EOS]] = neg
@@ -98,6 +107,7 @@ class _Beam:
         self.next_ys = [first]
         self.finished = []
         self.eos_top = False
+        self.min_margin = np.inf   # smallest gap between neighbours of the ranked candidates, down to the first one NOT taken
 
     def done(self):
         return self.eos_top and len(self.finished) >= self.n_best
@@ -114,7 +124,13 @@ class _Beam:
         else:
             cand = logp[0:1]  # first step: only beam 0 is live
         flat = cand.reshape(-1)
-        order = np.argsort(-flat, kind="stable")[: self.size]
+        order = np.argsort(-flat, kind="stable")[: self.size + 1]
+        top = flat[order].astype(np.float64)
+        live = top > -1e19                   # masked candidates (-1e20) tie with each other by construction: not a numeric tie
+        gaps = [top[i] - top[i + 1] for i in range(len(top) - 1) if live[i]]
+        if gaps:
+            self.min_margin = min(self.min_margin, float(min(gaps)))
+        order = order[: self.size]
         self.scores = flat[order].astype(F32)
         prev = order // V
         self.prev_ks.append(prev)
@@ -143,7 +159,8 @@ class _Beam:
         return hyps, scores
 
 
-def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=False, cell="gru"):
+def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=False, cell="gru", return_margins=False,
+         out_keep=None, p_out=0.3):
     """Returns (hyps, scores): hyps[i][j] = token list incl. leading START.  cell='lstm': the LSTM extension's decoder
     (h0 = [z;c], c0 = 0), the cell state reordered by the same back-pointers.
     return_history adds (tok, prev, score) arrays [steps,N,K] (tok=-1 where a sentence was not advanced): the record the
@@ -156,11 +173,11 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
     beams = [_Beam(beam_size, n_best, min_length) for _ in range(N)]
     tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
     hist = []
-    for _ in range(max_len):
+    for step in range(max_len):
         if cell == "lstm":
             logits, h, cst = lstm_decoder_step(P, tok, zc, h, cst)
-        else:
-            logits, h = decoder_step(P, tok, zc, h)
+        else:   # out_keep [steps, beam*N, H]: train-mode decode, rows beam-major like the states
+            logits, h = decoder_step(P, tok, zc, h, None if out_keep is None else out_keep[step], p_out)
         lg = logits.reshape(beam_size, N, -1)
         hv = h.reshape(beam_size, N, -1)
         cv = cst.reshape(beam_size, N, -1)
@@ -178,6 +195,10 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
         if all(b.done() for b in beams):
             break
     out = [b.best() for b in beams]
+    if return_margins:
+        # per sentence: the smallest score gap any of its top-k selections rested on (a gap below float32 resolution of the
+        # scores means either order is a correct evaluation: tests allow a differing hypothesis set only there)
+        return [o[0] for o in out], [o[1] for o in out], np.array([b.min_margin for b in beams])
     if return_history:
         return [o[0] for o in out], [o[1] for o in out], tuple(np.stack([h[i] for h in hist]) for i in range(3))
     return [o[0] for o in out], [o[1] for o in out]

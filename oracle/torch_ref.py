@@ -26,23 +26,33 @@ UNK, PAD, START, EOS = 0, 1, 2, 3  # models/mutils.py:5-8
 class RefWAE(nn.Module):
     """Same parameter names / shapes as the reference's RNN_VAE (classifier omitted: not part of the training step)."""
 
-    def __init__(self, n_vocab, emb_dim, enc_h, enc_layers, z_dim, c_dim=2, p_out=0.3):
+    def __init__(self, n_vocab, emb_dim, enc_h, enc_layers, z_dim, c_dim=2, p_out=0.3, cell="gru", skip=False):
+        """cell='lstm': the build's LSTM EXTENSION (BASELINE.json configs[1] names an LSTM; the reference has none):
+        nn.LSTM in place of nn.GRU, encoder read for its final HIDDEN states, decoder h0 = [z;c], c0 = 0.  Parity of that mode is
+        pinned to torch.nn.LSTM only - "parity unpinned" against the reference."""
         super().__init__()
+        self.cell = cell
+        rnn = {"gru": nn.GRU, "lstm": nn.LSTM}[cell]
         self.word_emb = nn.Embedding(n_vocab, emb_dim, PAD)
-        self.enc_rnn = nn.GRU(emb_dim, enc_h, num_layers=enc_layers, bidirectional=True, batch_first=True)
+        self.enc_rnn = rnn(emb_dim, enc_h, num_layers=enc_layers, bidirectional=True, batch_first=True)
         self.q_mu = nn.Linear(2 * enc_h, z_dim)
         self.q_logvar = nn.Linear(2 * enc_h, z_dim)
         hd = z_dim + c_dim
-        self.dec_rnn = nn.GRU(emb_dim + hd, hd, batch_first=True)
+        self.dec_rnn = rnn(emb_dim + hd, hd, batch_first=True)
         self.fc = nn.Linear(hd, n_vocab)
+        self.skip = skip
+        if skip:   # models/decoder.py:48-51
+            self.skip_weight_x = nn.Linear(hd, hd, bias=False)
+            self.skip_weight_z = nn.Linear(hd, hd, bias=False)
         self.p_out = p_out
         self.z_dim = z_dim
 
     _MAP = (("encoder.rnn.", "enc_rnn."), ("encoder.q_mu.", "q_mu."), ("encoder.q_logvar.", "q_logvar."),
-            ("decoder.rnn.", "dec_rnn."), ("decoder.fc.1.", "fc."))
+            ("decoder.rnn.", "dec_rnn."), ("decoder.fc.1.", "fc."), ("decoder.skip_weight_x.", "skip_weight_x."),
+            ("decoder.skip_weight_z.", "skip_weight_z."))
 
     @classmethod
-    def from_state(cls, P, p_out=0.3):
+    def from_state(cls, P, p_out=0.3, cell="gru"):
         """P: dict of numpy arrays / tensors keyed by the reference's state-dict names."""
         V, E = P["word_emb.weight"].shape
         He = P["encoder.rnn.weight_hh_l0"].shape[1]
@@ -50,7 +60,7 @@ class RefWAE(nn.Module):
         while f"encoder.rnn.weight_ih_l{L}" in P:
             L += 1
         Z = P["encoder.q_mu.weight"].shape[0]
-        m = cls(V, E, He, L, Z, P["decoder.rnn.weight_hh_l0"].shape[1] - Z, p_out)
+        m = cls(V, E, He, L, Z, P["decoder.rnn.weight_hh_l0"].shape[1] - Z, p_out, cell, "decoder.skip_weight_x.weight" in P)
         sd = {}
         for k, v in P.items():
             if k.startswith("classifier") or k == "decoder.emb.weight":
@@ -73,6 +83,8 @@ class RefWAE(nn.Module):
         """Order and multiplicity of RNN_VAE.vae_params() (models/model.py:88-94): the shared embedding comes twice."""
         enc = list(self.enc_rnn.parameters()) + list(self.q_mu.parameters()) + list(self.q_logvar.parameters())
         dec = [self.word_emb.weight] + list(self.dec_rnn.parameters()) + list(self.fc.parameters())
+        if self.skip:   # decoder.parameters() order: emb, rnn, fc, skip_weight_x, skip_weight_z
+            dec += [self.skip_weight_x.weight, self.skip_weight_z.weight]
         return [self.word_emb.weight] + enc + dec
 
     def forward(self, ids, rnd=None):
@@ -81,6 +93,8 @@ class RefWAE(nn.Module):
         rnd = rnd or {}
         B, T = ids.shape
         _, h = self.enc_rnn(self.word_emb(ids))                       # encoder.py:41-42
+        if self.cell == "lstm":
+            h = h[0]                                                  # (h_n, c_n): the hidden states take nn.GRU's place
         h = torch.cat((h[-2], h[-1]), dim=1)                          # encoder.py:46-47
         mu, logvar = self.q_mu(h), self.q_logvar(h)
         eps = rnd["eps"] if "eps" in rnd else torch.randn(B, self.z_dim)
@@ -91,7 +105,10 @@ class RefWAE(nn.Module):
         tok[wd.bool()] = UNK                                          # decoder.py:117-133 (no exemptions, also in eval)
         zc = torch.cat([z, c], 1)
         x = torch.cat([self.word_emb(tok), zc.unsqueeze(1).expand(-1, T, -1)], 2)   # decoder.py:67-74
-        out, _ = self.dec_rnn(x, zc.unsqueeze(0).contiguous())        # decoder.py:77 (h0 = [z;c])
+        h0 = zc.unsqueeze(0).contiguous()                             # decoder.py:77 (h0 = [z;c])
+        out, _ = self.dec_rnn(x, h0 if self.cell == "gru" else (h0, torch.zeros_like(h0)))
+        if self.skip:                                                 # decoder.py:80-81
+            out = self.skip_weight_x(out) + self.skip_weight_z(zc.unsqueeze(1).expand(-1, T, -1))
         if "out_mask" in rnd:
             out = out * rnd["out_mask"].float() / (1.0 - self.p_out)
         else:

@@ -26,12 +26,16 @@ def _enc_layers(P):
     return n
 
 
-def encoder_fwd(P, ids):
-    """ids [B,T] int -> mu, logvar [B,Z]; cache for backward.  Steps through ALL T positions incl. pads (F4)."""
+def encoder_fwd(P, ids, enc_keep=None, p_drop=0.0):
+    """ids [B,T] int -> mu, logvar [B,Z]; cache for backward.  Steps through ALL T positions incl. pads (F4).
+    enc_keep (optional, 0/1 [B,T,2*He]) with p_drop: nn.GRU(dropout=p_dropout) in train mode (models/encoder.py:25-30) - the
+    concatenated output of every layer but the last is multiplied by keep / (1 - p) before it feeds the next layer."""
     x = P["word_emb.weight"][ids]  # [B,T,E]
     B, T, _ = x.shape
     L = _enc_layers(P)
-    cache = {"ids": ids, "layers": []}
+    cache = {"ids": ids, "layers": [], "drop": None}
+    if enc_keep is not None and p_drop > 0 and L > 1:
+        cache["drop"] = (enc_keep.astype(F32) * F32(1.0 / (1.0 - p_drop))).astype(F32)
     for l in range(L):
         outs, lc = [], {"x": x}
         for sfx, rev in (("", False), ("_reverse", True)):
@@ -44,6 +48,8 @@ def encoder_fwd(P, ids):
             lc[sfx] = cs
         cache["layers"].append(lc)
         x = np.concatenate([outs[0][0], outs[1][0]], 2)
+        if cache["drop"] is not None and l < L - 1:
+            x = (x * cache["drop"]).astype(F32)
     h = np.concatenate([outs[0][1], outs[1][1]], 1)  # top layer fwd/bwd final states (encoder.py:46-47)
     mu = (h @ P["encoder.q_mu.weight"].T + P["encoder.q_mu.bias"]).astype(F32)
     logvar = (h @ P["encoder.q_logvar.weight"].T + P["encoder.q_logvar.bias"]).astype(F32)
@@ -79,6 +85,8 @@ def encoder_bwd(P, dmu, dlogvar, cache, G):
             G[f"encoder.rnn.bias_ih_l{l}{sfx}"] = flat.sum(0).astype(F32)
             dx += (flat @ w_ih).reshape(x.shape)
         dout = dx
+        if cache.get("drop") is not None and l > 0:
+            dout = (dout * cache["drop"]).astype(F32)   # through the dropout in front of layer l
     # embedding gradient (padding_idx row gets none: nn.Embedding(..., PAD_IDX), models/model.py:47)
     demb = np.zeros_like(P["word_emb.weight"])
     np.add.at(demb, ids.reshape(-1), dout.reshape(B * T, -1))
@@ -106,10 +114,16 @@ def decoder_fwd(P, ids, z, c, wd_mask, out_keep, p_out):
     H = w_hh.shape[1]
     gi = (x.reshape(B * T, -1) @ w_ih.T + b_ih).reshape(B, T, 3 * H).astype(F32)
     hs, _, cs = gru_seq_fwd(gi, zc, w_hh, b_hh)
+    rnn_out = hs
+    if "decoder.skip_weight_x.weight" in P:
+        # skip connections (models/decoder.py:48-51,80-81): rnn_out := skip_weight_x(rnn_out) + skip_weight_z([z;c]), bias-free
+        sx = (hs.reshape(B * T, H) @ P["decoder.skip_weight_x.weight"].T).reshape(B, T, H).astype(F32)
+        sz = (zc @ P["decoder.skip_weight_z.weight"].T).astype(F32)
+        rnn_out = (sx + sz[:, None, :]).astype(F32)
     scale = F32(1.0 / (1.0 - p_out)) if p_out > 0 else F32(1.0)
-    hd = (hs * (out_keep.astype(F32) * scale)).astype(F32)
+    hd = (rnn_out * (out_keep.astype(F32) * scale)).astype(F32)
     logits = (hd.reshape(B * T, H) @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).reshape(B, T, -1)
-    cache = dict(tok=tok, x=x, cs=cs, hd=hd, keep=out_keep.astype(F32) * scale, zc=zc)
+    cache = dict(tok=tok, x=x, cs=cs, hd=hd, keep=out_keep.astype(F32) * scale, zc=zc, hs=hs)
     return logits.astype(F32), cache
 
 
@@ -121,6 +135,14 @@ def decoder_bwd(P, dlogits, cache, G, E):
     G["decoder.fc.1.weight"] = (dl.T @ hd.reshape(B * T, H)).astype(F32)
     G["decoder.fc.1.bias"] = dl.sum(0).astype(F32)
     dhs = ((dl @ P["decoder.fc.1.weight"]).reshape(B, T, H) * cache["keep"]).astype(F32)
+    dzc_skip = 0.0
+    if "decoder.skip_weight_x.weight" in P:
+        d2 = dhs.reshape(B * T, H)
+        G["decoder.skip_weight_x.weight"] = (d2.T @ cache["hs"].reshape(B * T, H)).astype(F32)
+        dsz = dhs.sum(1).astype(F32)
+        G["decoder.skip_weight_z.weight"] = (dsz.T @ cache["zc"]).astype(F32)
+        dzc_skip = (dsz @ P["decoder.skip_weight_z.weight"]).astype(F32)
+        dhs = (d2 @ P["decoder.skip_weight_x.weight"]).reshape(B, T, H).astype(F32)
     w_ih, w_hh = P["decoder.rnn.weight_ih_l0"], P["decoder.rnn.weight_hh_l0"]
     dgi, dh0, dW_hh, db_hh = gru_seq_bwd(dhs, None, cache["cs"], w_hh)
     G["decoder.rnn.weight_hh_l0"], G["decoder.rnn.bias_hh_l0"] = dW_hh, db_hh
@@ -128,7 +150,7 @@ def decoder_bwd(P, dlogits, cache, G, E):
     G["decoder.rnn.weight_ih_l0"] = (flat.T @ x.reshape(B * T, -1)).astype(F32)
     G["decoder.rnn.bias_ih_l0"] = flat.sum(0).astype(F32)
     dx = (flat @ w_ih).reshape(B, T, -1)
-    dzc = (dx[:, :, E:].sum(1) + dh0).astype(F32)
+    dzc = (dx[:, :, E:].sum(1) + dh0 + dzc_skip).astype(F32)
     demb = np.zeros_like(P["word_emb.weight"])
     np.add.at(demb, cache["tok"].reshape(-1), dx[:, :, :E].reshape(B * T, E))
     demb[PAD] = 0
@@ -254,7 +276,7 @@ def train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, z_regu, sigma=7.0, p
     rnd: dict with eps, c, wd_mask, out_mask, z_prior_full, z_prior_rf, rf_w, rf_b.
     Returns (terms dict, grads dict keyed like the state dict, aux dict with z/logits/mu/logvar)."""
     E = P["word_emb.weight"].shape[1]
-    mu, lv, ec = encoder_fwd(P, ids)
+    mu, lv, ec = encoder_fwd(P, ids, rnd.get("enc_keep"), float(rnd.get("enc_p", 0.0)))
     std = np.exp(lv / 2).astype(F32)
     z = (mu + std * rnd["eps"]).astype(F32)
     c = rnd["c"].astype(F32)

@@ -86,13 +86,13 @@ def synth_ids(B, T, V, gen):
     return ids
 
 
-def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, p_word=0.3, p_out=0.3):
+def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, p_word=0.3, p_out=0.3, skip=False, enc_dropout=0.0):
     return dict(
         z_dim=z_dim, c_dim=2, emb_dim=emb_dim, pretrained_emb=None, freeze_embeddings=False,
         flow=0, flow_type='',
-        E_args=dict(h_dim=enc_h, biGRU=True, layers=enc_layers, p_dropout=0.0),
+        E_args=dict(h_dim=enc_h, biGRU=True, layers=enc_layers, p_dropout=enc_dropout),
         G_args=dict(G_class='gru',
-                    GRU_args=dict(p_word_dropout=p_word, p_out_dropout=p_out, skip_connetions=False),
+                    GRU_args=dict(p_word_dropout=p_word, p_out_dropout=p_out, skip_connetions=skip),
                     deconv_args=dict(max_seq_len=T, num_filters=100, kernel_size=4, num_deconv_layers=3,
                                      useRNN=False, temperature=1.0, use_batch_norm=True,
                                      num_conv_layers=2, add_final_conv_layer=True)),
@@ -644,3 +644,106 @@ def mmd_kernel_vectors(seed=1238, N=48, D=100, sigma=7.0):
 
 if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "mmd_kernels":
     mmd_kernel_vectors()
+
+
+# ------------------------------------------------------------------ option branches inside hot-path functions (round 4)
+def encoder_dropout_vectors(name="encdrop", seed=313, B=6, p=0.25, **kw):
+    """GRUEncoder with layers > 1 and p_dropout > 0 (models/encoder.py:25-30: nn.GRU(dropout=p_dropout) drops the output of every
+    layer but the last, in train mode).  The mask is drawn INSIDE ATen (at::dropout on the time-major [T,B,2*He] layer output, one
+    bernoulli_(1-p) fill from torch's CPU generator) - it is recovered here by replaying that draw from the same seed, and the
+    replay is VERIFIED: the reference's (mu, logvar) must equal those of the same weights run layer by layer with the replayed
+    mask applied.  Stored: weights, ids, the keep mask [B,T,2*He], (mu, logvar) in train mode, the reference's gradients of
+    sum(mu * gmu + logvar * glv) wrt every encoder parameter and the embedding; and the eval-mode (mu, logvar) (no dropout)."""
+    model = build(seed, **kw)
+    enc = model.encoder
+    assert enc.rnn.num_layers == 2 and enc.rnn.dropout == p
+    gen = torch.Generator().manual_seed(seed)
+    ids = synth_ids(B, T, V, gen)
+    He = enc.rnn.hidden_size
+    out = {k: v for k, v in np_state(model).items() if not k.startswith("w.classifier")}
+    model.train()
+    model.zero_grad()
+    torch.manual_seed(seed + 3)
+    mu, logvar = model.forward_encoder(ids)                      # first torch-generator draw of the call = the dropout noise
+    torch.manual_seed(seed + 3)
+    keep_tm = torch.empty(T, B, 2 * He).bernoulli_(1 - p)        # the replay (time-major, as ATen sees the layer output)
+    # verify the replay: same weights, layer by layer
+    sd = enc.rnn.state_dict()
+    l0 = torch.nn.GRU(model.emb_dim, He, bidirectional=True, batch_first=True)
+    l1 = torch.nn.GRU(2 * He, He, bidirectional=True, batch_first=True)
+    l0.load_state_dict({k: v for k, v in sd.items() if k.endswith("_l0") or k.endswith("_l0_reverse")})
+    l1.load_state_dict({k.replace("_l1", "_l0"): v for k, v in sd.items() if "_l1" in k})
+    with torch.no_grad():
+        o0, _ = l0(model.word_emb(ids))
+        _, h1 = l1(o0 * keep_tm.transpose(0, 1) / (1 - p))
+        hcat = torch.cat((h1[-2], h1[-1]), 1)
+        assert float((enc.q_mu(hcat) - mu).abs().max()) < 1e-6, "dropout-mask replay does not reproduce the reference's encoder"
+    g2 = torch.Generator().manual_seed(seed + 5)
+    gmu, glv = torch.randn(mu.shape, generator=g2), torch.randn(mu.shape, generator=g2)
+    ((mu * gmu).sum() + (logvar * glv).sum()).backward()
+    out.update(ids=ids.numpy(), enc_keep=keep_tm.transpose(0, 1).contiguous().to(torch.uint8).numpy(), p=np.float32(p),
+               mu_train=mu.detach().numpy(), logvar_train=logvar.detach().numpy(), gmu=gmu.numpy(), glv=glv.numpy())
+    for k, prm in model.named_parameters():
+        if (k.startswith("encoder") or k == "word_emb.weight") and prm.grad is not None:
+            out["g." + k] = prm.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        mu_e, lv_e = model.forward_encoder(ids)
+    out.update(mu_eval=mu_e.numpy(), logvar_eval=lv_e.numpy())
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz written; kept fraction {float(keep_tm.mean()):.3f}")
+
+
+def sample_train_mode_vectors(name="sample_train", seed=515, N=48, N_beam=12, **kw):
+    """RNN_VAE.generate_sentences(..., eval_mode=False) (models/model.py:216-221): the model STAYS in train mode, so the decoder's
+    nn.Dropout(p_out) (models/decoder.py:43-45) is live in every forward_sample step of sample_G (:86-109) - greedy and beam.  The
+    keep masks are captured with a forward hook, step by step."""
+    model = build(seed, **kw)
+    with torch.no_grad():
+        model.decoder.fc[1].weight.mul_(5.0)   # spread the logits: rows end at varied steps, dropout flips some argmaxes
+        model.decoder.fc[1].bias[3] += 1.0
+    gen = torch.Generator().manual_seed(seed + 5)
+    z = torch.randn(N, model.z_dim, generator=gen)
+    c = torch.zeros(N, 2)
+    c[torch.arange(N), torch.randint(0, 2, (N,), generator=gen)] = 1
+    out = {k: v for k, v in np_state(model).items() if not k.startswith("w.classifier")}
+    out.update(z=z.numpy(), c=c.numpy())
+    model.train()
+    hook = DropHook(model.decoder.fc[0])
+    torch.manual_seed(seed + 7)
+    with torch.no_grad():
+        ids, _, _ = model.generate_sentences(N, z, c, eval_mode=False, sample_mode='greedy')
+    assert model.training
+    out["greedy_ids"] = ids.numpy()
+    out["greedy_keep"] = torch.stack(hook.masks).numpy()                 # [steps, N, H]
+    assert out["greedy_keep"].mean() < 0.9, "dropout was not live"
+    with torch.no_grad():
+        model.eval()
+        ids_eval, _, _ = model.generate_sentences(N, z, c, eval_mode=True, sample_mode='greedy')
+        model.train()
+    out["greedy_ids_eval_mode"] = ids_eval.numpy()
+    hook.masks.clear()
+    torch.manual_seed(seed + 9)
+    with torch.no_grad():
+        hyps = model.sample_G(N_beam, z[:N_beam], c[:N_beam], sample_mode='beam', beam_size=5, n_best=3)
+    hook.remove()
+    out["beam_keep"] = torch.stack(hook.masks).numpy()                   # [steps, 5*N_beam, H], rows beam-major
+    arr = np.full((N_beam, 3, T + 2), -1, dtype=np.int64)
+    for i, hs in enumerate(hyps):
+        for j, hyp in enumerate(hs):
+            t_ = [int(t) for t in hyp]
+            arr[i, j, :len(t_)] = t_
+    out["beam_hyps"] = arr
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}.npz written: greedy {ids.shape}, rows differing from eval mode "
+          f"{int((ids.numpy()[:, :min(ids.shape[1], ids_eval.shape[1])] != ids_eval.numpy()[:, :min(ids.shape[1], ids_eval.shape[1])]).any(1).sum())}"
+          f"/{N}; beam steps {out['beam_keep'].shape[0]}")
+
+
+if __name__ == "__main__" and os.environ.get("CPG_GOLDEN_ONLY") == "options":
+    torch.set_num_threads(4)
+    # decoder skip connections (models/decoder.py:48-51,80-81,103-105): every vector of model_vectors for a model built with them
+    model_vectors("skip", 211, B=6, N_greedy=48, N_beam=12, z_regu_variants=["mmdrf"],
+                  **model_kwargs(z_dim=30, enc_h=24, emb_dim=20, skip=True))
+    encoder_dropout_vectors("encdrop", 313, **model_kwargs(z_dim=22, enc_h=24, enc_layers=2, emb_dim=20, enc_dropout=0.25))
+    sample_train_mode_vectors("sample_train", 515, **model_kwargs(z_dim=30, enc_h=24, emb_dim=20))

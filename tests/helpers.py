@@ -5,7 +5,7 @@ import torch
 from conftest import weights_of
 
 
-def model_kwargs_from_weights(P):
+def model_kwargs_from_weights(P, enc_dropout=0.0):
     V, E = P["word_emb.weight"].shape
     He = P["encoder.rnn.weight_hh_l0"].shape[1]
     Z = P["encoder.q_mu.weight"].shape[0]
@@ -14,15 +14,15 @@ def model_kwargs_from_weights(P):
         layers += 1
     return V, dict(
         z_dim=Z, c_dim=2, emb_dim=E, pretrained_emb=None, freeze_embeddings=False, flow=0, flow_type='',
-        E_args=dict(h_dim=He, biGRU=True, layers=layers, p_dropout=0.0),
-        G_args=dict(G_class='gru', GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False),
+        E_args=dict(h_dim=He, biGRU=True, layers=layers, p_dropout=enc_dropout),
+        G_args=dict(G_class='gru', GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions="decoder.skip_weight_x.weight" in P),
                     deconv_args=dict()),
         C_args=dict(min_filter_width=3, max_filter_width=5, num_filters=100, dropout=0.5))
 
 
-def build_model(P, device="cuda", T=25):
+def build_model(P, device="cuda", T=25, enc_dropout=0.0):
     from models.model import RNN_VAE
-    V, kw = model_kwargs_from_weights(P)
+    V, kw = model_kwargs_from_weights(P, enc_dropout)
     m = RNN_VAE(n_vocab=V, max_seq_len=T, **kw)
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in P.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)

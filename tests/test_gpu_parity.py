@@ -9,7 +9,8 @@ from helpers import (build_model, cu, rnd_cuda, check_encoder_golden, check_deco
                      check_losses_and_grads_golden, check_train_trajectory_golden)
 
 pytestmark = pytest.mark.gpu
-MODELS = ["A", "micro", "enc2", "A_200"]   # A_200: config A after 200 reference train_vae iterations
+# A_200: config A after 200 reference train_vae iterations; skip: a model built with decoder skip connections
+MODELS = ["A", "micro", "enc2", "A_200", "skip"]
 
 
 @pytest.fixture(autouse=True)
@@ -323,3 +324,68 @@ def test_fused_step_scalars_match_the_separate_forms():
     logits = torch.randn(16, 9, 24, device="cuda", generator=g)
     out = ops.ReconCEFn.apply(logits, ids)
     assert torch.equal(losses.recon_dec(ids, logits), out[0] / out[1].clamp(min=1.0))
+
+
+def test_encoder_interlayer_dropout_golden(golden):
+    """GRUEncoder with layers = 2, p_dropout = 0.25 in train mode (models/encoder.py:25-30) against the reference with ITS mask
+    injected: (mu, logvar) 1e-5, every encoder gradient and the embedding's 2e-6 + 1e-4 max|g|; eval mode runs without the mask;
+    a self-drawn mask (device stream) keeps the expected fraction."""
+    g = golden("encdrop")
+    m = build_model(weights_of(g), enc_dropout=float(g["p"]))
+    assert m.training
+    ids = cu(g["ids"])
+    mu, lv = m.forward_encoder(ids, enc_keep=cu(g["enc_keep"]))
+    np.testing.assert_allclose(mu.detach().cpu().numpy(), g["mu_train"], atol=1e-5)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), g["logvar_train"], atol=1e-5)
+    ((mu * cu(g["gmu"])).sum() + (lv * cu(g["glv"])).sum()).backward()
+    n = 0
+    for k, prm in m.named_parameters():
+        if k.startswith("encoder") or k == "word_emb.weight":
+            ref = g["g." + k]
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, atol=2e-6 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+            n += 1
+    assert n == 21
+    m.eval()
+    with torch.no_grad():
+        mu_e, _ = m.forward_encoder(ids)
+    np.testing.assert_allclose(mu_e.cpu().numpy(), g["mu_eval"], atol=1e-5)
+    m.train()
+    m.use_device_rng(5)
+    with torch.no_grad():
+        a, _ = m.forward_encoder(ids)
+        b, _ = m.forward_encoder(ids)
+    assert not torch.equal(a, b) and float((a - mu_e).abs().max()) > 1e-3     # fresh masks per call, and they act
+
+
+def test_sampling_in_train_mode_golden(golden):
+    """generate_sentences(..., eval_mode=False) (models/model.py:216-221): the decoder's out-dropout stays live in every
+    forward_sample step.  Greedy ids bit-exact and beam-5 / n-best-3 hypotheses exact against the reference with its captured
+    per-step masks injected; with self-drawn masks the decode differs from the eval-mode one and the model is left in train mode."""
+    g = golden("sample_train")
+    m = build_model(weights_of(g))
+    z, c = cu(g["z"]), cu(g["c"])
+    N = z.shape[0]
+    ids, _, _ = m.generate_sentences(N, z, c, eval_mode=False, sample_mode='greedy', out_keep=cu(g["greedy_keep"]))
+    assert m.training and np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+    ids_eval, _, _ = m.generate_sentences(N, z, c, sample_mode='greedy')
+    assert np.array_equal(ids_eval.cpu().numpy(), g["greedy_ids_eval_mode"])
+    n = g["beam_hyps"].shape[0]
+    hyps, _, _ = m.generate_sentences(n, z[:n], c[:n], eval_mode=False, sample_mode='beam', beam_size=5, n_best=3,
+                                      out_keep=cu(g["beam_keep"]))
+    for i in range(n):
+        for j in range(3):
+            assert hyps[i][j] == [int(t) for t in g["beam_hyps"][i, j] if t >= 0], (i, j)
+    m.use_device_rng(9)
+    own, _, _ = m.generate_sentences(N, z, c, eval_mode=False, sample_mode='greedy')
+    w = min(own.shape[1], ids_eval.shape[1])
+    assert (own[:, :w] != ids_eval[:, :w]).any()
+    # forward_sample itself (reference signature) in train mode draws a mask as well
+    h = m.decoder.init_hidden(z, c).unsqueeze(0)
+    tok = torch.full((N,), 2, device=z.device, dtype=torch.long)
+    l1, _ = m.decoder.forward_sample(None, tok, z, c, h)
+    l2, _ = m.decoder.forward_sample(None, tok, z, c, h)
+    assert not torch.equal(l1, l2)
+    m.eval()
+    l3, _ = m.decoder.forward_sample(None, tok, z, c, h)
+    l4, _ = m.decoder.forward_sample(None, tok, z, c, h)
+    assert torch.equal(l3, l4)

@@ -269,6 +269,61 @@ def test_config_c_step_vs_oracle():
     _check_greedy_vs_oracle(m, P, 128, 50, seed=18, tag="config C")
 
 
+def test_config_c_bench_batch_vs_oracle():
+    """Config C at the batch bench.py times it on (`extra.config_c`: B = 1024): above 512 rows the persistent forward runs as
+    consecutive row-range launches and the backward / dW launches pick their large-batch tiles - the same oracle comparison as at
+    B = 256 (round-3 verdict: the bench batch was only self-compared)."""
+    m, P, ids, rnd = _random_case(1024, 50, 24, 1022, 1024, 2, seed=19)
+    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
+
+
+BEAM_REPORT = []
+
+
+def _check_beam_vs_oracle(m, P, N, T, seed, eos_bias, tag, K=5, n_best=3):
+    """RNN_VAE.sample_G beam mode (models/model.py:258-276,314-328,364-376; models/Beam.py:56-132) against oracle.decode.beam:
+    hypotheses EXACT.  A sentence may differ only if one of the oracle's own top-k selections for it rested on a score gap below
+    2e-5 (float32 resolution of summed log-probabilities of O(10..50)): counted, reported, and bounded."""
+    from oracle import decode
+    from models.mutils import EOS_IDX
+    with torch.no_grad():     # a default-initialised decoder almost never emits <eos>: bias it so that beams finish at every length
+        m.decoder.fc[1].bias[EOS_IDX] += eos_bias
+    P = dict(P)
+    P["decoder.fc.1.bias"] = P["decoder.fc.1.bias"].copy()
+    P["decoder.fc.1.bias"][EOS_IDX] += np.float32(eos_bias)
+    rs = np.random.RandomState(seed)
+    z = rs.randn(N, m.z_dim).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+    ref, ref_scores, margins = decode.beam(P, z, c, T, beam_size=K, n_best=n_best, return_margins=True)
+    got, _, _ = m.generate_sentences(N, cu(z), cu(c), sample_mode='beam', beam_size=K, n_best=n_best)
+    lens = [len(h) for s in ref for h in s]
+    bad = [i for i in range(N) if [list(map(int, h)) for h in got[i]] != ref[i]]
+    for i in bad:
+        assert margins[i] < 2e-5, (tag, i, margins[i], got[i], ref[i])
+    BEAM_REPORT.append(dict(test=tag, sentences=N, beam=K, n_best=n_best, T=T, hyp_len_min=int(min(lens)), hyp_len_max=int(max(lens)),
+                            sentences_differing_at_a_float32_tie=len(bad), smallest_margin=float(margins.min())))
+    _write_report("beam_tie_report.json", BEAM_REPORT)
+    assert min(lens) < max(lens), "the biased decoder should end hypotheses at different lengths"
+    assert len(bad) <= max(1, N // 32), bad
+
+
+def test_beam_per_step_chain_vs_oracle_config_b_width():
+    """Beam-5 / n-best-3 at config-B width (decoder h = 512): no whole-loop kernel covers it, so sample_G runs the per-step chain
+    cpg_gru_step_fwd -> cpg_vocab_fc_fwd -> cpg_beam_select (+ cpg_beam_hypotheses), whose step kernel picks the split-bf16
+    tiles - compared with the oracle here, not only with the fused kernel at h = 102 (round-3 verdict, weak #1a)."""
+    from cpg import decode as cdecode
+    m, P, ids, rnd = _random_case(8, 25, 24, 510, 512, 1, seed=71)
+    assert not cdecode.fused_beam_fits(512, 24, 24, 5) or os.environ.get("CPG_EXPECT_FUSED_WIDE")
+    _check_beam_vs_oracle(m, P, 64, 25, seed=72, eos_bias=1.5, tag="beam-5, config B width")
+
+
+def test_beam_per_step_chain_vs_oracle_config_c_width():
+    """The same at config-C width (decoder h = 1024, T = 50)."""
+    m, P, ids, rnd = _random_case(8, 50, 24, 1022, 1024, 1, seed=73)
+    _check_beam_vs_oracle(m, P, 64, 50, seed=74, eos_bias=1.0, tag="beam-5, config C width")
+
+
 def test_other_seq_len_vs_oracle():
     """T != 25 at reference-default widths (He=80, Z=100): T=50 and T=7, B=192 (partial row tiles)."""
     for T, seed in ((50, 21), (7, 22)):

@@ -272,3 +272,68 @@ def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reve
     for a, b in zip(*out):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,He,Z,T,layers", [(64, 32, 30, 9, 1), (2048, 512, 510, 25, 1), (256, 128, 126, 12, 2)])
+def test_lstm_model_step_vs_torch_ref(B, He, Z, T, layers):
+    """A whole WAE training step of the LSTM extension (BASELINE.json configs[1] names an LSTM: encoder biLSTM, LSTM decoder with
+    h0 = [z;c], c0 = 0) against oracle/torch_ref.RefWAE(cell='lstm') - torch.nn.LSTM + autograd on the CPU - with every random draw
+    injected: loss terms 1e-4, mu / logits, and EVERY parameter gradient at 2e-6 + 1e-4 max|g|, incl. configs[1] size
+    (B = 2048, h = 512, T = 25).  **Parity unpinned against the reference** (it has no LSTM): this pins the model-level
+    composition - token tables, final-state read-out, decoder initial state, weight-gradient accumulation - to torch.nn.LSTM."""
+    import sys
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__file__)))
+    from bench import model_kwargs
+    from cpg.synth import synth_ids
+    from helpers import cu, set_losses_cfg
+    from models.model import RNN_VAE
+    from oracle import torch_ref
+    import losses
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    set_losses_cfg()
+    V = 24
+    torch.manual_seed(500 + B)
+    m = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, He, enc_layers=layers, cell='lstm'))
+    P = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    ref = torch_ref.RefWAE.from_state(P, cell="lstm")
+    rs = np.random.RandomState(B)
+    ids = synth_ids(B, T, V, torch.Generator().manual_seed(B))
+    c = np.zeros((B, 2), np.float32)
+    c[np.arange(B), rs.randint(0, 2, B)] = 1
+    rnd = dict(eps=rs.randn(B, Z).astype(np.float32), c=c, wd_mask=(rs.rand(B, T) < 0.3).astype(np.uint8),
+               out_mask=(rs.rand(B, T, Z + 2) >= 0.3).astype(np.uint8), z_prior_rf=rs.randn(B, Z).astype(np.float32),
+               rf_w=rs.randn(Z, 500).astype(np.float32), rf_b=(2 * np.pi * rs.rand(500)).astype(np.float32))
+    beta, lam_l1, lam_kl = 1.5, 0.05, 1e-3
+    torch.set_num_threads(min(32, __import__("os").cpu_count() or 1))
+    rt = {k: torch.from_numpy(v) for k, v in rnd.items()}
+    terms, aux = torch_ref.train_loss(ref, ids, rt, beta, lam_l1, lam_kl, "mmdrf", full_mmd=False)
+    terms["total"].backward()
+    G = {ref.ref_name(k): p.grad.numpy() for k, p in ref.named_parameters()}
+    m = m.cuda()
+    m.device = torch.device("cuda")
+    losses.rf.clear()
+    losses.rf['gaussian'] = (cu(rnd["rf_w"]), cu(rnd["rf_b"]))
+    idt = ids.cuda()
+    (mu, lv), (z, cc), logits = m(idt, q_c='prior', sample_z=1,
+                                  rnd=dict(eps=cu(rnd["eps"]), c=cu(rnd["c"]), wd_mask=cu(rnd["wd_mask"]), out_mask=cu(rnd["out_mask"])))
+    recon = losses.recon_dec(idt, logits)
+    mmdrf = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=cu(rnd["z_prior_rf"]))
+    l1, klmu, kl = losses.logvar_l1(lv), losses.kl_gaussian_sharedmu(mu, lv), losses.kl_gaussianprior(mu, lv)
+    loss = recon + beta * mmdrf + lam_l1 * l1 + lam_kl * klmu
+    loss.backward()
+    torch.cuda.synchronize()
+    for name, got in (("recon", recon), ("kl", kl), ("mmdrf", mmdrf), ("l1", l1), ("klmu", klmu), ("total", loss)):
+        want = float(terms[name])
+        assert abs(got.item() - want) < 1e-4 * max(1.0, abs(want)), (name, got.item(), want)
+    np.testing.assert_allclose(mu.detach().cpu().numpy(), aux["mu"].detach().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), aux["logits"].detach().numpy(), atol=1e-4, rtol=0)
+    checked = 0
+    for k, prm in m.named_parameters():
+        if k.startswith("classifier") or k == "decoder.emb.weight":
+            continue
+        want, got = G[k], prm.grad.cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=2e-6 + 1e-4 * np.abs(want).max(), rtol=0, err_msg=k)
+        checked += 1
+    assert checked == len(G)

@@ -5,7 +5,8 @@ import pytest
 from conftest import weights_of
 from oracle import wae, decode, optim, class_sampler
 
-MODELS = ["A", "micro", "enc2", "A_200"]   # A_200: config A after 200 reference train_vae iterations
+# A_200: config A after 200 reference train_vae iterations; skip: a model built with decoder skip connections
+MODELS = ["A", "micro", "enc2", "A_200", "skip"]
 
 
 def rnd_of(g):
@@ -230,3 +231,37 @@ def test_categorical_replay(golden, tag, kw):
     ref = g[tag + ".ids"]
     assert np.array_equal(ids, ref[:, :ids.shape[1]]) and (ref[:, ids.shape[1]:] == 1).all()
     assert (ref == 3).any(1).mean() > 0.3   # the fixture does exercise <eos> / finished rows
+
+
+def test_encoder_interlayer_dropout(golden):
+    """nn.GRU(dropout=p_dropout) between the layers of a 2-layer encoder in train mode (models/encoder.py:25-30), mask replayed from
+    the reference's own draw: (mu, logvar) and the reference's autograd gradients of sum(mu*gmu + logvar*glv); eval mode = no mask."""
+    g = golden("encdrop")
+    P = weights_of(g)
+    mu, lv, ec = wae.encoder_fwd(P, g["ids"], g["enc_keep"], float(g["p"]))
+    np.testing.assert_allclose(mu, g["mu_train"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(lv, g["logvar_train"], atol=2e-6, rtol=1e-5)
+    G = {}
+    demb = wae.encoder_bwd(P, g["gmu"], g["glv"], ec, G)
+    for k, v in G.items():
+        ref = g["g." + k]
+        np.testing.assert_allclose(v, ref, atol=5e-7 + 2e-5 * np.abs(ref).max(), rtol=0, err_msg=k)
+    np.testing.assert_allclose(demb, g["g.word_emb.weight"], atol=5e-7 + 2e-5 * np.abs(g["g.word_emb.weight"]).max(), rtol=0)
+    mu, lv, _ = wae.encoder_fwd(P, g["ids"])
+    np.testing.assert_allclose(mu, g["mu_eval"], atol=2e-6, rtol=1e-5)
+    assert np.abs(g["mu_eval"] - g["mu_train"]).max() > 1e-3      # the mask matters
+
+
+def test_sampling_in_train_mode(golden):
+    """generate_sentences(eval_mode=False) (models/model.py:216-221): out-dropout live in every decode step - greedy ids bit-exact
+    and beam-5 hypotheses exact with the reference's captured masks; without them the ids are the eval-mode ids."""
+    g = golden("sample_train")
+    P = weights_of(g)
+    ids = decode.greedy(P, g["z"], g["c"], 25, out_keep=g["greedy_keep"])
+    assert np.array_equal(ids, g["greedy_ids"])
+    assert np.array_equal(decode.greedy(P, g["z"], g["c"], 25), g["greedy_ids_eval_mode"])
+    n = g["beam_hyps"].shape[0]
+    hyps, _ = decode.beam(P, g["z"][:n], g["c"][:n], 25, beam_size=5, n_best=3, out_keep=g["beam_keep"])
+    for i in range(n):
+        for j in range(3):
+            assert hyps[i][j] == [int(t) for t in g["beam_hyps"][i, j] if t >= 0], (i, j)
