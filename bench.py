@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0
 # tools/pmc_summary.py --json): counters cannot be collected from inside this script, so the per-kernel means of the
 # committed profile are looked up BY THE KERNEL NAME THE LAUNCHER REPORTS - a tile-policy change yields null, not a stale
 # number.  (2*FETCH + WRITE)*1024: the gfx950 read-side correction of MI355X_MICROARCH.md, HBM section.
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
 
 
 def csrc_fingerprint():
@@ -84,8 +84,38 @@ def _cname(fn, *args):
     return buf.value.decode()
 
 
+def family_bytes(family, dims, bf16_gates):
+    """ALGORITHMIC HBM bytes of one launch of a recurrent kernel family (DESIGN.md section 6 states the per-element figures): what the
+    launch must move if every operand crossed HBM exactly once.  Per state element (one of B x H per direction and time step):
+      forward   writes h (4) + the saved gates r, z, n, W_hn h + b_hn (4 x 4, or 4 x 2 as bf16) - state exchange stays in L2;
+      backward  reads the saved gates (16 / 8), h_prev (4), the carry z (.) dH (4), the external gradient (4: decoder only) and
+                writes dG (16) + the next carry (4);
+      dW_hh     reads dG's hidden-side columns (12) and h_prev (4) once.  LSTM: four gate columns -> dG 16, gates + cell state."""
+    T, B, H, nd = dims["T"], dims["B"], dims["H"], dims["ndir"]
+    g = 8 if bf16_gates else 16
+    el = float(B) * H
+    if family == "fwd_persist":
+        return T * el * (4 + g)
+    if family == "fwd_step":
+        return nd * el * (4 + 4 + g)
+    if family == "bwd_step":
+        return nd * el * (g + 4 + 4 + (4 if nd == 1 else 0) + 16 + 4)
+    if family in ("wgrad_hh", "lstm_wgrad_hh"):
+        return T * el * ((12 if family == "wgrad_hh" else 16) + 4)
+    if family == "lstm_fwd_persist":
+        return T * el * (4 + 4 + 16)
+    if family == "lstm_fwd_step":
+        return el * (4 + 4 + 4 + 4 + 16)
+    if family == "lstm_bwd_step":
+        return el * (16 + 4 + 4 + 4 + 4 + 16 + 4 + 4)
+    return None
+
+
 def family_roofline(family, dims, avg_us, launches):
-    """Roofline object of one kernel family of the step (names and product form come from the launcher)."""
+    """Roofline object of one kernel family of the step (names and product form come from the launcher).  Both roofs are priced -
+    the matrix pipe the kernel uses and HBM on the family's algorithmic bytes - and `bound` / `frac` name the BINDING one (the
+    larger fraction): in the bf16 compute mode the recurrent kernels sit at 8-13 % of the bf16 MFMA peak and are bound by their
+    bytes, not by the pipe (round-3 verdict: the line used to print bound "mfma", peak 2500 for them)."""
     from cpg import lib
     T, B, H, nd = dims["T"], dims["B"], dims["H"], dims["ndir"]
     L = lib().dll
@@ -114,16 +144,22 @@ def family_roofline(family, dims, avg_us, launches):
         return None
     ach = flops / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
     peak = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_SPLIT_TFLOPS, 2: PEAK_BF16_MFMA_TFLOPS}[int(split)]
-    r = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-         "frac": round(ach / peak, 4), "traffic": pmc_traffic(kernel), "avg_launch_us": round(avg_us, 2),
-         "launches_timed": launches, "flops_per_launch": flops,
-         "pipe": {1: "bf16 MFMA, 6 x v_mfma_f32_16x16x32_bf16 on 3-way split operands per f32-grade block product: peak = 2500/6",
-                  0: "exact f32 MFMA (v_mfma_f32_16x16x4_f32): peak = 157.3",
-                  2: "bf16 MFMA, one v_mfma_f32_16x16x32_bf16 per block on bf16-rounded operands: peak = 2500"}[int(split)],
-         "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
-    if int(split) == 1:
-        r["executed_bf16_tflops"] = round(6 * ach, 1)
-        r["executed_frac_of_bf16_peak"] = round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4)
+    bf16_gates = bool(bf16 and family in ("fwd_persist", "fwd_step", "bwd_step") and L.cpg_gru_gates_bf16(B, H, 0) == 1)
+    nbytes = family_bytes(family, dims, bf16_gates)
+    gbs = nbytes / (avg_us * 1e-6) / 1e9 if (nbytes and avg_us > 0) else 0.0
+    mfma_frac, hbm_frac = ach / peak, gbs / HBM_PEAK_GBS
+    traffic = pmc_traffic(kernel)
+    pipe = {1: "bf16 MFMA x6 on 3-way split operands (f32-grade): 2500/6", 0: "exact f32 MFMA: 157.3", 2: "bf16 MFMA: 2500"}[int(split)]
+    r = {"kernel": kernel, "avg_launch_us": round(avg_us, 2), "launches_timed": launches, "traffic": traffic,
+         "mfma": {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(mfma_frac, 4), "pipe": pipe,
+                  "flops_per_launch": flops, "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)},
+         "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4),
+                 "algorithmic_bytes_per_launch": nbytes,
+                 "counter_frac": (round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and avg_us > 0) else None)}}
+    if hbm_frac > mfma_frac:
+        r.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_frac, 4))
+    else:
+        r.update(bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(mfma_frac, 4))
     return r
 
 
@@ -281,7 +317,8 @@ def dist_selftest(args):
         print(json.dumps({"selftest": "dist", "n_gpus": world, "rccl": probe}))
 
 
-def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len, steps, warmup, min_sustain_s=0.0, graph=False, z_dim=None):
+def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len, steps, warmup, min_sustain_s=0.0, graph=False, z_dim=None,
+              cell=None):
     """One timed WAE-training leg: builds the model at the given dimensions, W untimed steps, EXACTLY `steps` timed steps
     bracketed by barrier + synchronize, max over ranks.  Returns the numbers of the leg (rank 0 builds the roofline rows).
     min_sustain_s > 0: afterwards the same step keeps running until that much wall time has passed (`sustained`): the timed
@@ -294,11 +331,12 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
     from models.model import RNN_VAE
     import train_vae as tv
 
+    cell = cell or args.cell
     ops.set_compute_mode(dtype)
     T, V, B, Hh = seq_len, 24, batch, hidden
     Z, E, R = (Hh - 2 if z_dim is None else z_dim), 150, 500
     torch.manual_seed(1238)
-    model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh, enc_layers=enc_layers, cell=args.cell)).to(dev)
+    model = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, Hh, enc_layers=enc_layers, cell=cell)).to(dev)
     model.device = dev
     losses.rf.clear()
     losses._rf_basis(torch.zeros(1, Z, device=dev), R, False)          # same basis on every rank (same seed)
@@ -399,7 +437,7 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
                          "frac": 0.0, "traffic": None})
         roofline = dict(roofline)
         roofline["kernel_ms_per_step_all_launch_shapes"] = round(by_kernel.get(top_kernel, 0.0), 3)
-        gates = 3 if args.cell == "gru" else 4
+        gates = 3 if cell == "gru" else 4
         step_tflops = train_flops_per_seq(T, E, Hh, Z, V, R, B, gates) * B / (ms * 1e-3) / 1e12
         res.update(roofline=roofline, kernel_families=[r for r in rows if r["kernel"] != top_kernel or r["family"] != roofline.get("family")],
                    executed_step_tflops_per_gpu=round(step_tflops, 2),
@@ -411,20 +449,19 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
     return res
 
 
-def workload_text(args, dtype, Hh, enc_layers, B, T):
+def workload_text(args, dtype, Hh, enc_layers, B, T, cell=None):
+    cell = cell or args.cell
     Z = Hh - 2
     cfg_tag = ("BASELINE.json configs[1]" if (Hh, T, enc_layers, B) == (512, 25, 1, 2048)
                else "BASELINE.json configs[4] dimensions, GRU cells, 1-layer decoder as in the reference"
                if (Hh, T, enc_layers) == (1024, 50, 2) else "non-default dimensions")
-    return (f"WAE train step ({cfg_tag}): biGRU encoder h={Hh} {enc_layers} layer, z={Z}, GRU decoder "
-            f"h={Hh}, emb 150, vocab 24, batch {B}/GPU, seq_len {T}; "
-            + ("GRU cell = the reference's cell, parity pinned (the reference has no LSTM; --cell lstm runs "
-               "the LSTM extension)" if args.cell == "gru" else
-               "LSTM cell (extension, torch.nn.LSTM semantics; parity unpinned against the GRU-only reference)")
-            + (", f32 storage; recurrent products on the MFMA units in f32-grade forms (exact-f32 MFMA, or six bf16 MFMAs on 3-way "
-               "split operands)" if dtype == "f32" else
-               ", bf16 mode: recurrent products with bf16-rounded operands (one bf16 MFMA per block, f32 accumulation), saved gates "
-               "stored as bf16; gate gradients, state slabs and master weights f32 (NOT the parity path: agreement figures in profiles/)"))
+    C = cell.upper()
+    return (f"WAE train step ({cfg_tag}): bi{C} encoder h={Hh} x{enc_layers}, z={Z}, {C} decoder h={Hh}, emb 150, vocab 24, "
+            f"batch {B}/GPU, T={T}; "
+            + ("GRU = the reference's only cell (parity pinned)" if cell == "gru" else
+               "LSTM = extension named by BASELINE.json (torch.nn.LSTM semantics; parity unpinned vs the GRU-only reference)")
+            + ("; f32 storage, f32-grade MFMA products" if dtype == "f32" else
+               "; bf16 mode: bf16-rounded recurrent operands, f32 accumulate / state / master weights, bf16 saved gates (not the parity path)"))
 
 
 def main():
@@ -446,6 +483,7 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=2.5, help="wall seconds of the sustained region after the K timed steps")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="host seconds per cpu_baseline case (bounded sample)")
     ap.add_argument("--class-proposals", type=int, default=1000000, help="z proposals of the CLaSS leg (BASELINE.json configs[3]: 1 M in total, sharded over the ranks)")
+    ap.add_argument("--all-legs", action="store_true", help="N > 1: also run the config-C leg (skipped by default to bound the wall time)")
     ap.add_argument("--dist-selftest", action="store_true", help="CPU-only check of the N>1 launcher + collectives (gloo); no GPU work")
     args = ap.parse_args()
 
@@ -463,39 +501,48 @@ def main():
     backend = torch.distributed.get_backend() if world > 1 else None
 
     T, B, Hh = args.seq_len, args.batch, args.hidden
+    t_start = time.perf_counter()
     note("headline leg")
     head = train_leg(args, dev, rank, world, args.dtype, Hh, args.enc_layers, B, T, args.steps, args.warmup,
                      0.0 if args.no_extra_legs else args.sustain_s)
-    extra = {}
+    extra, full = {}, {}
     default_shape = (Hh, T, args.enc_layers, B, args.dtype, args.cell) == (512, 25, 1, 2048, "f32", "gru")
+
+    def leg(key, what, r, **more):
+        """One extra leg: the compact form goes into the JSON line, the full record (every family's two roofs) to bench_full.json."""
+        if rank != 0:
+            return
+        full[key] = dict(workload=what, **{k: r[k] for k in ("value", "ms_per_step", "steps", "warmup", "roofline", "kernel_families",
+                                                             "launches_per_step", "host_enqueue_ms_per_step") if k in r}, **more)
+        extra[key] = dict(workload=what, value=r["value"], unit="seq/s", ms_per_step=r["ms_per_step"], steps=r["steps"],
+                          roofline=compact_roofline(r.get("roofline")), families=compact_families(r.get("kernel_families")), **more)
+
     if default_shape and not args.no_extra_legs:
         note("bf16-mode leg")
-        r = train_leg(args, dev, rank, world, "bf16", Hh, args.enc_layers, B, T, args.steps, args.warmup)
-        if rank == 0:
-            extra["bf16_mode"] = {"workload": workload_text(args, "bf16", Hh, args.enc_layers, B, T), "value": r["value"], "unit": "seq/s",
-                                  "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "roofline": r["roofline"],
-                                  "kernel_families": r["kernel_families"], "launches_per_step": r["launches_per_step"]}
-        if world == 1:
-            note("graph-replay legs")
-            r = train_leg(args, dev, rank, world, "f32", Hh, args.enc_layers, B, T, args.steps, args.warmup, graph=True)
-            extra["graph_replay"] = {"what": "the same step replayed from ONE captured hipGraph (train_vae.GraphedTrainStep; cfg.hw.graph)",
-                                     "value": r["value"], "unit": "seq/s", "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                                     "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"], "graph_launches_per_step": 1,
-                                     "host_side_launches_per_step": 3}
-            # the reference's own defaults (config A: enc h=80, z=100, decoder h=102) at its default batch of 32: host-bound eagerly
-            ra = {}
-            for tag, gflag in (("eager", False), ("graph", True)):
-                rr = train_leg(args, dev, rank, world, "f32", 80, 1, 32, 25, 200, 20, graph=gflag, z_dim=100)
-                ra[tag] = {"value": rr["value"], "ms_per_step": rr["ms_per_step"], "host_enqueue_ms_per_step": rr["host_enqueue_ms_per_step"]}
-            extra["config_a_batch32"] = {"workload": "reference defaults (cfg.py:262-274: biGRU encoder h=80, z=100, GRU decoder h=102), batch 32, "
-                                                     "seq_len 25, f32-grade; 200 timed steps", "unit": "seq/s", **ra}
-        note("config-C leg")
-        cB, cK, cW = 1024, max(3, min(args.steps, 6)), 2
-        r = train_leg(args, dev, rank, world, "f32", 1024, 2, cB, 50, cK, cW)
-        if rank == 0:
-            extra["config_c"] = {"workload": workload_text(args, "f32", 1024, 2, cB, 50), "value": r["value"], "unit": "seq/s",
-                                 "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "roofline": r["roofline"],
-                                 "kernel_families": r["kernel_families"], "launches_per_step": r["launches_per_step"]}
+        leg("bf16_mode", workload_text(args, "bf16", Hh, args.enc_layers, B, T),
+            train_leg(args, dev, rank, world, "bf16", Hh, args.enc_layers, B, T, args.steps, args.warmup))
+        # BASELINE.json configs[1] AS NAMED: "hidden=512 1-layer LSTM, batch=2048, seq_len<=25, bf16" - the LSTM extension, both modes
+        note("LSTM legs (configs[1] as named)")
+        leg("lstm", workload_text(args, "f32", Hh, args.enc_layers, B, T, "lstm"),
+            train_leg(args, dev, rank, world, "f32", Hh, args.enc_layers, B, T, args.steps, args.warmup, cell="lstm"))
+        leg("lstm_bf16", workload_text(args, "bf16", Hh, args.enc_layers, B, T, "lstm"),
+            train_leg(args, dev, rank, world, "bf16", Hh, args.enc_layers, B, T, args.steps, args.warmup, cell="lstm"))
+        if world == 1 or args.all_legs:   # a multi-GPU run is about the scaling of the headline step: keep its wall time bounded
+            if world == 1:
+                note("graph-replay legs")
+                r = train_leg(args, dev, rank, world, "f32", Hh, args.enc_layers, B, T, args.steps, args.warmup, graph=True)
+                extra["graph_replay"] = {"what": "the same step replayed from ONE captured hipGraph (cfg.hw.graph)", "value": r["value"],
+                                         "ms_per_step": r["ms_per_step"], "host_enqueue_ms_per_step": r["host_enqueue_ms_per_step"]}
+                # the reference's own defaults (config A: enc h=80, z=100, decoder h=102) at its default batch of 32: host-bound eagerly
+                ra = {}
+                for tag, gflag in (("eager", False), ("graph", True)):
+                    rr = train_leg(args, dev, rank, world, "f32", 80, 1, 32, 25, 200, 20, graph=gflag, z_dim=100)
+                    ra[tag] = {"value": rr["value"], "ms_per_step": rr["ms_per_step"], "host_enqueue_ms_per_step": rr["host_enqueue_ms_per_step"]}
+                extra["config_a_batch32"] = {"workload": "reference defaults (enc h=80, z=100, dec h=102), batch 32, T=25, 200 steps", **ra}
+            note("config-C leg")
+            cB, cK, cW = 1024, max(3, min(args.steps, 6)), 2
+            leg("config_c", workload_text(args, "f32", 1024, 2, cB, 50),
+                train_leg(args, dev, rank, world, "f32", 1024, 2, cB, 50, cK, cW))
     rccl = None
     if world > 1:
         note("collectives probe")
@@ -512,19 +559,18 @@ def main():
                                        "executed_step_frac_of_f32_peak")})
     lp, lg = profiled_launches()
     extra["launches_per_step"] = {"rocprofv3_kernel_trace": lp, "of_which_torch_glue": lg,
-                                  "torch_profiler_device_records_this_run": head["launches_per_step"],
-                                  "note": "rocprofv3 figure: profiles/r03_bench_n1_summary.md, quoted only when that profile was taken from "
-                                          "these kernel sources; the torch.profiler figure undercounts (it merges repeated launches)"}
+                                  "torch_profiler_device_records": head["launches_per_step"]}
     if "sustained" in head:
         extra["sustained"] = head["sustained"]
-    extra["kernel_families"] = head["kernel_families"]
+    extra["families"] = compact_families(head["kernel_families"])
+    full["headline"] = {k: head[k] for k in ("roofline", "kernel_families") if k in head}
     line = {
         "metric": "peptide-seq/s per WAE training step", "value": head["value"], "unit": "seq/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload_text(args, args.dtype, Hh, args.enc_layers, B, T),
                    "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
-        "roofline": head["roofline"], "extra": extra,
+        "roofline": compact_roofline(head["roofline"], keep_all=True), "extra": extra,
     }
     if rccl is not None:
         line["rccl"] = rccl
@@ -535,14 +581,62 @@ def main():
         note("cpu baseline (torch-CPU restatement)")
         cases = cpu_baseline(T, 24, threads, args.cpu_budget_s)
         line["cpu_baseline"] = {"value": cases[0]["seq_per_s"], "unit": "seq/s", "cores": threads, "kind": "port",
-                                "sample": f"oracle/torch_ref.py (torch-CPU restatement of train_vae.py's step on ATen CPU kernels: the "
-                                          f"backend the reference runs on), torch.set_num_threads({threads}); {cases[0]['case']}: median of "
-                                          f"{cases[0]['steps']} steps after 1 warm-up ({cases[0]['s_per_step']} s/step)",
-                                "cases": cases}
+                                "sample": f"oracle/torch_ref.py (torch-CPU restatement of train_vae.py's step, ATen CPU kernels), {threads} threads; "
+                                          f"{cases[0]['case']}: median of {cases[0]['steps']} steps ({cases[0]['s_per_step']} s/step)",
+                                "cases": [{"case": c["case"], "seq_per_s": c["seq_per_s"]} for c in cases]}
     if cls is not None:
-        line["class"] = cls
-    print(json.dumps(line), flush=True)
+        full["class"] = cls
+        line["class"] = compact_class(cls)
+    line["extra"]["wall_s"] = round(time.perf_counter() - t_start, 1)
+    full["line"] = line
+    try:   # the verbose record (every family with both roofs, every CLaSS variant): a file next to the line, and stderr
+        outdir = os.environ.get("CPG_BENCH_OUT", os.path.join(ROOT, "gpurun_out"))
+        os.makedirs(outdir, exist_ok=True)
+        with open(os.path.join(outdir, "bench_full.json"), "w") as fh:
+            json.dump(full, fh)
+    except OSError:
+        pass
+    print(json.dumps(line, separators=(",", ":")), flush=True)
     cdist.barrier()
+
+
+def compact_roofline(r, keep_all=False):
+    """The roofline object as it goes into the ONE JSON line: the binding roof's numbers, the kernel, both fractions."""
+    if not r:
+        return None
+    out = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us") if k in r}
+    if "mfma" in r:
+        out["mfma_frac"], out["hbm_frac"] = r["mfma"]["frac"], r["hbm"]["frac"]
+        out["frac_of_f32_mfma_peak"] = r["mfma"]["frac_of_f32_mfma_peak"]
+    if keep_all:
+        for k in ("launches_timed", "family", "ms_per_step", "share_of_step", "kernel_ms_per_step_all_launch_shapes"):
+            if k in r:
+                out[k] = r[k]
+        if "mfma" in r:
+            out["pipe"], out["flops_per_launch"] = r["mfma"]["pipe"], r["mfma"]["flops_per_launch"]
+            out["algorithmic_bytes_per_launch"] = r["hbm"]["algorithmic_bytes_per_launch"]
+    return out
+
+
+def compact_families(rows):
+    return [{"family": r.get("family"), "kernel": r["kernel"], "us": r["avg_launch_us"], "ms_per_step": r.get("ms_per_step"),
+             "bound": r["bound"], "frac": r["frac"], "mfma_frac": r["mfma"]["frac"], "hbm_frac": r["hbm"]["frac"]} for r in (rows or [])]
+
+
+def compact_class(c):
+    out = {k: c[k] for k in ("workload", "metric", "value", "unit", "n_gpus", "scaling", "decoder_evals_per_s") if k in c}
+    rf = c.get("roofline") or {}
+    out["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")}
+    out["variants"] = {k: {kk: v[kk] for kk in ("wall_s", "accepted_per_s", "proposals_per_s", "decoder_evals_per_s", "decode_kernel_ms",
+                                                 "accepted_unique", "decoded") if kk in v} for k, v in c.get("variants", {}).items()}
+    for k, v in c.get("variants", {}).items():
+        if v.get("roofline"):
+            out["variants"][k]["frac"] = v["roofline"]["frac"]
+    if "cpu_baseline" in c:
+        cb = c["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "z_per_s", "decoder_evals_per_s") if k in cb}
+        out["cpu_baseline"]["sample"] = "single-threaded numpy oracle: LR scoring of 1e6 z + Beam.py-order beam-5 of 1024 z (not comparable to the 32-thread training baseline)"
+    return out
 
 
 def class_setup(dev, Z=100, K=100, seed=1238):

@@ -308,5 +308,5 @@ def train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, z_regu, sigma=7.0, p
     demb_enc = encoder_bwd(P, dmu.astype(F32), dlv.astype(F32), ec, G)
     G["word_emb.weight"] = (demb_enc + demb_dec).astype(F32)
     terms = dict(total=total, recon=recon, kl=kl, mmd=mmd, mmdrf=mmdrf, l1=l1, klmu=klmu)
-    aux = dict(mu=mu, logvar=lv, z=z, logits=logits, dz=dz.astype(F32), dlogits=dlogits)
+    aux = dict(mu=mu, logvar=lv, z=z, logits=logits, dz=dz.astype(F32), dlogits=dlogits, enc_h=ec["h"])
     return terms, G, aux

@@ -151,6 +151,8 @@ def _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", beta=1.5, lam_l1=0.1, la
     z.retain_grad()
     loss.backward()
     torch.cuda.synchronize()
+    if lam_l1 > 0:
+        _l1_kink_correction(G, aux, lv.detach().cpu().numpy(), P, lam_l1, slack, tag)
     for name, got in (("recon", recon), ("kl", kl), ("mmd", mmd), ("mmdrf", mmdrf), ("klmu", klmu), ("total", loss)):
         ref = float(terms[name])
         assert abs(got.item() - ref) < 1e-4 * max(1.0, abs(ref)) + slack.get(name, 0.0), (name, got.item(), ref)
@@ -164,6 +166,37 @@ def _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", beta=1.5, lam_l1=0.1, la
             continue
         ref, got = G[k], prm.grad.cpu().numpy()
         np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max() + slack.get("g." + k, 0.0), rtol=0, err_msg=k)
+
+
+def _l1_kink_correction(G, aux, lv_hip, P, lam_l1, slack, tag):
+    """|logvar|_1 is not differentiable at 0.  An element of logvar that the oracle puts within float32 rounding of zero may come
+    out with the other sign on the HIP path (mu / logvar agree to ~1e-6, not to the last bit); its d logvar then differs by
+    (sign_hip - sign_oracle) lam_l1 / B - a real, correct difference of two valid sub-gradients.  With B x Z ~ 10^6 elements this
+    happens (config C at B = 1024).  The flips are identified exactly, REQUIRED to sit at the kink (|logvar| < 1e-5 on both
+    sides), and the oracle's q_logvar gradients are moved to the HIP path's sub-gradient (rank-one terms d * h_b); what reaches the
+    rest of the encoder through d h = d logvar W_logvar gets a slack bounded by the flips' total weight."""
+    lv_ref = aux["logvar"]
+    B = lv_ref.shape[0]
+    flips = np.argwhere(np.sign(lv_hip) != np.sign(lv_ref))
+    if not len(flips):
+        return
+    assert np.abs(lv_ref[flips[:, 0], flips[:, 1]]).max() < 1e-5 and np.abs(lv_hip[flips[:, 0], flips[:, 1]]).max() < 1e-5, \
+        "logvar signs differ away from zero: not an L1-kink effect"
+    assert len(flips) <= 64
+    Wk, bk = "encoder.q_logvar.weight", "encoder.q_logvar.bias"
+    G[Wk], G[bk] = G[Wk].copy(), G[bk].copy()
+    total = 0.0
+    for b, zi in flips:
+        d = (np.sign(lv_hip[b, zi]) - np.sign(lv_ref[b, zi])) * lam_l1 / B
+        G[Wk][zi] += (d * aux["enc_h"][b]).astype(np.float32)
+        G[bk][zi] += np.float32(d)
+        total += abs(d)
+    up = 4.0 * total * float(np.abs(P[Wk]).max())
+    for k in G:
+        if (k.startswith("encoder.rnn") or k == "word_emb.weight"):
+            slack["g." + k] = slack.get("g." + k, 0.0) + up
+    CONDITION_REPORT.append(dict(test=tag or "step", logvar_sign_flips_at_the_L1_kink=int(len(flips)), upstream_gradient_slack=up))
+    _write_report("condition_report.json", CONDITION_REPORT)
 
 
 TIE_REPORT = []   # (test, rows decoded, rows that differ at an f32 tie of the oracle's own logits): written to gpurun_out/
@@ -274,7 +307,7 @@ def test_config_c_bench_batch_vs_oracle():
     consecutive row-range launches and the backward / dW launches pick their large-batch tiles - the same oracle comparison as at
     B = 256 (round-3 verdict: the bench batch was only self-compared)."""
     m, P, ids, rnd = _random_case(1024, 50, 24, 1022, 1024, 2, seed=19)
-    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf")
+    _check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", tag="config C, B=1024")
 
 
 BEAM_REPORT = []
