@@ -195,6 +195,7 @@ def _rowmajor(t):
 # ----------------------------------------------------------------------------------------------- dense
 DIRECT_GRAD = False   # only inside backward_scope (FusedAdamClip.backward): see _grad_buf
 DEFER_WGRAD = False   # only inside backward_scope: the decoder's dW_hh product runs on a side stream (GruSeqFn)
+DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... and so does the [z;c] block of its W_ih gradient (LinearColsFn)
 BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
 
 
@@ -361,6 +362,22 @@ class LinearColsFn(Function):
             dw = gw if direct else torch.zeros_like(ww)
             db = (gb if direct else torch.empty(N, device=dy.device, dtype=torch.float32)) if ctx.has_b else None
             nb = query("cpg_linear_bwd_weight_workspace", M, N, K)
+            if direct and DEFER_WGRAD and OVERLAP and DEFER_SMALL_WGRAD and M >= 1024:
+                # nothing downstream of the backward pass reads this product (it lands in the parameter's gradient buffer): queue it on
+                # the side stream BEHIND the decoder's deferred dW_hh instead of in front of the launches that lead to the encoder's
+                # BPTT.  On the main stream it ran beside that 240-workgroup product and crawled on the CUs left over (417 us for
+                # 3.2 GFLOP at config B, profiles/r03), holding up everything queued behind it.
+                side = side_streams(dy.device)[2]
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ws = workspace(nb, dy.device)
+                    call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw[:, c0:c1]), dw.stride(0), _p(db), M, N, K, 1,
+                         _p(ws), ws.numel(), _stream())
+                    _pending_events.append(side.record_event())
+                torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
+                for t in (dy, xx):
+                    t.record_stream(side)
+                return dx, None, None, None, None
             ws = workspace(nb, dy.device)
             call("cpg_linear_bwd_weight", _p(dy), lddy, _p(xx), ldx, _p(dw[:, c0:c1]), dw.stride(0), _p(db), M, N, K, int(direct),
                  _p(ws), ws.numel(), _stream())
@@ -919,6 +936,82 @@ class LstmSeqFn(Function):
                  _p(ws), ws.numel(), _stream())
         return (None, dtab, drowc, dG if has_dense else None, dh0 if has_h0 else None, dc0 if has_c0 else None, dw_hh, db_hh,
                 None, None)
+
+
+class LstmBiSeqFn(Function):
+    """Both directions of one biLSTM layer (torch.nn.LSTM semantics; extension - SURVEY F2) with ONE backward launch per time step
+    for the pair (cpg_lstm_biseq_bwd), as GruBiSeqFn.  Returns (slab_fwd, slab_rev) of hidden states, or with finals=True only
+    the two final hidden states (forward slot T, reverse slot 0), whose gradients then enter the backward recurrence directly."""
+
+    @staticmethod
+    def forward(ctx, tok, tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r, T, finals=False):
+        dev = w_hh_f.device
+        ctx.finals = bool(finals)
+        H = w_hh_f.shape[1]
+        B = tok.shape[1] if tok is not None else dense_f.shape[1]
+        cont = lambda t: t.contiguous() if t is not None else None
+        wf, bf, wr, br = cont(w_hh_f), cont(b_hh_f), cont(w_hh_r), cont(b_hh_r)
+        tf, tr, df, dr = cont(tab_f), cont(tab_r), cont(dense_f), cont(dense_r)
+        mk = lambda: torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
+        hs_f, hs_r, cs_f, cs_r = mk(), mk(), mk(), mk()
+        hs_f[0].zero_(), cs_f[0].zero_(), hs_r[T].zero_(), cs_r[T].zero_()
+        need_grad = any(t is not None and t.requires_grad for t in (tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r))
+        g_f = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        g_r = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
+        if lstm_persistent_fits(B, H):
+            with _prof("lstm_fwd_persist", 2, T=T, B=B, H=H, ndir=1):   # back to back on ONE stream: each needs every CU
+                lstm_seq_fwd_persistent(T, B, H, False, wf, bf, tok, tf, None, df, hs_f, cs_f, g_f)
+                lstm_seq_fwd_persistent(T, B, H, True, wr, br, tok, tr, None, dr, hs_r, cs_r, g_r)
+        else:
+            with _prof("lstm_fwd_step", 2 * T, T=T, B=B, H=H, ndir=1):
+                for rev, w, b, tb, dn, hs, cs, gt in ((0, wf, bf, tf, df, hs_f, cs_f, g_f), (1, wr, br, tr, dr, hs_r, cs_r, g_r)):
+                    call("cpg_lstm_seq_fwd", T, B, H, rev, _p(w), _p(b), _p(tok), _p(tb), None, _p(dn), _p(hs), _p(cs), _p(gt), _stream())
+        ctx.save_for_backward(tok, wf, wr, hs_f, hs_r, cs_f, cs_r, g_f, g_r)
+        ctx.leaves = (w_hh_f, w_hh_r)
+        ctx.dims = (T, B, H)
+        ctx.V = tab_f.shape[0] if tab_f is not None else 0
+        ctx.has_tab, ctx.has_dense = tab_f is not None, dense_f is not None
+        if finals:
+            return hs_f[T], hs_r[0]
+        return hs_f, hs_r
+
+    @staticmethod
+    def backward(ctx, g_hs_f, g_hs_r):
+        tok, wf, wr, hs_f, hs_r, cs_f, cs_r, gt_f, gt_r = ctx.saved_tensors
+        T, B, H = ctx.dims
+        dev = hs_f.device
+        BH = B * H
+        ext_f = ext_r = last_f = last_r = None
+        z = lambda g, like: g.contiguous() if g is not None else torch.zeros_like(like)
+        if ctx.finals:
+            last_f, last_r = z(g_hs_f, hs_f[0]), z(g_hs_r, hs_f[0])
+        else:
+            ext_f = z(g_hs_f, hs_f).view(-1)[BH:]        # slots 1..T
+            ext_r = z(g_hs_r, hs_r).view(-1)[:T * BH]    # slots 0..T-1
+        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
+        wT = torch.empty(2, H, 4 * H, device=dev, dtype=torch.float32)
+        with _prof("lstm_bwd_step", T, T=T, B=B, H=H, ndir=2):
+            call("cpg_lstm_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(cs_f), _p(cs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+        nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
+        ws = workspace(nb, dev)
+        outs = []
+        for rev, dG, hs in ((0, dG_f, hs_f), (1, dG_r, hs_r)):
+            gw = _grad_buf(ctx.leaves[rev])
+            dw = gw if gw is not None else torch.empty(4 * H, H, device=dev, dtype=torch.float32)
+            db = torch.empty(4 * H, device=dev, dtype=torch.float32)
+            with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                call("cpg_lstm_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None if ctx.has_tab else _p(db), int(gw is not None),
+                     _p(ws), ws.numel(), _stream())
+            dtab = None
+            if ctx.has_tab:
+                dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32)
+                call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(db), None, 0, _p(ws), ws.numel(), _stream())
+            outs.append((dtab, dG if ctx.has_dense else None, None if gw is not None else dw, db))
+        (dtab_f, dd_f, dw_f, db_f), (dtab_r, dd_r, dw_r, db_r) = outs
+        return None, dtab_f, dtab_r, dd_f, dd_r, dw_f, db_f, dw_r, db_r, None, None
 
 
 def lstm_step(tok, tab, rowc, h_prev, c_prev, h_out, c_out, w_hh, b_hh):

@@ -117,6 +117,7 @@ struct LstmBwdArgs {
     const float* w_hhT;    // [H,4H] = w_hh^T, or null (direct-to-LDS kernel only)
     const float* dC_next;  // [B,H] carried cell gradient dc_{s+1} * f_{s+1}, null on the first launch
     const float* ext;      // [B,H] external gradient on h_s
+    const float* ext2;     // [B,H] second external gradient (the final-state gradient, on the direction's first launch) or null
     const float* gates;    // [4,B,H] of step s; null on the closing launch (emits dh0 / dc0)
     const float* c_prev;   // [B,H] c_{s-1}
     const float* c_cur;    // [B,H] c_s
@@ -126,11 +127,18 @@ struct LstmBwdArgs {
     int B, H;
 };
 
+// Both directions of a bidirectional layer share ONE launch per step (blockIdx.z picks the direction), as the GRU pairs of
+// csrc/gru.hip: twice the work per launch over the same fixed per-launch phases.
+struct LstmBwdPair {
+    LstmBwdArgs d[2];
+};
+
 template <class TC, bool VEC>
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
-    const int H = g.H, B = g.B;
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdPair pr) {
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
+    const LstmBwdArgs& g = pr.d[bz];
+    const int H = g.H, B = g.B;
     const int m0 = by * TC::BM, j0 = bx * TC::BN;
     const size_t BH = (size_t)B * H;
     float pre[TC::NI][TC::MI][4], sv[TC::NI][TC::MI][4][7];
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 const size_t o = (size_t)((row < B) ? row : 0) * H + jc;
-                pre[ni][mi][r] = g.ext ? g.ext[o] : 0.f;
+                pre[ni][mi][r] = (g.ext ? g.ext[o] : 0.f) + (g.ext2 ? g.ext2[o] : 0.f);
                 sv[ni][mi][r][6] = g.dC_next ? g.dC_next[o] : 0.f;
                 if (g.gates) {
                     sv[ni][mi][r][0] = g.gates[o];
@@ -200,12 +208,13 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdArgs g) {
 // Backward step with the direct-to-LDS main loop (DlLoop, gemm_core.h): dG_next [B,4H] . W_hh^T rows, both K-contiguous, exact-f32
 // MFMA, 16-byte row-layout epilogue.  Same sums as lstm_step_bwd_kernel (same contraction order); dense full tiles only.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdArgs g) {
+__global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
     using DL = DlLoop<BM, BN, 3>;
     constexpr int MI = DL::MI, NI = DL::NI;
-    const int H = g.H;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
+    const LstmBwdArgs& g = pr.d[bz];
+    const int H = g.H;
     const int m0 = by * BM, j0 = bx * BN;
     const size_t BH = (size_t)g.B * H;
     extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdArgs g) {
                 const size_t o = (size_t)(rb0 + 16 * mi) * H + cb0 + 16 * ni;
                 const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
                 pre[mi][ni] = g.ext ? *reinterpret_cast<const f32x4*>(g.ext + o) : zero;
+                if (g.ext2) pre[mi][ni] += *reinterpret_cast<const f32x4*>(g.ext2 + o);
                 sv[mi][ni][6] = g.dC_next ? *reinterpret_cast<const f32x4*>(g.dC_next + o) : zero;
                 if (g.gates) {
 #pragma unroll
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdArgs g) {
             }
     };
     if (g.dG_next) {
-        const int hb = blockIdx.x + gridDim.x * blockIdx.y;
+        const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3, KT = 4 * H / 32;
         DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 4 * H, (size_t)4 * H, 4 * H, cpg_smem, acc,
                 min(phase * ((KT / 4) & ~1), KT - 1), load_ep);
@@ -364,46 +374,55 @@ static bool lstm_dl_ok(int B, int H) {
     return B % 64 == 0 && H % 32 == 0;
 }
 template <int BM, int BN>
-static int lstm_launch_dl(const LstmBwdArgs& a, hipStream_t s) {
+static int lstm_launch_dl(const LstmBwdPair& pr, int nd, hipStream_t s) {
+    const LstmBwdArgs& a = pr.d[0];
     const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
         const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN>), (int)smem);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN>), dim3(a.H / BN, a.B / BM), dim3(256), smem, s, a);
+    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN>), dim3(a.H / BN, a.B / BM, nd), dim3(256), smem, s, pr);
     return 0;
 }
 
-static int lstm_bwd_launch(const LstmBwdArgs& a, hipStream_t s) {
+// nd = 1: one direction (pr.d[0]); nd = 2: both directions of a bidirectional layer in one launch (same B, H; the two
+// argument sets must agree on which optional operands are present, which the sequence launchers guarantee)
+static int lstm_bwd_launch(const LstmBwdPair& pr, int nd, hipStream_t s) {
+    const LstmBwdArgs& a = pr.d[0];
     if (a.w_hhT && lstm_dl_ok(a.B, a.H)) {
-        const void* ptrs[] = {a.dG_next, a.w_hhT, a.dC_next, a.ext, a.gates, a.c_prev, a.c_cur, a.dH_out, a.dC_out, a.dG_out};
         bool al = true;
-        for (const void* q : ptrs) al = al && (!q || aligned16(q));
+        for (int d = 0; d < nd; ++d) {
+            const LstmBwdArgs& q = pr.d[d];
+            const void* ptrs[] = {q.dG_next, q.w_hhT, q.dC_next, q.ext, q.ext2, q.gates, q.c_prev, q.c_cur, q.dH_out, q.dC_out, q.dG_out};
+            for (const void* v : ptrs) al = al && (!v || aligned16(v));
+        }
         if (al) {
             // 64 x 64 tiles once they give two workgroups per CU, else 64 x 32 (as the GRU kernel: csrc/gru.hip)
-            const int rc = (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) >= 512) ? lstm_launch_dl<64, 64>(a, s) : lstm_launch_dl<64, 32>(a, s);
+            const int rc = (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) * nd >= 512) ? lstm_launch_dl<64, 64>(pr, nd, s)
+                                                                                        : lstm_launch_dl<64, 32>(pr, nd, s);
             if (rc) return rc;
             CPG_LAUNCH_CHECK();
             return 0;
         }
     }
-    const bool vec = a.H % 4 == 0 && aligned16(a.w_hh) && (!a.dG_next || aligned16(a.dG_next));
-    const int choice = lstm_bwd_choice(a.B, a.H);
+    bool vec = a.H % 4 == 0;
+    for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
+    const int choice = lstm_bwd_choice(a.B * nd, a.H);
     if (choice == 0) {
-        dim3 grid(cdiv(a.H, LB32N::BN), cdiv(a.B, LB32N::BM));
+        dim3 grid(cdiv(a.H, LB32N::BN), cdiv(a.B, LB32N::BM), nd);
         const size_t smem = LB32N::smem_floats<true, false>() * sizeof(float);
-        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, true>), grid, dim3(256), smem, s, a);
-        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, false>), grid, dim3(256), smem, s, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, true>), grid, dim3(256), smem, s, pr);
+        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32N, false>), grid, dim3(256), smem, s, pr);
     } else if (choice == 1) {
-        dim3 grid(cdiv(a.H, LB64::BN), cdiv(a.B, LB64::BM));
+        dim3 grid(cdiv(a.H, LB64::BN), cdiv(a.B, LB64::BM), nd);
         const size_t smem = LB64::smem_floats<true, false>() * sizeof(float);
-        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, true>), grid, dim3(256), smem, s, a);
-        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, false>), grid, dim3(256), smem, s, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, true>), grid, dim3(256), smem, s, pr);
+        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB64, false>), grid, dim3(256), smem, s, pr);
     } else {
-        dim3 grid(cdiv(a.H, LB32::BN), cdiv(a.B, LB32::BM));
+        dim3 grid(cdiv(a.H, LB32::BN), cdiv(a.B, LB32::BM), nd);
         const size_t smem = LB32::smem_floats<true, false>() * sizeof(float);
-        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32, true>), grid, dim3(256), smem, s, a);
-        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32, false>), grid, dim3(256), smem, s, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32, true>), grid, dim3(256), smem, s, pr);
+        else hipLaunchKernelGGL((lstm_step_bwd_kernel<LB32, false>), grid, dim3(256), smem, s, pr);
     }
     CPG_LAUNCH_CHECK();
     return 0;
@@ -455,11 +474,13 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
         if (p < 0 && !dh0) break;
         const int t = p < 0 ? -1 : (reverse ? T - 1 - p : p);
         const int cur = (p + 2) & 1;
-        LstmBwdArgs a;
+        LstmBwdPair pr;
+        LstmBwdArgs& a = pr.d[0];
         a.B = B;
         a.H = H;
         a.w_hh = w_hh;
         a.w_hhT = w_hhT_scratch;
+        a.ext2 = nullptr;
         a.dG_next = prev_t >= 0 ? dG + (size_t)prev_t * B * 4 * H : nullptr;
         a.dC_next = prev_t >= 0 ? scratch + (size_t)(cur ^ 1) * BH : nullptr;
         if (p >= 0) {
@@ -478,9 +499,65 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
             a.dC_out = dc0;
             a.dG_out = nullptr;
         }
-        int rc = lstm_bwd_launch(a, (hipStream_t)stream);
+        pr.d[1] = a;
+        int rc = lstm_bwd_launch(pr, 1, (hipStream_t)stream);
         if (rc) return rc;
         prev_t = t;
+    }
+    return 0;
+}
+
+// Both directions of one biLSTM layer, ONE launch per step for the pair (launch p: time p of the forward direction, time T-1-p
+// of the reverse one).  Arguments as cpg_lstm_seq_bwd per direction (_f forward, _r reverse); dh_last_* [B,H] (optional): the
+// gradient on a direction's final HIDDEN state enters at its last step; no initial-state gradients (the encoder starts from
+// h0 = c0 = 0).  (Extension: the reference has no LSTM - SURVEY F2; the pairing mirrors cpg_gru_biseq_bwd.)
+CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
+                                  const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
+                                  float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && cs_f && cs_r && gates_f && gates_r && dG_f && dG_r);
+    CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
+    CPG_CHECK_ARG((dhs_ext_f == nullptr) == (dhs_ext_r == nullptr) && (dh_last_f == nullptr) == (dh_last_r == nullptr));
+    if (w_hhT_scratch_f && !lstm_dl_ok(B, H)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;
+    const float* W[2] = {w_hh_f, w_hh_r};
+    float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
+    for (int d = 0; d < 2 && WT[d]; ++d) {
+        hipLaunchKernelGGL(lstm_transpose_w_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, (hipStream_t)stream, W[d],
+                           4 * H, H, WT[d]);
+        CPG_LAUNCH_CHECK();
+    }
+    const size_t BH = (size_t)B * H;
+    const float* CS[2] = {cs_f, cs_r};
+    const float* GT[2] = {gates_f, gates_r};
+    const float* EX[2] = {dhs_ext_f, dhs_ext_r};
+    const float* LAST[2] = {dh_last_f, dh_last_r};
+    float* DG[2] = {dG_f, dG_r};
+    float* SC[2] = {scratch_f, scratch_r};
+    int prev_t[2] = {-1, -1};
+    for (int p = T - 1; p >= 0; --p) {
+        LstmBwdPair pr;
+        const int cur = (p + 2) & 1;
+        for (int d = 0; d < 2; ++d) {
+            const int t = d ? T - 1 - p : p;
+            LstmBwdArgs& a = pr.d[d];
+            a.B = B;
+            a.H = H;
+            a.w_hh = W[d];
+            a.w_hhT = WT[d];
+            a.dG_next = prev_t[d] >= 0 ? DG[d] + (size_t)prev_t[d] * B * 4 * H : nullptr;
+            a.dC_next = prev_t[d] >= 0 ? SC[d] + (size_t)(cur ^ 1) * BH : nullptr;
+            a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
+            a.ext2 = (p == T - 1) ? LAST[d] : nullptr;
+            a.gates = GT[d] + (size_t)t * 4 * BH;
+            a.c_prev = d ? CS[d] + (size_t)(t + 1) * BH : CS[d] + (size_t)t * BH;
+            a.c_cur = d ? CS[d] + (size_t)t * BH : CS[d] + (size_t)(t + 1) * BH;
+            a.dH_out = nullptr;
+            a.dC_out = SC[d] + (size_t)cur * BH;
+            a.dG_out = DG[d] + (size_t)t * B * 4 * H;
+            prev_t[d] = t;
+        }
+        int rc = lstm_bwd_launch(pr, 2, (hipStream_t)stream);
+        if (rc) return rc;
     }
     return 0;
 }

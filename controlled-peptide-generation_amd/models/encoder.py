@@ -87,11 +87,12 @@ class GRUEncoder(nn.Module):
                         dense = ops.LinearFn.apply(xf, w_ih, b_ih).view(T, B, -1)
                 pre.append((tab, dense))
             new = []
-            if self.cell == 'gru' and self.biGRU and ops.OVERLAP:
-                # both directions share one launch per time step (GruBiSeqFn)
+            if self.biGRU and ops.OVERLAP:
+                # both directions share one launch per time step (GruBiSeqFn; LstmBiSeqFn for the LSTM extension)
                 (tab_f, dense_f), (tab_r, dense_r) = pre
                 top = l == self.layers - 1   # the top layer is read for its two final states only
-                new = list(ops.GruBiSeqFn.apply(tok if l == 0 else None, tab_f, tab_r, dense_f, dense_r,
+                BiFn = ops.GruBiSeqFn if self.cell == 'gru' else ops.LstmBiSeqFn
+                new = list(BiFn.apply(tok if l == 0 else None, tab_f, tab_r, dense_f, dense_r,
                                                 self._w("weight_hh", l, ""), self._w("bias_hh", l, ""),
                                                 self._w("weight_hh", l, "_reverse"), self._w("bias_hh", l, "_reverse"), T, top))
                 if top:

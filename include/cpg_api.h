@@ -200,6 +200,13 @@ CPG_API int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const 
                                         float* hs, float* cs, float* gates, void* sync_scratch, void* err_host, void* stream);
 CPG_API size_t cpg_lstm_persistent_err_offset(int B);
 CPG_API int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* stream);
+/* Both directions of one biLSTM layer in lock step, ONE launch per step for the pair (as cpg_gru_biseq_bwd): arguments as
+ * cpg_lstm_seq_bwd per direction; dh_last_* [B,H] (optional, both or neither) = gradient on each direction's final hidden state;
+ * no initial-state gradients.  Extension (the reference has no LSTM). */
+CPG_API int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
+                               const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                               const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
+                               float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream);
 /* Launcher introspection (as cpg_gru_step_kernel_name): kind 0 forward step, 1 backward step. */
 CPG_API int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int n);
 CPG_API int cpg_lstm_step_kernel_is_split(int kind, int B, int H);

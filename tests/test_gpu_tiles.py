@@ -190,8 +190,8 @@ def _l1_kink_correction(G, aux, lv_hip, P, lam_l1, slack, tag):
         d = (np.sign(lv_hip[b, zi]) - np.sign(lv_ref[b, zi])) * lam_l1 / B
         G[Wk][zi] += (d * aux["enc_h"][b]).astype(np.float32)
         G[bk][zi] += np.float32(d)
-        total += abs(d)
-    up = 4.0 * total * float(np.abs(P[Wk]).max())
+        total += float(abs(d))
+    up = float(4.0 * total * float(np.abs(P[Wk]).max()))
     for k in G:
         if (k.startswith("encoder.rnn") or k == "word_emb.weight"):
             slack["g." + k] = slack.get("g." + k, 0.0) + up
