@@ -445,7 +445,8 @@ def train_leg(args, dev, rank, world, dtype, hidden, enc_layers, batch, seq_len,
     del trainer, model, pool
     losses.set_distributed(None, 1)
     ops.set_compute_mode('f32')
-    torch.cuda.empty_cache()
+    if os.environ.get("CPG_BENCH_EMPTY_CACHE"):
+        torch.cuda.empty_cache()   # (default: keep the caching allocator's blocks for the next leg - 288 GB of HBM hold every leg)
     return res
 
 
@@ -632,6 +633,10 @@ def compact_class(c):
     for k, v in c.get("variants", {}).items():
         if v.get("roofline"):
             out["variants"][k]["frac"] = v["roofline"]["frac"]
+    if c.get("config_b_width"):
+        w = c["config_b_width"]
+        out["config_b_width"] = {k: ({kk: v[kk] for kk in ("wall_s", "accepted_per_s", "decoder_evals_per_s", "decode_chain_ms")} | {"frac": v["roofline"]["frac"], "kernel": v["roofline"]["kernel"]}
+                                     if isinstance(v, dict) else v) for k, v in w.items()}
     if "cpu_baseline" in c:
         cb = c["cpu_baseline"]
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "z_per_s", "decoder_evals_per_s") if k in cb}
@@ -639,7 +644,7 @@ def compact_class(c):
     return out
 
 
-def class_setup(dev, Z=100, K=100, seed=1238):
+def class_setup(dev, Z=100, K=100, seed=1238, enc_h=80):
     """SURVEY 8(d) synthetic CLaSS problem at the reference's default dims: proposal = diagonal GMM (K=100, means N(0,0.8^2),
     variances e^-2), two logistic-regression heads w ~ N(0,1/Z), b = 0, targets {amp: 1, tox: 0}."""
     import types
@@ -647,7 +652,7 @@ def class_setup(dev, Z=100, K=100, seed=1238):
     from density_modeling import mogQ
     from models.model import RNN_VAE
     torch.manual_seed(seed)
-    m = RNN_VAE(n_vocab=24, max_seq_len=25, **model_kwargs(Z, 80)).to(dev)
+    m = RNN_VAE(n_vocab=24, max_seq_len=25, **model_kwargs(Z, enc_h)).to(dev)
     m.device = dev
     rs = np.random.RandomState(seed)
     Q = mogQ.from_params(np.ones(K) / K, rs.randn(K, Z) * 0.8, np.full((K, Z), np.exp(-2.0)), device=dev)
@@ -733,15 +738,55 @@ def class_bench(dev, N=1000000, cpu=True, rank=0, world=1):
                              "algorithmic flops = live row-steps x (dense W_ih + W_hh + fc); per-GPU rate (rank 0's kernels)"}
         out[tag] = r
     head = out["beam5_all"]
+    wide = None
+    if world == 1:
+        wide = class_wide(dev)
     res = {"workload": f"BASELINE.json configs[3] on {world} GPU(s): {N} z proposals in total ({N // world} per GPU; synthetic GMM K=100), 2 LR heads, "
                        f"reference defaults z=100 / decoder h=102 / V=24 / T=25, c ~ Cat(.5,.5) per proposal, beam-5 decode of every proposal through "
                        f"sample_pipeline.run_rounds" + ("; rows all-gathered across the ranks and de-duplicated on the gathered set" if world > 1 else ""),
            "metric": "CLaSS accepted-samples/s", "value": head["accepted_per_s"], "unit": "accepted-samples/s", "n_gpus": world,
            "scaling": "strong", "decoder_evals_per_s": head["decoder_evals_per_s"], "roofline": head.get("roofline"), "variants": out}
+    if wide is not None:
+        res["config_b_width"] = wide
     if cpu and rank == 0:
         note("CLaSS cpu baseline")
         res["cpu_baseline"] = class_cpu_baseline(m, Q)
     return res
+
+
+def class_wide(dev, Z=510, N=131072):
+    """The CLaSS round at config-B width (z = 510, decoder h = 512, SURVEY 8d: 3.63 MFLOP per decoder row-step): no whole-loop kernel
+    covers that width (W_hh alone is 4.7 MB of planes), so sample_G runs the per-step launch chain cpg_gru_step_fwd -> cpg_vocab_fc_fwd
+    -> select (round-3 verdict: this path had no bench number).  One round of N proposals, greedy and beam-5 of every proposal."""
+    import logging
+    import sample_pipeline as sp
+    from cpg import ops
+    logging.getLogger('GenerationAPI').setLevel(logging.WARNING)
+    m, Q, ds = class_setup(dev, Z=Z, enc_h=64)
+    H = Z + 2
+    EVAL_FLOPS = 2.0 * 3 * H * (150 + H + H) + 2.0 * H * 24
+    out = {"workload": f"one CLaSS round of {N} proposals at z={Z} / decoder h={H} (config-B width), per-step decode launches", "flops_per_eval": EVAL_FLOPS}
+    sp.run_rounds(m, ds, Q, 8192, 10 ** 9, max_rounds=1, sample_mode='greedy')
+    for tag, mode in (("greedy_all", "greedy"), ("beam5_all", "beam")):
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        df, st = sp.run_rounds(m, ds, Q, N, 10 ** 9, max_rounds=1, return_stats=True, sample_mode=mode)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+        kms = sum(e0.elapsed_time(e1) for fam, e0, e1, _, _ in prof if fam == "decode_step_chain")
+        steps = sum(l for fam, _, _, l, _ in prof if fam == "decode_step_chain")
+        ach = st["decoder_evals"] * EVAL_FLOPS / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        out[tag] = {"wall_s": round(dt, 3), "accepted_per_s": round(float(df['accept'].sum()) / dt, 1), "decoder_evals": st["decoder_evals"],
+                    "decoder_evals_per_s": round(st["decoder_evals"] / dt, 1), "decode_chain_ms": round(kms, 2), "chain_steps": steps,
+                    "roofline": {"bound": "mfma", "kernel": _cname("cpg_gru_step_kernel_name", 0, 65536, H, 1, 0), "achieved": round(ach, 2),
+                                 "peak": round(PEAK_SPLIT_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_SPLIT_TFLOPS, 4),
+                                 "note": "algorithmic flops of the live row-steps (dense W_ih + W_hh + fc) over the time of the per-step "
+                                         "chain (step kernel + vocabulary projection + selection)"}}
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -130,6 +130,8 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     unfinished = torch.zeros(max_len, device=dev, dtype=torch.int32)
     logits = torch.empty(N, V, device=dev, dtype=torch.float32)
     scratch = torch.empty(264, device=dev, dtype=torch.float32)
+    prof = ops._prof("decode_step_chain", max_len, T=max_len, B=N, H=zc.shape[1], ndir=1)   # (bench.py: per-step decode launches)
+    prof.__enter__()
     for i in range(max_len):
         if lstm:
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
@@ -156,6 +158,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         else:
             raise ValueError(mode)
         h_a, h_b = h_b, h_a
+    prof.__exit__(None, None, None)
     return _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx)
 
 
@@ -168,8 +171,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
     oracle/decode.py:soft_sample."""
     if mode not in ("none_softmax", "greedy_softmax", "categorical_softmax"):
         raise ValueError(mode)
-    if getattr(decoder, "cell", "gru") != "gru":
-        raise NotImplementedError("soft sampling is implemented for the GRU decoder (the reference's cell)")
+    lstm = getattr(decoder, "cell", "gru") == "lstm"   # extension: torch.nn.LSTM semantics, h0 = [z;c], c0 = 0
     N = z.shape[0]
     dev = z.device
     zc = decoder.init_hidden(z, c).contiguous()
@@ -182,6 +184,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
     w_soft = ops.LinearFn.apply(rnn.weight_ih_l0[:, :E].contiguous(), decoder.emb.weight, None).contiguous()   # [3H,V]
     hs = torch.empty(2, N, H, device=dev, dtype=torch.float32)
     hs[0].copy_(zc)
+    cs = torch.zeros(2, N, H, device=dev, dtype=torch.float32) if lstm else None
     sz = decoder.skip_term(zc)
     logits = torch.empty(N, V, device=dev, dtype=torch.float32)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
@@ -192,11 +195,18 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
     soft = None
     for i in range(max_len):
         if soft is None:
-            ops.gru_step(tok, tab, rowc, hs[0], hs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
+            if lstm:
+                ops.lstm_step(tok, tab, rowc, hs[0], cs[0], hs[1], cs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
+            else:
+                ops.gru_step(tok, tab, rowc, hs[0], hs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
         else:
             dense = ops.LinearFn.apply(soft, w_soft, rnn.bias_ih_l0).contiguous()
-            call("cpg_gru_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
-                 _p(hs), None, 0, N, None, _stream())
+            if lstm:
+                call("cpg_lstm_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
+                     _p(hs), _p(cs), None, _stream())
+            else:
+                call("cpg_gru_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
+                     _p(hs), None, 0, N, None, _stream())
         _fc(decoder, hs[1], logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         soft = torch.softmax(logits / temp, dim=1)
         if mode == "greedy_softmax":
@@ -211,6 +221,8 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
         ids.append(t)
         softs.append(soft)
         hs[0].copy_(hs[1])
+        if lstm:
+            cs[0].copy_(cs[1])
         if mode != "none_softmax" and (i % 4) == 3 and len(ids) >= min_length and bool(finished.all()):
             # the reference tests this every step; steps run past the break only add all-<pad> columns, cut below
             break
@@ -272,6 +284,8 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
     n_active = torch.zeros(max_len, **i32)
     logits = torch.empty(K * N, V, device=dev, dtype=torch.float32)
     steps_run = 0
+    prof = ops._prof("decode_step_chain", max_len, T=max_len, B=K * N, H=H, ndir=K)
+    prof.__enter__()
     for i in range(max_len):
         if lstm:
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
@@ -286,6 +300,8 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
         steps_run = i + 1
         if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early
             break
+    prof.launches = steps_run
+    prof.__exit__(None, None, None)
     return hist_tok[:steps_run], hist_prev[:steps_run], hist_score[:steps_run]
 
 

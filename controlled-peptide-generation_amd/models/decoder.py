@@ -145,9 +145,26 @@ class GRUDecoder(nn.Module):
     def forward_sample(self, sampleSoft, sampleHard, z, c, h):
         """One decode step (reference signature, decoder.py:86-109): h is [1,N,H]; returns logits [N,V], h [1,N,H].
         sampleSoft [N,V] (a softmax row, or zeros) takes the soft-embedding branch; inference only (no autograd tape)."""
-        if self.cell != 'gru':
-            raise NotImplementedError('forward_sample keeps the reference signature (h only); LSTM decoding goes through cpg.decode')
         zc = self.init_hidden(z, c)
+        if self.cell == 'lstm':
+            # LSTM extension: the state is torch.nn.LSTM's pair - h = (h [1,N,H], c [1,N,H]) in, the same pair out
+            assert isinstance(h, (tuple, list)) and len(h) == 2, "LSTM decoder: pass the state as (h, c), as torch.nn.LSTM takes it"
+            with torch.no_grad():
+                tab, rowc = self._tables(zc)
+                h_prev, c_prev = h[0][0].contiguous(), h[1][0].contiguous()
+                N, H = h_prev.shape
+                hs, cs = torch.stack([h_prev, torch.empty_like(h_prev)]), torch.stack([c_prev, torch.empty_like(c_prev)])
+                if sampleSoft is not None:
+                    E = self.emb.weight.shape[1]
+                    w_soft = ops.LinearFn.apply(self.rnn.weight_ih_l0[:, :E].contiguous(), self.emb.weight, None)
+                    dense = ops.LinearFn.apply(sampleSoft.float().contiguous(), w_soft.contiguous(), self.rnn.bias_ih_l0)
+                    ops.call("cpg_lstm_seq_fwd", 1, N, H, 0, ops._p(self.rnn.weight_hh_l0), ops._p(self.rnn.bias_hh_l0), None, None,
+                             ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), ops._p(cs), None, ops._stream())
+                else:
+                    ops.lstm_step(sampleHard.to(torch.int32).contiguous(), tab, rowc, hs[0], cs[0], hs[1], cs[1],
+                                  self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
+                logits = self.project(hs[1], self.skip_term(zc))
+            return logits, (hs[1].unsqueeze(0), cs[1].unsqueeze(0))
         with torch.no_grad():
             tab, rowc = self._tables(zc)
             h_prev = h[0].contiguous()

@@ -204,7 +204,7 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
     return [o[0] for o in out], [o[1] for o in out]
 
 
-def soft_sample(P, z, c, max_len, mode, temp=1.0, min_length=1, sampled=None):
+def soft_sample(P, z, c, max_len, mode, temp=1.0, min_length=1, sampled=None, cell="gru"):
     """RNN_VAE.sample_G soft modes, models/model.py:337-359 with decoder.forward_sample's soft branch (decoder.py:87-89) and
     mutils.soft_embed (:39-45).  mode: 'none_softmax' | 'greedy_softmax' | 'categorical_softmax' (the hard draws of the
     latter are passed in as `sampled` [N, 1+steps], column 0 = <start>, to replay a recorded run).
@@ -226,7 +226,13 @@ def soft_sample(P, z, c, max_len, mode, temp=1.0, min_length=1, sampled=None):
         e = emb_w[tok] if soft_in is None else (soft_in @ emb_w).astype(F32)
         x = np.concatenate([e, zc], 1).astype(F32)
         gi = (x @ w_ih.T + b_ih).astype(F32)
-        h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        if cell == "lstm":   # the LSTM extension's cell (torch.nn.LSTM semantics, c0 = 0); not a reference component
+            from .lstm import lstm_cell_fwd
+            if i == 0:
+                cst = np.zeros_like(h)
+            h, cst, _ = lstm_cell_fwd(gi, h, cst, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        else:
+            h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
         logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
         sm = _log_softmax((logits / F32(temp)).astype(F32))
         soft = np.exp(sm).astype(F32)

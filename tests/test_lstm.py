@@ -337,3 +337,45 @@ def test_lstm_model_step_vs_torch_ref(B, He, Z, T, layers):
         np.testing.assert_allclose(got, want, atol=2e-6 + 1e-4 * np.abs(want).max(), rtol=0, err_msg=k)
         checked += 1
     assert checked == len(G)
+
+
+@pytest.mark.gpu
+def test_lstm_soft_modes_and_forward_sample_vs_oracle():
+    """The soft sampling modes (models/model.py:337-359) and the single decode step forward_sample (models/decoder.py:86-109) with
+    cell='lstm': ids exact and soft rows 2e-5 against oracle.decode.soft_sample(cell='lstm'); forward_sample takes and returns the
+    state as torch.nn.LSTM's (h, c) pair and one call equals one step of the greedy decode.  Extension: parity unpinned."""
+    import bench
+    from models.model import RNN_VAE
+    from oracle import decode as odec
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    m = RNN_VAE(n_vocab=24, max_seq_len=25, **bench.model_kwargs(46, 32, cell='lstm')).to(dev)
+    m.device = dev
+    with torch.no_grad():
+        m.decoder.fc[1].weight.mul_(6.0)
+        m.decoder.fc[1].bias[3] += 1.0
+    P = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    rs = np.random.RandomState(4)
+    N = 40
+    z = rs.randn(N, 46).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+    zt, ct = torch.from_numpy(z).to(dev), torch.from_numpy(c).to(dev)
+    for mode, temp in (("greedy_softmax", 1.0), ("greedy_softmax", 0.7), ("none_softmax", 1.0)):
+        (ids, soft), _, _ = m.generate_sentences(N, zt, ct, sample_mode=mode, temp=temp)
+        ref_ids, ref_soft = odec.soft_sample(P, z, c, 25, mode, temp=temp, cell="lstm")
+        assert np.array_equal(ids.cpu().numpy(), ref_ids), mode
+        np.testing.assert_allclose(soft.cpu().numpy(), ref_soft, atol=2e-5, err_msg=mode)
+    # forward_sample: (h, c) in, (h, c) out; first greedy step
+    m.eval()
+    h0 = m.decoder.init_hidden(zt, ct).unsqueeze(0)
+    tok = torch.full((N,), 2, device=dev, dtype=torch.long)
+    logits, (h1, c1) = m.decoder.forward_sample(None, tok, zt, ct, (h0, torch.zeros_like(h0)))
+    ref_logits, ref_h, ref_c = odec.lstm_decoder_step(P, np.full(N, 2), np.concatenate([z, c], 1), np.concatenate([z, c], 1), np.zeros((N, 48), np.float32))
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, atol=2e-5)
+    np.testing.assert_allclose(h1[0].cpu().numpy(), ref_h, atol=5e-6)
+    np.testing.assert_allclose(c1[0].cpu().numpy(), ref_c, atol=5e-6)
+    with pytest.raises(AssertionError):
+        m.decoder.forward_sample(None, tok, zt, ct, h0)          # a bare h is the GRU decoder's form
