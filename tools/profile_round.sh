@@ -5,7 +5,7 @@
 #   2. PMC passes (tools/pmc_run.sh: SQ / LDS / FETCH_SIZE / WRITE_SIZE, separate runs) over the training leg only
 #      -> per-kernel counter means as JSON (profiles/<tag>_pmc.json is what bench.py reads `roofline.traffic` from)
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
