@@ -172,7 +172,7 @@ def _l1_kink_correction(G, aux, lv_hip, P, lam_l1, slack, tag):
     """|logvar|_1 is not differentiable at 0.  An element of logvar that the oracle puts within float32 rounding of zero may come
     out with the other sign on the HIP path (mu / logvar agree to ~1e-6, not to the last bit); its d logvar then differs by
     (sign_hip - sign_oracle) lam_l1 / B - a real, correct difference of two valid sub-gradients.  With B x Z ~ 10^6 elements this
-    happens (config C at B = 1024).  The flips are identified exactly, REQUIRED to sit at the kink (|logvar| < 1e-5 on both
+    happens (config C at B = 1024).  The flips are identified exactly, REQUIRED to sit at the kink (|logvar| below the test's own mu / logvar bar on both
     sides), and the oracle's q_logvar gradients are moved to the HIP path's sub-gradient (rank-one terms d * h_b); what reaches the
     rest of the encoder through d h = d logvar W_logvar gets a slack bounded by the flips' total weight."""
     lv_ref = aux["logvar"]
@@ -180,7 +180,8 @@ def _l1_kink_correction(G, aux, lv_hip, P, lam_l1, slack, tag):
     flips = np.argwhere(np.sign(lv_hip) != np.sign(lv_ref))
     if not len(flips):
         return
-    assert np.abs(lv_ref[flips[:, 0], flips[:, 1]]).max() < 1e-5 and np.abs(lv_hip[flips[:, 0], flips[:, 1]]).max() < 1e-5, \
+    thr = 2e-5 + slack.get("mu", 0.0)    # the bar mu / logvar themselves are held to in this test (wider in the chaotic x8 regime)
+    assert np.abs(lv_ref[flips[:, 0], flips[:, 1]]).max() < thr and np.abs(lv_hip[flips[:, 0], flips[:, 1]]).max() < thr, \
         "logvar signs differ away from zero: not an L1-kink effect"
     assert len(flips) <= 64
     Wk, bk = "encoder.q_logvar.weight", "encoder.q_logvar.bias"
