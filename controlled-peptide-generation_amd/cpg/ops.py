@@ -628,6 +628,12 @@ def gates_dtype(B, H, ragged=False):
     return torch.bfloat16 if query("cpg_gru_gates_bf16", B, H, int(bool(ragged))) == 1 else torch.float32
 
 
+def dg_dtype(B, H, V, ragged=False):
+    """Element type of a GRU sequence's gate gradients dG [T,B,4H]: bf16 in the bf16 compute mode where every consumer of dG has a
+    bf16 form (cpg_gru_dg_bf16: dense batch, H % 128 == 0, B % 128 == 0, token table of 0 < V <= 31 rows), f32 otherwise."""
+    return torch.bfloat16 if query("cpg_gru_dg_bf16", int(B), int(H), int(bool(ragged)), int(V)) == 1 else torch.float32
+
+
 def _check_gates(gates, B, H, ragged=False):
     if gates is not None and gates.dtype != gates_dtype(B, H, ragged):
         raise CpgError("saved gates are %s but the library now expects %s: compute mode / options changed between the forward "
@@ -720,14 +726,17 @@ class GruSeqFn(Function):
         has_tab, has_rowc, has_dense, has_h0 = ctx.has
         step_rows = ctx.step_rows
         # ragged batch: gradient rows of dead (t,row) pairs are not written but are read by the reductions below
-        dG = (torch.zeros if step_rows is not None else torch.empty)(T, B, 4 * H, device=dev, dtype=torch.float32)
+        # bf16 gradient storage (bf16 compute mode): decided HERE, together with the saved gates' type, and handed to every consumer
+        dgt = dg_dtype(B, H, ctx.V if has_tab else 0, step_rows is not None) if (gates is not None and gates.dtype == torch.bfloat16) else torch.float32
+        dgb = int(dgt == torch.bfloat16)
+        dG = (torch.zeros if step_rows is not None else torch.empty)(T, B, 4 * H, device=dev, dtype=dgt)
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # receives W_hh^T for the direct-to-LDS step kernel
         _check_gates(gates, B, H, step_rows is not None)
         with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
             call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                 _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _stream())
+                 _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), dgb, _stream())
         if has_h0 and not ctx.tail:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -737,7 +746,7 @@ class GruSeqFn(Function):
         # with a token table, its gradient and the column sums of dG (= the b_hh gradient) come out of one pass over dG
         dsum = torch.empty(4 * H, device=dev, dtype=torch.float32) if has_tab else None
         if has_tab or has_rowc:
-            call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(),
+            call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(), dgb,
                  _stream())
         dl = ctx.defer_req
         defer = dl if (dl is not None and DEFER_WGRAD and OVERLAP and _grad_buf(dl[0]) is not None and _grad_buf(dl[1]) is not None) else None
@@ -753,7 +762,7 @@ class GruSeqFn(Function):
                 # whole CUs to the main stream's small launches.
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H)):
                     call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
-                         None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _stream())
+                         None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), dgb, _stream())
                 if has_tab:
                     defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
@@ -770,11 +779,11 @@ class GruSeqFn(Function):
             db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
             with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                 call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
-                     ws.numel(), _stream())
+                     ws.numel(), dgb, _stream())
         ddense = None
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
-            ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2)
+            ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2).float()
         return None, dtab, drowc, ddense, dh0, dw_hh, db_hh, None, None, None, None, None
 
 
@@ -833,14 +842,16 @@ class GruBiSeqFn(Function):
         else:
             ext_f = g_hs_f.contiguous().view(-1)[BH:] if g_hs_f is not None else None      # slots 1..T
             ext_r = g_hs_r.contiguous().view(-1)[:T * BH] if g_hs_r is not None else None  # slots 0..T-1
-        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        dgt = dg_dtype(B, H, ctx.V if ctx.has_tab else 0) if (gt_f is not None and gt_f.dtype == torch.bfloat16) else torch.float32
+        dgb = int(dgt == torch.bfloat16)   # bf16 gradient storage (bf16 compute mode; see GruSeqFn.backward)
+        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
+        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
         _check_gates(gt_f, B, H)
         with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
             call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), dgb, _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []
@@ -851,18 +862,18 @@ class GruBiSeqFn(Function):
             if ctx.has_tab:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                     call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, int(gw is not None), _p(ws), ws.numel(),
-                         _stream())
+                         dgb, _stream())
                 if gw is not None:
                     dw = None
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
                 dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
-                call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
+                call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(), dgb,
                      _stream())
                 db = dsum[:3 * H]
             else:
                 db = torch.empty(3 * H, device=dev, dtype=torch.float32)
-                call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), _stream())
-            ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2) if ctx.has_dense else None
+                call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), 0, _stream())
+            ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2).float() if ctx.has_dense else None
             outs.append((dtab, ddense, dw, db))
         (dtab_f, dd_f, dw_f, db_f), (dtab_r, dd_r, dw_r, db_r) = outs
         return None, dtab_f, dtab_r, dd_f, dd_r, dw_f, db_f, dw_r, db_r, None, None

@@ -9,8 +9,9 @@ int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const 
 int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int M, int N, int K, int accumulate,
                 const uint8_t* cmask, float cms, hipStream_t s);
 // dW[N,Kd] (+)= dY[Mr,N]^T (X .* xmask*xms)[Mr,Kd]
+// dy_bf16: dY holds bf16 elements (lddy in elements): the dW_hh product on bf16 gate gradients (bf16 compute mode)
 int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
-                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16 = 0);
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd);
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_colsum_workspace(int M, int N);
@@ -18,15 +19,17 @@ size_t cpg_colsum_workspace(int M, int N);
 // token-grouped / over-time reductions of the input-side gate gradients (+ dsum[4H] = column sums of dG);
 // lstm=1: 4H identity-mapped columns
 int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
-                        float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                        float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream, int dg_bf16 = 0);
 
 // 0 = f32-grade products, 1 = bf16 recurrent products (cpg_set_compute_mode, api.hip)
 int cpg_compute_mode_get();
 // saved gates of a GRU sequence stored as bf16 (gru.hip): bf16 compute mode, dense batches on shapes the direct-to-LDS backward covers
 bool cpg_gru_store_bf16(int B, int H, bool dense);
+// ... and the gate gradients dG too (bf16 gradient storage; V = rows of the sequence's token table, 0 = none)
+bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 309
+#define CPG_ABI_VERSION 310
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).
@@ -45,6 +48,7 @@ enum CpgOpt {
     OPT_DGI_MODE,         // input-side reductions: "mfma" (default) | "fused" | "gemm"
     OPT_MMD_DL,           // 0: register-staged Gram launch of the full-kernel MMD
     OPT_BF16_STORE,       // 0: f32 saved gates in the bf16 compute mode too (default there: bf16, see cpg_gru_gates_bf16)
+    OPT_BF16_DG,          // 0: f32 gate gradients in the bf16 compute mode too (default there: bf16 where covered, see cpg_gru_dg_bf16)
     OPT__COUNT
 };
 struct CpgOptVal {

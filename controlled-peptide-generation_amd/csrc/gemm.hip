@@ -24,6 +24,7 @@ struct GemmArgs {
     int k_chunk;        // split-K: blockIdx.z handles [z*k_chunk, min(K,(z+1)*k_chunk)), writes slab z
     size_t slab_stride; // floats between slabs (0 when not split)
     int pairs_a = 0, pairs_b = 0;  // 8-byte pairs of the scalar staging path are safe (OpA::pairs), set by launch_gemm
+    int a_bf16 = 0;                // A holds bf16 elements (OpA::bf16): the dW_hh product on bf16 gate gradients
 };
 
 // PREC: 7 = f32-grade, 1 = bf16 compute mode (cpg_set_compute_mode(1)); only the transposed-use (dW = dY^T X) products run on
@@ -32,10 +33,10 @@ template <class TC, bool A_KC, bool B_KC, int PREC>
 constexpr int gemm_split() {
     return (!A_KC && !B_KC && CPG_TN_PRODUCT_SPLIT == 7) ? PREC : 0;
 }
-template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC = 7>
-using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, B_KC, PREC>()>;
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC = 7, bool A_BF16 = false>
+using GemmLoop = MainLoop<TC, A_KC, B_KC, VEC, VEC, MASKS, gemm_split<TC, A_KC, B_KC, PREC>(), A_BF16>;
 
-template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC>
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC, bool A_BF16 = false>
 __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     int bx, by, bz;
     xcd_tile_order<PREC == 1>(bx, by, bz);
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     }
     const size_t aoff = A_KC ? (size_t)kb : (size_t)kb * g.lda;
     const size_t boff = B_KC ? (size_t)kb : (size_t)kb * g.ldb;
-    OpA a{g.A + aoff, g.lda, m0, g.M, g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a};
+    OpA a{g.a_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g.A) + aoff) : g.A + aoff, g.lda, m0, g.M,
+          g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a, g.a_bf16};
     OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale, g.pairs_b};
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     // transposed-operand products (dW = dY^T X: the 80 GFLOP dW_hh product) run on split bf16 operands, see gemm_core.h
-    GemmLoop<TC, A_KC, B_KC, VEC, MASKS, PREC>::run(a, b, K, acc);
+    GemmLoop<TC, A_KC, B_KC, VEC, MASKS, PREC, A_BF16>::run(a, b, K, acc);
     float* C = g.C + (size_t)bz * g.slab_stride;
     const bool plain = g.k_chunk == 0;
 #pragma unroll
@@ -135,6 +137,21 @@ static int launch_tc_p(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
                              reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, false, false, PREC>)};
         const int rc = cpg_allow_big_lds(ks[(vec ? 0 : 2) + (masks ? 0 : 1)], (int)smem);
         if (rc) return rc;
+    }
+    if constexpr (!A_KC && !B_KC) {
+        if (g.a_bf16) {   // bf16 gate gradients as the dY operand (cpg_gemm_tn checked the alignment conditions of the 16-byte path)
+            if (!vec || masks) {
+                cpg_set_error("gemm: a bf16 dY operand needs the 16-byte staging path and no keep-mask");
+                return -2;
+            }
+            if (smem > 64 * 1024) {
+                const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false, PREC, true>), (int)smem);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false, PREC, true>), grid, dim3(TC::NT), smem, s, g);
+            CPG_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if (vec && masks)
         hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, true, PREC>), grid, dim3(TC::NT), smem, s, g);
@@ -329,18 +346,24 @@ static TnPlan tn_plan(int M, int N, int K) {
 
 // C[N,Kd] (+)= A^T B where A = dY[Mr, N] (ld lddy), B = X[Mr, Kd] (ld ldx); contraction over the Mr rows.
 int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
-                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16) {
     TnPlan p = tn_plan(N, Kd, Mr);
     int S = p.S;
     const size_t slab = (size_t)N * Kd;
     if (S > 1 && ws_bytes < slab * S * sizeof(float)) {
         S = 1;
     }
+    if (dy_bf16 && !(lddy % 4 == 0 && N % 4 == 0 && (((uintptr_t)dY) & 15) == 0 && ldx % 4 == 0 && Kd % 4 == 0 && aligned16(X))) {
+        cpg_set_error("cpg_gemm_tn: bf16 dY needs the 16-byte staging path (aligned bases, leading dimensions and widths multiples of 4)");
+        return -2;
+    }
     if (S <= 1) {
         GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, dW, lddw, nullptr, accumulate, nullptr, 1.f, xmask, xms, nullptr, 1.f, 0, 0};
+        g.a_bf16 = dy_bf16;
         return launch_gemm<false, false>(g, 1, s, p.tile);
     }
     GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, ws, Kd, nullptr, 0, nullptr, 1.f, xmask, xms, nullptr, 1.f, p.k_chunk, slab};
+    g.a_bf16 = dy_bf16;
     int rc = launch_gemm<false, false>(g, S, s, p.tile);
     if (rc) return rc;
     const size_t n = slab;

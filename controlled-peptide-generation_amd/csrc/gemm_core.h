@@ -51,6 +51,8 @@ struct OpA {
     const uint8_t* mask;  // optional keep-mask with the same indexing as p (value = p * (mask ? mscale : 0))
     float mscale;
     int pairs = 0;        // 1: 8-byte pairs of the scalar (non-16-byte) staging path are aligned and never straddle a bound
+    int bf16 = 0;         // 1: p points at bf16 elements (ld, offsets in elements) - transposed-use operands on the 16-byte staging path
+                          // only (the dW_hh product on bf16 gate gradients): four elements = one 8-byte load, widened in registers
 };
 
 struct OpB {
@@ -194,8 +196,12 @@ __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, ui
 //            MFMA slot i of lane group q contracts k = 8q + i for both layouts.
 // (Pre-splitting the weight operand once per call instead of in every tile was tried and measured: no gain - 37.5 vs 37.1 us
 // per forward step - the conversion VALU work is not what bounds the small-tile step kernels.)
-template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC, bool MASKS = false, int SPLIT = 0>
+// A_BF16: the A operand holds bf16 elements in memory (transposed-use operands on the 16-byte staging path only: the dW_hh product
+// on bf16 gate gradients) - four elements are one 8-byte load, widened exactly in registers.  Compile-time: a run-time test in
+// front of every staging load cost the bf16-mode dW_hh launch 200 us (round 4).
+template <class TC, bool A_KC, bool B_KC, bool AVEC, bool BVEC, bool MASKS = false, int SPLIT = 0, bool A_BF16 = false>
 struct MainLoop {
+    static_assert(!A_BF16 || (!A_KC && AVEC && !MASKS), "bf16 A operands: transposed use, 16-byte staging path, no mask");
     static constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK;
     static constexpr int LDA = TC::template lda<A_KC, B_KC>();
     static constexpr int LDB = TC::template ldb<B_KC, A_KC>();
@@ -310,7 +316,8 @@ struct MainLoop {
     //  four predicates: half the memory instructions and a third of the VALU work of the scalar path, which the exact-f32
     //  MFMA cannot overlap with)
     __device__ static __forceinline__ float4 fetch(const float* p, const uint8_t* mask, size_t base, int n, bool rok, int ld,
-                                                   int k0, int K, int kk_xc, unsigned& okbits, uchar4& mk, bool pairs) {
+                                                   int k0, int K, int kk_xc, unsigned& okbits, uchar4& mk, bool pairs, bool src_bf16 = false,
+                                                   bool raw = false) {
         if (KC) {
             const int nk = K - (k0 + n);  // n = 4*kq
             if (VEC) {
@@ -348,6 +355,13 @@ struct MainLoop {
                 okbits = ok ? 0xFu : 0u;
                 const size_t o = ok ? base + (size_t)k0 * ld : 0;
                 if (MASKS && mask) mk = *reinterpret_cast<const uchar4*>(mask + o);
+                if (src_bf16) {   // four bf16 = 8 bytes; widening is exact, and the bf16-mode store rounds them back to themselves
+                    const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + o);
+                    // raw: the one-plane (bf16 mode) store takes the two packed pairs as they are - no widening, no re-rounding
+                    if (raw) return make_float4(__builtin_bit_cast(float, w.x), __builtin_bit_cast(float, w.y), 0.f, 0.f);
+                    return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+                }
                 return *reinterpret_cast<const float4*>(p + o);
             }
             if (pairs && !(MASKS && mask)) {
@@ -380,7 +394,7 @@ struct MainLoop {
         for (int i = 0; i < TC::AV; ++i) {
             int kk, xq_;
             xc_index<BM>(i, kk, xq_);
-            st.a[i] = fetch<A_KC, AVEC>(a.p, a.mask, pl.a[i], pl.an[i], pl.aok[i], a.ld, k0, K, kk, st.aok[i], st.am[i], a.pairs != 0);
+            st.a[i] = fetch<A_KC, AVEC>(a.p, a.mask, pl.a[i], pl.an[i], pl.aok[i], a.ld, k0, K, kk, st.aok[i], st.am[i], a.pairs != 0, A_BF16, A_BF16 && NP == 1);
         }
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) {
@@ -417,7 +431,8 @@ struct MainLoop {
             w1 = w2 = 0u;
         }
     }
-    template <bool KC, int BX, int NV, int PLW, int SX>
+    // RAW: r[i].x / .y already ARE the two packed bf16 pairs of the four elements (bf16 operand in memory, one-plane mode)
+    template <bool KC, int BX, int NV, int PLW, int SX, bool RAW = false>
     __device__ static __forceinline__ void sstore7_op(uint32_t* dst, const float4 (&r)[NV]) {
         const int tid = threadIdx.x;
         if (KC) {
@@ -438,9 +453,14 @@ struct MainLoop {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int v = tid + i * TC::NT, kk = v / (BX / 4), xq = v % (BX / 4);
-                uint32_t a0, a1, a2, b0, b1, b2;
-                split_pair(r[i].x, r[i].y, a0, a1, a2);
-                split_pair(r[i].z, r[i].w, b0, b1, b2);
+                uint32_t a0, a1 = 0, a2 = 0, b0, b1 = 0, b2 = 0;
+                if constexpr (RAW) {
+                    a0 = __builtin_bit_cast(uint32_t, r[i].x);
+                    b0 = __builtin_bit_cast(uint32_t, r[i].y);
+                } else {
+                    split_pair(r[i].x, r[i].y, a0, a1, a2);
+                    split_pair(r[i].z, r[i].w, b0, b1, b2);
+                }
                 uint32_t* q = dst + (xq >> 2) * TRW + kk * 8 + (xq & 3) * 2;
                 *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
                 if (NP == 3) {
@@ -472,7 +492,7 @@ struct MainLoop {
         float4 ra[TC::AV], rb[TC::BV];
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) ra[i] = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
-        sstore7_op<A_KC, BM, TC::AV, APL, SXA>(As, ra);
+        sstore7_op<A_KC, BM, TC::AV, APL, SXA, A_BF16 && NP == 1>(As, ra);
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) rb[i] = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
         sstore7_op<B_KC, BN, TC::BV, BPL, SXB>(Bs, rb);
@@ -797,6 +817,10 @@ __device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int
 // `hook` runs once ahead of slab hook_kt (the caller's own global loads; < 0: never).  smem: smem_floats() floats.
 // PREC = 1 ("bf16 compute mode"): each lane's eight slab values per block row are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) after
 // the fragment read and ONE v_mfma_f32_16x16x32_bf16 per block consumes the slab - same LDS image and reads as PREC = 0.
+// PREC = 2 (bf16 compute mode on operands that ARE bf16 in memory: the bf16 gradient storage of round 4): a slab is 64 k deep, so a
+// row is again 128 bytes = eight 16-byte chunks - the LDS image, the LDS-DMA pattern and the swizzle are those of the f32 slab;
+// chunk q of a row now holds k = 8q .. 8q+7, which is exactly the A / B fragment of v_mfma_f32_16x16x32_bf16 for lane group
+// q & 3 of k-block q >> 2: the two ds_read_b128 of a block row feed two MFMAs, no conversion, half the bytes per k.
 template <int BM, int BN, int NS = 3, int PREC = 0>
 struct DlLoop {
     static constexpr int MI = BM / 32, NI = BN / 32;
@@ -805,27 +829,31 @@ struct DlLoop {
     static constexpr int AHEAD = NS - 1;
     static constexpr size_t smem_floats() { return (size_t)NS * SF; }
 
-    template <class Hook>
-    __device__ static __forceinline__ void run(const float* A, size_t lda, const float* Bt, size_t ldb, int K, float* smem,
+    // E: element type of the operands in memory - float (PREC 0 / 1) or uint16_t = bf16 (PREC 2); K, lda, ldb count elements
+    template <class Hook, class E>
+    __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
                                                f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook) {
+        static_assert((PREC == 2) == (sizeof(E) == 2), "PREC 2 <-> bf16 operands in memory");
+        constexpr int EPC = 16 / (int)sizeof(E);   // elements per 16-byte chunk
+        constexpr int BKE = 8 * EPC;               // elements per slab (a row of a slab is always 128 bytes)
         // (a 512-thread workgroup runs two of these loops side by side - its two 256-thread halves, each on its own ring and its
         // own half of K: gru_step_bwd_dl2_kernel; the slab barrier is the workgroup's)
         const int tid = threadIdx.x & 255, lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
-        const int KT = K / 32;
+        const int KT = K / BKE;
         // this thread's 16-byte pieces of a slab: piece i covers row = 32 i + tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
         const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);   // f(32 i + r) = f(r)
-        const float* ga = A + (size_t)srow * lda + 4 * sch;
-        const float* gb = Bt + (size_t)srow * ldb + 4 * sch;
+        const E* ga = A + (size_t)srow * lda + EPC * sch;
+        const E* gb = Bt + (size_t)srow * ldb + EPC * sch;
         const size_t ga32 = 32 * lda, gb32 = 32 * ldb;
         auto issue = [&](int kt, float* stage) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                __builtin_amdgcn_global_load_lds(ga + i * ga32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(ga + i * ga32 + kt * BKE, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * 32, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * BKE, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
         };
         // fragment word offsets inside a stage (slab-invariant): row r of block mi / ni, k-chunk q = 4h + lq -> slot q ^ f(r)
         const int ra = wm * (BM / 2) + l15, rbn = wn * (BN / 2) + l15;
@@ -848,7 +876,26 @@ struct DlLoop {
             }
             __builtin_amdgcn_s_barrier();
             if (kt + AHEAD < KT) issue(kt + AHEAD, refill);
-            if constexpr (PREC == 1) {
+            if constexpr (PREC == 2) {
+                cpg_bf16x8 fa[2][MI], fb[2][NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    fa[0][mi] = *reinterpret_cast<const cpg_bf16x8*>(cur + oa0 + mi * 512);
+                    fa[1][mi] = *reinterpret_cast<const cpg_bf16x8*>(cur + oa1 + mi * 512);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    fb[0][ni] = *reinterpret_cast<const cpg_bf16x8*>(cur + ob0 + ni * 512);
+                    fb[1][ni] = *reinterpret_cast<const cpg_bf16x8*>(cur + ob1 + ni * 512);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h][mi], fb[h][ni], acc[mi][ni], 0, 0, 0);
+            } else if constexpr (PREC == 1) {
                 cpg_bf16x8 fa[MI], fb[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {

@@ -23,6 +23,8 @@
 
 typedef uint32_t pk_u32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int DM_ROWS_C = 128, DM_VMAX_C = 31;   // batch rows per workgroup / largest token table of dgi_mfma_kernel (asserted there)
+
 struct GruFwdArgs {
     const float* h_prev;
     const float* w_hh;
@@ -172,6 +174,7 @@ struct GruBwdArgs {
     const int32_t* nrows_next;  // rows live at step s+1: beyond them dG_next / dH_next were never written
     int ep_step;                // (even) slab spacing of the staggered epilogue-operand fetch; 0: every workgroup ahead of slab 0
     int gates_bf16;             // gates hold bf16 elements (bf16 compute mode, direct-to-LDS kernels only)
+    int dg_bf16;                // bf16 gradient storage (implies gates_bf16): dG_next / dG_out hold bf16 [B,4H], w_hhT bf16 [H,3H]
 };
 
 struct GruBwdPair {
@@ -349,7 +352,7 @@ using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 // values of an element are one 8-byte group, so a lane's four elements are 32 contiguous bytes: two loads instead of four.
 template <int PREC>
 __device__ __forceinline__ void ld_gates4(const float* gates, size_t BH, size_t o, int bf, f32x4* sv) {
-    if constexpr (PREC == 1) {
+    if constexpr (PREC >= 1) {
         if (bf) {
             const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(gates) + 4 * o);
             const uint4 w0 = p[0], w1 = p[1];   // (r|z, n|hn) of elements 0,1 and 2,3
@@ -366,7 +369,28 @@ __device__ __forceinline__ void ld_gates4(const float* gates, size_t BH, size_t 
     for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const f32x4*>(gates + q * BH + o);
 }
 
-// PREC 1: bf16 compute mode (operands rounded at the fragment read, one bf16 MFMA per block and slab)
+// dG row segment of a lane: four consecutive columns of each of the four gate-gradient blocks.  PREC 2 (bf16 gradient storage): the
+// values are rounded to bf16 (RNE) HERE - the rounding the bf16 mode's consumers applied to the f32 values when they read them (the
+// next step's fragment read, the dW_hh product's LDS store): the BPTT chain and dW_hh see the same operands as with f32 storage.
+template <int PREC>
+__device__ __forceinline__ void st_dg4(float* dG_out, size_t row, int H, int col, const f32x4 v0, const f32x4 v1, const f32x4 v2, const f32x4 v3) {
+    if constexpr (PREC == 2) {
+        uint16_t* d = reinterpret_cast<uint16_t*>(dG_out) + row * 4 * H + col;
+        *reinterpret_cast<uint2*>(d) = make_uint2(cvt_pk_bf16(v0[0], v0[1]), cvt_pk_bf16(v0[2], v0[3]));
+        *reinterpret_cast<uint2*>(d + H) = make_uint2(cvt_pk_bf16(v1[0], v1[1]), cvt_pk_bf16(v1[2], v1[3]));
+        *reinterpret_cast<uint2*>(d + 2 * H) = make_uint2(cvt_pk_bf16(v2[0], v2[1]), cvt_pk_bf16(v2[2], v2[3]));
+        *reinterpret_cast<uint2*>(d + 3 * H) = make_uint2(cvt_pk_bf16(v3[0], v3[1]), cvt_pk_bf16(v3[2], v3[3]));
+    } else {
+        float* d = dG_out + row * 4 * H + col;
+        *reinterpret_cast<f32x4*>(d) = v0;
+        *reinterpret_cast<f32x4*>(d + H) = v1;
+        *reinterpret_cast<f32x4*>(d + 2 * H) = v2;
+        *reinterpret_cast<f32x4*>(d + 3 * H) = v3;
+    }
+}
+
+// PREC 1: bf16 compute mode (operands rounded at the fragment read, one bf16 MFMA per block and slab); PREC 2: the same arithmetic on
+// bf16 gradient storage (dG and W_hh^T are bf16 in memory: DlLoop's 64-deep slabs)
 template <int BM, int BN, int NS, int PREC = 0>
 __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
     using DL = DlLoop<BM, BN, NS, PREC>;
@@ -415,8 +439,13 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
     if (g.dG_next && !(CPG_DL_ABLATE & 4)) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
-        DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
-                min(phase * g.ep_step, 3 * H / 32 - 1), load_ep);
+        if constexpr (PREC == 2)
+            DL::run(reinterpret_cast<const uint16_t*>(g.dG_next) + (size_t)m0 * 4 * H, (size_t)4 * H,
+                    reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
+                    min(phase * (g.ep_step / 2), 3 * H / 64 - 1), load_ep);
+        else
+            DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
+                    min(phase * g.ep_step, 3 * H / 32 - 1), load_ep);
     } else {
         load_ep();
     }
@@ -434,11 +463,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
             const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
             const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
-            float* d = g.dG_out + (size_t)row * 4 * H + col;
-            *reinterpret_cast<f32x4*>(d) = dr_pre;
-            *reinterpret_cast<f32x4*>(d + H) = dz_pre;
-            *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
-            *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+            st_dg4<PREC>(g.dG_out, (size_t)row, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre);
         }
 }
 
@@ -493,8 +518,13 @@ __global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
         const int Kh = 3 * H / 2;
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
-        DL::run(g.dG_next + (size_t)m0 * 4 * H + kg * Kh, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H + kg * Kh, (size_t)3 * H, Kh,
-                ring, acc, min(phase * (g.ep_step / 2), Kh / 32 - 1), load_ep);
+        if constexpr (PREC == 2)
+            DL::run(reinterpret_cast<const uint16_t*>(g.dG_next) + (size_t)m0 * 4 * H + kg * Kh, (size_t)4 * H,
+                    reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 3 * H + kg * Kh, (size_t)3 * H, Kh, ring, acc,
+                    min(phase * (g.ep_step / 4), Kh / 64 - 1), load_ep);
+        else
+            DL::run(g.dG_next + (size_t)m0 * 4 * H + kg * Kh, (size_t)4 * H, g.w_hhT + (size_t)j0 * 3 * H + kg * Kh, (size_t)3 * H, Kh,
+                    ring, acc, min(phase * (g.ep_step / 2), Kh / 32 - 1), load_ep);
         __syncthreads();   // every fragment read of the rings is done: their first 16 KB carry the swap
         f32x4* const xb = reinterpret_cast<f32x4*>(cpg_smem);
 #pragma unroll
@@ -518,11 +548,7 @@ __global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
         const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
         const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
         const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
-        float* d = g.dG_out + (size_t)rb * 4 * H + col;
-        *reinterpret_cast<f32x4*>(d) = dr_pre;
-        *reinterpret_cast<f32x4*>(d + H) = dz_pre;
-        *reinterpret_cast<f32x4*>(d + 2 * H) = dn_pre * rg;
-        *reinterpret_cast<f32x4*>(d + 3 * H) = dn_pre;
+        st_dg4<PREC>(g.dG_out, (size_t)rb, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre);
     }
 }
 
@@ -695,7 +721,18 @@ bool cpg_gru_store_bf16(int B, int H, bool dense) {
     if (o.set && o.i == 0) return false;
     return dense && H % 4 == 0 && bwd_dl_shape_ok(0, B, H);
 }
-// element e of a saved-gates buffer
+// Gate GRADIENTS (dG) stored as bf16 as well - "bf16 gradient storage": where the saved gates are bf16 (above), the width suits the
+// 64-deep slabs of the bf16-operand loop (both halves of the two-K-halves kernel: H % 128 == 0) and every consumer of dG has a bf16
+// form: the next step's operand (DlLoop PREC 2), the dW_hh product (bf16 A operand), the one-pass input-side reduction
+// (dgi_mfma_kernel: token table of V <= 31 rows, 128-row chunks).  Option bf16_dg = 0 keeps f32.  PMC of the f32-storage form
+// (profiles/r04_bf16_summary.md): the paired BPTT launch moves 137 MB at 0.52 of the HBM peak with the matrix pipe 7 % busy.
+bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V) {
+    if (!cpg_gru_store_bf16(B, H, dense)) return false;
+    const CpgOptVal& o = cpg_opt(OPT_BF16_DG);
+    if (o.set && o.i == 0) return false;
+    return H % 128 == 0 && B % DM_ROWS_C == 0 && V > 0 && V <= DM_VMAX_C;
+}
+// element e of a saved-gates / gate-gradient buffer
 static inline float* gate_at(const float* gates, size_t e, bool bf) {
     return const_cast<float*>(bf ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(gates) + e) : gates + e);
 }
@@ -735,11 +772,16 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
                       "scratch, aligned operands, option gru_bwd_dl unchanged since the forward pass)");
         return -4;
     }
+    const bool dgb = a.dg_bf16 != 0;   // bf16 gradient storage: PREC 2 kernels (64-deep slabs: 3H, and 3H/2 for the two-halves form, % 64)
+    if (dgb && (!a.gates_bf16 || (3 * a.H) % 64 != 0 || (pl.kind == BK_DL2 && (3 * a.H / 2) % 64 != 0))) {
+        cpg_set_error("gru backward: bf16 gradient storage needs bf16 saved gates and a width the 64-deep slabs divide (H %% 128 == 0)");
+        return -4;
+    }
     int rc = 0;
     if (pl.kind == BK_DL2) {
-        rc = pl.bf16 ? launch_dl2<1>(pr, nd, s) : launch_dl2<0>(pr, nd, s);
+        rc = dgb ? launch_dl2<2>(pr, nd, s) : pl.bf16 ? launch_dl2<1>(pr, nd, s) : launch_dl2<0>(pr, nd, s);
     } else if (pl.kind == BK_DL) {
-#define CPG_DL_PICK(BM, BN) (pl.bf16 ? launch_dl<BM, BN, 1>(pr, nd, s) : launch_dl<BM, BN, 0>(pr, nd, s))
+#define CPG_DL_PICK(BM, BN) (dgb ? launch_dl<BM, BN, 2>(pr, nd, s) : pl.bf16 ? launch_dl<BM, BN, 1>(pr, nd, s) : launch_dl<BM, BN, 0>(pr, nd, s))
         if (pl.tile.bm == 64 && pl.tile.bn == 64) rc = CPG_DL_PICK(64, 64);
         else if (pl.tile.bm == 64) rc = CPG_DL_PICK(64, 32);
         else if (pl.tile.bn == 64) rc = CPG_DL_PICK(32, 64);
@@ -772,8 +814,24 @@ __global__ void transpose_w_kernel(const float* w, int R, int C, float* out) {
     }
 }
 
-static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s) {
-    hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, wT);
+// the same, rounded to bf16 (RNE): the B operand of the bf16-storage backward step
+__global__ void transpose_w_bf16_kernel(const float* w, int R, int C, uint16_t* out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[i][threadIdx.x] = w[(size_t)r * C + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[(size_t)c * R + r] = (uint16_t)(cvt_pk_bf16(tile[threadIdx.x][i], 0.f) & 0xffffu);
+    }
+}
+
+static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s, bool bf16 = false) {
+    if (bf16) hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, reinterpret_cast<uint16_t*>(wT));
+    else hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, wT);
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -931,6 +989,7 @@ CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, in
 // step_rows), shape covered by the direct-to-LDS backward step.  The caller sizes / types the gates buffer by this answer and keeps
 // the compute mode and options unchanged between the forward and the backward pass of a sequence (the backward refuses otherwise).
 CPG_EXPORT int cpg_gru_gates_bf16(int B, int H, int ragged) { return cpg_gru_store_bf16(B, H, !ragged) ? 1 : 0; }
+CPG_EXPORT int cpg_gru_dg_bf16(int B, int H, int ragged, int V) { return cpg_gru_dg_store_bf16(B, H, !ragged, V) ? 1 : 0; }
 
 CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                                const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
@@ -975,16 +1034,19 @@ CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_
 // dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
 CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                               int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, void* stream) {
+                               int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, int dg_bf16,
+                               void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
     if (w_hhT_scratch && !bwd_wants_wt(row_end - row_begin, H, row_begin, step_rows == nullptr)) w_hhT_scratch = nullptr;  // W_hh as stored
+    const bool gbf = cpg_gru_store_bf16(B, H, step_rows == nullptr);
+    const bool dgb = dg_bf16 != 0;
+    CPG_CHECK_ARG(!dgb || (gbf && w_hhT_scratch && row_begin == 0 && row_end == B));   // bf16 gradient storage: whole dense batches on the direct-to-LDS step
     if (w_hhT_scratch) {
-        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream);
+        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb);
         if (rc) return rc;
     }
-    const bool gbf = cpg_gru_store_bf16(B, H, step_rows == nullptr);
     int prev_t = -1;
     for (int p = T - 1; p >= -1; --p) {  // p = processing index of the step whose dH we form; p=-1 closes with dh0
         if (p < 0 && !dh0) break;
@@ -999,9 +1061,10 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         a.nrows = (step_rows && t >= 0) ? step_rows + t : nullptr;
         a.nrows_next = (step_rows && prev_t >= 0) ? step_rows + prev_t : nullptr;
         a.gates_bf16 = gbf;
+        a.dg_bf16 = dgb;
         const int cur = (p + 2) & 1;
         if (prev_t >= 0) {
-            a.dG_next = dG + (size_t)prev_t * B * 4 * H;
+            a.dG_next = gate_at(dG, (size_t)prev_t * B * 4 * H, dgb);
             a.dH_next = dH_scratch + (size_t)(cur ^ 1) * BH;
         } else {
             a.dG_next = nullptr;
@@ -1013,7 +1076,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
             a.gates = gate_at(gates, (size_t)t * 4 * BH, gbf);
             a.h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
             a.dH_out = dH_scratch + (size_t)cur * BH;
-            a.dG_out = dG + (size_t)t * B * 4 * H;
+            a.dG_out = gate_at(dG, (size_t)t * B * 4 * H, dgb);
         } else {
             a.ext = nullptr;
             a.gates = nullptr;
@@ -1046,11 +1109,12 @@ CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
 
 // dW_hh[3H,H] (+)= sum_t dgh_t^T h_prev(t) ; db_hh[3H] (+)= sum dgh.
 CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
-                                float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                                float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && workspace);
+    CPG_CHECK_ARG(!dg_bf16 || !db_hh);   // bf16 gate gradients: the bias gradient comes out of cpg_gru_dgi_reduce's column sums
     const float* hprev = reverse ? hs + (size_t)B * H : hs;
     int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 3 * H, H, accumulate, (float*)workspace,
-                         workspace_bytes, (hipStream_t)stream);
+                         workspace_bytes, (hipStream_t)stream, dg_bf16);
     if (rc || !db_hh) return rc;  // db_hh null: the caller derives it (shared r,z columns come from the token-table gradient)
     return cpg_colsum(dG, 4 * H, T * B, 3 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1082,7 +1146,9 @@ __global__ void dgi_fused_final_kernel(const float* part_tab, const float* part_
 // the product (block column n <-> dG column 4 n + j) and the lane's running sum over time (drowc, complete rows: no partials).
 // dG is read once, 1 KB per wave and k-step against 8 MFMAs: the matrix pipe can take ~9.8 TB/s of it, HBM delivers ~5.
 constexpr int DM_RW = 32, DM_ROWS = 4 * DM_RW, DM_VMAX = 31;
-template <bool ROWC>
+static_assert(DM_ROWS == DM_ROWS_C && DM_VMAX == DM_VMAX_C, "cpg_gru_dg_store_bf16 states the shape limits of dgi_mfma_kernel");
+// DGBF: dG holds bf16 elements (bf16 gradient storage): a lane's four columns are one 8-byte load, widened exactly to f32
+template <bool ROWC, bool DGBF = false>
 __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const int32_t* tok, int T, int B, int H, int V, int lstm,
                                                         float* part_tab, float* part_sum, float* drowc, int accumulate) {
     __shared__ f32x4 dm_red[3][2][4][64];
@@ -1101,9 +1167,19 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
     auto fetch = [&](int t, f32x4 (&xv)[8], int (&tv)[8]) {
         const int4 t0 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw), t1 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw + 4);
         tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
-        const float* base = dG + ((size_t)t * B + bw) * C4 + col;
+        if constexpr (DGBF) {
+            const uint16_t* base = reinterpret_cast<const uint16_t*>(dG) + ((size_t)t * B + bw) * C4 + col;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) xv[ks] = *reinterpret_cast<const f32x4*>(base + (size_t)ks * C4);
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint2 w = *reinterpret_cast<const uint2*>(base + (size_t)ks * C4);
+                xv[ks] = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                               __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+            }
+        } else {
+            const float* base = dG + ((size_t)t * B + bw) * C4 + col;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) xv[ks] = *reinterpret_cast<const f32x4*>(base + (size_t)ks * C4);
+        }
     };
     fetch(0, x, tk);
     for (int t = 0; t < T; ++t) {
@@ -1176,18 +1252,26 @@ static bool dgi_mfma_ok(int B, int H, int V, const float* dG, const int32_t* tok
 //   dtab[V,3H]  (+)= sum over (t,b) with tok[t,b]==v     (gradient of the token table; null to skip)
 //   drowc[B,3H] (+)= sum over t                          (gradient of the constant-over-time term; null to skip)
 int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
-                        float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                        float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream, int dg_bf16) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG);
     const int NC = lstm ? 4 * H : 3 * H;
     hipStream_t s = (hipStream_t)stream;
     const int rows = T * B;
+    if (dg_bf16 && !((dtab || dsum) && dgi_mfma_ok(B, H, V, dG, tok, drowc, workspace_bytes))) {
+        cpg_set_error("cpg_gru_dgi_reduce: bf16 gate gradients are read by the one-pass matrix-core reduction only (token table of <= %d "
+                      "rows, batch %% %d == 0, H %% 64 == 0, option dgi_mode unset) - cpg_gru_dg_bf16 states the shapes", DM_VMAX, DM_ROWS);
+        return -4;
+    }
     if ((dtab || dsum) && dgi_mfma_ok(B, H, V, dG, tok, drowc, workspace_bytes)) {
         CPG_CHECK_ARG(workspace);
         const int chunks = B / DM_ROWS;
         float* part_tab = (float*)workspace;
         float* part_sum = part_tab + (size_t)chunks * V * 4 * H;
         const dim3 grid(4 * H / 64, chunks);
-        if (drowc) hipLaunchKernelGGL(dgi_mfma_kernel<true>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
+        if (dg_bf16) {
+            if (drowc) hipLaunchKernelGGL((dgi_mfma_kernel<true, true>), grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
+            else hipLaunchKernelGGL((dgi_mfma_kernel<false, true>), grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
+        } else if (drowc) hipLaunchKernelGGL(dgi_mfma_kernel<true>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
         else hipLaunchKernelGGL(dgi_mfma_kernel<false>, grid, dim3(256), 0, s, dG, tok, T, B, H, V, lstm, part_tab, part_sum, drowc, accumulate);
         CPG_LAUNCH_CHECK();
         const int m = V * NC > 4 * H ? V * NC : 4 * H;
@@ -1256,8 +1340,8 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
 }
 
 CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
-                                  float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-    return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, dsum, drowc, accumulate, workspace, workspace_bytes, stream);
+                                  float* drowc, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream) {
+    return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, dsum, drowc, accumulate, workspace, workspace_bytes, stream, dg_bf16);
 }
 
 static void fill_fwd(GruFwdArgs& a, int t, int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
@@ -1307,13 +1391,15 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
                                  const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
                                  float* dG_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
-                                 float* w_hhT_scratch_r, void* stream) {
+                                 float* w_hhT_scratch_r, int dg_bf16, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
     if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
+    const bool dgb = dg_bf16 != 0;
+    CPG_CHECK_ARG(!dgb || (cpg_gru_store_bf16(B, H, true) && w_hhT_scratch_f));
     if (w_hhT_scratch_f) {
-        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream);
-        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream);
+        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream, dgb);
+        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream, dgb);
         if (rc) return rc;
     }
     const float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
@@ -1336,6 +1422,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.nrows = nullptr;
             a.nrows_next = nullptr;
             a.gates_bf16 = gbf;
+            a.dg_bf16 = dgb;
             a.B = B;
             a.H = H;
             a.row0 = 0;
@@ -1343,7 +1430,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.w_hh = W[d];
             a.w_hhT = WT[d];
             if (prev_t[d] >= 0) {
-                a.dG_next = DG[d] + (size_t)prev_t[d] * B * 4 * H;
+                a.dG_next = gate_at(DG[d], (size_t)prev_t[d] * B * 4 * H, dgb);
                 a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;
             } else {
                 a.dG_next = nullptr;
@@ -1354,7 +1441,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.gates = gate_at(GT[d], (size_t)t * 4 * BH, gbf);
             a.h_prev = d ? HS[d] + (size_t)(t + 1) * BH : HS[d] + (size_t)t * BH;
             a.dH_out = SC[d] + (size_t)cur * BH;
-            a.dG_out = DG[d] + (size_t)t * B * 4 * H;
+            a.dG_out = gate_at(DG[d], (size_t)t * B * 4 * H, dgb);
             prev_t[d] = t;
         }
         int rc = gru_bwd_launch(pr, 2, (hipStream_t)stream);

@@ -38,7 +38,7 @@ CPG_API const char* cpg_last_error(void);
 CPG_API int cpg_version(void);
 CPG_API int cpg_device_count(void);
 /* Launch-policy options ("gru_persist", "gru_fwd_bm", "gru_bwd_dl", "gru_bwd_tile", "gru_bwd_dl2", "gru_bwd_stagger",
- * "lstm_persist", "lstm_bwd_dl", "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl"; KNOBS.md).  value: a decimal
+ * "lstm_persist", "lstm_bwd_dl", "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl", "bf16_store", "bf16_dg"; KNOBS.md).  value: a decimal
  * number or a short token such as "64x32"; null or "" returns the option to the built-in policy.  Unknown name: -2. */
 CPG_API int cpg_set_option(const char* name, const char* value);
 /* copies the option's text ("" when unset) into buf; returns 1 when set, 0 when unset, -2 for an unknown name */
@@ -108,6 +108,13 @@ CPG_API int cpg_get_compute_mode(void);
  * needed again, so the tail of the batch drops out step by step.  The counts are read by the kernels (no host sync);
  * state / gate slots of dead (t,row) pairs are left untouched - hand in zeroed slabs if they are read elsewhere. */
 CPG_API int cpg_gru_gates_bf16(int B, int H, int ragged /* step_rows given */);
+/* bf16 GRADIENT storage (bf16 compute mode only): 1 when the gate gradients dG [T,B,4H] of a sequence are bf16 elements as well - a
+ * buffer of half the bytes behind the same pointer type - i.e. where cpg_gru_gates_bf16 answers 1, H % 128 == 0, B % 128 == 0 and
+ * the sequence has a token table of 0 < V <= 31 rows (every consumer of dG then has a bf16 form: the next BPTT step's operand, the
+ * dW_hh product, the one-pass input-side reduction).  Option bf16_dg = 0 keeps f32.  The caller asks once per sequence, sizes dG
+ * accordingly and passes the answer as `dg_bf16` to cpg_gru_seq_bwd / cpg_gru_biseq_bwd / cpg_gru_wgrad_hh / cpg_gru_dgi_reduce
+ * (which with bf16 gradients must be given the token table: db_hh comes out of its column sums, cpg_gru_wgrad_hh's db_hh = null). */
+CPG_API int cpg_gru_dg_bf16(int B, int H, int ragged, int V);
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
                             int row_begin, int row_end, const int32_t* step_rows, void* stream);
@@ -123,7 +130,7 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
                             int row_begin, int row_end, const int32_t* step_rows /* as in cpg_gru_seq_fwd; dG rows of dead
-                            (t,row) pairs are not written: pass a zeroed dG */, float* w_hhT_scratch, void* stream);
+                            (t,row) pairs are not written: pass a zeroed dG */, float* w_hhT_scratch, int dg_bf16, void* stream);
 /* Both directions of one biGRU layer in lock step, ONE launch per step for the pair (launch p: time p forward, time
  * T-1-p reverse).  Arguments as in cpg_gru_seq_fwd / _bwd per direction (_f forward, _r reverse); no initial-state
  * gradient (the encoder starts from h0 = 0). */
@@ -136,7 +143,7 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
                               const float* dhs_ext_r, const float* dh_last_f /* [B,H] gradient on the final state of the
                               direction, or null */, const float* dh_last_r, float* dG_f, float* dG_r, float* scratch_f,
                               float* scratch_r, float* w_hhT_scratch_f,
-                              float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */, void* stream);
+                              float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */, int dg_bf16, void* stream);
 /* Persistent form: the WHOLE time loop of one direction in ONE launch (csrc/gru_persist.hip): each workgroup keeps the
  * W_hh rows of 16 hidden units in LDS (already split into bf16 planes) for 256 batch rows and the column-tile workgroups of
  * a row tile hand h_t to each other through the state slab (write-through stores + arrival counters), so nothing is
@@ -177,12 +184,12 @@ CPG_API int cpg_gemm_tn_split(int Mr, int N, int Kd);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
-                             float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                             float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream);
 /* dtab[V,3H] (+)= sum of input-side gate gradients grouped by token ; dsum[4H] (+)= column sums of dG (dsum[0:3H] is the
  * b_hh gradient) ; drowc[B,3H] (+)= sum over time (any may be null).  dtab and dsum come from ONE pass over dG:
  * dG^T . [onehot(tok) | 1] on the matrix cores. */
 CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
-                               float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                               float* drowc, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream);
 
 /* ---- LSTM (NOT in the reference, which is GRU-only - SURVEY F2; semantics = torch.nn.LSTM, gate row order i,f,g,o) --------
  * Same conventions as the GRU entry points; cs is the cell-state slab [(T+1),B,H] (c0 in slot 0 / T), gates [T,4,B,H] =

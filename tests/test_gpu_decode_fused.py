@@ -142,7 +142,7 @@ def test_dgi_reduce_one_pass_sums(Tn, B, H):
     ws = ops.workspace(ops.query("cpg_gru_wgrad_workspace", Tn, B, H, V), d)
     dG_d, tok_d = cu(dG), cu(tok)  # keep the device tensors alive across the asynchronous call
     ops.call("cpg_gru_dgi_reduce", Tn, B, H, ops._p(dG_d), ops._p(tok_d), V, ops._p(dtab), ops._p(dsum), ops._p(drowc), 0,
-             ops._p(ws), ws.numel(), ops._stream())
+             ops._p(ws), ws.numel(), 0, ops._stream())
     flat = dG.reshape(-1, 4 * H).astype(np.float64)
     dgi = np.concatenate([flat[:, :2 * H], flat[:, 3 * H:]], 1)
     ref_tab = np.zeros((V, 3 * H))
@@ -173,7 +173,7 @@ def test_dgi_reduce_matrix_core_pass_accumulates(lstm):
     for with_rowc in (True, False):
         dtab, dsum, drowc = torch.ones(V, NC, device=d), torch.full((4 * H,), 2.0, device=d), torch.full((B, NC), 3.0, device=d)
         ops.call(name, Tn, B, H, ops._p(dG_d), ops._p(tok_d), V, ops._p(dtab), ops._p(dsum), ops._p(drowc) if with_rowc else None, 1,
-                 ops._p(ws), ws.numel(), ops._stream())
+                 ops._p(ws), ws.numel(), *(() if lstm else (0,)), ops._stream())
         np.testing.assert_allclose(dtab.cpu().numpy(), 1.0 + ref_tab[:V], atol=1e-4)
         np.testing.assert_allclose(dsum.cpu().numpy(), 2.0 + flat.sum(0), atol=2e-4)
         if with_rowc:

@@ -140,7 +140,7 @@ def _bwd(d, B, H, T, reverse, hs, gates, dhs, last, with_wT=True):
     scr = torch.empty(2, B, H, device=dev)
     wT = torch.empty(H, 3 * H, device=dev) if with_wT else None
     call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(hs), _p(gates), _p(dhs), _p(last), _p(dG), _p(scr), _p(dh0),
-         0, B, None, _p(wT), _stream())
+         0, B, None, _p(wT), 0, _stream())
     torch.cuda.synchronize()
     return dG, dh0
 

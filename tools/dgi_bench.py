@@ -12,7 +12,7 @@ ws = ops.workspace(ops.query("cpg_gru_wgrad_workspace", T, B, H, V), d)
 for rowc in (False, True):
     def run():
         ops.call("cpg_gru_dgi_reduce", T, B, H, ops._p(dG), ops._p(tok), V, ops._p(dtab), ops._p(dsum), ops._p(drowc) if rowc else None, 0,
-                 ops._p(ws), ws.numel(), ops._stream())
+                 ops._p(ws), ws.numel(), 0, ops._stream())
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -66,10 +66,10 @@ def main():
         "fwd": (lambda: call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B,
                              None, _stream()), T),
         "bwd": (lambda: call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), 0, B, None,
-                             _p(wT), _stream()), T + 1),
+                             _p(wT), 0, _stream()), T + 1),
         "bwd2": (lambda: call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), None,
-                              None, _p(dG), _p(dG2), _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), _stream()), T),
-        "wgrad": (lambda: call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(big_ws), big_ws.numel(), _stream()), 1),
+                              None, _p(dG), _p(dG2), _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), 0, _stream()), T),
+        "wgrad": (lambda: call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(big_ws), big_ws.numel(), 0, _stream()), 1),
     }
     fns["fwd"][0]()   # valid state slab / gates for the backward kernels
     fl = 2.0 * B * H * 3 * H
