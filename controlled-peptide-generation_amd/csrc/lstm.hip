@@ -207,9 +207,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdPair pr) {
 
 // Backward step with the direct-to-LDS main loop (DlLoop, gemm_core.h): dG_next [B,4H] . W_hh^T rows, both K-contiguous, exact-f32
 // MFMA, 16-byte row-layout epilogue.  Same sums as lstm_step_bwd_kernel (same contraction order); dense full tiles only.
-template <int BM, int BN>
+// PREC 1: bf16 compute mode - operands rounded to bf16 at the fragment read, one bf16 MFMA per block and slab (as the GRU kernel)
+template <int BM, int BN, int PREC = 0>
 __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
-    using DL = DlLoop<BM, BN, 3>;
+    using DL = DlLoop<BM, BN, 3, PREC>;
     constexpr int MI = DL::MI, NI = DL::NI;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -311,7 +312,8 @@ CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int 
     }
     if (kind == 1) {
         if (lstm_dl_ok(B, H) && H % 4 == 0)
-            return snprintf(buf, n, "lstm_step_bwd_dl_kernel<64, %d>", (H % 64 == 0 && (long)(B / 64) * (H / 64) >= 512) ? 64 : 32);
+            return snprintf(buf, n, "lstm_step_bwd_dl_kernel<64, %d, %d>", (H % 64 == 0 && (long)(B / 64) * (H / 64) >= 512) ? 64 : 32,
+                            cpg_compute_mode_get() == 1 ? 1 : 0);   // (B: rows of the launch - both directions' rows for a paired one)
         const int c = lstm_bwd_choice(B, H);
         if (c == 0) lstm_tc_name<LB32N>(tc, sizeof tc);
         else if (c == 1) lstm_tc_name<LB64>(tc, sizeof tc);
@@ -322,7 +324,8 @@ CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int 
 }
 CPG_EXPORT int cpg_lstm_step_kernel_is_split(int kind, int B, int H) {
     if (kind == 0) return lstm_fwd_choice(B, H) != 2;   // 64-row tiles run the plane engine (LstmFwdLoop)
-    return 0;                                           // backward: exact-f32 MFMA
+    // backward: exact-f32 MFMA; on the direct-to-LDS loop in the bf16 compute mode one bf16 MFMA per block (2, as the GRU reports it)
+    return (cpg_compute_mode_get() == 1 && lstm_dl_ok(B, H) && H % 4 == 0) ? 2 : 0;
 }
 
 static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
@@ -373,16 +376,21 @@ static bool lstm_dl_ok(int B, int H) {
     if (o.set && o.i == 0) return false;
     return B % 64 == 0 && H % 32 == 0;
 }
-template <int BM, int BN>
-static int lstm_launch_dl(const LstmBwdPair& pr, int nd, hipStream_t s) {
+template <int BM, int BN, int PREC>
+static int lstm_launch_dl_p(const LstmBwdPair& pr, int nd, hipStream_t s) {
     const LstmBwdArgs& a = pr.d[0];
-    const size_t smem = (DlLoop<BM, BN, 3>::smem_floats() + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, 3, PREC>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
-        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN>), (int)smem);
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN, PREC>), (int)smem);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN>), dim3(a.H / BN, a.B / BM, nd), dim3(256), smem, s, pr);
+    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN, PREC>), dim3(a.H / BN, a.B / BM, nd), dim3(256), smem, s, pr);
     return 0;
+}
+// bf16 compute mode (cpg_set_compute_mode(1)): the step product with bf16-rounded operands, like every other recurrent product of the mode
+template <int BM, int BN>
+static int lstm_launch_dl(const LstmBwdPair& pr, int nd, hipStream_t s) {
+    return cpg_compute_mode_get() == 1 ? lstm_launch_dl_p<BM, BN, 1>(pr, nd, s) : lstm_launch_dl_p<BM, BN, 0>(pr, nd, s);
 }
 
 // nd = 1: one direction (pr.d[0]); nd = 2: both directions of a bidirectional layer in one launch (same B, H; the two

@@ -379,3 +379,60 @@ def test_lstm_soft_modes_and_forward_sample_vs_oracle():
     np.testing.assert_allclose(c1[0].cpu().numpy(), ref_c, atol=5e-6)
     with pytest.raises(AssertionError):
         m.decoder.forward_sample(None, tok, zt, ct, h0)          # a bare h is the GRU decoder's form
+
+
+@pytest.mark.gpu
+def test_lstm_bf16_mode_step_agreement():
+    """The LSTM extension in the bf16 compute mode (BASELINE.json configs[1] as named: LSTM + bf16): forward / backward step products
+    and dW_hh with bf16-rounded operands (round 4: the backward step too - lstm_step_bwd_dl_kernel<.., 1>), f32 accumulation and
+    storage.  Agreement against torch.nn.LSTM on the CPU, the bf16 mode's own bars (tests/test_gpu_bf16.py): loss terms within 2e-3,
+    every gradient within 3 % relative L2."""
+    import os
+    from bench import model_kwargs
+    from cpg import ops
+    from cpg.synth import synth_ids
+    from helpers import cu, set_losses_cfg
+    from models.model import RNN_VAE
+    from oracle import torch_ref
+    import losses
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    set_losses_cfg()
+    B, He, Z, T, V = 256, 128, 126, 12, 24
+    torch.manual_seed(77)
+    m = RNN_VAE(n_vocab=V, max_seq_len=T, **model_kwargs(Z, He, cell='lstm'))
+    P = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    ref = torch_ref.RefWAE.from_state(P, cell="lstm")
+    rs = np.random.RandomState(7)
+    ids = synth_ids(B, T, V, torch.Generator().manual_seed(7))
+    c = np.zeros((B, 2), np.float32)
+    c[np.arange(B), rs.randint(0, 2, B)] = 1
+    rnd = dict(eps=rs.randn(B, Z).astype(np.float32), c=c, wd_mask=(rs.rand(B, T) < 0.3).astype(np.uint8),
+               out_mask=(rs.rand(B, T, Z + 2) >= 0.3).astype(np.uint8), z_prior_rf=rs.randn(B, Z).astype(np.float32),
+               rf_w=rs.randn(Z, 500).astype(np.float32), rf_b=(2 * np.pi * rs.rand(500)).astype(np.float32))
+    terms, _ = torch_ref.train_loss(ref, ids, {k: torch.from_numpy(v) for k, v in rnd.items()}, 1.5, 0.0, 1e-3, "mmdrf", full_mmd=False)
+    terms["total"].backward()
+    G = {ref.ref_name(k): p.grad.numpy() for k, p in ref.named_parameters()}
+    m = m.cuda()
+    m.device = torch.device("cuda")
+    ops.set_compute_mode('bf16')
+    try:
+        losses.rf.clear()
+        losses.rf['gaussian'] = (cu(rnd["rf_w"]), cu(rnd["rf_b"]))
+        idt = ids.cuda()
+        (mu, lv), (z, cc), logits = m(idt, q_c='prior', sample_z=1,
+                                      rnd=dict(eps=cu(rnd["eps"]), c=cu(rnd["c"]), wd_mask=cu(rnd["wd_mask"]), out_mask=cu(rnd["out_mask"])))
+        recon = losses.recon_dec(idt, logits)
+        loss = recon + 1.5 * losses.wae_mmd_gaussianprior(z, method='rf', z_prior=cu(rnd["z_prior_rf"])) + 1e-3 * losses.kl_gaussian_sharedmu(mu, lv)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_mode('f32')
+    assert abs(recon.item() - float(terms["recon"])) < 2e-3 and abs(loss.item() - float(terms["total"])) < 2e-3
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        if k.startswith("classifier") or k == "decoder.emb.weight":
+            continue
+        want = G[k].astype(np.float64)
+        worst = max(worst, float(np.linalg.norm(prm.grad.cpu().numpy() - want) / max(np.linalg.norm(want), 1e-30)))
+    assert 1e-6 < worst < 3e-2, worst
