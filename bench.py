@@ -132,7 +132,7 @@ def family_roofline(family, dims, avg_us, launches):
         kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), 2.0 * 3 * H * H * T * B
         split = 2 if kernel.endswith(", 1>") else 1
     elif family == "lstm_fwd_persist":
-        kernel, split, flops = "lstm_seq_fwd_persist_kernel<%d>" % (1 if bf16 else 3), (2 if bf16 else 1), T * 2.0 * B * H * 4 * H
+        kernel, split, flops = _cname("cpg_lstm_persistent_kernel_name", B, H), (2 if bf16 else 1), T * 2.0 * B * H * 4 * H
     elif family in ("lstm_fwd_step", "lstm_bwd_step"):   # LSTM extension: four gates
         kind = 0 if family == "lstm_fwd_step" else 1
         kernel, split = _cname("cpg_lstm_step_kernel_name", kind, B * nd, H), L.cpg_lstm_step_kernel_is_split(kind, B, H)

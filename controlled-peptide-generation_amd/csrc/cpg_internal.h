@@ -29,13 +29,14 @@ bool cpg_gru_store_bf16(int B, int H, bool dense);
 bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 310
+#define CPG_ABI_VERSION 311
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).
 enum CpgOpt {
     OPT_GRU_PERSIST,      // 0: per-step launches instead of the whole-sequence persistent forward
     OPT_LSTM_PERSIST,     // same for the LSTM extension
+    OPT_LSTM_PERSIST_NG,  // 1 | 2 | 4: upper bound on the 8-unit groups one workgroup of the persistent LSTM forward holds (default: 4)
     OPT_GRU_FWD_BM,       // 32 | 64 | 128: row-tile height of the per-step forward kernel
     OPT_GRU_BWD_DL,       // 0: register-staged exact-f32 backward step instead of the direct-to-LDS loop
     OPT_GRU_BWD_TILE,     // "32x32" | "64x32" | "32x64" | "64x64": tile of the backward step

@@ -22,19 +22,17 @@
 
 namespace {
 
-constexpr int L_CT = 8;              // hidden units per workgroup
-constexpr int L_NC = 4 * L_CT;       // gate columns per workgroup: two MFMA blocks
+// NG (round 4): 8-unit GROUPS per workgroup.  The LDS holds NP x 32 NG gate rows of W_hh planes: with the three planes of the
+// f32-grade mode that is one group (101 KB at H = 512); the bf16 compute mode keeps ONE plane, so FOUR groups fit (32 units, 135 KB).
+// The workgroup count stays the chip's (rows per workgroup shrink with it: 512 / NG), and what a workgroup reads of the exchanged
+// state per step - rows x H x 2 NP bytes - shrinks by NG: 524 -> 131 KB at H = 512 in the bf16 mode, with a quarter of the producers
+// per row tile to wait for.  A wave owns 64 / NG rows and, per group, the two MFMA blocks [i|f], [g|o] described above.
 constexpr int L_WAVES = 8;
-constexpr int L_WROWS = 64;          // rows per wave
-constexpr int L_MI = L_WROWS / 16;
-#ifndef CPG_LSTM_PERSIST_HM
-#define CPG_LSTM_PERSIST_HM 2
-#endif
 #ifndef CPG_LSTM_PERSIST_DEPTH
 #define CPG_LSTM_PERSIST_DEPTH 2
 #endif
-constexpr int L_HM = CPG_LSTM_PERSIST_HM;        // row blocks per product pass (two passes per step)
 constexpr int L_DEPTH = CPG_LSTM_PERSIST_DEPTH;  // register ring over k-blocks
+constexpr int L_MIN_WROWS = 16;      // smallest row tile (NG = 4): the arrival counters are laid out for it
 constexpr int L_CNT_STRIDE = 64;     // words between arrival counters (one 256-byte line each)
 constexpr int L_TBW = 16;
 constexpr unsigned L_SPIN_LIMIT = 400000u;
@@ -93,8 +91,14 @@ __device__ __forceinline__ f32x4 cell_to_rows(float* tb, float v0, float v1, int
     return *reinterpret_cast<const f32x4*>(tb + (lane >> 2) * L_TBW + 4 * (lane & 3));
 }
 
-template <int NP>
+template <int NP, int NG>
 __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(LFwdArgs a) {
+    constexpr int L_CT = 8 * NG;            // hidden units per workgroup
+    constexpr int L_NC = 32 * NG;           // gate columns per workgroup: two MFMA blocks per group
+    constexpr int L_WROWS = 64 / NG;        // rows per wave
+    constexpr int L_MI = L_WROWS / 16;
+    constexpr int L_HM = L_MI >= 2 ? 2 : 1; // row blocks per product pass
+    static_assert(NG == 1 || NG == 2 || NG == 4, "1, 2 or 4 groups of 8 hidden units");
     extern __shared__ __attribute__((aligned(16))) uint32_t lpsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,10 +110,10 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
     uint32_t* const planes = lpsm;
     float* const tb = reinterpret_cast<float*>(lpsm + NP * PLW) + wave * (16 * L_TBW);
 
-    // ---- W_hh slice -> bf16 planes in LDS, once per sequence: plane[c = gate*8 + u][k pair]
+    // ---- W_hh slice -> bf16 planes in LDS, once per sequence: plane[c = group*32 + gate*8 + u][k pair]
     for (int idx = tid; idx < L_NC * (H / 2); idx += L_WAVES * 64) {
         const int c = idx / (H / 2), kp = idx - c * (H / 2);
-        const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c >> 3) * H + j0 + (c & 7))) * H + 2 * kp);
+        const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)(((c >> 3) & 3) * H + j0 + 8 * (c >> 5) + (c & 7))) * H + 2 * kp);
         uint32_t w0, w1 = 0, w2 = 0;
         if (NP == 3) split3_pair(v.x, v.y, w0, w1, w2);
         else w0 = cvt_pk_bf16(v.x, v.y);
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
     if (row0 >= B) return;
     const int l15 = lane & 15, lq = lane >> 4;
     const int u = lane & 7, half = (lane >> 3) & 1;
-    const int col = j0 + u;                       // hidden unit of this lane's cell elements
+    const int col = j0 + u;                       // hidden unit of this lane's cell elements IN GROUP 0 (group gp: + 8 gp)
     const int srow = lane >> 2, scq = lane & 3;   // row-layout coordinates after cell_to_rows
     const size_t BH = (size_t)B * H;
 
@@ -136,22 +140,25 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
     bool dead = false;
 
     // per-lane constants of the cell: rows 16 mi + 4 lq + 2 half + e (e = 0, 1), unit u, all four gates
-    float rc[L_MI][2][4], cst[L_MI][2], bh[4];
+    float rc[NG][L_MI][2][4], cst[NG][L_MI][2], bh[NG][4];
     const size_t slot0 = (size_t)(a.reverse ? T : 0) * BH;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bh[q] = a.b_hh[q * H + col];
+    for (int gp = 0; gp < NG; ++gp) {
 #pragma unroll
-    for (int mi = 0; mi < L_MI; ++mi)
+        for (int q = 0; q < 4; ++q) bh[gp][q] = a.b_hh[q * H + col + 8 * gp];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int row = min(row0 + 16 * mi + 4 * lq + 2 * half + e, B - 1);
+        for (int mi = 0; mi < L_MI; ++mi)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rc[mi][e][q] = a.rowc ? a.rowc[(size_t)row * 4 * H + q * H + col] : 0.f;
-            cst[mi][e] = a.cs[slot0 + (size_t)row * H + col];
-        }
+            for (int e = 0; e < 2; ++e) {
+                const int row = min(row0 + 16 * mi + 4 * lq + 2 * half + e, B - 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rc[gp][mi][e][q] = a.rowc ? a.rowc[(size_t)row * 4 * H + q * H + col + 8 * gp] : 0.f;
+                cst[gp][mi][e] = a.cs[slot0 + (size_t)row * H + col + 8 * gp];
+            }
+    }
 
-    // row-layout publish of 8 columns (16 bytes per plane): the lane with (l & 3) == 0 collects its neighbour's four columns
-    auto publish = [&](const f32x4 v, int row, unsigned slot_off) {
+    // row-layout publish of a group's 8 columns (16 bytes per plane): the lane with (l & 3) == 0 collects its neighbour's four columns
+    auto publish = [&](const f32x4 v, int row, unsigned slot_off, int jg) {
         const float n0 = l_xor1(v[0]), n1 = l_xor1(v[1]), n2 = l_xor1(v[2]), n3 = l_xor1(v[3]);
         if (scq == 0 && row < B) {
             uint32_t w0[4], w1[4], w2[4];
@@ -164,8 +171,8 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
                 w0[0] = cvt_pk_bf16(v[0], v[1]); w0[1] = cvt_pk_bf16(v[2], v[3]);
                 w0[2] = cvt_pk_bf16(n0, n1); w0[3] = cvt_pk_bf16(n2, n3);
             }
-            const int voff = row * 64 + (j0 & 31) * 2;
-            const unsigned off = slot_off + (unsigned)(j0 >> 5) * kb_bytes;
+            const int voff = row * 64 + (jg & 31) * 2;
+            const unsigned off = slot_off + (unsigned)(jg >> 5) * kb_bytes;
             __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w0[0], w0[1], w0[2], w0[3]}, rx, voff, off, 16);   // 16 = sc1: write-through
             if (NP == 3) {
                 __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, off + plane_bytes, 16);
@@ -176,12 +183,14 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
 
     // h0 enters the exchange like any step's output: slot 0, arrival #1
 #pragma unroll
-    for (int mi = 0; mi < L_MI; ++mi) {
-        const int row = row0 + 16 * mi + srow;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (scq < 2) v = *reinterpret_cast<const f32x4*>(a.hs + slot0 + (size_t)min(row, B - 1) * H + j0 + 4 * scq);
-        publish(v, row, 0u);
-    }
+    for (int gp = 0; gp < NG; ++gp)
+#pragma unroll
+        for (int mi = 0; mi < L_MI; ++mi) {
+            const int row = row0 + 16 * mi + srow;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (scq < 2) v = *reinterpret_cast<const f32x4*>(a.hs + slot0 + (size_t)min(row, B - 1) * H + j0 + 8 * gp + 4 * scq);
+            publish(v, row, 0u, j0 + 8 * gp);
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * L_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
@@ -195,25 +204,28 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
         const unsigned in_off = (unsigned)p * 3u * plane_bytes, out_off = (unsigned)(p + 1) * 3u * plane_bytes;
 
         // input-side pre-activations of this step (independent of the recurrence, fetched before the wait)
-        float gi[L_MI][2][4];
+        float gi[NG][L_MI][2][4];
 #pragma unroll
         for (int mi = 0; mi < L_MI; ++mi)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int row = min(row0 + 16 * mi + 4 * lq + 2 * half + e, B - 1);
-                float x[4] = {rc[mi][e][0], rc[mi][e][1], rc[mi][e][2], rc[mi][e][3]};
-                if (a.tok) {
-                    const float* t = a.tab + (size_t)a.tok[(size_t)tt * B + row] * 4 * H + col;
+                const float* tt_ = a.tok ? a.tab + (size_t)a.tok[(size_t)tt * B + row] * 4 * H + col : nullptr;
+                const float* td_ = a.dense ? a.dense + ((size_t)tt * B + row) * 4 * H + col : nullptr;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] += t[q * H];
+                for (int gp = 0; gp < NG; ++gp) {
+                    float x[4] = {rc[gp][mi][e][0], rc[gp][mi][e][1], rc[gp][mi][e][2], rc[gp][mi][e][3]};
+                    if (tt_) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] += tt_[q * H + 8 * gp];
+                    }
+                    if (td_) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] += td_[q * H + 8 * gp];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gi[gp][mi][e][q] = x[q];
                 }
-                if (a.dense) {
-                    const float* t = a.dense + ((size_t)tt * B + row) * 4 * H + col;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] += t[q * H];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gi[mi][e][q] = x[q];
             }
 
         l_wait_ge(a.cnt + rt * L_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
@@ -225,11 +237,11 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
         float* const cout = a.cs + (size_t)(a.reverse ? tt : tt + 1) * BH;
 #pragma unroll
         for (int hp = 0; hp < L_MI / L_HM; ++hp) {
-            f32x4 acc[L_HM][2];
+            f32x4 acc[L_HM][2 * NG];
 #pragma unroll
             for (int m = 0; m < L_HM; ++m)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 2 * NG; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             lu32x4 buf[L_DEPTH][L_HM][NP];
             auto load = [&](lu32x4 (&b)[L_HM][NP], int kb) {
 #pragma unroll
@@ -239,9 +251,9 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
                         b[m][pl] = __builtin_amdgcn_raw_buffer_load_b128(rx, aoff[hp * L_HM + m], in_off + pl * plane_bytes + kb * kb_bytes, 0);
             };
             auto compute = [&](const lu32x4 (&bf)[L_HM][NP], int kb) {
-                cpg_bf16x8 fb[2][NP];
+                cpg_bf16x8 fb[2 * NG][NP];
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int q = 0; q < 2 * NG; ++q)
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl)
                         fb[q][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + q * 16 * S + kb * 16);
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
 #pragma unroll
                     for (int m = 0; m < L_HM; ++m)
 #pragma unroll
-                        for (int q = 0; q < 2; ++q)
+                        for (int q = 0; q < 2 * NG; ++q)
                             acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, bf[m][NP == 3 ? TA[t] : 0]),
                                                                                 fb[q][NP == 3 ? TB[t] : 0], acc[m][q], 0, 0, 0);
             };
@@ -272,33 +284,35 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
             // for rows 0..3.  Half 0 runs rows 0,1 and half 1 rows 2,3: each sends the partner the two gates it holds of the
             // partner's rows and receives the two it lacks of its own (one row_ror:8 per value).
 #pragma unroll
-            for (int m = 0; m < L_HM; ++m) {
+            for (int m = 0; m < L_HM; ++m)
+#pragma unroll
+            for (int gp = 0; gp < NG; ++gp) {
                 const int mi = hp * L_HM + m;
                 float ig[2], fg[2], gg[2], og[2], hv[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     // what this lane sends: its block values of the PARTNER's rows (half 0 -> rows 2,3 ; half 1 -> rows 0,1)
-                    const float s0 = half ? acc[m][0][e] : acc[m][0][2 + e];
-                    const float s1 = half ? acc[m][1][e] : acc[m][1][2 + e];
+                    const float s0 = half ? acc[m][2 * gp][e] : acc[m][2 * gp][2 + e];
+                    const float s1 = half ? acc[m][2 * gp + 1][e] : acc[m][2 * gp + 1][2 + e];
                     const float r0 = ror8(s0), r1 = ror8(s1);   // partner's block 0 / block 1 value of MY row e
-                    const float m0 = half ? acc[m][0][2 + e] : acc[m][0][e];
-                    const float m1 = half ? acc[m][1][2 + e] : acc[m][1][e];
+                    const float m0 = half ? acc[m][2 * gp][2 + e] : acc[m][2 * gp][e];
+                    const float m1 = half ? acc[m][2 * gp + 1][2 + e] : acc[m][2 * gp + 1][e];
                     const float pi = half ? r0 : m0, pf = half ? m0 : r0, pg = half ? r1 : m1, po = half ? m1 : r1;
-                    ig[e] = sigmoidf_(gi[mi][e][0] + (pi + bh[0]));
-                    fg[e] = sigmoidf_(gi[mi][e][1] + (pf + bh[1]));
-                    gg[e] = tanhf(gi[mi][e][2] + (pg + bh[2]));
-                    og[e] = sigmoidf_(gi[mi][e][3] + (po + bh[3]));
-                    const float cn = fg[e] * cst[mi][e] + ig[e] * gg[e];
-                    cst[mi][e] = cn;
+                    ig[e] = sigmoidf_(gi[gp][mi][e][0] + (pi + bh[gp][0]));
+                    fg[e] = sigmoidf_(gi[gp][mi][e][1] + (pf + bh[gp][1]));
+                    gg[e] = tanhf(gi[gp][mi][e][2] + (pg + bh[gp][2]));
+                    og[e] = sigmoidf_(gi[gp][mi][e][3] + (po + bh[gp][3]));
+                    const float cn = fg[e] * cst[gp][mi][e] + ig[e] * gg[e];
+                    cst[gp][mi][e] = cn;
                     hv[e] = og[e] * tanhf(cn);
                 }
                 // ---- publish h_t (split planes, write-through), then the f32 slabs and the saved gates, all as 16-byte row accesses
                 const int row = row0 + 16 * mi + srow;
                 const f32x4 hrow = cell_to_rows(tb, hv[0], hv[1], lane);
-                if (p + 1 < T) publish(hrow, row, out_off);
-                const f32x4 crow = cell_to_rows(tb, cst[mi][0], cst[mi][1], lane);
+                if (p + 1 < T) publish(hrow, row, out_off, j0 + 8 * gp);
+                const f32x4 crow = cell_to_rows(tb, cst[gp][mi][0], cst[gp][mi][1], lane);
                 const bool st = scq < 2 && row < B;
-                const size_t o = (size_t)row * H + j0 + 4 * scq;
+                const size_t o = (size_t)row * H + j0 + 8 * gp + 4 * scq;
                 if (st) {
                     *reinterpret_cast<f32x4*>(hout + o) = hrow;
                     *reinterpret_cast<f32x4*>(cout + o) = crow;
@@ -329,28 +343,54 @@ int l_plane_stride_words(int H) {
     while (s % 64 != 8) ++s;
     return s;
 }
-size_t l_lds_bytes(int H, int np) { return ((size_t)np * L_NC * l_plane_stride_words(H) + L_WAVES * 16 * L_TBW) * 4; }
-size_t l_cnt_words(int B) { return (size_t)cdiv(B, L_WROWS) * L_CNT_STRIDE; }
+size_t l_lds_bytes(int H, int np, int ng) { return ((size_t)np * 32 * ng * l_plane_stride_words(H) + L_WAVES * 16 * L_TBW) * 4; }
+size_t l_cnt_words(int B) { return (size_t)cdiv(B, L_MIN_WROWS) * L_CNT_STRIDE; }   // one line per row tile of the smallest tile height
 size_t l_sync_words(int B) { return (l_cnt_words(B) + 16 + 63) / 64 * 64; }
+
+template <int NP, int NG>
+long l_resident(size_t lds) {   // workgroups the current device holds at once, by the occupancy API's count
+    const void* k = reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<NP, NG>);
+    if (cpg_allow_big_lds(k, 160 * 1024) != 0) return 0;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_fwd_persist_kernel<NP, NG>, L_WAVES * 64, lds) != hipSuccess) return 0;
+    return (long)per_cu * cpg_device_cus();
+}
+
+// Groups of 8 hidden units per workgroup for a [B, H] sequence in the current compute mode: the largest of 4 / 2 / 1 whose plane slice
+// fits the LDS, divides H, and whose workgroups (row groups of 8 waves x 64 / NG rows, times H / (8 NG) column tiles) are all
+// co-resident; 0 = not covered.  More groups = fewer, wider column tiles: less state re-read per workgroup, fewer producers per tile.
+int l_pick_ng(int B, int H) {
+    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const CpgOptVal cap = cpg_opt(OPT_LSTM_PERSIST_NG);
+    const int top = cap.set && (cap.i == 1 || cap.i == 2) ? (int)cap.i : 4;
+    for (int ng = np == 1 ? top : 1; ng >= 1; ng >>= 1) {   // three planes: one group (wider forms do not fit 256 registers without spills)
+        if (H % (8 * ng) != 0) continue;
+        const size_t lds = l_lds_bytes(H, np, ng);
+        if (lds > 160 * 1024) continue;
+        const long wgs = (long)cdiv(cdiv(B, 64 / ng), L_WAVES) * (H / (8 * ng));
+        long fit = 0;
+        if (np == 1) fit = ng == 4 ? l_resident<1, 4>(lds) : ng == 2 ? l_resident<1, 2>(lds) : l_resident<1, 1>(lds);
+        else fit = l_resident<3, 1>(lds);
+        if (wgs <= fit) return ng;
+    }
+    return 0;
+}
 
 }  // namespace
 
-// 1 when the persistent LSTM forward kernel covers [B rows, H hidden] on this device (one workgroup of 8 hidden units x 512
-// rows per CU, all co-resident).  Option lstm_persist = 0 disables the path (per-step launches).
+// 1 when the persistent LSTM forward kernel covers [B rows, H hidden] on this device in the current compute mode (every workgroup
+// co-resident).  Option lstm_persist = 0 disables the path (per-step launches).
 CPG_EXPORT int cpg_lstm_persistent_fits(int B, int H) {
     const CpgOptVal& o = cpg_opt(OPT_LSTM_PERSIST);
     if (o.set && o.i == 0) return 0;
     if (B <= 0 || H < 32 || H % 32 != 0) return 0;
-    if (l_lds_bytes(H, cpg_compute_mode_get() == 1 ? 1 : 3) > 160 * 1024) return 0;
     if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
-    const long wgs = (long)cdiv(cdiv(B, L_WROWS), L_WAVES) * (H / L_CT);
-    const bool bf = cpg_compute_mode_get() == 1;
-    const void* k = bf ? reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<1>) : reinterpret_cast<const void*>(lstm_seq_fwd_persist_kernel<3>);
-    if (cpg_allow_big_lds(k, 160 * 1024) != 0) return 0;
-    int per_cu = 0;   // co-residency by the occupancy API's count, not by assumption
-    const hipError_t e = bf ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_fwd_persist_kernel<1>, L_WAVES * 64, l_lds_bytes(H, 1))
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_fwd_persist_kernel<3>, L_WAVES * 64, l_lds_bytes(H, 3));
-    return e == hipSuccess && wgs <= (long)per_cu * cpg_device_cus();
+    return l_pick_ng(B, H) > 0;
+}
+
+// Name of the kernel a persistent launch runs, as rocprofv3 prints it (bench.py's roofline object)
+CPG_EXPORT int cpg_lstm_persistent_kernel_name(int B, int H, char* buf, int n) {
+    return snprintf(buf, n, "lstm_seq_fwd_persist_kernel<%d, %d>", cpg_compute_mode_get() == 1 ? 1 : 3, l_pick_ng(B, H));
 }
 
 CPG_EXPORT size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H) {
@@ -365,7 +405,8 @@ CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, con
                                            float* hs, float* cs, float* gates, void* sync_scratch, void* err_host, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && cs && sync_scratch);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
-    if (!cpg_lstm_persistent_fits(B, H)) {
+    const int ng = cpg_lstm_persistent_fits(B, H) ? l_pick_ng(B, H) : 0;
+    if (ng == 0) {
         cpg_set_error("cpg_lstm_seq_fwd_persistent: B=%d H=%d does not fit the persistent kernel on this device", B, H);
         return -5;
     }
@@ -378,12 +419,15 @@ CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, con
     a.err_host = (unsigned*)err_host;
     a.xch = (uint16_t*)(a.cnt + l_sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
-    a.groups = cdiv(cdiv(B, L_WROWS), L_WAVES);
+    a.groups = cdiv(cdiv(B, 64 / ng), L_WAVES);
     a.S = l_plane_stride_words(H);
     const bool bf = cpg_compute_mode_get() == 1;
-    const size_t lds = l_lds_bytes(H, bf ? 1 : 3);
-    if (bf) hipLaunchKernelGGL(lstm_seq_fwd_persist_kernel<1>, dim3(a.groups * (H / L_CT)), dim3(L_WAVES * 64), lds, s, a);
-    else hipLaunchKernelGGL(lstm_seq_fwd_persist_kernel<3>, dim3(a.groups * (H / L_CT)), dim3(L_WAVES * 64), lds, s, a);
+    const size_t lds = l_lds_bytes(H, bf ? 1 : 3, ng);
+    const dim3 grid(a.groups * (H / (8 * ng))), block(L_WAVES * 64);
+#define CPG_LP(NP_, NG_) hipLaunchKernelGGL((lstm_seq_fwd_persist_kernel<NP_, NG_>), grid, block, lds, s, a)
+    if (bf) { if (ng == 4) CPG_LP(1, 4); else if (ng == 2) CPG_LP(1, 2); else CPG_LP(1, 1); }
+    else CPG_LP(3, 1);
+#undef CPG_LP
     CPG_LAUNCH_CHECK();
     return 0;
 }

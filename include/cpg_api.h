@@ -206,6 +206,8 @@ CPG_API int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const 
                                         const int32_t* tok, const float* tab, const float* rowc, const float* dense,
                                         float* hs, float* cs, float* gates, void* sync_scratch, void* err_host, void* stream);
 CPG_API size_t cpg_lstm_persistent_err_offset(int B);
+/* name of the kernel a persistent LSTM launch runs at this shape in the current compute mode (profiling label) */
+CPG_API int cpg_lstm_persistent_kernel_name(int B, int H, char* buf, int n);
 CPG_API int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* stream);
 /* Both directions of one biLSTM layer in lock step, ONE launch per step for the pair (as cpg_gru_biseq_bwd): arguments as
  * cpg_lstm_seq_bwd per direction; dh_last_* [B,H] (optional, both or neither) = gradient on each direction's final hidden state;

@@ -220,6 +220,57 @@ def test_lstm_persistent_forward_matches_per_step(B, H, T, reverse, dense, rowc)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,T,reverse,dense,rowc,ng", [
+    (2048, 512, 25, False, False, True, 4),   # bench decoder shape: four groups of 8 units per workgroup (32 units, 128 rows)
+    (2048, 512, 25, True, False, False, 4),
+    (200, 96, 6, False, False, True, 4),      # partial row tiles of 16 rows
+    (333, 128, 9, True, True, False, 4),
+    (1000, 80 * 2, 5, False, True, True, 4),  # H = 160: 5 column tiles of 32 units
+    (512, 48 * 2, 4, False, False, True, 4),
+    (300, 16 * 6, 7, True, False, True, 4),
+    (1024, 8 * 36, 3, False, False, True, 4), # H = 288
+    (256, 8 * 20, 3, False, False, True, 4),
+    (640, 16 * 10, 4, True, False, False, 4),
+])
+def test_lstm_persistent_forward_bf16_mode_groups(B, H, T, reverse, dense, rowc, ng):
+    """bf16 compute mode: the persistent kernel keeps ONE W_hh plane and so holds up to four 8-unit groups per workgroup
+    (lstm_seq_fwd_persist_kernel<1, NG>, round 4).  Every group count computes each unit's gates with the same k order from the
+    same bf16-rounded operands, so the wide forms equal the one-group form (option lstm_persist_groups=1) BIT FOR BIT; and the
+    mode's result stays within its bar of the f32-grade per-step kernels (whose step product is never rounded to bf16).  The kernel
+    name the launcher reports carries the group count."""
+    import ctypes
+    from cpg import ops, lib
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    d = _lstm_inputs(B, H, T, 24, seed=B + H + T, dense=dense, rowc=rowc)
+    ops.set_compute_mode('bf16')
+    try:
+        buf = ctypes.create_string_buffer(128)
+        lib().dll.cpg_lstm_persistent_kernel_name(B, H, buf, 128)
+        name = buf.value.decode()
+        assert name.startswith("lstm_seq_fwd_persist_kernel<1, "), name
+        wide = int(name.split(",")[1].strip(" >"))
+        assert wide in (1, 2, 4) and H % (8 * wide) == 0
+        hp, cp, gp = _lstm_run(d, B, H, T, reverse, True)
+        outs = {}
+        for cap in (1, 2):
+            with ops.options(lstm_persist_groups=cap):
+                lib().dll.cpg_lstm_persistent_kernel_name(B, H, buf, 128)
+                got = int(buf.value.decode().split(",")[1].strip(" >"))
+                assert got <= cap
+                outs[cap] = _lstm_run(d, B, H, T, reverse, True)
+        hq, cq, gq = _lstm_run(d, B, H, T, reverse, False)
+    finally:
+        ops.set_compute_mode('f32')
+    assert torch.isfinite(hp).all() and torch.isfinite(cp).all()
+    for cap, (h1, c1, g1) in outs.items():
+        assert torch.equal(hp, h1) and torch.equal(cp, c1) and torch.equal(gp, g1), cap
+    assert (hp - hq).abs().max().item() < 2e-2
+    assert (cp - cq).abs().max().item() < 4e-2
+    assert (gp - gq).abs().max().item() < 2e-2
+
+
+@pytest.mark.gpu
 def test_lstm_persistent_forward_vs_oracle_and_repeatable():
     B, H, T, V = 130, 64, 7, 24
     d = _lstm_inputs(B, H, T, V, seed=5)
@@ -325,7 +376,7 @@ def test_lstm_model_step_vs_torch_ref(B, He, Z, T, layers):
     loss.backward()
     torch.cuda.synchronize()
     for name, got in (("recon", recon), ("kl", kl), ("mmdrf", mmdrf), ("l1", l1), ("klmu", klmu), ("total", loss)):
-        want = float(terms[name])
+        want = float(terms[name].detach()) if torch.is_tensor(terms[name]) else float(terms[name])
         assert abs(got.item() - want) < 1e-4 * max(1.0, abs(want)), (name, got.item(), want)
     np.testing.assert_allclose(mu.detach().cpu().numpy(), aux["mu"].detach().numpy(), atol=2e-5, rtol=0)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), aux["logits"].detach().numpy(), atol=1e-4, rtol=0)
