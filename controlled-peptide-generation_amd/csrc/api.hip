@@ -1,4 +1,5 @@
 // Library-wide plumbing of libcpg_hip.so: version, thread-local error text, the option table, small layout kernels.
+#include <string.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <mutex>
@@ -19,7 +20,7 @@ CPG_EXPORT int cpg_version(void) { return CPG_ABI_VERSION; }
 // ---- option table: the launch policy's tuning knobs, ONE process-wide struct.  Filled once, on first use, from the
 // environment (CPG_<NAME IN CAPITALS>), afterwards changed only through cpg_set_option: no launch path calls getenv.
 static const char* const g_opt_names[OPT__COUNT] = {
-    "gru_persist", "lstm_persist", "lstm_persist_groups", "gru_fwd_bm", "gru_bwd_dl", "gru_bwd_tile", "gru_bwd_dl2", "gru_bwd_stagger", "lstm_bwd_dl",
+    "gru_persist", "lstm_persist", "f32_engine", "lstm_persist_groups", "gru_fwd_bm", "gru_bwd_dl", "gru_bwd_tile", "gru_bwd_dl2", "gru_bwd_stagger", "lstm_bwd_dl",
     "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl", "bf16_store", "bf16_dg"};
 static CpgOptVal g_opts[OPT__COUNT];
 static std::once_flag g_opts_once;
@@ -118,6 +119,11 @@ int cpg_allow_big_lds(const void* kernel, int bytes) {
 // per block, f32 accumulation; BASELINE.json configs[1]/[4] "bf16").  Process-wide like the option table, read at launch time.
 static int g_compute_mode = 0;
 int cpg_compute_mode_get() { return g_compute_mode; }
+int cpg_persist_planes() {
+    if (g_compute_mode == 1) return 1;
+    const CpgOptVal o = cpg_opt(OPT_F32_ENGINE);
+    return (o.set && strcmp(o.s, "bf16x3") == 0) ? 3 : 2;
+}
 CPG_EXPORT int cpg_set_compute_mode(int mode) {
     if (mode != 0 && mode != 1) {
         cpg_set_error("cpg_set_compute_mode: mode %d (0 = f32-grade, 1 = bf16 recurrent products)", mode);

@@ -36,6 +36,7 @@ bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 enum CpgOpt {
     OPT_GRU_PERSIST,      // 0: per-step launches instead of the whole-sequence persistent forward
     OPT_LSTM_PERSIST,     // same for the LSTM extension
+    OPT_F32_ENGINE,       // "f16x2" (default) | "bf16x3": split of the f32-grade persistent forward kernels (gemm_core.h)
     OPT_LSTM_PERSIST_NG,  // 1 | 2 | 4: upper bound on the 8-unit groups one workgroup of the persistent LSTM forward holds (default: 4)
     OPT_GRU_FWD_BM,       // 32 | 64 | 128: row-tile height of the per-step forward kernel
     OPT_GRU_BWD_DL,       // 0: register-staged exact-f32 backward step instead of the direct-to-LDS loop
@@ -58,5 +59,6 @@ struct CpgOptVal {
     char s[24];   // the text
 };
 CpgOptVal cpg_opt(CpgOpt o);   // a copy, taken under the table's mutex (api.hip)
+int cpg_persist_planes();      // operand planes of the persistent forward kernels now: 1 bf16 compute mode, 2 f16 pair, 3 bf16 triple
 int cpg_device_cus();                                   // CUs of the current device (cached per device)
 int cpg_allow_big_lds(const void* kernel, int bytes);   // opt a kernel into > 64 KB dynamic LDS, once per (kernel, device)

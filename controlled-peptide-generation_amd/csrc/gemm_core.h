@@ -185,6 +185,23 @@ __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, ui
     w2 = cvt_pk_bf16(l2, h2);
 }
 
+// f16 pair split (the persistent forward kernels' f32-grade engine since round 4): x = x0 + x1 with x_i f16 (11 significand
+// bits each, round to nearest even; residual <= 2^-23 |x| while x1 is a normal f16, <= 2^-25 absolute below that - the MFMA keeps
+// f16 subnormal inputs, measured on MI355X: tools/micro/f16_subnormal.hip); a.b ~= a1b0 + a0b1 + a0b0 (dropped a1b1 <= 2^-22
+// |a.b|): THREE v_mfma_f32_16x16x32_f16 per block and 4 bytes per element in place of six MFMAs and 6 bytes.  f16 has five
+// exponent bits: an operand whose magnitudes are not O(1) (weights) is multiplied by a power of two first (exact), the
+// accumulator by its inverse.
+typedef _Float16 cpg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cpg_f16x2 __attribute__((ext_vector_type(2)));
+typedef float cpg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t& w0, uint32_t& w1) {
+    const cpg_f16x2 a = __builtin_convertvector(cpg_f32x2{lo, hi}, cpg_f16x2);   // v_cvt_pk_f16_f32
+    const cpg_f32x2 b = __builtin_convertvector(a, cpg_f32x2);
+    const cpg_f16x2 c = __builtin_convertvector(cpg_f32x2{lo - b[0], hi - b[1]}, cpg_f16x2);
+    w0 = __builtin_bit_cast(uint32_t, a);
+    w1 = __builtin_bit_cast(uint32_t, c);
+}
+
 // SPLIT = 0: exact-f32 MFMA on f32 LDS images (the layouts described at the top of this file).
 // (Splitting per wave at fragment-read time on the f32 LDS images was tried first: the conversion is then repeated by
 //  every wave that shares an operand - VALU-bound; not kept.)

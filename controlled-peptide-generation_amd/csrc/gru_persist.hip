@@ -226,7 +226,12 @@ __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffe
     const float n0 = lane_xor1(v[0]), n1 = lane_xor1(v[1]), n2 = lane_xor1(v[2]), n3 = lane_xor1(v[3]);
     if ((lane & 1) == 0 && ok) {   // ok also carries the column bound of narrow (CT = 8) tiles
         uint32_t w0[4], w1[4], w2[4];
-        if (NP == 3) {
+        if (NP == 2) {   // f16 pair
+            split2h_pair(v[0], v[1], w0[0], w1[0]);
+            split2h_pair(v[2], v[3], w0[1], w1[1]);
+            split2h_pair(n0, n1, w0[2], w1[2]);
+            split2h_pair(n2, n3, w0[3], w1[3]);
+        } else if (NP == 3) {
             split3_pair(v[0], v[1], w0[0], w1[0], w2[0]);
             split3_pair(v[2], v[3], w0[1], w1[1], w2[1]);
             split3_pair(n0, n1, w0[2], w1[2], w2[2]);
@@ -237,14 +242,13 @@ __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffe
         }
         constexpr int AUX = (CPG_PERSIST_PLAIN_STORES || PLAIN) ? 0 : 16;   // 16 = sc1: write-through; 0: the line stays in this XCD's L2
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w0[1], w0[2], w0[3]}, rx, voff, slot_off, AUX);
-        if (NP == 3) {
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, slot_off + plane_bytes, AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, slot_off + 2 * plane_bytes, AUX);
-        }
+        if (NP >= 2) __builtin_amdgcn_raw_buffer_store_b128(u32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, slot_off + plane_bytes, AUX);
+        if (NP == 3) __builtin_amdgcn_raw_buffer_store_b128(u32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, slot_off + 2 * plane_bytes, AUX);
     }
 }
 
-// NP: planes of the split - 3 = f32-grade (six MFMAs per block), 1 = bf16 compute mode (cpg_set_compute_mode(1))
+// NP: planes of the split - 2 = f32-grade on an f16 pair (three MFMAs per block, gemm_core.h; the default), 3 = f32-grade on three
+//     bf16 planes (six MFMAs per block; option f32_engine = bf16x3), 1 = bf16 compute mode (cpg_set_compute_mode(1))
 // CT: hidden units per workgroup - 16 (one MFMA column block per gate) or 8 (blocks [r | z] and [n | n], see the header)
 typedef uint32_t pk_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -265,18 +269,43 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     uint32_t* const planes = psm;
     float* const tb = reinterpret_cast<float*>(psm + NP * PLW) + wave * (16 * P_TBW);
 
-    // ---- W_hh slice -> three bf16 planes in LDS, once per sequence: plane[c = gate*CT + u][k pair]
+    // ---- W_hh slice -> NP planes in LDS, once per sequence: plane[c = gate*CT + u][k pair]
+    // f16 pair: the slice is multiplied by a power of two first so that its largest magnitude lands in [2^13, 2^14) - the low
+    // plane of a weight of typical size (0.04) would otherwise be an f16 subnormal (absolute 2^-25: 7e-7 of the weight); the
+    // accumulators are multiplied by the inverse (both exact)
+    float wscale = 1.f, descale = 1.f;
+    if constexpr (NP == 2) {
+        float m = 0.f;
+        for (int idx = tid; idx < NC * (H / 2); idx += P_WAVES * 64) {
+            const int c = idx / (H / 2), kp = idx - c * (H / 2);
+            const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c / CT) * H + j0 + (c % CT))) * H + 2 * kp);
+            m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float* const red = reinterpret_cast<float*>(psm);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < P_WAVES; ++w) m = fmaxf(m, red[w]);
+        __syncthreads();
+        int e = 0;
+        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);   // m = f 2^e, f in [0.5, 1)
+        e = max(-100, min(100, 14 - e));
+        wscale = ldexpf(1.f, e);
+        descale = ldexpf(1.f, -e);
+    }
     for (int idx = tid; idx < NC * (H / 2); idx += P_WAVES * 64) {
         const int c = idx / (H / 2), kp = idx - c * (H / 2);
         const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)((c / CT) * H + j0 + (c % CT))) * H + 2 * kp);
         uint32_t w0, w1 = 0, w2 = 0;
         if (NP == 3) split3_pair(v.x, v.y, w0, w1, w2);
+        else if (NP == 2) split2h_pair(v.x * wscale, v.y * wscale, w0, w1);
         else w0 = cvt_pk_bf16(v.x, v.y);
         planes[c * S + kp] = w0;
-        if (NP == 3) {
-            planes[PLW + c * S + kp] = w1;
-            planes[2 * PLW + c * S + kp] = w2;
-        }
+        if (NP >= 2) planes[PLW + c * S + kp] = w1;
+        if (NP == 3) planes[2 * PLW + c * S + kp] = w2;
     }
     __syncthreads();
 
@@ -298,7 +327,10 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         gcol[1] = 2 * H + hcol;            // n (both half-rows multiply the same eight W_hn rows; the upper copy is unused)
     }
 
-    const unsigned plane_bytes = (unsigned)((size_t)B * H * 2), kb_bytes = (unsigned)B * 64u;
+    // exchange rows are padded to an even count: a k-block of a plane then starts on a 128-byte line, so no line holds rows of two
+    // row tiles (two arrival counters) - a reader of one tile would otherwise cache the other's not yet written chunk
+    const unsigned Bx = ((unsigned)B + 1u) & ~1u;
+    const unsigned plane_bytes = (unsigned)((size_t)Bx * H * 2), kb_bytes = Bx * 64u;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xch, (unsigned)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3u * plane_bytes);
     bool dead = false;
 
@@ -434,7 +466,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             }
 
         if (!(CPG_PERSIST_ABLATE & 1)) wait_ge(cnt0 + sb * P_CNT_STRIDE, (unsigned)(NCT * (p + 1)), a.err, a.err_host, dead);
-        if (CPG_PERSIST_XCD_FAST && NP == 3 && p == 0 && sb == 0 && !dead) {
+        if (CPG_PERSIST_XCD_FAST && NP >= 2 && p == 0 && sb == 0 && !dead) {
             // All NCT producers of this row tile have arrived once, so all of them have posted their XCD.  If every one of them
             // sits on THIS XCD they share one L2, and from here on the tile's planes are published with PLAIN stores: the lines stay
             // in that L2 (an sc1 store writes through and drops them, and the readers then fetch at the cross-XCD rate) and are
@@ -494,6 +526,18 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
             // six products per block in the per-step kernel's order, walked TERM BY TERM over the NB P_MI independent
             // accumulators: a dependent MFMA waits for its predecessor to leave the pipe, independent ones issue back to back
             constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+            if constexpr (NP == 2) {   // f16 pair: low x high, high x low, high x high
+                constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int mi = MI0; mi < MI1; ++mi)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+                            acc[mi][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cpg_f16x8, bf[mi][HA[t]]),
+                                                                                __builtin_bit_cast(cpg_f16x8, fb[b][HB[t]]), acc[mi][b], 0, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int t = (NP == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
@@ -523,6 +567,10 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         for (int mi = MI0; mi < MI1; ++mi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if constexpr (NP == 2) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[mi][b][r] *= descale;
+                }
                 float pr, pz, pn;     // r / z pre-activations, and gi_n
                 if constexpr (CT == 16) {
                     pr = gi[mi][r][0] + (acc[mi][0][r] + bh[0]);
@@ -621,12 +669,13 @@ static long resident_workgroups(size_t lds) {
 CPG_EXPORT int cpg_gru_persistent_rows(int H) {
     const CpgOptVal& o = cpg_opt(OPT_GRU_PERSIST);
     if (o.set && o.i == 0) return 0;
-    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const int np = cpg_persist_planes();
     const int ct = pick_ct(H, np);
     if (ct == 0) return 0;
     const size_t lds = fwd_lds_bytes(H, ct, np);
-    const long fit = np == 1 ? (ct == 16 ? resident_workgroups<1, 16>(lds) : resident_workgroups<1, 8>(lds))
-                             : (ct == 16 ? resident_workgroups<3, 16>(lds) : resident_workgroups<3, 8>(lds));
+    const long fit = np == 1   ? (ct == 16 ? resident_workgroups<1, 16>(lds) : resident_workgroups<1, 8>(lds))
+                     : np == 2 ? (ct == 16 ? resident_workgroups<2, 16>(lds) : resident_workgroups<2, 8>(lds))
+                               : (ct == 16 ? resident_workgroups<3, 16>(lds) : resident_workgroups<3, 8>(lds));
     const long groups = fit / (H / ct);          // row groups of 256 rows (8 waves x 32 rows)
     return (int)(groups * P_WAVES * P_WROWS);
 }
@@ -634,7 +683,7 @@ CPG_EXPORT int cpg_gru_persistent_rows(int H) {
 // 1 when ONE launch covers a [B rows, H hidden] sequence
 CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
     if (B <= 0) return 0;
-    if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
+    if ((size_t)(B + 1) * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
     return B <= cpg_gru_persistent_rows(H);
 }
 
@@ -648,7 +697,7 @@ CPG_EXPORT size_t cpg_gru_persistent_path_offset(int B) { return (cnt_words(B) +
 CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
     // counters + error word, then the exchange slots: three bf16 planes of the state, two slots (a slot per step + the initial
     // state with CPG_PERSIST_PLAIN_LOADS)
-    size_t n = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
+    size_t n = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * ((B + 1) & ~1) * H * sizeof(uint16_t);
 #if CPG_PERSIST_TRACE
     n = (n + 255) / 256 * 256 + (size_t)cdiv(cdiv(B, P_WROWS), P_WAVES) * (H / 8) * P_WAVES * T * 8 * sizeof(unsigned long long);
 #endif
@@ -666,7 +715,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const int rows = row_end - row_begin;
-    if (rows > cpg_gru_persistent_rows(H) || (size_t)B * H * 6 * 64 > (size_t)3 << 30) {
+    if (rows > cpg_gru_persistent_rows(H) || (size_t)(B + 1) * H * 6 * 64 > (size_t)3 << 30) {
         cpg_set_error("cpg_gru_seq_fwd_persistent: %d rows of B=%d at H=%d do not fit one persistent launch on this device", rows, B, H);
         return -5;
     }
@@ -687,17 +736,19 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     a.S = plane_stride_words(H);
 #if CPG_PERSIST_TRACE
     {
-        const size_t base = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * B * H * sizeof(uint16_t);
+        const size_t base = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * ((B + 1) & ~1) * H * sizeof(uint16_t);
         a.trace = (unsigned long long*)((char*)sync_scratch + (base + 255) / 256 * 256);
     }
 #endif
     // (the > 64 KB dynamic-LDS opt-in happened in cpg_gru_persistent_rows -> resident_workgroups, per device)
-    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const int np = cpg_persist_planes();
     const int ct = pick_ct(H, np);
     const dim3 grid(a.groups * (H / ct)), block(P_WAVES * 64);
     const size_t lds = fwd_lds_bytes(H, ct, np);
     if (np == 1 && ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<1, 16>), grid, block, lds, s, a);
     else if (np == 1) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<1, 8>), grid, block, lds, s, a);
+    else if (np == 2 && ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<2, 16>), grid, block, lds, s, a);
+    else if (np == 2) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<2, 8>), grid, block, lds, s, a);
     else if (ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<3, 16>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<3, 8>), grid, block, lds, s, a);
     CPG_LAUNCH_CHECK();
@@ -706,7 +757,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
 
 // Name of the kernel a persistent launch at width H runs, as rocprofv3 prints it (bench.py's roofline object)
 CPG_EXPORT int cpg_gru_persistent_kernel_name(int H, char* buf, int n) {
-    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const int np = cpg_persist_planes();
     return snprintf(buf, n, "gru_seq_fwd_persist_kernel<%d, %d>", np, pick_ct(H, np));
 }
 

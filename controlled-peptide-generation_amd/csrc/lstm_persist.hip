@@ -111,17 +111,41 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
     float* const tb = reinterpret_cast<float*>(lpsm + NP * PLW) + wave * (16 * L_TBW);
 
     // ---- W_hh slice -> bf16 planes in LDS, once per sequence: plane[c = group*32 + gate*8 + u][k pair]
+    // NP = 2 (f16 pair, gemm_core.h): the slice is scaled by a power of two so that its largest magnitude lands in [2^13, 2^14), the
+    // accumulators by the inverse - as in csrc/gru_persist.hip
+    float wscale = 1.f, descale = 1.f;
+    if constexpr (NP == 2) {
+        float m = 0.f;
+        for (int idx = tid; idx < L_NC * (H / 2); idx += L_WAVES * 64) {
+            const int c = idx / (H / 2), kp = idx - c * (H / 2);
+            const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)(((c >> 3) & 3) * H + j0 + 8 * (c >> 5) + (c & 7))) * H + 2 * kp);
+            m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float* const red = reinterpret_cast<float*>(lpsm);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < L_WAVES; ++w) m = fmaxf(m, red[w]);
+        __syncthreads();
+        int e = 0;
+        if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &e);
+        e = max(-100, min(100, 14 - e));
+        wscale = ldexpf(1.f, e);
+        descale = ldexpf(1.f, -e);
+    }
     for (int idx = tid; idx < L_NC * (H / 2); idx += L_WAVES * 64) {
         const int c = idx / (H / 2), kp = idx - c * (H / 2);
         const float2 v = *reinterpret_cast<const float2*>(a.w_hh + ((size_t)(((c >> 3) & 3) * H + j0 + 8 * (c >> 5) + (c & 7))) * H + 2 * kp);
         uint32_t w0, w1 = 0, w2 = 0;
         if (NP == 3) split3_pair(v.x, v.y, w0, w1, w2);
+        else if (NP == 2) split2h_pair(v.x * wscale, v.y * wscale, w0, w1);
         else w0 = cvt_pk_bf16(v.x, v.y);
         planes[c * S + kp] = w0;
-        if (NP == 3) {
-            planes[PLW + c * S + kp] = w1;
-            planes[2 * PLW + c * S + kp] = w2;
-        }
+        if (NP >= 2) planes[PLW + c * S + kp] = w1;
+        if (NP == 3) planes[2 * PLW + c * S + kp] = w2;
     }
     __syncthreads();
 
@@ -134,7 +158,11 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
     const int srow = lane >> 2, scq = lane & 3;   // row-layout coordinates after cell_to_rows
     const size_t BH = (size_t)B * H;
 
-    const unsigned plane_bytes = (unsigned)(BH * 2), kb_bytes = (unsigned)B * 64u;
+    // exchange rows are padded to an even count: a k-block of a plane then starts on a 128-byte line.  (With odd B a line held the
+    // last row of one k-block and row 0 of the next - rows of two row tiles with their own arrival counters: the reader of the last
+    // tile cached row 0's chunk before its producers had written it, and row 0's tile then read the stale copy.)
+    const unsigned Bx = ((unsigned)B + 1u) & ~1u;
+    const unsigned plane_bytes = (unsigned)((size_t)Bx * H * 2), kb_bytes = Bx * 64u;
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(a.xch, 0, (unsigned)(T + 1) * 3u * plane_bytes, 0x00020000);
     bool dead = false;
@@ -162,7 +190,12 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
         const float n0 = l_xor1(v[0]), n1 = l_xor1(v[1]), n2 = l_xor1(v[2]), n3 = l_xor1(v[3]);
         if (scq == 0 && row < B) {
             uint32_t w0[4], w1[4], w2[4];
-            if (NP == 3) {
+            if (NP == 2) {
+                split2h_pair(v[0], v[1], w0[0], w1[0]);
+                split2h_pair(v[2], v[3], w0[1], w1[1]);
+                split2h_pair(n0, n1, w0[2], w1[2]);
+                split2h_pair(n2, n3, w0[3], w1[3]);
+            } else if (NP == 3) {
                 split3_pair(v[0], v[1], w0[0], w1[0], w2[0]);
                 split3_pair(v[2], v[3], w0[1], w1[1], w2[1]);
                 split3_pair(n0, n1, w0[2], w1[2], w2[2]);
@@ -174,10 +207,8 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
             const int voff = row * 64 + (jg & 31) * 2;
             const unsigned off = slot_off + (unsigned)(jg >> 5) * kb_bytes;
             __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w0[0], w0[1], w0[2], w0[3]}, rx, voff, off, 16);   // 16 = sc1: write-through
-            if (NP == 3) {
-                __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, off + plane_bytes, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, off + 2 * plane_bytes, 16);
-            }
+            if (NP >= 2) __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w1[0], w1[1], w1[2], w1[3]}, rx, voff, off + plane_bytes, 16);
+            if (NP == 3) __builtin_amdgcn_raw_buffer_store_b128(lu32x4{w2[0], w2[1], w2[2], w2[3]}, rx, voff, off + 2 * plane_bytes, 16);
         }
     };
 
@@ -258,6 +289,18 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
                     for (int pl = 0; pl < NP; ++pl)
                         fb[q][pl] = *reinterpret_cast<const cpg_bf16x8*>(bbase + pl * PLW + q * 16 * S + kb * 16);
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+                if constexpr (NP == 2) {
+                    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int m = 0; m < L_HM; ++m)
+#pragma unroll
+                            for (int q = 0; q < 2 * NG; ++q)
+                                acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cpg_f16x8, bf[m][HA[t]]),
+                                                                                   __builtin_bit_cast(cpg_f16x8, fb[q][HB[t]]), acc[m][q], 0, 0, 0);
+                    return;
+                }
 #pragma unroll
                 for (int t = (NP == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
@@ -287,6 +330,10 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
             for (int m = 0; m < L_HM; ++m)
 #pragma unroll
             for (int gp = 0; gp < NG; ++gp) {
+                if constexpr (NP == 2) {
+                    acc[m][2 * gp] *= descale;
+                    acc[m][2 * gp + 1] *= descale;
+                }
                 const int mi = hp * L_HM + m;
                 float ig[2], fg[2], gg[2], og[2], hv[2];
 #pragma unroll
@@ -360,16 +407,18 @@ long l_resident(size_t lds) {   // workgroups the current device holds at once, 
 // fits the LDS, divides H, and whose workgroups (row groups of 8 waves x 64 / NG rows, times H / (8 NG) column tiles) are all
 // co-resident; 0 = not covered.  More groups = fewer, wider column tiles: less state re-read per workgroup, fewer producers per tile.
 int l_pick_ng(int B, int H) {
-    const int np = cpg_compute_mode_get() == 1 ? 1 : 3;
+    const int np = cpg_persist_planes();
     const CpgOptVal cap = cpg_opt(OPT_LSTM_PERSIST_NG);
     const int top = cap.set && (cap.i == 1 || cap.i == 2) ? (int)cap.i : 4;
-    for (int ng = np == 1 ? top : 1; ng >= 1; ng >>= 1) {   // three planes: one group (wider forms do not fit 256 registers without spills)
+    // three planes: one group (wider forms do not fit 256 registers without spills); the f16 pair: up to two
+    for (int ng = np == 1 ? top : np == 2 ? min(top, 2) : 1; ng >= 1; ng >>= 1) {
         if (H % (8 * ng) != 0) continue;
         const size_t lds = l_lds_bytes(H, np, ng);
         if (lds > 160 * 1024) continue;
         const long wgs = (long)cdiv(cdiv(B, 64 / ng), L_WAVES) * (H / (8 * ng));
         long fit = 0;
         if (np == 1) fit = ng == 4 ? l_resident<1, 4>(lds) : ng == 2 ? l_resident<1, 2>(lds) : l_resident<1, 1>(lds);
+        else if (np == 2) fit = ng == 2 ? l_resident<2, 2>(lds) : l_resident<2, 1>(lds);
         else fit = l_resident<3, 1>(lds);
         if (wgs <= fit) return ng;
     }
@@ -384,17 +433,17 @@ CPG_EXPORT int cpg_lstm_persistent_fits(int B, int H) {
     const CpgOptVal& o = cpg_opt(OPT_LSTM_PERSIST);
     if (o.set && o.i == 0) return 0;
     if (B <= 0 || H < 32 || H % 32 != 0) return 0;
-    if ((size_t)B * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
+    if ((size_t)(B + 1) * H * 6 * 64 > (size_t)3 << 30) return 0;   // exchange slots are addressed through one 32-bit buffer range
     return l_pick_ng(B, H) > 0;
 }
 
 // Name of the kernel a persistent launch runs, as rocprofv3 prints it (bench.py's roofline object)
 CPG_EXPORT int cpg_lstm_persistent_kernel_name(int B, int H, char* buf, int n) {
-    return snprintf(buf, n, "lstm_seq_fwd_persist_kernel<%d, %d>", cpg_compute_mode_get() == 1 ? 1 : 3, l_pick_ng(B, H));
+    return snprintf(buf, n, "lstm_seq_fwd_persist_kernel<%d, %d>", cpg_persist_planes(), l_pick_ng(B, H));
 }
 
 CPG_EXPORT size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H) {
-    return l_sync_words(B) * sizeof(unsigned) + (size_t)(T + 1) * 3 * B * H * sizeof(uint16_t);
+    return l_sync_words(B) * sizeof(unsigned) + (size_t)(T + 1) * 3 * ((B + 1) & ~1) * H * sizeof(uint16_t);
 }
 
 // Whole forward sequence in one launch; arguments as cpg_lstm_seq_fwd.  sync_scratch: cpg_lstm_persistent_scratch_bytes(T,B,H)
@@ -421,11 +470,12 @@ CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, con
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.groups = cdiv(cdiv(B, 64 / ng), L_WAVES);
     a.S = l_plane_stride_words(H);
-    const bool bf = cpg_compute_mode_get() == 1;
-    const size_t lds = l_lds_bytes(H, bf ? 1 : 3, ng);
+    const int np = cpg_persist_planes();
+    const size_t lds = l_lds_bytes(H, np, ng);
     const dim3 grid(a.groups * (H / (8 * ng))), block(L_WAVES * 64);
 #define CPG_LP(NP_, NG_) hipLaunchKernelGGL((lstm_seq_fwd_persist_kernel<NP_, NG_>), grid, block, lds, s, a)
-    if (bf) { if (ng == 4) CPG_LP(1, 4); else if (ng == 2) CPG_LP(1, 2); else CPG_LP(1, 1); }
+    if (np == 1) { if (ng == 4) CPG_LP(1, 4); else if (ng == 2) CPG_LP(1, 2); else CPG_LP(1, 1); }
+    else if (np == 2) { if (ng == 2) CPG_LP(2, 2); else CPG_LP(2, 1); }
     else CPG_LP(3, 1);
 #undef CPG_LP
     CPG_LAUNCH_CHECK();
