@@ -28,6 +28,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide)
 # Kernels on the split engine compute an f32-grade product as SIX bf16 MFMAs on 3-way split operands: the best f32-grade rate
 # that pipe can give is the bf16 peak / 6.  Exact kernels (v_mfma_f32_16x16x4_f32) are priced against the f32 MFMA peak.
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_PAIR_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0   # f32-grade on f16 pairs: three f16 MFMAs (same rate as bf16) per block (csrc/gemm_core.h)
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch from PMC counters (FETCH_SIZE / WRITE_SIZE in KB, separate rocprofv3 passes, tools/pmc_run.sh +
 # tools/pmc_summary.py --json): counters cannot be collected from inside this script, so the per-kernel means of the
@@ -121,7 +122,8 @@ def family_roofline(family, dims, avg_us, launches):
     L = lib().dll
     bf16 = L.cpg_get_compute_mode() == 1
     if family == "fwd_persist":
-        kernel, split, flops = _cname("cpg_gru_persistent_kernel_name", H), (2 if bf16 else 1), T * 2.0 * B * H * 3 * H
+        kernel, flops = _cname("cpg_gru_persistent_kernel_name", H), T * 2.0 * B * H * 3 * H
+        split = {1: 2, 2: 3, 3: 1}[int(kernel.split("<")[1].split(",")[0])]   # planes of the kernel: 1 bf16 mode, 2 f16 pair, 3 bf16 triple
     elif family == "fwd_step":
         kernel, split = _cname("cpg_gru_step_kernel_name", 0, B, H, nd, 0), L.cpg_gru_step_kernel_is_split(0, B, H, nd, 0)
         flops = nd * 2.0 * B * H * 3 * H
@@ -132,7 +134,8 @@ def family_roofline(family, dims, avg_us, launches):
         kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), 2.0 * 3 * H * H * T * B
         split = 2 if kernel.endswith(", 1>") else 1
     elif family == "lstm_fwd_persist":
-        kernel, split, flops = _cname("cpg_lstm_persistent_kernel_name", B, H), (2 if bf16 else 1), T * 2.0 * B * H * 4 * H
+        kernel, flops = _cname("cpg_lstm_persistent_kernel_name", B, H), T * 2.0 * B * H * 4 * H
+        split = {1: 2, 2: 3, 3: 1}[int(kernel.split("<")[1].split(",")[0])]
     elif family in ("lstm_fwd_step", "lstm_bwd_step"):   # LSTM extension: four gates
         kind = 0 if family == "lstm_fwd_step" else 1
         kernel, split = _cname("cpg_lstm_step_kernel_name", kind, B * nd, H), L.cpg_lstm_step_kernel_is_split(kind, B, H)
@@ -143,13 +146,14 @@ def family_roofline(family, dims, avg_us, launches):
     else:
         return None
     ach = flops / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
-    peak = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_SPLIT_TFLOPS, 2: PEAK_BF16_MFMA_TFLOPS}[int(split)]
+    peak = {0: PEAK_F32_MFMA_TFLOPS, 1: PEAK_SPLIT_TFLOPS, 2: PEAK_BF16_MFMA_TFLOPS, 3: PEAK_PAIR_TFLOPS}[int(split)]
     bf16_gates = bool(bf16 and family in ("fwd_persist", "fwd_step", "bwd_step") and L.cpg_gru_gates_bf16(B, H, 0) == 1)
     nbytes = family_bytes(family, dims, bf16_gates)
     gbs = nbytes / (avg_us * 1e-6) / 1e9 if (nbytes and avg_us > 0) else 0.0
     mfma_frac, hbm_frac = ach / peak, gbs / HBM_PEAK_GBS
     traffic = pmc_traffic(kernel)
-    pipe = {1: "bf16 MFMA x6 on 3-way split operands (f32-grade): 2500/6", 0: "exact f32 MFMA: 157.3", 2: "bf16 MFMA: 2500"}[int(split)]
+    pipe = {1: "bf16 MFMA x6 on 3-way split operands (f32-grade): 2500/6", 0: "exact f32 MFMA: 157.3", 2: "bf16 MFMA: 2500",
+            3: "f16 MFMA x3 on f16-pair operands (f32-grade): 2500/3"}[int(split)]
     r = {"kernel": kernel, "avg_launch_us": round(avg_us, 2), "launches_timed": launches, "traffic": traffic,
          "mfma": {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(mfma_frac, 4), "pipe": pipe,
                   "flops_per_launch": flops, "frac_of_f32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 4)},

@@ -622,6 +622,16 @@ def _persist_failed(kind):
                    "per-step kernels" % (kind.upper(), kind))
 
 
+def _pair_scratch(B, H, ndir, dev):
+    """Scratch of the f16-pair backward step (cpg_gru_bwd_pair_bytes): [ndir, bytes] uint8, or None where that step does not
+    cover the shape / compute mode (the exact-f32 product then)."""
+    nb = int(query("cpg_gru_bwd_pair_bytes", int(B), int(H), int(ndir)))
+    if nb == 0:
+        return None
+    t = torch.empty(ndir, (nb + 255) // 256 * 256, device=dev, dtype=torch.uint8)
+    return t if ndir == 2 else t[0]
+
+
 def gates_dtype(B, H, ragged=False):
     """Element type of a GRU sequence's saved gates [T,4,B,H]: bf16 in the bf16 compute mode on dense batches that the
     direct-to-LDS backward step covers (cpg_gru_gates_bf16: the BPTT epilogue is HBM-bound there), f32 otherwise."""
@@ -733,10 +743,11 @@ class GruSeqFn(Function):
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # receives W_hh^T for the direct-to-LDS step kernel
+        pair = _pair_scratch(B, H, 1, dev) if (step_rows is None and not dgb) else None   # f16-pair form of that step
         _check_gates(gates, B, H, step_rows is not None)
         with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
             call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                 _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), dgb, _stream())
+                 _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _p(pair), dgb, _stream())
         if has_h0 and not ctx.tail:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -848,10 +859,12 @@ class GruBiSeqFn(Function):
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
+        pair = _pair_scratch(B, H, 2, dev) if not dgb else None
         _check_gates(gt_f, B, H)
         with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
             call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), dgb, _stream())
+                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]),
+                 _p(pair[0]) if pair is not None else None, _p(pair[1]) if pair is not None else None, dgb, _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []

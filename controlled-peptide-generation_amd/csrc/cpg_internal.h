@@ -29,7 +29,7 @@ bool cpg_gru_store_bf16(int B, int H, bool dense);
 bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 311
+#define CPG_ABI_VERSION 312
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).
@@ -43,6 +43,7 @@ enum CpgOpt {
     OPT_GRU_BWD_TILE,     // "32x32" | "64x32" | "32x64" | "64x64": tile of the backward step
     OPT_GRU_BWD_DL2,      // 0 never / 1 whenever tiles are full: the 512-thread two-K-halves backward step
     OPT_GRU_BWD_STAGGER,  // slabs between the staggered epilogue-operand fetches of the register-staged backward step
+    OPT_GRU_BWD_ENGINE,   // "f16x2" (default) | "exact": product of the direct-to-LDS backward step in the f32-grade mode
     OPT_LSTM_BWD_DL,      // 0: register-staged LSTM backward step
     OPT_TN_TILE,          // tile of the dW (transposed-use) products, e.g. "256x128"
     OPT_TN_SPLIT,         // split-K factor of those products

@@ -838,6 +838,11 @@ __device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int
 // row is again 128 bytes = eight 16-byte chunks - the LDS image, the LDS-DMA pattern and the swizzle are those of the f32 slab;
 // chunk q of a row now holds k = 8q .. 8q+7, which is exactly the A / B fragment of v_mfma_f32_16x16x32_bf16 for lane group
 // q & 3 of k-block q >> 2: the two ds_read_b128 of a block row feed two MFMAs, no conversion, half the bytes per k.
+// PREC = 3 (f32-grade on f16 PAIRS that are pairs in memory, round 4): a 128-byte slab row holds 32 k as [32 hi | 32 lo] f16, so
+// chunks 0..3 are the high halves of k = 8q .. 8q+7 and chunks 4..7 the low halves of the same k - the reads of PREC 2, feeding
+// THREE v_mfma_f32_16x16x32_f16 per block and slab (lo x hi, hi x lo, hi x hi): the bytes per k of the f32 slab, 32 k per slab, and
+// 48 matrix-pipe cycles per block and slab in place of the 268 of eight f32 MFMAs.  `pre(kt)` runs ahead of slab kt's products
+// (the caller rescales its accumulators when the operands' power-of-two scale changes along k) and returns false to skip them.
 template <int BM, int BN, int NS = 3, int PREC = 0>
 struct DlLoop {
     static constexpr int MI = BM / 32, NI = BN / 32;
@@ -850,7 +855,12 @@ struct DlLoop {
     template <class Hook, class E>
     __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
                                                f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook) {
-        static_assert((PREC == 2) == (sizeof(E) == 2), "PREC 2 <-> bf16 operands in memory");
+        run(A, lda, Bt, ldb, K, smem, acc, hook_kt, hook, [](int) { return true; });
+    }
+    template <class Hook, class E, class Pre>
+    __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
+                                               f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre) {
+        static_assert((PREC >= 2) == (sizeof(E) == 2), "PREC 2 / 3 <-> 16-bit operands in memory");
         constexpr int EPC = 16 / (int)sizeof(E);   // elements per 16-byte chunk
         constexpr int BKE = 8 * EPC;               // elements per slab (a row of a slab is always 128 bytes)
         // (a 512-thread workgroup runs two of these loops side by side - its two 256-thread halves, each on its own ring and its
@@ -893,7 +903,29 @@ struct DlLoop {
             }
             __builtin_amdgcn_s_barrier();
             if (kt + AHEAD < KT) issue(kt + AHEAD, refill);
-            if constexpr (PREC == 2) {
+            if constexpr (PREC == 3) {
+                if (pre(kt)) {
+                    cpg_f16x8 fa[2][MI], fb[2][NI];   // [0] high halves, [1] low halves
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        fa[0][mi] = *reinterpret_cast<const cpg_f16x8*>(cur + oa0 + mi * 512);
+                        fa[1][mi] = *reinterpret_cast<const cpg_f16x8*>(cur + oa1 + mi * 512);
+                    }
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        fb[0][ni] = *reinterpret_cast<const cpg_f16x8*>(cur + ob0 + ni * 512);
+                        fb[1][ni] = *reinterpret_cast<const cpg_f16x8*>(cur + ob1 + ni * 512);
+                    }
+                    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[HA[t]][mi], fb[HB[t]][ni], acc[mi][ni], 0, 0, 0);
+                }
+            } else if constexpr (PREC == 2) {
                 cpg_bf16x8 fa[2][MI], fb[2][NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {

@@ -16,6 +16,8 @@
 #include "gemm_core.h"
 #include "cpg_internal.h"
 #include <stdlib.h>
+#include <limits.h>
+#include <string.h>
 
 #ifndef CPG_FWD_PREFETCH
 #define CPG_FWD_PREFETCH 0   // measured: fetching the epilogue operands ahead of the MFMA loop costs registers (occupancy) for no gain
@@ -175,7 +177,17 @@ struct GruBwdArgs {
     int ep_step;                // (even) slab spacing of the staggered epilogue-operand fetch; 0: every workgroup ahead of slab 0
     int gates_bf16;             // gates hold bf16 elements (bf16 compute mode, direct-to-LDS kernels only)
     int dg_bf16;                // bf16 gradient storage (implies gates_bf16): dG_next / dG_out hold bf16 [B,4H], w_hhT bf16 [H,3H]
+    // f16-pair engine of the direct-to-LDS step (PREC 3, below): the three recurrent blocks of dG once more, as the NEXT launch's
+    // A operand - [B][6H] f16, k-groups of 32 in the order (column group, block), each 128 bytes = [32 hi | 32 lo] of the values
+    // times 2^e, e = ex[(row / 32) * (H / 32) + column group] (INT_MAX: the 32 x 32 x 3 values are all zero).  w_hhT then holds the
+    // same layout of W_hh^T times 2^W_PAIR_EXP.
+    const uint16_t* pp_next;
+    const int* ex_next;
+    uint16_t* pp_out;
+    int* ex_out;
 };
+
+constexpr int W_PAIR_EXP = 8;   // power-of-two scale of the f16-pair image of W_hh^T (pair_w_kernel)
 
 struct GruBwdPair {
     GruBwdArgs d[2];
@@ -436,10 +448,46 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
                 }
             }
     };
+    int e_cur = 0;   // PREC 3: acc holds (sum so far) x 2^(e_cur + W_PAIR_EXP)
     if (g.dG_next && !(CPG_DL_ABLATE & 4)) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
-        if constexpr (PREC == 2)
+        if constexpr (PREC == 3) {
+            // exponents of this wave's 32 rows, one per 32-column group of the gate axis: lane l holds group l's
+            const int NG32 = H / 32;
+            const int ev = lane < NG32 ? g.ex_next[(size_t)((m0 + wm * 32) / 32) * NG32 + lane] : INT_MAX;
+            int e_ref = ev;   // the largest-magnitude group's exponent (the smallest)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) e_ref = min(e_ref, __shfl_xor(e_ref, o));
+            e_cur = e_ref == INT_MAX ? 0 : e_ref;
+            bool live = false;
+            auto pre = [&](int kt) {
+                const int gi = kt / 3;
+                if (kt - 3 * gi == 0) {
+                    const int e = __builtin_amdgcn_readlane(ev, gi);
+                    // groups of zeros, and groups more than 2^60 below the largest one (their contribution is below every bit
+                    // of the f32 result; rescaling the accumulators to their unit could overflow), are skipped
+                    live = e != INT_MAX && e - e_ref <= 60;
+                    if (live && e != e_cur) {
+                        const float f = __builtin_bit_cast(float, (unsigned)(127 + (e - e_cur)) << 23);   // |e - e_cur| <= 60
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= f;
+                        e_cur = e;
+                    }
+                }
+                return live;
+            };
+            DL::run(g.pp_next + (size_t)m0 * 6 * H, (size_t)6 * H, reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 6 * H,
+                    (size_t)6 * H, 6 * H, cpg_smem, acc, min(phase * g.ep_step, 3 * H / 32 - 1), load_ep, pre);
+            // back to the unit of dh: 2^-(e_cur + W_PAIR_EXP), two exact factors (each a normal f32)
+            const float f0 = __builtin_bit_cast(float, (unsigned)(127 - e_cur) << 23), f1 = __builtin_bit_cast(float, (unsigned)(127 - W_PAIR_EXP) << 23);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[mi][ni] * f0 * f1;
+        } else if constexpr (PREC == 2)
             DL::run(reinterpret_cast<const uint16_t*>(g.dG_next) + (size_t)m0 * 4 * H, (size_t)4 * H,
                     reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
                     min(phase * (g.ep_step / 2), 3 * H / 64 - 1), load_ep);
@@ -449,6 +497,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
     } else {
         load_ep();
     }
+    f32x4 pv[PREC == 3 ? MI : 1][PREC == 3 ? NI : 1][3];   // PREC 3: the three recurrent blocks of dG, kept for the pair planes
+    float vmax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -464,7 +514,55 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
             const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
             st_dg4<PREC>(g.dG_out, (size_t)row, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre);
+            if constexpr (PREC == 3) {
+                pv[mi][ni][0] = dr_pre; pv[mi][ni][1] = dz_pre; pv[mi][ni][2] = dn_pre * rg;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(pv[mi][ni][q][j]));   // (fmaxf drops a NaN: see below)
+            }
         }
+    if constexpr (PREC == 3) {
+        if (!g.gates || !g.pp_out) return;   // (block-uniform)
+        // ---- the next launch's A operand: this wave's 32 rows x BN/2 columns x 3 blocks as f16 pairs times 2^e, e chosen so that
+        // the largest magnitude of the 32 x 32 x 3 group lands in [2^13, 2^14)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if constexpr (BN == 32) {   // two waves (wn = 0, 1) share a 32-column group
+            float* const red = cpg_smem;   // (the ring is idle: every wave is past its last fragment read after this barrier)
+            __syncthreads();
+            if (lane == 0) red[wave] = vmax;
+            __syncthreads();
+            vmax = fmaxf(red[2 * wm], red[2 * wm + 1]);
+        }
+        int e = INT_MAX;
+        if (vmax > 0.f) {
+            int fe = 0;
+            if (vmax < 3.0e38f) { (void)frexpf(vmax, &fe); e = max(-100, min(100, 14 - fe)); }
+            else e = 0;   // an infinity among the values: unscaled, it (and any NaN) reaches the planes as it is
+        }
+        const int grp = (j0 + wn * (BN / 2)) / 32;
+        if (lane == 0 && (BN == 64 || wn == 0)) g.ex_out[(size_t)((m0 + wm * 32) / 32) * (H / 32) + grp] = e;
+        if (e != INT_MAX) {
+            const float sc = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
+                    uint16_t* const d = g.pp_out + (size_t)row * 6 * H + (size_t)(3 * (col / 32)) * 64 + (col & 31);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const f32x4 v = pv[mi][ni][q] * sc;
+                        uint32_t h0, l0, h1, l1;
+                        split2h_pair(v[0], v[1], h0, l0);
+                        split2h_pair(v[2], v[3], h1, l1);
+                        *reinterpret_cast<uint2*>(d + q * 64) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(d + q * 64 + 32) = make_uint2(l0, l1);
+                    }
+                }
+        }
+    }
 }
 
 
@@ -742,14 +840,22 @@ struct BwdPlan {
     BwdKernelKind kind;
     BwdTile tile;
     bool bf16;
+    bool pair_ok;   // the f16-pair form of the direct-to-LDS step covers this launch shape (f32-grade mode, 64-row tiles)
 };
+// f16-pair engine of the backward step (PREC 3): option gru_bwd_engine = "exact" keeps the exact-f32 MFMA
+static bool bwd_pair_enabled() {
+    if (cpg_compute_mode_get() == 1) return false;
+    const CpgOptVal o = cpg_opt(OPT_GRU_BWD_ENGINE);
+    return !(o.set && strcmp(o.s, "exact") == 0);
+}
 static BwdPlan bwd_plan(int rows, int H, int nd, int row0, bool vec, bool have_wt, bool dense) {
     const bool bf16 = cpg_compute_mode_get() == 1;
     if (vec && have_wt && dense && bwd_dl_shape_ok(row0, row0 + rows, H)) {
-        if (!cpg_opt(OPT_GRU_BWD_TILE).set && bwd_dl2_wanted(rows, H, nd, bf16)) return {BK_DL2, {64, 64}, bf16};
-        return {BK_DL, dl_tile(rows, H, nd), bf16};
+        if (!cpg_opt(OPT_GRU_BWD_TILE).set && bwd_dl2_wanted(rows, H, nd, bf16)) return {BK_DL2, {64, 64}, bf16, false};
+        const BwdTile t = dl_tile(rows, H, nd);
+        return {BK_DL, t, bf16, t.bm == 64 && H <= 2048 && bwd_pair_enabled()};
     }
-    return {BK_STAGED, staged_tile(rows, H, nd), false};   // exact f32 in either compute mode
+    return {BK_STAGED, staged_tile(rows, H, nd), false, false};   // exact f32 in either compute mode
 }
 
 static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
@@ -772,6 +878,12 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
                       "scratch, aligned operands, option gru_bwd_dl unchanged since the forward pass)");
         return -4;
     }
+    const bool pair = a.pp_next != nullptr || a.pp_out != nullptr;
+    if (pair && !(pl.kind == BK_DL && pl.pair_ok)) {
+        cpg_set_error("gru backward: the f16-pair step was prepared for this sequence but a launch of it is not covered (options changed "
+                      "between the launches of one sequence?)");
+        return -4;
+    }
     const bool dgb = a.dg_bf16 != 0;   // bf16 gradient storage: PREC 2 kernels (64-deep slabs: 3H, and 3H/2 for the two-halves form, % 64)
     if (dgb && (!a.gates_bf16 || (3 * a.H) % 64 != 0 || (pl.kind == BK_DL2 && (3 * a.H / 2) % 64 != 0))) {
         cpg_set_error("gru backward: bf16 gradient storage needs bf16 saved gates and a width the 64-deep slabs divide (H %% 128 == 0)");
@@ -782,7 +894,8 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
         rc = dgb ? launch_dl2<2>(pr, nd, s) : pl.bf16 ? launch_dl2<1>(pr, nd, s) : launch_dl2<0>(pr, nd, s);
     } else if (pl.kind == BK_DL) {
 #define CPG_DL_PICK(BM, BN) (dgb ? launch_dl<BM, BN, 2>(pr, nd, s) : pl.bf16 ? launch_dl<BM, BN, 1>(pr, nd, s) : launch_dl<BM, BN, 0>(pr, nd, s))
-        if (pl.tile.bm == 64 && pl.tile.bn == 64) rc = CPG_DL_PICK(64, 64);
+        if (pair) rc = pl.tile.bn == 64 ? launch_dl<64, 64, 3>(pr, nd, s) : launch_dl<64, 32, 3>(pr, nd, s);
+        else if (pl.tile.bm == 64 && pl.tile.bn == 64) rc = CPG_DL_PICK(64, 64);
         else if (pl.tile.bm == 64) rc = CPG_DL_PICK(64, 32);
         else if (pl.tile.bn == 64) rc = CPG_DL_PICK(32, 64);
         else rc = CPG_DL_PICK(32, 32);
@@ -797,6 +910,25 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     if (rc) return rc;
     CPG_LAUNCH_CHECK();
     return 0;
+}
+
+// W_hh^T as f16 pairs for the PREC 3 backward step: out[j][6H] f16, k-groups of 32 in the order (column group, block) as the dG
+// planes, each [32 hi | 32 lo] of W_hh[k][j] x 2^W_PAIR_EXP.  The scale is FIXED: weights of magnitude 2^-11 .. 255 keep a normal
+// low half (2^-22 relative), smaller ones 2^-33 absolute; a weight of 256 or more overflows the f16 high half to infinity (loud:
+// it reaches every gradient).  grid (H/32, 3H/32), block (32, 8).
+__global__ void pair_w_kernel(const float* w, int H, uint16_t* out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // tile[k - r0][j - c0]
+    for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = w[(size_t)(r0 + i) * H + c0 + threadIdx.x];
+    __syncthreads();
+    const int tid = threadIdx.y * 32 + threadIdx.x, jj = tid >> 3, q = tid & 7, c8 = (q & 3) * 8;
+    const int blk = r0 / H, grp = (r0 - blk * H) / 32;
+    const float sc = __builtin_bit_cast(float, (unsigned)(127 + W_PAIR_EXP) << 23);
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2h_pair(tile[c8 + 2 * i][jj] * sc, tile[c8 + 2 * i + 1][jj] * sc, hi[i], lo[i]);
+    uint16_t* const d = out + (size_t)(c0 + jj) * 6 * H + (size_t)(3 * grp + blk) * 64 + (q >> 2) * 32 + c8;
+    *reinterpret_cast<uint4*>(d) = (q >> 2) ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 
 // out[H,3H] = w[3H,H]^T
@@ -829,8 +961,9 @@ __global__ void transpose_w_bf16_kernel(const float* w, int R, int C, uint16_t* 
     }
 }
 
-static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s, bool bf16 = false) {
-    if (bf16) hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, reinterpret_cast<uint16_t*>(wT));
+static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s, bool bf16 = false, bool pair = false) {
+    if (pair) hipLaunchKernelGGL(pair_w_kernel, dim3(H / 32, 3 * H / 32), dim3(32, 8), 0, s, w_hh, H, reinterpret_cast<uint16_t*>(wT));
+    else if (bf16) hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, reinterpret_cast<uint16_t*>(wT));
     else hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, wT);
     CPG_LAUNCH_CHECK();
     return 0;
@@ -966,7 +1099,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     if (kind == 1) {
         const BwdPlan pl = bwd_plan(B, H, ndir, 0, vec, have_wt != 0, true);
         if (pl.kind == BK_DL2) return snprintf(buf, n, "gru_step_bwd_dl2_kernel<%d>", pl.bf16 ? 1 : 0);
-        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3, %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : 0);
+        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3, %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : pl.pair_ok ? 3 : 0);
         if (pl.tile.bm == 64) tc_name<GB64>(tc, sizeof tc);
         else if (pl.tile.bn == 64) tc_name<GB32>(tc, sizeof tc);
         else tc_name<GB32N>(tc, sizeof tc);
@@ -976,11 +1109,11 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
 }
 
 // Product form of the named step kernel: 0 exact-f32 MFMA, 1 split-bf16 engine (six bf16 MFMAs per block), 2 one bf16 MFMA
-// per block (bf16 compute mode).
+// per block (bf16 compute mode), 3 f16 pairs (three f16 MFMAs per block).
 CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt) {
     if (kind == 0) return cpg_compute_mode_get() == 1 ? 2 : 1;
     const BwdPlan pl = bwd_plan(B, H, ndir, 0, H % 4 == 0, have_wt != 0, true);
-    if (pl.kind != BK_STAGED) return pl.bf16 ? 2 : 0;
+    if (pl.kind != BK_STAGED) return pl.bf16 ? 2 : (pl.kind == BK_DL && pl.pair_ok) ? 3 : 0;
     return pl.tile.bn == 64 ? 1 : 0;   // XC k-row pairs: 64-column tiles run the split engine
 }
 
@@ -1030,12 +1163,28 @@ CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_
     return cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
 }
 
+// Scratch of the f16-pair backward step, per direction: two [B][6H] f16 plane images (ping-pong over the steps) and their two
+// [B/32][H/32] exponent tables.  0: the pair step does not cover this shape / mode (pass null).
+CPG_EXPORT size_t cpg_gru_bwd_pair_bytes(int rows, int H, int ndir) {
+    if (rows <= 0 || H <= 0 || H % 32 != 0 || rows % 64 != 0) return 0;
+    const BwdPlan pl = bwd_plan(rows, H, ndir, 0, true, true, true);
+    if (!(pl.kind == BK_DL && pl.pair_ok)) return 0;
+    return 2 * ((size_t)rows * 6 * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int));
+}
+static void pair_split(void* scratch, int B, int H, uint16_t* (&pp)[2], int* (&ex)[2]) {
+    const size_t plane = (size_t)B * 6 * H;
+    pp[0] = (uint16_t*)scratch;
+    pp[1] = pp[0] + plane;
+    ex[0] = (int*)(pp[1] + plane);
+    ex[1] = ex[0] + (size_t)(B / 32) * (H / 32);
+}
+
 // dhs_ext: [T,B,H] time-aligned external gradients on every step's output (or null); dh_last: gradient on the final state.
 // dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
 CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
-                               int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, int dg_bf16,
-                               void* stream) {
+                               int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, void* pair_scratch,
+                               int dg_bf16, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
@@ -1043,8 +1192,13 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     const bool gbf = cpg_gru_store_bf16(B, H, step_rows == nullptr);
     const bool dgb = dg_bf16 != 0;
     CPG_CHECK_ARG(!dgb || (gbf && w_hhT_scratch && row_begin == 0 && row_end == B));   // bf16 gradient storage: whole dense batches on the direct-to-LDS step
+    // f16-pair step: every launch of the sequence has the same shape, so the plan of one decides for all
+    const bool pair = pair_scratch && w_hhT_scratch && !dgb && cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) > 0 && row_begin % 64 == 0;
+    uint16_t* PP[2] = {nullptr, nullptr};
+    int* EX[2] = {nullptr, nullptr};
+    if (pair) pair_split(pair_scratch, B, H, PP, EX);
     if (w_hhT_scratch) {
-        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb);
+        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb, pair);
         if (rc) return rc;
     }
     int prev_t = -1;
@@ -1063,13 +1217,16 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         a.gates_bf16 = gbf;
         a.dg_bf16 = dgb;
         const int cur = (p + 2) & 1;
+        a.pp_next = nullptr; a.ex_next = nullptr; a.pp_out = nullptr; a.ex_out = nullptr;
         if (prev_t >= 0) {
             a.dG_next = gate_at(dG, (size_t)prev_t * B * 4 * H, dgb);
             a.dH_next = dH_scratch + (size_t)(cur ^ 1) * BH;
+            if (pair) { a.pp_next = PP[cur ^ 1]; a.ex_next = EX[cur ^ 1]; }
         } else {
             a.dG_next = nullptr;
             a.dH_next = nullptr;
         }
+        if (pair && p >= 0) { a.pp_out = PP[cur]; a.ex_out = EX[cur]; }
         a.ext2 = (p == T - 1) ? dh_last : nullptr;
         if (p >= 0) {
             a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
@@ -1391,15 +1548,22 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
                                  const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
                                  float* dG_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
-                                 float* w_hhT_scratch_r, int dg_bf16, void* stream) {
+                                 float* w_hhT_scratch_r, void* pair_scratch_f, void* pair_scratch_r, int dg_bf16, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
     if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
     const bool dgb = dg_bf16 != 0;
     CPG_CHECK_ARG(!dgb || (cpg_gru_store_bf16(B, H, true) && w_hhT_scratch_f));
+    const bool pair = pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && !dgb && cpg_gru_bwd_pair_bytes(B, H, 2) > 0;
+    uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    if (pair) {
+        pair_split(pair_scratch_f, B, H, PP[0], EXP[0]);
+        pair_split(pair_scratch_r, B, H, PP[1], EXP[1]);
+    }
     if (w_hhT_scratch_f) {
-        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream, dgb);
-        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream, dgb);
+        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream, dgb, pair);
+        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream, dgb, pair);
         if (rc) return rc;
     }
     const float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
@@ -1429,13 +1593,17 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.row1 = B;
             a.w_hh = W[d];
             a.w_hhT = WT[d];
+            a.pp_next = nullptr; a.ex_next = nullptr;
+            a.pp_out = pair ? PP[d][cur] : nullptr;
+            a.ex_out = pair ? EXP[d][cur] : nullptr;
             if (prev_t[d] >= 0) {
                 a.dG_next = gate_at(DG[d], (size_t)prev_t[d] * B * 4 * H, dgb);
                 a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;
+                if (pair) { a.pp_next = PP[d][cur ^ 1]; a.ex_next = EXP[d][cur ^ 1]; }
             } else {
                 a.dG_next = nullptr;
                 a.dH_next = nullptr;
-                }
+            }
             a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
             a.ext2 = (p == T - 1) ? LAST[d] : nullptr;   // gradient on the direction's final state enters at its last step
             a.gates = gate_at(GT[d], (size_t)t * 4 * BH, gbf);

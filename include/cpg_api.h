@@ -126,11 +126,17 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
  * columns 0..3H are the hidden-side gate gradients, columns {0..2H, 3H..4H} the input-side ones;
  * dH_scratch [2,B,H]; dh0 [B,H] gradient of the initial state (null to skip).
  * w_hhT_scratch [H,3H] (optional): receives W_hh^T once per call for the direct-to-LDS step kernel (both operands
- * K-contiguous; full 32 x 32 tiles of dense batches); null keeps the register-staged kernel for every shape. */
+ * K-contiguous; full 32 x 32 tiles of dense batches); null keeps the register-staged kernel for every shape.
+ * pair_scratch (optional; with w_hhT_scratch): cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) bytes for the f16-pair form of
+ * that step (f32-grade mode, 64-row tiles): every launch then also writes the three recurrent blocks of its dG as f16 pairs
+ * times a power of two per 32 x 32 group - the next launch's operand, three f16 MFMAs per block in place of eight f32 ones -
+ * and w_hhT_scratch receives W_hh^T in the same form.  null (or a query answer of 0): the exact-f32 product. */
+CPG_API size_t cpg_gru_bwd_pair_bytes(int rows, int H, int ndir /* 1 | 2: directions per launch */);
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
                             int row_begin, int row_end, const int32_t* step_rows /* as in cpg_gru_seq_fwd; dG rows of dead
-                            (t,row) pairs are not written: pass a zeroed dG */, float* w_hhT_scratch, int dg_bf16, void* stream);
+                            (t,row) pairs are not written: pass a zeroed dG */, float* w_hhT_scratch, void* pair_scratch, int dg_bf16,
+                            void* stream);
 /* Both directions of one biGRU layer in lock step, ONE launch per step for the pair (launch p: time p forward, time
  * T-1-p reverse).  Arguments as in cpg_gru_seq_fwd / _bwd per direction (_f forward, _r reverse); no initial-state
  * gradient (the encoder starts from h0 = 0). */
@@ -143,7 +149,9 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
                               const float* dhs_ext_r, const float* dh_last_f /* [B,H] gradient on the final state of the
                               direction, or null */, const float* dh_last_r, float* dG_f, float* dG_r, float* scratch_f,
                               float* scratch_r, float* w_hhT_scratch_f,
-                              float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */, int dg_bf16, void* stream);
+                              float* w_hhT_scratch_r /* as in cpg_gru_seq_bwd; both or neither */,
+                              void* pair_scratch_f, void* pair_scratch_r /* cpg_gru_bwd_pair_bytes(B, H, 2) bytes each, or null */,
+                              int dg_bf16, void* stream);
 /* Persistent form: the WHOLE time loop of one direction in ONE launch (csrc/gru_persist.hip): each workgroup keeps the
  * W_hh rows of 16 hidden units in LDS (already split into bf16 planes) for 256 batch rows and the column-tile workgroups of
  * a row tile hand h_t to each other through the state slab (write-through stores + arrival counters), so nothing is

@@ -182,14 +182,20 @@ def _bwd_inputs(d, B, H, T, reverse, seed, dh_last=True):
     return hs, gates, dhs, last
 
 
-def _bwd(d, B, H, T, reverse, hs, gates, dhs, last, with_wT=True):
+def _bwd(d, B, H, T, reverse, hs, gates, dhs, last, with_wT=True, pair=False):
+    """pair: hand the scratch of the f16-pair step (the training path does, cpg/ops.py); without it the exact-f32 product runs."""
+    from cpg import ops
     from cpg.ops import _p, _stream, call
     dev = torch.device("cuda")
     dG, dh0 = torch.zeros(T, B, 4 * H, device=dev), torch.zeros(B, H, device=dev)
     scr = torch.empty(2, B, H, device=dev)
     wT = torch.empty(H, 3 * H, device=dev) if with_wT else None
+    ps = ops._pair_scratch(B, H, 1, dev) if pair else None
+    assert not pair or ps is not None
+    if ps is not None:
+        ps.fill_(0xFF)   # NaN patterns: nothing may be read before it is written
     call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(hs), _p(gates), _p(dhs), _p(last), _p(dG), _p(scr), _p(dh0),
-         0, B, None, _p(wT), 0, _stream())
+         0, B, None, _p(wT), _p(ps), 0, _stream())
     torch.cuda.synchronize()
     return dG, dh0
 
@@ -213,6 +219,56 @@ def test_backward_direct_to_lds_tiles_match_the_register_staged_kernel(B, H, T, 
         assert torch.equal(dh0, ref0), t
     dG, dh0 = _bwd(d, B, H, T, reverse, hs, gates, dhs, last)     # the launcher's own choice
     assert torch.equal(dG, ref) and torch.equal(dh0, ref0)
+
+
+@pytest.mark.parametrize("B,H,T,reverse", [(2048, 512, 25, False), (2048, 512, 25, True), (256, 128, 6, False), (192, 96, 5, True),
+                                             (1024, 1024, 4, False)])
+def test_backward_f16_pair_step_vs_exact(B, H, T, reverse):
+    """The f16-pair form of the direct-to-LDS step (PREC 3: dG handed from launch to launch as f16 pairs times a power of two per
+    32 x 32 group, three f16 MFMAs per block) against the exact-f32 product, both tiles: dG of every step and dh0 within f32
+    rounding of the products (the BPTT chain is 25 steps long: a few 1e-7 of the largest value).  Then the same with gradient
+    magnitudes spread over 30 orders (column groups and rows scaled by powers of ten, one group and one row block all zero): every
+    element must agree RELATIVE to the largest value of its own 32-row block - the per-group exponents, the accumulator rescaling
+    and the skip of all-zero groups."""
+    from cpg import ops
+    d = _inputs(B, H, T, 24, seed=B + H + T + 2)
+    hs, gates, dhs, last = _bwd_inputs(d, B, H, T, reverse, seed=3)
+    ref, ref0 = _bwd(d, B, H, T, reverse, hs, gates, dhs, last)
+    tiles = ["64x32"] + (["64x64"] if H % 64 == 0 else [])
+    for t in tiles:
+        with ops.options(gru_bwd_tile=t):
+            buf = ctypes_name(1, B, H, 1)
+            assert buf.endswith(", 3, 3>"), buf
+            dG, dh0 = _bwd(d, B, H, T, reverse, hs, gates, dhs, last, pair=True)
+        assert torch.isfinite(dG).all()
+        assert (dG - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), t
+        assert (dh0 - ref0).abs().max().item() <= 2e-6 * ref0.abs().max().item(), t
+    # gradients of very different magnitude side by side
+    g = torch.Generator().manual_seed(11)
+    colexp = torch.randint(-14, 6, (H // 32,), generator=g).repeat_interleave(32).float()
+    rowexp = torch.randint(-8, 6, (B // 32,), generator=g).repeat_interleave(32).float()
+    scale = (10.0 ** colexp)[None, None, :] * (10.0 ** rowexp)[None, :, None]
+    scale[:, :, 32:64] = 0.0
+    scale[:, 32:64, :] = 0.0
+    dhs2 = dhs * scale.to(dhs.device)
+    last2 = last * scale[0].to(dhs.device)
+    ref, ref0 = _bwd(d, B, H, T, reverse, hs, gates, dhs2, last2)
+    with ops.options(gru_bwd_tile=tiles[-1]):
+        dG, dh0 = _bwd(d, B, H, T, reverse, hs, gates, dhs2, last2, pair=True)
+    assert torch.isfinite(dG).all() and torch.isfinite(dh0).all()
+    blk = ref.abs().view(T, B // 32, 32, 4 * H).amax(dim=(2, 3), keepdim=True).expand(T, B // 32, 32, 4 * H).reshape(T, B, 4 * H)
+    assert ((dG - ref).abs() <= 4e-6 * blk).all()
+    blk0 = ref0.abs().view(B // 32, 32, H).amax(dim=(1, 2), keepdim=True).expand(B // 32, 32, H).reshape(B, H)
+    assert ((dh0 - ref0).abs() <= 4e-6 * blk0).all()
+    assert torch.equal(dG[:, 32:64], ref[:, 32:64])   # the all-zero row block stays exactly zero
+
+
+def ctypes_name(kind, B, H, ndir):
+    import ctypes
+    from cpg import lib
+    buf = ctypes.create_string_buffer(160)
+    lib().dll.cpg_gru_step_kernel_name(kind, B, H, ndir, 1, buf, 160)
+    return buf.value.decode()
 
 
 @pytest.mark.parametrize("tile", ["32x32", "64x32", "32x64"])

@@ -60,15 +60,17 @@ def main():
     dh0 = torch.empty(B, H, device=dev)
     dw, db = torch.empty(3 * H, H, device=dev), torch.empty(3 * H, device=dev)
     wT, wT2 = torch.empty(H, 3 * H, device=dev), torch.empty(2, H, 3 * H, device=dev)
+    ps1, ps2 = ops._pair_scratch(B, H, 1, dev), ops._pair_scratch(B, H, 2, dev)   # f16-pair backward step (None: not covered)
     big_ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
     fns = {
         "fwdp": (lambda: ops.gru_seq_fwd_persistent(T, B, H, False, w_hh, b_hh, tok, tab, rowc, None, hs, gates), T),
         "fwd": (lambda: call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B,
                              None, _stream()), T),
         "bwd": (lambda: call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), 0, B, None,
-                             _p(wT), 0, _stream()), T + 1),
+                             _p(wT), _p(ps1), 0, _stream()), T + 1),
         "bwd2": (lambda: call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), None,
-                              None, _p(dG), _p(dG2), _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), 0, _stream()), T),
+                              None, _p(dG), _p(dG2), _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), _p(ps2[0]) if ps2 is not None else None,
+                              _p(ps2[1]) if ps2 is not None else None, 0, _stream()), T),
         "wgrad": (lambda: call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(big_ws), big_ws.numel(), 0, _stream()), 1),
     }
     fns["fwd"][0]()   # valid state slab / gates for the backward kernels
