@@ -131,8 +131,9 @@ def family_roofline(family, dims, avg_us, launches):
         kernel, split = _cname("cpg_gru_step_kernel_name", 1, B, H, nd, 1), L.cpg_gru_step_kernel_is_split(1, B, H, nd, 1)
         flops = nd * 2.0 * B * 3 * H * H
     elif family == "wgrad_hh":
-        kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H), 2.0 * 3 * H * H * T * B
-        split = 2 if kernel.endswith(", 1>") else 1
+        pairs = int(L.cpg_gru_bwd_pair_bytes(B, H, 1) > 0)   # the f16-pair BPTT hands its column exponents to the product
+        kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H, pairs), 2.0 * 3 * H * H * T * B
+        split = 2 if kernel.endswith(", 1>") else 3 if kernel.endswith(", 8>") else 1
     elif family == "lstm_fwd_persist":
         kernel, flops = _cname("cpg_lstm_persistent_kernel_name", B, H), T * 2.0 * B * H * 4 * H
         split = {1: 2, 2: 3, 3: 1}[int(kernel.split("<")[1].split(",")[0])]
@@ -141,7 +142,7 @@ def family_roofline(family, dims, avg_us, launches):
         kernel, split = _cname("cpg_lstm_step_kernel_name", kind, B * nd, H), L.cpg_lstm_step_kernel_is_split(kind, B, H)
         flops = nd * 2.0 * B * H * 4 * H
     elif family == "lstm_wgrad_hh":
-        kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 4 * H, H), 2.0 * 4 * H * H * T * B
+        kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 4 * H, H, 0), 2.0 * 4 * H * H * T * B
         split = 2 if kernel.endswith(", 1>") else 1
     else:
         return None

@@ -773,7 +773,7 @@ class GruSeqFn(Function):
                 # whole CUs to the main stream's small launches.
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H)):
                     call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
-                         None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), dgb, _stream())
+                         None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _p(pair), dgb, _stream())
                 if has_tab:
                     defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
@@ -781,7 +781,7 @@ class GruSeqFn(Function):
             # the backward pass ends, so ANY reader of .grad after loss.backward() (clip_grad_norm_, another optimiser, a
             # test) sees the finished gradient - not only FusedAdamClip, which joins explicitly
             torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
-            for t in (dG, hs, db_hh):
+            for t in (dG, hs, db_hh, pair):
                 if t is not None:
                     t.record_stream(side)
             dw_hh = db_hh = None
@@ -790,7 +790,7 @@ class GruSeqFn(Function):
             db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
             with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                 call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
-                     ws.numel(), dgb, _stream())
+                     ws.numel(), _p(pair), dgb, _stream())
         ddense = None
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
@@ -875,7 +875,7 @@ class GruBiSeqFn(Function):
             if ctx.has_tab:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                     call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, int(gw is not None), _p(ws), ws.numel(),
-                         dgb, _stream())
+                         _p(pair[rev]) if pair is not None else None, dgb, _stream())
                 if gw is not None:
                     dw = None
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
@@ -885,7 +885,8 @@ class GruBiSeqFn(Function):
                 db = dsum[:3 * H]
             else:
                 db = torch.empty(3 * H, device=dev, dtype=torch.float32)
-                call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(), 0, _stream())
+                call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(ws), ws.numel(),
+                     _p(pair[rev]) if pair is not None else None, 0, _stream())
             ddense = torch.cat([dG[:, :, :2 * H], dG[:, :, 3 * H:]], 2).float() if ctx.has_dense else None
             outs.append((dtab, ddense, dw, db))
         (dtab_f, dd_f, dw_f, db_f), (dtab_r, dd_r, dw_r, db_r) = outs

@@ -11,7 +11,8 @@ int cpg_gemm_nn(const float* X, int ldx, const float* Bm, int ldb, float* Y, int
 // dW[N,Kd] (+)= dY[Mr,N]^T (X .* xmask*xms)[Mr,Kd]
 // dy_bf16: dY holds bf16 elements (lddy in elements): the dW_hh product on bf16 gate gradients (bf16 compute mode)
 int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
-                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16 = 0);
+                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16 = 0,
+                const int* dy_exps = nullptr /* f16-pair form: exponent per 32 columns of dY, see GemmArgs::a_exps */, int dy_exps_mod = 1);
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd);
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_colsum_workspace(int M, int N);

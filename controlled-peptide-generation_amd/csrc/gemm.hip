@@ -25,10 +25,13 @@ struct GemmArgs {
     size_t slab_stride; // floats between slabs (0 when not split)
     int pairs_a = 0, pairs_b = 0;  // 8-byte pairs of the scalar staging path are safe (OpA::pairs), set by launch_gemm
     int a_bf16 = 0;                // A holds bf16 elements (OpA::bf16): the dW_hh product on bf16 gate gradients
+    const int* a_exps = nullptr;   // PREC 8 (f16 pairs): power-of-two exponent per 32-column group of A's M axis (OpA::exps); the kernel
+    int a_exps_mod = 1;            // multiplies the columns by 2^e on the way in and the output rows by 2^-e on the way out
 };
 
-// PREC: 7 = f32-grade, 1 = bf16 compute mode (cpg_set_compute_mode(1)); only the transposed-use (dW = dY^T X) products run on
-// the plane engine, everything else is the exact-f32 MFMA whatever PREC says
+// PREC: 7 = f32-grade (three bf16 planes), 8 = f32-grade on f16 pairs (the dW_hh product behind the f16-pair BPTT), 1 = bf16 compute
+// mode (cpg_set_compute_mode(1)); only the transposed-use (dW = dY^T X) products run on the plane engine, everything else is the
+// exact-f32 MFMA whatever PREC says
 template <class TC, bool A_KC, bool B_KC, int PREC>
 constexpr int gemm_split() {
     return (!A_KC && !B_KC && CPG_TN_PRODUCT_SPLIT == 7) ? PREC : 0;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     const size_t aoff = A_KC ? (size_t)kb : (size_t)kb * g.lda;
     const size_t boff = B_KC ? (size_t)kb : (size_t)kb * g.ldb;
     OpA a{g.a_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g.A) + aoff) : g.A + aoff, g.lda, m0, g.M,
-          g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a, g.a_bf16};
+          g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a, g.a_bf16, g.a_exps, g.a_exps_mod};
     OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale, g.pairs_b};
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
@@ -72,6 +75,10 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 if (row >= g.M) continue;
                 const size_t o = (size_t)row * g.ldc + col;
+                if constexpr (PREC == 8) {   // take the column scale of the A operand back out (exact)
+                    const int e = g.a_exps ? g.a_exps[(row % g.a_exps_mod) / 32] : 0;
+                    acc[mi][ni][r] *= __builtin_bit_cast(float, (unsigned)(127 - (e == INT_MAX ? 0 : e)) << 23);
+                }
                 float v = acc[mi][ni][r] + bv;
                 if (plain) {
                     if (g.accumulate) v += C[o];
@@ -171,6 +178,19 @@ template <class TC, bool A_KC, bool B_KC>
 static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
     if constexpr (!A_KC && !B_KC && (TC::NT == 512 || (TC::BM == 128 && TC::BN == 128))) {
         if (cpg_compute_mode_get() == 1) return launch_tc_p<TC, A_KC, B_KC, 1>(g, zdim, vec, s);
+    }
+    if constexpr (!A_KC && !B_KC && TC::NT == 512) {   // f16 pairs: the big tiles of the dW_hh product, 16-byte staging path, no masks
+        if (g.a_exps && vec && !g.a_mask && !g.b_mask && !g.a_bf16) {
+            const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false, 8>::smem_bytes();
+            if (smem > 64 * 1024) {
+                const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gemm_kernel<TC, A_KC, B_KC, true, false, 8>), (int)smem);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL((gemm_kernel<TC, A_KC, B_KC, true, false, 8>), dim3(cdiv(g.N, TC::BN), cdiv(g.M, TC::BM), zdim), dim3(TC::NT),
+                               smem, s, g);
+            CPG_LAUNCH_CHECK();
+            return 0;
+        }
     }
     return launch_tc_p<TC, A_KC, B_KC, 7>(g, zdim, vec, s);
 }
@@ -346,7 +366,8 @@ static TnPlan tn_plan(int M, int N, int K) {
 
 // C[N,Kd] (+)= A^T B where A = dY[Mr, N] (ld lddy), B = X[Mr, Kd] (ld ldx); contraction over the Mr rows.
 int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
-                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16) {
+                int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16, const int* dy_exps,
+                int dy_exps_mod) {
     TnPlan p = tn_plan(N, Kd, Mr);
     int S = p.S;
     const size_t slab = (size_t)N * Kd;
@@ -360,10 +381,12 @@ int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_
     if (S <= 1) {
         GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, dW, lddw, nullptr, accumulate, nullptr, 1.f, xmask, xms, nullptr, 1.f, 0, 0};
         g.a_bf16 = dy_bf16;
+        g.a_exps = dy_exps; g.a_exps_mod = dy_exps_mod;
         return launch_gemm<false, false>(g, 1, s, p.tile);
     }
     GemmArgs g{dY, lddy, N, X, ldx, Kd, Mr, ws, Kd, nullptr, 0, nullptr, 1.f, xmask, xms, nullptr, 1.f, p.k_chunk, slab};
     g.a_bf16 = dy_bf16;
+    g.a_exps = dy_exps; g.a_exps_mod = dy_exps_mod;
     int rc = launch_gemm<false, false>(g, S, s, p.tile);
     if (rc) return rc;
     const size_t n = slab;
@@ -375,7 +398,8 @@ int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_
 
 // Name (as rocprofv3 prints it, without "void " and the argument list) and split-K factor of the kernel cpg_gemm_tn picks
 // for dW[N,Kd] = dY[Mr,N]^T X[Mr,Kd] with 16-byte aligned operands - for bench.py's roofline object.
-CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n) {
+// dy_pairs: the call hands column exponents (the dW_hh product behind the f16-pair BPTT, cpg_gru_wgrad_hh with its pair scratch)
+CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs, char* buf, int n) {
     const TnPlan p = tn_plan(N, Kd, Mr);
     TnTile t = p.tile;
     if (t == TN_AUTO) {
@@ -387,8 +411,9 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n) 
                      t == TN_128x64 ? "128, 64, 32, 2, 2, 1, 256" : t == TN_64x64 ? "64, 64, 32, 2, 2, 1, 256" :
                      t == TN_128x32 ? "128, 32, 32, 4, 1, 1, 256" : "32, 128, 32, 1, 4, 1, 256";
     const bool vec = N % 4 == 0 && Kd % 4 == 0 && p.k_chunk % 4 == 0;
+    const bool bf = (t == TN_256x128 || t == TN_192x128 || t == TN_128x128) && cpg_compute_mode_get() == 1;
     return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false, %d>", tc, vec ? "true" : "false",
-                    ((t == TN_256x128 || t == TN_192x128 || t == TN_128x128) && cpg_compute_mode_get() == 1) ? 1 : 7);
+                    bf ? 1 : (dy_pairs && vec && (t == TN_256x128 || t == TN_192x128)) ? 8 : 7);
 }
 CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
 

@@ -22,6 +22,7 @@
 // global row/col = seg*seg_stride + j, valid iff j < seg_len.  NSEG=1 is the plain map.
 #pragma once
 #include "cpg_common.h"
+#include <limits.h>
 
 // Diagnostic builds only (tools/ablate.sh): -DCPG_ABLATE=<mask> removes one phase of the slab loop after the first slab so its
 // cost can be measured in isolation.  1: no global loads / LDS writes   2: no LDS fragment reads   4: no barrier
@@ -53,6 +54,8 @@ struct OpA {
     int pairs = 0;        // 1: 8-byte pairs of the scalar (non-16-byte) staging path are aligned and never straddle a bound
     int bf16 = 0;         // 1: p points at bf16 elements (ld, offsets in elements) - transposed-use operands on the 16-byte staging path
                           // only (the dW_hh product on bf16 gate gradients): four elements = one 8-byte load, widened in registers
+    const int* exps = nullptr;   // SPLIT 8 (f16 pairs): power-of-two exponent of M column m = exps[(m % exps_mod) / 32]; INT_MAX: 0
+    int exps_mod = 1;
 };
 
 struct OpB {
@@ -243,13 +246,16 @@ struct MainLoop {
     // SPLIT = 1 ("bf16 compute mode", cfg.hw.dtype = 'bf16'): the same plane engine with ONE plane - operands rounded to
     // bf16 (round to nearest even) when the slab is stored, one MFMA per block, f32 accumulation.  NOT f32-grade: its own
     // tests state agreement thresholds instead of the 1e-4 bars.
-    static constexpr int NP = SPLIT == 7 ? 3 : 1;
+    // SPLIT = 8: f32-grade on f16 PAIRS split at LDS-store time (two planes, three v_mfma_f32_16x16x32_f16 per block; the
+    // transposed-use dW_hh product whose dY columns carry a power-of-two scale - OpA::exps - that the caller takes back out)
+    static constexpr int NP = SPLIT == 7 ? 3 : SPLIT == 8 ? 2 : 1;
     static constexpr int TRW = 264;  // words per subtile: 32 rows x 8 words + 8 pad (consecutive subtiles on distinct banks)
     static constexpr int APL = A_KC ? BM * KCW : (TRX ? (BM / 16) * TRW : (BK / 2) * SXA);
     static constexpr int BPL = B_KC ? BN * KCW : (TRX ? (BN / 16) * TRW : (BK / 2) * SXB);
     static constexpr int ASZ7 = NP * APL, BSZ7 = NP * BPL;
-    static_assert(SPLIT == 0 || SPLIT == 7 || SPLIT == 1,
-                  "0: exact f32; 7: f32-grade, three bf16 planes split at LDS-store time, six MFMAs; 1: bf16 compute mode, one plane, one MFMA");
+    static_assert(SPLIT == 0 || SPLIT == 7 || SPLIT == 1 || SPLIT == 8,
+                  "0: exact f32; 7: f32-grade, three bf16 planes split at LDS-store time, six MFMAs; 1: bf16 compute mode, one plane, one MFMA; 8: f16 pairs");
+    static_assert(SPLIT != 8 || (TRX && AVEC && !MASKS), "f16 pairs: the transposed-use product on the 16-byte staging path");
     static_assert(SPLIT == 0 || BK == 32, "plane products are written for 32-deep slabs");
     static_assert(SPLIT == 0 || TRX || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
     // SB ("single buffer", the 128 x 128 transposed-use tile on the plane engine): ONE LDS image per operand, two barriers per
@@ -282,6 +288,7 @@ struct MainLoop {
         size_t a[TC::AV], b[TC::BV];  // element offset of the vector at k0 = 0 (clamped to a valid row / column)
         int an[TC::AV], bn[TC::BV];   // KC: 4*kq (k offset inside the slab) ; XC: number of valid columns (0..4)
         bool aok[TC::AV], bok[TC::BV];  // KC: row in range ; XC: unused
+        float asc[SPLIT == 8 ? TC::AV : 1];   // SPLIT 8: power-of-two scale of this thread's four A columns (one 32-column group)
     };
 
     __device__ static __forceinline__ void plan(const OpA& a, const OpB& b, Plan& pl) {
@@ -303,6 +310,10 @@ struct MainLoop {
                 pl.aok[i] = true;
                 pl.an[i] = nc;
                 pl.a[i] = (size_t)kk * a.ld + (nc > 0 ? gm : 0);
+                if constexpr (SPLIT == 8) {
+                    const int e = (a.exps && nc > 0) ? a.exps[(gm % a.exps_mod) / 32] : 0;
+                    pl.asc[i] = __builtin_bit_cast(float, (unsigned)(127 + (e == INT_MAX ? 0 : e)) << 23);
+                }
             }
         }
 #pragma unroll
@@ -443,6 +454,9 @@ struct MainLoop {
     __device__ static __forceinline__ void split_pair(float lo, float hi, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
         if (NP == 3) {
             split3_pair(lo, hi, w0, w1, w2);
+        } else if (NP == 2) {
+            split2h_pair(lo, hi, w0, w1);
+            w2 = 0u;
         } else {
             w0 = cvt_pk_bf16(lo, hi);
             w1 = w2 = 0u;
@@ -461,10 +475,8 @@ struct MainLoop {
                 split_pair(r[i].z, r[i].w, b0, b1, b2);
                 uint32_t* q = dst + row * KCW + 2 * kq;
                 *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
-                if (NP == 3) {
-                    *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
-                    *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
-                }
+                if (NP >= 2) *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
+                if (NP == 3) *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
             }
         } else if (TRX) {
 #pragma unroll
@@ -480,10 +492,8 @@ struct MainLoop {
                 }
                 uint32_t* q = dst + (xq >> 2) * TRW + kk * 8 + (xq & 3) * 2;
                 *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
-                if (NP == 3) {
-                    *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
-                    *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
-                }
+                if (NP >= 2) *reinterpret_cast<uint2*>(q + PLW) = make_uint2(a1, b1);
+                if (NP == 3) *reinterpret_cast<uint2*>(q + 2 * PLW) = make_uint2(a2, b2);
             }
         } else {
 #pragma unroll
@@ -497,18 +507,22 @@ struct MainLoop {
                 split_pair(e.w, o.w, w0[3], w1[3], w2[3]);
                 uint32_t* q = dst + p * SX + 4 * xq;
                 *reinterpret_cast<uint4*>(q) = make_uint4(w0[0], w0[1], w0[2], w0[3]);
-                if (NP == 3) {
-                    *reinterpret_cast<uint4*>(q + PLW) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
-                    *reinterpret_cast<uint4*>(q + 2 * PLW) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
-                }
+                if (NP >= 2) *reinterpret_cast<uint4*>(q + PLW) = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+                if (NP == 3) *reinterpret_cast<uint4*>(q + 2 * PLW) = make_uint4(w2[0], w2[1], w2[2], w2[3]);
             }
         }
     }
 
-    __device__ static __forceinline__ void sstore7(const OpA& a, const OpB& b, uint32_t* As, uint32_t* Bs, const Stage& st) {
+    __device__ static __forceinline__ void sstore7(const OpA& a, const OpB& b, uint32_t* As, uint32_t* Bs, const Stage& st, const Plan& pl) {
         float4 ra[TC::AV], rb[TC::BV];
 #pragma unroll
-        for (int i = 0; i < TC::AV; ++i) ra[i] = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
+        for (int i = 0; i < TC::AV; ++i) {
+            ra[i] = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
+            if constexpr (SPLIT == 8) {
+                const float f = pl.asc[i];
+                ra[i] = make_float4(ra[i].x * f, ra[i].y * f, ra[i].z * f, ra[i].w * f);
+            }
+        }
         sstore7_op<A_KC, BM, TC::AV, APL, SXA, A_BF16 && NP == 1>(As, ra);
 #pragma unroll
         for (int i = 0; i < TC::BV; ++i) rb[i] = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
@@ -544,7 +558,7 @@ struct MainLoop {
     static constexpr int MG = (TC::MI % 2 == 0) ? 2 : 1;   // row blocks walked together (independent accumulators)
     template <bool STORE>
     __device__ static __forceinline__ void slab7(const OpA& a, const OpB& b, const uint32_t* Ac, const uint32_t* Bc, uint32_t* An,
-                                                 uint32_t* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI]) {
+                                                 uint32_t* Bn, const Stage& st, f32x4 (&acc)[TC::MI][TC::NI], const Plan& pl) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int wm = wave / TC::WN, wn = wave % TC::WN;
         const int l15 = lane & 15, lq = lane >> 4;
@@ -580,6 +594,19 @@ struct MainLoop {
                 // dependent MFMA issues only when its predecessor has left the pipe (8 passes for 16x16x32 against a 4-pass
                 // issue slot), so the MG x NG independent blocks are walked term by term - same sums, no dependency stalls.
                 constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+                if constexpr (SPLIT == 8) {   // f16 pairs: low x high, high x low, high x high
+                    constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int m = 0; m < MG; ++m)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                acc[m0 + m][n0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(cpg_f16x8, fa[m][HA[t]]),
+                                                                                             __builtin_bit_cast(cpg_f16x8, fb[g][HB[t]]),
+                                                                                             acc[m0 + m][n0 + g], 0, 0, 0);
+                    continue;
+                }
 #pragma unroll
                 for (int t = (NP == 3 ? 0 : 5); t < 6; ++t)
 #pragma unroll
@@ -589,7 +616,7 @@ struct MainLoop {
                             acc[m0 + m][n0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[m][TA[t]], fb[g][TB[t]], acc[m0 + m][n0 + g], 0, 0, 0);
             }
         }
-        if (STORE && !(CPG_ABLATE & 1)) sstore7(a, b, An, Bn, st);
+        if (STORE && !(CPG_ABLATE & 1)) sstore7(a, b, An, Bn, st, pl);
     }
 
     template <class Hook>
@@ -608,37 +635,37 @@ struct MainLoop {
         gload(a, b, pl, 0, K, st);
         if constexpr (SB) {
             uint32_t* const Bs = base + ASZ7;
-            sstore7(a, b, A0, Bs, st);
+            sstore7(a, b, A0, Bs, st, pl);
             __syncthreads();
             for (int kt = 0; kt < KT; ++kt) {
                 if (kt == hook_kt) hook();
                 if (kt + 1 < KT) gload(a, b, pl, (kt + 1) * BK, K, st);
-                slab7<false>(a, b, A0, Bs, A0, Bs, st, acc);
+                slab7<false>(a, b, A0, Bs, A0, Bs, st, acc, pl);
                 __syncthreads();
                 if (kt + 1 < KT) {
-                    sstore7(a, b, A0, Bs, st);
+                    sstore7(a, b, A0, Bs, st, pl);
                     __syncthreads();
                 }
             }
             return;
         }
-        sstore7(a, b, A0, B0, st);
+        sstore7(a, b, A0, B0, st, pl);
         __syncthreads();
         for (int kt = 0; kt < KT; kt += 2) {
             if (kt == hook_kt) hook();
             if (kt + 1 < KT) {
                 if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 1) * BK, K, st);
-                slab7<true>(a, b, A0, B0, A1, B1, st, acc);
+                slab7<true>(a, b, A0, B0, A1, B1, st, acc, pl);
             } else {
-                slab7<false>(a, b, A0, B0, A1, B1, st, acc);
+                slab7<false>(a, b, A0, B0, A1, B1, st, acc, pl);
             }
             __syncthreads();
             if (kt + 1 >= KT) break;
             if (kt + 2 < KT) {
                 if (!(CPG_ABLATE & 1)) gload(a, b, pl, (kt + 2) * BK, K, st);
-                slab7<true>(a, b, A1, B1, A0, B0, st, acc);
+                slab7<true>(a, b, A1, B1, A0, B0, st, acc, pl);
             } else {
-                slab7<false>(a, b, A1, B1, A0, B0, st, acc);
+                slab7<false>(a, b, A1, B1, A0, B0, st, acc, pl);
             }
             __syncthreads();
         }

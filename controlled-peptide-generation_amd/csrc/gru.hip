@@ -185,6 +185,8 @@ struct GruBwdArgs {
     const int* ex_next;
     uint16_t* pp_out;
     int* ex_out;
+    int* ex_min;   // [H/32] smallest exponent of every column group over the launches of the sequence so far (pair_w_kernel resets it):
+                   // the column scale of the dW_hh product on f16 pairs (cpg_gru_wgrad_hh)
 };
 
 constexpr int W_PAIR_EXP = 8;   // power-of-two scale of the f16-pair image of W_hh^T (pair_w_kernel)
@@ -542,7 +544,11 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             else e = 0;   // an infinity among the values: unscaled, it (and any NaN) reaches the planes as it is
         }
         const int grp = (j0 + wn * (BN / 2)) / 32;
-        if (lane == 0 && (BN == 64 || wn == 0)) g.ex_out[(size_t)((m0 + wm * 32) / 32) * (H / 32) + grp] = e;
+        if (lane == 0 && (BN == 64 || wn == 0)) {
+            g.ex_out[(size_t)((m0 + wm * 32) / 32) * (H / 32) + grp] = e;
+            // (the table only decreases: a stale read can only cause a redundant atomic)
+            if (e != INT_MAX && e < __hip_atomic_load(g.ex_min + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(g.ex_min + grp, e);
+        }
         if (e != INT_MAX) {
             const float sc = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
 #pragma unroll
@@ -916,8 +922,11 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
 // planes, each [32 hi | 32 lo] of W_hh[k][j] x 2^W_PAIR_EXP.  The scale is FIXED: weights of magnitude 2^-11 .. 255 keep a normal
 // low half (2^-22 relative), smaller ones 2^-33 absolute; a weight of 256 or more overflows the f16 high half to infinity (loud:
 // it reaches every gradient).  grid (H/32, 3H/32), block (32, 8).
-__global__ void pair_w_kernel(const float* w, int H, uint16_t* out) {
+__global__ void pair_w_kernel(const float* w, int H, uint16_t* out, int* ex_min) {
     __shared__ float tile[32][33];
+    if (ex_min && blockIdx.x == 0 && blockIdx.y == 0) {   // a new sequence: no exponent seen yet
+        for (int i = threadIdx.y * 32 + threadIdx.x; i < H / 32; i += 256) ex_min[i] = INT_MAX;
+    }
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // tile[k - r0][j - c0]
     for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = w[(size_t)(r0 + i) * H + c0 + threadIdx.x];
     __syncthreads();
@@ -961,8 +970,8 @@ __global__ void transpose_w_bf16_kernel(const float* w, int R, int C, uint16_t* 
     }
 }
 
-static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s, bool bf16 = false, bool pair = false) {
-    if (pair) hipLaunchKernelGGL(pair_w_kernel, dim3(H / 32, 3 * H / 32), dim3(32, 8), 0, s, w_hh, H, reinterpret_cast<uint16_t*>(wT));
+static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s, bool bf16 = false, bool pair = false, int* ex_min = nullptr) {
+    if (pair) hipLaunchKernelGGL(pair_w_kernel, dim3(H / 32, 3 * H / 32), dim3(32, 8), 0, s, w_hh, H, reinterpret_cast<uint16_t*>(wT), ex_min);
     else if (bf16) hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, reinterpret_cast<uint16_t*>(wT));
     else hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, wT);
     CPG_LAUNCH_CHECK();
@@ -1169,14 +1178,15 @@ CPG_EXPORT size_t cpg_gru_bwd_pair_bytes(int rows, int H, int ndir) {
     if (rows <= 0 || H <= 0 || H % 32 != 0 || rows % 64 != 0) return 0;
     const BwdPlan pl = bwd_plan(rows, H, ndir, 0, true, true, true);
     if (!(pl.kind == BK_DL && pl.pair_ok)) return 0;
-    return 2 * ((size_t)rows * 6 * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int));
+    return 2 * ((size_t)rows * 6 * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int)) + (size_t)(H / 32) * sizeof(int);
 }
-static void pair_split(void* scratch, int B, int H, uint16_t* (&pp)[2], int* (&ex)[2]) {
+static void pair_split(void* scratch, int B, int H, uint16_t* (&pp)[2], int* (&ex)[2], int*& ex_min) {
     const size_t plane = (size_t)B * 6 * H;
     pp[0] = (uint16_t*)scratch;
     pp[1] = pp[0] + plane;
     ex[0] = (int*)(pp[1] + plane);
     ex[1] = ex[0] + (size_t)(B / 32) * (H / 32);
+    ex_min = ex[1] + (size_t)(B / 32) * (H / 32);
 }
 
 // dhs_ext: [T,B,H] time-aligned external gradients on every step's output (or null); dh_last: gradient on the final state.
@@ -1196,9 +1206,10 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     const bool pair = pair_scratch && w_hhT_scratch && !dgb && cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) > 0 && row_begin % 64 == 0;
     uint16_t* PP[2] = {nullptr, nullptr};
     int* EX[2] = {nullptr, nullptr};
-    if (pair) pair_split(pair_scratch, B, H, PP, EX);
+    int* EMIN = nullptr;
+    if (pair) pair_split(pair_scratch, B, H, PP, EX, EMIN);
     if (w_hhT_scratch) {
-        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb, pair);
+        int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb, pair, EMIN);
         if (rc) return rc;
     }
     int prev_t = -1;
@@ -1217,7 +1228,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         a.gates_bf16 = gbf;
         a.dg_bf16 = dgb;
         const int cur = (p + 2) & 1;
-        a.pp_next = nullptr; a.ex_next = nullptr; a.pp_out = nullptr; a.ex_out = nullptr;
+        a.pp_next = nullptr; a.ex_next = nullptr; a.pp_out = nullptr; a.ex_out = nullptr; a.ex_min = EMIN;
         if (prev_t >= 0) {
             a.dG_next = gate_at(dG, (size_t)prev_t * B * 4 * H, dgb);
             a.dH_next = dH_scratch + (size_t)(cur ^ 1) * BH;
@@ -1265,13 +1276,26 @@ CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
 }
 
 // dW_hh[3H,H] (+)= sum_t dgh_t^T h_prev(t) ; db_hh[3H] (+)= sum dgh.
+// pair_scratch (optional): the scratch the sequence's cpg_gru_seq_bwd / _biseq_bwd call was given (same B, H; that call enqueued
+// earlier on a stream this one is ordered after) - the product then runs on f16 pairs, three MFMAs per block, with the gate-gradient
+// columns scaled by the power of two the backward steps recorded per 32-column group (their largest magnitude over the sequence
+// lands in [2^13, 2^14)) and the rows of dW_hh scaled back.
 CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
-                                float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream) {
+                                float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, const void* pair_scratch,
+                                int dg_bf16, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && workspace);
     CPG_CHECK_ARG(!dg_bf16 || !db_hh);   // bf16 gate gradients: the bias gradient comes out of cpg_gru_dgi_reduce's column sums
     const float* hprev = reverse ? hs + (size_t)B * H : hs;
+    const int* exps = nullptr;
+    if (pair_scratch && !dg_bf16 && cpg_compute_mode_get() != 1) {
+        uint16_t* pp[2];
+        int* ex[2];
+        int* emin = nullptr;
+        pair_split(const_cast<void*>(pair_scratch), B, H, pp, ex, emin);
+        exps = emin;
+    }
     int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 3 * H, H, accumulate, (float*)workspace,
-                         workspace_bytes, (hipStream_t)stream, dg_bf16);
+                         workspace_bytes, (hipStream_t)stream, dg_bf16, exps, H);
     if (rc || !db_hh) return rc;  // db_hh null: the caller derives it (shared r,z columns come from the token-table gradient)
     return cpg_colsum(dG, 4 * H, T * B, 3 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1557,13 +1581,14 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
     const bool pair = pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && !dgb && cpg_gru_bwd_pair_bytes(B, H, 2) > 0;
     uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int* EMIN[2] = {nullptr, nullptr};
     if (pair) {
-        pair_split(pair_scratch_f, B, H, PP[0], EXP[0]);
-        pair_split(pair_scratch_r, B, H, PP[1], EXP[1]);
+        pair_split(pair_scratch_f, B, H, PP[0], EXP[0], EMIN[0]);
+        pair_split(pair_scratch_r, B, H, PP[1], EXP[1], EMIN[1]);
     }
     if (w_hhT_scratch_f) {
-        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream, dgb, pair);
-        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream, dgb, pair);
+        int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream, dgb, pair, EMIN[0]);
+        if (!rc) rc = transpose_w(w_hh_r, H, w_hhT_scratch_r, (hipStream_t)stream, dgb, pair, EMIN[1]);
         if (rc) return rc;
     }
     const float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
@@ -1593,7 +1618,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.row1 = B;
             a.w_hh = W[d];
             a.w_hhT = WT[d];
-            a.pp_next = nullptr; a.ex_next = nullptr;
+            a.pp_next = nullptr; a.ex_next = nullptr; a.ex_min = EMIN[d];
             a.pp_out = pair ? PP[d][cur] : nullptr;
             a.ex_out = pair ? EXP[d][cur] : nullptr;
             if (prev_t[d] >= 0) {

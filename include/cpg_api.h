@@ -187,12 +187,16 @@ CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* str
  * kind 0 forward step, 1 backward step; ndir 1 | 2 (paired biGRU launches); have_wt: W_hh^T handed to the backward. */
 CPG_API int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int have_wt, char* buf, int n);
 CPG_API int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt);
-CPG_API int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, char* buf, int n);
+CPG_API int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs /* the f16-pair form cpg_gru_wgrad_hh runs with a pair scratch */,
+                                    char* buf, int n);
 CPG_API int cpg_gemm_tn_split(int Mr, int N, int Kd);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
-/* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null) */
+/* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null).
+ * pair_scratch (optional): the scratch the sequence's cpg_gru_seq_bwd / cpg_gru_biseq_bwd call received (same B and H, enqueued
+ * before this call) - the product then runs on f16 pairs with the column exponents those launches recorded. */
 CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
-                             float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream);
+                             float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, const void* pair_scratch,
+                             int dg_bf16, void* stream);
 /* dtab[V,3H] (+)= sum of input-side gate gradients grouped by token ; dsum[4H] (+)= column sums of dG (dsum[0:3H] is the
  * b_hh gradient) ; drowc[B,3H] (+)= sum over time (any may be null).  dtab and dsum come from ONE pass over dG:
  * dG^T . [onehot(tok) | 1] on the matrix cores. */

@@ -197,6 +197,8 @@ def _bwd(d, B, H, T, reverse, hs, gates, dhs, last, with_wT=True, pair=False):
     call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(hs), _p(gates), _p(dhs), _p(last), _p(dG), _p(scr), _p(dh0),
          0, B, None, _p(wT), _p(ps), 0, _stream())
     torch.cuda.synchronize()
+    if pair == "keep":
+        return dG, dh0, ps
     return dG, dh0
 
 
@@ -261,6 +263,41 @@ def test_backward_f16_pair_step_vs_exact(B, H, T, reverse):
     blk0 = ref0.abs().view(B // 32, 32, H).amax(dim=(1, 2), keepdim=True).expand(B // 32, 32, H).reshape(B, H)
     assert ((dh0 - ref0).abs() <= 4e-6 * blk0).all()
     assert torch.equal(dG[:, 32:64], ref[:, 32:64])   # the all-zero row block stays exactly zero
+
+
+@pytest.mark.parametrize("B,H,T,reverse", [(2048, 512, 25, False), (2048, 512, 25, True), (1024, 1024, 8, False)])
+def test_wgrad_hh_on_f16_pairs_vs_split_engine(B, H, T, reverse):
+    """dW_hh = sum_t dG_t^T h_prev(t) with the pair scratch of the sequence's BPTT (gemm_kernel<256x128, ..., 8>: f16 pairs, the
+    gate-gradient columns scaled by the power of two the backward steps recorded per 32-column group) against the same call without
+    it (three bf16 planes, six MFMAs) and against an f64 sum: both f32-grade, the pair form no further from the f64 result.  Then
+    with column groups of very different magnitude: every row group of dW_hh relative to its own largest value."""
+    import ctypes
+    from cpg import ops, lib
+    from cpg.ops import _p, _stream, call, query
+    d = _inputs(B, H, T, 24, seed=B + H + T + 4)
+    hs, gates, dhs, last = _bwd_inputs(d, B, H, T, reverse, seed=5)
+    buf = ctypes.create_string_buffer(160)
+    lib().dll.cpg_gemm_tn_kernel_name(T * B, 3 * H, H, 1, buf, 160)
+    assert buf.value.decode().endswith(", 8>"), buf.value
+    dev = hs.device
+    g = torch.Generator().manual_seed(13)
+    colexp = torch.randint(-12, 4, (H // 32,), generator=g).repeat_interleave(32).float()
+    for wild in (False, True):
+        sc = (10.0 ** colexp)[None, None, :].to(dev) if wild else 1.0
+        dG, dh0, ps = _bwd(d, B, H, T, reverse, hs, gates, dhs * sc, last * (sc[0] if wild else 1.0), pair="keep")
+        ws = torch.empty(query("cpg_gru_wgrad_workspace", T, B, H, 24), device=dev, dtype=torch.uint8)
+        outs = []
+        for scratch in (ps, None):
+            dw = torch.zeros(3 * H, H, device=dev)
+            call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _p(scratch), 0, _stream())
+            torch.cuda.synchronize()
+            outs.append(dw)
+        hprev = (hs[1:] if reverse else hs[:-1]).reshape(T * B, H).double()
+        ref = (dG[:, :, :3 * H].reshape(T * B, 3 * H).double().T @ hprev)
+        grp = ref.abs().view(3, H // 32, 32, H).amax(dim=(2, 3), keepdim=True).expand(3, H // 32, 32, H).reshape(3 * H, H)
+        err = [((o.double() - ref).abs() / grp.clamp_min(1e-300)).max().item() for o in outs]
+        assert err[0] < 3e-6 and err[1] < 3e-6, (wild, err)
+        assert err[0] < 1.5 * err[1] + 1e-7, (wild, err)
 
 
 def ctypes_name(kind, B, H, ndir):

@@ -71,7 +71,7 @@ def main():
         "bwd2": (lambda: call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), None,
                               None, _p(dG), _p(dG2), _p(sc2[0]), _p(sc2[1]), _p(wT2[0]), _p(wT2[1]), _p(ps2[0]) if ps2 is not None else None,
                               _p(ps2[1]) if ps2 is not None else None, 0, _stream()), T),
-        "wgrad": (lambda: call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(big_ws), big_ws.numel(), 0, _stream()), 1),
+        "wgrad": (lambda: call("cpg_gru_wgrad_hh", T, B, H, 0, _p(dG), _p(hs), _p(dw), _p(db), 0, _p(big_ws), big_ws.numel(), None, 0, _stream()), 1),
     }
     fns["fwd"][0]()   # valid state slab / gates for the backward kernels
     fl = 2.0 * B * H * 3 * H
