@@ -622,10 +622,10 @@ def _persist_failed(kind):
                    "per-step kernels" % (kind.upper(), kind))
 
 
-def _pair_scratch(B, H, ndir, dev):
-    """Scratch of the f16-pair backward step (cpg_gru_bwd_pair_bytes): [ndir, bytes] uint8, or None where that step does not
-    cover the shape / compute mode (the exact-f32 product then)."""
-    nb = int(query("cpg_gru_bwd_pair_bytes", int(B), int(H), int(ndir)))
+def _pair_scratch(B, H, ndir, dev, lstm=False):
+    """Scratch of the f16-pair backward step (cpg_gru_bwd_pair_bytes / cpg_lstm_bwd_pair_bytes): [ndir, bytes] uint8, or None where
+    that step does not cover the shape / compute mode (the exact-f32 product then)."""
+    nb = int(query("cpg_lstm_bwd_pair_bytes", int(B), int(H))) if lstm else int(query("cpg_gru_bwd_pair_bytes", int(B), int(H), int(ndir)))
     if nb == 0:
         return None
     t = torch.empty(ndir, (nb + 255) // 256 * 256, device=dev, dtype=torch.uint8)
@@ -962,8 +962,9 @@ class LstmSeqFn(Function):
         dc0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
         with _prof("lstm_bwd_step", T + (1 if need0 else 0), T=T, B=B, H=H, ndir=1):
             wT = torch.empty(H, 4 * H, device=dev, dtype=torch.float32)   # W_hh^T for the direct-to-LDS step kernel
+            pair = _pair_scratch(B, H, 1, dev, lstm=True)
             call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
-                 _p(dh0), _p(dc0), _p(wT), _stream())
+                 _p(dh0), _p(dc0), _p(wT), _p(pair), _stream())
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -972,7 +973,7 @@ class LstmSeqFn(Function):
         db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
         with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
             call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
-                 ws.numel(), _stream())
+                 ws.numel(), _p(pair), _stream())
         dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32) if has_tab else None
         drowc = torch.empty(B, 4 * H, device=dev, dtype=torch.float32) if has_rowc else None
         if has_tab or has_rowc:
@@ -1036,9 +1037,11 @@ class LstmBiSeqFn(Function):
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 4 * H, device=dev, dtype=torch.float32)
+        pair = _pair_scratch(B, H, 2, dev, lstm=True)
         with _prof("lstm_bwd_step", T, T=T, B=B, H=H, ndir=2):
             call("cpg_lstm_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(cs_f), _p(cs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _stream())
+                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]),
+                 _p(pair[0]) if pair is not None else None, _p(pair[1]) if pair is not None else None, _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []
@@ -1048,7 +1051,7 @@ class LstmBiSeqFn(Function):
             db = torch.empty(4 * H, device=dev, dtype=torch.float32)
             with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                 call("cpg_lstm_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None if ctx.has_tab else _p(db), int(gw is not None),
-                     _p(ws), ws.numel(), _stream())
+                     _p(ws), ws.numel(), _p(pair[rev]) if pair is not None else None, _stream())
             dtab = None
             if ctx.has_tab:
                 dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32)

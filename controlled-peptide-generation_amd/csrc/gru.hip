@@ -15,6 +15,7 @@
 // So h_{prev}(t) is one contiguous [T*B,H] block in both directions (offset 0 / B*H) for the dW_hh product.
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include "pair_engine.h"
 #include <stdlib.h>
 #include <limits.h>
 #include <string.h>
@@ -188,8 +189,6 @@ struct GruBwdArgs {
     int* ex_min;   // [H/32] smallest exponent of every column group over the launches of the sequence so far (pair_w_kernel resets it):
                    // the column scale of the dW_hh product on f16 pairs (cpg_gru_wgrad_hh)
 };
-
-constexpr int W_PAIR_EXP = 8;   // power-of-two scale of the f16-pair image of W_hh^T (pair_w_kernel)
 
 struct GruBwdPair {
     GruBwdArgs d[2];
@@ -450,45 +449,15 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
                 }
             }
     };
-    int e_cur = 0;   // PREC 3: acc holds (sum so far) x 2^(e_cur + W_PAIR_EXP)
+    PairConsumer<MI, NI, 3> pc;   // PREC 3 (pair_engine.h)
     if (g.dG_next && !(CPG_DL_ABLATE & 4)) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
         if constexpr (PREC == 3) {
-            // exponents of this wave's 32 rows, one per 32-column group of the gate axis: lane l holds group l's
-            const int NG32 = H / 32;
-            const int ev = lane < NG32 ? g.ex_next[(size_t)((m0 + wm * 32) / 32) * NG32 + lane] : INT_MAX;
-            int e_ref = ev;   // the largest-magnitude group's exponent (the smallest)
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) e_ref = min(e_ref, __shfl_xor(e_ref, o));
-            e_cur = e_ref == INT_MAX ? 0 : e_ref;
-            bool live = false;
-            auto pre = [&](int kt) {
-                const int gi = kt / 3;
-                if (kt - 3 * gi == 0) {
-                    const int e = __builtin_amdgcn_readlane(ev, gi);
-                    // groups of zeros, and groups more than 2^60 below the largest one (their contribution is below every bit
-                    // of the f32 result; rescaling the accumulators to their unit could overflow), are skipped
-                    live = e != INT_MAX && e - e_ref <= 60;
-                    if (live && e != e_cur) {
-                        const float f = __builtin_bit_cast(float, (unsigned)(127 + (e - e_cur)) << 23);   // |e - e_cur| <= 60
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= f;
-                        e_cur = e;
-                    }
-                }
-                return live;
-            };
+            pc.init(g.ex_next + (size_t)((m0 + wm * 32) / 32) * (H / 32), H / 32, lane);
             DL::run(g.pp_next + (size_t)m0 * 6 * H, (size_t)6 * H, reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 6 * H,
-                    (size_t)6 * H, 6 * H, cpg_smem, acc, min(phase * g.ep_step, 3 * H / 32 - 1), load_ep, pre);
-            // back to the unit of dh: 2^-(e_cur + W_PAIR_EXP), two exact factors (each a normal f32)
-            const float f0 = __builtin_bit_cast(float, (unsigned)(127 - e_cur) << 23), f1 = __builtin_bit_cast(float, (unsigned)(127 - W_PAIR_EXP) << 23);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[mi][ni] * f0 * f1;
+                    (size_t)6 * H, 6 * H, cpg_smem, acc, min(phase * g.ep_step, 3 * H / 32 - 1), load_ep, [&](int kt) { return pc.pre(kt, acc); });
+            pc.finish(acc);
         } else if constexpr (PREC == 2)
             DL::run(reinterpret_cast<const uint16_t*>(g.dG_next) + (size_t)m0 * 4 * H, (size_t)4 * H,
                     reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
@@ -526,47 +495,18 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
         }
     if constexpr (PREC == 3) {
         if (!g.gates || !g.pp_out) return;   // (block-uniform)
-        // ---- the next launch's A operand: this wave's 32 rows x BN/2 columns x 3 blocks as f16 pairs times 2^e, e chosen so that
-        // the largest magnitude of the 32 x 32 x 3 group lands in [2^13, 2^14)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if constexpr (BN == 32) {   // two waves (wn = 0, 1) share a 32-column group
-            float* const red = cpg_smem;   // (the ring is idle: every wave is past its last fragment read after this barrier)
-            __syncthreads();
-            if (lane == 0) red[wave] = vmax;
-            __syncthreads();
-            vmax = fmaxf(red[2 * wm], red[2 * wm + 1]);
-        }
-        int e = INT_MAX;
-        if (vmax > 0.f) {
-            int fe = 0;
-            if (vmax < 3.0e38f) { (void)frexpf(vmax, &fe); e = max(-100, min(100, 14 - fe)); }
-            else e = 0;   // an infinity among the values: unscaled, it (and any NaN) reaches the planes as it is
-        }
+        // ---- the next launch's A operand (pair_engine.h): this wave's 32 rows x BN/2 columns x 3 blocks
         const int grp = (j0 + wn * (BN / 2)) / 32;
-        if (lane == 0 && (BN == 64 || wn == 0)) {
-            g.ex_out[(size_t)((m0 + wm * 32) / 32) * (H / 32) + grp] = e;
-            // (the table only decreases: a stale read can only cause a redundant atomic)
-            if (e != INT_MAX && e < __hip_atomic_load(g.ex_min + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(g.ex_min + grp, e);
-        }
+        const int e = pair_group_exponent<BN>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
+                                              g.ex_min + grp);
         if (e != INT_MAX) {
-            const float sc = __builtin_bit_cast(float, (unsigned)(127 + e) << 23);
+            const float sc = pair_pow2(e);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int row = rb0 + 16 * mi, col = cb0 + 16 * ni;
-                    uint16_t* const d = g.pp_out + (size_t)row * 6 * H + (size_t)(3 * (col / 32)) * 64 + (col & 31);
+                for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const f32x4 v = pv[mi][ni][q] * sc;
-                        uint32_t h0, l0, h1, l1;
-                        split2h_pair(v[0], v[1], h0, l0);
-                        split2h_pair(v[2], v[3], h1, l1);
-                        *reinterpret_cast<uint2*>(d + q * 64) = make_uint2(h0, h1);
-                        *reinterpret_cast<uint2*>(d + q * 64 + 32) = make_uint2(l0, l1);
-                    }
-                }
+                    for (int q = 0; q < 3; ++q) pair_store4<3>(g.pp_out, (size_t)(rb0 + 16 * mi), H, cb0 + 16 * ni, q, pv[mi][ni][q] * sc);
         }
     }
 }
@@ -918,11 +858,11 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
     return 0;
 }
 
-// W_hh^T as f16 pairs for the PREC 3 backward step: out[j][6H] f16, k-groups of 32 in the order (column group, block) as the dG
-// planes, each [32 hi | 32 lo] of W_hh[k][j] x 2^W_PAIR_EXP.  The scale is FIXED: weights of magnitude 2^-11 .. 255 keep a normal
-// low half (2^-22 relative), smaller ones 2^-33 absolute; a weight of 256 or more overflows the f16 high half to infinity (loud:
-// it reaches every gradient).  grid (H/32, 3H/32), block (32, 8).
-__global__ void pair_w_kernel(const float* w, int H, uint16_t* out, int* ex_min) {
+// W_hh^T as f16 pairs for the PREC 3 backward steps (pair_engine.h): out[j][2 G H] f16, k-groups of 32 in the order (column group,
+// block) as the dG planes, each [32 hi | 32 lo] of W_hh[k][j] x 2^W_PAIR_EXP.  The scale is FIXED: weights of magnitude
+// 2^-11 .. 255 keep a normal low half (2^-22 relative), smaller ones 2^-33 absolute; a weight of 256 or more overflows the f16 high
+// half to infinity (loud: it reaches every gradient).  grid (H/32, G H/32), block (32, 8).
+__global__ void pair_w_kernel(const float* w, int G, int H, uint16_t* out, int* ex_min) {
     __shared__ float tile[32][33];
     if (ex_min && blockIdx.x == 0 && blockIdx.y == 0) {   // a new sequence: no exponent seen yet
         for (int i = threadIdx.y * 32 + threadIdx.x; i < H / 32; i += 256) ex_min[i] = INT_MAX;
@@ -932,12 +872,17 @@ __global__ void pair_w_kernel(const float* w, int H, uint16_t* out, int* ex_min)
     __syncthreads();
     const int tid = threadIdx.y * 32 + threadIdx.x, jj = tid >> 3, q = tid & 7, c8 = (q & 3) * 8;
     const int blk = r0 / H, grp = (r0 - blk * H) / 32;
-    const float sc = __builtin_bit_cast(float, (unsigned)(127 + W_PAIR_EXP) << 23);
+    const float sc = pair_pow2(W_PAIR_EXP);
     uint32_t hi[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2h_pair(tile[c8 + 2 * i][jj] * sc, tile[c8 + 2 * i + 1][jj] * sc, hi[i], lo[i]);
-    uint16_t* const d = out + (size_t)(c0 + jj) * 6 * H + (size_t)(3 * grp + blk) * 64 + (q >> 2) * 32 + c8;
+    uint16_t* const d = out + (size_t)(c0 + jj) * 2 * G * H + (size_t)(G * grp + blk) * 64 + (q >> 2) * 32 + c8;
     *reinterpret_cast<uint4*>(d) = (q >> 2) ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(hi[0], hi[1], hi[2], hi[3]);
+}
+int cpg_pair_w(const float* w_hh, int G, int H, uint16_t* out, int* ex_min, hipStream_t s) {
+    hipLaunchKernelGGL(pair_w_kernel, dim3(H / 32, G * H / 32), dim3(32, 8), 0, s, w_hh, G, H, out, ex_min);
+    CPG_LAUNCH_CHECK();
+    return 0;
 }
 
 // out[H,3H] = w[3H,H]^T
@@ -971,8 +916,8 @@ __global__ void transpose_w_bf16_kernel(const float* w, int R, int C, uint16_t* 
 }
 
 static int transpose_w(const float* w_hh, int H, float* wT, hipStream_t s, bool bf16 = false, bool pair = false, int* ex_min = nullptr) {
-    if (pair) hipLaunchKernelGGL(pair_w_kernel, dim3(H / 32, 3 * H / 32), dim3(32, 8), 0, s, w_hh, H, reinterpret_cast<uint16_t*>(wT), ex_min);
-    else if (bf16) hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, reinterpret_cast<uint16_t*>(wT));
+    if (pair) return cpg_pair_w(w_hh, 3, H, reinterpret_cast<uint16_t*>(wT), ex_min, s);
+    if (bf16) hipLaunchKernelGGL(transpose_w_bf16_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, reinterpret_cast<uint16_t*>(wT));
     else hipLaunchKernelGGL(transpose_w_kernel, dim3(cdiv(H, 32), cdiv(3 * H, 32)), dim3(32, 8), 0, s, w_hh, 3 * H, H, wT);
     CPG_LAUNCH_CHECK();
     return 0;
@@ -1178,15 +1123,7 @@ CPG_EXPORT size_t cpg_gru_bwd_pair_bytes(int rows, int H, int ndir) {
     if (rows <= 0 || H <= 0 || H % 32 != 0 || rows % 64 != 0) return 0;
     const BwdPlan pl = bwd_plan(rows, H, ndir, 0, true, true, true);
     if (!(pl.kind == BK_DL && pl.pair_ok)) return 0;
-    return 2 * ((size_t)rows * 6 * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int)) + (size_t)(H / 32) * sizeof(int);
-}
-static void pair_split(void* scratch, int B, int H, uint16_t* (&pp)[2], int* (&ex)[2], int*& ex_min) {
-    const size_t plane = (size_t)B * 6 * H;
-    pp[0] = (uint16_t*)scratch;
-    pp[1] = pp[0] + plane;
-    ex[0] = (int*)(pp[1] + plane);
-    ex[1] = ex[0] + (size_t)(B / 32) * (H / 32);
-    ex_min = ex[1] + (size_t)(B / 32) * (H / 32);
+    return pair_scratch_bytes(rows, H, 3);
 }
 
 // dhs_ext: [T,B,H] time-aligned external gradients on every step's output (or null); dh_last: gradient on the final state.
@@ -1207,7 +1144,7 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     uint16_t* PP[2] = {nullptr, nullptr};
     int* EX[2] = {nullptr, nullptr};
     int* EMIN = nullptr;
-    if (pair) pair_split(pair_scratch, B, H, PP, EX, EMIN);
+    if (pair) pair_split(pair_scratch, B, H, 3, PP, EX, EMIN);
     if (w_hhT_scratch) {
         int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb, pair, EMIN);
         if (rc) return rc;
@@ -1291,7 +1228,7 @@ CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* d
         uint16_t* pp[2];
         int* ex[2];
         int* emin = nullptr;
-        pair_split(const_cast<void*>(pair_scratch), B, H, pp, ex, emin);
+        pair_split(const_cast<void*>(pair_scratch), B, H, 3, pp, ex, emin);
         exps = emin;
     }
     int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 3 * H, H, accumulate, (float*)workspace,
@@ -1583,8 +1520,8 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
     int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EMIN[2] = {nullptr, nullptr};
     if (pair) {
-        pair_split(pair_scratch_f, B, H, PP[0], EXP[0], EMIN[0]);
-        pair_split(pair_scratch_r, B, H, PP[1], EXP[1], EMIN[1]);
+        pair_split(pair_scratch_f, B, H, 3, PP[0], EXP[0], EMIN[0]);
+        pair_split(pair_scratch_r, B, H, 3, PP[1], EXP[1], EMIN[1]);
     }
     if (w_hhT_scratch_f) {
         int rc = transpose_w(w_hh_f, H, w_hhT_scratch_f, (hipStream_t)stream, dgb, pair, EMIN[0]);

@@ -9,6 +9,8 @@
 // gradients (identical for the input side and the hidden side).
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include "pair_engine.h"
+#include <string.h>
 #include <stdlib.h>
 
 struct LstmFwdArgs {
@@ -125,6 +127,12 @@ struct LstmBwdArgs {
     float* dC_out;         // [B,H] dc_s * f_s   (closing launch: dc0 = dC_next passthrough)
     float* dG_out;         // [B,4H]
     int B, H;
+    // f16-pair hand-off of the direct-to-LDS step (PREC 3; pair_engine.h): dG once more as [B][8H] f16 pairs x 2^e per 32 x 32 group
+    const uint16_t* pp_next;
+    const int* ex_next;
+    uint16_t* pp_out;
+    int* ex_out;
+    int* ex_min;
 };
 
 // Both directions of a bidirectional layer share ONE launch per step (blockIdx.z picks the direction), as the GRU pairs of
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdPair pr) {
 // Backward step with the direct-to-LDS main loop (DlLoop, gemm_core.h): dG_next [B,4H] . W_hh^T rows, both K-contiguous, exact-f32
 // MFMA, 16-byte row-layout epilogue.  Same sums as lstm_step_bwd_kernel (same contraction order); dense full tiles only.
 // PREC 1: bf16 compute mode - operands rounded to bf16 at the fragment read, one bf16 MFMA per block and slab (as the GRU kernel)
+// PREC 3: f32-grade on f16 pairs handed from launch to launch (pair_engine.h; as gru_step_bwd_dl_kernel) - three f16 MFMAs per block
 template <int BM, int BN, int PREC = 0>
 __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
     using DL = DlLoop<BM, BN, 3, PREC>;
@@ -248,14 +257,24 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
                 }
             }
     };
+    PairConsumer<MI, NI, 4> pc;
     if (g.dG_next) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3, KT = 4 * H / 32;
-        DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 4 * H, (size_t)4 * H, 4 * H, cpg_smem, acc,
-                min(phase * ((KT / 4) & ~1), KT - 1), load_ep);
+        if constexpr (PREC == 3) {
+            pc.init(g.ex_next + (size_t)((m0 + wm * 32) / 32) * (H / 32), H / 32, lane);
+            DL::run(g.pp_next + (size_t)m0 * 8 * H, (size_t)8 * H, reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 8 * H,
+                    (size_t)8 * H, 8 * H, cpg_smem, acc, min(phase * ((KT / 4) & ~1), KT - 1), load_ep, [&](int kt) { return pc.pre(kt, acc); });
+            pc.finish(acc);
+        } else {
+            DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 4 * H, (size_t)4 * H, 4 * H, cpg_smem, acc,
+                    min(phase * ((KT / 4) & ~1), KT - 1), load_ep);
+        }
     } else {
         load_ep();
     }
+    f32x4 pv[PREC == 3 ? MI : 1][PREC == 3 ? NI : 1][4];   // PREC 3: the four blocks of dG, kept for the pair planes
+    float vmax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -275,11 +294,34 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
             const f32x4 dc = dcn + dh * og * (1.f - tc * tc);
             *reinterpret_cast<f32x4*>(g.dC_out + o) = dc * fg;
             float* d = g.dG_out + (size_t)(rb0 + 16 * mi) * 4 * H + cb0 + 16 * ni;
-            *reinterpret_cast<f32x4*>(d) = dc * gg * ig * (1.f - ig);
-            *reinterpret_cast<f32x4*>(d + H) = dc * cpv * fg * (1.f - fg);
-            *reinterpret_cast<f32x4*>(d + 2 * H) = dc * ig * (1.f - gg * gg);
-            *reinterpret_cast<f32x4*>(d + 3 * H) = dh * tc * og * (1.f - og);
+            const f32x4 d0 = dc * gg * ig * (1.f - ig), d1 = dc * cpv * fg * (1.f - fg), d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+            *reinterpret_cast<f32x4*>(d) = d0;
+            *reinterpret_cast<f32x4*>(d + H) = d1;
+            *reinterpret_cast<f32x4*>(d + 2 * H) = d2;
+            *reinterpret_cast<f32x4*>(d + 3 * H) = d3;
+            if constexpr (PREC == 3) {
+                pv[mi][ni][0] = d0; pv[mi][ni][1] = d1; pv[mi][ni][2] = d2; pv[mi][ni][3] = d3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(pv[mi][ni][q][j]));
+            }
         }
+    if constexpr (PREC == 3) {
+        if (!g.gates || !g.pp_out) return;   // (block-uniform)
+        const int grp = (j0 + wn * (BN / 2)) / 32;
+        const int e = pair_group_exponent<BN>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
+                                              g.ex_min + grp);
+        if (e != INT_MAX) {
+            const float sc = pair_pow2(e);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pair_store4<4>(g.pp_out, (size_t)(rb0 + 16 * mi), H, cb0 + 16 * ni, q, pv[mi][ni][q] * sc);
+        }
+    }
 }
 
 using LF64 = TileCfg<64, 128, 32, 2, 2, 4>;
@@ -290,6 +332,12 @@ using LB32 = TileCfg<32, 64, 32, 2, 2, 1>;
 using LB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
 static bool lstm_dl_ok(int B, int H);
+// f16-pair form of the direct-to-LDS backward step: f32-grade mode, option gru_bwd_engine = exact switches it off (as csrc/gru.hip)
+static bool lstm_pair_enabled(int H) {
+    if (cpg_compute_mode_get() == 1 || H > 2048) return false;
+    const CpgOptVal o = cpg_opt(OPT_GRU_BWD_ENGINE);
+    return !(o.set && strcmp(o.s, "exact") == 0);
+}
 // tile choices of the step launches (shared by the launchers and the introspection entry point below)
 static int lstm_fwd_choice(int B, int H) { return B >= 64 ? 0 : ((B > 32 && (long)cdiv(B, 32) * cdiv(H, 32) < 1024) ? 1 : 2); }  // LF64S | LF64 | LF32
 static int lstm_bwd_choice(int B, int H) { return (long)cdiv(B, 32) * cdiv(H, 32) >= 1024 ? 0 : (B > 32 ? 1 : 2); }               // LB32N | LB64 | LB32
@@ -313,7 +361,7 @@ CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int 
     if (kind == 1) {
         if (lstm_dl_ok(B, H) && H % 4 == 0)
             return snprintf(buf, n, "lstm_step_bwd_dl_kernel<64, %d, %d>", (H % 64 == 0 && (long)(B / 64) * (H / 64) >= 512) ? 64 : 32,
-                            cpg_compute_mode_get() == 1 ? 1 : 0);   // (B: rows of the launch - both directions' rows for a paired one)
+                            cpg_compute_mode_get() == 1 ? 1 : lstm_pair_enabled(H) ? 3 : 0);   // (B: rows of the launch - both directions' rows for a paired one)
         const int c = lstm_bwd_choice(B, H);
         if (c == 0) lstm_tc_name<LB32N>(tc, sizeof tc);
         else if (c == 1) lstm_tc_name<LB64>(tc, sizeof tc);
@@ -325,7 +373,8 @@ CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int 
 CPG_EXPORT int cpg_lstm_step_kernel_is_split(int kind, int B, int H) {
     if (kind == 0) return lstm_fwd_choice(B, H) != 2;   // 64-row tiles run the plane engine (LstmFwdLoop)
     // backward: exact-f32 MFMA; on the direct-to-LDS loop in the bf16 compute mode one bf16 MFMA per block (2, as the GRU reports it)
-    return (cpg_compute_mode_get() == 1 && lstm_dl_ok(B, H) && H % 4 == 0) ? 2 : 0;
+    if (!(lstm_dl_ok(B, H) && H % 4 == 0)) return 0;
+    return cpg_compute_mode_get() == 1 ? 2 : lstm_pair_enabled(H) ? 3 : 0;
 }
 
 static int lstm_fwd_launch(const LstmFwdArgs& a, hipStream_t s) {
@@ -390,6 +439,7 @@ static int lstm_launch_dl_p(const LstmBwdPair& pr, int nd, hipStream_t s) {
 // bf16 compute mode (cpg_set_compute_mode(1)): the step product with bf16-rounded operands, like every other recurrent product of the mode
 template <int BM, int BN>
 static int lstm_launch_dl(const LstmBwdPair& pr, int nd, hipStream_t s) {
+    if (pr.d[0].pp_next || pr.d[0].pp_out) return lstm_launch_dl_p<BM, BN, 3>(pr, nd, s);
     return cpg_compute_mode_get() == 1 ? lstm_launch_dl_p<BM, BN, 1>(pr, nd, s) : lstm_launch_dl_p<BM, BN, 0>(pr, nd, s);
 }
 
@@ -412,6 +462,10 @@ static int lstm_bwd_launch(const LstmBwdPair& pr, int nd, hipStream_t s) {
             CPG_LAUNCH_CHECK();
             return 0;
         }
+    }
+    if (a.pp_next || a.pp_out) {
+        cpg_set_error("lstm backward: the f16-pair step was prepared for this sequence but a launch of it is not covered (unaligned operand?)");
+        return -4;
     }
     bool vec = a.H % 4 == 0;
     for (int d = 0; d < nd; ++d) vec = vec && aligned16(pr.d[d].w_hh) && (!pr.d[d].dG_next || aligned16(pr.d[d].dG_next));
@@ -466,13 +520,27 @@ CPG_EXPORT int cpg_lstm_step_fwd(int B, int H, const float* w_hh, const float* b
 
 // dhs_ext [T,B,H] (time-aligned, may be null); dG out [T,B,4H]; scratch [2,B,H] (carried cell gradient);
 // dh0, dc0 [B,H] (both or neither).
+// Scratch of the f16-pair backward step per direction (pair_engine.h); 0: not covered (pass null)
+CPG_EXPORT size_t cpg_lstm_bwd_pair_bytes(int B, int H) {
+    if (B <= 0 || H <= 0 || !lstm_dl_ok(B, H) || H % 4 != 0 || !lstm_pair_enabled(H)) return 0;
+    return pair_scratch_bytes(B, H, 4);
+}
+
 CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
                                 const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
-                                void* stream) {
+                                void* pair_scratch, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && cs && gates && dG && scratch && ((dh0 == nullptr) == (dc0 == nullptr)));
     const size_t BH = (size_t)B * H;
     if (w_hhT_scratch && !lstm_dl_ok(B, H)) w_hhT_scratch = nullptr;
-    if (w_hhT_scratch) {   // W_hh^T [H,4H] once per sequence: the direct-to-LDS kernel wants both operands K-contiguous
+    const bool pair = pair_scratch && w_hhT_scratch && cpg_lstm_bwd_pair_bytes(B, H) > 0;
+    uint16_t* PP[2] = {nullptr, nullptr};
+    int* EX[2] = {nullptr, nullptr};
+    int* EMIN = nullptr;
+    if (pair) pair_split(pair_scratch, B, H, 4, PP, EX, EMIN);
+    if (pair) {
+        int rc = cpg_pair_w(w_hh, 4, H, reinterpret_cast<uint16_t*>(w_hhT_scratch), EMIN, (hipStream_t)stream);
+        if (rc) return rc;
+    } else if (w_hhT_scratch) {   // W_hh^T [H,4H] once per sequence: the direct-to-LDS kernel wants both operands K-contiguous
         hipLaunchKernelGGL(lstm_transpose_w_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, (hipStream_t)stream, w_hh,
                            4 * H, H, w_hhT_scratch);
         CPG_LAUNCH_CHECK();
@@ -491,6 +559,11 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
         a.ext2 = nullptr;
         a.dG_next = prev_t >= 0 ? dG + (size_t)prev_t * B * 4 * H : nullptr;
         a.dC_next = prev_t >= 0 ? scratch + (size_t)(cur ^ 1) * BH : nullptr;
+        a.pp_next = (pair && prev_t >= 0) ? PP[cur ^ 1] : nullptr;
+        a.ex_next = (pair && prev_t >= 0) ? EX[cur ^ 1] : nullptr;
+        a.pp_out = (pair && p >= 0) ? PP[cur] : nullptr;
+        a.ex_out = (pair && p >= 0) ? EX[cur] : nullptr;
+        a.ex_min = EMIN;
         if (p >= 0) {
             a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
             a.gates = gates + (size_t)t * 4 * BH;
@@ -522,14 +595,28 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
 CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
                                   const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                                   const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
-                                  float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream) {
+                                  float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
+                                  void* pair_scratch_f, void* pair_scratch_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && cs_f && cs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
     CPG_CHECK_ARG((dhs_ext_f == nullptr) == (dhs_ext_r == nullptr) && (dh_last_f == nullptr) == (dh_last_r == nullptr));
     if (w_hhT_scratch_f && !lstm_dl_ok(B, H)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;
     const float* W[2] = {w_hh_f, w_hh_r};
     float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
+    const bool pair = pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && cpg_lstm_bwd_pair_bytes(B, H) > 0;
+    uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int* EMIN[2] = {nullptr, nullptr};
+    if (pair) {
+        pair_split(pair_scratch_f, B, H, 4, PP[0], EXP[0], EMIN[0]);
+        pair_split(pair_scratch_r, B, H, 4, PP[1], EXP[1], EMIN[1]);
+    }
     for (int d = 0; d < 2 && WT[d]; ++d) {
+        if (pair) {
+            int rc = cpg_pair_w(W[d], 4, H, reinterpret_cast<uint16_t*>(WT[d]), EMIN[d], (hipStream_t)stream);
+            if (rc) return rc;
+            continue;
+        }
         hipLaunchKernelGGL(lstm_transpose_w_kernel, dim3(cdiv(H, 32), cdiv(4 * H, 32)), dim3(32, 8), 0, (hipStream_t)stream, W[d],
                            4 * H, H, WT[d]);
         CPG_LAUNCH_CHECK();
@@ -554,6 +641,11 @@ CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, cons
             a.w_hhT = WT[d];
             a.dG_next = prev_t[d] >= 0 ? DG[d] + (size_t)prev_t[d] * B * 4 * H : nullptr;
             a.dC_next = prev_t[d] >= 0 ? SC[d] + (size_t)(cur ^ 1) * BH : nullptr;
+            a.pp_next = (pair && prev_t[d] >= 0) ? PP[d][cur ^ 1] : nullptr;
+            a.ex_next = (pair && prev_t[d] >= 0) ? EXP[d][cur ^ 1] : nullptr;
+            a.pp_out = pair ? PP[d][cur] : nullptr;
+            a.ex_out = pair ? EXP[d][cur] : nullptr;
+            a.ex_min = EMIN[d];
             a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
             a.ext2 = (p == T - 1) ? LAST[d] : nullptr;
             a.gates = GT[d] + (size_t)t * 4 * BH;
@@ -571,12 +663,22 @@ CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, cons
 }
 
 // dw_hh[4H,H] (+)= sum_t dG_t^T h_prev(t) ; db_hh[4H] (+)= sum dG.   workspace: cpg_gru_wgrad_workspace(T,B,H,V)
+// pair_scratch (optional): the scratch of the sequence's backward call - the product then runs on f16 pairs (as cpg_gru_wgrad_hh)
 CPG_EXPORT int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
-                                 float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                                 float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, const void* pair_scratch,
+                                 void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && dG && hs && dw_hh && workspace);
     const float* hprev = reverse ? hs + (size_t)B * H : hs;
+    const int* exps = nullptr;
+    if (pair_scratch && cpg_lstm_bwd_pair_bytes(B, H) > 0) {
+        uint16_t* pp[2];
+        int* ex[2];
+        int* emin = nullptr;
+        pair_split(const_cast<void*>(pair_scratch), B, H, 4, pp, ex, emin);
+        exps = emin;
+    }
     int rc = cpg_gemm_tn(dG, 4 * H, hprev, H, nullptr, 1.f, dw_hh, H, T * B, 4 * H, H, accumulate, (float*)workspace,
-                         workspace_bytes, (hipStream_t)stream);
+                         workspace_bytes, (hipStream_t)stream, 0, exps, H);
     if (rc || !db_hh) return rc;  // db_hh null: the caller takes it from cpg_lstm_dgi_reduce's column sums
     return cpg_colsum(dG, 4 * H, T * B, 4 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -1,0 +1,109 @@
+// f16-pair hand-off between the launches of a BPTT chain (direct-to-LDS backward steps of csrc/gru.hip and csrc/lstm.hip, PREC 3 of
+// DlLoop in gemm_core.h).  A launch leaves the G recurrent blocks of its gate gradients dG [B, G H] once more, as the NEXT launch's
+// A operand: planes[B][2 G H] f16, k-groups of 32 in the order (32-column group, block), each 128 bytes = [32 hi | 32 lo] of the
+// values times 2^e, e = ex[(row / 32) * (H / 32) + group] chosen so that the largest magnitude of the 32 rows x 32 columns x G
+// blocks lands in [2^13, 2^14) (INT_MAX: all zero).  W_hh^T is laid out the same way (cpg_pair_w) times 2^W_PAIR_EXP.  The consumer
+// rescales its accumulators (an exact power of two) where the exponent changes along k and skips groups that are all zero or more
+// than 2^60 below the largest one.  ex_min[group] keeps the smallest exponent any launch of the sequence recorded: the column scale
+// of the dW_hh product on f16 pairs (gemm.hip, PREC 8).
+#pragma once
+#include "gemm_core.h"
+#include <limits.h>
+
+constexpr int W_PAIR_EXP = 8;   // power-of-two scale of the f16-pair image of W_hh^T
+
+__device__ __forceinline__ float pair_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // |e| <= 126
+
+// ---- consumer side: exponents of this wave's 32 rows (lane l holds group l's), the rescaling hook of DlLoop::run, the final factor
+template <int MI, int NI, int G>
+struct PairConsumer {
+    int ev, e_ref, e_cur;
+    bool live;
+    __device__ __forceinline__ void init(const int* ex_row /* this wave's 32-row block */, int ngroups, int lane) {
+        ev = lane < ngroups ? ex_row[lane] : INT_MAX;
+        e_ref = ev;   // the largest-magnitude group's exponent (the smallest)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) e_ref = min(e_ref, __shfl_xor(e_ref, o));
+        e_cur = e_ref == INT_MAX ? 0 : e_ref;
+        live = false;
+    }
+    // ahead of slab kt (G slabs per 32-column group): true = multiply this slab
+    __device__ __forceinline__ bool pre(int kt, f32x4 (&acc)[MI][NI]) {
+        const int gi = kt / G;
+        if (kt - G * gi == 0) {
+            const int e = __builtin_amdgcn_readlane(ev, gi);
+            live = e != INT_MAX && e - e_ref <= 60;
+            if (live && e != e_cur) {
+                const float f = pair_pow2(e - e_cur);   // |e - e_cur| <= 60
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= f;
+                e_cur = e;
+            }
+        }
+        return live;
+    }
+    // accumulators hold (sum) x 2^(e_cur + W_PAIR_EXP): back to the unit of the result, two exact factors (each a normal f32)
+    __device__ __forceinline__ void finish(f32x4 (&acc)[MI][NI]) const {
+        const float f0 = pair_pow2(-e_cur), f1 = pair_pow2(-W_PAIR_EXP);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[mi][ni] * f0 * f1;
+    }
+};
+
+// ---- producer side.  A wave of the 64 x BN tile (2 x 2 waves) owns 32 rows x BN/2 columns; vmax = the largest |value| of its G
+// blocks (per lane on entry).  Returns the exponent of the wave's 32 x 32 group (two waves share one when BN = 32: `red` = 4 floats
+// of LDS that every wave is done with, the barriers are the workgroup's), records it in ex_out / ex_min.
+template <int BN>
+__device__ __forceinline__ int pair_group_exponent(float vmax, float* red, int wave, int lane, int* ex_out_entry, int* ex_min_entry) {
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if constexpr (BN == 32) {
+        __syncthreads();
+        if (lane == 0) red[wave] = vmax;
+        __syncthreads();
+        vmax = fmaxf(red[2 * wm], red[2 * wm + 1]);
+    }
+    int e = INT_MAX;
+    if (vmax > 0.f) {
+        int fe = 0;
+        if (vmax < 3.0e38f) { (void)frexpf(vmax, &fe); e = max(-100, min(100, 14 - fe)); }
+        else e = 0;   // an infinity among the values: unscaled, it (and any NaN) reaches the planes as it is
+    }
+    if (lane == 0 && (BN == 64 || wn == 0)) {
+        *ex_out_entry = e;
+        // (the table only decreases: a stale read can only cause a redundant atomic)
+        if (e != INT_MAX && e < __hip_atomic_load(ex_min_entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(ex_min_entry, e);
+    }
+    return e;
+}
+
+// four consecutive columns (col .. col + 3) of block q of one row: 8 bytes of high halves, 8 bytes of low halves
+template <int G>
+__device__ __forceinline__ void pair_store4(uint16_t* planes, size_t row, int H, int col, int q, const f32x4 v) {
+    uint16_t* const d = planes + row * 2 * G * H + (size_t)(G * (col / 32) + q) * 64 + (col & 31);
+    uint32_t h0, l0, h1, l1;
+    split2h_pair(v[0], v[1], h0, l0);
+    split2h_pair(v[2], v[3], h1, l1);
+    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(d + 32) = make_uint2(l0, l1);
+}
+
+// scratch of one direction: two plane images (ping-pong over the steps), their two exponent tables, the column minima
+static inline size_t pair_scratch_bytes(int rows, int H, int G) {
+    return 2 * ((size_t)rows * 2 * G * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int)) + (size_t)(H / 32) * sizeof(int);
+}
+static inline void pair_split(void* scratch, int B, int H, int G, uint16_t* (&pp)[2], int* (&ex)[2], int*& ex_min) {
+    const size_t plane = (size_t)B * 2 * G * H;
+    pp[0] = (uint16_t*)scratch;
+    pp[1] = pp[0] + plane;
+    ex[0] = (int*)(pp[1] + plane);
+    ex[1] = ex[0] + (size_t)(B / 32) * (H / 32);
+    ex_min = ex[1] + (size_t)(B / 32) * (H / 32);
+}
+// W_hh [G H, H] -> f16-pair image of W_hh^T (csrc/gru.hip), resetting ex_min for a new sequence
+int cpg_pair_w(const float* w_hh, int G, int H, uint16_t* out, int* ex_min, hipStream_t s);

@@ -227,7 +227,9 @@ CPG_API int cpg_lstm_persistent_status(int B, const void* sync_scratch, void* st
 CPG_API int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
                                const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                                const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
-                               float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r, void* stream);
+                               float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
+                               void* pair_scratch_f, void* pair_scratch_r /* cpg_lstm_bwd_pair_bytes(B, H) bytes each, or null */,
+                               void* stream);
 /* Launcher introspection (as cpg_gru_step_kernel_name): kind 0 forward step, 1 backward step. */
 CPG_API int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int n);
 CPG_API int cpg_lstm_step_kernel_is_split(int kind, int B, int H);
@@ -237,12 +239,15 @@ CPG_API int cpg_lstm_seq_fwd(int T, int B, int H, int reverse, const float* w_hh
 CPG_API int cpg_lstm_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
                               const float* rowc, const float* h_prev, const float* c_prev, float* h_out, float* c_out,
                               void* stream);
+/* f16-pair form of the direct-to-LDS backward step, as cpg_gru_bwd_pair_bytes: bytes of scratch per direction, 0 = not covered */
+CPG_API size_t cpg_lstm_bwd_pair_bytes(int B, int H);
 CPG_API int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
                              const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0,
                              float* w_hhT_scratch /* [H,4H] or null: receives W_hh^T for the direct-to-LDS step kernel */,
-                             void* stream);
+                             void* pair_scratch /* cpg_lstm_bwd_pair_bytes(B, H) bytes or null */, void* stream);
 CPG_API int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG, const float* hs, float* dw_hh,
-                              float* db_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                              float* db_hh, int accumulate, void* workspace, size_t workspace_bytes,
+                              const void* pair_scratch /* the sequence's, or null */, void* stream);
 CPG_API int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                 float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -344,13 +344,59 @@ def test_lstm_backward_direct_to_lds_kernel_is_the_step_arithmetic(B, H, T, reve
         dh0, dc0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
         wT = torch.empty(H, 4 * H, device=dev)
         call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dhs), _p(dG), _p(scr), _p(dh0), _p(dc0),
-             _p(wT), _stream())
+             _p(wT), None, _stream())
         torch.cuda.synchronize()
         out.append((dG, dh0, dc0))
     ops.set_option("lstm_bwd_dl", None)
     for a, b in zip(*out):
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,T,reverse", [(128, 64, 5, False), (192, 96, 4, True), (2048, 512, 25, False), (2048, 512, 25, True)])
+def test_lstm_backward_f16_pair_step_and_wgrad_vs_exact(B, H, T, reverse):
+    """The f16-pair form of the LSTM backward step (lstm_step_bwd_dl_kernel<.., 3>, csrc/pair_engine.h: as the GRU's) and the dW_hh
+    product on f16 pairs behind it, against the exact-f32 step / the split-engine product: dG, dh0, dc0 and dW_hh within a few
+    1e-6 of their scale, incl. gradients whose magnitude differs by many orders between column groups."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call, query
+    dev = torch.device("cuda")
+    d = _lstm_inputs(B, H, T, 24, seed=B + H + 1)
+    hs, cs, gates = _lstm_run(d, B, H, T, reverse, False)
+    g = torch.Generator().manual_seed(3)
+    dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
+    colexp = torch.randint(-12, 4, (H // 32,), generator=g).repeat_interleave(32).float().to(dev)
+    for wild in (False, True):
+        dh = dhs * (10.0 ** colexp)[None, None, :] if wild else dhs
+        res = []
+        for pair in (True, False):
+            dG = torch.zeros(T, B, 4 * H, device=dev)
+            scr = torch.empty(2, B, H, device=dev)
+            dh0, dc0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+            wT = torch.empty(H, 4 * H, device=dev)
+            ps = ops._pair_scratch(B, H, 1, dev, lstm=True) if pair else None
+            assert not pair or ps is not None
+            if ps is not None:
+                ps.fill_(0xFF)
+            call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dh), _p(dG), _p(scr), _p(dh0), _p(dc0),
+                 _p(wT), _p(ps), _stream())
+            ws = torch.empty(query("cpg_gru_wgrad_workspace", T, B, H, 24), device=dev, dtype=torch.uint8)
+            dw = torch.zeros(4 * H, H, device=dev)
+            call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _p(ps), _stream())
+            torch.cuda.synchronize()
+            res.append((dG, dh0, dc0, dw))
+        (dG, dh0, dc0, dw), (rG, r0, rc0, rw) = res
+        assert torch.isfinite(dG).all() and torch.isfinite(dw).all()
+        blk = rG.abs().view(T, B // 32, 32, 4 * H).amax(dim=(2, 3), keepdim=True).expand(T, B // 32, 32, 4 * H).reshape(T, B, 4 * H)
+        assert ((dG - rG).abs() <= 4e-6 * blk + 1e-37).all(), wild
+        assert (dh0 - r0).abs().max().item() <= 4e-6 * r0.abs().max().item()
+        assert (dc0 - rc0).abs().max().item() <= 4e-6 * rc0.abs().max().item()
+        # dW_hh: against an f64 sum over the pair run's own dG, per 32-row group of the gate axis
+        hprev = (hs[1:] if reverse else hs[:-1]).reshape(T * B, H).double()
+        ref = dG.reshape(T * B, 4 * H).double().T @ hprev
+        grp = ref.abs().view(4, H // 32, 32, H).amax(dim=(2, 3), keepdim=True).expand(4, H // 32, 32, H).reshape(4 * H, H)
+        assert ((dw.double() - ref).abs() <= 3e-6 * grp + 1e-37).all(), wild
 
 
 @pytest.mark.gpu
