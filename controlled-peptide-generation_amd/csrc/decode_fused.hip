@@ -21,7 +21,17 @@
 //                and the hidden rows are re-gathered by back-pointer inside LDS.
 // One workgroup (4 waves, 1 per SIMD) per CU; the launch is persistent over tiles.
 #include "cpg_internal.h"
+#include "gemm_core.h"
 #include <stdio.h>
+
+// Product engine of the two fused kernels.  1 (default, round 4): f32-grade on f16 pairs (gemm_core.h: split2h_pair) - W_hh lives in
+// registers as f16-pair MFMA B-fragments times 2^8 (the register count of the f32 fragments it replaces), the A fragments (state
+// rows from LDS) and the fc rows are split when they are read, THREE v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block in place of
+// eight v_mfma_f32_16x16x4_f32 (48-61 matrix-pipe cycles against 268; products exact in the f32 accumulator, dropped lo x lo term
+// <= 2^-22 of a product: closer to the exact sums than a k-ordered f32 fma chain, tests/test_gpu_persistent.py).  0: exact-f32 MFMA.
+#ifndef CPG_FUSED_PAIR
+#define CPG_FUSED_PAIR 1
+#endif
 
 // Diagnostic builds of the beam kernel (results wrong): 1 no product, 2 no cell, 4 no vocabulary projection, 8 no stage 1 (row
 // lists), 16 no stage 2 (sentence merge), 32 no re-gather
@@ -42,6 +52,10 @@ template <int G, int R>
 struct FusedCfg {
     static constexpr int KSTEPS = 4 * G + R;
     static constexpr int KP = 16 * G + 4 * R;
+    // f16-pair product: KB 32-deep k-blocks (v_mfma_f32_16x16x32_f16) + KT 16-deep ones for the tail (v_mfma_f32_16x16x16_f16: half
+    // the fragment registers of a padded 32-deep block - at H = 102 the tail is 8 k); k >= KP reads as zero
+    static constexpr int KB = KP / 32;
+    static constexpr int KT = (KP % 32 + 15) / 16;
     // row stride = 4 * odd: the 8 rows one ds_read_b128 lane group touches land in disjoint bank quads
     static constexpr int LDH = ((KP / 4 + 1) % 2 == 1) ? KP + 4 : KP + 8;
     // hidden units per wave: wave w owns [UPW*w, UPW*(w+1)); column tile `sub` holds its units 16*sub .. 16*sub+15, lanes
@@ -66,7 +80,12 @@ __device__ __forceinline__ int k_of_step(int s, int lq) {
 // Per-lane constants of one wave: its W_hh fragments and biases.
 template <int G, int R>
 struct WaveWeights {
+#if CPG_FUSED_PAIR
+    cpg_f16x8 Bh[FusedCfg<G, R>::KB][6], Bl[FusedCfg<G, R>::KB][6];   // W_hh x 2^8 as f16 pairs: lane (unit l15, k = 32 kb + 8 lq + i)
+    cpg_f16x4 Bth[FusedCfg<G, R>::KT > 0 ? FusedCfg<G, R>::KT : 1][6], Btl[FusedCfg<G, R>::KT > 0 ? FusedCfg<G, R>::KT : 1][6];   // tail: k = 32 KB + 16 kt + 4 lq + i
+#else
     float Bf[FusedCfg<G, R>::KSTEPS][6];
+#endif
     float bh[6];
     float ownf[2];  // 1 where this lane's unit of column tile `sub` is a real hidden unit, else 0
     int ucl[2];     // that unit clamped into [0,H): the lane computes a throw-away duplicate instead of branching
@@ -82,11 +101,40 @@ struct WaveWeights {
             const int g = nt >> 1, ul = 16 * (nt & 1) + l15, unit = C::UPW * wave + ul;
             const bool own = ul < C::UPW && unit < w.H;
             bh[nt] = own ? w.b_hh[g * w.H + unit] : 0.f;
+#if CPG_FUSED_PAIR
+#pragma unroll
+            for (int kb = 0; kb < C::KB; ++kb) {
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 32 * kb + 8 * lq + 2 * i;
+                    const float x0 = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] * 256.f : 0.f;
+                    const float x1 = (own && k + 1 < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k + 1] * 256.f : 0.f;
+                    split2h_pair(x0, x1, hi[i], lo[i]);
+                }
+                Bh[kb][nt] = __builtin_bit_cast(cpg_f16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+                Bl[kb][nt] = __builtin_bit_cast(cpg_f16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+            }
+#pragma unroll
+            for (int kt = 0; kt < C::KT; ++kt) {
+                uint32_t hi[2], lo[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = 32 * C::KB + 16 * kt + 4 * lq + 2 * i;
+                    const float x0 = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] * 256.f : 0.f;
+                    const float x1 = (own && k + 1 < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k + 1] * 256.f : 0.f;
+                    split2h_pair(x0, x1, hi[i], lo[i]);
+                }
+                Bth[kt][nt] = __builtin_bit_cast(cpg_f16x4, make_uint2(hi[0], hi[1]));
+                Btl[kt][nt] = __builtin_bit_cast(cpg_f16x4, make_uint2(lo[0], lo[1]));
+            }
+#else
 #pragma unroll
             for (int s = 0; s < C::KSTEPS; ++s) {
                 const int k = k_of_step<G, R>(s, lq);
                 Bf[s][nt] = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] : 0.f;
             }
+#endif
         }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -113,6 +161,39 @@ __device__ __forceinline__ void stage_tables(const DecoderWeights& w, float* tab
     }
 }
 
+// Eight consecutive k (32 kb + 8 lq ..) of one LDS row of stride LDH as an f16-pair fragment; k >= KP reads as zero (the row's
+// padding columns [KP, LDH) hold zeros, so a chunk that straddles KP is covered; whole chunks past it are masked).  scale: a power of two.
+template <int KP>
+__device__ __forceinline__ void pair_frag(const float* row, int kb, int lq, float scale, cpg_f16x8& hi, cpg_f16x8& lo) {
+    const int k0 = 32 * kb + 8 * lq;
+    const bool in = k0 < KP;
+    const float* p = row + (in ? k0 : 0);
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4);
+    const float f = in ? scale : 0.f;
+    x0 *= f;
+    x1 *= f;
+    uint32_t h[4], l[4];
+    split2h_pair(x0[0], x0[1], h[0], l[0]);
+    split2h_pair(x0[2], x0[3], h[1], l[1]);
+    split2h_pair(x1[0], x1[1], h[2], l[2]);
+    split2h_pair(x1[2], x1[3], h[3], l[3]);
+    hi = __builtin_bit_cast(cpg_f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(cpg_f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+// the same for a 16-deep tail block: four consecutive k (k0 = 32 KB + 16 kt + 4 lq)
+template <int KP>
+__device__ __forceinline__ void pair_frag16(const float* row, int k0, float scale, cpg_f16x4& hi, cpg_f16x4& lo) {
+    const bool in = k0 < KP;
+    f32x4 x = *reinterpret_cast<const f32x4*>(row + (in ? k0 : 0));
+    x *= in ? scale : 0.f;
+    uint32_t h[2], l[2];
+    split2h_pair(x[0], x[1], h[0], l[0]);
+    split2h_pair(x[2], x[3], h[1], l[1]);
+    hi = __builtin_bit_cast(cpg_f16x4, make_uint2(h[0], h[1]));
+    lo = __builtin_bit_cast(cpg_f16x4, make_uint2(l[0], l[1]));
+}
+
 // acc[mt][gate*2+sub] = h_src[rows of m-tiles MT0..MT0+NMT-1] . W_hh^T for this wave's hidden units
 template <int G, int R, int MT0, int NMT>
 __device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const float* h_src, f32x4 (&acc)[NMT][6]) {
@@ -122,6 +203,42 @@ __device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const f
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CPG_FUSED_PAIR
+#pragma unroll
+    for (int kb = 0; kb < C::KB; ++kb) {
+        cpg_f16x8 ah[NMT], al[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) pair_frag<C::KP>(h_src + ((MT0 + mt) * 16 + l15) * C::LDH, kb, lq, 1.f, ah[mt], al[mt]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)   // low x high, high x low, high x high
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(t == 0 ? al[mt] : ah[mt], t == 1 ? ww.Bl[kb][nt] : ww.Bh[kb][nt],
+                                                                         acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kt = 0; kt < C::KT; ++kt) {
+        cpg_f16x4 ah[NMT], al[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+            pair_frag16<C::KP>(h_src + ((MT0 + mt) * 16 + l15) * C::LDH, 32 * C::KB + 16 * kt + 4 * lq, 1.f, ah[mt], al[mt]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(t == 0 ? al[mt] : ah[mt], t == 1 ? ww.Btl[kt][nt] : ww.Bth[kt][nt],
+                                                                        acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] *= (1.f / 256.f);   // the weights' 2^8 back out (exact)
+    return;
+#else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         f32x4 af[NMT];
@@ -147,6 +264,23 @@ __device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const f
             for (int nt = 0; nt < 6; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[mt], ww.Bf[4 * G + r][nt], acc[mt][nt], 0, 0, 0);
     }
+#endif
+}
+
+// Cell nonlinearities.  CPG_FUSED_FAST_CELL = 1 (default since round 4): hardware exp2 / reciprocal forms (v_exp_f32 on x log2(e),
+// v_rcp_f32) - ~2 ulp against ~1 ulp of the library expf + IEEE division (0: -DCPG_FUSED_FAST_CELL=0), a third of the instructions.
+// With the f16-pair product the fused kernels are bound by their VALU work, not by the matrix pipe: beam-5 over 1 M z 163 -> 132 ms,
+// greedy 27.3 -> 21.1 ms.  Every decode parity test (golden ids bit-exact, oracle ids exact outside f32 ties of margin < 1e-5, tie
+// counts bounded) passes with either form, with the same tie counts (profiles/r04_*_tie_report.json).
+#ifndef CPG_FUSED_FAST_CELL
+#define CPG_FUSED_FAST_CELL 1
+#endif
+__device__ __forceinline__ float sigmoid_c(float x) {
+#if CPG_FUSED_FAST_CELL
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+#else
+    return sigmoidf_(x);
+#endif
 }
 
 // tanh without control flow (the cell must stay one basic block so the scheduler can slide it under MFMAs):
@@ -160,7 +294,11 @@ __device__ __forceinline__ float tanh_bf(float x) {
     p = fmaf(p, t, 0.13333310186862946f);
     p = fmaf(p, t, -0.3333333432674408f);
     const float small = fmaf(a * t, p, a);
+#if CPG_FUSED_FAST_CELL
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * a) + 1.f);
+#else
     const float big = 1.f - 2.f / (expf(2.f * a) + 1.f);
+#endif
     return copysignf(a < 0.625f ? small : big, x);
 }
 
@@ -187,8 +325,8 @@ __device__ __forceinline__ void gru_cell(const WaveWeights<G, R>& ww, const f32x
                 const float gi_z = tr[H + uc] + rc[H + uc];
                 const float gi_n = tr[2 * H + uc] + rc[2 * H + uc];
                 const float hn = acc[mt][4 + sub][jj] + ww.bh[4 + sub];
-                const float rg = sigmoidf_(gi_r + (acc[mt][sub][jj] + ww.bh[sub]));
-                const float zg = sigmoidf_(gi_z + (acc[mt][2 + sub][jj] + ww.bh[2 + sub]));
+                const float rg = sigmoid_c(gi_r + (acc[mt][sub][jj] + ww.bh[sub]));
+                const float zg = sigmoid_c(gi_z + (acc[mt][2 + sub][jj] + ww.bh[2 + sub]));
                 const float ng = tanh_bf(gi_n + rg * hn);
                 const float hold = h_src[row * C::LDH + uc];
                 // multiply (not select) by the ownership mask: a select lets the compiler sink the whole cell under a branch
@@ -203,6 +341,37 @@ __device__ __forceinline__ void vocab_logits(const WaveWeights<G, R>& ww, const 
     using C = FusedCfg<G, R>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     f32x4 lg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#if CPG_FUSED_PAIR
+#pragma unroll
+    for (int kb = 0; kb < C::KB; ++kb) {
+        cpg_f16x8 ah, al, bh0, bl0, bh1, bl1;
+        pair_frag<C::KP>(h + (wave * 16 + l15) * C::LDH, kb, lq, 1.f, ah, al);
+        pair_frag<C::KP>(fc_l + ww.vclamp0 * C::LDH, kb, lq, 256.f, bh0, bl0);
+        pair_frag<C::KP>(fc_l + ww.vclamp1 * C::LDH, kb, lq, 256.f, bh1, bl1);
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, lg[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kt = 0; kt < C::KT; ++kt) {
+        const int k0 = 32 * C::KB + 16 * kt + 4 * lq;
+        cpg_f16x4 ah, al, bh0, bl0, bh1, bl1;
+        pair_frag16<C::KP>(h + (wave * 16 + l15) * C::LDH, k0, 1.f, ah, al);
+        pair_frag16<C::KP>(fc_l + ww.vclamp0 * C::LDH, k0, 256.f, bh0, bl0);
+        pair_frag16<C::KP>(fc_l + ww.vclamp1 * C::LDH, k0, 256.f, bh1, bl1);
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh0, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh1, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl0, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl1, lg[1], 0, 0, 0);
+        lg[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh0, lg[0], 0, 0, 0);
+        lg[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh1, lg[1], 0, 0, 0);
+    }
+    lg[0] *= (1.f / 256.f);
+    lg[1] *= (1.f / 256.f);
+#else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const f32x4 af = *reinterpret_cast<const f32x4*>(&h[(wave * 16 + l15) * C::LDH + 16 * g + 4 * lq]);
@@ -220,6 +389,7 @@ __device__ __forceinline__ void vocab_logits(const WaveWeights<G, R>& ww, const 
         lg[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, fc_l[ww.vclamp0 * C::LDH + 16 * G + 4 * r + lq], lg[0], 0, 0, 0);
         lg[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, fc_l[ww.vclamp1 * C::LDH + 16 * G + 4 * r + lq], lg[1], 0, 0, 0);
     }
+#endif
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const int row = wave * 16 + 4 * lq + jj;
@@ -262,6 +432,28 @@ __device__ __forceinline__ void half_logits(const float* h, const float* fc_l, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const int mrow = (MT0 + (wave >> 1)) * 16, v = 16 * (wave & 1) + l15, vc = min(v, V - 1);
     f32x4 lg = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CPG_FUSED_PAIR
+#pragma unroll
+    for (int kb = 0; kb < C::KB; ++kb) {
+        cpg_f16x8 ah, al, bh, bl;
+        pair_frag<C::KP>(h + (mrow + l15) * C::LDH, kb, lq, 1.f, ah, al);
+        pair_frag<C::KP>(fc_l + vc * C::LDH, kb, lq, 256.f, bh, bl);
+        lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, lg, 0, 0, 0);
+    }
+#pragma unroll
+    for (int kt = 0; kt < C::KT; ++kt) {
+        const int k0 = 32 * C::KB + 16 * kt + 4 * lq;
+        cpg_f16x4 ah, al, bh, bl;
+        pair_frag16<C::KP>(h + (mrow + l15) * C::LDH, k0, 1.f, ah, al);
+        pair_frag16<C::KP>(fc_l + vc * C::LDH, k0, 256.f, bh, bl);
+        lg = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, lg, 0, 0, 0);
+        lg = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, lg, 0, 0, 0);
+    }
+    lg *= (1.f / 256.f);
+#else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const f32x4 af = *reinterpret_cast<const f32x4*>(&h[(mrow + l15) * C::LDH + 16 * g + 4 * lq]);
@@ -273,6 +465,7 @@ __device__ __forceinline__ void half_logits(const float* h, const float* fc_l, c
     for (int r = 0; r < R; ++r)
         lg = __builtin_amdgcn_mfma_f32_16x16x4f32(h[(mrow + l15) * C::LDH + 16 * G + 4 * r + lq],
                                                   fc_l[vc * C::LDH + 16 * G + 4 * r + lq], lg, 0, 0, 0);
+#endif
     const float bias = fc_b[vc];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) logit_l[(mrow + 4 * lq + jj) * LGS + v] = lg[jj] + bias;

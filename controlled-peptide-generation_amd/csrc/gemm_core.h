@@ -195,6 +195,7 @@ __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t& w0, ui
 // exponent bits: an operand whose magnitudes are not O(1) (weights) is multiplied by a power of two first (exact), the
 // accumulator by its inverse.
 typedef _Float16 cpg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cpg_f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 cpg_f16x2 __attribute__((ext_vector_type(2)));
 typedef float cpg_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t& w0, uint32_t& w1) {
