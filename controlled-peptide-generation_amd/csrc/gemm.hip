@@ -10,6 +10,9 @@
 #endif
 #include <stdlib.h>
 #include <string.h>
+#ifndef CPG_PAIR_TN_128
+#define CPG_PAIR_TN_128 1   // the f16-pair dW_hh product on the single-buffered 128 x 128 tile (two workgroups per CU) instead of 256 x 128
+#endif
 
 struct GemmArgs {
     const float* A; int lda; int M;
@@ -179,7 +182,7 @@ static int launch_tc(const GemmArgs& g, int zdim, bool vec, hipStream_t s) {
     if constexpr (!A_KC && !B_KC && (TC::NT == 512 || (TC::BM == 128 && TC::BN == 128))) {
         if (cpg_compute_mode_get() == 1) return launch_tc_p<TC, A_KC, B_KC, 1>(g, zdim, vec, s);
     }
-    if constexpr (!A_KC && !B_KC && TC::NT == 512) {   // f16 pairs: the big tiles of the dW_hh product, 16-byte staging path, no masks
+    if constexpr (!A_KC && !B_KC && (TC::NT == 512 || (TC::BM == 128 && TC::BN == 128))) {   // f16 pairs: the big tiles of the dW_hh product, 16-byte staging path, no masks
         if (g.a_exps && vec && !g.a_mask && !g.b_mask && !g.a_bf16) {
             const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false, 8>::smem_bytes();
             if (smem > 64 * 1024) {
@@ -328,7 +331,7 @@ struct TnPlan {
     TnTile tile;
     int S, k_chunk;
 };
-static TnPlan tn_plan(int M, int N, int K) {
+static TnPlan tn_plan(int M, int N, int K, bool pairs = false) {
     TnPlan p{tn_tile_knob(), 1, 0};
     const CpgOptVal& split = cpg_opt(OPT_TN_SPLIT);
     // Large products (the dW_hh product: M=3H, N=H, K=T*B): 256x128 tiles, ONE 512-thread workgroup per CU, split-K chosen
@@ -336,7 +339,7 @@ static TnPlan tn_plan(int M, int N, int K) {
     // (bf16 compute mode: the single-buffered 128x128 tile, two workgroups per CU - 347 us against 365 at the dW_hh shape incl.
     // the reductions; in f32-grade mode it is the slower one, 604 against 564)
     if (p.tile == TN_AUTO && M >= 512 && N >= 256 && K >= 8192 && M % 4 == 0 && N % 4 == 0)
-        p.tile = (cpg_compute_mode_get() == 1 && M % 128 == 0 && N % 128 == 0) ? TN_128x128 : TN_256x128;
+        p.tile = ((cpg_compute_mode_get() == 1 || (pairs && CPG_PAIR_TN_128)) && M % 128 == 0 && N % 128 == 0) ? TN_128x128 : TN_256x128;
     long want;
     if (p.tile == TN_256x128) {
         const long tiles = (long)cdiv(M, 256) * cdiv(N, 128);
@@ -368,7 +371,7 @@ static TnPlan tn_plan(int M, int N, int K) {
 int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_t* xmask, float xms, float* dW, int lddw,
                 int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16, const int* dy_exps,
                 int dy_exps_mod) {
-    TnPlan p = tn_plan(N, Kd, Mr);
+    TnPlan p = tn_plan(N, Kd, Mr, dy_exps != nullptr);
     int S = p.S;
     const size_t slab = (size_t)N * Kd;
     if (S > 1 && ws_bytes < slab * S * sizeof(float)) {
@@ -400,7 +403,7 @@ int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_
 // for dW[N,Kd] = dY[Mr,N]^T X[Mr,Kd] with 16-byte aligned operands - for bench.py's roofline object.
 // dy_pairs: the call hands column exponents (the dW_hh product behind the f16-pair BPTT, cpg_gru_wgrad_hh with its pair scratch)
 CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs, char* buf, int n) {
-    const TnPlan p = tn_plan(N, Kd, Mr);
+    const TnPlan p = tn_plan(N, Kd, Mr, dy_pairs != 0);
     TnTile t = p.tile;
     if (t == TN_AUTO) {
         if (N <= 32) t = TN_32x128;
@@ -413,7 +416,7 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs, char
     const bool vec = N % 4 == 0 && Kd % 4 == 0 && p.k_chunk % 4 == 0;
     const bool bf = (t == TN_256x128 || t == TN_192x128 || t == TN_128x128) && cpg_compute_mode_get() == 1;
     return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false, %d>", tc, vec ? "true" : "false",
-                    bf ? 1 : (dy_pairs && vec && (t == TN_256x128 || t == TN_192x128)) ? 8 : 7);
+                    bf ? 1 : (dy_pairs && vec && (t == TN_256x128 || t == TN_192x128 || t == TN_128x128)) ? 8 : 7);
 }
 CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
 

@@ -395,9 +395,11 @@ __device__ __forceinline__ void st_dg4(float* dG_out, size_t row, int H, int col
         *reinterpret_cast<uint2*>(d + 3 * H) = make_uint2(cvt_pk_bf16(v3[0], v3[1]), cvt_pk_bf16(v3[2], v3[3]));
     } else {
         float* d = dG_out + row * 4 * H + col;
+#ifndef CPG_DIAG_SKIP_REC_F32   // diagnostic build (results wrong downstream): what the f32 copy of the recurrent blocks costs the PREC 3 step
         *reinterpret_cast<f32x4*>(d) = v0;
         *reinterpret_cast<f32x4*>(d + H) = v1;
         *reinterpret_cast<f32x4*>(d + 2 * H) = v2;
+#endif
         *reinterpret_cast<f32x4*>(d + 3 * H) = v3;
     }
 }
