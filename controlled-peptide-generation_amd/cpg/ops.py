@@ -210,6 +210,7 @@ def _deferred_split(Mr, N, Kd):
         return {"tn_split": int(DEFER_SPLIT)}
     s = int(query("cpg_gemm_tn_split", int(Mr), int(N), int(Kd)))
     return {"tn_split": max(1, (4 * s) // 5)} if s >= 5 else {}
+DEFER_ENC_WGRAD = _os.environ.get('CPG_DEFER_ENC_WGRAD', '1') != '0'   # the encoder's reverse-direction dW_hh beside the forward one (GruBiSeqFn)
 DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... and so does the [z;c] block of its W_ih gradient (LinearColsFn)
 BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
 
@@ -873,9 +874,25 @@ class GruBiSeqFn(Function):
             dw = gw if gw is not None else torch.empty(3 * H, H, device=dev, dtype=torch.float32)
             dtab = None
             if ctx.has_tab:
-                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                    call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, int(gw is not None), _p(ws), ws.numel(),
-                         _p(pair[rev]) if pair is not None else None, dgb, _stream())
+                if rev == 1 and gw is not None and DEFER_WGRAD and OVERLAP and DEFER_ENC_WGRAD:
+                    # the reverse direction's dW_hh product beside the forward direction's, on a side stream: either launch alone
+                    # is bound by the latency of its operand loads (two workgroups per CU), together they fill each other's stalls
+                    side = side_streams(dev)[1]
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        ws2 = workspace(nb, dev)
+                        with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                            call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(gw), None, 1, _p(ws2), ws2.numel(),
+                                 _p(pair[rev]) if pair is not None else None, dgb, _stream())
+                        _pending_events.append(side.record_event())
+                    torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
+                    for t in (dG, hs, pair):
+                        if t is not None:
+                            t.record_stream(side)
+                else:
+                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                        call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, int(gw is not None), _p(ws), ws.numel(),
+                             _p(pair[rev]) if pair is not None else None, dgb, _stream())
                 if gw is not None:
                     dw = None
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
