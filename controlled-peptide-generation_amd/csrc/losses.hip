@@ -444,18 +444,37 @@ __global__ __launch_bounds__(256) void mmd_gram_fused_kernel(MmdArgs g) {
 // ---- the same launch on the direct-to-LDS loop (gemm_core.h DlLoop, 64x64 tiles): needs K-contiguous operands whose row length
 // is a multiple of 32, so the row-norm pre-pass also writes zero-padded copies zp [2N, Dp] (8 MB at 2048 x 510, L2-resident);
 // the padding adds exact zeros to every dot product.  N % 64 == 0.
-using MmdDl = DlLoop<64, 64, 3>;
+// CPG_MMD_PAIR = 1 (round 4): the Gram products on f16 pairs (gemm_core.h, DlLoop PREC 3) - the padded operand copy that
+// rownorm2_pad_kernel writes anyway holds [32 hi | 32 lo] f16 per 32 k instead of 32 floats (same bytes), three f16 MFMAs per block and
+// slab in place of eight f32 ones.  z and the prior samples are O(1): no scale.  0: exact-f32 MFMA on the f32 copy.
+#ifndef CPG_MMD_PAIR
+#define CPG_MMD_PAIR 1
+#endif
+using MmdDl = DlLoop<64, 64, 3, CPG_MMD_PAIR ? 3 : 0>;
 __global__ void rownorm2_pad_kernel(const float* z1, const float* z2, int N, int D, int Dp, float* n1, float* n2, float* zp) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= 2 * N) return;
     const float* r = (wave < N ? z1 : z2) + (size_t)(wave % N) * D;
     float* o = zp + (size_t)wave * Dp;
     float s = 0.f;
+#if CPG_MMD_PAIR
+    uint32_t* const op = reinterpret_cast<uint32_t*>(o);   // per 32 k: 16 words of high halves, 16 words of low halves
+    for (int kp = lane; kp < Dp / 2; kp += 64) {
+        const int k = 2 * kp;
+        const float x0 = k < D ? r[k] : 0.f, x1 = k + 1 < D ? r[k + 1] : 0.f;
+        uint32_t hi, lo;
+        split2h_pair(x0, x1, hi, lo);
+        op[(kp >> 4) * 32 + (kp & 15)] = hi;
+        op[(kp >> 4) * 32 + 16 + (kp & 15)] = lo;
+        s += x0 * x0 + x1 * x1;
+    }
+#else
     for (int k = lane; k < Dp; k += 64) {
         const float x = k < D ? r[k] : 0.f;
         o[k] = x;
         s += x * x;
     }
+#endif
     s = wave_sum(s);
     if (lane == 0) (wave < N ? n1 : n2)[wave % N] = s;
 }
@@ -479,7 +498,12 @@ __global__ __launch_bounds__(256) void mmd_gram_dl_kernel(MmdArgs g, const float
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CPG_MMD_PAIR
+        MmdDl::run(reinterpret_cast<const uint16_t*>(A + (size_t)m0 * Dp), (size_t)2 * Dp, reinterpret_cast<const uint16_t*>(Bm + (size_t)n0 * Dp),
+                   (size_t)2 * Dp, 2 * Dp, dl_smem, acc, -1, [] {}, [](int) { return true; });
+#else
         MmdDl::run(A + (size_t)m0 * Dp, (size_t)Dp, Bm + (size_t)n0 * Dp, (size_t)Dp, Dp, dl_smem, acc, -1, [] {});
+#endif
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
         const float cf = 1.f / ((float)N * (float)(N - 1));
 #pragma unroll
