@@ -134,7 +134,10 @@ def workspace(nbytes, device, tag=0):
 
 _side = {}
 import os as _os
-OVERLAP = _os.environ.get('CPG_NO_OVERLAP', '') == ''  # run independent launch chains (encoder directions, deferred weight gradients) on side streams
+# run independent launch chains (encoder directions, deferred weight gradients) on side streams - never when several ranks share this GPU
+# (CPG_SHARED_DEVICE, the single-GPU fallback of `bench.py --gpus N`): two processes' streams time-slice the device launch by launch, a
+# 22 ms step became 150-780 ms with the side streams on
+OVERLAP = _os.environ.get('CPG_NO_OVERLAP', '') == '' and not _os.environ.get('CPG_SHARED_DEVICE')
 
 
 def side_streams(device, n=3):
