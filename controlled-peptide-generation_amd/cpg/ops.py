@@ -201,7 +201,7 @@ DEFER_WGRAD = False   # only inside backward_scope: the decoder's dW_hh product 
 DEFER_SPLIT = _os.environ.get('CPG_DEFER_SPLIT', '')   # split-K of the DEFERRED dW_hh launch only: '' = 4/5 of the plan's, '0' = the plan's own, n = n
 
 
-def _deferred_split(Mr, N, Kd):
+def _deferred_split(Mr, N, Kd, pairs=0):
     """Option override for the deferred (side-stream) dW_hh launch.  The plan of the TN product fills the chip with ONE round of
     150 KB-LDS workgroups (24 tiles x split-K 10 = 240 at config B): right for a launch that has the GPU to itself, wrong for one that
     is meant to run UNDER the main stream's small launches - those then crawl on the 16 CUs left over (profiles/r04: a 5-us
@@ -211,7 +211,7 @@ def _deferred_split(Mr, N, Kd):
         return {}
     if DEFER_SPLIT:
         return {"tn_split": int(DEFER_SPLIT)}
-    s = int(query("cpg_gemm_tn_split", int(Mr), int(N), int(Kd)))
+    s = int(query("cpg_gemm_tn_split", int(Mr), int(N), int(Kd), int(pairs)))
     return {"tn_split": max(1, (4 * s) // 5)} if s >= 5 else {}
 DEFER_ENC_WGRAD = _os.environ.get('CPG_DEFER_ENC_WGRAD', '1') != '0'   # the encoder's reverse-direction dW_hh beside the forward one (GruBiSeqFn)
 DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... and so does the [z;c] block of its W_ih gradient (LinearColsFn)
@@ -775,7 +775,7 @@ class GruSeqFn(Function):
                 # plan's 240 workgroups hold 150 KB of LDS and every register of 240 CUs: whatever the main stream launches meanwhile
                 # crawls on the 16 CUs left (profiles/r04: a 5-us gradient add takes 370 us there).  Fewer, longer workgroups leave
                 # whole CUs to the main stream's small launches.
-                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H)):
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H, pair is not None)):
                     call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
                          None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _p(pair), dgb, _stream())
                 if has_tab:

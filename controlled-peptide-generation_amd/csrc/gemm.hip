@@ -10,6 +10,9 @@
 #endif
 #include <stdlib.h>
 #include <string.h>
+#ifndef CPG_PAIR_TN_WGS
+#define CPG_PAIR_TN_WGS 512   // workgroups the f16-pair 128 x 128 dW_hh launch aims at (its 51 KB of LDS and 136 registers allow three per CU)
+#endif
 #ifndef CPG_PAIR_TN_128
 #define CPG_PAIR_TN_128 1   // the f16-pair dW_hh product on the single-buffered 128 x 128 tile (two workgroups per CU) instead of 256 x 128
 #endif
@@ -349,7 +352,7 @@ static TnPlan tn_plan(int M, int N, int K, bool pairs = false) {
         want = 256 / tiles;
     } else if (p.tile == TN_128x128) {   // single-buffered plane images: two workgroups per CU, one round
         const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
-        want = 512 / tiles;
+        want = ((pairs && cpg_compute_mode_get() != 1) ? CPG_PAIR_TN_WGS : 512) / tiles;
     } else {
         // Two 128x64 workgroups are resident per CU (57 KB LDS each): aim at ~3 full rounds of 512 workgroups so the
         // last round is not half empty (measured at M=1536,N=512,K=51200: S=4 (384 WGs) 1356 us, S=16 (1536 WGs) 1084 us).
@@ -418,11 +421,11 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs, char
     return snprintf(buf, n, "gemm_kernel<TileCfg<%s>, false, false, %s, false, %d>", tc, vec ? "true" : "false",
                     bf ? 1 : (dy_pairs && vec && (t == TN_256x128 || t == TN_192x128 || t == TN_128x128)) ? 8 : 7);
 }
-CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd) { return tn_plan(N, Kd, Mr).S; }
+CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd, int dy_pairs) { return tn_plan(N, Kd, Mr, dy_pairs != 0).S; }
 
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
-    const TnPlan p = tn_plan(N, Kd, Mr);
-    return (size_t)N * Kd * p.S * sizeof(float) + 256;
+    const TnPlan p = tn_plan(N, Kd, Mr), q = tn_plan(N, Kd, Mr, true);   // either form of the call (with / without column exponents)
+    return (size_t)N * Kd * (p.S > q.S ? p.S : q.S) * sizeof(float) + 256;
 }
 
 // Row chunks of the column sum: 256-row chunks (at most 96) for wide matrices; narrow ones (few 64-column blocks) get more,

@@ -1203,7 +1203,8 @@ static size_t dgi_mm_workspace(int T, int B, int H) {
 }
 
 CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
-    size_t a = cpg_gemm_tn_workspace(T * B, 4 * H, H);
+    size_t a = cpg_gemm_tn_workspace(T * B, 4 * H, H), a3 = cpg_gemm_tn_workspace(T * B, 3 * H, H);   // LSTM / GRU gate widths: the split-K factors differ
+    if (a3 > a) a = a3;
     size_t b = cpg_colsum_workspace(T * B, 4 * H);
     int chunks = cdiv(T * B, 512);
     if (chunks > 256) chunks = 256;

@@ -189,7 +189,7 @@ CPG_API int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int have_
 CPG_API int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt);
 CPG_API int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs /* the f16-pair form cpg_gru_wgrad_hh runs with a pair scratch */,
                                     char* buf, int n);
-CPG_API int cpg_gemm_tn_split(int Mr, int N, int Kd);
+CPG_API int cpg_gemm_tn_split(int Mr, int N, int Kd, int dy_pairs);
 CPG_API size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V);
 /* dw_hh[3H,H] (+)= sum_t dgh_t^T h_{prev(t)} ; db_hh[3H] (+)= sum dgh (db_hh may be null).
  * pair_scratch (optional): the scratch the sequence's cpg_gru_seq_bwd / cpg_gru_biseq_bwd call received (same B and H, enqueued
