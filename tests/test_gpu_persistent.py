@@ -300,6 +300,31 @@ def test_wgrad_hh_on_f16_pairs_vs_split_engine(B, H, T, reverse):
         assert err[0] < 1.5 * err[1] + 1e-7, (wild, err)
 
 
+def test_backward_f16_pair_step_edge_values():
+    """Edge values through the f16-pair backward step: all-zero gradients (every group takes the all-zero path: results exactly
+    zero, nothing read from the unwritten planes), a NaN and an infinity in the incoming gradient (they reach dh0 / dG: loud, as
+    with the exact step), and a recurrent weight beyond the f16-pair image's range (|w| >= 256 at the fixed 2^8 scale, csrc/pair_engine.h:
+    documented to overflow to infinity - the gradients become non-finite instead of silently wrong)."""
+    from cpg import ops
+    B, H, T = 256, 128, 5
+    d = _inputs(B, H, T, 24, seed=77)
+    hs, gates, dhs, last = _bwd_inputs(d, B, H, T, False, seed=8)
+    with ops.options(gru_bwd_tile="64x64"):
+        dG, dh0 = _bwd(d, B, H, T, False, hs, gates, torch.zeros_like(dhs), torch.zeros_like(last), pair=True)
+        assert not dG.any() and not dh0.any()
+        for bad in (float("nan"), float("inf")):
+            x = dhs.clone()
+            x[T - 1, 3, 5] = bad
+            dG, dh0 = _bwd(d, B, H, T, False, hs, gates, x, last, pair=True)
+            assert not torch.isfinite(dh0[3]).all() and not torch.isfinite(dG[0, 3]).all()
+            assert torch.isfinite(dh0[4:]).all()          # other rows are independent recurrences
+        d2 = dict(d)
+        d2["w_hh"] = d["w_hh"].clone()
+        d2["w_hh"][7, 9] = 300.0
+        dG, dh0 = _bwd(d2, B, H, T, False, hs, gates, dhs, last, pair=True)
+        assert not torch.isfinite(dh0).all()
+
+
 def ctypes_name(kind, B, H, ndir):
     import ctypes
     from cpg import lib
