@@ -775,6 +775,8 @@ def class_wide(dev, Z=510, N=131072):
     EVAL_FLOPS = 2.0 * 3 * H * (150 + H + H) + 2.0 * H * 24
     out = {"workload": f"one CLaSS round of {N} proposals at z={Z} / decoder h={H} (config-B width), per-step decode launches", "flops_per_eval": EVAL_FLOPS}
     sp.run_rounds(m, ds, Q, 8192, 10 ** 9, max_rounds=1, sample_mode='greedy')
+    kname = _cname("cpg_gru_step_kernel_name", 0, 65536, H, 1, 0)
+    wpeak = PEAK_PAIR_TFLOPS if kname.endswith(", 8>") else PEAK_SPLIT_TFLOPS   # the step kernel's product form (f16 pairs / bf16 triple)
     for tag, mode in (("greedy_all", "greedy"), ("beam5_all", "beam")):
         torch.cuda.synchronize()
         ops.PROFILE = []
@@ -788,8 +790,8 @@ def class_wide(dev, Z=510, N=131072):
         ach = st["decoder_evals"] * EVAL_FLOPS / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         out[tag] = {"wall_s": round(dt, 3), "accepted_per_s": round(float(df['accept'].sum()) / dt, 1), "decoder_evals": st["decoder_evals"],
                     "decoder_evals_per_s": round(st["decoder_evals"] / dt, 1), "decode_chain_ms": round(kms, 2), "chain_steps": steps,
-                    "roofline": {"bound": "mfma", "kernel": _cname("cpg_gru_step_kernel_name", 0, 65536, H, 1, 0), "achieved": round(ach, 2),
-                                 "peak": round(PEAK_SPLIT_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_SPLIT_TFLOPS, 4),
+                    "roofline": {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
+                                 "peak": round(wpeak, 1), "unit": "TFLOP/s", "frac": round(ach / wpeak, 4),
                                  "note": "algorithmic flops of the live row-steps (dense W_ih + W_hh + fc) over the time of the per-step "
                                          "chain (step kernel + vocabulary projection + selection)"}}
     del m

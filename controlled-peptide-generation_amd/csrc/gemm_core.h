@@ -67,6 +67,8 @@ struct OpB {
     const uint8_t* mask;
     float mscale;
     int pairs = 0;   // as OpA::pairs
+    float pscale = 1.f;   // SPLIT 8 (f16 pairs): power of two the operand is multiplied by before the split (weights: 2^8, see the f16-pair
+                          // notes above split2h_pair); the caller takes it back out of the accumulators
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSEG_, int NT_ = 256>
@@ -256,7 +258,8 @@ struct MainLoop {
     static constexpr int ASZ7 = NP * APL, BSZ7 = NP * BPL;
     static_assert(SPLIT == 0 || SPLIT == 7 || SPLIT == 1 || SPLIT == 8,
                   "0: exact f32; 7: f32-grade, three bf16 planes split at LDS-store time, six MFMAs; 1: bf16 compute mode, one plane, one MFMA; 8: f16 pairs");
-    static_assert(SPLIT != 8 || (TRX && AVEC && !MASKS), "f16 pairs: the transposed-use product on the 16-byte staging path");
+    static_assert(SPLIT != 8 || !MASKS, "f16 pairs: no keep-masks");
+    static_assert(SPLIT != 8 || !TRX || AVEC, "f16 pairs, transposed use: the 16-byte staging path (column exponents per vector)");
     static_assert(SPLIT == 0 || BK == 32, "plane products are written for 32-deep slabs");
     static_assert(SPLIT == 0 || TRX || ((A_KC || TC::AV % 2 == 0) && (B_KC || TC::BV % 2 == 0)), "XC staging works on k-row pairs");
     // SB ("single buffer", the 128 x 128 transposed-use tile on the plane engine): ONE LDS image per operand, two barriers per
@@ -519,14 +522,20 @@ struct MainLoop {
 #pragma unroll
         for (int i = 0; i < TC::AV; ++i) {
             ra[i] = finish4(st.a[i], st.aok[i], MASKS && a.mask != nullptr, st.am[i], a.mscale);
-            if constexpr (SPLIT == 8) {
+            if constexpr (SPLIT == 8 && !A_KC) {   // column exponents of a transposed-use A operand (plan())
                 const float f = pl.asc[i];
                 ra[i] = make_float4(ra[i].x * f, ra[i].y * f, ra[i].z * f, ra[i].w * f);
             }
         }
         sstore7_op<A_KC, BM, TC::AV, APL, SXA, A_BF16 && NP == 1>(As, ra);
 #pragma unroll
-        for (int i = 0; i < TC::BV; ++i) rb[i] = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
+        for (int i = 0; i < TC::BV; ++i) {
+            rb[i] = finish4(st.b[i], st.bok[i], MASKS && b.mask != nullptr, st.bm[i], b.mscale);
+            if constexpr (SPLIT == 8) {
+                const float f = b.pscale;
+                rb[i] = make_float4(rb[i].x * f, rb[i].y * f, rb[i].z * f, rb[i].w * f);
+            }
+        }
         sstore7_op<B_KC, BN, TC::BV, BPL, SXB>(Bs, rb);
     }
 

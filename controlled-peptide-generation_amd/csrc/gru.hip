@@ -59,7 +59,7 @@ struct GruFwdPair {
 #endif
 // PREC: 7 = f32-grade (three planes, six MFMAs), 1 = bf16 compute mode (one plane, one MFMA; cpg_set_compute_mode(1))
 template <class TC, bool VEC, int PREC = 7>
-using FwdLoop = MainLoop<TC, true, true, VEC, VEC, false, (CPG_STEP_FWD_SPLIT == 7 && TC::BK == 32) ? PREC : 0>;
+using FwdLoop = MainLoop<TC, true, true, VEC, VEC, false, (CPG_STEP_FWD_SPLIT == 7 && TC::BK == 32) ? PREC : 0>;   // PREC 7 | 8 | 1
 
 template <class TC, bool VEC, int PREC>
 __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
@@ -114,12 +114,20 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
 
     OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
     OpB b{g.w_hh, H, j0, H, H, nullptr, 1.f};
+    constexpr bool PAIR = FwdLoop<TC, VEC, PREC>::NP == 2;   // PREC 8 on the plane engine: f16 pairs, W_hh times 2^8 (gemm_core.h)
+    if constexpr (PAIR) b.pscale = 256.f;
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     FwdLoop<TC, VEC, PREC>::run(a, b, H, acc);
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] *= (1.f / 256.f);
+    }
 #if !CPG_FWD_PREFETCH
     fetch();
 #endif
@@ -619,7 +627,9 @@ static int launch_fwd_p(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
 
 template <class TC>
 static int launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
-    return cpg_compute_mode_get() == 1 ? launch_fwd_p<TC, 1>(pr, nd, vec, s) : launch_fwd_p<TC, 7>(pr, nd, vec, s);
+    // f32-grade mode: the engine of the persistent forward kernels (option f32_engine: f16 pairs by default, three bf16 planes)
+    const int np = cpg_persist_planes();
+    return np == 1 ? launch_fwd_p<TC, 1>(pr, nd, vec, s) : np == 2 ? launch_fwd_p<TC, 8>(pr, nd, vec, s) : launch_fwd_p<TC, 7>(pr, nd, vec, s);
 }
 
 template <class TC>
@@ -1050,7 +1060,8 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
         if (bm == 128) tc_name<GF128>(tc, sizeof tc);
         else if (bm == 64) tc_name<GF64>(tc, sizeof tc);
         else tc_name<GF32>(tc, sizeof tc);
-        return snprintf(buf, n, "gru_step_fwd_kernel<%s, %s, %d>", tc, vec ? "true" : "false", cpg_compute_mode_get() == 1 ? 1 : 7);
+        const int np = cpg_persist_planes();
+        return snprintf(buf, n, "gru_step_fwd_kernel<%s, %s, %d>", tc, vec ? "true" : "false", np == 1 ? 1 : np == 2 ? 8 : 7);
     }
     if (kind == 1) {
         const BwdPlan pl = bwd_plan(B, H, ndir, 0, vec, have_wt != 0, true);
@@ -1067,7 +1078,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
 // Product form of the named step kernel: 0 exact-f32 MFMA, 1 split-bf16 engine (six bf16 MFMAs per block), 2 one bf16 MFMA
 // per block (bf16 compute mode), 3 f16 pairs (three f16 MFMAs per block).
 CPG_EXPORT int cpg_gru_step_kernel_is_split(int kind, int B, int H, int ndir, int have_wt) {
-    if (kind == 0) return cpg_compute_mode_get() == 1 ? 2 : 1;
+    if (kind == 0) { const int np = cpg_persist_planes(); return np == 1 ? 2 : np == 2 ? 3 : 1; }
     const BwdPlan pl = bwd_plan(B, H, ndir, 0, H % 4 == 0, have_wt != 0, true);
     if (pl.kind != BK_STAGED) return pl.bf16 ? 2 : (pl.kind == BK_DL && pl.pair_ok) ? 3 : 0;
     return pl.tile.bn == 64 ? 1 : 0;   // XC k-row pairs: 64-column tiles run the split engine

@@ -58,20 +58,26 @@ def _run(d, B, H, T, reverse, persistent):
     (4096, 512, 3, True, False, False),     # the same at H = 512 (2048 rows per launch)
 ])
 def test_persistent_forward_matches_per_step(B, H, T, reverse, dense, rowc):
-    """Same cell formulas as the per-step kernel.  Option f32_engine = bf16x3: the same split and MFMA order as the per-step kernel
-    with 64-row split tiles too - results agree to f32 rounding of the reordered k-block sums (bit-identical is not required: the
-    per-step launcher may pick the exact engine for small shapes).  Default engine (f16 pair, three MFMAs per block): a different
-    f32-grade decomposition of the same product - both sit within f32 rounding of the exact sums (test_persistent_engines_vs_f64:
-    the pair is the closer one), so they differ from each other by the sum of the two."""
+    """Same cell formulas and the same product engine as the per-step kernel with 64-row split tiles (option f32_engine selects it for
+    both: f16 pairs by default, three bf16 planes) - results agree to f32 rounding of the reordered k-block sums (bit-identical is not
+    required: the per-step launcher may pick the exact engine for small shapes).  Across engines (persistent on pairs against per-step
+    on the triple) the two f32-grade decompositions differ by the sum of their roundings (test_persistent_engines_vs_f64: the pair is
+    the closer one to the exact sums)."""
     from cpg import ops
     d = _inputs(B, H, T, 24, seed=B + H + T, dense=dense, rowc=rowc)
-    hs_s, g_s = _run(d, B, H, T, reverse, False)
-    for engine, tol in (("f16x2", 1.5e-5), ("bf16x3", 5e-6)):
+    per_step = {}
+    for engine in ("f16x2", "bf16x3"):
         with ops.options(f32_engine=engine):
+            per_step[engine] = _run(d, B, H, T, reverse, False)
             hs_p, g_p = _run(d, B, H, T, reverse, True)
+        hs_s, g_s = per_step[engine]
         assert torch.isfinite(hs_p).all()
-        assert (hs_p - hs_s).abs().max().item() < tol, engine
-        assert (g_p - g_s).abs().max().item() < tol, engine
+        assert (hs_p - hs_s).abs().max().item() < 5e-6, engine
+        assert (g_p - g_s).abs().max().item() < 5e-6, engine
+        if engine == "f16x2":
+            pair = (hs_p, g_p)
+    assert (pair[0] - per_step["bf16x3"][0]).abs().max().item() < 1.5e-5
+    assert (pair[1] - per_step["bf16x3"][1]).abs().max().item() < 1.5e-5
 
 
 @pytest.mark.parametrize("B,H", [(2048, 512), (512, 1024), (256, 96)])
@@ -296,7 +302,7 @@ def test_wgrad_hh_on_f16_pairs_vs_split_engine(B, H, T, reverse):
         ref = (dG[:, :, :3 * H].reshape(T * B, 3 * H).double().T @ hprev)
         grp = ref.abs().view(3, H // 32, 32, H).amax(dim=(2, 3), keepdim=True).expand(3, H // 32, 32, H).reshape(3 * H, H)
         err = [((o.double() - ref).abs() / grp.clamp_min(1e-300)).max().item() for o in outs]
-        assert err[0] < 3e-6 and err[1] < 3e-6, (wild, err)
+        assert err[0] < 5e-6 and err[1] < 5e-6, (wild, err)   # f32 accumulation over up to 51 200 rows
         assert err[0] < 1.5 * err[1] + 1e-7, (wild, err)
 
 
