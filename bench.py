@@ -59,7 +59,8 @@ def pmc_traffic(kernel):
         return None
     if d.get("_csrc_sha256_16") != csrc_fingerprint():
         return None
-    r = d.get(kernel)
+    # (rocprofv3 prints gemm_kernel's trailing bf16-operand template argument, the launcher's name query does not)
+    r = d.get(kernel) or d.get(kernel[:-1] + ", false>") or d.get(kernel[:-1] + ", true>")
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
         return None
     return (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
