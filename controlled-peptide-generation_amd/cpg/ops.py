@@ -300,14 +300,16 @@ def _grad_buf(p):
     return g
 
 
-def linear_raw(x, w, b, out=None, accumulate=False):
+def linear_raw(x, w, b, out=None, accumulate=False, states=False):
+    """states: x holds recurrent states (magnitudes O(1)) - large products then run on f16 pairs (cpg_linear_fwd_pairs)."""
     x, ldx = _rowmajor(x)
     w, ldw = _rowmajor(w)
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    call("cpg_linear_fwd", _p(x), ldx, _p(w), ldw, _p(b), _p(out), out.stride(0), M, N, K, int(accumulate), _stream())
+    call("cpg_linear_fwd_pairs" if states else "cpg_linear_fwd", _p(x), ldx, _p(w), ldw, _p(b), _p(out), out.stride(0), M, N, K,
+         int(accumulate), _stream())
     return out
 
 
@@ -413,8 +415,8 @@ class Linear2Fn(Function):
     def forward(ctx, x1, x2, w, b):
         ctx.save_for_backward(x1, x2, w)
         K1 = x1.shape[1]
-        y = linear_raw(x1, w[:, :K1], b)
-        linear_raw(x2, w[:, K1:], None, out=y, accumulate=True)
+        y = linear_raw(x1, w[:, :K1], b, states=True)      # x1, x2: state slabs of the lower layer
+        linear_raw(x2, w[:, K1:], None, out=y, accumulate=True, states=True)
         return y
 
     @staticmethod

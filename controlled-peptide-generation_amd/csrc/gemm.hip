@@ -33,6 +33,7 @@ struct GemmArgs {
     int a_bf16 = 0;                // A holds bf16 elements (OpA::bf16): the dW_hh product on bf16 gate gradients
     const int* a_exps = nullptr;   // PREC 8 (f16 pairs): power-of-two exponent per 32-column group of A's M axis (OpA::exps); the kernel
     int a_exps_mod = 1;            // multiplies the columns by 2^e on the way in and the output rows by 2^-e on the way out
+    float b_pscale = 1.f;          // PREC 8, nn.Linear-shaped form: B (the weights) times this power of two before the split, the result by its inverse
 };
 
 // PREC: 7 = f32-grade (three bf16 planes), 8 = f32-grade on f16 pairs (the dW_hh product behind the f16-pair BPTT), 1 = bf16 compute
@@ -40,6 +41,7 @@ struct GemmArgs {
 // exact-f32 MFMA whatever PREC says
 template <class TC, bool A_KC, bool B_KC, int PREC>
 constexpr int gemm_split() {
+    if (PREC == 8 && A_KC && B_KC && TC::BK == 32) return 8;   // y = x W^T on f16 pairs: only where the caller vouches for x (cpg_linear_fwd_pairs)
     return (!A_KC && !B_KC && CPG_TN_PRODUCT_SPLIT == 7) ? PREC : 0;
 }
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool MASKS, int PREC = 7, bool A_BF16 = false>
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     OpA a{g.a_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g.A) + aoff) : g.A + aoff, g.lda, m0, g.M,
           g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a, g.a_bf16, g.a_exps, g.a_exps_mod};
     OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale, g.pairs_b};
+    if constexpr (PREC == 8 && A_KC && B_KC) b.pscale = g.b_pscale;
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -81,7 +84,9 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
                 const int row = m0 + acc_row<TC>(mi, r);
                 if (row >= g.M) continue;
                 const size_t o = (size_t)row * g.ldc + col;
-                if constexpr (PREC == 8) {   // take the column scale of the A operand back out (exact)
+                if constexpr (PREC == 8 && A_KC && B_KC) {
+                    acc[mi][ni][r] *= 1.f / g.b_pscale;   // the weights' power of two back out (exact)
+                } else if constexpr (PREC == 8) {   // take the column scale of the A operand back out (exact)
                     const int e = g.a_exps ? g.a_exps[(row % g.a_exps_mod) / 32] : 0;
                     acc[mi][ni][r] *= __builtin_bit_cast(float, (unsigned)(127 - (e == INT_MAX ? 0 : e)) << 23);
                 }
@@ -289,6 +294,27 @@ int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const 
     return launch_gemm<true, true>(g, 1, s);
 }
 
+// y = x W^T + b on f16 pairs (three f16 MFMAs per block, gemm_core.h) for inputs the CALLER vouches for: magnitudes O(1) (|x| < 65504,
+// absolute precision 2^-25 below 2^-14) - recurrent states.  W goes in times 2^8 (weights of magnitude 2^-11 .. 255 keep full precision).
+// Large products only (the 128 x 64 tile, 16-byte staging path); everything else runs cpg_gemm_nt.
+int cpg_gemm_nt_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K,
+                      int accumulate, hipStream_t s) {
+    const bool vec = aligned16(X) && aligned16(W) && ldx % 4 == 0 && ldw % 4 == 0 && K % 4 == 0;
+    if (!vec || cpg_compute_mode_get() == 1 || (long)cdiv(M, 128) * cdiv(N, 64) < 512 || K < 256)
+        return cpg_gemm_nt(X, ldx, nullptr, 1.f, W, ldw, bias, Y, ldy, M, N, K, accumulate, s);
+    GemmArgs g{X, ldx, M, W, ldw, N, K, Y, ldy, bias, accumulate, nullptr, 1.f, nullptr, 1.f, nullptr, 1.f, 0, 0};
+    g.b_pscale = 256.f;
+    using TC = TileCfg<128, 64, 32, 2, 2, 1>;
+    const size_t smem = GemmLoop<TC, true, true, true, false, 8>::smem_bytes();
+    if (smem > 64 * 1024) {
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gemm_kernel<TC, true, true, true, false, 8>), (int)smem);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((gemm_kernel<TC, true, true, true, false, 8>), dim3(cdiv(N, TC::BN), cdiv(M, TC::BM), 1), dim3(TC::NT), smem, s, g);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 // Y[m,n] (+)= sum_k X[m,k] B[k,n] for a handful of rows (M <= 32) and long K: one (64-column, row) block with 16 K-lanes
 // and a fixed-order LDS reduction.  The tile engine would put such a problem on 1-2 workgroups walking K serially.
 __global__ void skinny_nn_kernel(const float* X, int ldx, const float* Bm, int ldb, float* Y, int ldy, int N, int K,
@@ -460,6 +486,14 @@ CPG_EXPORT int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
                               int N, int K, int accumulate, void* stream) {
     CPG_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
     return cpg_gemm_nt(X, ldx, nullptr, 1.f, W, ldw, bias, Y, ldy, M, N, K, accumulate, (hipStream_t)stream);
+}
+
+// cpg_linear_fwd for an input of O(1) magnitudes (recurrent states: the input projection of an upper encoder layer) - large products
+// then run on f16 pairs, see cpg_gemm_nt_pairs; same results within f32 rounding
+CPG_EXPORT int cpg_linear_fwd_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
+                                    int N, int K, int accumulate, void* stream) {
+    CPG_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
+    return cpg_gemm_nt_pairs(X, ldx, W, ldw, bias, Y, ldy, M, N, K, accumulate, (hipStream_t)stream);
 }
 
 CPG_EXPORT int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,

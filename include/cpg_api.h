@@ -57,6 +57,10 @@ CPG_API int cpg_transpose01_u8(const uint8_t* src, int d0, int d1, int inner, ui
 /* Y[M,N] (+)= X[M,K] W[N,K]^T + bias[N] */
 CPG_API int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                            int M, int N, int K, int accumulate, void* stream);
+/* The same for an input whose magnitudes are O(1) - recurrent states (|x| < 65504; absolute precision 2^-25 below 2^-14): large products
+ * run on f16 pairs (three f16 MFMAs per block), same results within f32 rounding.  The caller vouches for the input's range. */
+CPG_API int cpg_linear_fwd_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
+                                 int N, int K, int accumulate, void* stream);
 /* dX[M,K] (+)= dY[M,N] W[N,K] */
 CPG_API int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,
                                  int K, int accumulate, void* stream);

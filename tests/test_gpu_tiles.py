@@ -410,3 +410,37 @@ def test_column_sums_every_chunking(M, N, ld):
     assert (out.double() - 2 * ref).abs().max().item() <= 2 * tol
     with pytest.raises(ops.CpgError):
         call("cpg_colsum_f32", _p(x), ld, M, N, _p(out), 0, _p(ws), 8, _stream())     # workspace too small: refused
+
+
+@pytest.mark.gpu
+def test_linear_fwd_on_f16_pairs_for_state_inputs():
+    """cpg_linear_fwd_pairs (the input projection of an upper encoder layer: x = the lower layer's states, |x| <= 1; csrc/gemm.hip
+    cpg_gemm_nt_pairs) against cpg_linear_fwd (exact-f32 MFMA) and an f64 product: both f32-grade, the pair form no further from f64;
+    with accumulate; small products fall through to the exact kernel (bit-identical)."""
+    import torch
+    from cpg.ops import _p, _stream, call
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 8192, 3072, 1024
+    x = (torch.rand(M, K, generator=g) * 2 - 1).to(dev)
+    x[:, :7] *= 1e-6                      # tiny state values: absolute precision is what counts
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    ref = (x.double() @ w.double().T + b.double())
+    outs = {}
+    for name in ("cpg_linear_fwd_pairs", "cpg_linear_fwd"):
+        y = torch.zeros(M, N, device=dev)
+        call(name, _p(x), K, _p(w), K, _p(b), _p(y), N, M, N, K, 0, _stream())
+        call(name, _p(x), K, _p(w), K, None, _p(y), N, M, N, K, 1, _stream())     # accumulate: y = 2 x W^T + b
+        torch.cuda.synchronize()
+        outs[name] = ((y.double() - (2 * ref - b.double())).abs().max().item(), y)
+    scale = ref.abs().max().item()
+    assert outs["cpg_linear_fwd_pairs"][0] < 3e-6 * scale and outs["cpg_linear_fwd"][0] < 3e-6 * scale, {k: v[0] for k, v in outs.items()}
+    assert outs["cpg_linear_fwd_pairs"][0] < 1.5 * outs["cpg_linear_fwd"][0] + 1e-7
+    xs, ws = x[:256].contiguous(), w[:96].contiguous()
+    ya, yb = torch.zeros(256, 96, device=dev), torch.zeros(256, 96, device=dev)
+    call("cpg_linear_fwd_pairs", _p(xs), K, _p(ws), K, None, _p(ya), 96, 256, 96, K, 0, _stream())
+    call("cpg_linear_fwd", _p(xs), K, _p(ws), K, None, _p(yb), 96, 256, 96, K, 0, _stream())
+    assert torch.equal(ya, yb)
