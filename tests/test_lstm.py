@@ -206,6 +206,8 @@ def _lstm_run(d, B, H, T, reverse, persistent):
     (333, 128, 9, True, True, False),       # dense input term (upper layers), reverse
     (64, 512, 50, False, False, True),
     (1000, 256, 3, False, True, True),
+    (256, 1024, 4, False, False, True),     # configs[4] width: covered since the f16-pair planes (32 x 1024 x 4 B = 131 KB of LDS; the bf16 triple needed 196)
+    (1024, 1024, 3, True, True, False),     # ... up to 1024 rows per launch (256 co-resident workgroups)
 ])
 def test_lstm_persistent_forward_matches_per_step(B, H, T, reverse, dense, rowc):
     """State slabs (h, c) and saved gates of every step against the per-step kernels.  Option f32_engine = bf16x3: same split
@@ -217,6 +219,9 @@ def test_lstm_persistent_forward_matches_per_step(B, H, T, reverse, dense, rowc)
     hq, cq, gq = _lstm_run(d, B, H, T, reverse, False)
     for engine, k in (("f16x2", 3.0), ("bf16x3", 1.0)):
         with ops.options(f32_engine=engine):
+            if not ops.lstm_persistent_fits(B, H):    # three bf16 planes do not fit the LDS at H = 1024
+                assert engine == "bf16x3" and H > 512
+                continue
             hp, cp, gp = _lstm_run(d, B, H, T, reverse, True)
         assert torch.isfinite(hp).all() and torch.isfinite(cp).all()
         assert (hp - hq).abs().max().item() < k * 5e-6, engine
@@ -319,6 +324,10 @@ def test_lstm_persistent_limits_and_option():
     assert ops.lstm_persistent_fits(2048, 512)
     assert not ops.lstm_persistent_fits(2048, 100)     # H % 32 != 0
     assert not ops.lstm_persistent_fits(8192, 512)     # 1024 workgroups
+    assert ops.lstm_persistent_fits(1024, 1024)        # configs[4] width (f16-pair planes: round 4)
+    assert not ops.lstm_persistent_fits(2048, 1024)    # 512 workgroups of 131 KB LDS
+    with ops.options(f32_engine="bf16x3"):
+        assert not ops.lstm_persistent_fits(1024, 1024)    # three bf16 planes of 32 gate rows x 1024: 196 KB
     with ops.options(lstm_persist=0):
         assert not ops.lstm_persistent_fits(2048, 512)
 
