@@ -169,11 +169,11 @@ def family_roofline(family, dims, avg_us, launches):
     return r
 
 
-def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, cell='gru'):
+def model_kwargs(z_dim, enc_h, enc_layers=1, emb_dim=150, cell='gru', dec_layers=1):
     return dict(
         z_dim=z_dim, c_dim=2, emb_dim=emb_dim, pretrained_emb=None, freeze_embeddings=False, flow=0, flow_type='',
         E_args=dict(h_dim=enc_h, biGRU=True, layers=enc_layers, p_dropout=0.0, cell=cell),
-        G_args=dict(G_class='gru', GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False, cell=cell),
+        G_args=dict(G_class='gru', GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False, cell=cell, layers=dec_layers),
                     deconv_args=dict()),
         C_args=dict(min_filter_width=3, max_filter_width=5, num_filters=100, dropout=0.5))
 

@@ -4,7 +4,8 @@ callers of the same kernels, with the reference's names, arguments and return va
   generate_interpolated_samples :208-238, recon_sequence :241-255, interpolate_peptides :258-274, pretty_print_samples
   :277-287, get_model_and_vocab_path :290-305, get_result_for_model :308-334.
 Differences: the model lives on the GPU (`load_trained_model(..., device=)`; the reference maps to CPU) and a checkpoint
-that does not match the model is an error instead of being silently ignored (strict=False, :93)."""
+that LACKS a parameter of the model is an error instead of being silently ignored (strict=False, :93); keys the model does not have
+(the AAE discriminator the reference's comment at :94 names) are ignored exactly as the reference ignores them."""
 import codecs
 import json
 import logging
@@ -53,14 +54,17 @@ class Vocab:
 
 
 def load_state_dict_checked(model, sd):
-    """load_state_dict that tolerates exactly what the reference's checkpoints legitimately lack or add - nothing on the
-    VAE path.  The reference passes strict=False (api.py:93), which silently ignores any mismatch; a mismatched checkpoint
-    would leave parts of the model randomly initialised, so every missing / unexpected key is an error here except the
-    aliased `decoder.emb.weight` (same tensor as `word_emb.weight`)."""
+    """load_state_dict as the reference calls it (api.py:90-95: strict=False "only meaning to ignore AAE discriminator from AAE"):
+    UNEXPECTED keys - parameters of modules this model does not have, e.g. an AAE checkpoint's discriminator - are ignored (logged
+    once), so such checkpoints load as they do in the reference.  MISSING keys stay an error (the reference's own commented-out
+    `assert not missing_keys`): they would leave parts of the model randomly initialised; the aliased `decoder.emb.weight` (same
+    tensor as `word_emb.weight`) is the one exemption.  Shape mismatches raise in torch itself, as in the reference."""
     missing, unexpected = model.load_state_dict(sd, strict=False)
     missing = [k for k in missing if k != 'decoder.emb.weight']
-    if missing or unexpected:
-        raise RuntimeError('checkpoint does not match the model: missing {}, unexpected {}'.format(missing, unexpected))
+    if missing:
+        raise RuntimeError('checkpoint does not match the model: missing {}'.format(missing))
+    if unexpected:
+        LOG.warning('checkpoint keys ignored (no such module in the model): %s', sorted(unexpected))
     return model
 
 

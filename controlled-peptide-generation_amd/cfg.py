@@ -188,7 +188,7 @@ model = _bunchify(dict(
     E_args=dict(h_dim=80, biGRU=True, layers=1, p_dropout=0.0, cell='gru'),   # cell: 'gru' (reference) | 'lstm' (extension)
     G_args=dict(
         G_class='gru',
-        GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False, cell='gru'),
+        GRU_args=dict(p_word_dropout=0.3, p_out_dropout=0.3, skip_connetions=False, cell='gru', layers=1),   # layers > 1: extension
         deconv_args=dict(max_seq_len=max_seq_len, num_filters=100, kernel_size=4, num_deconv_layers=3, useRNN=False,
                          temperature=1.0, use_batch_norm=True, num_conv_layers=2, add_final_conv_layer=True),
     ),

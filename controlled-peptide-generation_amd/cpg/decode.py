@@ -23,17 +23,79 @@ def _fc(decoder, h, logits, sz=None, keep=None):
 
 
 def _plain(decoder):
-    """The whole-loop kernels cover the plain decode step only: no skip connections, no live out-dropout (train-mode sampling)."""
-    return not getattr(decoder, "skip_connetions", False) and not (decoder.training and decoder.p_out > 0)
+    """The whole-loop kernels cover the plain decode step only: one layer, no skip connections, no live out-dropout (train-mode
+    sampling)."""
+    return (getattr(decoder, "layers", 1) == 1 and not getattr(decoder, "skip_connetions", False)
+            and not (decoder.training and decoder.p_out > 0))
+
+
+class UpperLayers:
+    """Layers 1..L-1 of a multi-layer decoder during a per-step decode (EXTENSION: the reference's decoder has one layer,
+    models/decoder.py:40-41; semantics = torch.nn.GRU / nn.LSTM(num_layers=L), every layer starting from h0 = [z;c], c0 = 0).
+    Each layer keeps a two-slot state slab [2,R,H]: slot 0 = state before the step, slot 1 = state after it; `step` runs the
+    layers on the lower layer's new state, `commit` / `reorder` move slot 1 to slot 0 (as it is / through beam back-pointers)."""
+
+    def __init__(self, decoder, h0, lstm):
+        self.rnn, self.lstm, self.L = decoder.rnn, lstm, decoder.layers
+        self.hs = [torch.stack([h0, torch.empty_like(h0)]) for _ in range(1, self.L)]
+        self.cs = [torch.zeros(2, *h0.shape, device=h0.device, dtype=torch.float32) for _ in range(1, self.L)] if lstm else None
+
+    def __bool__(self):
+        return self.L > 1
+
+    def _w(self, name, l):
+        return getattr(self.rnn, f"{name}_l{l}")
+
+    def step(self, x):
+        """x [R,H]: layer 0's state after this step -> the top layer's state after this step."""
+        for j, l in enumerate(range(1, self.L)):
+            R, H = x.shape
+            dense = ops.linear_raw(x.contiguous(), self._w("weight_ih", l), self._w("bias_ih", l))
+            if self.lstm:
+                call("cpg_lstm_seq_fwd", 1, R, H, 0, _p(self._w("weight_hh", l)), _p(self._w("bias_hh", l)), None, None, None,
+                     _p(dense), _p(self.hs[j]), _p(self.cs[j]), None, _stream())
+            else:
+                call("cpg_gru_seq_fwd", 1, R, H, 0, _p(self._w("weight_hh", l)), _p(self._w("bias_hh", l)), None, None, None,
+                     _p(dense), _p(self.hs[j]), None, 0, R, None, _stream())
+            x = self.hs[j][1]
+        return x
+
+    def commit(self):
+        for j in range(self.L - 1):
+            self.hs[j][0].copy_(self.hs[j][1])
+            if self.lstm:
+                self.cs[j][0].copy_(self.cs[j][1])
+
+    def reorder(self, origin, N, K):
+        for j in range(self.L - 1):
+            H = self.hs[j].shape[2]
+            call("cpg_beam_reorder", _p(self.hs[j][1]), _p(self.hs[j][0]), _p(origin), N, K, H, _stream())
+            if self.lstm:
+                call("cpg_beam_reorder", _p(self.cs[j][1]), _p(self.cs[j][0]), _p(origin), N, K, H, _stream())
+
+    def states(self):
+        """(h [L-1,R,H] after the last step, c or None)."""
+        return torch.stack([h[1] for h in self.hs]), (torch.stack([c[1] for c in self.cs]) if self.lstm else None)
 
 
 def _step_keep(decoder, out_keep, i, rows, dev):
     """Out-dropout mask of step i: the injected one, else the decoder's own draw when it is in train mode, else None."""
     if out_keep is not None:
-        k = out_keep[i] if i < out_keep.shape[0] else None
-        assert k is None or tuple(k.shape) == (rows, decoder.h_dim)
-        return k.contiguous() if k is not None else decoder.step_keep(rows, dev)
+        if i >= out_keep.shape[0]:
+            # the device loops run all max_len steps and cut afterwards (no host sync per step): steps past the injected masks can
+            # only produce columns that are cut - the callers CHECK that (_check_keep_covers) and raise otherwise
+            return None
+        k = out_keep[i]
+        assert tuple(k.shape) == (rows, decoder.h_dim)
+        return k.contiguous()
     return decoder.step_keep(rows, dev)
+
+
+def _check_keep_covers(out_keep, steps_used):
+    """Injected out-dropout masks must cover every decode step whose result is RETURNED (round-4 advisor finding: a short mask tensor
+    silently changed the semantics of the later steps)."""
+    if out_keep is not None and steps_used > out_keep.shape[0]:
+        raise ValueError("out_keep holds masks for %d decode steps but %d steps contribute to the result" % (out_keep.shape[0], steps_used))
 
 
 LDS_PER_WORKGROUP = 160 * 1024  # gfx950
@@ -123,6 +185,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     h_a, h_b = zc.clone(), torch.empty_like(zc)
     if lstm:
         c_a, c_b = torch.zeros_like(zc), torch.empty_like(zc)
+    upper = UpperLayers(decoder, zc, lstm)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
     finished = torch.zeros(N, device=dev, dtype=torch.uint8)
     ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
@@ -138,7 +201,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
             c_a, c_b = c_b, c_a
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
-        _fc(decoder, h_b, logits, sz, _step_keep(decoder, out_keep, i, N, dev))
+        _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         pe = 1 if (prevent_empty and i == 0) else 0
         if mode == "greedy":
             call("cpg_greedy_select", _p(logits), N, V, _p(finished), _p(ids), max_len + 1, i + 1, _p(tok), PAD_IDX,
@@ -158,8 +221,11 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         else:
             raise ValueError(mode)
         h_a, h_b = h_b, h_a
+        upper.commit()
     prof.__exit__(None, None, None)
-    return _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx)
+    out = _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx)
+    _check_keep_covers(out_keep, out.shape[1] - 1)
+    return out
 
 
 @torch.no_grad()
@@ -186,6 +252,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
     hs[0].copy_(zc)
     cs = torch.zeros(2, N, H, device=dev, dtype=torch.float32) if lstm else None
     sz = decoder.skip_term(zc)
+    upper = UpperLayers(decoder, zc, lstm)
     logits = torch.empty(N, V, device=dev, dtype=torch.float32)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
     finished = torch.zeros(N, device=dev, dtype=torch.bool)
@@ -207,7 +274,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
             else:
                 call("cpg_gru_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
                      _p(hs), None, 0, N, None, _stream())
-        _fc(decoder, hs[1], logits, sz, _step_keep(decoder, out_keep, i, N, dev))
+        _fc(decoder, upper.step(hs[1]) if upper else hs[1], logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         soft = torch.softmax(logits / temp, dim=1)
         if mode == "greedy_softmax":
             t = torch.argmax(logits, 1)
@@ -223,6 +290,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
         hs[0].copy_(hs[1])
         if lstm:
             cs[0].copy_(cs[1])
+        upper.commit()
         if mode != "none_softmax" and (i % 4) == 3 and len(ids) >= min_length and bool(finished.all()):
             # the reference tests this every step; steps run past the break only add all-<pad> columns, cut below
             break
@@ -233,6 +301,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
         if fin_step is not None:
             keep = max(fin_step + 1, min(min_length, ids_t.shape[1]))
             ids_t, soft_t = ids_t[:, :keep], soft_t[:, :keep]
+    _check_keep_covers(out_keep, ids_t.shape[1] - 1)
     return ids_t, soft_t
 
 
@@ -266,6 +335,7 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
     if lstm:
         c_a, c_b = torch.zeros_like(h_a), torch.empty_like(h_a)
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
+    upper = UpperLayers(decoder, h_a, lstm)
     H = h_a.shape[1]
     V = decoder.fc[1].weight.shape[0]
     i32 = dict(device=dev, dtype=torch.int32)
@@ -291,17 +361,20 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
-        _fc(decoder, h_b, logits, sz, _step_keep(decoder, out_keep, i, K * N, dev))
+        _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, K * N, dev))
         call("cpg_beam_select", _p(logits), N, V, K, i, n_best, min_length, START_IDX, EOS_IDX, _p(scores), _p(last_tok),
              _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active), _p(h_b),
              _p(h_a), H, _stream())
         if lstm:   # the cell state follows the same back-pointers (Beam-major rows)
             call("cpg_beam_reorder", _p(c_b), _p(c_a), _p(origin), N, K, H, _stream())
+        upper.reorder(origin, N, K)   # upper layers' states follow the same back-pointers (_update_hidden, models/model.py:378-385)
         steps_run = i + 1
         if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early
             break
     prof.launches = steps_run
     prof.__exit__(None, None, None)
+    if out_keep is not None:
+        _check_keep_covers(out_keep, int((hist_tok[:steps_run, :, 0] >= 0).any(1).sum().item()))
     return hist_tok[:steps_run], hist_prev[:steps_run], hist_score[:steps_run]
 
 

@@ -108,15 +108,31 @@ class _prof:
         return False
 
 
-GRAPH_CAPTURED = False   # set by train_vae.GraphedTrainStep: a hipGraph now holds raw pointers into the caches below
-_retired = []            # buffers superseded AFTER a capture: kept alive, a replay still writes to them
+GRAPH_CAPTURED = 0       # live hipGraphs (train_vae.GraphedTrainStep: graph_captured() / graph_released()) holding raw pointers into the caches below
+_retired = []            # buffers superseded while a captured graph is alive: kept, a replay still writes to them
+
+
+def graph_captured():
+    """A capture is about to start: from here on superseded scratch buffers are parked in _retired (buffers replaced DURING the
+    capture are referenced by its nodes as well)."""
+    global GRAPH_CAPTURED
+    GRAPH_CAPTURED += 1
+
+
+def graph_released():
+    """A captured graph was dropped (or its capture failed): once no graph is alive the parked buffers go back to the allocator
+    (round-4 advisor finding: the flag was never reset, pinning every superseded buffer for the life of the process)."""
+    global GRAPH_CAPTURED
+    GRAPH_CAPTURED = max(0, GRAPH_CAPTURED - 1)
+    if not GRAPH_CAPTURED:
+        _retired.clear()
 
 
 def _retire(old):
     """A cached scratch buffer is being replaced by a larger one.  Once a training step has been captured into a hipGraph the
     graph's kernel nodes carry the OLD buffer's address (the side-stream workspaces included: side_streams() is shared by eager
     and captured code), so dropping the last reference would hand that memory back to the caching allocator while every replay
-    still writes to it.  Superseded buffers are therefore parked here for the life of the process (round-3 advisor finding)."""
+    still writes to it.  Superseded buffers are therefore parked here while any captured graph is alive (round-3 advisor finding)."""
     if GRAPH_CAPTURED and old is not None:
         _retired.append(old)
 
@@ -218,57 +234,74 @@ DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... 
 BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
 
 
+def _count_boundaries(root):
+    """tag -> number of GradBoundaryFn nodes reachable from `root`'s autograd graph: the boundaries THIS backward pass will reach."""
+    roots = root if isinstance(root, (tuple, list)) else (root,)
+    counts, seen, stack = {}, {}, [t.grad_fn for t in roots if t is not None and t.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn is None or id(fn) in seen:
+            continue
+        seen[id(fn)] = fn     # keeps the Python wrapper of the node alive: ids of collected wrappers are reused
+        if type(fn).__name__ == 'GradBoundaryFnBackward':
+            counts[fn.tag] = counts.get(fn.tag, 0) + 1
+        stack.extend(nf for nf, _ in fn.next_functions)
+    return counts
+
+
 class backward_scope:
-    """`with backward_scope(boundary_cb): loss.backward()` - the fused-optimiser form of the backward pass: weight-gradient
+    """`with backward_scope(boundary_cb, root=loss): loss.backward()` - the fused-optimiser form of the backward pass: weight-gradient
     kernels accumulate straight into the parameters' existing .grad buffers (the Functions then return None for those
     inputs), the decoder's dW_hh product runs on a side stream, gradient-bucket boundaries fire `boundary_cb(tag)`.  Leaving
     the scope joins the side stream and restores plain autograd semantics (every Function returns its gradients), so
-    torch.autograd.grad, parameter hooks and any other optimiser see standard behaviour outside it."""
+    torch.autograd.grad, parameter hooks and any other optimiser see standard behaviour outside it.
+    root: the tensor(s) being differentiated - REQUIRED with a boundary_cb: the boundaries of each tag are counted ON THAT GRAPH, so
+    whether and when a bucket's all-reduce starts is a function of the graph alone, identical on every rank that differentiates the
+    same model (round-4 advisor finding: a process-global count of forward passes made it depend on host history - a grad-enabled
+    forward that was never differentiated on ONE rank changed that rank's collective sequence)."""
 
-    def __init__(self, boundary_cb=None):
-        self.cb = boundary_cb
+    def __init__(self, boundary_cb=None, root=None):
+        if boundary_cb is not None and root is None:
+            raise ValueError("backward_scope: a boundary callback needs `root`, the tensor(s) being differentiated")
+        self.cb, self.root = boundary_cb, root
 
     def __enter__(self):
-        global DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB
-        self.prev = (DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB)
+        global DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB, _boundary_left
+        self.prev = (DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB, _boundary_left)
         DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB = True, True, self.cb
+        _boundary_left = _count_boundaries(self.root) if self.cb is not None else {}
         return self
 
     def __exit__(self, *exc):
-        global DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB
-        DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB = self.prev
+        global DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB, _boundary_left
+        DIRECT_GRAD, DEFER_WGRAD, BOUNDARY_CB, _boundary_left = self.prev
         join_deferred()
         return False
 
 
-_boundary_pending = {}   # tag -> boundaries of that tag registered by forward passes and not yet reached by a backward pass
-
-
-def reset_boundaries():
-    """Forget boundaries registered by forward passes that were never differentiated (FusedAdamClip.step calls this)."""
-    _boundary_pending.clear()
+_boundary_left = {}   # inside a backward_scope with a callback: tag -> boundaries of the graph being differentiated not yet reached
 
 
 class GradBoundaryFn(Function):
     """Identity on its tensor inputs.  Its backward runs once the gradients of ALL of them are complete - i.e. after every
     backward node downstream of the boundary has been enqueued - and then fires BOUNDARY_CB(tag): the optimiser starts the
     all-reduce of the gradient bucket that became final there while the rest of the backward pass still runs.
-    A module may run more than once in the graph being differentiated (the decoder of a multi-decode loss): every forward
-    registers its boundary, and the callback fires only when the LAST registered boundary of the tag has been reached - the
-    bucket's gradients are not final before that (round-3 advisor finding)."""
+    A module may run more than once in the graph being differentiated (the decoder of a multi-decode loss): the callback fires
+    only when the LAST boundary of the tag IN THAT GRAPH has been reached (backward_scope counts them on the graph) - the bucket's
+    gradients are not final before that (round-3 advisor finding).  The forward pass keeps no state anywhere but on its own node."""
 
     @staticmethod
     def forward(ctx, tag, *ts):
         ctx.tag = tag
-        _boundary_pending[tag] = _boundary_pending.get(tag, 0) + 1
         return tuple(t.view_as(t) for t in ts)
 
     @staticmethod
     def backward(ctx, *gs):
-        left = _boundary_pending.get(ctx.tag, 1) - 1
-        _boundary_pending[ctx.tag] = max(left, 0)
-        if BOUNDARY_CB is not None and left <= 0:
-            BOUNDARY_CB(ctx.tag)
+        if BOUNDARY_CB is not None:
+            left = _boundary_left.get(ctx.tag, 1) - 1
+            _boundary_left[ctx.tag] = left
+            if left == 0:
+                BOUNDARY_CB(ctx.tag)
         return (None,) + gs
 
 

@@ -52,8 +52,12 @@ class BucketReducer:
             self.inflight.append((self.async_reduce_fn(g), None))
             return
         main = torch.cuda.current_stream()
-        side = ops.side_streams(self.flat_g.device)[2]   # the deferred dW_hh accumulation of this bucket is queued there
+        streams = ops.side_streams(self.flat_g.device)
+        side = streams[2]                                # the deferred dW_hh accumulation of this bucket is queued there
         side.wait_stream(main)
+        for s in streams:                                # ... and EVERY other side stream that carries deferred accumulations into
+            if s is not side:                            # .grad (GruBiSeqFn's reverse dW_hh on side[1]): a bucket must not leave
+                side.wait_stream(s)                      # before them, whichever stream its parameters' products ran on
         with torch.cuda.stream(side):
             work = self.async_reduce_fn(g)
         self.inflight.append((work, side))
@@ -167,7 +171,7 @@ class FusedAdamClip:
         """loss.backward() in the fused form (cpg.ops.backward_scope): direct accumulation into the flat gradient buffer, the
         decoder's dW_hh on the side stream, bucket all-reduces started from the gradient boundaries."""
         cb = self.reducer.on_boundary if self.reducer.overlapped else None
-        with ops.backward_scope(cb):
+        with ops.backward_scope(cb, root=loss):   # boundaries are counted on loss's own graph: same decision on every rank
             loss.backward()
 
     def _finish_reduce(self):
@@ -213,4 +217,3 @@ class FusedAdamClip:
             off = self.segs[i][0]
             adam(off, n - off, 1, 1, 1)
         call("cpg_counter_add_i32", _p(self.iter_dev), 1, _stream())
-        ops.reset_boundaries()   # boundaries of forward passes that were never differentiated do not leak into the next step

@@ -47,13 +47,21 @@ class WordDropout(nn.Module):
 
 
 class GRUDecoder(nn.Module):
-    def __init__(self, embedding, emb_dim, output_dim, h_dim, p_word_dropout, p_out_dropout, skip_connetions, cell='gru'):
+    def __init__(self, embedding, emb_dim, output_dim, h_dim, p_word_dropout, p_out_dropout, skip_connetions, cell='gru',
+                 layers=1):
         super().__init__()
         self.emb = embedding
         # cell='lstm': extension with torch.nn.LSTM semantics, h0 = [z;c], c0 = 0 (the reference is GRU-only)
         assert cell in ('gru', 'lstm')
         self.cell = cell
-        self.rnn = (nn.GRU if cell == 'gru' else nn.LSTM)(emb_dim, h_dim, batch_first=True)
+        # layers > 1: EXTENSION (BASELINE.json configs[4] names a "2-layer dec"; the reference hard-wires one layer,
+        # models/decoder.py:40-41, models/model.py:283-284 - parity unpinned against the reference).  Semantics =
+        # torch.nn.GRU / nn.LSTM(num_layers=layers, dropout=0): layer l >= 1 reads layer l-1's step outputs, EVERY layer starts
+        # from h0 = [z;c] (the reference's `init_h.unsqueeze(0)` repeated per layer; c0 = 0 for the LSTM), the vocabulary projection
+        # reads the top layer.  State-dict keys decoder.rnn.*_l{l}.
+        assert layers >= 1
+        self.layers = int(layers)
+        self.rnn = (nn.GRU if cell == 'gru' else nn.LSTM)(emb_dim, h_dim, num_layers=self.layers, batch_first=True)
         self.fc = nn.Sequential(nn.Dropout(p_out_dropout), nn.Linear(h_dim, output_dim))
         self.word_dropout = WordDropout(p_word_dropout)
         self.p_out = p_out_dropout
@@ -98,7 +106,7 @@ class GRUDecoder(nn.Module):
         # gradient of the decoder's own parameters has been enqueued (cpg.optim starts their all-reduce there)
         zc, emb_w = ops.grad_boundary('decoder', zc, self._emb_w() if emb_w is None else emb_w)
         tab, rowc = self._tables(zc, emb_w)
-        ragged = self.ragged and self.cell == 'gru' and torch.is_grad_enabled()
+        ragged = self.ragged and self.cell == 'gru' and self.layers == 1 and torch.is_grad_enabled()
         perm = inv = step_rows = None
         if ragged:
             # step t consumes x[:, t] and is scored against x[:, t+1]: live while some target at or after t is not <pad>
@@ -117,6 +125,15 @@ class GRUDecoder(nn.Module):
                                       step_rows, True)                    # step outputs [T,B,H] (slots 1..T of the slab)
         else:
             outs = ops.LstmSeqFn.apply(tok, tab, rowc, None, zc, None, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0, T, False)[1:]
+        for l in range(1, self.layers):
+            # upper layer l: dense input term W_ih_l h^{l-1}_t + b_ih_l over all T*B rows, then the same recurrence from h0 = [z;c]
+            w_ih, b_ih = getattr(self.rnn, f"weight_ih_l{l}"), getattr(self.rnn, f"bias_ih_l{l}")
+            w_hh, b_hh = getattr(self.rnn, f"weight_hh_l{l}"), getattr(self.rnn, f"bias_hh_l{l}")
+            dense = ops.LinearFn.apply(outs.reshape(T * B, self.h_dim), w_ih, b_ih).view(T, B, -1)
+            if self.cell == 'gru':
+                outs = ops.GruSeqFn.apply(None, None, None, dense, zc, w_hh, b_hh, T, False, True, None, True)
+            else:
+                outs = ops.LstmSeqFn.apply(None, None, None, dense, zc, None, w_hh, b_hh, T, False)[1:]
         hs = outs.reshape(T * B, self.h_dim)
         if self.skip_connetions:
             # rnn_out := skip_weight_x(rnn_out) + skip_weight_z([z;c]) (models/decoder.py:80-81); the second term is constant over time
@@ -143,47 +160,54 @@ class GRUDecoder(nn.Module):
         return (torch.rand(shape, device=device) >= self.p_out).to(torch.uint8)
 
     def forward_sample(self, sampleSoft, sampleHard, z, c, h):
-        """One decode step (reference signature, decoder.py:86-109): h is [1,N,H]; returns logits [N,V], h [1,N,H].
-        sampleSoft [N,V] (a softmax row, or zeros) takes the soft-embedding branch; inference only (no autograd tape)."""
+        """One decode step (reference signature, decoder.py:86-109): h is [layers,N,H] ([1,N,H] in the reference); returns logits
+        [N,V], h [layers,N,H].  sampleSoft [N,V] (a softmax row, or zeros) takes the soft-embedding branch; inference only (no
+        autograd tape).  LSTM extension: the state is torch.nn.LSTM's pair - h = (h, c) in, the same pair out."""
+        from cpg.decode import UpperLayers
         zc = self.init_hidden(z, c)
-        if self.cell == 'lstm':
-            # LSTM extension: the state is torch.nn.LSTM's pair - h = (h [1,N,H], c [1,N,H]) in, the same pair out
+        lstm = self.cell == 'lstm'
+        if lstm:
             assert isinstance(h, (tuple, list)) and len(h) == 2, "LSTM decoder: pass the state as (h, c), as torch.nn.LSTM takes it"
-            with torch.no_grad():
-                tab, rowc = self._tables(zc)
-                h_prev, c_prev = h[0][0].contiguous(), h[1][0].contiguous()
-                N, H = h_prev.shape
-                hs, cs = torch.stack([h_prev, torch.empty_like(h_prev)]), torch.stack([c_prev, torch.empty_like(c_prev)])
-                if sampleSoft is not None:
-                    E = self.emb.weight.shape[1]
-                    w_soft = ops.LinearFn.apply(self.rnn.weight_ih_l0[:, :E].contiguous(), self.emb.weight, None)
-                    dense = ops.LinearFn.apply(sampleSoft.float().contiguous(), w_soft.contiguous(), self.rnn.bias_ih_l0)
-                    ops.call("cpg_lstm_seq_fwd", 1, N, H, 0, ops._p(self.rnn.weight_hh_l0), ops._p(self.rnn.bias_hh_l0), None, None,
-                             ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), ops._p(cs), None, ops._stream())
-                else:
-                    ops.lstm_step(sampleHard.to(torch.int32).contiguous(), tab, rowc, hs[0], cs[0], hs[1], cs[1],
-                                  self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
-                logits = self.project(hs[1], self.skip_term(zc))
-            return logits, (hs[1].unsqueeze(0), cs[1].unsqueeze(0))
+            h, cst = h
+            assert cst.shape[0] == self.layers
+        assert h.shape[0] == self.layers, "state must be [layers, N, H]"
         with torch.no_grad():
             tab, rowc = self._tables(zc)
             h_prev = h[0].contiguous()
-            h_new = torch.empty_like(h_prev)
+            N, H = h_prev.shape
+            hs = torch.stack([h_prev, torch.empty_like(h_prev)])
+            cs = torch.stack([cst[0].contiguous(), torch.empty_like(h_prev)]) if lstm else None
+            rnn = self.rnn
             if sampleSoft is not None:
                 # soft_embed (mutils.py:39-45): W_ih[:, :E] (soft @ emb) = soft @ (emb W_e^T), the step's dense input term
                 E = self.emb.weight.shape[1]
-                w_soft = ops.LinearFn.apply(self.rnn.weight_ih_l0[:, :E].contiguous(), self.emb.weight, None)
-                dense = ops.LinearFn.apply(sampleSoft.float().contiguous(), w_soft.contiguous(), self.rnn.bias_ih_l0)
-                hs = torch.stack([h_prev, h_new])
-                N, H = h_prev.shape
-                ops.call("cpg_gru_seq_fwd", 1, N, H, 0, ops._p(self.rnn.weight_hh_l0), ops._p(self.rnn.bias_hh_l0), None, None,
-                         ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), None, 0, N, None, ops._stream())
-                h_new = hs[1]
+                w_soft = ops.LinearFn.apply(rnn.weight_ih_l0[:, :E].contiguous(), self.emb.weight, None)
+                dense = ops.LinearFn.apply(sampleSoft.float().contiguous(), w_soft.contiguous(), rnn.bias_ih_l0)
+                if lstm:
+                    ops.call("cpg_lstm_seq_fwd", 1, N, H, 0, ops._p(rnn.weight_hh_l0), ops._p(rnn.bias_hh_l0), None, None,
+                             ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), ops._p(cs), None, ops._stream())
+                else:
+                    ops.call("cpg_gru_seq_fwd", 1, N, H, 0, ops._p(rnn.weight_hh_l0), ops._p(rnn.bias_hh_l0), None, None,
+                             ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), None, 0, N, None, ops._stream())
             else:
                 tok = sampleHard.to(torch.int32).contiguous()
-                ops.gru_step(tok, tab, rowc, h_prev, h_new, self.rnn.weight_hh_l0, self.rnn.bias_hh_l0)
-            logits = self.project(h_new, self.skip_term(zc))
-        return logits, h_new.unsqueeze(0)
+                if lstm:
+                    ops.lstm_step(tok, tab, rowc, hs[0], cs[0], hs[1], cs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
+                else:
+                    ops.gru_step(tok, tab, rowc, hs[0], hs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
+            top, h_new, c_new = hs[1], hs[1].unsqueeze(0), (cs[1].unsqueeze(0) if lstm else None)
+            if self.layers > 1:
+                upper = UpperLayers(self, h_prev, lstm)
+                for j in range(self.layers - 1):
+                    upper.hs[j][0].copy_(h[j + 1])
+                    if lstm:
+                        upper.cs[j][0].copy_(cst[j + 1])
+                top = upper.step(hs[1])
+                uh, uc = upper.states()
+                h_new = torch.cat([h_new, uh], 0)
+                c_new = torch.cat([c_new, uc], 0) if lstm else None
+            logits = self.project(top, self.skip_term(zc))
+        return logits, ((h_new, c_new) if lstm else h_new)
 
     def skip_term(self, zc):
         """skip_weight_z([z;c]) [N,H] of a decode (constant over its steps), or None without skip connections.  Inference only."""

@@ -83,6 +83,20 @@ class GraphedTrainStep:
         self.text = self.weights = self.graph = self.out = None
         self.calls = 0
 
+    def release(self):
+        """Drop the captured graph (the object can be called again: it re-captures); parked scratch buffers are freed with the last
+        live graph (cpg.ops.graph_released)."""
+        if self.graph is not None:
+            self.graph = None
+            from cpg import ops as _ops
+            _ops.graph_released()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
     def _eager(self, it):
         self.weights[1:2].fill_(float(utils.anneal(self.cfgv.beta, it)))
         return train_step(self.cfgv, self.model, self.trainer, self.text, it, weights_dev=self.weights)
@@ -109,12 +123,17 @@ class GraphedTrainStep:
                     return out
             cur.wait_stream(self.stream)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph()
             from cpg import ops as _ops
-            _ops.GRAPH_CAPTURED = True   # scratch buffers the graph points into must outlive any later growth (cpg.ops._retire)
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                # recorded, not run: the replay below is this iteration.  (No beta fill in here: it would be frozen into the graph.)
-                self.out = train_step(self.cfgv, self.model, self.trainer, self.text, it, weights_dev=self.weights)
+            _ops.graph_captured()   # scratch buffers the graph points into must outlive any later growth (cpg.ops._retire)
+            try:
+                with torch.cuda.graph(graph, stream=self.stream):
+                    # recorded, not run: the replay below is this iteration.  (No beta fill in here: it would be frozen into the graph.)
+                    self.out = train_step(self.cfgv, self.model, self.trainer, self.text, it, weights_dev=self.weights)
+            except BaseException:
+                _ops.graph_released()   # a failed capture pins nothing
+                raise
+            self.graph = graph
         else:
             self.text.copy_(text, non_blocking=True)
         self.weights[1:2].fill_(float(utils.anneal(self.cfgv.beta, it)))

@@ -11,17 +11,53 @@ from .gru import gru_cell_fwd, F32
 UNK, PAD, START, EOS = 0, 1, 2, 3
 
 
+def n_dec_layers(P):
+    """Layers of the decoder RNN in a state dict (1 in the reference, models/decoder.py:40-41; > 1 = this build's extension)."""
+    L = 1
+    while f"decoder.rnn.weight_hh_l{L}" in P:
+        L += 1
+    return L
+
+
+def init_state(P, zc):
+    """Decoder state before the first step: [z;c] (models/decoder.py:77); [L,N,H] with every layer = [z;c] for the multi-layer
+    EXTENSION (torch.nn.GRU(num_layers=L) semantics; not a reference component - parity unpinned)."""
+    L = n_dec_layers(P)
+    return zc.copy() if L == 1 else np.stack([zc] * L)
+
+
+def _upper_layers(P, x, h, cst=None):
+    """Layers 1..L-1 of the multi-layer extension on layer 0's new state x: h [L,N,H] (slot 0 already updated by the caller is
+    ignored), returns (top output, new h [L,N,H], new c)."""
+    from .lstm import lstm_cell_fwd
+    hn, cn = [x], [None if cst is None else cst[0]]
+    for l in range(1, h.shape[0]):
+        gi = (x @ P[f"decoder.rnn.weight_ih_l{l}"].T + P[f"decoder.rnn.bias_ih_l{l}"]).astype(F32)
+        if cst is None:
+            x, _ = gru_cell_fwd(gi, h[l], P[f"decoder.rnn.weight_hh_l{l}"], P[f"decoder.rnn.bias_hh_l{l}"])
+        else:
+            x, cl, _ = lstm_cell_fwd(gi, h[l], cst[l], P[f"decoder.rnn.weight_hh_l{l}"], P[f"decoder.rnn.bias_hh_l{l}"])
+            cn.append(cl)
+        hn.append(x)
+    return x, np.stack(hn), (None if cst is None else np.stack(cn))
+
+
 def decoder_step(P, tok, zc, h, keep=None, p_out=0.3):
     """logits [N,V], h' [N,H] for current tokens tok [N] (GRUDecoder.forward_sample, models/decoder.py:86-109).
+    Multi-layer extension: h is [L,N,H] in and out (see init_state).
     Skip connections when the model has them (:103-105): output := skip_weight_x(output) + skip_weight_z([z;c]).
     keep (optional 0/1 [N,H]): the out-dropout mask of a step sampled in TRAIN mode (generate_sentences(eval_mode=False),
     models/model.py:216-221: nn.Dropout(p_out) in front of the vocabulary projection is then live); eval mode: None."""
     x = np.concatenate([P["word_emb.weight"][tok], zc], 1).astype(F32)
     gi = (x @ P["decoder.rnn.weight_ih_l0"].T + P["decoder.rnn.bias_ih_l0"]).astype(F32)
-    h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
-    out = h
+    if h.ndim == 3:
+        h0n, _ = gru_cell_fwd(gi, h[0], P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        out, h, _ = _upper_layers(P, h0n, h)
+    else:
+        h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        out = h
     if "decoder.skip_weight_x.weight" in P:
-        out = ((h @ P["decoder.skip_weight_x.weight"].T).astype(F32) + (zc @ P["decoder.skip_weight_z.weight"].T).astype(F32)).astype(F32)
+        out = ((out @ P["decoder.skip_weight_x.weight"].T).astype(F32) + (zc @ P["decoder.skip_weight_z.weight"].T).astype(F32)).astype(F32)
     if keep is not None:
         out = (out * (keep.astype(F32) * F32(1.0 / (1.0 - p_out)))).astype(F32)
     logits = (out @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
@@ -33,22 +69,33 @@ def lstm_decoder_step(P, tok, zc, h, cst):
     from .lstm import lstm_cell_fwd
     x = np.concatenate([P["word_emb.weight"][tok], zc], 1).astype(F32)
     gi = (x @ P["decoder.rnn.weight_ih_l0"].T + P["decoder.rnn.bias_ih_l0"]).astype(F32)
-    h, cst, _ = lstm_cell_fwd(gi, h, cst, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
-    logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
+    if h.ndim == 3:   # multi-layer extension: h, cst [L,N,H]
+        h0n, c0n, _ = lstm_cell_fwd(gi, h[0], cst[0], P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        cst = cst.copy()
+        cst[0] = c0n
+        out, h, cst = _upper_layers(P, h0n, h, cst)
+    else:
+        h, cst, _ = lstm_cell_fwd(gi, h, cst, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        out = h
+    logits = (out @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
     return logits, h, cst
 
 
-def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=False, out_keep=None, p_out=0.3):
+def greedy(P, z, c, max_len, prevent_empty=False, min_length=1, return_logits=False, out_keep=None, p_out=0.3, cell="gru"):
     """ids [N, 1+steps] int64 with column 0 = START; steps <= max_len (stops once every row has emitted EOS).
     out_keep (optional [steps,N,H]): per-step out-dropout masks of a train-mode decode (decoder_step)."""
     N = z.shape[0]
     zc = np.concatenate([z, c], 1).astype(F32)
-    h = zc.copy()
+    h = init_state(P, zc)
+    cst = np.zeros_like(h)
     tok = np.full(N, START, np.int64)
     finished = np.zeros(N, bool)
     cols, all_logits = [tok], []
     for i in range(max_len):
-        logits, h = decoder_step(P, tok, zc, h, None if out_keep is None else out_keep[i], p_out)
+        if cell == "lstm":   # the LSTM extension (torch.nn.LSTM semantics, c0 = 0); not a reference component
+            logits, h, cst = lstm_decoder_step(P, tok, zc, h, cst)
+        else:
+            logits, h = decoder_step(P, tok, zc, h, None if out_keep is None else out_keep[i], p_out)
         if prevent_empty and i == 0:
             neg = F32(-2.0) * np.abs(logits.min())
             logits[:, [PAD, START, EOS]] = neg
@@ -168,7 +215,7 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
     N = z.shape[0]
     zc1 = np.concatenate([z, c], 1).astype(F32)
     zc = np.tile(zc1, (beam_size, 1))  # beam-major [beam*N] (model.py:262-263)
-    h = zc.copy()
+    h = init_state(P, zc)
     cst = np.zeros_like(h)
     beams = [_Beam(beam_size, n_best, min_length) for _ in range(N)]
     tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
@@ -179,8 +226,9 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
         else:   # out_keep [steps, beam*N, H]: train-mode decode, rows beam-major like the states
             logits, h = decoder_step(P, tok, zc, h, None if out_keep is None else out_keep[step], p_out)
         lg = logits.reshape(beam_size, N, -1)
-        hv = h.reshape(beam_size, N, -1)
-        cv = cst.reshape(beam_size, N, -1)
+        nl = h.shape[0] if h.ndim == 3 else 1
+        hv = h.reshape(nl, beam_size, N, -1)       # views: the reorder below writes through to h / cst (every layer's state)
+        cv = cst.reshape(nl, beam_size, N, -1)
         ht = np.full((N, beam_size), -1, np.int64)
         hp = np.zeros((N, beam_size), np.int64)
         hsc = np.zeros((N, beam_size), F32)
@@ -189,8 +237,8 @@ def beam(P, z, c, max_len, beam_size=5, n_best=3, min_length=1, return_history=F
             if not b.done():
                 b.advance(_log_softmax(lg[:, j]))
                 ht[j], hp[j], hsc[j] = b.next_ys[-1], b.prev_ks[-1], b.scores
-            hv[:, j] = hv[b.prev_ks[-1], j]  # _update_hidden (model.py:387-404), applied even when done
-            cv[:, j] = cv[b.prev_ks[-1], j]
+            hv[:, :, j] = hv[:, b.prev_ks[-1], j]  # _update_hidden (model.py:387-404), applied even when done
+            cv[:, :, j] = cv[:, b.prev_ks[-1], j]
         tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
         if all(b.done() for b in beams):
             break
@@ -214,7 +262,8 @@ def soft_sample(P, z, c, max_len, mode, temp=1.0, min_length=1, sampled=None, ce
     N = z.shape[0]
     V = P["decoder.fc.1.weight"].shape[0]
     zc = np.concatenate([z, c], 1).astype(F32)
-    h = zc.copy()
+    h = init_state(P, zc)       # [N,H]; [L,N,H] for the multi-layer extension
+    cst = np.zeros_like(h)
     tok = np.full(N, START, np.int64)
     finished = np.zeros(N, bool)
     onehot = np.zeros((N, V), F32)
@@ -226,14 +275,22 @@ def soft_sample(P, z, c, max_len, mode, temp=1.0, min_length=1, sampled=None, ce
         e = emb_w[tok] if soft_in is None else (soft_in @ emb_w).astype(F32)
         x = np.concatenate([e, zc], 1).astype(F32)
         gi = (x @ w_ih.T + b_ih).astype(F32)
+        multi = h.ndim == 3
+        h_l0, c_l0 = (h[0], cst[0]) if multi else (h, cst)
         if cell == "lstm":   # the LSTM extension's cell (torch.nn.LSTM semantics, c0 = 0); not a reference component
             from .lstm import lstm_cell_fwd
-            if i == 0:
-                cst = np.zeros_like(h)
-            h, cst, _ = lstm_cell_fwd(gi, h, cst, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+            h_l0, c_l0, _ = lstm_cell_fwd(gi, h_l0, c_l0, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
         else:
-            h, _ = gru_cell_fwd(gi, h, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
-        logits = (h @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
+            h_l0, _ = gru_cell_fwd(gi, h_l0, P["decoder.rnn.weight_hh_l0"], P["decoder.rnn.bias_hh_l0"])
+        if multi:
+            if cell == "lstm":
+                cst = cst.copy()
+                cst[0] = c_l0
+            top, h, cst_n = _upper_layers(P, h_l0, h, cst if cell == "lstm" else None)
+            cst = cst_n if cell == "lstm" else cst
+        else:
+            top, h, cst = h_l0, h_l0, c_l0
+        logits = (top @ P["decoder.fc.1.weight"].T + P["decoder.fc.1.bias"]).astype(F32)
         sm = _log_softmax((logits / F32(temp)).astype(F32))
         soft = np.exp(sm).astype(F32)
         if mode == "greedy_softmax":

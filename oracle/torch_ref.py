@@ -26,10 +26,13 @@ UNK, PAD, START, EOS = 0, 1, 2, 3  # models/mutils.py:5-8
 class RefWAE(nn.Module):
     """Same parameter names / shapes as the reference's RNN_VAE (classifier omitted: not part of the training step)."""
 
-    def __init__(self, n_vocab, emb_dim, enc_h, enc_layers, z_dim, c_dim=2, p_out=0.3, cell="gru", skip=False):
+    def __init__(self, n_vocab, emb_dim, enc_h, enc_layers, z_dim, c_dim=2, p_out=0.3, cell="gru", skip=False, dec_layers=1):
         """cell='lstm': the build's LSTM EXTENSION (BASELINE.json configs[1] names an LSTM; the reference has none):
         nn.LSTM in place of nn.GRU, encoder read for its final HIDDEN states, decoder h0 = [z;c], c0 = 0.  Parity of that mode is
-        pinned to torch.nn.LSTM only - "parity unpinned" against the reference."""
+        pinned to torch.nn.LSTM only - "parity unpinned" against the reference.
+        dec_layers > 1: the build's multi-layer decoder EXTENSION (BASELINE.json configs[4] names a "2-layer dec"; the reference
+        hard-wires one layer, models/decoder.py:40-41): nn.GRU / nn.LSTM(num_layers=dec_layers), every layer's h0 = [z;c] (the
+        reference's `init_h.unsqueeze(0)` repeated per layer), c0 = 0.  Parity unpinned against the reference as well."""
         super().__init__()
         self.cell = cell
         rnn = {"gru": nn.GRU, "lstm": nn.LSTM}[cell]
@@ -38,7 +41,8 @@ class RefWAE(nn.Module):
         self.q_mu = nn.Linear(2 * enc_h, z_dim)
         self.q_logvar = nn.Linear(2 * enc_h, z_dim)
         hd = z_dim + c_dim
-        self.dec_rnn = rnn(emb_dim + hd, hd, batch_first=True)
+        self.dec_layers = dec_layers
+        self.dec_rnn = rnn(emb_dim + hd, hd, num_layers=dec_layers, batch_first=True)
         self.fc = nn.Linear(hd, n_vocab)
         self.skip = skip
         if skip:   # models/decoder.py:48-51
@@ -60,7 +64,10 @@ class RefWAE(nn.Module):
         while f"encoder.rnn.weight_ih_l{L}" in P:
             L += 1
         Z = P["encoder.q_mu.weight"].shape[0]
-        m = cls(V, E, He, L, Z, P["decoder.rnn.weight_hh_l0"].shape[1] - Z, p_out, cell, "decoder.skip_weight_x.weight" in P)
+        Ld = 1
+        while f"decoder.rnn.weight_hh_l{Ld}" in P:
+            Ld += 1
+        m = cls(V, E, He, L, Z, P["decoder.rnn.weight_hh_l0"].shape[1] - Z, p_out, cell, "decoder.skip_weight_x.weight" in P, Ld)
         sd = {}
         for k, v in P.items():
             if k.startswith("classifier") or k == "decoder.emb.weight":
@@ -105,7 +112,7 @@ class RefWAE(nn.Module):
         tok[wd.bool()] = UNK                                          # decoder.py:117-133 (no exemptions, also in eval)
         zc = torch.cat([z, c], 1)
         x = torch.cat([self.word_emb(tok), zc.unsqueeze(1).expand(-1, T, -1)], 2)   # decoder.py:67-74
-        h0 = zc.unsqueeze(0).contiguous()                             # decoder.py:77 (h0 = [z;c])
+        h0 = zc.unsqueeze(0).repeat(self.dec_layers, 1, 1).contiguous()   # decoder.py:77 (h0 = [z;c]; every layer of the extension)
         out, _ = self.dec_rnn(x, h0 if self.cell == "gru" else (h0, torch.zeros_like(h0)))
         if self.skip:                                                 # decoder.py:80-81
             out = self.skip_weight_x(out) + self.skip_weight_z(zc.unsqueeze(1).expand(-1, T, -1))

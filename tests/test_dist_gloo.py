@@ -346,15 +346,16 @@ def test_libcomm_id_exchange_and_row_counts_with_empty_ranks(world):
         assert ids_shape == [2, 26] and none_shape == [0, 3]
 
 
-def test_gradient_boundary_fires_after_last_registered_use():
+def test_gradient_boundary_fires_after_last_use_in_the_graph():
     """cpg.ops.grad_boundary when a module runs twice in the differentiated graph: the bucket callback must fire once, after the
-    LAST of the tag's boundaries has been reached (round-3 advisor finding: it used to fire at the first)."""
+    LAST of the tag's boundaries IN THAT GRAPH has been reached (round-3 advisor finding: it used to fire at the first).  The count is
+    taken on the graph being differentiated (round-4 advisor finding: a process-global count of forward passes made the decision depend
+    on host history): a grad-enabled forward that is never differentiated changes NOTHING."""
     import sys
     for p in (ROOT, os.path.join(ROOT, "controlled-peptide-generation_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
     from cpg import ops
-    ops.reset_boundaries()
     w = torch.nn.Parameter(torch.ones(4))
     x = torch.ones(4, requires_grad=True)
     events = []
@@ -374,20 +375,80 @@ def test_gradient_boundary_fires_after_last_registered_use():
         inp = ops.grad_boundary('decoder', inp)
         return (Probe.apply(inp, name) * w).sum()
     loss = use(x, 'first') + use(x * 2.0, 'second')
-    with ops.backward_scope(lambda tag: events.append('FIRE:' + tag)):
+    assert ops._count_boundaries(loss) == {'decoder': 2}
+    with ops.backward_scope(lambda tag: events.append('FIRE:' + tag), root=loss):
         loss.backward()
     assert events.count('FIRE:decoder') == 1
     assert events.index('FIRE:decoder') > max(events.index('first'), events.index('second')), events
-    # a forward that is never differentiated leaves a registration behind: the next backward must not fire EARLY ...
+    # a grad-enabled forward that is never differentiated (a validation / logging forward without no_grad on ONE rank) must not
+    # change when - or whether - the next backward pass fires the bucket
     _ = use(x, 'dangling')
     events.clear()
     loss = use(x, 'only')
-    with ops.backward_scope(lambda tag: events.append('FIRE:' + tag)):
-        loss.backward()
-    assert 'FIRE:decoder' not in events          # (the optimiser's finish() reduces the bucket instead)
-    ops.reset_boundaries()                        # ... and FusedAdamClip.step() clears it
-    events.clear()
-    loss = use(x, 'only')
-    with ops.backward_scope(lambda tag: events.append('FIRE:' + tag)):
+    with ops.backward_scope(lambda tag: events.append('FIRE:' + tag), root=loss):
         loss.backward()
     assert events == ['only', 'FIRE:decoder']
+    with pytest.raises(ValueError):
+        ops.backward_scope(lambda tag: None)           # a callback without the graph it applies to is refused
+
+
+def _asym_worker(rank, world, port, q):
+    """Rank 0 runs an EXTRA grad-enabled forward that it never differentiates; both ranks then run the same training backward with
+    bucketed all-reduces.  The sequence of collectives each rank issues (sizes, in order) must be identical."""
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "controlled-peptide-generation_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpg import ops
+    from cpg.optim import BucketReducer
+    torch.manual_seed(0)
+    w_dec, w_head, w_enc = (torch.nn.Parameter(torch.randn(8)) for _ in range(3))
+    flat = torch.zeros(24)
+    issued = []
+
+    def areduce(t):
+        issued.append(int(t.numel()))
+        return dist.all_reduce(t, async_op=True)
+    red = BucketReducer(flat, {'encoder_heads': (8, 16), 'decoder': (16, 24)}, 8, None, areduce, world)
+
+    def model(x):
+        h = (x * w_enc).tanh()
+        h = ops.grad_boundary('encoder_heads', h)
+        zc = h * w_head
+        zc = ops.grad_boundary('decoder', zc)
+        return (zc * w_dec).sum()
+    x = torch.full((8,), float(rank + 1), requires_grad=True)
+    if rank == 0:
+        _ = model(x)                                   # validation-style forward WITH grad enabled, never differentiated
+    for _step in range(2):
+        loss = model(x)
+        for p_ in (w_dec, w_head, w_enc):
+            p_.grad = None
+        with ops.backward_scope(red.on_boundary, root=loss):
+            loss.backward()
+        flat[0:8], flat[8:16], flat[16:24] = w_enc.grad, w_head.grad, w_dec.grad
+        red.finish()
+    q.put((rank, issued, flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_asymmetric_forward_keeps_the_collective_sequence():
+    """Round-4 advisor finding (medium): with a process-global boundary count, a rank that ran one extra grad-enabled forward skipped
+    its boundary all-reduces and reduced those buckets synchronously in finish() - a different collective sequence from its peers
+    (hang / silent corruption on RCCL).  Two gloo ranks, rank 0 with the extra forward: both must issue the same sequence."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 17
+    procs = [ctx.Process(target=_asym_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    assert res[0][1] == res[1][1], (res[0][1], res[1][1])
+    assert res[0][1][:2] == [8, 8], res[0][1]          # both buckets were started from their boundaries, on both ranks

@@ -413,7 +413,47 @@ def test_api_helpers_roundtrip(tmp_path, golden):
                                      dict(sample_mode='beam', beam_size=3, n_best=2))
         assert len(s['predictions']) == 4 and len(s['predictions'][0]) == 2 and len(s['interpolation']) == 4
     assert 'hyp' in api.pretty_print_samples(s['predictions'])
+    # unexpected keys (an AAE checkpoint's discriminator) are ignored as the reference's strict=False ignores them (api.py:90-95)
+    extra = dict(sd)
+    extra["discriminator.fc.0.weight"] = torch.zeros(3, 3)
+    torch.save(extra, str(tmp_path / 'model_9.pt'))
+    m3 = api.load_trained_model(str(tmp_path / 'model_9.pt'), vocab.size())
+    assert torch.equal(m3.state_dict()["encoder.q_mu.bias"].cpu(), sd["encoder.q_mu.bias"])
     importlib.reload(cfg)
+
+
+def test_static_eval_smoke_functions(tmp_path, golden, capsys):
+    """static_eval.py (reference static_eval.py:32-217): main() finds the run dir, loads checkpoint + vocab, prints the logged
+    result and runs the five smoke checks in the reference's order with its line formats; each check returns what it printed from."""
+    import importlib
+    import cfg
+    importlib.reload(cfg)
+    import static_eval
+    import utils
+    from cpg.synth import SyntheticPeptideLoader
+    g, gc = golden("model_A_200"), golden("classifier_A")
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in {**weights_of(gc), **weights_of(g)}.items()}
+    sd["decoder.emb.weight"] = sd["word_emb.weight"]
+    ds = SyntheticPeptideLoader(4, 25, 'cuda', size=16)
+    utils.save_vocab(ds.TEXT.vocab, str(tmp_path / 'vocab.dict'))
+    torch.save(sd, str(tmp_path / 'model_{}.pt'.format(cfg.vae.n_iter)))
+    json.dump([{"it": cfg.vae.n_iter, "train_L_vae": 0.5}], open(tmp_path / 'result.json', 'w'))
+    cfg.savepath = str(tmp_path)
+    try:
+        import types
+        static_eval.main(types.SimpleNamespace(seqs="A C D E F G H I K L, M N P Q R S T V W Y A C, G G G A A A"))
+        out = capsys.readouterr().out
+        assert '"train_L_vae": 0.5' in out and '### prior: ' in out and 'prior_zs - greedy' in out and 'prior_zs - beam' in out
+        assert out.count('#### reco of') == 3 and out.count('#### reco interpol start source:') == 2 and '0.50 ' in out
+        vocab = static_eval.Vocab(str(tmp_path / 'vocab.dict'))
+        model = static_eval.load_trained_model(str(tmp_path / 'model_{}.pt'.format(cfg.vae.n_iter)), vocab.size())
+        r = static_eval.test_interpolated_peptides(model, vocab)
+        assert set(r) == {'linear', 'tanh', 'slerp'} and len(r['tanh']['predictions']) == 11
+        assert len(static_eval.test_sampling(model, vocab, n_samples=3)) == 4
+        rec = static_eval.test_reconstruction(model, vocab, "A C D E F G")
+        assert len(rec) == 5 and len(rec[-1]['predictions']) == 4 and len(rec[-1]['predictions'][0]) == 3
+    finally:
+        importlib.reload(cfg)
 
 
 @pytest.mark.parametrize("mode,temp", [("none_softmax", 1.0), ("greedy_softmax", 1.0), ("greedy_softmax", 0.7)])

@@ -236,7 +236,9 @@ def _check_greedy_vs_oracle(m, P, N, T, seed, f64=False, tag=""):
         ties += 1
     TIE_REPORT.append(dict(test=tag or "greedy", rows=int(N), T=int(T), ties=int(ties), ill_conditioned_rows=int((~keep).sum())))
     _write_report("greedy_tie_report.json", TIE_REPORT)
-    assert ties <= max(1, N // 256), ties
+    # fixed seeds: every report of rounds 3-4 shows ZERO tie rows (profiles/r0[34]_greedy_tie_report.json), so the fixed-seed cases are
+    # strict - "bit-exact" with no allowance (round-4 verdict); the margin analysis above stays as the diagnostic of a failure
+    assert ties == 0, ties
     assert (~keep).sum() <= N // 4, "the float32 restatement itself departs from float64 on more than a quarter of the rows"
     if ties == 0:
         assert np.array_equal(got[keep][:, :w], ref[keep][:, :w])
@@ -339,7 +341,7 @@ def _check_beam_vs_oracle(m, P, N, T, seed, eos_bias, tag, K=5, n_best=3):
                             sentences_differing_at_a_float32_tie=len(bad), smallest_margin=float(margins.min())))
     _write_report("beam_tie_report.json", BEAM_REPORT)
     assert min(lens) < max(lens), "the biased decoder should end hypotheses at different lengths"
-    assert len(bad) <= max(1, N // 32), bad
+    assert not bad, bad     # fixed seeds: exact, no tie allowance (profiles/r04_beam_tie_report.json: zero differing sentences)
 
 
 def test_beam_per_step_chain_vs_oracle_config_b_width():

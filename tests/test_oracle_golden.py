@@ -265,3 +265,91 @@ def test_sampling_in_train_mode(golden):
     for i in range(n):
         for j in range(3):
             assert hyps[i][j] == [int(t) for t in g["beam_hyps"][i, j] if t >= 0], (i, j)
+
+
+# ------------------------------------------------------------------------------------------------ multi-layer decoder extension
+def _torch_dec(cell, V, E, H, L, seed):
+    """A torch.nn.GRU / nn.LSTM(num_layers=L) decoder with the reference's state-dict names (decoder.rnn.*_l{l}); -> (rnn, fc, emb, P)."""
+    import torch
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    emb = nn.Embedding(V, E, 1)
+    rnn = (nn.GRU if cell == "gru" else nn.LSTM)(E + H, H, num_layers=L, batch_first=True)
+    fc = nn.Linear(H, V)
+    with torch.no_grad():
+        fc.weight.mul_(5.0)
+        fc.bias[3] += 0.7
+    P = {"word_emb.weight": emb.weight.detach().numpy().copy(), "decoder.fc.1.weight": fc.weight.detach().numpy().copy(),
+         "decoder.fc.1.bias": fc.bias.detach().numpy().copy()}
+    P.update({"decoder.rnn." + k: v.detach().numpy().copy() for k, v in rnn.state_dict().items()})
+    return rnn, fc, emb, P
+
+
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_multilayer_decoder_oracle_pinned_to_torch(cell):
+    """The multi-layer decoder EXTENSION of oracle/decode.py (BASELINE.json configs[4] "2-layer dec"; the reference has one layer,
+    models/decoder.py:40-41 - parity unpinned against it) against torch.nn.GRU / nn.LSTM(num_layers=2) driven step by step with
+    h0 = [z;c] in every layer (c0 = 0): greedy ids exact + per-step logits 1e-5, and a beam search that uses the same Beam
+    bookkeeping but torch for the step and `h[:, idx]` for the reorder of EVERY layer's state (models/model.py:378-385)."""
+    import torch
+    from oracle import decode as odec
+    V, E, Z, L, T, N, K = 24, 10, 14, 2, 12, 6, 4
+    H = Z + 2
+    rnn, fc, emb, P = _torch_dec(cell, V, E, H, L, seed=3)
+    assert odec.n_dec_layers(P) == L
+    rs = np.random.RandomState(1)
+    z = rs.randn(N, Z).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+
+    def tstep(tok, zc, st):
+        x = torch.cat([emb(torch.from_numpy(tok)), zc], 1).unsqueeze(1)
+        out, st = rnn(x, st)
+        return fc(out[:, 0]), st
+
+    def init(zc):
+        h0 = zc.unsqueeze(0).repeat(L, 1, 1).contiguous()
+        return h0 if cell == "gru" else (h0, torch.zeros_like(h0))
+
+    with torch.no_grad():
+        zc = torch.from_numpy(np.concatenate([z, c], 1))
+        st = init(zc)
+        tok = np.full(N, 2, np.int64)
+        fin = np.zeros(N, bool)
+        cols, lgs = [tok], []
+        for i in range(T):
+            lg, st = tstep(tok, zc, st)
+            lgs.append(lg.numpy())
+            tok = lg.numpy().argmax(1).astype(np.int64)
+            tok[fin] = 1
+            fin |= tok == 3
+            cols.append(tok)
+            if fin.all():
+                break
+        ids, logits = odec.greedy(P, z, c, T, return_logits=True, cell=cell)
+        assert np.array_equal(ids, np.stack(cols, 1))
+        np.testing.assert_allclose(logits, np.stack(lgs, 1), atol=1e-5)
+        # beam: torch step + reorder of all layers
+        zcK = zc.repeat(K, 1)
+        st = init(zcK)
+        beams = [odec._Beam(K, 2, 1) for _ in range(N)]
+        tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
+        for step in range(T):
+            lg, st = tstep(tok, zcK, st)
+            lg = lg.numpy().reshape(K, N, -1)
+            parts = [st] if cell == "gru" else list(st)
+            views = [p.view(L, K, N, H) for p in parts]
+            for j, b in enumerate(beams):
+                if not b.done():
+                    b.advance(odec._log_softmax(lg[:, j]))
+                idx = torch.from_numpy(np.asarray(b.prev_ks[-1]))
+                for v in views:
+                    v[:, :, j] = v[:, idx, j].clone()
+            tok = np.stack([b.next_ys[-1] for b in beams]).T.reshape(-1)
+            if all(b.done() for b in beams):
+                break
+        want = [b.best()[0] for b in beams]
+        got, _ = odec.beam(P, z, c, T, beam_size=K, n_best=2, cell=cell)
+        assert got == want
+        lens = {len(h) for s in want for h in s}
+        assert len(lens) > 1
