@@ -177,9 +177,9 @@ CPG_EXPORT int cpg_categorical_select(const float* logits, int N, int V, float t
 // reads its K logits rows as contiguous 96-byte runs).  Rows are beam-major (row = k*N + i).
 // Restates Beam.advance: BOS column := -1e20; first step uses beam 0 only; children of EOS-ended beams := -1e20;
 // top-K over the flat K*V candidates (ties: lower flat index first); done when top beam is EOS and >= n_best finished.
-#define CPG_MAX_BEAM 8
+#define CPG_MAX_BEAM 32   // widest beam any instantiation holds (KMAX = 8 for the usual widths, 32 above: static_eval.py's beam 15)
 #define CPG_BEAM_VREG 32   // vocabularies up to this size are held in registers
-template <bool VREG>
+template <bool VREG, int KMAX>
 __global__ void beam_select_kernel(const float* __restrict__ logits, int N, int V, int K, int step, int n_best, int min_length,
                                    int bos, int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,
                                    int32_t* hist_tok, int32_t* hist_prev, float* hist_score, int32_t* origin,
@@ -190,10 +190,10 @@ __global__ void beam_select_kernel(const float* __restrict__ logits, int N, int 
         if (done[i]) {  // not advanced: keeps its last tokens; reference re-applies the last origin (irrelevant once done)
             for (int k = 0; k < K; ++k) tok_next[(size_t)k * N + i] = last_tok[(size_t)i * K + k];
         } else {
-            float bs[CPG_MAX_BEAM];
-            int bc[CPG_MAX_BEAM];
+            float bs[KMAX];
+            int bc[KMAX];
 #pragma unroll
-            for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+            for (int p = 0; p < KMAX; ++p) {
                 bs[p] = -INFINITY;
                 bc[p] = 0;
             }
@@ -240,7 +240,7 @@ __global__ void beam_select_kernel(const float* __restrict__ logits, int N, int 
                     int cc = k * V + v;
                     bool carried = false;
 #pragma unroll
-                    for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+                    for (int p = 0; p < KMAX; ++p) {
                         if (p >= K) break;
                         if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
                             const float fs = bs[p];
@@ -253,7 +253,7 @@ __global__ void beam_select_kernel(const float* __restrict__ logits, int N, int 
                         }
                     }
 #pragma unroll
-                    for (int p = 0; p < CPG_MAX_BEAM; ++p)
+                    for (int p = 0; p < KMAX; ++p)
                         if (p == K - 1) worst = bs[p];
                 };
                 if (VREG) {
@@ -267,7 +267,7 @@ __global__ void beam_select_kernel(const float* __restrict__ logits, int N, int 
             int nf = n_finished[i];
             int top = 0;
 #pragma unroll
-            for (int k = 0; k < CPG_MAX_BEAM; ++k) {
+            for (int k = 0; k < KMAX; ++k) {
                 if (k >= K) break;
                 const int pk = bc[k] / V, tk = bc[k] - pk * V;
                 if (k == 0) top = tk;
@@ -307,14 +307,18 @@ CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int ste
     CPG_CHECK_ARG(logits && scores && last_tok && n_finished && done && hist_tok && hist_prev && hist_score && origin);
     CPG_CHECK_ARG(N > 0 && V > 0 && K > 0 && K <= CPG_MAX_BEAM && h_in && h_out && h_in != h_out && tok_next && n_active);
     hipStream_t s = (hipStream_t)stream;
-    if (V <= CPG_BEAM_VREG && V % 4 == 0)
-        hipLaunchKernelGGL(beam_select_kernel<true>, dim3(cdiv(N, 64)), dim3(64), 0, s, logits, N, V, K, step, n_best, min_length,
-                           bos, eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,
-                           n_active + step);
-    else
-        hipLaunchKernelGGL(beam_select_kernel<false>, dim3(cdiv(N, 64)), dim3(64), 0, s, logits, N, V, K, step, n_best, min_length,
-                           bos, eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,
-                           n_active + step);
+    CPG_CHECK_ARG(K <= V);   // the first step ranks the V children of beam 0 only (topk(size) over V candidates, models/Beam.py:82-84)
+#define CPG_BEAM_LAUNCH(VR, KM)                                                                                                      \
+    hipLaunchKernelGGL((beam_select_kernel<VR, KM>), dim3(cdiv(N, 64)), dim3(64), 0, s, logits, N, V, K, step, n_best, min_length,   \
+                       bos, eos, scores, last_tok, n_finished, done, hist_tok, hist_prev, hist_score, origin, tok_next,              \
+                       n_active + step)
+    const bool vreg = V <= CPG_BEAM_VREG && V % 4 == 0;
+    if (K <= 8) {
+        if (vreg) CPG_BEAM_LAUNCH(true, 8); else CPG_BEAM_LAUNCH(false, 8);
+    } else {
+        if (vreg) CPG_BEAM_LAUNCH(true, CPG_MAX_BEAM); else CPG_BEAM_LAUNCH(false, CPG_MAX_BEAM);
+    }
+#undef CPG_BEAM_LAUNCH
     CPG_LAUNCH_CHECK();
     const size_t n = (size_t)K * N * H;
     hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h_in, h_out, origin, N, K, H);
@@ -337,15 +341,16 @@ CPG_EXPORT int cpg_beam_reorder(const float* h_in, float* h_out, const int32_t* 
 // (token, back-pointer, score) history [T,N,K].  Finished entries are ranked in insertion order (step asc, beam asc) by
 // raw summed log-prob, ties keep the earlier entry (python's stable sort); when fewer than n_best finished the live beam's
 // first (n_best - n_finished) entries of the last advanced step are appended.  hyps[i][b] = <start> + tokens, -1 padded.
+template <int KMAX>
 __global__ void beam_hyp_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ prev,
                                 const float* __restrict__ score, int T, int N, int K, int n_best, int eos, int start,
                                 int32_t* __restrict__ hyps, int32_t* __restrict__ lens, float* __restrict__ out_sc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    float bs[CPG_MAX_BEAM];
-    int bt[CPG_MAX_BEAM], bk[CPG_MAX_BEAM];
+    float bs[KMAX];
+    int bt[KMAX], bk[KMAX];
 #pragma unroll
-    for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+    for (int p = 0; p < KMAX; ++p) {
         bs[p] = -INFINITY;
         bt[p] = 0;
         bk[p] = 0;
@@ -353,7 +358,7 @@ __global__ void beam_hyp_kernel(const int32_t* __restrict__ tok, const int32_t* 
     auto insert = [&](float cs, int ct, int ck) {
         bool carried = false;  // a displaced entry is older than everything below it: it wins ties on the way down
 #pragma unroll
-        for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+        for (int p = 0; p < KMAX; ++p) {
             if (p >= n_best) break;
             if (carried ? (cs >= bs[p]) : (cs > bs[p])) {
                 const float fs = bs[p];
@@ -383,7 +388,7 @@ __global__ void beam_hyp_kernel(const int32_t* __restrict__ tok, const int32_t* 
     for (int j = 0; j < need; ++j) insert(score[((size_t)last * N + i) * K + j], Ti, j);
     const int L = T + 1;
 #pragma unroll
-    for (int p = 0; p < CPG_MAX_BEAM; ++p) {
+    for (int p = 0; p < KMAX; ++p) {
         if (p >= n_best) break;
         int32_t* h = hyps + ((size_t)i * n_best + p) * L;
         const int tl = bt[p];
@@ -408,8 +413,12 @@ CPG_EXPORT int cpg_beam_hypotheses(const int32_t* hist_tok, const int32_t* hist_
                                    void* stream) {
     CPG_CHECK_ARG(hist_tok && hist_prev && hist_score && hyps && lens && scores);
     CPG_CHECK_ARG(T > 0 && N > 0 && K > 0 && K <= CPG_MAX_BEAM && n_best > 0 && n_best <= K);
-    hipLaunchKernelGGL(beam_hyp_kernel, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, hist_tok, hist_prev, hist_score,
-                       T, N, K, n_best, eos, start, hyps, lens, scores);
+    if (n_best <= 8)
+        hipLaunchKernelGGL(beam_hyp_kernel<8>, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, hist_tok, hist_prev, hist_score,
+                           T, N, K, n_best, eos, start, hyps, lens, scores);
+    else
+        hipLaunchKernelGGL(beam_hyp_kernel<CPG_MAX_BEAM>, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, hist_tok, hist_prev,
+                           hist_score, T, N, K, n_best, eos, start, hyps, lens, scores);
     CPG_LAUNCH_CHECK();
     return 0;
 }

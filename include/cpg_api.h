@@ -298,7 +298,8 @@ CPG_API int cpg_decode_beam_fused(const float* h0, const float* rowc, const floa
                                   const float* b_hh, const float* fc_w, const float* fc_b, int N, int H, int V, int T, int K,
                                   int n_best, int min_length, int bos, int eos, int32_t* hist_tok, int32_t* hist_prev,
                                   float* hist_score, void* stream);
-/* beam: one Beam.advance for every sentence (rows beam-major: row = k*N + i) + hidden-state reorder.
+/* beam: one Beam.advance for every sentence (rows beam-major: row = k*N + i) + hidden-state reorder.  K <= 32 and K <= V
+ * (the first step ranks the V children of beam 0 only, models/Beam.py:82-84); the reference's static_eval.py:130 uses K = 15.
  * scores/last_tok/origin [N,K]; n_finished, done [N]; hist_* [T,N,K]; n_active[step] += sentences not yet done. */
 CPG_API int cpg_beam_select(const float* logits, int N, int V, int K, int step, int n_best, int min_length, int bos,
                             int eos, float* scores, int32_t* last_tok, int32_t* n_finished, uint8_t* done,

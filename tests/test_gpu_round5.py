@@ -290,6 +290,34 @@ def test_beam_long_hypotheses_per_step_chain(Z, T, tag):
     assert len(set(all_lens)) >= 8, sorted(set(all_lens))
 
 
+@pytest.mark.parametrize("K,n_best", [(15, 3), (9, 9), (24, 5)])
+def test_beam_wider_than_eight_vs_oracle(golden, K, n_best):
+    """Beam widths above 8 (the reference's static_eval.py:130,152 decodes with beam_size = 15): the per-step chain's
+    beam_select_kernel<., 32> / beam_hyp_kernel<32> against oracle.decode.beam on the golden model trained for 200 reference
+    iterations - hypotheses exact, scores 1e-4."""
+    from oracle import decode as odec
+    g = golden("model_A_200")
+    P = weights_of(g)
+    m = build_model(P)
+    m.eval()
+    rs = np.random.RandomState(K)
+    N = 24
+    z = rs.randn(N, g["greedy_z"].shape[1]).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+    ref, ref_sc, margins = odec.beam(P, z, c, 25, beam_size=K, n_best=n_best, return_margins=True)
+    got, _, _ = m.generate_sentences(N, cu(z), cu(c), sample_mode='beam', beam_size=K, n_best=n_best)
+    bad = [i for i in range(N) if [list(map(int, h)) for h in got[i]] != ref[i]]
+    assert all(margins[i] < 2e-5 for i in bad) and len(bad) <= 1, (bad, [margins[i] for i in bad])
+    from cpg import decode as cdecode
+    m.eval()      # generate_sentences returned the model to TRAIN mode (models/model.py:221-222; SURVEY F8): out-dropout would be live
+    _, _, sc = cdecode.decode_beam_arrays(m.decoder, cu(z), cu(c), 25, K, n_best)
+    ok = [i for i in range(N) if i not in bad]
+    np.testing.assert_allclose(sc[ok], np.asarray(ref_sc, np.float32)[ok], atol=1e-4)
+    with pytest.raises(Exception):
+        m.generate_sentences(N, cu(z), cu(c), sample_mode='beam', beam_size=33, n_best=3)
+
+
 # ------------------------------------------------------------------------------------------------ CLaSS at 10^6 rows
 def _clf(coef, icpt):
     from sklearn.linear_model import LogisticRegression
