@@ -229,6 +229,17 @@ def _deferred_split(Mr, N, Kd, pairs=0):
         return {"tn_split": int(DEFER_SPLIT)}
     s = int(query("cpg_gemm_tn_split", int(Mr), int(N), int(Kd), int(pairs)))
     return {"tn_split": max(1, (4 * s) // 5)} if s >= 5 else {}
+def _deferred_split_ap(R, M, N):
+    """The same for the all-T planes product (cpg_gru_wgrad_hh_ap: 128 x 128 tiles, two 68 KB workgroups per CU, split over the rows so
+    that one round covers the chip): four fifths of its split for the launch that runs under the main stream's launches."""
+    if DEFER_SPLIT == '0':
+        return {}
+    if DEFER_SPLIT:
+        return {"tn_split": int(DEFER_SPLIT)}
+    s = int(query("cpg_pair_tn_split", int(M), int(N), int(R)))
+    return {"tn_split": max(1, (4 * s) // 5)} if s >= 5 else {}
+
+
 DEFER_ENC_WGRAD = _os.environ.get('CPG_DEFER_ENC_WGRAD', '1') != '0'   # the encoder's reverse-direction dW_hh beside the forward one (GruBiSeqFn)
 DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... and so does the [z;c] block of its W_ih gradient (LinearColsFn)
 BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
@@ -671,6 +682,16 @@ def _pair_scratch(B, H, ndir, dev, lstm=False):
     return t if ndir == 2 else t[0]
 
 
+def _ap_scratch(T, B, H, ndir, dev):
+    """Scratch of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes: kept gate-gradient planes of every step, their
+    exponent tables, the state planes): [ndir, bytes] uint8, or None where the form does not cover the shape / compute mode."""
+    nb = int(query("cpg_gru_ap_bytes", int(T), int(B), int(H), int(ndir)))
+    if nb == 0:
+        return None
+    t = torch.empty(ndir, (nb + 255) // 256 * 256, device=dev, dtype=torch.uint8)
+    return t if ndir == 2 else t[0]
+
+
 def gates_dtype(B, H, ragged=False):
     """Element type of a GRU sequence's saved gates [T,4,B,H]: bf16 in the bf16 compute mode on dense batches that the
     direct-to-LDS backward step covers (cpg_gru_gates_bf16: the BPTT epilogue is HBM-bound there), f32 otherwise."""
@@ -778,15 +799,26 @@ class GruSeqFn(Function):
         # bf16 gradient storage (bf16 compute mode): decided HERE, together with the saved gates' type, and handed to every consumer
         dgt = dg_dtype(B, H, ctx.V if has_tab else 0, step_rows is not None) if (gates is not None and gates.dtype == torch.bfloat16) else torch.float32
         dgb = int(dgt == torch.bfloat16)
-        dG = (torch.zeros if step_rows is not None else torch.empty)(T, B, 4 * H, device=dev, dtype=dgt)
+        # all-T planes form (cpg_gru_ap_bytes): sequences with a token table and no dense input term (their input-side gradients are
+        # consumed by the plane-reading reductions only); the recurrent dG blocks then exist only as the kept f16-pair planes
+        ap = _ap_scratch(T, B, H, 1, dev) if (step_rows is None and not dgb and has_tab and not has_dense and gates is not None
+                                              and gates.dtype == torch.float32) else None
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # receives W_hh^T for the direct-to-LDS step kernel
-        pair = _pair_scratch(B, H, 1, dev) if (step_rows is None and not dgb) else None   # f16-pair form of that step
         _check_gates(gates, B, H, step_rows is not None)
-        with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
-            call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
-                 _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _p(pair), dgb, _stream())
+        if ap is not None:
+            pair = None
+            dG = torch.empty(T, B, H, device=dev, dtype=torch.float32)      # dn_pre only
+            with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1, ap=1):
+                call("cpg_gru_seq_bwd_ap", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
+                     _p(scratch), _p(dh0), _p(wT), _p(ap), _stream())
+        else:
+            dG = (torch.zeros if step_rows is not None else torch.empty)(T, B, 4 * H, device=dev, dtype=dgt)
+            pair = _pair_scratch(B, H, 1, dev) if (step_rows is None and not dgb) else None   # f16-pair form of that step
+            with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1):
+                call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
+                     _p(scratch), _p(dh0), 0, B, _p(step_rows), _p(wT), _p(pair), dgb, _stream())
         if has_h0 and not ctx.tail:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
@@ -795,7 +827,10 @@ class GruSeqFn(Function):
         drowc = torch.empty(B, 3 * H, device=dev, dtype=torch.float32) if has_rowc else None
         # with a token table, its gradient and the column sums of dG (= the b_hh gradient) come out of one pass over dG
         dsum = torch.empty(4 * H, device=dev, dtype=torch.float32) if has_tab else None
-        if has_tab or has_rowc:
+        if ap is not None:
+            call("cpg_gru_dgi_reduce_ap", T, B, H, _p(ap), _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(),
+                 _stream())
+        elif has_tab or has_rowc:
             call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(), dgb,
                  _stream())
         dl = ctx.defer_req
@@ -810,9 +845,13 @@ class GruSeqFn(Function):
                 # plan's 240 workgroups hold 150 KB of LDS and every register of 240 CUs: whatever the main stream launches meanwhile
                 # crawls on the 16 CUs left (profiles/r04: a 5-us gradient add takes 370 us there).  Fewer, longer workgroups leave
                 # whole CUs to the main stream's small launches.
-                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H, pair is not None)):
-                    call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
-                         None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _p(pair), dgb, _stream())
+                if ap is not None:
+                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1), options(**_deferred_split_ap(T * B, 3 * H, H)):
+                        call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(defer[0].grad), 1, _p(ws2), ws2.numel(), _stream())
+                else:
+                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H, pair is not None)):
+                        call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
+                             None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _p(pair), dgb, _stream())
                 if has_tab:
                     defer[1].grad.add_(db_hh)
                 _pending_events.append(side.record_event())
@@ -820,16 +859,20 @@ class GruSeqFn(Function):
             # the backward pass ends, so ANY reader of .grad after loss.backward() (clip_grad_norm_, another optimiser, a
             # test) sees the finished gradient - not only FusedAdamClip, which joins explicitly
             torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
-            for t in (dG, hs, db_hh, pair):
+            for t in (dG, hs, db_hh, pair, ap):
                 if t is not None:
                     t.record_stream(side)
             dw_hh = db_hh = None
         else:
             dw_hh = torch.empty(3 * H, H, device=dev, dtype=torch.float32)
             db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
-            with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
-                     ws.numel(), _p(pair), dgb, _stream())
+            if ap is not None:
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1):
+                    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dw_hh), 0, _p(ws), ws.numel(), _stream())
+            else:
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                    call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
+                         ws.numel(), _p(pair), dgb, _stream())
         ddense = None
         if has_dense:
             # input-side gate gradients are columns {0..2H, 3H..4H} of dG (layout only; upper encoder layers)
@@ -894,19 +937,38 @@ class GruBiSeqFn(Function):
             ext_r = g_hs_r.contiguous().view(-1)[:T * BH] if g_hs_r is not None else None  # slots 0..T-1
         dgt = dg_dtype(B, H, ctx.V if ctx.has_tab else 0) if (gt_f is not None and gt_f.dtype == torch.bfloat16) else torch.float32
         dgb = int(dgt == torch.bfloat16)   # bf16 gradient storage (bf16 compute mode; see GruSeqFn.backward)
-        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
-        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
+        # all-T planes form (see GruSeqFn.backward): token-table layers only
+        ap = _ap_scratch(T, B, H, 2, dev) if (not dgb and ctx.has_tab and not ctx.has_dense and gt_f.dtype == torch.float32) else None
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
-        pair = _pair_scratch(B, H, 2, dev) if not dgb else None
         _check_gates(gt_f, B, H)
-        with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
-            call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]),
-                 _p(pair[0]) if pair is not None else None, _p(pair[1]) if pair is not None else None, dgb, _stream())
+        if ap is not None:
+            pair = None
+            dG_f = torch.empty(T, B, H, device=dev, dtype=torch.float32)      # dn_pre only
+            dG_r = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+            with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2, ap=1):
+                call("cpg_gru_biseq_bwd_ap", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                     _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _p(ap[0]), _p(ap[1]), _stream())
+        else:
+            dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
+            dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=dgt)
+            pair = _pair_scratch(B, H, 2, dev) if not dgb else None
+            with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2):
+                call("cpg_gru_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                     _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]),
+                     _p(pair[0]) if pair is not None else None, _p(pair[1]) if pair is not None else None, dgb, _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []
+
+        def wgrad(rev, dG, hs, dst, acc, wsx):
+            if ap is not None:
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1):
+                    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap[rev]), _p(dst), acc, _p(wsx), wsx.numel(), _stream())
+            else:
+                with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
+                    call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dst), None, acc, _p(wsx), wsx.numel(),
+                         _p(pair[rev]) if pair is not None else None, dgb, _stream())
         for rev, dG, hs in ((0, dG_f, hs_f), (1, dG_r, hs_r)):
             gw = _grad_buf(ctx.leaves[rev]) if ctx.has_tab else None
             dw = gw if gw is not None else torch.empty(3 * H, H, device=dev, dtype=torch.float32)
@@ -919,24 +981,24 @@ class GruBiSeqFn(Function):
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         ws2 = workspace(nb, dev)
-                        with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                            call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(gw), None, 1, _p(ws2), ws2.numel(),
-                                 _p(pair[rev]) if pair is not None else None, dgb, _stream())
+                        wgrad(rev, dG, hs, gw, 1, ws2)
                         _pending_events.append(side.record_event())
                     torch.autograd.Variable._execution_engine.queue_callback(join_deferred)
-                    for t in (dG, hs, pair):
+                    for t in (dG, hs, pair, ap):
                         if t is not None:
                             t.record_stream(side)
                 else:
-                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                        call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None, int(gw is not None), _p(ws), ws.numel(),
-                             _p(pair[rev]) if pair is not None else None, dgb, _stream())
+                    wgrad(rev, dG, hs, dw, int(gw is not None), ws)
                 if gw is not None:
                     dw = None
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
                 dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
-                call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(), dgb,
-                     _stream())
+                if ap is not None:
+                    call("cpg_gru_dgi_reduce_ap", T, B, H, _p(ap[rev]), _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
+                         _stream())
+                else:
+                    call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(), dgb,
+                         _stream())
                 db = dsum[:3 * H]
             else:
                 db = torch.empty(3 * H, device=dev, dtype=torch.float32)

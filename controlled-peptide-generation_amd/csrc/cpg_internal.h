@@ -14,6 +14,12 @@ int cpg_gemm_tn(const float* dY, int lddy, const float* X, int ldx, const uint8_
                 int Mr, int N, int Kd, int accumulate, float* ws, size_t ws_bytes, hipStream_t s, int dy_bf16 = 0,
                 const int* dy_exps = nullptr /* f16-pair form: exponent per 32 columns of dY, see GemmArgs::a_exps */, int dy_exps_mod = 1);
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd);
+// dW[M,N] (+)= A^T B over R rows, both operands as f16-pair plane images (csrc/pair_tn.h): row r of an image = columns/32 segments of
+// [32 hi | 32 lo] f16; A's segments carry 2^a_ex[(r/32) * a_groups + seg / a_seg_per_group], brought to 2^a_emin[group] in the
+// kernel and taken back out of the output rows; with G = a_seg_per_group > 1 the image interleaves G blocks of M / G columns
+int cpg_pair_tn(const uint16_t* A, size_t lda, const int* a_ex, const int* a_emin, int a_groups, int a_seg_per_group, const uint16_t* B,
+                size_t ldb, float* dW, int lddw, int M, int N, int R, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+size_t cpg_pair_tn_workspace(int M, int N, int R);
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_colsum_workspace(int M, int N);
 
@@ -30,7 +36,7 @@ bool cpg_gru_store_bf16(int B, int H, bool dense);
 bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 313
+#define CPG_ABI_VERSION 314
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).
@@ -53,6 +59,7 @@ enum CpgOpt {
     OPT_MMD_DL,           // 0: register-staged Gram launch of the full-kernel MMD
     OPT_BF16_STORE,       // 0: f32 saved gates in the bf16 compute mode too (default there: bf16, see cpg_gru_gates_bf16)
     OPT_BF16_DG,          // 0: f32 gate gradients in the bf16 compute mode too (default there: bf16 where covered, see cpg_gru_dg_bf16)
+    OPT_GRU_AP,           // 0: f32 gate gradients + ping-pong planes instead of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes)
     OPT__COUNT
 };
 struct CpgOptVal {

@@ -5,6 +5,7 @@
 //   cpg_matmul_nn          Y = X B                (losses.py:85  z @ rf_w)
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include "pair_tn.h"
 #ifndef CPG_TN_PRODUCT_SPLIT
 #define CPG_TN_PRODUCT_SPLIT 7  // 0: exact-f32 MFMA; 7: six bf16 MFMAs on 3-way split operands, f32-grade (gemm_core.h)
 #endif
@@ -448,6 +449,64 @@ CPG_EXPORT int cpg_gemm_tn_kernel_name(int Mr, int N, int Kd, int dy_pairs, char
                     bf ? 1 : (dy_pairs && vec && (t == TN_256x128 || t == TN_192x128 || t == TN_128x128)) ? 8 : 7);
 }
 CPG_EXPORT int cpg_gemm_tn_split(int Mr, int N, int Kd, int dy_pairs) { return tn_plan(N, Kd, Mr, dy_pairs != 0).S; }
+
+// ---- dW[M, N] (+)= A^T B with both operands as f16-pair plane images in memory (pair_tn.h): the dW_hh product of the all-T planes
+// form.  128 x 128 tiles (two 68 KB workgroups per CU), split over the R rows so that ONE round of workgroups covers the chip
+// (option tn_split overrides), partial slabs reduced in a fixed order.  Needs M % 128 == 0, N % 128 == 0, R % 32 == 0.
+static int pair_tn_split(int M, int N, int R, size_t ws_bytes) {
+    const long tiles = (long)(M / 128) * (N / 128);
+    long S = (2L * cpg_device_cus()) / tiles;
+    const CpgOptVal split = cpg_opt(OPT_TN_SPLIT);
+    if (split.set && split.i > 0) S = split.i;
+    const long maxs = R / 512 > 0 ? R / 512 : 1;   // at least 16 slabs per workgroup
+    if (S > maxs) S = maxs;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    while (S > 1 && (size_t)M * N * S * sizeof(float) > ws_bytes) --S;
+    // the exponent-factor table of a workgroup's slabs sits behind the LDS ring: keep two workgroups per CU where the problem allows
+    while (S < maxs && PairTn<2, 2, 2>::smem_bytes(cdiv(cdiv(R, (int)S), 32)) > 80 * 1024 && (size_t)M * N * (S + 1) * sizeof(float) <= ws_bytes) ++S;
+    return (int)S;
+}
+int cpg_pair_tn(const uint16_t* A, size_t lda, const int* a_ex, const int* a_emin, int a_groups, int a_seg_per_group, const uint16_t* B,
+                size_t ldb, float* dW, int lddw, int M, int N, int R, int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+    if (!(M > 0 && N > 0 && R > 0 && M % 128 == 0 && N % 128 == 0 && R % 32 == 0 && aligned16(A) && aligned16(B) && lda % 8 == 0 && ldb % 8 == 0)) {
+        cpg_set_error("cpg_pair_tn: needs M %% 128 == 0, N %% 128 == 0, rows %% 32 == 0 and 16-byte aligned plane images");
+        return -2;
+    }
+    using P = PairTn<2, 2, 2>;
+    int S = pair_tn_split(M, N, R, ws_bytes);
+    PairTnArgs g{A, lda, a_ex, a_emin, a_groups, a_seg_per_group, B, ldb, nullptr, 0, 0, M, N, R, 0, 0};
+    g.r_chunk = cdiv(cdiv(R, S), 32) * 32;
+    S = cdiv(R, g.r_chunk);
+    const size_t smem = P::smem_bytes(g.r_chunk / 32);
+    if (smem > 160 * 1024) {
+        cpg_set_error("cpg_pair_tn: workspace too small for a split that fits the exponent table into LDS");
+        return -3;
+    }
+    int rc = cpg_allow_big_lds((const void*)pair_tn_kernel<2, 2, 2, 0, 0>, (int)smem);
+    if (rc) return rc;
+    if (S > 1) {
+        g.C = ws; g.ldc = N; g.slab_stride = (size_t)M * N; g.accumulate = 0;
+    } else {
+        g.C = dW; g.ldc = lddw; g.slab_stride = 0; g.accumulate = accumulate;
+    }
+    hipLaunchKernelGGL((pair_tn_kernel<2, 2, 2, 0, 0>), dim3(N / P::BN, M / P::BM, S), dim3(P::NT), smem, s, g);
+    CPG_LAUNCH_CHECK();
+    if (S > 1) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n, S, dW, lddw, M, N, accumulate);
+        CPG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+size_t cpg_pair_tn_workspace(int M, int N, int R) {
+    const long tiles = (long)(M / 128) * (N / 128);
+    long S = tiles > 0 ? (2L * cpg_device_cus()) / tiles : 1;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    return (size_t)M * N * S * sizeof(float) + 256;
+}
+CPG_EXPORT int cpg_pair_tn_split(int M, int N, int R) { return pair_tn_split(M, N, R, (size_t)1 << 40); }
 
 size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd) {
     const TnPlan p = tn_plan(N, Kd, Mr), q = tn_plan(N, Kd, Mr, true);   // either form of the call (with / without column exponents)

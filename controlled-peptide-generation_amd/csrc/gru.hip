@@ -196,6 +196,9 @@ struct GruBwdArgs {
     int* ex_out;
     int* ex_min;   // [H/32] smallest exponent of every column group over the launches of the sequence so far (pair_w_kernel resets it):
                    // the column scale of the dW_hh product on f16 pairs (cpg_gru_wgrad_hh)
+    // all-T planes form (pair_engine.h: ApScratch): pp_out / ex_out are step s's OWN images (kept), dG_out receives ONLY the
+    // input-side n-gate block dn_pre as [B,H] f32, and the step also leaves h_prev as unscaled f16-pair planes [B][2H]
+    uint16_t* hp_out = nullptr;
 };
 
 struct GruBwdPair {
@@ -394,7 +397,12 @@ __device__ __forceinline__ void ld_gates4(const float* gates, size_t BH, size_t 
 // values are rounded to bf16 (RNE) HERE - the rounding the bf16 mode's consumers applied to the f32 values when they read them (the
 // next step's fragment read, the dW_hh product's LDS store): the BPTT chain and dW_hh see the same operands as with f32 storage.
 template <int PREC>
-__device__ __forceinline__ void st_dg4(float* dG_out, size_t row, int H, int col, const f32x4 v0, const f32x4 v1, const f32x4 v2, const f32x4 v3) {
+__device__ __forceinline__ void st_dg4(float* dG_out, size_t row, int H, int col, const f32x4 v0, const f32x4 v1, const f32x4 v2, const f32x4 v3,
+                                       bool ap = false) {
+    if (PREC == 3 && ap) {   // all-T planes form: the three recurrent blocks live in the kept plane images only; dn_pre as [B,H]
+        *reinterpret_cast<f32x4*>(dG_out + row * H + col) = v3;
+        return;
+    }
     if constexpr (PREC == 2) {
         uint16_t* d = reinterpret_cast<uint16_t*>(dG_out) + row * 4 * H + col;
         *reinterpret_cast<uint2*>(d) = make_uint2(cvt_pk_bf16(v0[0], v0[1]), cvt_pk_bf16(v0[2], v0[3]));
@@ -494,8 +502,9 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             const f32x4 dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
             const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
             const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
-            st_dg4<PREC>(g.dG_out, (size_t)row, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre);
+            st_dg4<PREC>(g.dG_out, (size_t)row, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre, g.hp_out != nullptr);
             if constexpr (PREC == 3) {
+                if (g.hp_out) pair_store4<1>(g.hp_out, (size_t)row, H, col, 0, hp);   // h_prev: the dW_hh product's B operand
                 pv[mi][ni][0] = dr_pre; pv[mi][ni][1] = dz_pre; pv[mi][ni][2] = dn_pre * rg;
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -509,8 +518,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
         const int grp = (j0 + wn * (BN / 2)) / 32;
         const int e = pair_group_exponent<BN>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
                                               g.ex_min + grp);
-        if (e != INT_MAX) {
-            const float sc = pair_pow2(e);
+        if (e != INT_MAX || g.hp_out) {   // kept images (all-T form) are read by consumers that do not look at the table first: zeros
+            const float sc = e == INT_MAX ? 1.f : pair_pow2(e);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1141,10 +1150,48 @@ CPG_EXPORT size_t cpg_gru_bwd_pair_bytes(int rows, int H, int ndir) {
 
 // dhs_ext: [T,B,H] time-aligned external gradients on every step's output (or null); dh_last: gradient on the final state.
 // dG out [T,B,4H]; dH_scratch [2,B,H]; dh0 [B,H] (or null when the initial state needs no gradient).
+// All-T planes form of the BPTT chain (pair_engine.h: ApScratch): covered where the f16-pair backward step is (whole dense batches,
+// f32-grade mode) AND every consumer of the kept images has its form - the dW_hh product on pair_tn_kernel (128 x 128 tiles: H % 128),
+// the one-pass input-side reduction (B % 128, H % 64).  Option gru_ap = 0 keeps the f32 gate gradients.
+static bool gru_ap_ok(int B, int H, int ndir) {
+    const CpgOptVal o = cpg_opt(OPT_GRU_AP);
+    if (o.set && o.i == 0) return false;
+    if (B <= 0 || H <= 0 || H % 128 != 0 || B % 128 != 0) return false;
+    return cpg_gru_bwd_pair_bytes(B, H, ndir) > 0;
+}
+CPG_EXPORT size_t cpg_gru_ap_bytes(int T, int B, int H, int ndir) {
+    if (T <= 0 || !gru_ap_ok(B, H, ndir)) return 0;
+    return ap_scratch_bytes(T, B, H, 3);
+}
+
+static int gru_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                            const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
+                            int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, void* pair_scratch,
+                            int dg_bf16, void* ap_scratch, void* stream);
+
 CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
                                int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, void* pair_scratch,
                                int dg_bf16, void* stream) {
+    return gru_seq_bwd_impl(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dG, dH_scratch, dh0, row_begin, row_end, step_rows,
+                            w_hhT_scratch, pair_scratch, dg_bf16, nullptr, stream);
+}
+CPG_EXPORT int cpg_gru_seq_bwd_ap(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                                  const float* dhs_ext, const float* dh_last, float* dN, float* dH_scratch, float* dh0,
+                                  float* w_hhT_scratch, void* ap, void* stream) {
+    CPG_CHECK_ARG(ap && w_hhT_scratch && aligned16(ap));
+    if (cpg_gru_ap_bytes(T, B, H, 1) == 0) {
+        cpg_set_error("cpg_gru_seq_bwd_ap: shape / mode not covered (cpg_gru_ap_bytes answers 0: f32-grade mode, H %% 128 == 0, B %% 128 == 0)");
+        return -4;
+    }
+    return gru_seq_bwd_impl(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dN, dH_scratch, dh0, 0, B, nullptr, w_hhT_scratch,
+                            nullptr, 0, ap, stream);
+}
+
+static int gru_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                            const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
+                            int row_begin, int row_end, const int32_t* step_rows, float* w_hhT_scratch, void* pair_scratch,
+                            int dg_bf16, void* ap_scratch, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && hs && gates && dG && dH_scratch);
     CPG_CHECK_ARG(0 <= row_begin && row_begin < row_end && row_end <= B);
     const size_t BH = (size_t)B * H;
@@ -1153,11 +1200,15 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
     const bool dgb = dg_bf16 != 0;
     CPG_CHECK_ARG(!dgb || (gbf && w_hhT_scratch && row_begin == 0 && row_end == B));   // bf16 gradient storage: whole dense batches on the direct-to-LDS step
     // f16-pair step: every launch of the sequence has the same shape, so the plan of one decides for all
-    const bool pair = pair_scratch && w_hhT_scratch && !dgb && cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) > 0 && row_begin % 64 == 0;
+    const bool allt = ap_scratch != nullptr;   // all-T planes: the caller asked cpg_gru_ap_bytes
+    const bool pair = allt || (pair_scratch && w_hhT_scratch && !dgb && cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) > 0 && row_begin % 64 == 0);
     uint16_t* PP[2] = {nullptr, nullptr};
     int* EX[2] = {nullptr, nullptr};
     int* EMIN = nullptr;
-    if (pair) pair_split(pair_scratch, B, H, 3, PP, EX, EMIN);
+    ApScratch AP{};
+    const size_t ppt = (size_t)B * 6 * H, ext = (size_t)(B / 32) * (H / 32);   // per step: plane image, exponent table
+    if (allt) { AP = ap_split(ap_scratch, T, B, H, 3); EMIN = AP.ex_min; }
+    else if (pair) pair_split(pair_scratch, B, H, 3, PP, EX, EMIN);
     if (w_hhT_scratch) {
         int rc = transpose_w(w_hh, H, w_hhT_scratch, (hipStream_t)stream, dgb, pair, EMIN);
         if (rc) return rc;
@@ -1180,21 +1231,23 @@ CPG_EXPORT int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_
         const int cur = (p + 2) & 1;
         a.pp_next = nullptr; a.ex_next = nullptr; a.pp_out = nullptr; a.ex_out = nullptr; a.ex_min = EMIN;
         if (prev_t >= 0) {
-            a.dG_next = gate_at(dG, (size_t)prev_t * B * 4 * H, dgb);
+            a.dG_next = allt ? dG /* non-null marker: the operand is pp_next */ : gate_at(dG, (size_t)prev_t * B * 4 * H, dgb);
             a.dH_next = dH_scratch + (size_t)(cur ^ 1) * BH;
-            if (pair) { a.pp_next = PP[cur ^ 1]; a.ex_next = EX[cur ^ 1]; }
+            if (allt) { a.pp_next = AP.planes + prev_t * ppt; a.ex_next = AP.ex + prev_t * ext; }
+            else if (pair) { a.pp_next = PP[cur ^ 1]; a.ex_next = EX[cur ^ 1]; }
         } else {
             a.dG_next = nullptr;
             a.dH_next = nullptr;
         }
-        if (pair && p >= 0) { a.pp_out = PP[cur]; a.ex_out = EX[cur]; }
+        if (allt && p >= 0) { a.pp_out = AP.planes + (size_t)t * ppt; a.ex_out = AP.ex + (size_t)t * ext; a.hp_out = AP.hplanes + (size_t)t * B * 2 * H; }
+        else if (pair && p >= 0) { a.pp_out = PP[cur]; a.ex_out = EX[cur]; }
         a.ext2 = (p == T - 1) ? dh_last : nullptr;
         if (p >= 0) {
             a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
             a.gates = gate_at(gates, (size_t)t * 4 * BH, gbf);
             a.h_prev = reverse ? hs + (size_t)(t + 1) * BH : hs + (size_t)t * BH;
             a.dH_out = dH_scratch + (size_t)cur * BH;
-            a.dG_out = gate_at(dG, (size_t)t * B * 4 * H, dgb);
+            a.dG_out = allt ? dG + (size_t)t * BH : gate_at(dG, (size_t)t * B * 4 * H, dgb);
         } else {
             a.ext = nullptr;
             a.gates = nullptr;
@@ -1251,6 +1304,21 @@ CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* d
     return cpg_colsum(dG, 4 * H, T * B, 3 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// All-T planes form: dW_hh[3H,H] (+)= sum over (t, b) of the kept gate-gradient planes^T x the state planes, both read as they were
+// written by the sequence's cpg_gru_seq_bwd_ap / _biseq_bwd_ap call (pair_tn.h: no conversion in the loop).  The bias gradient comes
+// out of cpg_gru_dgi_reduce_ap's column sums.
+CPG_EXPORT int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, float* dw_hh, int accumulate, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && ap && dw_hh && workspace);
+    if (cpg_gru_ap_bytes(T, B, H, 1) == 0) {
+        cpg_set_error("cpg_gru_wgrad_hh_ap: shape / mode not covered (cpg_gru_ap_bytes answers 0)");
+        return -4;
+    }
+    const ApScratch a = ap_split(const_cast<void*>(ap), T, B, H, 3);
+    return cpg_pair_tn(a.planes, (size_t)6 * H, a.ex, a.ex_min, H / 32, 3, a.hplanes, (size_t)2 * H, dw_hh, H, 3 * H, H, T * B, accumulate,
+                       (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // final reduction of the per-chunk partials of dgi_mfma_kernel (B/DM_ROWS chunks, fixed order)
 __global__ void dgi_fused_final_kernel(const float* part_tab, const float* part_sum, int chunks, int H, int V, int lstm, float* dtab,
                                        float* dsum, int accumulate) {
@@ -1280,9 +1348,12 @@ __global__ void dgi_fused_final_kernel(const float* part_tab, const float* part_
 constexpr int DM_RW = 32, DM_ROWS = 4 * DM_RW, DM_VMAX = 31;
 static_assert(DM_ROWS == DM_ROWS_C && DM_VMAX == DM_VMAX_C, "cpg_gru_dg_store_bf16 states the shape limits of dgi_mfma_kernel");
 // DGBF: dG holds bf16 elements (bf16 gradient storage): a lane's four columns are one 8-byte load, widened exactly to f32
-template <bool ROWC, bool DGBF = false>
+// DGAP (all-T planes form, GRU): column blocks of the three recurrent gate-gradient blocks read the kept f16-pair plane images
+// (ap_planes [T][B][6H], exponents ap_ex [T][B/32][H/32]: value = (hi + lo) 2^-e, exact in f32), the dn_pre block reads dG = dN [T,B,H]
+template <bool ROWC, bool DGBF = false, bool DGAP = false>
 __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const int32_t* tok, int T, int B, int H, int V, int lstm,
-                                                        float* part_tab, float* part_sum, float* drowc, int accumulate) {
+                                                        float* part_tab, float* part_sum, float* drowc, int accumulate,
+                                                        const uint16_t* ap_planes = nullptr, const int* ap_ex = nullptr) {
     __shared__ f32x4 dm_red[3][2][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
     const int C4 = 4 * H, col = blockIdx.x * 64 + 4 * l15;
@@ -1299,7 +1370,26 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
     auto fetch = [&](int t, f32x4 (&xv)[8], int (&tv)[8]) {
         const int4 t0 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw), t1 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw + 4);
         tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
-        if constexpr (DGBF) {
+        if constexpr (DGAP) {
+            const int q = col / H, c = col - q * H;   // (block-uniform q: 64-column blocks never straddle a gate block, H % 64 == 0)
+            if (q < 3) {
+                const int e = ap_ex[((size_t)t * (B / 32) + bw / 32) * (H / 32) + c / 32];
+                const float sc = __builtin_bit_cast(float, (unsigned)(127 - (e == INT_MAX ? 0 : e)) << 23);
+                const uint16_t* base = ap_planes + ((size_t)t * B + bw) * 6 * H + (size_t)(3 * (c / 32) + q) * 64 + (c & 31);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const uint2 hi = *reinterpret_cast<const uint2*>(base + (size_t)ks * 6 * H), lo = *reinterpret_cast<const uint2*>(base + (size_t)ks * 6 * H + 32);
+                    const cpg_f16x2 h0 = __builtin_bit_cast(cpg_f16x2, hi.x), h1 = __builtin_bit_cast(cpg_f16x2, hi.y);
+                    const cpg_f16x2 l0 = __builtin_bit_cast(cpg_f16x2, lo.x), l1 = __builtin_bit_cast(cpg_f16x2, lo.y);
+                    xv[ks] = f32x4{((float)h0[0] + (float)l0[0]) * sc, ((float)h0[1] + (float)l0[1]) * sc,
+                                   ((float)h1[0] + (float)l1[0]) * sc, ((float)h1[1] + (float)l1[1]) * sc};
+                }
+            } else {
+                const float* base = dG + ((size_t)t * B + bw) * H + c;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) xv[ks] = *reinterpret_cast<const f32x4*>(base + (size_t)ks * H);
+            }
+        } else if constexpr (DGBF) {
             const uint16_t* base = reinterpret_cast<const uint16_t*>(dG) + ((size_t)t * B + bw) * C4 + col;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
@@ -1471,6 +1561,33 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
     return 0;
 }
 
+// All-T planes form of the input-side reductions: the three recurrent gate-gradient blocks are read from the kept plane images of
+// `ap`, the n-gate's input-side block from dN [T,B,H]; results as cpg_gru_dgi_reduce (dsum[4H] = column sums of dr, dz, dhn, dn).
+CPG_EXPORT int cpg_gru_dgi_reduce_ap(int T, int B, int H, const void* ap, const float* dN, const int32_t* tok, int V, float* dtab,
+                                     float* dsum, float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && ap && dN && tok && workspace && (dtab || dsum));
+    if (cpg_gru_ap_bytes(T, B, H, 1) == 0 || !(V > 0 && V <= DM_VMAX) || !aligned16(dN) || !aligned16(tok) || (drowc && !aligned16(drowc)) ||
+        workspace_bytes < dgi_mfma_workspace(B, H, V)) {
+        cpg_set_error("cpg_gru_dgi_reduce_ap: not covered (cpg_gru_ap_bytes, token table of 1..%d rows, aligned operands, workspace of "
+                      "cpg_gru_wgrad_workspace bytes)", DM_VMAX);
+        return -4;
+    }
+    const ApScratch a = ap_split(const_cast<void*>(ap), T, B, H, 3);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = B / DM_ROWS;
+    float* part_tab = (float*)workspace;
+    float* part_sum = part_tab + (size_t)chunks * V * 4 * H;
+    const dim3 grid(4 * H / 64, chunks);
+    if (drowc) hipLaunchKernelGGL((dgi_mfma_kernel<true, false, true>), grid, dim3(256), 0, s, dN, tok, T, B, H, V, 0, part_tab, part_sum, drowc, accumulate, a.planes, a.ex);
+    else hipLaunchKernelGGL((dgi_mfma_kernel<false, false, true>), grid, dim3(256), 0, s, dN, tok, T, B, H, V, 0, part_tab, part_sum, drowc, accumulate, a.planes, a.ex);
+    CPG_LAUNCH_CHECK();
+    const int m = V * 3 * H > 4 * H ? V * 3 * H : 4 * H;
+    hipLaunchKernelGGL(dgi_fused_final_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, (const float*)part_tab, (const float*)part_sum, chunks, H, V, 0,
+                       dtab, dsum, accumulate);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 CPG_EXPORT int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                   float* drowc, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream) {
     return cpg_dgi_reduce_impl(T, B, H, 0, dG, tok, V, dtab, dsum, drowc, accumulate, workspace, workspace_bytes, stream, dg_bf16);
@@ -1519,21 +1636,58 @@ CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const
 // BPTT of both directions in lock step (no initial-state gradient: the encoder starts from h0 = 0).
 // dhs_ext_* [T,B,H] time-aligned (null = zeros); dh_last_* [B,H] gradient on the direction's final state (null = zeros);
 // dG_* [T,B,4H]; scratch_* [2,B,H].
+static int gru_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                              const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                              const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
+                              float* dG_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
+                              float* w_hhT_scratch_r, void* pair_scratch_f, void* pair_scratch_r, int dg_bf16, void* ap_f, void* ap_r,
+                              void* stream);
 CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                                  const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
                                  float* dG_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
                                  float* w_hhT_scratch_r, void* pair_scratch_f, void* pair_scratch_r, int dg_bf16, void* stream) {
+    return gru_biseq_bwd_impl(T, B, H, w_hh_f, w_hh_r, hs_f, hs_r, gates_f, gates_r, dhs_ext_f, dhs_ext_r, dh_last_f, dh_last_r, dG_f, dG_r,
+                              scratch_f, scratch_r, w_hhT_scratch_f, w_hhT_scratch_r, pair_scratch_f, pair_scratch_r, dg_bf16, nullptr,
+                              nullptr, stream);
+}
+CPG_EXPORT int cpg_gru_biseq_bwd_ap(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                                    const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                    const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dN_f,
+                                    float* dN_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
+                                    float* w_hhT_scratch_r, void* ap_f, void* ap_r, void* stream) {
+    CPG_CHECK_ARG(ap_f && ap_r && w_hhT_scratch_f && w_hhT_scratch_r && aligned16(ap_f) && aligned16(ap_r));
+    if (cpg_gru_ap_bytes(T, B, H, 2) == 0) {
+        cpg_set_error("cpg_gru_biseq_bwd_ap: shape / mode not covered (cpg_gru_ap_bytes answers 0)");
+        return -4;
+    }
+    return gru_biseq_bwd_impl(T, B, H, w_hh_f, w_hh_r, hs_f, hs_r, gates_f, gates_r, dhs_ext_f, dhs_ext_r, dh_last_f, dh_last_r, dN_f, dN_r,
+                              scratch_f, scratch_r, w_hhT_scratch_f, w_hhT_scratch_r, nullptr, nullptr, 0, ap_f, ap_r, stream);
+}
+static int gru_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                              const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                              const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f,
+                              float* dG_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
+                              float* w_hhT_scratch_r, void* pair_scratch_f, void* pair_scratch_r, int dg_bf16, void* ap_f, void* ap_r,
+                              void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && hs_f && hs_r && gates_f && gates_r && dG_f && dG_r);
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
     if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
     const bool dgb = dg_bf16 != 0;
     CPG_CHECK_ARG(!dgb || (cpg_gru_store_bf16(B, H, true) && w_hhT_scratch_f));
-    const bool pair = pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && !dgb && cpg_gru_bwd_pair_bytes(B, H, 2) > 0;
+    const bool allt = ap_f != nullptr && ap_r != nullptr;
+    const bool pair = allt || (pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && !dgb && cpg_gru_bwd_pair_bytes(B, H, 2) > 0);
     uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EMIN[2] = {nullptr, nullptr};
-    if (pair) {
+    ApScratch AP[2] = {};
+    const size_t ppt = (size_t)B * 6 * H, ext = (size_t)(B / 32) * (H / 32);
+    if (allt) {
+        AP[0] = ap_split(ap_f, T, B, H, 3);
+        AP[1] = ap_split(ap_r, T, B, H, 3);
+        EMIN[0] = AP[0].ex_min;
+        EMIN[1] = AP[1].ex_min;
+    } else if (pair) {
         pair_split(pair_scratch_f, B, H, 3, PP[0], EXP[0], EMIN[0]);
         pair_split(pair_scratch_r, B, H, 3, PP[1], EXP[1], EMIN[1]);
     }
@@ -1570,12 +1724,14 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.w_hh = W[d];
             a.w_hhT = WT[d];
             a.pp_next = nullptr; a.ex_next = nullptr; a.ex_min = EMIN[d];
-            a.pp_out = pair ? PP[d][cur] : nullptr;
-            a.ex_out = pair ? EXP[d][cur] : nullptr;
+            a.pp_out = allt ? AP[d].planes + (size_t)t * ppt : pair ? PP[d][cur] : nullptr;
+            a.ex_out = allt ? AP[d].ex + (size_t)t * ext : pair ? EXP[d][cur] : nullptr;
+            a.hp_out = allt ? AP[d].hplanes + (size_t)t * B * 2 * H : nullptr;
             if (prev_t[d] >= 0) {
-                a.dG_next = gate_at(DG[d], (size_t)prev_t[d] * B * 4 * H, dgb);
+                a.dG_next = allt ? DG[d] : gate_at(DG[d], (size_t)prev_t[d] * B * 4 * H, dgb);
                 a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;
-                if (pair) { a.pp_next = PP[d][cur ^ 1]; a.ex_next = EXP[d][cur ^ 1]; }
+                if (allt) { a.pp_next = AP[d].planes + (size_t)prev_t[d] * ppt; a.ex_next = AP[d].ex + (size_t)prev_t[d] * ext; }
+                else if (pair) { a.pp_next = PP[d][cur ^ 1]; a.ex_next = EXP[d][cur ^ 1]; }
             } else {
                 a.dG_next = nullptr;
                 a.dH_next = nullptr;
@@ -1585,7 +1741,7 @@ CPG_EXPORT int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const
             a.gates = gate_at(GT[d], (size_t)t * 4 * BH, gbf);
             a.h_prev = d ? HS[d] + (size_t)(t + 1) * BH : HS[d] + (size_t)t * BH;
             a.dH_out = SC[d] + (size_t)cur * BH;
-            a.dG_out = gate_at(DG[d], (size_t)t * B * 4 * H, dgb);
+            a.dG_out = allt ? DG[d] + (size_t)t * BH : gate_at(DG[d], (size_t)t * B * 4 * H, dgb);
             prev_t[d] = t;
         }
         int rc = gru_bwd_launch(pr, 2, (hipStream_t)stream);

@@ -105,5 +105,28 @@ static inline void pair_split(void* scratch, int B, int H, int G, uint16_t* (&pp
     ex[1] = ex[0] + (size_t)(B / 32) * (H / 32);
     ex_min = ex[1] + (size_t)(B / 32) * (H / 32);
 }
+// ---- "all-T planes" form (round 5): the plane images of EVERY step of a sequence are kept - [T][B][2 G H] f16 with their exponent
+// tables [T][B/32][H/32] - and become the only copy of the G recurrent gate-gradient blocks (the f32 dG of those blocks is not
+// written): the next BPTT launch reads step t+1's image as before, the dW_hh product reads all of them as its A operand through
+// LDS-DMA and transposing LDS reads with no conversion in its loop (pair_tn.h), the input-side reductions widen them exactly.
+// Beside them the backward steps leave the state planes [T][B][2 H] f16 (h_prev of step t, unscaled: |h| <= 1) - the dW_hh
+// product's B operand - which they have in registers anyway.
+struct ApScratch {
+    uint16_t* planes;    // [T][B][2 G H]
+    uint16_t* hplanes;   // [T][B][2 H]
+    int* ex;             // [T][B/32][H/32]
+    int* ex_min;         // [H/32]
+};
+static inline size_t ap_scratch_bytes(int T, int B, int H, int G) {
+    return (size_t)T * B * 2 * (G + 1) * H * sizeof(uint16_t) + ((size_t)T * (B / 32) * (H / 32) + (size_t)(H / 32)) * sizeof(int);
+}
+static inline ApScratch ap_split(void* scratch, int T, int B, int H, int G) {
+    ApScratch a;
+    a.planes = (uint16_t*)scratch;
+    a.hplanes = a.planes + (size_t)T * B * 2 * G * H;
+    a.ex = (int*)(a.hplanes + (size_t)T * B * 2 * H);
+    a.ex_min = a.ex + (size_t)T * (B / 32) * (H / 32);
+    return a;
+}
 // W_hh [G H, H] -> f16-pair image of W_hh^T (csrc/gru.hip), resetting ex_min for a new sequence
 int cpg_pair_w(const float* w_hh, int G, int H, uint16_t* out, int* ex_min, hipStream_t s);

@@ -207,6 +207,36 @@ CPG_API int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* dG, 
 CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                float* drowc, int accumulate, void* workspace, size_t workspace_bytes, int dg_bf16, void* stream);
 
+/* ---- All-T planes form of the f16-pair BPTT chain (round 5; csrc/pair_engine.h ApScratch, csrc/pair_tn.h).  Same results as the
+ * calls above (nn.GRU's backward, models/encoder.py:25-30,42 / models/decoder.py:40-41,77 under train_vae.py:39), different storage:
+ * the three recurrent gate-gradient blocks (dr_pre, dz_pre, d(W_hn h + b_hn)) of EVERY step are kept ONLY as the f16-pair plane
+ * images the next backward launch reads anyway ([T][B][6H] f16 + one power-of-two exponent per 32 x 32 group, [T][B/32][H/32]) - no
+ * f32 copy of them is written - and each step also leaves h_prev as unscaled f16-pair planes ([T][B][2H]).  `ap` holds all of it:
+ * cpg_gru_ap_bytes(T, B, H, ndir) bytes per direction, 16-byte aligned (0 = not covered: f32-grade mode, whole dense batches,
+ * H % 128 == 0, B % 128 == 0, the f16-pair step available; option gru_ap = 0 answers 0).  dN [T,B,H] receives the one block that
+ * is not recurrent: dn_pre, the n-gate's input-side gradient.  Consumers:
+ *   cpg_gru_wgrad_hh_ap    dW_hh (+)= planes^T x state planes: LDS-DMA operands, transposing LDS reads, three f16 MFMAs per block,
+ *                          NO conversion in the loop; segments are brought to their column group's smallest exponent on the way;
+ *   cpg_gru_dgi_reduce_ap  token-table gradient, column sums (dsum[4H] as cpg_gru_dgi_reduce: [:3H] = db_hh) and sums over time
+ *                          from the planes (widened exactly: (hi + lo) 2^-e) + dN, one pass on the matrix cores (V <= 31 rows).
+ * Every value that reaches a gradient is the f16 pair's 22-bit form of the f32 value (2^-22 relative to the largest magnitude of its
+ * 32 x 32 group), as in the f16-pair backward step itself. */
+CPG_API size_t cpg_gru_ap_bytes(int T, int B, int H, int ndir /* 1 | 2: directions per launch */);
+CPG_API int cpg_gru_seq_bwd_ap(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
+                               const float* dhs_ext, const float* dh_last, float* dN, float* dH_scratch, float* dh0,
+                               float* w_hhT_scratch, void* ap, void* stream);
+CPG_API int cpg_gru_biseq_bwd_ap(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
+                                 const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                 const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dN_f,
+                                 float* dN_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
+                                 float* w_hhT_scratch_r, void* ap_f, void* ap_r, void* stream);
+CPG_API int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, float* dw_hh, int accumulate, void* workspace,
+                                size_t workspace_bytes, void* stream);
+CPG_API int cpg_gru_dgi_reduce_ap(int T, int B, int H, const void* ap, const float* dN, const int32_t* tok, int V, float* dtab,
+                                  float* dsum, float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* split factor over the rows that cpg_gru_wgrad_hh_ap's product dW[M,N] over R rows runs with (bench.py: workgroups per launch) */
+CPG_API int cpg_pair_tn_split(int M, int N, int R);
+
 /* ---- LSTM (NOT in the reference, which is GRU-only - SURVEY F2; semantics = torch.nn.LSTM, gate row order i,f,g,o) --------
  * Same conventions as the GRU entry points; cs is the cell-state slab [(T+1),B,H] (c0 in slot 0 / T), gates [T,4,B,H] =
  * i,f,g,o, dG [T,B,4H] = pre-activation gradients (identical for the input and the hidden side). */
