@@ -72,6 +72,10 @@ class _CApi:
         from . import ops
         ops.call("cpg_comm_destroy", comm)
 
+    def count(self, comm):
+        from . import ops
+        return int(ops.query("cpg_comm_count", comm))
+
     def record(self):
         return torch.cuda.current_stream().record_event()
 
@@ -93,6 +97,10 @@ class LibComm:
             dist.broadcast(idt, 0)
             idt = idt.cpu()
         self._comm = self.api.init(bytes(idt.numpy().tobytes()), rank, world)
+
+    def ranks_seen(self):
+        """Ranks the communicator itself reports (ncclCommCount); -1 when the entry point is unavailable."""
+        return self.api.count(self._comm) if hasattr(self.api, "count") else -1
 
     def allreduce_sum(self, t):
         """In-place SUM on the CURRENT stream (asynchronous to the host)."""

@@ -240,6 +240,7 @@ def _deferred_split_ap(R, M, N):
     return {"tn_split": max(1, (4 * s) // 5)} if s >= 5 else {}
 
 
+DEFER_DEC_WGRAD = _os.environ.get('CPG_DEFER_DEC_WGRAD', '1') != '0'   # the decoder's dW_hh product on the side stream (GruSeqFn(defer=True))
 DEFER_ENC_WGRAD = _os.environ.get('CPG_DEFER_ENC_WGRAD', '1') != '0'   # the encoder's reverse-direction dW_hh beside the forward one (GruBiSeqFn)
 DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... and so does the [z;c] block of its W_ih gradient (LinearColsFn)
 BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
@@ -834,7 +835,7 @@ class GruSeqFn(Function):
             call("cpg_gru_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(), dgb,
                  _stream())
         dl = ctx.defer_req
-        defer = dl if (dl is not None and DEFER_WGRAD and OVERLAP and _grad_buf(dl[0]) is not None and _grad_buf(dl[1]) is not None) else None
+        defer = dl if (dl is not None and DEFER_WGRAD and DEFER_DEC_WGRAD and OVERLAP and _grad_buf(dl[0]) is not None and _grad_buf(dl[1]) is not None) else None
         if defer is not None:
             db_hh = dsum[:3 * H] if has_tab else None
             side = side_streams(dev)[2]
@@ -974,9 +975,11 @@ class GruBiSeqFn(Function):
             dw = gw if gw is not None else torch.empty(3 * H, H, device=dev, dtype=torch.float32)
             dtab = None
             if ctx.has_tab:
-                if rev == 1 and gw is not None and DEFER_WGRAD and OVERLAP and DEFER_ENC_WGRAD:
+                if rev == 1 and gw is not None and DEFER_WGRAD and OVERLAP and DEFER_ENC_WGRAD and ap is None:
                     # the reverse direction's dW_hh product beside the forward direction's, on a side stream: either launch alone
-                    # is bound by the latency of its operand loads (two workgroups per CU), together they fill each other's stalls
+                    # is bound by the latency of its operand loads (two workgroups per CU), together they fill each other's stalls.
+                    # (Not the all-T planes product: its loop is conversion-free and fills the CUs by itself - side by side the two
+                    # launches only time-slice them, 5.10 against 5.05 ms per step in situ, round 5.)
                     side = side_streams(dev)[1]
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):

@@ -19,6 +19,7 @@ struct Rccl {
     int (*GetUniqueId)(rcclUniqueId*);
     int (*CommInitRank)(rcclComm*, int, rcclUniqueId, int);
     int (*CommDestroy)(rcclComm);
+    int (*CommCount)(const rcclComm, int*);
     int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm, hipStream_t);
     int (*Broadcast)(const void*, void*, size_t, int, int, rcclComm, hipStream_t);
     int (*GroupStart)();
@@ -40,6 +41,7 @@ Rccl& rccl() {
         CPG_SYM(GetUniqueId, "ncclGetUniqueId");
         CPG_SYM(CommInitRank, "ncclCommInitRank");
         CPG_SYM(CommDestroy, "ncclCommDestroy");
+        CPG_SYM(CommCount, "ncclCommCount");
         CPG_SYM(AllReduce, "ncclAllReduce");
         CPG_SYM(Broadcast, "ncclBroadcast");
         CPG_SYM(GroupStart, "ncclGroupStart");
@@ -83,6 +85,14 @@ CPG_EXPORT int cpg_comm_init(const void* id128, int rank, int world, void** comm
     memcpy(&id, id128, sizeof(id));
     CPG_RCCL(rccl().CommInitRank((rcclComm*)comm, world, id, rank), "ncclCommInitRank");
     return 0;
+}
+
+// ranks the communicator itself reports (ncclCommCount): what a first multi-GPU run prints next to the launcher's WORLD_SIZE
+CPG_EXPORT int cpg_comm_count(void* comm) {
+    if (!rccl().ok || !rccl().CommCount || !comm) return -1;
+    int n = -1;
+    const int rc = rccl().CommCount((rcclComm)comm, &n);
+    return rc == 0 ? n : -1;
 }
 
 CPG_EXPORT int cpg_comm_destroy(void* comm) {

@@ -433,6 +433,8 @@ CPG_API int cpg_comm_available(void);
 CPG_API int cpg_comm_unique_id(void* id128);
 CPG_API int cpg_comm_init(const void* id128, int rank, int world, void** comm);
 CPG_API int cpg_comm_destroy(void* comm);
+/* ranks the communicator reports (ncclCommCount), -1 if unavailable: bench.py prints it as rccl.ranks_seen */
+CPG_API int cpg_comm_count(void* comm);
 CPG_API int cpg_allreduce_f32(void* comm, float* buf, size_t n, void* stream);
 CPG_API int cpg_allgatherv(void* comm, const void* send, const size_t* counts, int rank, int world, void* recv, void* stream);
 

@@ -5,7 +5,7 @@
 # other way more than once.   bash tools/insitu.sh ["opt=val opt=val" ...]
 cd "$(dirname "$0")/.."
 one() {
-  python bench.py --steps 10 --warmup 3 --no-extra-legs --no-class --no-cpu-baseline 2>/dev/null | python -c "
+  python bench.py --steps ${INSITU_STEPS:-10} --warmup 3 --no-extra-legs --no-class --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); f=[d['roofline']]+d['extra']['families']
 print('%-28s %7.3f ms/step  %s' % (sys.argv[1], d['ms_per_step'], {x['family']: x.get('us', x.get('avg_launch_us')) for x in f}))" "$1"
