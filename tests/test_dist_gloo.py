@@ -148,7 +148,7 @@ def _class_rounds(rank, world):
     sp.sample_round_arrays = _fake_round_factory()
     ds = SyntheticPeptideLoader(4, 25, 'cpu', size=8)
     df, st = sp.run_rounds(None, ds, _FakeQ(), 64, 40, max_rounds=30, return_stats=True)
-    return list(df['peptide']), [bool(a) for a in df['accept']], [z.tolist() for z in df['z']], st
+    return list(df['peptide']), [bool(a) for a in df['accept']], [np.asarray(z).tolist() for z in df['z']], st
 
 
 def test_class_rounds_sharded_equal_single_rank():
