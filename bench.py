@@ -137,7 +137,8 @@ def family_roofline(family, dims, avg_us, launches):
         flops = nd * 2.0 * B * 3 * H * H
     elif family == "wgrad_hh" and dims.get("ap"):
         # all-T planes form (cpg_gru_wgrad_hh_ap -> csrc/pair_tn.h): both operands f16-pair planes in memory, three f16 MFMAs per block
-        kernel, flops, split = "pair_tn_kernel<2, 2, 2, 0, 0>", 2.0 * 3 * H * H * T * B, 3
+        # (bf16 compute mode: the same loop on one bf16 plane per operand - its bf16 gate gradients and a bf16 copy of the states)
+        kernel, flops, split = ("pair_tn_kernel<2, 2, 2, 0, 0, 1>" if bf16 else "pair_tn_kernel<2, 2, 2, 0, 0, 2>"), 2.0 * 3 * H * H * T * B, (2 if bf16 else 3)
     elif family == "wgrad_hh":
         pairs = int(L.cpg_gru_bwd_pair_bytes(B, H, 1) > 0)   # the f16-pair BPTT hands its column exponents to the product
         kernel, flops = _cname("cpg_gemm_tn_kernel_name", T * B, 3 * H, H, pairs), 2.0 * 3 * H * H * T * B

@@ -811,15 +811,17 @@ class GruSeqFn(Function):
         dgb = int(dgt == torch.bfloat16)
         # all-T planes form (cpg_gru_ap_bytes): sequences with a token table and no dense input term (their input-side gradients are
         # consumed by the plane-reading reductions only); the recurrent dG blocks then exist only as the kept f16-pair planes
-        ap = _ap_scratch(T, B, H, 1, dev) if (step_rows is None and not dgb and has_tab and not has_dense and gates is not None
-                                              and gates.dtype == torch.float32) else None
+        # (bf16 compute mode with bf16 gradient storage: the same entry points keep that mode's dG and add a bf16 copy of the states,
+        # so that its dW_hh product runs the conversion-free loop on one bf16 plane per operand)
+        ap = _ap_scratch(T, B, H, 1, dev) if (step_rows is None and has_tab and not has_dense and gates is not None
+                                              and (dgb or gates.dtype == torch.float32)) else None
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
         wT = torch.empty(H, 3 * H, device=dev, dtype=torch.float32)  # receives W_hh^T for the direct-to-LDS step kernel
         _check_gates(gates, B, H, step_rows is not None)
         if ap is not None:
             pair = None
-            dG = torch.empty(T, B, H, device=dev, dtype=torch.float32)      # dn_pre only
+            dG = torch.empty(T, B, 4 * H, device=dev, dtype=dgt) if dgb else torch.empty(T, B, H, device=dev, dtype=torch.float32)   # f32-grade: dn_pre only
             with _prof("bwd_step", T + (1 if has_h0 else 0), T=T, B=B, H=H, ndir=1, ap=1):
                 call("cpg_gru_seq_bwd_ap", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs_ext), None, _p(dG),
                      _p(scratch), _p(dh0), _p(wT), _p(ap), _stream())
@@ -837,7 +839,7 @@ class GruSeqFn(Function):
         drowc = torch.empty(B, 3 * H, device=dev, dtype=torch.float32) if has_rowc else None
         # with a token table, its gradient and the column sums of dG (= the b_hh gradient) come out of one pass over dG
         dsum = torch.empty(4 * H, device=dev, dtype=torch.float32) if has_tab else None
-        if ap is not None:
+        if ap is not None and not dgb:
             call("cpg_gru_dgi_reduce_ap", T, B, H, _p(ap), _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(),
                  _stream())
         elif has_tab or has_rowc:
@@ -857,7 +859,7 @@ class GruSeqFn(Function):
                 # whole CUs to the main stream's small launches.
                 if ap is not None:
                     with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1), options(**_deferred_split_ap(T * B, 3 * H, H)):
-                        call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(defer[0].grad), 1, _p(ws2), ws2.numel(), _stream())
+                        call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dG) if dgb else None, _p(defer[0].grad), 1, _p(ws2), ws2.numel(), _stream())
                 else:
                     with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H, pair is not None)):
                         call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
@@ -878,7 +880,7 @@ class GruSeqFn(Function):
             db_hh = dsum[:3 * H] if has_tab else torch.empty(3 * H, device=dev, dtype=torch.float32)
             if ap is not None:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1):
-                    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dw_hh), 0, _p(ws), ws.numel(), _stream())
+                    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dG) if dgb else None, _p(dw_hh), 0, _p(ws), ws.numel(), _stream())
             else:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                     call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
@@ -948,14 +950,14 @@ class GruBiSeqFn(Function):
         dgt = dg_dtype(B, H, ctx.V if ctx.has_tab else 0) if (gt_f is not None and gt_f.dtype == torch.bfloat16) else torch.float32
         dgb = int(dgt == torch.bfloat16)   # bf16 gradient storage (bf16 compute mode; see GruSeqFn.backward)
         # all-T planes form (see GruSeqFn.backward): token-table layers only
-        ap = _ap_scratch(T, B, H, 2, dev) if (not dgb and ctx.has_tab and not ctx.has_dense and gt_f.dtype == torch.float32) else None
+        ap = _ap_scratch(T, B, H, 2, dev) if (ctx.has_tab and not ctx.has_dense and (dgb or gt_f.dtype == torch.float32)) else None
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
         _check_gates(gt_f, B, H)
         if ap is not None:
             pair = None
-            dG_f = torch.empty(T, B, H, device=dev, dtype=torch.float32)      # dn_pre only
-            dG_r = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+            dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=dgt) if dgb else torch.empty(T, B, H, device=dev, dtype=torch.float32)   # f32-grade: dn_pre only
+            dG_r = torch.empty_like(dG_f)
             with _prof("bwd_step", T, T=T, B=B, H=H, ndir=2, ap=1):
                 call("cpg_gru_biseq_bwd_ap", T, B, H, _p(wf), _p(wr), _p(hs_f), _p(hs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
                      _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _p(ap[0]), _p(ap[1]), _stream())
@@ -974,7 +976,7 @@ class GruBiSeqFn(Function):
         def wgrad(rev, dG, hs, dst, acc, wsx):
             if ap is not None:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1):
-                    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap[rev]), _p(dst), acc, _p(wsx), wsx.numel(), _stream())
+                    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap[rev]), _p(dG) if dgb else None, _p(dst), acc, _p(wsx), wsx.numel(), _stream())
             else:
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                     call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dst), None, acc, _p(wsx), wsx.numel(),
@@ -1005,7 +1007,7 @@ class GruBiSeqFn(Function):
                     dw = None
                 dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
                 dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
-                if ap is not None:
+                if ap is not None and not dgb:
                     call("cpg_gru_dgi_reduce_ap", T, B, H, _p(ap[rev]), _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
                          _stream())
                 else:

@@ -20,6 +20,8 @@ size_t cpg_gemm_tn_workspace(int Mr, int N, int Kd);
 int cpg_pair_tn(const uint16_t* A, size_t lda, const int* a_ex, const int* a_emin, int a_groups, int a_seg_per_group, const uint16_t* B,
                 size_t ldb, float* dW, int lddw, int M, int N, int R, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_pair_tn_workspace(int M, int N, int R);
+int cpg_pair_tn_bf16(const uint16_t* A, size_t lda, const uint16_t* B, size_t ldb, float* dW, int lddw, int M, int N, int R, int accumulate,
+                     float* ws, size_t ws_bytes, hipStream_t s);
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_colsum_workspace(int M, int N);
 
@@ -36,7 +38,7 @@ bool cpg_gru_store_bf16(int B, int H, bool dense);
 bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 315
+#define CPG_ABI_VERSION 316
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).

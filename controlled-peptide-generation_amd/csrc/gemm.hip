@@ -499,6 +499,35 @@ int cpg_pair_tn(const uint16_t* A, size_t lda, const int* a_ex, const int* a_emi
     }
     return 0;
 }
+// the same product on ONE bf16 plane per operand (pair_tn.h, NP = 1): A [R, lda] bf16 (M leading columns used), B [R, ldb] bf16
+int cpg_pair_tn_bf16(const uint16_t* A, size_t lda, const uint16_t* B, size_t ldb, float* dW, int lddw, int M, int N, int R, int accumulate,
+                     float* ws, size_t ws_bytes, hipStream_t s) {
+    if (!(M > 0 && N > 0 && R > 0 && M % 128 == 0 && N % 128 == 0 && R % 32 == 0 && aligned16(A) && aligned16(B) && lda % 8 == 0 && ldb % 8 == 0)) {
+        cpg_set_error("cpg_pair_tn_bf16: needs M %% 128 == 0, N %% 128 == 0, rows %% 32 == 0 and 16-byte aligned operands");
+        return -2;
+    }
+    using P = PairTn<2, 2, 2, 1>;
+    int S = pair_tn_split(M, N, R, ws_bytes);
+    PairTnArgs g{A, lda, nullptr, nullptr, 1, 1, B, ldb, nullptr, 0, 0, M, N, R, 0, 0};
+    g.r_chunk = cdiv(cdiv(R, S), 32) * 32;
+    S = cdiv(R, g.r_chunk);
+    const size_t smem = P::smem_bytes(0);
+    int rc = cpg_allow_big_lds((const void*)pair_tn_kernel<2, 2, 2, 0, 0, 1>, (int)smem);
+    if (rc) return rc;
+    if (S > 1) {
+        g.C = ws; g.ldc = N; g.slab_stride = (size_t)M * N; g.accumulate = 0;
+    } else {
+        g.C = dW; g.ldc = lddw; g.slab_stride = 0; g.accumulate = accumulate;
+    }
+    hipLaunchKernelGGL((pair_tn_kernel<2, 2, 2, 0, 0, 1>), dim3(N / P::BN, M / P::BM, S), dim3(P::NT), smem, s, g);
+    CPG_LAUNCH_CHECK();
+    if (S > 1) {
+        const size_t n = (size_t)M * N;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, n, S, dW, lddw, M, N, accumulate);
+        CPG_LAUNCH_CHECK();
+    }
+    return 0;
+}
 size_t cpg_pair_tn_workspace(int M, int N, int R) {
     const long tiles = (long)(M / 128) * (N / 128);
     long S = tiles > 0 ? (2L * cpg_device_cus()) / tiles : 1;

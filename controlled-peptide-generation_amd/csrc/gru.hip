@@ -199,6 +199,9 @@ struct GruBwdArgs {
     // all-T planes form (pair_engine.h: ApScratch): pp_out / ex_out are step s's OWN images (kept), dG_out receives ONLY the
     // input-side n-gate block dn_pre as [B,H] f32, and the step also leaves h_prev as unscaled f16-pair planes [B][2H]
     uint16_t* hp_out = nullptr;
+    // bf16 compute mode with bf16 gradient storage, all-T form: the step also leaves h_prev rounded to bf16 [B][H] (the rounding the
+    // mode's dW_hh product applied when it staged the f32 states) - the B operand of its conversion-free product (pair_tn.h, NP = 1)
+    uint16_t* hb_out = nullptr;
 };
 
 struct GruBwdPair {
@@ -503,6 +506,9 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
             const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
             st_dg4<PREC>(g.dG_out, (size_t)row, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre, g.hp_out != nullptr);
+            if constexpr (PREC == 2) {
+                if (g.hb_out) *reinterpret_cast<uint2*>(g.hb_out + o) = make_uint2(cvt_pk_bf16(hp[0], hp[1]), cvt_pk_bf16(hp[2], hp[3]));
+            }
             if constexpr (PREC == 3) {
                 if (g.hp_out) pair_store4<1>(g.hp_out, (size_t)row, H, col, 0, hp);   // h_prev: the dW_hh product's B operand
                 pv[mi][ni][0] = dr_pre; pv[mi][ni][1] = dz_pre; pv[mi][ni][2] = dn_pre * rg;
@@ -612,6 +618,9 @@ __global__ __launch_bounds__(512) void gru_step_bwd_dl2_kernel(GruBwdPair pr) {
         const f32x4 dz_pre = dh * (hp - ng) * zg * (1.f - zg);
         const f32x4 dr_pre = dn_pre * hn * rg * (1.f - rg);
         st_dg4<PREC>(g.dG_out, (size_t)rb, H, col, dr_pre, dz_pre, dn_pre * rg, dn_pre);
+        if constexpr (PREC == 2) {
+            if (g.hb_out) *reinterpret_cast<uint2*>(g.hb_out + o) = make_uint2(cvt_pk_bf16(hp[0], hp[1]), cvt_pk_bf16(hp[2], hp[3]));
+        }
     }
 }
 
@@ -1157,10 +1166,13 @@ static bool gru_ap_ok(int B, int H, int ndir) {
     const CpgOptVal o = cpg_opt(OPT_GRU_AP);
     if (o.set && o.i == 0) return false;
     if (B <= 0 || H <= 0 || H % 128 != 0 || B % 128 != 0) return false;
+    // bf16 compute mode: the form is the bf16 state copy beside the mode's bf16 gate gradients (cpg_gru_dg_bf16 with a token table)
+    if (cpg_compute_mode_get() == 1) return cpg_gru_dg_store_bf16(B, H, true, 1);
     return cpg_gru_bwd_pair_bytes(B, H, ndir) > 0;
 }
 CPG_EXPORT size_t cpg_gru_ap_bytes(int T, int B, int H, int ndir) {
     if (T <= 0 || !gru_ap_ok(B, H, ndir)) return 0;
+    if (cpg_compute_mode_get() == 1) return (size_t)T * B * H * sizeof(uint16_t);   // the bf16 copy of h_prev of every step
     return ap_scratch_bytes(T, B, H, 3);
 }
 
@@ -1185,7 +1197,7 @@ CPG_EXPORT int cpg_gru_seq_bwd_ap(int T, int B, int H, int reverse, const float*
         return -4;
     }
     return gru_seq_bwd_impl(T, B, H, reverse, w_hh, hs, gates, dhs_ext, dh_last, dN, dH_scratch, dh0, 0, B, nullptr, w_hhT_scratch,
-                            nullptr, 0, ap, stream);
+                            nullptr, cpg_compute_mode_get() == 1 ? 1 : 0, ap, stream);
 }
 
 static int gru_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
@@ -1200,7 +1212,8 @@ static int gru_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh,
     const bool dgb = dg_bf16 != 0;
     CPG_CHECK_ARG(!dgb || (gbf && w_hhT_scratch && row_begin == 0 && row_end == B));   // bf16 gradient storage: whole dense batches on the direct-to-LDS step
     // f16-pair step: every launch of the sequence has the same shape, so the plan of one decides for all
-    const bool allt = ap_scratch != nullptr;   // all-T planes: the caller asked cpg_gru_ap_bytes
+    const bool allb = ap_scratch != nullptr && dgb;   // bf16 mode's all-T form: bf16 dG as ever + the bf16 state copy in ap_scratch
+    const bool allt = ap_scratch != nullptr && !dgb;  // all-T planes: the caller asked cpg_gru_ap_bytes
     const bool pair = allt || (pair_scratch && w_hhT_scratch && !dgb && cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) > 0 && row_begin % 64 == 0);
     uint16_t* PP[2] = {nullptr, nullptr};
     int* EX[2] = {nullptr, nullptr};
@@ -1241,6 +1254,7 @@ static int gru_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh,
         }
         if (allt && p >= 0) { a.pp_out = AP.planes + (size_t)t * ppt; a.ex_out = AP.ex + (size_t)t * ext; a.hp_out = AP.hplanes + (size_t)t * B * 2 * H; }
         else if (pair && p >= 0) { a.pp_out = PP[cur]; a.ex_out = EX[cur]; }
+        if (allb && p >= 0) a.hb_out = (uint16_t*)ap_scratch + (size_t)t * BH;
         a.ext2 = (p == T - 1) ? dh_last : nullptr;
         if (p >= 0) {
             a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
@@ -1307,12 +1321,17 @@ CPG_EXPORT int cpg_gru_wgrad_hh(int T, int B, int H, int reverse, const float* d
 // All-T planes form: dW_hh[3H,H] (+)= sum over (t, b) of the kept gate-gradient planes^T x the state planes, both read as they were
 // written by the sequence's cpg_gru_seq_bwd_ap / _biseq_bwd_ap call (pair_tn.h: no conversion in the loop).  The bias gradient comes
 // out of cpg_gru_dgi_reduce_ap's column sums.
-CPG_EXPORT int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, float* dw_hh, int accumulate, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+CPG_EXPORT int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, const void* dG_bf16, float* dw_hh, int accumulate,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && ap && dw_hh && workspace);
     if (cpg_gru_ap_bytes(T, B, H, 1) == 0) {
         cpg_set_error("cpg_gru_wgrad_hh_ap: shape / mode not covered (cpg_gru_ap_bytes answers 0)");
         return -4;
+    }
+    if (cpg_compute_mode_get() == 1) {   // bf16 mode: A = the bf16 gate gradients [T B, 4H] (columns 0 .. 3H), B = the bf16 state copy
+        CPG_CHECK_ARG(dG_bf16 != nullptr);
+        return cpg_pair_tn_bf16((const uint16_t*)dG_bf16, (size_t)4 * H, (const uint16_t*)ap, (size_t)H, dw_hh, H, 3 * H, H, T * B, accumulate,
+                                (float*)workspace, workspace_bytes, (hipStream_t)stream);
     }
     const ApScratch a = ap_split(const_cast<void*>(ap), T, B, H, 3);
     return cpg_pair_tn(a.planes, (size_t)6 * H, a.ex, a.ex_min, H / 32, 3, a.hplanes, (size_t)2 * H, dw_hh, H, 3 * H, H, T * B, accumulate,
@@ -1662,7 +1681,8 @@ CPG_EXPORT int cpg_gru_biseq_bwd_ap(int T, int B, int H, const float* w_hh_f, co
         return -4;
     }
     return gru_biseq_bwd_impl(T, B, H, w_hh_f, w_hh_r, hs_f, hs_r, gates_f, gates_r, dhs_ext_f, dhs_ext_r, dh_last_f, dh_last_r, dN_f, dN_r,
-                              scratch_f, scratch_r, w_hhT_scratch_f, w_hhT_scratch_r, nullptr, nullptr, 0, ap_f, ap_r, stream);
+                              scratch_f, scratch_r, w_hhT_scratch_f, w_hhT_scratch_r, nullptr, nullptr, cpg_compute_mode_get() == 1 ? 1 : 0,
+                              ap_f, ap_r, stream);
 }
 static int gru_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                               const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
@@ -1675,7 +1695,8 @@ static int gru_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const fl
     if (w_hhT_scratch_f && !bwd_wants_wt(B, H, 0, true)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;  // W_hh as stored
     const bool dgb = dg_bf16 != 0;
     CPG_CHECK_ARG(!dgb || (cpg_gru_store_bf16(B, H, true) && w_hhT_scratch_f));
-    const bool allt = ap_f != nullptr && ap_r != nullptr;
+    const bool allb = ap_f != nullptr && ap_r != nullptr && dgb;   // bf16 mode: bf16 state copies
+    const bool allt = ap_f != nullptr && ap_r != nullptr && !dgb;
     const bool pair = allt || (pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && !dgb && cpg_gru_bwd_pair_bytes(B, H, 2) > 0);
     uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -1727,6 +1748,7 @@ static int gru_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const fl
             a.pp_out = allt ? AP[d].planes + (size_t)t * ppt : pair ? PP[d][cur] : nullptr;
             a.ex_out = allt ? AP[d].ex + (size_t)t * ext : pair ? EXP[d][cur] : nullptr;
             a.hp_out = allt ? AP[d].hplanes + (size_t)t * B * 2 * H : nullptr;
+            a.hb_out = allb ? (uint16_t*)(d ? ap_r : ap_f) + (size_t)t * BH : nullptr;
             if (prev_t[d] >= 0) {
                 a.dG_next = allt ? DG[d] : gate_at(DG[d], (size_t)prev_t[d] * B * 4 * H, dgb);
                 a.dH_next = SC[d] + (size_t)(cur ^ 1) * BH;

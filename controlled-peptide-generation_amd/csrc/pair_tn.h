@@ -33,10 +33,14 @@ struct PairTnArgs {
     int accumulate;                  // S == 1 only
 };
 
-template <int WM, int WN, int NS>
+// NP = 2: f16-pair images (a 128-byte segment = [32 hi | 32 lo] of 32 columns, three f16 MFMAs per block);
+// NP = 1: ONE bf16 plane (a segment = 64 columns; one bf16 MFMA per block; no exponents): the bf16 compute mode's dW_hh product on its
+//         bf16 gate gradients [R, lda] and a bf16 copy of the states - the same conversion-free loop with half the LDS traffic per column
+template <int WM, int WN, int NS, int NP = 2>
 struct PairTn {
     static constexpr int BM = 64 * WM, BN = 64 * WN, NT = 64 * WM * WN;
-    static constexpr int SA = BM / 32, SB = BN / 32;            // segments per slab
+    static constexpr int SEGC = NP == 2 ? 32 : 64;              // columns per 128-byte segment
+    static constexpr int SA = BM / SEGC, SB = BN / SEGC;        // segments per slab
     static constexpr int STAGE = (SA + SB) * 4096;              // bytes
     static constexpr int NW = WM * WN;
     static constexpr int DMA = (SA + SB) * 4;                   // wave-instructions per slab (8 rows x 128 bytes each)
@@ -46,10 +50,11 @@ struct PairTn {
 };
 
 // ABL (diagnostic builds of tools/micro/wgrad_planes.hip, wrong results): 1 no MFMAs, 2 no fragment reads, 4 no LDS-DMA after the prologue
-template <int WM, int WN, int NS, int ABL = 0, int PIPE = 0>
+template <int WM, int WN, int NS, int ABL = 0, int PIPE = 0, int NP = 2>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_tn_kernel(PairTnArgs g) {
-    using P = PairTn<WM, WN, NS>;
-    constexpr int BM = P::BM, BN = P::BN, SA = P::SA, STAGE = P::STAGE, LPS = P::LPS, NW = P::NW;
+    using P = PairTn<WM, WN, NS, NP>;
+    constexpr int BM = P::BM, BN = P::BN, SA = P::SA, STAGE = P::STAGE, LPS = P::LPS, NW = P::NW, SEGC = P::SEGC;
+    constexpr int WS = 64 / SEGC;   // segments of a wave's 64 columns
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
     extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 
     // ---- exponent factors of this workgroup's slabs: fac[kt][seg] as packed f16 pairs (2^(emin - e), 0 for an all-zero segment)
     uint32_t* const fac = reinterpret_cast<uint32_t*>(smem + (size_t)NS * STAGE);
-    if (g.a_ex) {
+    if (NP == 2 && g.a_ex) {
         for (int i = tid; i < KT * SA; i += P::NT) {
             const int kt = i / SA, sg = i - kt * SA;
             const int grp = (m0 / 32 + sg) / g.a_seg_per_group;
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         const int row = 8 * j + (lane >> 3);
         const int ch = (lane & 7) ^ (((row >> 1) & 3) << 1);
         const bool isA = sg < SA;
-        const uint16_t* base = isA ? g.A + (size_t)(m0 / 32 + sg) * 64 : g.B + (size_t)(n0 / 32 + (sg - SA)) * 64;
+        const uint16_t* base = isA ? g.A + (size_t)(m0 / SEGC + sg) * 64 : g.B + (size_t)(n0 / SEGC + (sg - SA)) * 64;
         src[i] = base + (size_t)(r0 + row) * (isA ? g.lda : g.ldb) + 8 * ch;
         dst[i] = sg * 4096 + j * 1024;           // + 16 * lane by the instruction itself
     }
@@ -114,19 +119,20 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     const int s = lane & 15, q = lane >> 4;
     const int krow = 4 * q + (s >> 2);                       // + 16 h
     const int fsw = ((krow >> 1) & 3) << 1;                  // f(krow) = f(krow + 16)
-    auto frag_off = [&](int seg, int u, int p, int h) {
-        const int c = (4 * p + 2 * u + ((s & 3) >> 1)) ^ fsw;
+    auto frag_off = [&](int seg0, int b, int p, int h) {   // block b (16 columns) of the wave's 64 columns, whose first segment is seg0
+        const int seg = NP == 2 ? seg0 + (b >> 1) : seg0;
+        const int c = (NP == 2 ? (4 * p + 2 * (b & 1) + ((s & 3) >> 1)) : (2 * b + ((s & 3) >> 1))) ^ fsw;
         return seg * 4096 + (krow + 16 * h) * 128 + c * 16 + (s & 1) * 8;
     };
-    int offA[4][2][2], offB[4][2][2];                        // [16-column block of the wave's 64][plane][k half]
+    int offA[4][NP][2], offB[4][NP][2];                      // [16-column block of the wave's 64][plane][k half]
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                offA[b][p][h] = frag_off(wm * 2 + (b >> 1), b & 1, p, h);
-                offB[b][p][h] = frag_off(SA + wn * 2 + (b >> 1), b & 1, p, h);
+                offA[b][p][h] = frag_off(wm * WS, b, p, h);
+                offB[b][p][h] = frag_off(SA + wn * WS, b, p, h);
             }
 
     f32x4 acc[4][4];
@@ -152,19 +158,19 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     // of the other - a wave's LDS reads run under its own MFMAs (the matrix pipe does not idle across the slab barrier, also at one
     // wave per SIMD).  A stage is free for the next LDS-DMA once every wave has READ it: reads of slab kt - 1 are waited for
     // (lgkmcnt(0)) in front of iteration kt's barrier.
-    cpg_f16x8 fA[PIPE ? 2 : 1][4][2], fB[PIPE ? 2 : 1][4][2];
+    cpg_f16x8 fA[PIPE ? 2 : 1][4][NP], fB[PIPE ? 2 : 1][4][NP];
     uint32_t f2[PIPE ? 2 : 1][2] = {{0x3c003c00u, 0x3c003c00u}};   // [register set][segment of the wave]: 2^(emin - e) twice
     auto load_frags = [&](int buf, int kt, int cur) {
         const char* st = smem + cur * STAGE;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) fB[buf][b][p] = rd(st, offB[b][p][0], offB[b][p][1]);
+            for (int p = 0; p < NP; ++p) fB[buf][b][p] = rd(st, offB[b][p][0], offB[b][p][1]);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) fA[buf][mi][p] = rd(st, offA[mi][p][0], offA[mi][p][1]);
-        if (g.a_ex) {
+            for (int p = 0; p < NP; ++p) fA[buf][mi][p] = rd(st, offA[mi][p][0], offA[mi][p][1]);
+        if (NP == 2 && g.a_ex) {
             f2[buf][0] = fac[kt * SA + wm * 2];
             f2[buf][1] = fac[kt * SA + wm * 2 + 1];
         } else {
@@ -173,9 +179,18 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     };
     auto multiply = [&](int buf) {
         if (ABL & 1) return;
+        if constexpr (NP == 1) {   // one bf16 plane: one MFMA per block
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cpg_bf16x8, fA[buf][mi][0]),
+                                                                          __builtin_bit_cast(cpg_bf16x8, fB[buf][ni][0]), acc[mi][ni], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            cpg_f16x8 a0 = fA[buf][mi][0], a1 = fA[buf][mi][1];
+            cpg_f16x8 a0 = fA[buf][mi][0], a1 = fA[buf][mi][NP - 1];
             if (g.a_ex) {   // the segment's power of two, applied where the fragment is consumed (the reads stay wait-free)
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 const h2 f = __builtin_bit_cast(h2, f2[buf][mi >> 1]);
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, fB[buf][ni][0], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, fB[buf][ni][1], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, fB[buf][ni][NP - 1], acc[mi][ni], 0, 0, 0);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, fB[buf][ni][0], acc[mi][ni], 0, 0, 0);
         }
@@ -237,12 +252,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     for (int mi = 0; mi < 4; ++mi) {
         const int mrow = m0 + wm * 64 + mi * 16 + 4 * q;
         float sc = 1.f;
-        const int seg = mrow / 32, G = g.a_seg_per_group;
-        if (g.a_ex) {
+        const int seg = mrow / 32, G = NP == 2 ? g.a_seg_per_group : 1;
+        if (NP == 2 && g.a_ex) {
             const int em = g.a_emin[seg / G];
             sc = __builtin_bit_cast(float, (unsigned)(127 - (em == INT_MAX ? 0 : em)) << 23);
         }
-        const int orow = (seg % G) * (g.M / G) + 32 * (seg / G) + (mrow & 31);
+        const int orow = NP == 2 ? (seg % G) * (g.M / G) + 32 * (seg / G) + (mrow & 31) : mrow;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int col = n0 + wn * 64 + ni * 16 + s;

@@ -220,7 +220,11 @@ CPG_API int cpg_gru_dgi_reduce(int T, int B, int H, const float* dG, const int32
  *   cpg_gru_dgi_reduce_ap  token-table gradient, column sums (dsum[4H] as cpg_gru_dgi_reduce: [:3H] = db_hh) and sums over time
  *                          from the planes (widened exactly: (hi + lo) 2^-e) + dN, one pass on the matrix cores (V <= 31 rows).
  * Every value that reaches a gradient is the f16 pair's 22-bit form of the f32 value (2^-22 relative to the largest magnitude of its
- * 32 x 32 group), as in the f16-pair backward step itself. */
+ * 32 x 32 group), as in the f16-pair backward step itself.
+ * bf16 compute mode (cpg_set_compute_mode(1), where cpg_gru_dg_bf16 answers 1): the same entry points keep the mode's storage - `dN` of
+ * the _bwd_ap calls IS the bf16 gate-gradient buffer [T,B,4H] of cpg_gru_seq_bwd(dg_bf16 = 1), cpg_gru_dgi_reduce(dg_bf16 = 1) reads it
+ * as before - and `ap` (cpg_gru_ap_bytes = T B H x 2 bytes) receives h_prev of every step rounded to bf16, so that
+ * cpg_gru_wgrad_hh_ap(ap, dG_bf16) runs the same conversion-free loop on ONE bf16 plane per operand (one MFMA per block). */
 CPG_API size_t cpg_gru_ap_bytes(int T, int B, int H, int ndir /* 1 | 2: directions per launch */);
 CPG_API int cpg_gru_seq_bwd_ap(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                                const float* dhs_ext, const float* dh_last, float* dN, float* dH_scratch, float* dh0,
@@ -230,8 +234,8 @@ CPG_API int cpg_gru_biseq_bwd_ap(int T, int B, int H, const float* w_hh_f, const
                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dN_f,
                                  float* dN_r, float* scratch_f, float* scratch_r, float* w_hhT_scratch_f,
                                  float* w_hhT_scratch_r, void* ap_f, void* ap_r, void* stream);
-CPG_API int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, float* dw_hh, int accumulate, void* workspace,
-                                size_t workspace_bytes, void* stream);
+CPG_API int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, const void* dG_bf16 /* bf16 compute mode only, else null */,
+                                float* dw_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 CPG_API int cpg_gru_dgi_reduce_ap(int T, int B, int H, const void* ap, const float* dN, const int32_t* tok, int V, float* dtab,
                                   float* dsum, float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* split factor over the rows that cpg_gru_wgrad_hh_ap's product dW[M,N] over R rows runs with (bench.py: workgroups per launch) */

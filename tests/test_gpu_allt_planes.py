@@ -99,13 +99,13 @@ def _chain_vs_exact(B, H, T, reverse, wild):
     hprev = hpl
     ws = torch.empty(query("cpg_gru_wgrad_workspace", T, B, H, V), device=dev, dtype=torch.uint8)
     dw = torch.full((3 * H, H), 3.0, device=dev)
-    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dw), 0, _p(ws), ws.numel(), _stream())
+    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), None, _p(dw), 0, _p(ws), ws.numel(), _stream())
     torch.cuda.synchronize()
     dw2 = dw.clone()
-    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dw2), 1, _p(ws), ws.numel(), _stream())      # accumulate: twice the product
+    call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), None, _p(dw2), 1, _p(ws), ws.numel(), _stream())      # accumulate: twice the product
     with ops.options(tn_split=1):
         dw3 = torch.zeros(3 * H, H, device=dev)
-        call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dw3), 0, _p(ws), ws.numel(), _stream())  # no split over the rows
+        call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), None, _p(dw3), 0, _p(ws), ws.numel(), _stream())  # no split over the rows
     torch.cuda.synchronize()
     want = refn[:, :, :3 * H].reshape(T * B, 3 * H).T @ hprev.reshape(T * B, H)
     grp = np.abs(want).reshape(3, H // 32, 32, H).max(axis=(2, 3), keepdims=True).repeat(32, 2).reshape(3 * H, 1)
@@ -185,10 +185,60 @@ def test_all_t_planes_option_and_coverage():
     with ops.options(gru_ap=0):
         assert query("cpg_gru_ap_bytes", 25, 2048, 512, 1) == 0
     ops.set_compute_mode('bf16')
-    try:
-        assert query("cpg_gru_ap_bytes", 25, 2048, 512, 1) == 0
+    try:   # bf16 compute mode: the form is the bf16 state copy next to the mode's bf16 gate gradients
+        assert query("cpg_gru_ap_bytes", 25, 2048, 512, 1) == 25 * 2048 * 512 * 2
+        with ops.options(bf16_dg=0):
+            assert query("cpg_gru_ap_bytes", 25, 2048, 512, 1) == 0
     finally:
         ops.set_compute_mode('f32')
     x = torch.zeros(64, device="cuda")
     with pytest.raises(ops.CpgError):
-        call("cpg_gru_wgrad_hh_ap", 4, 64, 96, _p(x), _p(x), 0, _p(x), 256, _stream())
+        call("cpg_gru_wgrad_hh_ap", 4, 64, 96, _p(x), None, _p(x), 0, _p(x), 256, _stream())
+
+
+@pytest.mark.parametrize("B,H,T,reverse", [(256, 128, 6, False), (2048, 512, 25, True)])
+def test_bf16_mode_all_t_form(B, H, T, reverse):
+    """bf16 compute mode: cpg_gru_seq_bwd_ap keeps the mode's bf16 gate gradients (bit-identical to cpg_gru_seq_bwd(dg_bf16 = 1)) and
+    leaves h_prev of every step rounded to bf16; cpg_gru_wgrad_hh_ap(ap, dG) - one bf16 MFMA per block on operands that ARE bf16 in
+    memory - against an f64 sum over exactly those bf16 operands (1e-5 of each 32-row group's largest value: f32 accumulation only) and
+    against the mode's register-staged product of the same call (which rounds h to bf16 only in its large-shape one-plane form: 1e-2,
+    the size of that rounding)."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call, query
+    dev = torch.device("cuda")
+    V = 24
+    ops.set_compute_mode('bf16')
+    try:
+        if B * H < 512 * 64 * 64:
+            ops.set_option("gru_bwd_tile", "64x64")
+        d = _inputs(B, H, T, V, seed=B + H + T + 19)
+        hs, gates, dhs, last = _bwd_inputs(d, B, H, T, reverse, seed=17)
+        assert gates.dtype == torch.bfloat16 and query("cpg_gru_dg_bf16", B, H, 0, V) == 1 and query("cpg_gru_ap_bytes", T, B, H, 1) == T * B * H * 2
+        scr, wT = torch.empty(2, B, H, device=dev), torch.empty(H, 3 * H, device=dev)
+        ref = torch.zeros(T, B, 4 * H, device=dev, dtype=torch.bfloat16)
+        r0 = torch.zeros(B, H, device=dev)
+        call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(hs), _p(gates), _p(dhs), _p(last), _p(ref), _p(scr), _p(r0), 0, B, None,
+             _p(wT), None, 1, _stream())
+        ap = ops._ap_scratch(T, B, H, 1, dev)
+        ap.fill_(0xFF)
+        dG = torch.zeros(T, B, 4 * H, device=dev, dtype=torch.bfloat16)
+        dh0 = torch.zeros(B, H, device=dev)
+        call("cpg_gru_seq_bwd_ap", T, B, H, int(reverse), _p(d["w_hh"]), _p(hs), _p(gates), _p(dhs), _p(last), _p(dG), _p(scr), _p(dh0), _p(wT),
+             _p(ap), _stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dG.view(torch.int16), ref.view(torch.int16)) and torch.equal(dh0, r0)
+        hb = ap[:T * B * H * 2].view(torch.bfloat16).view(T, B, H)
+        hprev = hs[1:] if reverse else hs[:-1]
+        assert torch.equal(hb.view(torch.int16), hprev.to(torch.bfloat16).view(torch.int16))           # RNE, as the staged product rounds
+        ws = torch.empty(query("cpg_gru_wgrad_workspace", T, B, H, V), device=dev, dtype=torch.uint8)
+        dw, dwo = torch.zeros(3 * H, H, device=dev), torch.zeros(3 * H, H, device=dev)
+        call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dG), _p(dw), 0, _p(ws), ws.numel(), _stream())
+        call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dwo), None, 0, _p(ws), ws.numel(), None, 1, _stream())
+        torch.cuda.synchronize()
+        want = dG[:, :, :3 * H].reshape(T * B, 3 * H).double().T @ hb.reshape(T * B, H).double()
+        grp = want.abs().view(3, H // 32, 32, H).amax(dim=(2, 3), keepdim=True).expand(3, H // 32, 32, H).reshape(3 * H, H)
+        assert ((dw.double() - want).abs() <= 1e-5 * grp + 1e-30).all(), float(((dw.double() - want).abs() / (grp + 1e-30)).max())
+        assert ((dw - dwo).abs().double() <= 1e-2 * grp + 1e-30).all()
+    finally:
+        ops.set_option("gru_bwd_tile", None)
+        ops.set_compute_mode('f32')
