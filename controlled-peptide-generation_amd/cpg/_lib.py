@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER = os.path.join(ROOT, "include", "cpg_api.h")
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("CPG_LIB_PATH", os.path.join(PKG_DIR, "libcpg_hip.so"))  # override: diagnostic builds only
-SOURCES = ["api.hip", "gemm.hip", "gru.hip", "gru_persist.hip", "lstm.hip", "lstm_persist.hip", "decode.hip", "decode_fused.hip", "losses.hip", "optim.hip", "rng.hip", "class.hip", "classifier.hip", "comm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gru.hip", "gru_persist.hip", "lstm.hip", "lstm_persist.hip", "decode.hip", "decode_fused.hip", "losses.hip", "optim.hip", "rng.hip", "class.hip", "classifier.hip", "comm.hip", "planes.hip"]
 
 
 class LibraryMissing(RuntimeError):

@@ -495,6 +495,63 @@ class Linear2Fn(Function):
         return dxs[0], dxs[1], dw, db
 
 
+def planes_ok(R, K, N):
+    """The plane-image forms of an nn.Linear-shaped product (csrc/planes.hip) cover R rows x contraction K x N outputs."""
+    return _os.environ.get("CPG_NO_LINEAR_PLANES", "") == "" and bool(query("cpg_planes_ok", int(R), int(K), int(N)))
+
+
+def pair_rows(x1, x2=None):
+    """f16-pair image (uint8 tensor) of x = [x1 | x2]: rows [R, C1 (+ C2)] f32 -> [R][2 C] f16 (cpg_pair_rows); no gradient."""
+    x1c, ld1 = _rowmajor(x1)
+    R, C1 = x1c.shape
+    x2c, ld2, C2 = (None, 0, 0) if x2 is None else (*_rowmajor(x2), x2.shape[1])
+    img = torch.empty(int(query("cpg_pair_rows_bytes", R, C1 + C2)), device=x1.device, dtype=torch.uint8)
+    call("cpg_pair_rows", _p(x1c), ld1, C1, _p(x2c), ld2, C2, R, _p(img), _stream())
+    return img
+
+
+class Linear2PlanesFn(Function):
+    """Linear2Fn on f16-pair plane images (csrc/planes.hip; round 5): y = [x1 | x2] W^T + b over T B rows with every product
+    conversion-free - ximg is the image of [x1 | x2] (ops.pair_rows: built ONCE per layer, shared by the layer's two directions and by the
+    weight gradient), the incoming gradient is imaged once per direction and feeds both dX (one launch for both halves) and dW.
+    gates: 3 (GRU) | 4 (LSTM) blocks of the output."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, ximg, w, b, gates):
+        R, K1, K2 = x1.shape[0], x1.shape[1], x2.shape[1]
+        N, K = w.shape
+        assert K == K1 + K2 and N % gates == 0
+        wc = w.contiguous()
+        y = torch.empty(R, N, device=w.device, dtype=torch.float32)
+        sc = workspace(int(query("cpg_pair_rows_bytes", N, K)), w.device, tag=7)
+        call("cpg_linear_fwd_planes", _p(ximg), R, K, _p(wc), K, _p(b), _p(y), N, N, 0, _p(sc), sc.numel(), _stream())
+        ctx.save_for_backward(ximg, wc)
+        ctx.dims = (R, K1, K2, N, int(gates))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ximg, w = ctx.saved_tensors
+        R, K1, K2, N, G = ctx.dims
+        K, H = K1 + K2, N // G
+        dev = dy.device
+        dy, lddy = _rowmajor(dy)
+        off = (ctypes.c_int * 4)(*[q * H for q in range(G)], *([0] * (4 - G)))
+        gp = torch.empty(int(query("cpg_grad_planes_bytes", R, H, G)), device=dev, dtype=torch.uint8)
+        call("cpg_grad_planes", _p(dy), lddy, R, H, G, off, _p(gp), _stream())
+        dx = torch.empty(R, K, device=dev, dtype=torch.float32)
+        sc = workspace(int(query("cpg_pair_rows_bytes", K, N)), dev, tag=7)
+        call("cpg_linear_bwd_input_planes", _p(gp), R, H, G, _p(w), K, _p(dx), K, K, 0, _p(sc), sc.numel(), _stream())
+        dw = torch.empty_like(w)
+        ws = workspace(int(query("cpg_linear_bwd_weight_planes_workspace", R, H, G, K)), dev)
+        call("cpg_linear_bwd_weight_planes", _p(gp), R, H, G, _p(ximg), K, _p(dw), K, 0, _p(ws), ws.numel(), _stream())
+        db = torch.empty(N, device=dev, dtype=torch.float32)
+        nb = int(query("cpg_colsum_workspace_bytes", R, N))
+        ws2 = workspace(nb, dev, tag=8)
+        call("cpg_colsum_f32", _p(dy), lddy, R, N, _p(db), 0, _p(ws2), nb, _stream())
+        return dx[:, :K1], dx[:, K1:], None, dw, db, None
+
+
 class MaskedLinear2Fn(Function):
     """y = (x1 .* keep1*scale) W[:, :K1]^T (+ (x2 .* keep2*scale) W[:, K1:]^T) + b: nn.Dropout in front of the input projection of an
     upper encoder layer - nn.GRU(dropout=p_dropout) drops the (concatenated) output of every layer but the last in train mode

@@ -880,6 +880,7 @@ __device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int
 // THREE v_mfma_f32_16x16x32_f16 per block and slab (lo x hi, hi x lo, hi x hi): the bytes per k of the f32 slab, 32 k per slab, and
 // 48 matrix-pipe cycles per block and slab in place of the 268 of eight f32 MFMAs.  `pre(kt)` runs ahead of slab kt's products
 // (the caller rescales its accumulators when the operands' power-of-two scale changes along k) and returns false to skip them.
+struct DlNoScale {};   // DlLoop::run without a fragment-scale hook
 template <int BM, int BN, int NS = 3, int PREC = 0>
 struct DlLoop {
     static constexpr int MI = BM / 32, NI = BN / 32;
@@ -897,6 +898,14 @@ struct DlLoop {
     template <class Hook, class E, class Pre>
     __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
                                                f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre) {
+        run(A, lda, Bt, ldb, K, smem, acc, hook_kt, hook, pre, DlNoScale{});
+    }
+    // fscale (PREC 3 only): uint32 fscale(kt, mi) = a power of two <= 1 as two packed f16, multiplied into block row mi's A fragments
+    // of slab kt (v_pk_mul_f16) - A images whose k-segments carry different power-of-two scales are brought to ONE unit on the way into
+    // the MFMAs, so the accumulators never need rescaling (planes.hip: gradient images of two 32-row blocks per wave)
+    template <class Hook, class E, class Pre, class FS>
+    __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
+                                               f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre, FS&& fscale) {
         static_assert((PREC >= 2) == (sizeof(E) == 2), "PREC 2 / 3 <-> 16-bit operands in memory");
         constexpr int EPC = 16 / (int)sizeof(E);   // elements per 16-byte chunk
         constexpr int BKE = 8 * EPC;               // elements per slab (a row of a slab is always 128 bytes)
@@ -947,6 +956,18 @@ struct DlLoop {
                     for (int mi = 0; mi < MI; ++mi) {
                         fa[0][mi] = *reinterpret_cast<const cpg_f16x8*>(cur + oa0 + mi * 512);
                         fa[1][mi] = *reinterpret_cast<const cpg_f16x8*>(cur + oa1 + mi * 512);
+                        if constexpr (!__is_same(__remove_cvref(FS), DlNoScale)) {
+                            const cpg_f16x2 f = __builtin_bit_cast(cpg_f16x2, (uint32_t)fscale(kt, mi));
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) {
+                                uint4 w = __builtin_bit_cast(uint4, fa[p][mi]);
+                                w.x = __builtin_bit_cast(uint32_t, __builtin_bit_cast(cpg_f16x2, w.x) * f);
+                                w.y = __builtin_bit_cast(uint32_t, __builtin_bit_cast(cpg_f16x2, w.y) * f);
+                                w.z = __builtin_bit_cast(uint32_t, __builtin_bit_cast(cpg_f16x2, w.z) * f);
+                                w.w = __builtin_bit_cast(uint32_t, __builtin_bit_cast(cpg_f16x2, w.w) * f);
+                                fa[p][mi] = __builtin_bit_cast(cpg_f16x8, w);
+                            }
+                        }
                     }
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {

@@ -1,0 +1,266 @@
+// nn.Linear-shaped products over MANY rows on f16-pair plane images (round 5): the input projection of an upper encoder layer
+// (models/encoder.py:25-30: nn.GRU(num_layers > 1) feeds layer l the concatenated outputs of layer l-1 - [T B, 2 He] x [2 He, 3 He] per
+// direction) and its two gradients.  At BASELINE.json configs[4] dimensions (T B = 51 200 rows, He = 1024) these three products were
+// 27 of the step's 58 ms on engines that convert in their loops (exact-f32 MFMA 114 TFLOP/s, in-loop f16 split 154, bf16 triple 171).
+// Here every operand is turned into a plane image ONCE by a bandwidth-bound pass and the products run conversion-free:
+//   y  = x W^T + b        DlLoop<128,128,2,3>: both images K-contiguous, LDS-DMA ring, ds_read_b128 fragments (409 TFLOP/s measured)
+//   dx = dy W             the same loop; dy's image carries one power of two per (32 rows x 32-unit group): every A fragment is brought to
+//                         its row block's common unit on the way into the MFMAs (DlLoop's fscale hook), W^T is imaged in dy's k order
+//   dW = dy^T x           pair_tn_kernel (pair_tn.h): LDS-DMA + transposing reads over the same two images
+// Image formats: pair_engine.h / pair_tn.h (a row = 128-byte segments of [32 hi | 32 lo] f16).
+#include "pair_engine.h"
+#include "pair_tn.h"
+#include "cpg_internal.h"
+
+namespace {
+
+// ---- x [R, C1 (+ C2)] f32 -> unscaled image [R][2 (C1 + C2)] (|x| <= 65504; states: |x| <= 1).  One thread = 4 columns of one row.
+__global__ void pair_rows_kernel(const float* __restrict__ x1, int ld1, int C1, const float* __restrict__ x2, int ld2, int C2, int R,
+                                 uint16_t* __restrict__ img, float scale) {
+    const int C = C1 + C2, q4 = C / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * q4) return;
+    const size_t row = i / q4;
+    const int col = (int)(i - row * q4) * 4;
+    const f32x4 v = col < C1 ? *reinterpret_cast<const f32x4*>(x1 + row * ld1 + col) : *reinterpret_cast<const f32x4*>(x2 + row * ld2 + (col - C1));
+    pair_store4<1>(img, row, C, col, 0, v * scale);
+}
+
+// ---- W [G Hk, Nc] (row-major, ld) -> image of W^T: out[n][2 G Hk], k-segments in the order (32-unit group, block) - the k order of a
+// gradient image (below) - times 2^W_PAIR_EXP.  grid (Nc/32, G Hk/32), block (32, 8): a 32 x 32 tile through LDS.
+__global__ void pair_wT_kernel(const float* __restrict__ w, int ld, int G, int Hk, int Nc, uint16_t* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // tile[k - r0][n - c0]
+    for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = w[(size_t)(r0 + i) * ld + c0 + threadIdx.x];
+    __syncthreads();
+    const int tid = threadIdx.y * 32 + threadIdx.x, jj = tid >> 3, q = tid & 7, c8 = (q & 3) * 8;
+    const int blk = r0 / Hk, grp = (r0 - blk * Hk) / 32;
+    const float sc = pair_pow2(W_PAIR_EXP);
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2h_pair(tile[c8 + 2 * i][jj] * sc, tile[c8 + 2 * i + 1][jj] * sc, hi[i], lo[i]);
+    uint16_t* const d = out + (size_t)(c0 + jj) * 2 * G * Hk + (size_t)(G * grp + blk) * 64 + (q >> 2) * 32 + c8;
+    *reinterpret_cast<uint4*>(d) = (q >> 2) ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(hi[0], hi[1], hi[2], hi[3]);
+}
+
+// ---- gate gradients dG [R, ldg] f32, G blocks of H columns at column offsets off[q] -> image [R][2 G H] in the order (32-unit
+// group, block), times 2^e with ONE e per (32 rows x group) over its G blocks (largest magnitude -> [2^13, 2^14); INT_MAX: all zero,
+// zeros stored), ex[R/32][H/32], emin[H/32] (atomicMin; preset to INT_MAX by the caller's memset pattern 0x7f... see the launcher).
+// One workgroup = 32 rows x one group: thread (row = tid / 8, 4 columns).
+struct GradPlanesArgs {
+    const float* dG; size_t ldg; int R, H, G; int off[4];
+    uint16_t* img; int* ex; int* emin;
+};
+template <int G>
+__global__ __launch_bounds__(256) void grad_planes_kernel(GradPlanesArgs a) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x, rb = blockIdx.y;
+    const size_t row = (size_t)rb * 32 + (tid >> 3);
+    const int col = grp * 32 + (tid & 7) * 4;
+    f32x4 v[G];
+    float vmax = 0.f;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        v[q] = *reinterpret_cast<const f32x4*>(a.dG + row * a.ldg + a.off[q] + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(v[q][j]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) red[wave] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int e = INT_MAX;
+    if (vmax > 0.f) {
+        int fe = 0;
+        if (vmax < 3.0e38f) { (void)frexpf(vmax, &fe); e = max(-100, min(100, 14 - fe)); }
+        else e = 0;
+    }
+    if (tid == 0) {
+        a.ex[(size_t)rb * (a.H / 32) + grp] = e;
+        if (e != INT_MAX) atomicMin(a.emin + grp, e);
+    }
+    const float sc = e == INT_MAX ? 1.f : pair_pow2(e);
+#pragma unroll
+    for (int q = 0; q < G; ++q) pair_store4<G>(a.img, row, a.H, col, q, v[q] * sc);
+}
+__global__ void fill_int_kernel(int* p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---- C[R, N] (+)= A B^T on K-contiguous images.  A: [R][K2] with optional exponents (one per 32-row block and group of G consecutive
+// 32-k segments: a gradient image), B: [N][K2] times 2^b_exp.  128 x 128 tiles, 2 x 2 waves of 64 x 64.
+struct PairNtArgs {
+    const uint16_t* A; size_t lda;
+    const int* a_ex; int a_groups;     // null: unscaled A
+    const uint16_t* B; size_t ldb;
+    int K2;                            // elements of a row of either image (2 x logical K)
+    float* C; size_t ldc;
+    const float* bias;
+    int accumulate, b_exp;
+};
+template <int G>
+__global__ __launch_bounds__(256) void pair_nt_kernel(PairNtArgs g) {
+    using DL = DlLoop<128, 128, 2, 3>;
+    constexpr int MI = DL::MI, NI = DL::NI;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int m0 = by * 128, n0 = bx * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float back = pair_pow2(-g.b_exp);
+    float f0 = 1.f, f1 = 1.f;   // per 32-row block of the wave's 64 rows: 2^-e_ref takes the block's unit back out
+    if (g.a_ex) {
+        // A wave's 64 rows are TWO 32-row blocks with their own exponents per group (accumulator rows mi 0,1 / mi 2,3).  Every segment
+        // is brought to its block's common unit 2^e_ref (e_ref = the block's smallest exponent = its largest-magnitude group) where the
+        // fragment is read: the factor 2^(e_ref - e) <= 1 is exact while the product stays a normal f16 and flushes gracefully below
+        // (2^-38 of the block's largest value) - no accumulator rescaling, no per-block liveness in the slab loop.
+        const int rb = (m0 + wm * 64) / 32;
+        int ev0 = lane < g.a_groups ? g.a_ex[(size_t)rb * g.a_groups + lane] : INT_MAX;
+        int ev1 = lane < g.a_groups ? g.a_ex[(size_t)(rb + 1) * g.a_groups + lane] : INT_MAX;
+        int er0 = ev0, er1 = ev1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            er0 = min(er0, __shfl_xor(er0, o));
+            er1 = min(er1, __shfl_xor(er1, o));
+        }
+        er0 = __builtin_amdgcn_readfirstlane(er0);
+        er1 = __builtin_amdgcn_readfirstlane(er1);
+        f0 = er0 == INT_MAX ? 0.f : pair_pow2(-er0);
+        f1 = er1 == INT_MAX ? 0.f : pair_pow2(-er1);
+        auto fac = [&](int ev, int eref, int gi) -> uint32_t {
+            const int e = __builtin_amdgcn_readlane(ev, gi);
+            if (e == INT_MAX) return 0u;                       // all-zero segment (zeros stored)
+            const int d = max(eref - e, -30);                  // <= 0
+            const uint32_t bits = (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)__builtin_bit_cast(float, (unsigned)(127 + d) << 23));
+            return bits | (bits << 16);
+        };
+        DL::run(g.A + (size_t)m0 * g.lda, g.lda, g.B + (size_t)n0 * g.ldb, g.ldb, g.K2, cpg_smem, acc, -1, []() {}, [](int) { return true; },
+                [&](int kt, int mi) { return mi < MI / 2 ? fac(ev0, er0, kt / G) : fac(ev1, er1, kt / G); });
+    } else {
+        DL::run(g.A + (size_t)m0 * g.lda, g.lda, g.B + (size_t)n0 * g.ldb, g.ldb, g.K2, cpg_smem, acc, -1, []() {});
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[mi][ni] * (mi < MI / 2 ? f0 : f1);
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * 64 + ni * 16 + l15;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(m0 + wm * 64 + mi * 16 + 4 * lq + r) * g.ldc + col;
+                float v = acc[mi][ni][r] * back + bv;
+                if (g.accumulate) v += g.C[o];
+                g.C[o] = v;
+            }
+        }
+}
+
+size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------ entry points
+// Shapes covered by the plane products: whole 128-row / 128-column tiles and 32-unit groups.
+CPG_EXPORT int cpg_planes_ok(int R, int K, int N) {
+    return (cpg_compute_mode_get() != 1 && R > 0 && R % 128 == 0 && K > 0 && K % 128 == 0 && N > 0 && N % 128 == 0 && (long)R * N >= (1L << 22)) ? 1 : 0;
+}
+// image of x = [x1 | x2] (x2 optional): R rows of 2 (C1 + C2) f16
+CPG_EXPORT size_t cpg_pair_rows_bytes(int R, int C) { return (size_t)R * 2 * C * sizeof(uint16_t); }
+CPG_EXPORT int cpg_pair_rows(const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int R, void* img, void* stream) {
+    CPG_CHECK_ARG(x1 && img && R > 0 && C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2) && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0));
+    CPG_CHECK_ARG(aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(img));
+    const size_t n = (size_t)R * ((C1 + C2) / 4);
+    hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x1, ld1, C1, x2, ld2, C2, R,
+                       (uint16_t*)img, 1.f);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// y [R, N] (+)= ximg [R][2K] . W[N, K]^T + bias; scratch: cpg_pair_rows_bytes(N, K) bytes for W's image
+CPG_EXPORT int cpg_linear_fwd_planes(const void* ximg, int R, int K, const float* W, int ldw, const float* bias, float* Y, int ldy, int N,
+                                     int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+    CPG_CHECK_ARG(ximg && W && Y && scratch && cpg_planes_ok(R, K, N) && ldw % 4 == 0 && aligned16(W) && aligned16(scratch));
+    CPG_CHECK_ARG(scratch_bytes >= cpg_pair_rows_bytes(N, K));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)N * (K / 4);
+    hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, K, (const float*)nullptr, 0, 0, N,
+                       (uint16_t*)scratch, (float)(1 << W_PAIR_EXP));
+    CPG_LAUNCH_CHECK();
+    PairNtArgs g{(const uint16_t*)ximg, (size_t)2 * K, nullptr, 0, (const uint16_t*)scratch, (size_t)2 * K, 2 * K, Y, (size_t)ldy, bias, accumulate,
+                 W_PAIR_EXP};
+    const size_t smem = DlLoop<128, 128, 2, 3>::smem_floats() * sizeof(float);
+    int rc = cpg_allow_big_lds((const void*)pair_nt_kernel<3>, (int)smem);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pair_nt_kernel<3>, dim3(N / 128, R / 128), dim3(256), smem, s, g);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// gradient image of dG's G blocks (column offsets off[0..G-1], H columns each): planes [R][2 G H], ex [R/32][H/32], emin [H/32]
+CPG_EXPORT size_t cpg_grad_planes_bytes(int R, int H, int G) {
+    return align256((size_t)R * 2 * G * H * sizeof(uint16_t)) + align256((size_t)(R / 32) * (H / 32) * sizeof(int)) + align256((size_t)(H / 32) * sizeof(int));
+}
+static void grad_planes_split(void* gp, int R, int H, int G, uint16_t*& img, int*& ex, int*& emin) {
+    img = (uint16_t*)gp;
+    ex = (int*)((char*)gp + align256((size_t)R * 2 * G * H * sizeof(uint16_t)));
+    emin = (int*)((char*)ex + align256((size_t)(R / 32) * (H / 32) * sizeof(int)));
+}
+CPG_EXPORT int cpg_grad_planes(const float* dG, int ldg, int R, int H, int G, const int* off, void* gp, void* stream) {
+    CPG_CHECK_ARG(dG && gp && off && R > 0 && R % 32 == 0 && H > 0 && H % 32 == 0 && (G == 3 || G == 4) && ldg % 4 == 0 && aligned16(dG) && aligned16(gp));
+    GradPlanesArgs a{dG, (size_t)ldg, R, H, G, {0, 0, 0, 0}, nullptr, nullptr, nullptr};
+    for (int q = 0; q < G; ++q) {
+        CPG_CHECK_ARG(off[q] >= 0 && off[q] % 4 == 0);
+        a.off[q] = off[q];
+    }
+    grad_planes_split(gp, R, H, G, a.img, a.ex, a.emin);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_int_kernel, dim3(cdiv(H / 32, 64)), dim3(64), 0, s, a.emin, H / 32, INT_MAX);
+    CPG_LAUNCH_CHECK();
+    if (G == 3) hipLaunchKernelGGL(grad_planes_kernel<3>, dim3(H / 32, R / 32), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(grad_planes_kernel<4>, dim3(H / 32, R / 32), dim3(256), 0, s, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// dx [R, In] (+)= dGin . W   (W [G H, In] row-major); scratch: cpg_pair_rows_bytes(In, G H) bytes for the image of W^T
+CPG_EXPORT int cpg_linear_bwd_input_planes(const void* gp, int R, int H, int G, const float* W, int ldw, float* dX, int lddx, int In,
+                                           int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+    CPG_CHECK_ARG(gp && W && dX && scratch && (G == 3 || G == 4) && cpg_planes_ok(R, G * H, In) && H % 32 == 0 && H / 32 <= 64 && aligned16(scratch));
+    CPG_CHECK_ARG(scratch_bytes >= cpg_pair_rows_bytes(In, G * H));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pair_wT_kernel, dim3(In / 32, G * H / 32), dim3(32, 8), 0, s, W, ldw, G, H, In, (uint16_t*)scratch);
+    CPG_LAUNCH_CHECK();
+    uint16_t* img; int* ex; int* emin;
+    grad_planes_split(const_cast<void*>(gp), R, H, G, img, ex, emin);
+    PairNtArgs g{img, (size_t)2 * G * H, ex, H / 32, (const uint16_t*)scratch, (size_t)2 * G * H, 2 * G * H, dX, (size_t)lddx, nullptr, accumulate, W_PAIR_EXP};
+    const size_t smem = DlLoop<128, 128, 2, 3>::smem_floats() * sizeof(float);
+    const void* k = G == 3 ? (const void*)pair_nt_kernel<3> : (const void*)pair_nt_kernel<4>;
+    int rc = cpg_allow_big_lds(k, (int)smem);
+    if (rc) return rc;
+    if (G == 3) hipLaunchKernelGGL(pair_nt_kernel<3>, dim3(In / 128, R / 128), dim3(256), smem, s, g);
+    else hipLaunchKernelGGL(pair_nt_kernel<4>, dim3(In / 128, R / 128), dim3(256), smem, s, g);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// dW [G H, In] (+)= dGin^T . x   (x as its image [R][2 In]); workspace: cpg_pair_tn_workspace bytes (cpg_linear_bwd_weight_planes_workspace)
+CPG_EXPORT size_t cpg_linear_bwd_weight_planes_workspace(int R, int H, int G, int In) { return cpg_pair_tn_workspace(G * H, In, R); }
+CPG_EXPORT int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G, const void* ximg, int In, float* dW, int lddw, int accumulate,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(gp && ximg && dW && workspace && (G == 3 || G == 4) && cpg_planes_ok(R, G * H, In));
+    uint16_t* img; int* ex; int* emin;
+    grad_planes_split(const_cast<void*>(gp), R, H, G, img, ex, emin);
+    return cpg_pair_tn(img, (size_t)2 * G * H, ex, emin, H / 32, G, (const uint16_t*)ximg, (size_t)2 * In, dW, lddw, G * H, In, R, accumulate,
+                       (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}

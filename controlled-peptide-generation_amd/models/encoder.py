@@ -66,6 +66,13 @@ class GRUEncoder(nn.Module):
             pre = []
             keeps = self._layer_keep(l, T, (tok.shape[1] if tok is not None else dense_x.shape[1]), enc_keep, dev)
             scale = 1.0 / (1.0 - self.p_dropout) if keeps is not None else 1.0
+            ximg = None   # f16-pair image of the layer's input rows [xf | xb] (ops.Linear2PlanesFn): built once, shared by both directions
+            gates = 3 if self.cell == 'gru' else 4
+            if l > 0 and self.biGRU and keeps is None:
+                Bq = slabs[0].shape[1]
+                if ops.planes_ok(T * Bq, 2 * self.h_dim, gates * self.h_dim):
+                    with torch.no_grad():
+                        ximg = ops.pair_rows(slabs[0][1:].reshape(T * Bq, -1), slabs[1][:T].reshape(T * Bq, -1))
             for sfx, rev in self._dirs():
                 w_ih, b_ih = self._w("weight_ih", l, sfx), self._w("bias_ih", l, sfx)
                 tab = dense = None
@@ -81,6 +88,8 @@ class GRUEncoder(nn.Module):
                     if keeps is not None:                           # inter-layer dropout fused into the projection's operand load
                         dense = ops.MaskedLinear2Fn.apply(xf, keeps[0], xb, keeps[1] if self.biGRU else None, scale, w_ih,
                                                           b_ih).view(T, B, -1)
+                    elif self.biGRU and ximg is not None:
+                        dense = ops.Linear2PlanesFn.apply(xf, xb, ximg, w_ih, b_ih, gates).view(T, B, -1)
                     elif self.biGRU:
                         dense = ops.Linear2Fn.apply(xf, xb, w_ih, b_ih).view(T, B, -1)
                     else:

@@ -238,6 +238,31 @@ CPG_API int cpg_gru_wgrad_hh_ap(int T, int B, int H, const void* ap, const void*
                                 float* dw_hh, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 CPG_API int cpg_gru_dgi_reduce_ap(int T, int B, int H, const void* ap, const float* dN, const int32_t* tok, int V, float* dtab,
                                   float* dsum, float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- nn.Linear-shaped products over many rows on f16-pair plane images (round 5; csrc/planes.hip): the input projection of an upper
+ * encoder layer (models/encoder.py:25-30: nn.GRU(num_layers > 1): layer l reads the concatenated outputs of layer l-1) and its two
+ * gradients - at BASELINE.json configs[4] dimensions 27 of the step's 58 ms before.  Every operand is turned into an image ONCE by a
+ * bandwidth-bound pass (a row = 128-byte segments of [32 high halves | 32 low halves] f16: x = hi + lo, 22 significand bits) and the
+ * products run conversion-free: LDS-DMA operands, three f16 MFMAs per block, f32 accumulation - f32-grade like the f16-pair recurrence.
+ *   cpg_planes_ok(R, K, N)     1 where the forms cover a product of R rows, contraction K, N outputs (f32-grade mode, multiples of 128)
+ *   cpg_pair_rows              x = [x1 | x2] (x2 optional) f32 -> image [R][2 (C1 + C2)], unscaled (|x| <= 65504; states: |x| <= 1)
+ *   cpg_linear_fwd_planes      Y [R, N] (+)= x W^T + bias from x's image; scratch = cpg_pair_rows_bytes(N, K) bytes (W's image, x 2^8)
+ *   cpg_grad_planes            gate gradients dG [R, ldg] (G = 3 | 4 blocks of H columns at column offsets off[]) -> `gp`
+ *                              (cpg_grad_planes_bytes): image [R][2 G H] in the order (32-unit group, block) times ONE power of two per
+ *                              (32 rows x group), the exponent table, the smallest exponent per group
+ *   cpg_linear_bwd_input_planes   dX [R, In] (+)= dGin W   (W [G H, In]); scratch = cpg_pair_rows_bytes(In, G H) bytes (image of W^T)
+ *   cpg_linear_bwd_weight_planes  dW [G H, In] (+)= dGin^T x from gp and x's image (csrc/pair_tn.h); workspace per the _workspace query */
+CPG_API int cpg_planes_ok(int R, int K, int N);
+CPG_API size_t cpg_pair_rows_bytes(int R, int C);
+CPG_API int cpg_pair_rows(const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int R, void* img, void* stream);
+CPG_API int cpg_linear_fwd_planes(const void* ximg, int R, int K, const float* W, int ldw, const float* bias, float* Y, int ldy, int N,
+                                  int accumulate, void* scratch, size_t scratch_bytes, void* stream);
+CPG_API size_t cpg_grad_planes_bytes(int R, int H, int G);
+CPG_API int cpg_grad_planes(const float* dG, int ldg, int R, int H, int G, const int* off, void* gp, void* stream);
+CPG_API int cpg_linear_bwd_input_planes(const void* gp, int R, int H, int G, const float* W, int ldw, float* dX, int lddx, int In,
+                                        int accumulate, void* scratch, size_t scratch_bytes, void* stream);
+CPG_API size_t cpg_linear_bwd_weight_planes_workspace(int R, int H, int G, int In);
+CPG_API int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G, const void* ximg, int In, float* dW, int lddw, int accumulate,
+                                         void* workspace, size_t workspace_bytes, void* stream);
 /* split factor over the rows that cpg_gru_wgrad_hh_ap's product dW[M,N] over R rows runs with (bench.py: workgroups per launch) */
 CPG_API int cpg_pair_tn_split(int M, int N, int R);
 
