@@ -30,6 +30,13 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+def _stream_id():
+    """Raw handle (int) of the current stream of the current device: the key of stream-bound caches."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
     """The current HIP stream of the current device as a launch argument.  torch.cuda.current_stream() costs ~9 us of python per call
     (device-index plumbing, an os.getenv inside is_available) - 45 calls per training step, 0.4 ms of its 2.5 ms of host time
@@ -148,7 +155,7 @@ def _retire(old):
 
 def workspace(nbytes, device, tag=0):
     """Stream-keyed scratch buffer (grown on demand, reused across calls: launches on one stream are ordered)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    key = (device.index, _stream_id(), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         _retire(buf)
@@ -518,7 +525,7 @@ class Linear2PlanesFn(Function):
 
     @staticmethod
     def forward(ctx, x1, x2, ximg, w, b, gates):
-        R, K1, K2 = x1.shape[0], x1.shape[1], x2.shape[1]
+        R, K1, K2 = x1.shape[0], x1.shape[1], (x2.shape[1] if x2 is not None else 0)   # x2 None: one source (a decoder's upper layer)
         N, K = w.shape
         assert K == K1 + K2 and N % gates == 0
         wc = w.contiguous()
@@ -549,7 +556,7 @@ class Linear2PlanesFn(Function):
         nb = int(query("cpg_colsum_workspace_bytes", R, N))
         ws2 = workspace(nb, dev, tag=8)
         call("cpg_colsum_f32", _p(dy), lddy, R, N, _p(db), 0, _p(ws2), nb, _stream())
-        return dx[:, :K1], dx[:, K1:], None, dw, db, None
+        return dx[:, :K1], (dx[:, K1:] if K2 else None), None, dw, db, None
 
 
 class MaskedLinear2Fn(Function):
@@ -721,7 +728,7 @@ def _persist_entry(kind, T, B, H, dev):
     """Scratch of the persistent launches on the current stream: ONE buffer per (kind, device, stream, B, H), grown to the largest
     T seen; with it a pinned, host-mapped error word that a timed-out wave sets directly - looked at here, before the next launch
     on this scratch, without any stream operation."""
-    key = (kind, dev.index, torch.cuda.current_stream().cuda_stream, B, H)
+    key = (kind, dev.index, _stream_id(), B, H)
     ent = _persist_scratch.get(key)
     if ent is None or ent[1] < T:
         nb = query("cpg_gru_persistent_scratch_bytes" if kind == "gru" else "cpg_lstm_persistent_scratch_bytes", T, B, H)

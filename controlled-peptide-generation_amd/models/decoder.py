@@ -129,7 +129,14 @@ class GRUDecoder(nn.Module):
             # upper layer l: dense input term W_ih_l h^{l-1}_t + b_ih_l over all T*B rows, then the same recurrence from h0 = [z;c]
             w_ih, b_ih = getattr(self.rnn, f"weight_ih_l{l}"), getattr(self.rnn, f"bias_ih_l{l}")
             w_hh, b_hh = getattr(self.rnn, f"weight_hh_l{l}"), getattr(self.rnn, f"bias_hh_l{l}")
-            dense = ops.LinearFn.apply(outs.reshape(T * B, self.h_dim), w_ih, b_ih).view(T, B, -1)
+            xin = outs.reshape(T * B, self.h_dim)
+            gates = 3 if self.cell == 'gru' else 4
+            if ops.planes_ok(T * B, self.h_dim, gates * self.h_dim):   # many rows: conversion-free products on f16-pair images (csrc/planes.hip)
+                with torch.no_grad():
+                    ximg = ops.pair_rows(xin)
+                dense = ops.Linear2PlanesFn.apply(xin, None, ximg, w_ih, b_ih, gates).view(T, B, -1)
+            else:
+                dense = ops.LinearFn.apply(xin, w_ih, b_ih).view(T, B, -1)
             if self.cell == 'gru':
                 outs = ops.GruSeqFn.apply(None, None, None, dense, zc, w_hh, b_hh, T, False, True, None, True)
             else:
