@@ -29,6 +29,38 @@ def _plain(decoder):
             and not (decoder.training and decoder.p_out > 0))
 
 
+class PlaneStep:
+    """The GRU decode step on f16-pair plane images (cpg_gru_step_fwd_planes, csrc/planes.hip) for decode chains over many rows: the
+    state travels as (h f32, image), W_hh's image is built once per decode.  `ok` where the form covers (rows, H); GRU, one layer of
+    the recurrence per object (layer 0: token table + row constant)."""
+
+    def __init__(self, decoder, rows, H, lstm):
+        self.ok = (not lstm and os.environ.get("CPG_NO_STEP_PLANES", "") == "" and bool(ops.query("cpg_gru_step_planes_ok", int(rows), int(H))))
+        if not self.ok:
+            return
+        w = decoder.rnn.weight_hh_l0
+        self.wimg = torch.empty(int(ops.query("cpg_pair_rows_bytes", 3 * H, H)), device=w.device, dtype=torch.uint8)
+        call("cpg_gru_step_w_image", _p(w.contiguous()), H, _p(self.wimg), _stream())
+        self.b_hh = decoder.rnn.bias_hh_l0
+        self.rows, self.H = rows, H
+        self.img_a = self.img_b = None
+
+    def start(self, h0):
+        self.img_a = ops.pair_rows(h0)
+        self.img_b = torch.empty_like(self.img_a)
+
+    def step(self, tok, tab, rowc, h_a, h_b):
+        call("cpg_gru_step_fwd_planes", self.rows, self.H, _p(self.wimg), _p(self.b_hh), _p(tok), _p(tab), _p(rowc), _p(h_a), _p(self.img_a),
+             _p(h_b), _p(self.img_b), _stream())
+
+    def swap(self):
+        self.img_a, self.img_b = self.img_b, self.img_a
+
+    def reorder(self, origin, N, K):
+        """Beam search: the new state's image follows the back-pointers like the state itself (rows of H floats = 2H halves)."""
+        call("cpg_beam_reorder", _p(self.img_b), _p(self.img_a), _p(origin), N, K, self.H, _stream())
+
+
 class UpperLayers:
     """Layers 1..L-1 of a multi-layer decoder during a per-step decode (EXTENSION: the reference's decoder has one layer,
     models/decoder.py:40-41; semantics = torch.nn.GRU / nn.LSTM(num_layers=L), every layer starting from h0 = [z;c], c0 = 0).
@@ -186,6 +218,9 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     if lstm:
         c_a, c_b = torch.zeros_like(zc), torch.empty_like(zc)
     upper = UpperLayers(decoder, zc, lstm)
+    planes = PlaneStep(decoder, N, zc.shape[1], lstm)
+    if planes.ok:
+        planes.start(h_a)
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
     finished = torch.zeros(N, device=dev, dtype=torch.uint8)
     ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
@@ -199,6 +234,8 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         if lstm:
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
             c_a, c_b = c_b, c_a
+        elif planes.ok:
+            planes.step(tok, tab, rowc, h_a, h_b)
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
         _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, N, dev))
@@ -221,6 +258,8 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         else:
             raise ValueError(mode)
         h_a, h_b = h_b, h_a
+        if planes.ok:
+            planes.swap()
         upper.commit()
     prof.__exit__(None, None, None)
     out = _cut_at_all_finished(ids, unfinished, max_len, min_length, prepend_start_idx)
@@ -337,6 +376,9 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
     upper = UpperLayers(decoder, h_a, lstm)
     H = h_a.shape[1]
+    planes = PlaneStep(decoder, K * N, H, lstm)
+    if planes.ok:
+        planes.start(h_a)
     V = decoder.fc[1].weight.shape[0]
     i32 = dict(device=dev, dtype=torch.int32)
     scores = torch.zeros(N, K, device=dev, dtype=torch.float32)
@@ -359,6 +401,8 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
     for i in range(max_len):
         if lstm:
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
+        elif planes.ok:
+            planes.step(tok, tab, rowc, h_a, h_b)
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
         _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, K * N, dev))
@@ -367,6 +411,8 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
              _p(h_a), H, _stream())
         if lstm:   # the cell state follows the same back-pointers (Beam-major rows)
             call("cpg_beam_reorder", _p(c_b), _p(c_a), _p(origin), N, K, H, _stream())
+        if planes.ok:
+            planes.reorder(origin, N, K)   # (cpg_beam_select moved the f32 state h_b -> h_a; the image follows)
         upper.reorder(origin, N, K)   # upper layers' states follow the same back-pointers (_update_hidden, models/model.py:378-385)
         steps_run = i + 1
         if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early

@@ -170,6 +170,79 @@ __global__ __launch_bounds__(256) void pair_nt_kernel(PairNtArgs g) {
         }
 }
 
+// ---- one GRU decode step on plane images (GRUDecoder.forward_sample's recurrent part, models/decoder.py:86-99, for the per-step
+// decode chain of decoders too wide for the whole-loop kernels: CLaSS at config-B / C width).  h_{t-1} arrives as its f16-pair image
+// (written by the previous step), W_hh as an image whose rows are ordered so that a 96-row tile = r, z, n of 32 hidden units
+// (16 per wave); the product is DlLoop<128, 96, 2, 3> - no conversion in the loop (the round-4 step kernel splits both operands
+// in every tile: 0.30 of the pair roof) -, the cell runs in the accumulator layout and the new state goes out as f32 AND as the next
+// step's image.  Arithmetic of the cell = gru_step_fwd_kernel's.
+struct StepPlanesArgs {
+    const uint16_t* hp_in; uint16_t* hp_out;
+    const float* h_prev; float* h_out;
+    const uint16_t* wimg; const float* b_hh;
+    const int32_t* tok; const float* tab; const float* rowc;
+    int N, H;
+};
+__global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs g) {
+    using DL = DlLoop<128, 96, 2, 3>;
+    constexpr int MI = DL::MI, NI = DL::NI;
+    static_assert(NI == 3, "a wave holds the r, z, n blocks of its 16 hidden units");
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    int bx, by, bz;
+    xcd_tile_order(bx, by, bz);
+    const int H = g.H, m0 = by * 128, j0 = bx * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    DL::run(g.hp_in + (size_t)m0 * 2 * H, (size_t)2 * H, g.wimg + (size_t)bx * 96 * 2 * H, (size_t)2 * H, 2 * H, cpg_smem, acc, -1, []() {});
+    const float back = 1.f / (float)(1 << W_PAIR_EXP);
+    const int u = j0 + wn * 16 + l15;
+    const float bh_r = g.b_hh[u], bh_z = g.b_hh[H + u], bh_n = g.b_hh[2 * H + u];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        f32x4 hnew;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t row = (size_t)m0 + wm * 64 + mi * 16 + 4 * lq + r;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            if (g.tok) {
+                const float* t = g.tab + (size_t)g.tok[row] * 3 * H;
+                a0 += t[u]; a1 += t[H + u]; a2 += t[2 * H + u];
+            }
+            if (g.rowc) {
+                const float* t = g.rowc + row * 3 * H;
+                a0 += t[u]; a1 += t[H + u]; a2 += t[2 * H + u];
+            }
+            const float hp = g.h_prev[row * H + u];
+            const float hn = acc[mi][2][r] * back + bh_n;
+            const float rg = sigmoidf_(a0 + (acc[mi][0][r] * back + bh_r));
+            const float zg = sigmoidf_(a1 + (acc[mi][1][r] * back + bh_z));
+            const float ng = tanhf(a2 + rg * hn);
+            hnew[r] = (1.f - zg) * ng + zg * hp;
+            g.h_out[row * H + u] = hnew[r];
+        }
+        // the next step's A operand: the 16 x 16 block in row layout (lane -> row lane / 4, four consecutive units)
+        const f32x4 v = acc_block_to_rows(tb, hnew, lane);
+        pair_store4<1>(g.hp_out, (size_t)m0 + wm * 64 + mi * 16 + (lane >> 2), H, j0 + wn * 16 + 4 * (lane & 3), 0, v);
+    }
+}
+// W_hh [3H, H] -> image [3H][2H] x 2^W_PAIR_EXP with rows in tile order: image row 96 t + 48 w + 16 gate + i = W_hh row gate H + 32 t + 16 w + i
+__global__ void gru_step_w_image_kernel(const float* __restrict__ w, int H, uint16_t* __restrict__ img) {
+    const int q4 = H / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)3 * H * q4) return;
+    const int ir = (int)(i / q4), col = (int)(i - (size_t)ir * q4) * 4;
+    const int t = ir / 96, rr = ir - 96 * t, wv = rr / 48, gate = (rr - 48 * wv) / 16, ii = rr & 15;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(gate * H + 32 * t + 16 * wv + ii) * H + col);
+    pair_store4<1>(img, (size_t)ir, H, col, 0, v * (float)(1 << W_PAIR_EXP));
+}
+
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
 
 }  // namespace
@@ -263,4 +336,29 @@ CPG_EXPORT int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G,
     grad_planes_split(const_cast<void*>(gp), R, H, G, img, ex, emin);
     return cpg_pair_tn(img, (size_t)2 * G * H, ex, emin, H / 32, G, (const uint16_t*)ximg, (size_t)2 * In, dW, lddw, G * H, In, R, accumulate,
                        (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- GRU decode step on plane images (see gru_step_fwd_planes_kernel).  cpg_gru_step_planes_ok: 1 where the form covers N rows at width H
+// (f32-grade mode, N % 128 == 0, H % 128 == 0, enough rows to amortise the images).  The W_hh image (cpg_pair_rows_bytes(3H, H) bytes) is
+// built once per decode by cpg_gru_step_w_image; the state travels as (h f32 [N,H], image [N][2H]) - cpg_pair_rows makes the first image.
+CPG_EXPORT int cpg_gru_step_planes_ok(int N, int H) {
+    return (cpg_compute_mode_get() != 1 && N >= 1024 && N % 128 == 0 && H >= 128 && H % 128 == 0) ? 1 : 0;
+}
+CPG_EXPORT int cpg_gru_step_w_image(const float* w_hh, int H, void* wimg, void* stream) {
+    CPG_CHECK_ARG(w_hh && wimg && H > 0 && H % 128 == 0 && aligned16(w_hh) && aligned16(wimg));
+    const size_t n = (size_t)3 * H * (H / 4);
+    hipLaunchKernelGGL(gru_step_w_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_hh, H, (uint16_t*)wimg);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+CPG_EXPORT int cpg_gru_step_fwd_planes(int N, int H, const void* wimg, const float* b_hh, const int32_t* tok, const float* tab, const float* rowc,
+                                       const float* h_prev, const void* hp_in, float* h_out, void* hp_out, void* stream) {
+    CPG_CHECK_ARG(wimg && b_hh && h_prev && hp_in && h_out && hp_out && h_prev != h_out && hp_in != hp_out && cpg_gru_step_planes_ok(N, H));
+    StepPlanesArgs g{(const uint16_t*)hp_in, (uint16_t*)hp_out, h_prev, h_out, (const uint16_t*)wimg, b_hh, tok, tab, rowc, N, H};
+    const size_t smem = (DlLoop<128, 96, 2, 3>::smem_floats() + 4 * 256) * sizeof(float);
+    int rc = cpg_allow_big_lds((const void*)gru_step_fwd_planes_kernel, (int)smem);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gru_step_fwd_planes_kernel, dim3(H / 32, N / 128), dim3(256), smem, (hipStream_t)stream, g);
+    CPG_LAUNCH_CHECK();
+    return 0;
 }

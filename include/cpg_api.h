@@ -263,6 +263,16 @@ CPG_API int cpg_linear_bwd_input_planes(const void* gp, int R, int H, int G, con
 CPG_API size_t cpg_linear_bwd_weight_planes_workspace(int R, int H, int G, int In);
 CPG_API int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G, const void* ximg, int In, float* dW, int lddw, int accumulate,
                                          void* workspace, size_t workspace_bytes, void* stream);
+/* One GRU decode step on plane images: GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) for decode chains over MANY
+ * rows of decoders too wide for the whole-loop kernels (CLaSS at config-B / C width: models/model.py:295-363 over 10^5..10^6 rows).
+ * The state travels as (h f32 [N,H], its f16-pair image [N][2H]: cpg_pair_rows makes the first one, every step writes the next);
+ * W_hh's image (cpg_pair_rows_bytes(3H, H) bytes, rows in tile order) is built once per decode.  Same cell arithmetic and the same
+ * 22-bit operands as cpg_gru_step_fwd, no conversion in the product loop.  cpg_gru_step_planes_ok: f32-grade mode, N % 128 == 0,
+ * N >= 1024, H % 128 == 0. */
+CPG_API int cpg_gru_step_planes_ok(int N, int H);
+CPG_API int cpg_gru_step_w_image(const float* w_hh, int H, void* wimg, void* stream);
+CPG_API int cpg_gru_step_fwd_planes(int N, int H, const void* wimg, const float* b_hh, const int32_t* tok, const float* tab,
+                                    const float* rowc, const float* h_prev, const void* hp_in, float* h_out, void* hp_out, void* stream);
 /* split factor over the rows that cpg_gru_wgrad_hh_ap's product dW[M,N] over R rows runs with (bench.py: workgroups per launch) */
 CPG_API int cpg_pair_tn_split(int M, int N, int R);
 

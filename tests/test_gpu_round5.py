@@ -318,6 +318,47 @@ def test_beam_wider_than_eight_vs_oracle(golden, K, n_best):
         m.generate_sentences(N, cu(z), cu(c), sample_mode='beam', beam_size=33, n_best=3)
 
 
+@pytest.mark.parametrize("Z,T,N,NB", [(510, 25, 2048, 256), (1022, 50, 1024, 256)], ids=["config-B-width", "config-C-width"])
+def test_plane_step_decode_chain_vs_oracle(Z, T, N, NB):
+    """The GRU decode step on plane images (cpg_gru_step_fwd_planes, csrc/planes.hip: the per-step chain of sample_G for decoders too wide
+    for the whole-loop kernels, taken from 1024 rows up - CLaSS at config-B / C width) against the oracle: greedy ids of N z BIT-EXACT,
+    beam-5 / n-best-3 hypotheses of NB z (5 NB = 1280 rows through the plane step, images re-gathered by back-pointer) EXACT, with
+    hypotheses of several lengths.  models/model.py:295-363, models/decoder.py:86-99."""
+    from bench import model_kwargs
+    from cpg import decode as cdecode
+    from models.model import RNN_VAE
+    from models.mutils import EOS_IDX
+    from oracle import decode as odec
+    dev = torch.device("cuda")
+    torch.manual_seed(Z + 3)
+    m = RNN_VAE(n_vocab=24, max_seq_len=T, **model_kwargs(Z, 32)).to(dev)
+    m.device = dev
+    with torch.no_grad():
+        m.decoder.fc[1].bias[EOS_IDX] += 0.5
+    P = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    assert cdecode.PlaneStep(m.decoder, N, Z + 2, False).ok and cdecode.PlaneStep(m.decoder, 5 * NB, Z + 2, False).ok
+    rs = np.random.RandomState(Z)
+    z = rs.randn(N, Z).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+    ids, _, _ = m.generate_sentences(N, cu(z), cu(c), sample_mode='greedy')
+    ref = odec.greedy(P, z, c, T)
+    assert np.array_equal(ids.cpu().numpy(), ref)
+    got, _, _ = m.generate_sentences(NB, cu(z[:NB]), cu(c[:NB]), sample_mode='beam', beam_size=5, n_best=3)
+    hyps, _, margins = odec.beam(P, z[:NB], c[:NB], T, beam_size=5, n_best=3, return_margins=True)
+    bad = [i for i in range(NB) if [list(map(int, h)) for h in got[i]] != hyps[i]]
+    assert not bad, (bad, [margins[i] for i in bad])
+    assert len({len(h) for s_ in hyps for h in s_}) >= 4
+    # and the same decode with the form switched off (the round-4 step kernel) gives the same ids
+    import os
+    os.environ["CPG_NO_STEP_PLANES"] = "1"
+    try:
+        ids2, _, _ = m.generate_sentences(N, cu(z), cu(c), sample_mode='greedy')
+    finally:
+        del os.environ["CPG_NO_STEP_PLANES"]
+    assert torch.equal(ids, ids2)
+
+
 # ------------------------------------------------------------------------------------------------ CLaSS at 10^6 rows
 def _clf(coef, icpt):
     from sklearn.linear_model import LogisticRegression
