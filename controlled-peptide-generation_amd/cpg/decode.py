@@ -49,15 +49,18 @@ class PlaneStep:
         self.img_a = ops.pair_rows(h0)
         self.img_b = torch.empty_like(self.img_a)
 
-    def step(self, tok, tab, rowc, h_a, h_b):
-        call("cpg_gru_step_fwd_planes", self.rows, self.H, _p(self.wimg), _p(self.b_hh), _p(tok), _p(tab), _p(rowc), _p(h_a), _p(self.img_a),
-             _p(h_b), _p(self.img_b), _stream())
+    def step(self, tok, tab, rowc, h_a, h_b, origin=None, nsent=0, K=0):
+        """rowc: [rows, 3H], or [nsent, 3H] shared by the K beam-major rows of a sentence.  origin ([nsent, K] back-pointers of the
+        previous Beam.advance, or None): the previous state - f32 AND image - is gathered through it (models/model.py:378-385)."""
+        call("cpg_gru_step_fwd_planes", self.rows, self.H, _p(self.wimg), _p(self.b_hh), _p(tok), _p(tab), _p(rowc), rowc.shape[0], _p(h_a),
+             _p(self.img_a), _p(origin), nsent, K, _p(h_b), _p(self.img_b), _stream())
 
     def swap(self):
         self.img_a, self.img_b = self.img_b, self.img_a
 
     def reorder(self, origin, N, K):
-        """Beam search: the new state's image follows the back-pointers like the state itself (rows of H floats = 2H halves)."""
+        """Explicit re-gather of the new image by back-pointer (rows of H floats = 2H halves): only where the step cannot fold it
+        (multi-layer decoders: the upper layers' dense steps read re-gathered states)."""
         call("cpg_beam_reorder", _p(self.img_b), _p(self.img_a), _p(origin), N, K, self.H, _stream())
 
 
@@ -377,8 +380,10 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
     upper = UpperLayers(decoder, h_a, lstm)
     H = h_a.shape[1]
     planes = PlaneStep(decoder, K * N, H, lstm)
+    fold = planes.ok and not upper      # the plane step gathers its previous state through the back-pointers: Beam.advance moves no state
     if planes.ok:
         planes.start(h_a)
+        rowc1 = rowc1.contiguous()
     V = decoder.fc[1].weight.shape[0]
     i32 = dict(device=dev, dtype=torch.int32)
     scores = torch.zeros(N, K, device=dev, dtype=torch.float32)
@@ -402,17 +407,22 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
         if lstm:
             ops.lstm_step(tok, tab, rowc, h_a, c_a, h_b, c_b, w_hh, b_hh)
         elif planes.ok:
-            planes.step(tok, tab, rowc, h_a, h_b)
+            # the step reads its previous state THROUGH the back-pointers of the previous Beam.advance (no separate re-gather pass over
+            # the f32 state and its image), and the constant input term once per sentence instead of once per beam row
+            planes.step(tok, tab, rowc1, h_a, h_b, origin if (fold and i > 0) else None, N, K)
         else:
             ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
         _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, K * N, dev))
         call("cpg_beam_select", _p(logits), N, V, K, i, n_best, min_length, START_IDX, EOS_IDX, _p(scores), _p(last_tok),
-             _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active), _p(h_b),
-             _p(h_a), H, _stream())
+             _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active),
+             None if fold else _p(h_b), None if fold else _p(h_a), 0 if fold else H, _stream())
+        if fold:
+            h_a, h_b = h_b, h_a
+            planes.swap()
+        elif planes.ok:
+            planes.reorder(origin, N, K)   # (cpg_beam_select moved the f32 state h_b -> h_a; the image follows)
         if lstm:   # the cell state follows the same back-pointers (Beam-major rows)
             call("cpg_beam_reorder", _p(c_b), _p(c_a), _p(origin), N, K, H, _stream())
-        if planes.ok:
-            planes.reorder(origin, N, K)   # (cpg_beam_select moved the f32 state h_b -> h_a; the image follows)
         upper.reorder(origin, N, K)   # upper layers' states follow the same back-pointers (_update_hidden, models/model.py:378-385)
         steps_run = i + 1
         if (i % 8) == 7 and int(n_active[i].item()) == 0:  # all beams done (model.py:364-366): stop early

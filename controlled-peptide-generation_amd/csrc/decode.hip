@@ -305,7 +305,8 @@ CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int ste
                                int32_t* hist_prev, float* hist_score, int32_t* origin, int32_t* tok_next, int* n_active,
                                const float* h_in, float* h_out, int H, void* stream) {
     CPG_CHECK_ARG(logits && scores && last_tok && n_finished && done && hist_tok && hist_prev && hist_score && origin);
-    CPG_CHECK_ARG(N > 0 && V > 0 && K > 0 && K <= CPG_MAX_BEAM && h_in && h_out && h_in != h_out && tok_next && n_active);
+    CPG_CHECK_ARG(N > 0 && V > 0 && K > 0 && K <= CPG_MAX_BEAM && tok_next && n_active && H >= 0);
+    CPG_CHECK_ARG(H == 0 || (h_in && h_out && h_in != h_out));   // H = 0: no state is moved (the next plane step gathers through origin)
     hipStream_t s = (hipStream_t)stream;
     CPG_CHECK_ARG(K <= V);   // the first step ranks the V children of beam 0 only (topk(size) over V candidates, models/Beam.py:82-84)
 #define CPG_BEAM_LAUNCH(VR, KM)                                                                                                      \
@@ -320,6 +321,7 @@ CPG_EXPORT int cpg_beam_select(const float* logits, int N, int V, int K, int ste
     }
 #undef CPG_BEAM_LAUNCH
     CPG_LAUNCH_CHECK();
+    if (H == 0) return 0;
     const size_t n = (size_t)K * N * H;
     hipLaunchKernelGGL(beam_reorder_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h_in, h_out, origin, N, K, H);
     CPG_LAUNCH_CHECK();

@@ -906,6 +906,14 @@ struct DlLoop {
     template <class Hook, class E, class Pre, class FS>
     __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
                                                f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre, FS&& fscale) {
+        run(A, lda, Bt, ldb, K, smem, acc, hook_kt, hook, pre, fscale, DlNoScale{});
+    }
+    // arow (optional): const E* arow(i, r) = start of the A row that tile row 32 i + r (r = this thread's tid / 8) is GATHERED from -
+    // an LDS-DMA lane supplies its own global address, so a row-gathered A operand (beam search: states re-gathered by back-pointer,
+    // planes.hip) costs nothing in the loop
+    template <class Hook, class E, class Pre, class FS, class AR>
+    __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
+                                               f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre, FS&& fscale, AR&& arow) {
         static_assert((PREC >= 2) == (sizeof(E) == 2), "PREC 2 / 3 <-> 16-bit operands in memory");
         constexpr int EPC = 16 / (int)sizeof(E);   // elements per 16-byte chunk
         constexpr int BKE = 8 * EPC;               // elements per slab (a row of a slab is always 128 bytes)
@@ -920,10 +928,16 @@ struct DlLoop {
         const E* ga = A + (size_t)srow * lda + EPC * sch;
         const E* gb = Bt + (size_t)srow * ldb + EPC * sch;
         const size_t ga32 = 32 * lda, gb32 = 32 * ldb;
+        const E* gar[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (__is_same(__remove_cvref(AR), DlNoScale)) gar[i] = ga + i * ga32;
+            else gar[i] = arow(i, srow) + EPC * sch;
+        }
         auto issue = [&](int kt, float* stage) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                __builtin_amdgcn_global_load_lds(ga + i * ga32 + kt * BKE, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gar[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
                 __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * BKE, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);

@@ -182,6 +182,9 @@ struct StepPlanesArgs {
     const uint16_t* wimg; const float* b_hh;
     const int32_t* tok; const float* tab; const float* rowc;
     int N, H;
+    int rowc_rows;            // rowc holds this many rows, row r reads rowc[r % rowc_rows] (beam-major rows k N + i share sentence i's term)
+    const int32_t* origin;    // beam search: [nsent][K] back-pointers - row k nsent + i takes its previous state from row origin[i][k] nsent + i
+    int nsent, K;             // (the re-gather of _update_hidden, models/model.py:378-385, folded into the operand loads); null: identity
 };
 __global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs g) {
     using DL = DlLoop<128, 96, 2, 3>;
@@ -200,7 +203,27 @@ __global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    DL::run(g.hp_in + (size_t)m0 * 2 * H, (size_t)2 * H, g.wimg + (size_t)bx * 96 * 2 * H, (size_t)2 * H, 2 * H, cpg_smem, acc, -1, []() {});
+    // rows are beam-major (row = k nsent + i): sentence and beam of the tile's 128 consecutive rows without a division per element
+    // (64-bit div / mod per gathered element doubled the launch time) - one scalar division per workgroup, then a conditional subtract
+    // (nsent >= 128 here: cpg_gru_step_fwd_planes checks it); ns = the period of rowc as well (rowc_rows; N when rowc has a row per row)
+    const unsigned ns = g.origin ? (unsigned)g.nsent : (unsigned)g.rowc_rows;
+    const unsigned k0 = (unsigned)m0 / ns, i0 = (unsigned)m0 - k0 * ns;
+    auto sent_beam = [&](unsigned d, unsigned& i, unsigned& k) {   // row m0 + d, d < 128
+        i = i0 + d;
+        k = k0;
+        if (i >= ns) { i -= ns; ++k; }
+    };
+    auto src_row = [&](unsigned d) -> size_t {
+        if (!g.origin) return (size_t)m0 + d;
+        unsigned i, k;
+        sent_beam(d, i, k);
+        return (size_t)g.origin[(size_t)i * g.K + k] * ns + i;
+    };
+    if (g.origin)
+        DL::run(g.hp_in, (size_t)2 * H, g.wimg + (size_t)bx * 96 * 2 * H, (size_t)2 * H, 2 * H, cpg_smem, acc, -1, []() {}, [](int) { return true; },
+                DlNoScale{}, [&](int i, int r) { return g.hp_in + src_row((unsigned)(32 * i + r)) * 2 * H; });
+    else
+        DL::run(g.hp_in + (size_t)m0 * 2 * H, (size_t)2 * H, g.wimg + (size_t)bx * 96 * 2 * H, (size_t)2 * H, 2 * H, cpg_smem, acc, -1, []() {});
     const float back = 1.f / (float)(1 << W_PAIR_EXP);
     const int u = j0 + wn * 16 + l15;
     const float bh_r = g.b_hh[u], bh_z = g.b_hh[H + u], bh_n = g.b_hh[2 * H + u];
@@ -209,17 +232,20 @@ __global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs
         f32x4 hnew;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const size_t row = (size_t)m0 + wm * 64 + mi * 16 + 4 * lq + r;
+            const unsigned d = (unsigned)(wm * 64 + mi * 16 + 4 * lq + r);
+            const size_t row = (size_t)m0 + d;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             if (g.tok) {
                 const float* t = g.tab + (size_t)g.tok[row] * 3 * H;
                 a0 += t[u]; a1 += t[H + u]; a2 += t[2 * H + u];
             }
+            unsigned si, sk;
+            sent_beam(d, si, sk);
             if (g.rowc) {
-                const float* t = g.rowc + row * 3 * H;
+                const float* t = g.rowc + (size_t)(g.rowc_rows == g.N ? row : si) * 3 * H;
                 a0 += t[u]; a1 += t[H + u]; a2 += t[2 * H + u];
             }
-            const float hp = g.h_prev[row * H + u];
+            const float hp = g.h_prev[(g.origin ? (size_t)g.origin[(size_t)si * g.K + sk] * ns + si : row) * H + u];
             const float hn = acc[mi][2][r] * back + bh_n;
             const float rg = sigmoidf_(a0 + (acc[mi][0][r] * back + bh_r));
             const float zg = sigmoidf_(a1 + (acc[mi][1][r] * back + bh_z));
@@ -352,9 +378,13 @@ CPG_EXPORT int cpg_gru_step_w_image(const float* w_hh, int H, void* wimg, void* 
     return 0;
 }
 CPG_EXPORT int cpg_gru_step_fwd_planes(int N, int H, const void* wimg, const float* b_hh, const int32_t* tok, const float* tab, const float* rowc,
-                                       const float* h_prev, const void* hp_in, float* h_out, void* hp_out, void* stream) {
+                                       int rowc_rows, const float* h_prev, const void* hp_in, const int32_t* origin, int nsent, int K,
+                                       float* h_out, void* hp_out, void* stream) {
     CPG_CHECK_ARG(wimg && b_hh && h_prev && hp_in && h_out && hp_out && h_prev != h_out && hp_in != hp_out && cpg_gru_step_planes_ok(N, H));
-    StepPlanesArgs g{(const uint16_t*)hp_in, (uint16_t*)hp_out, h_prev, h_out, (const uint16_t*)wimg, b_hh, tok, tab, rowc, N, H};
+    CPG_CHECK_ARG((!rowc || (rowc_rows >= 128 && N % rowc_rows == 0)) && (!origin || (nsent >= 128 && K > 0 && (long)nsent * K == N)));
+    CPG_CHECK_ARG(!origin || !rowc || rowc_rows == nsent || rowc_rows == N);
+    StepPlanesArgs g{(const uint16_t*)hp_in, (uint16_t*)hp_out, h_prev, h_out, (const uint16_t*)wimg, b_hh, tok, tab, rowc, N, H,
+                     rowc ? rowc_rows : N, origin, nsent, K};
     const size_t smem = (DlLoop<128, 96, 2, 3>::smem_floats() + 4 * 256) * sizeof(float);
     int rc = cpg_allow_big_lds((const void*)gru_step_fwd_planes_kernel, (int)smem);
     if (rc) return rc;

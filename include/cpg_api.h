@@ -268,11 +268,16 @@ CPG_API int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G, co
  * The state travels as (h f32 [N,H], its f16-pair image [N][2H]: cpg_pair_rows makes the first one, every step writes the next);
  * W_hh's image (cpg_pair_rows_bytes(3H, H) bytes, rows in tile order) is built once per decode.  Same cell arithmetic and the same
  * 22-bit operands as cpg_gru_step_fwd, no conversion in the product loop.  cpg_gru_step_planes_ok: f32-grade mode, N % 128 == 0,
- * N >= 1024, H % 128 == 0. */
+ * N >= 1024, H % 128 == 0.  cpg_beam_select with H = 0 advances the beams WITHOUT moving any state (h_in / h_out ignored): the next
+ * plane step gathers through `origin`. */
 CPG_API int cpg_gru_step_planes_ok(int N, int H);
 CPG_API int cpg_gru_step_w_image(const float* w_hh, int H, void* wimg, void* stream);
 CPG_API int cpg_gru_step_fwd_planes(int N, int H, const void* wimg, const float* b_hh, const int32_t* tok, const float* tab,
-                                    const float* rowc, const float* h_prev, const void* hp_in, float* h_out, void* hp_out, void* stream);
+                                    const float* rowc, int rowc_rows /* row r reads rowc[r % rowc_rows]: beam-major rows share a sentence's term */,
+                                    const float* h_prev, const void* hp_in,
+                                    const int32_t* origin /* [nsent][K] beam back-pointers or null: row k nsent + i takes its previous state (h_prev
+                                    AND image) from row origin[i][k] nsent + i - _update_hidden (models/model.py:378-385) folded into the loads */,
+                                    int nsent, int K, float* h_out, void* hp_out, void* stream);
 /* split factor over the rows that cpg_gru_wgrad_hh_ap's product dW[M,N] over R rows runs with (bench.py: workgroups per launch) */
 CPG_API int cpg_pair_tn_split(int M, int N, int R);
 
