@@ -972,10 +972,11 @@ class GruBiSeqFn(Function):
         cont = lambda t: t.contiguous() if t is not None else None
         wf, bf, wr, br = cont(w_hh_f), cont(b_hh_f), cont(w_hh_r), cont(b_hh_r)
         tf, tr, df, dr = cont(tab_f), cont(tab_r), cont(dense_f), cont(dense_r)
-        hs_f = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
-        hs_r = torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
-        hs_f[0].zero_()
-        hs_r[T].zero_()
+        # one allocation [reverse | forward]: the two zero initial states (slot T of the reverse slab, slot 0 of the forward one) are
+        # adjacent - one fill launch
+        hs2 = torch.empty(2 * (T + 1), B, H, device=dev, dtype=torch.float32)
+        hs_r, hs_f = hs2[:T + 1], hs2[T + 1:]
+        hs2[T:T + 2].zero_()
         need_grad = any(t is not None and t.requires_grad for t in (tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r))
         g_f = torch.empty(T, 4, B, H, device=dev, dtype=gates_dtype(B, H)) if need_grad else None
         g_r = torch.empty(T, 4, B, H, device=dev, dtype=gates_dtype(B, H)) if need_grad else None
@@ -1192,9 +1193,11 @@ class LstmBiSeqFn(Function):
         cont = lambda t: t.contiguous() if t is not None else None
         wf, bf, wr, br = cont(w_hh_f), cont(b_hh_f), cont(w_hh_r), cont(b_hh_r)
         tf, tr, df, dr = cont(tab_f), cont(tab_r), cont(dense_f), cont(dense_r)
-        mk = lambda: torch.empty(T + 1, B, H, device=dev, dtype=torch.float32)
-        hs_f, hs_r, cs_f, cs_r = mk(), mk(), mk(), mk()
-        hs_f[0].zero_(), cs_f[0].zero_(), hs_r[T].zero_(), cs_r[T].zero_()
+        # [reverse | forward] per slab: the zero initial slots (T of the reverse half, 0 of the forward half) are adjacent - one fill each
+        hs2 = torch.empty(2 * (T + 1), B, H, device=dev, dtype=torch.float32)
+        cs2 = torch.empty(2 * (T + 1), B, H, device=dev, dtype=torch.float32)
+        hs_r, hs_f, cs_r, cs_f = hs2[:T + 1], hs2[T + 1:], cs2[:T + 1], cs2[T + 1:]
+        hs2[T:T + 2].zero_(), cs2[T:T + 2].zero_()
         need_grad = any(t is not None and t.requires_grad for t in (tab_f, tab_r, dense_f, dense_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r))
         g_f = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
         g_r = torch.empty(T, 4, B, H, device=dev, dtype=torch.float32) if need_grad else None
@@ -1603,6 +1606,13 @@ def rng_bernoulli(shape, p_one, seed, offset, device, base=None):
     return out
 
 
+def rng_onehot2(n, p_one, seed, offset, device, base=None):
+    """One-hot float rows [n,2] of the draws rng_bernoulli((n,), p_one, ...) makes (cpg_rng_onehot2)."""
+    out = torch.empty(n, 2, device=device, dtype=torch.float32)
+    call("cpg_rng_onehot2", _p(out), int(n), float(p_one), int(seed), int(offset), _p(base), _stream())
+    return out
+
+
 class DeviceRng:
     """Counter-based device streams of one model (Philox4x32-10, cpg_rng_*): every draw takes the next counter range.  The
     counter is split in two: a host-side offset RELATIVE to the current training step and a device-side base that `end_step()`
@@ -1637,6 +1647,11 @@ class DeviceRng:
             n *= int(d)
         seed, off = self.next(n)
         return rng_bernoulli(shape, p_one, seed, off, device, self.base_for(device))
+
+    def onehot2(self, n, p_one, device):
+        """c ~ Cat([1 - p_one, p_one]) as one-hot float rows [n,2]: the draws of bernoulli((n,), p_one), one launch."""
+        seed, off = self.next(int(n))
+        return rng_onehot2(n, p_one, seed, off, device, self.base_for(device))
 
     def end_step(self):
         """Close the current step: the device base moves past everything drawn since the last call, offsets restart at 0."""

@@ -171,8 +171,11 @@ class FusedAdamClip:
         """loss.backward() in the fused form (cpg.ops.backward_scope): direct accumulation into the flat gradient buffer, the
         decoder's dW_hh on the side stream, bucket all-reduces started from the gradient boundaries."""
         cb = self.reducer.on_boundary if self.reducer.overlapped else None
+        one = self._one if getattr(self, "_one", None) is not None and self._one.device == loss.device and loss.dim() == 0 else None
+        if one is None and loss.dim() == 0 and loss.dtype == torch.float32:
+            one = self._one = torch.ones((), device=loss.device, dtype=torch.float32)   # the root gradient, built once (not one fill per step)
         with ops.backward_scope(cb, root=loss):   # boundaries are counted on loss's own graph: same decision on every rank
-            loss.backward()
+            loss.backward(one)
 
     def _finish_reduce(self):
         self.reducer.finish()

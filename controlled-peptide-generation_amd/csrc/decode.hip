@@ -11,9 +11,292 @@ CPG_EXPORT int cpg_vocab_fc_fwd(const float* hs, const uint8_t* keep, float scal
     return cpg_gemm_nt(hs, H, keep, scale, w, H, b, logits, V, R, V, H, 0, (hipStream_t)stream);
 }
 
+// ---- backward for small vocabularies (V <= 32: the peptide alphabet has 24 symbols) -----------------------------------------
+// dhs = (dlogits W) .* keep is a K = V product whose output (R x H f32: 105 MB at config B) is the whole cost, and dw = dlogits^T hs
+// an M = V product that reads hs once; on the tile engine the two took 79 + 43 us (+ 41 us of reductions) at config B - staging
+// 32-deep slabs for a 24-deep contraction.  Here a wave owns 256 columns (one float4 per lane): W's / the accumulators' V float4
+// live in registers, a row's V gradient values are wave-uniform (scalar loads), the arithmetic is plain f32 FMA (exact products,
+// f32 accumulation in row order), rows stream through with four in flight per wave.
+__device__ __forceinline__ float lane_value(float x, int l) {   // x of lane l (compile-time l) as a wave-uniform value
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
+template <int VV, bool MASK>
+__global__ __launch_bounds__(256) void vocab_bwd_dh_kernel(const float* __restrict__ dl, const uint8_t* __restrict__ keep, float scale,
+                                                           const float* __restrict__ w, float* __restrict__ dhs, int R, int H, int V) {
+    constexpr int NR = 8;   // rows per trip; the next trip's loads are issued before this trip's arithmetic (no branch in the pipelined loop)
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int nqb = H >> 8, nrs = (gridDim.x * 4) / nqb;   // 256-column blocks, row streams
+    const int qb = gw % nqb, rs = gw / nqb;
+    const int col = qb * 256 + 4 * lane;
+    const bool lvok = lane < V;
+    const int lv = lvok ? lane : 0;
+    float4 wv[VV];
+#pragma unroll
+    for (int v = 0; v < VV; ++v) wv[v] = v < V ? *reinterpret_cast<const float4*>(w + (size_t)v * H + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint8_t* kbase = MASK ? keep + col : nullptr;
+    struct Trip {
+        uchar4 kp[NR];
+        float dv[NR];   // lane v holds dlogits[row][v] (0 from lane V on)
+    };
+    auto load = [&](int rb, Trip& t) {   // rows rb + j nrs, all < R
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const size_t r = (size_t)(rb + j * nrs);
+            if constexpr (MASK) t.kp[j] = *reinterpret_cast<const uchar4*>(kbase + r * H);
+            t.dv[j] = dl[r * V + lv];
+        }
+    };
+    auto row = [&](int r, uchar4 kp, float dv) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        dv = lvok ? dv : 0.f;
+#pragma unroll
+        for (int v = 0; v < VV; ++v) {
+            const float g = lane_value(dv, v);
+            a.x = fmaf(g, wv[v].x, a.x);
+            a.y = fmaf(g, wv[v].y, a.y);
+            a.z = fmaf(g, wv[v].z, a.z);
+            a.w = fmaf(g, wv[v].w, a.w);
+        }
+        if constexpr (MASK) {
+            a.x *= kp.x ? scale : 0.f;
+            a.y *= kp.y ? scale : 0.f;
+            a.z *= kp.z ? scale : 0.f;
+            a.w *= kp.w ? scale : 0.f;
+        }
+        *reinterpret_cast<float4*>(dhs + (size_t)r * H + col) = a;
+    };
+    auto work = [&](int rb, const Trip& t) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) row(rb + j * nrs, t.kp[j], t.dv[j]);
+    };
+    const int cnt = rs < R ? (R - rs + nrs - 1) / nrs : 0;   // rows of this stream: rs + i nrs
+    const int npair = cnt / (2 * NR);                          // pipelined part: pairs of trips
+    const int step = NR * nrs;
+    if (npair > 0) {
+        Trip ta, tb;
+        load(rs, ta);
+        for (int p = 0; p < npair; ++p) {
+            const int rb = rs + 2 * p * step;
+            const int nx = rs + 2 * (p + 1 < npair ? p + 1 : p) * step;   // the last pair re-loads itself: no branch around the loads
+            load(rb + step, tb);
+            work(rb, ta);
+            load(nx, ta);
+            work(rb + step, tb);
+        }
+    }
+    for (int i = npair * 2 * NR; i < cnt; ++i) {
+        const size_t r = (size_t)(rs + i * nrs);
+        uchar4 kp = make_uchar4(1, 1, 1, 1);
+        if constexpr (MASK) kp = *reinterpret_cast<const uchar4*>(kbase + r * H);
+        row((int)r, kp, dl[r * V + lv]);
+    }
+}
+
+// part[g][v][:] = sum over the rows of workgroup g of dlogits[r][v] * (hs[r][:] .* keep*scale); part_db[g'][v] = sum of dlogits[r][v].
+// A workgroup's four waves are min(H/256, 4) column blocks x row lanes; the row lanes are summed through LDS in lane order.
+template <int VV, bool MASK>
+__global__ __launch_bounds__(256) void vocab_bwd_dw_kernel(const float* __restrict__ dl, const float* __restrict__ hs,
+                                                           const uint8_t* __restrict__ keep, float scale, float* __restrict__ part,
+                                                           float* __restrict__ part_db, int R, int H, int V, int rows_per_wg) {
+    constexpr int NR = 4;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    float4* red = reinterpret_cast<float4*>(cpg_smem);   // [qpw][VV][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nqb = H >> 8, qpw = nqb < 4 ? nqb : 4, nrl = 4 / qpw;
+    const int ql = wave % qpw, rl = wave / qpw;
+    const int qb = blockIdx.y * qpw + ql;
+    const int col = qb * 256 + 4 * lane;
+    const int r0 = blockIdx.x * rows_per_wg + rl, r1 = min(R, (int)(blockIdx.x + 1) * rows_per_wg);
+    const bool lvok = lane < V;
+    const int lv = lvok ? lane : 0;
+    float4 acc[VV];
+#pragma unroll
+    for (int v = 0; v < VV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dbacc = 0.f;
+    const uint8_t* kbase = MASK ? keep + col : nullptr;
+    struct Trip {
+        float4 hv[NR];
+        uchar4 kp[NR];
+        float dv[NR];
+    };
+    auto load = [&](int rb, Trip& t) {   // rows rb + j nrl, all < r1
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const size_t r = (size_t)(rb + j * nrl);
+            t.hv[j] = *reinterpret_cast<const float4*>(hs + r * H + col);
+            if constexpr (MASK) t.kp[j] = *reinterpret_cast<const uchar4*>(kbase + r * H);
+            t.dv[j] = dl[r * V + lv];
+        }
+    };
+    auto row = [&](float4 h, uchar4 kp, float dv) {
+        dv = lvok ? dv : 0.f;
+        if constexpr (MASK) {
+            h.x *= kp.x ? scale : 0.f;
+            h.y *= kp.y ? scale : 0.f;
+            h.z *= kp.z ? scale : 0.f;
+            h.w *= kp.w ? scale : 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < VV; ++v) {
+            const float g = lane_value(dv, v);
+            acc[v].x = fmaf(g, h.x, acc[v].x);
+            acc[v].y = fmaf(g, h.y, acc[v].y);
+            acc[v].z = fmaf(g, h.z, acc[v].z);
+            acc[v].w = fmaf(g, h.w, acc[v].w);
+        }
+        dbacc += dv;
+    };
+    auto work = [&](const Trip& t) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) row(t.hv[j], t.kp[j], t.dv[j]);
+    };
+    const int cnt = r0 < r1 ? (r1 - r0 + nrl - 1) / nrl : 0;
+    const int npair = cnt / (2 * NR);
+    const int step = NR * nrl;
+    if (npair > 0) {
+        Trip ta, tb;
+        load(r0, ta);
+        for (int p = 0; p < npair; ++p) {
+            const int rb = r0 + 2 * p * step;
+            const int nx = r0 + 2 * (p + 1 < npair ? p + 1 : p) * step;
+            load(rb + step, tb);
+            work(ta);
+            load(nx, ta);
+            work(tb);
+        }
+    }
+    for (int i = npair * 2 * NR; i < cnt; ++i) {
+        const size_t r = (size_t)(r0 + i * nrl);
+        uchar4 kp = make_uchar4(1, 1, 1, 1);
+        if constexpr (MASK) kp = *reinterpret_cast<const uchar4*>(kbase + r * H);
+        row(*reinterpret_cast<const float4*>(hs + r * H + col), kp, dl[r * V + lv]);
+    }
+    for (int l = 1; l < nrl; ++l) {
+        if (rl == l) {
+#pragma unroll
+            for (int v = 0; v < VV; ++v) red[(ql * VV + v) * 64 + lane] = acc[v];
+        }
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int v = 0; v < VV; ++v) {
+                const float4 t = red[(ql * VV + v) * 64 + lane];
+                acc[v].x += t.x;
+                acc[v].y += t.y;
+                acc[v].z += t.z;
+                acc[v].w += t.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (rl == 0) {
+#pragma unroll
+        for (int v = 0; v < VV; ++v)
+            if (v < V) *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * V + v) * H + col) = acc[v];
+    }
+    if (qb == 0 && lane < 32) part_db[((size_t)blockIdx.x * nrl + rl) * 32 + lane] = dbacc;
+}
+
+// dw[v][c] (+)= sum_g part[g][v][c], db[v] (+)= sum_g part_db[g][v]: 32 float4 columns x 32 slab lanes per block, fixed order.
+__global__ __launch_bounds__(1024) void vocab_bwd_final_kernel(const float* __restrict__ part, const float* __restrict__ part_db, int G, int GDB,
+                                                               int V, int H, float* dw, float* db, int accumulate) {
+    __shared__ float4 red[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int nq = V * H / 4;
+    const int nblk = (nq + 31) / 32;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((int)blockIdx.x < nblk) {
+        const int q = blockIdx.x * 32 + tx;
+        if (q < nq)
+            for (int g = ty; g < G; g += 32) {
+                const float4 t = *reinterpret_cast<const float4*>(part + ((size_t)g * nq + q) * 4);
+                s.x += t.x;
+                s.y += t.y;
+                s.z += t.z;
+                s.w += t.w;
+            }
+    } else if (tx < V) {   // the bias block: one column per tx
+        for (int g = ty; g < GDB; g += 32) s.x += part_db[(size_t)g * 32 + tx];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+        float4 t = red[0][tx];
+#pragma unroll
+        for (int j = 1; j < 32; ++j) {
+            t.x += red[j][tx].x;
+            t.y += red[j][tx].y;
+            t.z += red[j][tx].z;
+            t.w += red[j][tx].w;
+        }
+        if ((int)blockIdx.x < nblk) {
+            const int q = blockIdx.x * 32 + tx;
+            if (q < nq && dw) {
+                float4* o = reinterpret_cast<float4*>(dw) + q;
+                if (accumulate) {
+                    const float4 c = *o;
+                    t.x += c.x;
+                    t.y += c.y;
+                    t.z += c.z;
+                    t.w += c.w;
+                }
+                *o = t;
+            }
+        } else if (tx < V && db) {
+            db[tx] = accumulate ? db[tx] + t.x : t.x;
+        }
+    }
+}
+
+// the streaming form covers: V <= 32, H a multiple of 256, enough rows to fill the chip; CPG_VOCAB_BWD=gemm keeps the tile engine
+static bool vocab_bwd_streams(int R, int H, int V) {
+    static const bool off = [] { const char* e = getenv("CPG_VOCAB_BWD"); return e && !strcmp(e, "gemm"); }();
+    return !off && V <= 32 && H % 256 == 0 && (H / 256 <= 4 || (H / 256) % 4 == 0) && R >= 4096;
+}
+static int vocab_bwd_wgs(int R) {
+    int g = 2 * cpg_device_cus();
+    if (g > R / 32) g = R / 32;
+    return g < 1 ? 1 : g;
+}
+
 CPG_EXPORT size_t cpg_vocab_fc_bwd_workspace(int R, int H, int V) {
     size_t a = cpg_gemm_tn_workspace(R, V, H), b = cpg_colsum_workspace(R, V);
-    return (a > b ? a : b) + 256;
+    size_t c = vocab_bwd_streams(R, H, V) ? (size_t)vocab_bwd_wgs(R) * ((size_t)V * H + 4 * 32) * sizeof(float) : 0;
+    a = a > b ? a : b;
+    return (a > c ? a : c) + 256;
+}
+
+template <int VV>
+static int vocab_bwd_launch(const float* dl, const float* hs, const uint8_t* keep, float scale, const float* w, float* dhs, float* dw, float* db,
+                            int R, int H, int V, int accumulate, float* ws, hipStream_t s) {
+    if (dhs) {
+        int g = 2 * cpg_device_cus();
+        while ((g * 4) % (H / 256)) ++g;
+        if (keep)
+            hipLaunchKernelGGL((vocab_bwd_dh_kernel<VV, true>), dim3(g), dim3(256), 0, s, dl, keep, scale, w, dhs, R, H, V);
+        else
+            hipLaunchKernelGGL((vocab_bwd_dh_kernel<VV, false>), dim3(g), dim3(256), 0, s, dl, keep, scale, w, dhs, R, H, V);
+        CPG_LAUNCH_CHECK();
+    }
+    if (dw || db) {
+        const int G = vocab_bwd_wgs(R), nqb = H / 256, qpw = nqb < 4 ? nqb : 4, nrl = 4 / qpw;
+        const int rows = cdiv(R, G);
+        float* part = ws;
+        float* part_db = ws + (size_t)G * V * H;
+        const size_t smem = nrl > 1 ? (size_t)qpw * VV * 64 * sizeof(float4) : 0;
+        if (keep)
+            hipLaunchKernelGGL((vocab_bwd_dw_kernel<VV, true>), dim3(G, nqb / qpw), dim3(256), smem, s, dl, hs, keep, scale, part, part_db, R, H, V, rows);
+        else
+            hipLaunchKernelGGL((vocab_bwd_dw_kernel<VV, false>), dim3(G, nqb / qpw), dim3(256), smem, s, dl, hs, keep, scale, part, part_db, R, H, V, rows);
+        CPG_LAUNCH_CHECK();
+        const int nblk = cdiv(V * H / 4, 32);
+        hipLaunchKernelGGL(vocab_bwd_final_kernel, dim3(nblk + 1), dim3(32, 32), 0, s, part, part_db, G, G * nrl, V, H, dw, db, accumulate);
+        CPG_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 // dhs[R,H] = (dlogits W) .* keep*scale ; dw[V,H] (+)= dlogits^T (hs .* keep*scale) ; db[V] (+)= colsum(dlogits)
@@ -23,6 +306,14 @@ CPG_EXPORT int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uin
     CPG_CHECK_ARG(dlogits && hs && w && R > 0 && H > 0 && V > 0);
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
+    if (vocab_bwd_streams(R, H, V) && (!(dw || db) || (dw && db && workspace && workspace_bytes >= cpg_vocab_fc_bwd_workspace(R, H, V) - 256)) &&
+        aligned16(hs) && aligned16(w) && (!dhs || aligned16(dhs)) && (!dw || aligned16(dw))) {
+        float* ws = (float*)workspace;
+        if (V <= 8) return vocab_bwd_launch<8>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
+        if (V <= 16) return vocab_bwd_launch<16>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
+        if (V <= 24) return vocab_bwd_launch<24>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
+        return vocab_bwd_launch<32>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
+    }
     if (dhs) rc = cpg_gemm_nn(dlogits, V, w, H, dhs, H, R, H, V, 0, keep, scale, s);
     if (rc) return rc;
     if (dw) {

@@ -85,6 +85,21 @@ __global__ void rng_bernoulli_kernel(uint8_t* out, size_t n, float p_one, uint64
         if (q * 4 + k < n) out[q * 4 + k] = u01(r[k]) < p_one ? 1 : 0;
 }
 
+// out[i][:] = one-hot of the SAME draw rng_bernoulli_kernel makes for element i: c ~ Cat([1 - p_one, p_one]) as float rows
+// (RNN_VAE.sample_c_prior, models/model.py:122-126, in one launch instead of draw + cast + fill + scatter)
+__global__ void rng_onehot2_kernel(float* out, size_t n, float p_one, uint64_t seed, uint64_t offset, const uint64_t* base) {
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    uint32_t r[4];
+    philox4x32(seed, offset + (base ? *base : 0) + q, 2u, r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q * 4 + k < n) {
+            const bool one = u01(r[k]) < p_one;
+            *reinterpret_cast<float2*>(out + 2 * (q * 4 + k)) = make_float2(one ? 0.f : 1.f, one ? 1.f : 0.f);
+        }
+}
+
 #define RNG_LAUNCH(kern, per, ...)                                                                                  \
     do {                                                                                                            \
         const size_t nq = (n + (per) - 1) / (per);                                                                  \
@@ -111,6 +126,12 @@ CPG_EXPORT int cpg_rng_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint64_
                                     void* stream) {
     CPG_CHECK_ARG(out && n > 0 && p_one >= 0.f && p_one <= 1.f);
     RNG_LAUNCH(rng_bernoulli_kernel, 4, out, n, p_one, seed, offset, base);
+    return 0;
+}
+
+CPG_EXPORT int cpg_rng_onehot2(float* out, size_t n, float p_one, uint64_t seed, uint64_t offset, const uint64_t* base, void* stream) {
+    CPG_CHECK_ARG(out && n > 0 && p_one >= 0.f && p_one <= 1.f);
+    RNG_LAUNCH(rng_onehot2_kernel, 4, out, n, p_one, seed, offset, base);
     return 0;
 }
 

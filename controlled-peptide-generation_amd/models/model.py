@@ -117,10 +117,7 @@ class RNN_VAE(nn.Module):
     def sample_c_prior(self, mbsize):
         """c ~ Cat([.5,.5]) one-hot [mbsize, 2]."""
         if self.rng is not None:
-            bit = self.rng.bernoulli((mbsize,), 0.5, self.device).long()
-            c = torch.zeros(mbsize, 2, device=self.device)
-            c.scatter_(1, bit.unsqueeze(1), 1.0)
-            return c
+            return self.rng.onehot2(mbsize, 0.5, self.device)   # the draws of bernoulli((mbsize,), 0.5) as one-hot rows, one launch
         return torch.from_numpy(np.random.multinomial(1, [0.5, 0.5], mbsize).astype('float32')).to(self.device)
 
     def forward_decoder(self, inputs, z, c, wd_mask=None, out_keep=None, emb_w=None):

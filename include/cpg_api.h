@@ -490,6 +490,9 @@ CPG_API int cpg_rng_uniform(float* out, size_t n, uint64_t seed, uint64_t offset
 CPG_API int cpg_rng_uniform_f64(double* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* base, void* stream);
 CPG_API int cpg_rng_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint64_t seed, uint64_t offset, const uint64_t* base,
                                  void* stream);
+/* c ~ Cat([1 - p_one, p_one]) as one-hot float rows out[n][2] from the draws cpg_rng_bernoulli_u8 makes with the same
+ * (seed, offset, base): RNN_VAE.sample_c_prior (models/model.py:122-126) in one launch. */
+CPG_API int cpg_rng_onehot2(float* out, size_t n, float p_one, uint64_t seed, uint64_t offset, const uint64_t* base, void* stream);
 /* device-side step counters of a captured training step: *p += by (one thread) */
 CPG_API int cpg_counter_add_u64(uint64_t* p, uint64_t by, void* stream);
 CPG_API int cpg_counter_add_i32(int32_t* p, int32_t by, void* stream);

@@ -434,3 +434,47 @@ def test_class_round_of_one_million_rows(golden, mode):
     assert np.array_equal(ref_n.numpy(), got_n)
     w = min(ref_letters.shape[1], got_letters.shape[1])
     assert np.array_equal(ref_letters.numpy()[:, :w], got_letters[:, :w])
+
+
+# ------------------------------------------------------------------------------------------------ vocabulary projection, backward
+@pytest.mark.parametrize("R,H,V,masked", [(51200, 512, 24, True), (8192, 1024, 24, False), (4099, 256, 20, True), (6000, 2048, 32, True)])
+def test_vocab_fc_backward_streaming_form_vs_f64(R, H, V, masked):
+    """nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab) backward (models/decoder.py:43-45,83) in its small-vocabulary streaming form
+    (csrc/decode.hip: vocab_bwd_*_kernel) against f64 products of the same f32 inputs, with and without the keep-mask, writing and
+    accumulating; rows not a multiple of anything, V below its padded width."""
+    from cpg import ops
+    g = torch.Generator().manual_seed(R + H + V)
+    dev = torch.device('cuda:0')
+    hs = torch.randn(R, H, generator=g)
+    dl = torch.randn(R, V, generator=g) * torch.logspace(-6, 0, R).unsqueeze(1)      # row magnitudes over six orders
+    w = torch.randn(V, H, generator=g) * 0.1
+    keep = (torch.rand(R, H, generator=g) >= 0.3).to(torch.uint8) if masked else None
+    scale = 1.0 / 0.7 if masked else 1.0
+    m64 = keep.double() * scale if masked else torch.ones(1, dtype=torch.float64)
+    dh_ref = (dl.double() @ w.double()) * m64
+    dw_ref = dl.double().t() @ (hs.double() * m64)
+    db_ref = dl.double().sum(0)
+    dw_bound = dl.abs().double().t() @ (hs.abs().double() * m64)                 # sum of |terms| per output
+    dh_bound = dl.abs().double() @ w.abs().double()
+    hs_d, dl_d, w_d = hs.to(dev), dl.to(dev), w.to(dev)
+    keep_d = keep.to(dev) if masked else None
+    for accumulate in (0, 1):
+        dhs = torch.full((R, H), float("nan"), device=dev)
+        dw0 = torch.randn(V, H, generator=g)
+        db0 = torch.randn(V, generator=g)
+        dw, db = dw0.to(dev), db0.to(dev)
+        ws = ops.workspace(ops.query("cpg_vocab_fc_bwd_workspace", R, H, V), dev)
+        ops.call("cpg_vocab_fc_bwd", ops._p(dl_d), ops._p(hs_d), ops._p(keep_d), float(scale), ops._p(w_d), ops._p(dhs), ops._p(dw), ops._p(db),
+                 R, H, V, accumulate, ops._p(ws), ws.numel(), ops._stream())
+        torch.cuda.synchronize()
+        dhs_c = dhs.cpu().double()
+        assert torch.isfinite(dhs_c).all()
+        assert ((dhs_c - dh_ref).abs() <= 4e-7 * dh_bound * scale + 1e-30).all()
+        if masked:
+            assert (dhs_c[keep == 0] == 0).all()
+        dw_c = dw.cpu().double() - (dw0.double() if accumulate else 0)
+        db_c = db.cpu().double() - (db0.double() if accumulate else 0)
+        # f32 accumulation over R rows in a fixed order: a few ulp of the running sums + (accumulate) one rounding of the old value
+        tol_w = 3e-6 * dw_bound + (2e-7 * dw0.abs().double() if accumulate else 0)
+        assert ((dw_c - dw_ref).abs() <= tol_w).all(), float(((dw_c - dw_ref).abs() / dw_bound).max())
+        assert ((db_c - db_ref).abs() <= 3e-6 * dl.abs().double().sum(0) + (2e-7 * db0.abs().double() if accumulate else 0)).all()

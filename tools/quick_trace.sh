@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/qt
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-class "$@" > $OUT/line.json 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-class --no-extra-legs "$@" > $OUT/line.json 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
 python - <<'PY'
 import csv, collections, glob
 f = glob.glob('gpurun_out/qt/trace/**/t_kernel_trace.csv', recursive=True)[0]
@@ -25,3 +25,4 @@ print(f"steps {n}  kernel time {tot / n:.1f} us/step  span {span / n:.1f} us/ste
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{v[1] / n:8.1f} us/step  x{v[0] / n:5.1f}  avg {v[1] / v[0]:7.1f}  {k}")
 PY
+python tools/step_timeline.py $OUT/trace > $OUT/timeline.txt 2>&1 || tail -3 $OUT/timeline.txt
