@@ -756,10 +756,10 @@ def _pair_scratch(B, H, ndir, dev, lstm=False):
     return t if ndir == 2 else t[0]
 
 
-def _ap_scratch(T, B, H, ndir, dev):
-    """Scratch of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes: kept gate-gradient planes of every step, their
-    exponent tables, the state planes): [ndir, bytes] uint8, or None where the form does not cover the shape / compute mode."""
-    nb = int(query("cpg_gru_ap_bytes", int(T), int(B), int(H), int(ndir)))
+def _ap_scratch(T, B, H, ndir, dev, lstm=False):
+    """Scratch of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes / cpg_lstm_ap_bytes: kept gate-gradient planes of
+    every step, their exponent tables, the state planes): [ndir, bytes] uint8, or None where the form does not cover the shape / mode."""
+    nb = int(query("cpg_lstm_ap_bytes", int(T), int(B), int(H))) if lstm else int(query("cpg_gru_ap_bytes", int(T), int(B), int(H), int(ndir)))
     if nb == 0:
         return None
     t = torch.empty(ndir, (nb + 255) // 256 * 256, device=dev, dtype=torch.uint8)
@@ -922,10 +922,10 @@ class GruSeqFn(Function):
                 # crawls on the 16 CUs left (profiles/r04: a 5-us gradient add takes 370 us there).  Fewer, longer workgroups leave
                 # whole CUs to the main stream's small launches.
                 if ap is not None:
-                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1), options(**_deferred_split_ap(T * B, 3 * H, H)):
+                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=1, side=1), options(**_deferred_split_ap(T * B, 3 * H, H)):
                         call("cpg_gru_wgrad_hh_ap", T, B, H, _p(ap), _p(dG) if dgb else None, _p(defer[0].grad), 1, _p(ws2), ws2.numel(), _stream())
                 else:
-                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1), options(**_deferred_split(T * B, 3 * H, H, pair is not None)):
+                    with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1, side=1), options(**_deferred_split(T * B, 3 * H, H, pair is not None)):
                         call("cpg_gru_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(defer[0].grad),
                              None if has_tab else _p(defer[1].grad), 1, _p(ws2), ws2.numel(), _p(pair), dgb, _stream())
                 if has_tab:
@@ -1151,28 +1151,40 @@ class LstmSeqFn(Function):
         flat = ghs.view(-1)
         dhs_ext = flat[BH:] if not reverse else flat[:T * BH]
         has_tab, has_rowc, has_dense, has_h0, has_c0 = ctx.has
-        dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        # all-T planes form (token-table layers: their bias gradient comes from the input-side reduction): the images of dG the steps
+        # hand to each other are kept, feed the conversion-free dW_hh product and the input-side reductions - no f32 dG at all
+        ap = _ap_scratch(T, B, H, 1, dev, lstm=True) if (has_tab and not has_dense) else None
+        dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32) if ap is None else None
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         need0 = has_h0 or has_c0
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
         dc0 = torch.empty(B, H, device=dev, dtype=torch.float32) if need0 else None
         with _prof("lstm_bwd_step", T + (1 if need0 else 0), T=T, B=B, H=H, ndir=1):
             wT = torch.empty(H, 4 * H, device=dev, dtype=torch.float32)   # W_hh^T for the direct-to-LDS step kernel
-            pair = _pair_scratch(B, H, 1, dev, lstm=True)
-            call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
-                 _p(dh0), _p(dc0), _p(wT), _p(pair), _stream())
+            pair = _pair_scratch(B, H, 1, dev, lstm=True) if ap is None else None
+            if ap is not None:
+                call("cpg_lstm_seq_bwd_ap", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
+                     _p(dh0), _p(dc0), _p(wT), _p(ap), _stream())
+            else:
+                call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(cs), _p(gates), _p(dhs_ext), _p(dG), _p(scratch),
+                     _p(dh0), _p(dc0), _p(wT), _p(pair), _stream())
         if has_h0:
             dh0 = dh0 + (ghs[T] if reverse else ghs[0])
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         dw_hh = torch.empty(4 * H, H, device=dev, dtype=torch.float32)
         db_hh = torch.empty(4 * H, device=dev, dtype=torch.float32)
-        with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-            call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
-                 ws.numel(), _p(pair), _stream())
+        with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=int(ap is not None)):
+            if ap is not None:
+                call("cpg_lstm_wgrad_hh_ap", T, B, H, int(reverse), _p(ap), _p(hs), _p(dw_hh), 0, _p(ws), ws.numel(), _stream())
+            else:
+                call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw_hh), None if has_tab else _p(db_hh), 0, _p(ws),
+                     ws.numel(), _p(pair), _stream())
         dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32) if has_tab else None
         drowc = torch.empty(B, 4 * H, device=dev, dtype=torch.float32) if has_rowc else None
-        if has_tab or has_rowc:
+        if ap is not None:
+            call("cpg_lstm_dgi_reduce_ap", T, B, H, _p(ap), _p(tok), ctx.V, _p(dtab), _p(db_hh), _p(drowc), 0, _p(ws), ws.numel(), _stream())
+        elif has_tab or has_rowc:
             call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(db_hh) if has_tab else None, _p(drowc), 0,
                  _p(ws), ws.numel(), _stream())
         return (None, dtab, drowc, dG if has_dense else None, dh0 if has_h0 else None, dc0 if has_c0 else None, dw_hh, db_hh,
@@ -1231,15 +1243,20 @@ class LstmBiSeqFn(Function):
         else:
             ext_f = z(g_hs_f, hs_f).view(-1)[BH:]        # slots 1..T
             ext_r = z(g_hs_r, hs_r).view(-1)[:T * BH]    # slots 0..T-1
-        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
-        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        ap = _ap_scratch(T, B, H, 2, dev, lstm=True) if (ctx.has_tab and not ctx.has_dense) else None   # all-T planes form (see LstmSeqFn.backward)
+        dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32) if ap is None else None
+        dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32) if ap is None else None
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 4 * H, device=dev, dtype=torch.float32)
-        pair = _pair_scratch(B, H, 2, dev, lstm=True)
+        pair = _pair_scratch(B, H, 2, dev, lstm=True) if ap is None else None
         with _prof("lstm_bwd_step", T, T=T, B=B, H=H, ndir=2):
-            call("cpg_lstm_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(cs_f), _p(cs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
-                 _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]),
-                 _p(pair[0]) if pair is not None else None, _p(pair[1]) if pair is not None else None, _stream())
+            if ap is not None:
+                call("cpg_lstm_biseq_bwd_ap", T, B, H, _p(wf), _p(wr), _p(cs_f), _p(cs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                     _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]), _p(ap[0]), _p(ap[1]), _stream())
+            else:
+                call("cpg_lstm_biseq_bwd", T, B, H, _p(wf), _p(wr), _p(cs_f), _p(cs_r), _p(gt_f), _p(gt_r), _p(ext_f), _p(ext_r),
+                     _p(last_f), _p(last_r), _p(dG_f), _p(dG_r), _p(sc[0]), _p(sc[1]), _p(wT[0]), _p(wT[1]),
+                     _p(pair[0]) if pair is not None else None, _p(pair[1]) if pair is not None else None, _stream())
         nb = query("cpg_gru_wgrad_workspace", T, B, H, max(ctx.V, 1))
         ws = workspace(nb, dev)
         outs = []
@@ -1247,13 +1264,19 @@ class LstmBiSeqFn(Function):
             gw = _grad_buf(ctx.leaves[rev])
             dw = gw if gw is not None else torch.empty(4 * H, H, device=dev, dtype=torch.float32)
             db = torch.empty(4 * H, device=dev, dtype=torch.float32)
-            with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
-                call("cpg_lstm_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None if ctx.has_tab else _p(db), int(gw is not None),
-                     _p(ws), ws.numel(), _p(pair[rev]) if pair is not None else None, _stream())
+            with _prof("lstm_wgrad_hh", 1, T=T, B=B, H=H, ndir=1, ap=int(ap is not None)):
+                if ap is not None:
+                    call("cpg_lstm_wgrad_hh_ap", T, B, H, rev, _p(ap[rev]), _p(hs), _p(dw), int(gw is not None), _p(ws), ws.numel(), _stream())
+                else:
+                    call("cpg_lstm_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dw), None if ctx.has_tab else _p(db), int(gw is not None),
+                         _p(ws), ws.numel(), _p(pair[rev]) if pair is not None else None, _stream())
             dtab = None
             if ctx.has_tab:
                 dtab = torch.empty(ctx.V, 4 * H, device=dev, dtype=torch.float32)
-                call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(db), None, 0, _p(ws), ws.numel(), _stream())
+                if ap is not None:
+                    call("cpg_lstm_dgi_reduce_ap", T, B, H, _p(ap[rev]), _p(tok), ctx.V, _p(dtab), _p(db), None, 0, _p(ws), ws.numel(), _stream())
+                else:
+                    call("cpg_lstm_dgi_reduce", T, B, H, _p(dG), _p(tok), ctx.V, _p(dtab), _p(db), None, 0, _p(ws), ws.numel(), _stream())
             outs.append((dtab, dG if ctx.has_dense else None, None if gw is not None else dw, db))
         (dtab_f, dd_f, dw_f, db_f), (dtab_r, dd_r, dw_r, db_r) = outs
         return None, dtab_f, dtab_r, dd_f, dd_r, dw_f, db_f, dw_r, db_r, None, None

@@ -22,6 +22,8 @@ int cpg_pair_tn(const uint16_t* A, size_t lda, const int* a_ex, const int* a_emi
 size_t cpg_pair_tn_workspace(int M, int N, int R);
 int cpg_pair_tn_bf16(const uint16_t* A, size_t lda, const uint16_t* B, size_t ldb, float* dW, int lddw, int M, int N, int R, int accumulate,
                      float* ws, size_t ws_bytes, hipStream_t s);
+// x = [x1 | x2] (x2 optional) f32 -> unscaled f16-pair image [R][2 (C1 + C2)] (csrc/planes.hip; exported: include/cpg_api.h)
+extern "C" int cpg_pair_rows(const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int R, void* img, void* stream);
 int cpg_colsum(const float* X, int ld, int M, int N, float* out, int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
 size_t cpg_colsum_workspace(int M, int N);
 
@@ -38,7 +40,7 @@ bool cpg_gru_store_bf16(int B, int H, bool dense);
 bool cpg_gru_dg_store_bf16(int B, int H, bool dense, int V);
 
 // ABI version: bumped whenever an exported signature changes (cpg/_lib.py refuses a library whose version differs)
-#define CPG_ABI_VERSION 319
+#define CPG_ABI_VERSION 320
 
 // ---- option table (api.hip): tuning knobs of the launch policy, read from the environment ONCE and set through
 // cpg_set_option afterwards.  Unset = the built-in policy (the measured best at the bench configuration).

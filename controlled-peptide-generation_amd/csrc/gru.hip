@@ -1290,6 +1290,11 @@ CPG_EXPORT size_t cpg_gru_wgrad_workspace(int T, int B, int H, int V) {
     size_t d = dgi_mm_workspace(T, B, H);
     size_t m = a > b ? a : b;
     m = m > c ? m : c;
+    if (H % 128 == 0) {   // the all-T planes products (pair_tn.h): one round of 128 x 128 tiles, split over the rows
+        const size_t e = cpg_pair_tn_workspace(4 * H, H, T * B), e3 = cpg_pair_tn_workspace(3 * H, H, T * B);
+        m = m > e ? m : e;
+        m = m > e3 ? m : e3;
+    }
     return (m > d ? m : d) + 256;
 }
 
@@ -1391,13 +1396,15 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
         tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
         if constexpr (DGAP) {
             const int q = col / H, c = col - q * H;   // (block-uniform q: 64-column blocks never straddle a gate block, H % 64 == 0)
-            if (q < 3) {
+            const int G = lstm ? 4 : 3;                // LSTM: all four blocks are kept images (dG may be null)
+            if (q < G) {
                 const int e = ap_ex[((size_t)t * (B / 32) + bw / 32) * (H / 32) + c / 32];
                 const float sc = __builtin_bit_cast(float, (unsigned)(127 - (e == INT_MAX ? 0 : e)) << 23);
-                const uint16_t* base = ap_planes + ((size_t)t * B + bw) * 6 * H + (size_t)(3 * (c / 32) + q) * 64 + (c & 31);
+                const size_t ldp = (size_t)2 * G * H;
+                const uint16_t* base = ap_planes + ((size_t)t * B + bw) * ldp + (size_t)(G * (c / 32) + q) * 64 + (c & 31);
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const uint2 hi = *reinterpret_cast<const uint2*>(base + (size_t)ks * 6 * H), lo = *reinterpret_cast<const uint2*>(base + (size_t)ks * 6 * H + 32);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(base + (size_t)ks * ldp), lo = *reinterpret_cast<const uint2*>(base + (size_t)ks * ldp + 32);
                     const cpg_f16x2 h0 = __builtin_bit_cast(cpg_f16x2, hi.x), h1 = __builtin_bit_cast(cpg_f16x2, hi.y);
                     const cpg_f16x2 l0 = __builtin_bit_cast(cpg_f16x2, lo.x), l1 = __builtin_bit_cast(cpg_f16x2, lo.y);
                     xv[ks] = f32x4{((float)h0[0] + (float)l0[0]) * sc, ((float)h0[1] + (float)l0[1]) * sc,
@@ -1577,6 +1584,34 @@ int cpg_dgi_reduce_impl(int T, int B, int H, int lstm, const float* dG, const in
                                accumulate, lstm);
         CPG_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// LSTM extension, all-T planes form: all four gate-gradient blocks are read from the kept images (ap: cpg_lstm_ap_bytes); results as
+// cpg_lstm_dgi_reduce.
+extern "C" size_t cpg_lstm_ap_bytes(int T, int B, int H);
+CPG_EXPORT int cpg_lstm_dgi_reduce_ap(int T, int B, int H, const void* ap, const int32_t* tok, int V, float* dtab, float* dsum, float* drowc,
+                                      int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && ap && tok && workspace && (dtab || dsum));
+    if (cpg_lstm_ap_bytes(T, B, H) == 0 || !(V > 0 && V <= DM_VMAX) || !aligned16(tok) || (drowc && !aligned16(drowc)) ||
+        workspace_bytes < dgi_mfma_workspace(B, H, V)) {
+        cpg_set_error("cpg_lstm_dgi_reduce_ap: not covered (cpg_lstm_ap_bytes, token table of 1..%d rows, aligned operands, workspace of "
+                      "cpg_gru_wgrad_workspace bytes)", DM_VMAX);
+        return -4;
+    }
+    const ApScratch a = ap_split(const_cast<void*>(ap), T, B, H, 4);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = B / DM_ROWS;
+    float* part_tab = (float*)workspace;
+    float* part_sum = part_tab + (size_t)chunks * V * 4 * H;
+    const dim3 grid(4 * H / 64, chunks);
+    if (drowc) hipLaunchKernelGGL((dgi_mfma_kernel<true, false, true>), grid, dim3(256), 0, s, (const float*)nullptr, tok, T, B, H, V, 1, part_tab, part_sum, drowc, accumulate, a.planes, a.ex);
+    else hipLaunchKernelGGL((dgi_mfma_kernel<false, false, true>), grid, dim3(256), 0, s, (const float*)nullptr, tok, T, B, H, V, 1, part_tab, part_sum, drowc, accumulate, a.planes, a.ex);
+    CPG_LAUNCH_CHECK();
+    const int m = V * 4 * H;
+    hipLaunchKernelGGL(dgi_fused_final_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, (const float*)part_tab, (const float*)part_sum, chunks, H, V, 1,
+                       dtab, dsum, accumulate);
+    CPG_LAUNCH_CHECK();
     return 0;
 }
 

@@ -133,6 +133,7 @@ struct LstmBwdArgs {
     uint16_t* pp_out;
     int* ex_out;
     int* ex_min;
+    int ap;                // all-T planes form: the image is read later by the dW_hh product - all-zero groups store zeros too
 };
 
 // Both directions of a bidirectional layer share ONE launch per step (blockIdx.z picks the direction), as the GRU pairs of
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
             }
     };
     PairConsumer<MI, NI, 4> pc;
-    if (g.dG_next) {
+    if (PREC == 3 ? g.pp_next != nullptr : g.dG_next != nullptr) {   // (the all-T planes form has no f32 dG)
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3, KT = 4 * H / 32;
         if constexpr (PREC == 3) {
@@ -293,12 +294,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
             for (int e = 0; e < 4; ++e) tc[e] = tanhf(sv[mi][ni][5][e]);
             const f32x4 dc = dcn + dh * og * (1.f - tc * tc);
             *reinterpret_cast<f32x4*>(g.dC_out + o) = dc * fg;
-            float* d = g.dG_out + (size_t)(rb0 + 16 * mi) * 4 * H + cb0 + 16 * ni;
             const f32x4 d0 = dc * gg * ig * (1.f - ig), d1 = dc * cpv * fg * (1.f - fg), d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
-            *reinterpret_cast<f32x4*>(d) = d0;
-            *reinterpret_cast<f32x4*>(d + H) = d1;
-            *reinterpret_cast<f32x4*>(d + 2 * H) = d2;
-            *reinterpret_cast<f32x4*>(d + 3 * H) = d3;
+            if (g.dG_out) {   // (null in the all-T planes form: the kept images are the only copy)
+                float* d = g.dG_out + (size_t)(rb0 + 16 * mi) * 4 * H + cb0 + 16 * ni;
+                *reinterpret_cast<f32x4*>(d) = d0;
+                *reinterpret_cast<f32x4*>(d + H) = d1;
+                *reinterpret_cast<f32x4*>(d + 2 * H) = d2;
+                *reinterpret_cast<f32x4*>(d + 3 * H) = d3;
+            }
             if constexpr (PREC == 3) {
                 pv[mi][ni][0] = d0; pv[mi][ni][1] = d1; pv[mi][ni][2] = d2; pv[mi][ni][3] = d3;
 #pragma unroll
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
         const int grp = (j0 + wn * (BN / 2)) / 32;
         const int e = pair_group_exponent<BN>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
                                               g.ex_min + grp);
-        if (e != INT_MAX) {
-            const float sc = pair_pow2(e);
+        if (e != INT_MAX || g.ap) {   // (the chain's own consumer looks at the table first; the all-T form's dW_hh product does not)
+            const float sc = e != INT_MAX ? pair_pow2(e) : 0.f;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -526,17 +529,42 @@ CPG_EXPORT size_t cpg_lstm_bwd_pair_bytes(int B, int H) {
     return pair_scratch_bytes(B, H, 4);
 }
 
-CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
-                                const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
-                                void* pair_scratch, void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && cs && gates && dG && scratch && ((dh0 == nullptr) == (dc0 == nullptr)));
+// ---- all-T planes form (round 5, as csrc/gru.hip's): the f16-pair images of dG the backward steps hand to each other are KEPT for all T
+// ([T][B][8H] f16 + exponents, pair_engine.h ApScratch with G = 4) and are the A operand of the dW_hh product (pair_tn.h: LDS-DMA,
+// transposing reads, no conversion in its loop); the B operand is the unscaled image of h_prev that cpg_lstm_wgrad_hh_ap makes in one
+// pass over the state slab.  With an LSTM the input-side gradient IS dG: the token-table / row-constant reductions read the images too
+// (cpg_lstm_dgi_reduce_ap) and dG may be null - the images are then the only copy (16 B per state element either way; what goes away
+// is the in-loop conversion of the dW_hh product and the cache-resident ping-pong images).  Layers with a dense input term pass dG as
+// well (their nn.Linear-shaped products read f32).  Coverage: f32-grade mode, the f16-pair backward step, B and H multiples of
+// 128; option gru_ap = 0 switches the form off for both cells.
+static bool lstm_ap_ok(int B, int H) {
+    const CpgOptVal o = cpg_opt(OPT_GRU_AP);
+    if (o.set && o.i == 0) return false;
+    if (B <= 0 || H <= 0 || H % 128 != 0 || B % 128 != 0 || cpg_compute_mode_get() == 1) return false;
+    return cpg_lstm_bwd_pair_bytes(B, H) > 0;
+}
+CPG_EXPORT size_t cpg_lstm_ap_bytes(int T, int B, int H) { return (T > 0 && lstm_ap_ok(B, H)) ? ap_scratch_bytes(T, B, H, 4) : 0; }
+
+static int lstm_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
+                             const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
+                             void* pair_scratch, void* ap_scratch, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && cs && gates && (dG || ap_scratch) && scratch && ((dh0 == nullptr) == (dc0 == nullptr)));
     const size_t BH = (size_t)B * H;
     if (w_hhT_scratch && !lstm_dl_ok(B, H)) w_hhT_scratch = nullptr;
-    const bool pair = pair_scratch && w_hhT_scratch && cpg_lstm_bwd_pair_bytes(B, H) > 0;
+    const bool allt = ap_scratch != nullptr;
+    const bool pair = (allt || pair_scratch) && w_hhT_scratch && cpg_lstm_bwd_pair_bytes(B, H) > 0;
     uint16_t* PP[2] = {nullptr, nullptr};
     int* EX[2] = {nullptr, nullptr};
     int* EMIN = nullptr;
-    if (pair) pair_split(pair_scratch, B, H, 4, PP, EX, EMIN);
+    ApScratch A{nullptr, nullptr, nullptr, nullptr};
+    if (allt) {
+        if (!pair) return -4;
+        A = ap_split(ap_scratch, T, B, H, 4);
+        EMIN = A.ex_min;
+    } else if (pair) {
+        pair_split(pair_scratch, B, H, 4, PP, EX, EMIN);
+    }
+    const size_t plane = (size_t)B * 8 * H, extab = (size_t)(B / 32) * (H / 32);
     if (pair) {
         int rc = cpg_pair_w(w_hh, 4, H, reinterpret_cast<uint16_t*>(w_hhT_scratch), EMIN, (hipStream_t)stream);
         if (rc) return rc;
@@ -557,13 +585,14 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
         a.w_hh = w_hh;
         a.w_hhT = w_hhT_scratch;
         a.ext2 = nullptr;
-        a.dG_next = prev_t >= 0 ? dG + (size_t)prev_t * B * 4 * H : nullptr;
+        a.dG_next = (prev_t >= 0 && dG) ? dG + (size_t)prev_t * B * 4 * H : nullptr;
         a.dC_next = prev_t >= 0 ? scratch + (size_t)(cur ^ 1) * BH : nullptr;
-        a.pp_next = (pair && prev_t >= 0) ? PP[cur ^ 1] : nullptr;
-        a.ex_next = (pair && prev_t >= 0) ? EX[cur ^ 1] : nullptr;
-        a.pp_out = (pair && p >= 0) ? PP[cur] : nullptr;
-        a.ex_out = (pair && p >= 0) ? EX[cur] : nullptr;
+        a.pp_next = (pair && prev_t >= 0) ? (allt ? A.planes + (size_t)prev_t * plane : PP[cur ^ 1]) : nullptr;
+        a.ex_next = (pair && prev_t >= 0) ? (allt ? A.ex + (size_t)prev_t * extab : EX[cur ^ 1]) : nullptr;
+        a.pp_out = (pair && p >= 0) ? (allt ? A.planes + (size_t)t * plane : PP[cur]) : nullptr;
+        a.ex_out = (pair && p >= 0) ? (allt ? A.ex + (size_t)t * extab : EX[cur]) : nullptr;
         a.ex_min = EMIN;
+        a.ap = allt ? 1 : 0;
         if (p >= 0) {
             a.ext = dhs_ext ? dhs_ext + (size_t)t * BH : nullptr;
             a.gates = gates + (size_t)t * 4 * BH;
@@ -571,7 +600,7 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
             a.c_cur = reverse ? cs + (size_t)t * BH : cs + (size_t)(t + 1) * BH;
             a.dH_out = nullptr;
             a.dC_out = scratch + (size_t)cur * BH;
-            a.dG_out = dG + (size_t)t * B * 4 * H;
+            a.dG_out = dG ? dG + (size_t)t * B * 4 * H : nullptr;
         } else {
             a.ext = nullptr;
             a.gates = nullptr;
@@ -588,29 +617,54 @@ CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w
     return 0;
 }
 
+CPG_EXPORT int cpg_lstm_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
+                                const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
+                                void* pair_scratch, void* stream) {
+    return lstm_seq_bwd_impl(T, B, H, reverse, w_hh, cs, gates, dhs_ext, dG, scratch, dh0, dc0, w_hhT_scratch, pair_scratch, nullptr, stream);
+}
+CPG_EXPORT int cpg_lstm_seq_bwd_ap(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
+                                   const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
+                                   void* ap, void* stream) {
+    CPG_CHECK_ARG(ap && w_hhT_scratch && aligned16(ap));
+    if (cpg_lstm_ap_bytes(T, B, H) == 0) {
+        cpg_set_error("cpg_lstm_seq_bwd_ap: shape / mode not covered (cpg_lstm_ap_bytes answers 0: f32-grade mode, H %% 128 == 0, B %% 128 == 0)");
+        return -4;
+    }
+    return lstm_seq_bwd_impl(T, B, H, reverse, w_hh, cs, gates, dhs_ext, dG, scratch, dh0, dc0, w_hhT_scratch, nullptr, ap, stream);
+}
+
 // Both directions of one biLSTM layer, ONE launch per step for the pair (launch p: time p of the forward direction, time T-1-p
 // of the reverse one).  Arguments as cpg_lstm_seq_bwd per direction (_f forward, _r reverse); dh_last_* [B,H] (optional): the
 // gradient on a direction's final HIDDEN state enters at its last step; no initial-state gradients (the encoder starts from
 // h0 = c0 = 0).  (Extension: the reference has no LSTM - SURVEY F2; the pairing mirrors cpg_gru_biseq_bwd.)
-CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
-                                  const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
-                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
-                                  float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
-                                  void* pair_scratch_f, void* pair_scratch_r, void* stream) {
-    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && cs_f && cs_r && gates_f && gates_r && dG_f && dG_r);
+static int lstm_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
+                               const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                               const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
+                               float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
+                               void* pair_scratch_f, void* pair_scratch_r, void* ap_f, void* ap_r, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && w_hh_r && cs_f && cs_r && gates_f && gates_r && ((dG_f && dG_r) || (ap_f && ap_r && !dG_f && !dG_r)));
     CPG_CHECK_ARG(scratch_f && scratch_r && (w_hhT_scratch_f == nullptr) == (w_hhT_scratch_r == nullptr));
     CPG_CHECK_ARG((dhs_ext_f == nullptr) == (dhs_ext_r == nullptr) && (dh_last_f == nullptr) == (dh_last_r == nullptr));
     if (w_hhT_scratch_f && !lstm_dl_ok(B, H)) w_hhT_scratch_f = w_hhT_scratch_r = nullptr;
     const float* W[2] = {w_hh_f, w_hh_r};
     float* WT[2] = {w_hhT_scratch_f, w_hhT_scratch_r};
-    const bool pair = pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && cpg_lstm_bwd_pair_bytes(B, H) > 0;
+    const bool allt = ap_f && ap_r;
+    const bool pair = ((pair_scratch_f && pair_scratch_r) || allt) && w_hhT_scratch_f && cpg_lstm_bwd_pair_bytes(B, H) > 0;
     uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EMIN[2] = {nullptr, nullptr};
-    if (pair) {
+    ApScratch A[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    if (allt) {
+        if (!pair) return -4;
+        A[0] = ap_split(ap_f, T, B, H, 4);
+        A[1] = ap_split(ap_r, T, B, H, 4);
+        EMIN[0] = A[0].ex_min;
+        EMIN[1] = A[1].ex_min;
+    } else if (pair) {
         pair_split(pair_scratch_f, B, H, 4, PP[0], EXP[0], EMIN[0]);
         pair_split(pair_scratch_r, B, H, 4, PP[1], EXP[1], EMIN[1]);
     }
+    const size_t plane = (size_t)B * 8 * H, extab = (size_t)(B / 32) * (H / 32);
     for (int d = 0; d < 2 && WT[d]; ++d) {
         if (pair) {
             int rc = cpg_pair_w(W[d], 4, H, reinterpret_cast<uint16_t*>(WT[d]), EMIN[d], (hipStream_t)stream);
@@ -639,13 +693,14 @@ CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, cons
             a.H = H;
             a.w_hh = W[d];
             a.w_hhT = WT[d];
-            a.dG_next = prev_t[d] >= 0 ? DG[d] + (size_t)prev_t[d] * B * 4 * H : nullptr;
+            a.dG_next = (prev_t[d] >= 0 && DG[d]) ? DG[d] + (size_t)prev_t[d] * B * 4 * H : nullptr;
             a.dC_next = prev_t[d] >= 0 ? SC[d] + (size_t)(cur ^ 1) * BH : nullptr;
-            a.pp_next = (pair && prev_t[d] >= 0) ? PP[d][cur ^ 1] : nullptr;
-            a.ex_next = (pair && prev_t[d] >= 0) ? EXP[d][cur ^ 1] : nullptr;
-            a.pp_out = pair ? PP[d][cur] : nullptr;
-            a.ex_out = pair ? EXP[d][cur] : nullptr;
+            a.pp_next = (pair && prev_t[d] >= 0) ? (allt ? A[d].planes + (size_t)prev_t[d] * plane : PP[d][cur ^ 1]) : nullptr;
+            a.ex_next = (pair && prev_t[d] >= 0) ? (allt ? A[d].ex + (size_t)prev_t[d] * extab : EXP[d][cur ^ 1]) : nullptr;
+            a.pp_out = pair ? (allt ? A[d].planes + (size_t)t * plane : PP[d][cur]) : nullptr;
+            a.ex_out = pair ? (allt ? A[d].ex + (size_t)t * extab : EXP[d][cur]) : nullptr;
             a.ex_min = EMIN[d];
+            a.ap = allt ? 1 : 0;
             a.ext = EX[d] ? EX[d] + (size_t)t * BH : nullptr;
             a.ext2 = (p == T - 1) ? LAST[d] : nullptr;
             a.gates = GT[d] + (size_t)t * 4 * BH;
@@ -653,13 +708,35 @@ CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, cons
             a.c_cur = d ? CS[d] + (size_t)t * BH : CS[d] + (size_t)(t + 1) * BH;
             a.dH_out = nullptr;
             a.dC_out = SC[d] + (size_t)cur * BH;
-            a.dG_out = DG[d] + (size_t)t * B * 4 * H;
+            a.dG_out = DG[d] ? DG[d] + (size_t)t * B * 4 * H : nullptr;
             prev_t[d] = t;
         }
         int rc = lstm_bwd_launch(pr, 2, (hipStream_t)stream);
         if (rc) return rc;
     }
     return 0;
+}
+
+CPG_EXPORT int cpg_lstm_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
+                                  const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
+                                  float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
+                                  void* pair_scratch_f, void* pair_scratch_r, void* stream) {
+    return lstm_biseq_bwd_impl(T, B, H, w_hh_f, w_hh_r, cs_f, cs_r, gates_f, gates_r, dhs_ext_f, dhs_ext_r, dh_last_f, dh_last_r, dG_f, dG_r,
+                               scratch_f, scratch_r, w_hhT_scratch_f, w_hhT_scratch_r, pair_scratch_f, pair_scratch_r, nullptr, nullptr, stream);
+}
+CPG_EXPORT int cpg_lstm_biseq_bwd_ap(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
+                                     const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                     const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
+                                     float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
+                                     void* ap_f, void* ap_r, void* stream) {
+    CPG_CHECK_ARG(ap_f && ap_r && w_hhT_scratch_f && w_hhT_scratch_r && aligned16(ap_f) && aligned16(ap_r));
+    if (cpg_lstm_ap_bytes(T, B, H) == 0) {
+        cpg_set_error("cpg_lstm_biseq_bwd_ap: shape / mode not covered (cpg_lstm_ap_bytes answers 0)");
+        return -4;
+    }
+    return lstm_biseq_bwd_impl(T, B, H, w_hh_f, w_hh_r, cs_f, cs_r, gates_f, gates_r, dhs_ext_f, dhs_ext_r, dh_last_f, dh_last_r, dG_f, dG_r,
+                               scratch_f, scratch_r, w_hhT_scratch_f, w_hhT_scratch_r, nullptr, nullptr, ap_f, ap_r, stream);
 }
 
 // dw_hh[4H,H] (+)= sum_t dG_t^T h_prev(t) ; db_hh[4H] (+)= sum dG.   workspace: cpg_gru_wgrad_workspace(T,B,H,V)
@@ -681,6 +758,23 @@ CPG_EXPORT int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* 
                          workspace_bytes, (hipStream_t)stream, 0, exps, H);
     if (rc || !db_hh) return rc;  // db_hh null: the caller takes it from cpg_lstm_dgi_reduce's column sums
     return cpg_colsum(dG, 4 * H, T * B, 4 * H, db_hh, accumulate, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// All-T planes form: dw_hh[4H,H] (+)= kept gate-gradient images^T x the image of h_prev (made here: one pass over the state slab
+// hs [T+1,B,H] - slots 0..T-1 forward, 1..T reverse; |h| < 1: unscaled).  The bias gradient comes out of cpg_lstm_dgi_reduce's column
+// sums (token-table layers) - this form covers those layers only.
+CPG_EXPORT int cpg_lstm_wgrad_hh_ap(int T, int B, int H, int reverse, void* ap, const float* hs, float* dw_hh, int accumulate,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && ap && hs && dw_hh && workspace && aligned16(hs));
+    if (cpg_lstm_ap_bytes(T, B, H) == 0) {
+        cpg_set_error("cpg_lstm_wgrad_hh_ap: shape / mode not covered (cpg_lstm_ap_bytes answers 0)");
+        return -4;
+    }
+    const ApScratch a = ap_split(ap, T, B, H, 4);
+    int rc = cpg_pair_rows(reverse ? hs + (size_t)B * H : hs, H, H, nullptr, 0, 0, T * B, a.hplanes, stream);
+    if (rc) return rc;
+    return cpg_pair_tn(a.planes, (size_t)8 * H, a.ex, a.ex_min, H / 32, 4, a.hplanes, (size_t)2 * H, dw_hh, H, 4 * H, H, T * B, accumulate,
+                       (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 CPG_EXPORT int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,

@@ -328,6 +328,28 @@ CPG_API int cpg_lstm_wgrad_hh(int T, int B, int H, int reverse, const float* dG,
                               const void* pair_scratch /* the sequence's, or null */, void* stream);
 CPG_API int cpg_lstm_dgi_reduce(int T, int B, int H, const float* dG, const int32_t* tok, int V, float* dtab, float* dsum,
                                 float* drowc, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* All-T planes form of the LSTM extension's f16-pair BPTT chain (as cpg_gru_*_ap; csrc/pair_engine.h ApScratch with four blocks):
+ * the plane images of dG that the backward steps hand to each other are KEPT for every step in `ap` (cpg_lstm_ap_bytes(T, B, H) bytes
+ * per direction; 0 = not covered: f32-grade mode, B % 128 == 0, H % 128 == 0, the f16-pair step; option gru_ap = 0 switches it off)
+ * and cpg_lstm_wgrad_hh_ap forms dw_hh [4H,H] (+)= images^T x image(h_prev) with no conversion in its loop (it images the state
+ * slab hs [T+1,B,H] itself; workspace as cpg_gru_wgrad_workspace).  dG [T,B,4H] f32 may be null in the _ap calls: with an LSTM the
+ * input-side gradient is dG and cpg_lstm_dgi_reduce_ap reads the images (token-table layers; their bias gradient is that reduction's
+ * column sums); layers with a dense input term pass dG as well. */
+CPG_API size_t cpg_lstm_ap_bytes(int T, int B, int H);
+CPG_API int cpg_lstm_seq_bwd_ap(int T, int B, int H, int reverse, const float* w_hh, const float* cs, const float* gates,
+                                const float* dhs_ext, float* dG, float* scratch, float* dh0, float* dc0, float* w_hhT_scratch,
+                                void* ap, void* stream);
+CPG_API int cpg_lstm_biseq_bwd_ap(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* cs_f,
+                                  const float* cs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
+                                  const float* dhs_ext_r, const float* dh_last_f, const float* dh_last_r, float* dG_f, float* dG_r,
+                                  float* scratch_f, float* scratch_r, float* w_hhT_scratch_f, float* w_hhT_scratch_r,
+                                  void* ap_f, void* ap_r, void* stream);
+CPG_API int cpg_lstm_wgrad_hh_ap(int T, int B, int H, int reverse, void* ap, const float* hs, float* dw_hh, int accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+/* token-grouped sums / column sums / sums over time of the input-side gradient (= dG for an LSTM) read from the kept images;
+ * results as cpg_lstm_dgi_reduce.  With it cpg_lstm_seq_bwd_ap / _biseq_bwd_ap may be given dG = null (token-table layers). */
+CPG_API int cpg_lstm_dgi_reduce_ap(int T, int B, int H, const void* ap, const int32_t* tok, int V, float* dtab, float* dsum, float* drowc,
+                                   int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- vocabulary projection: nn.Dropout(p_out)+nn.Linear(h_dim,n_vocab), models/decoder.py:43-45,83,107 ----------- */
 /* logits[R,V] = (hs[R,H] .* keep*scale) W[V,H]^T + b   (keep uint8 [R,H] or null) */

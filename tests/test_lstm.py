@@ -409,6 +409,102 @@ def test_lstm_backward_f16_pair_step_and_wgrad_vs_exact(B, H, T, reverse):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,T,reverse", [(128, 128, 5, False), (256, 128, 4, True), (2048, 512, 25, False), (2048, 512, 25, True), (1024, 1024, 6, True)])
+def test_lstm_all_t_planes_form_vs_ping_pong(B, H, T, reverse):
+    """All-T planes form of the LSTM chain (cpg_lstm_seq_bwd_ap / cpg_lstm_biseq_bwd_ap / cpg_lstm_wgrad_hh_ap, round 5): dG, dh0, dc0
+    are bit-identical to the ping-pong chain (same kernels, same arithmetic: only where the images live changes); dW_hh against an f64
+    sum over that dG per 32-unit group of the gate axis, with gradient magnitudes spread over 16 orders, an all-zero column group and
+    an all-zero row block (images of all-zero groups must read as zeros); the paired launches equal the single ones bit for bit."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call, query
+    dev = torch.device("cuda")
+    assert query("cpg_lstm_ap_bytes", T, B, H) > 0
+    d = _lstm_inputs(B, H, T, 24, seed=B + H + 5)
+    hs, cs, gates = _lstm_run(d, B, H, T, reverse, False)
+    g = torch.Generator().manual_seed(5)
+    dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
+    colexp = torch.randint(-12, 4, (H // 32,), generator=g).repeat_interleave(32).float().to(dev)
+    dh = dhs * (10.0 ** colexp)[None, None, :]
+    dh[:, 32:64, :] = 0.0          # a row block without any gradient ...
+    dh[:, :, 64:96] = 0.0          # ... and a column group that receives none from outside
+    ws = torch.empty(query("cpg_gru_wgrad_workspace", T, B, H, 24), device=dev, dtype=torch.uint8)
+
+    def run(allt):
+        dG = torch.zeros(T, B, 4 * H, device=dev)
+        scr = torch.empty(2, B, H, device=dev)
+        dh0, dc0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+        wT = torch.empty(H, 4 * H, device=dev)
+        dw = torch.full((4 * H, H), float("nan"), device=dev)
+        if allt:
+            ap = ops._ap_scratch(T, B, H, 1, dev, lstm=True)
+            ap.fill_(0xFF)   # NaN halves / garbage exponents wherever the chain does not write
+            call("cpg_lstm_seq_bwd_ap", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dh), _p(dG), _p(scr), _p(dh0), _p(dc0),
+                 _p(wT), _p(ap), _stream())
+            call("cpg_lstm_wgrad_hh_ap", T, B, H, int(reverse), _p(ap), _p(hs), _p(dw), 0, _p(ws), ws.numel(), _stream())
+        else:
+            ps = ops._pair_scratch(B, H, 1, dev, lstm=True)
+            call("cpg_lstm_seq_bwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dh), _p(dG), _p(scr), _p(dh0), _p(dc0),
+                 _p(wT), _p(ps), _stream())
+            call("cpg_lstm_wgrad_hh", T, B, H, int(reverse), _p(dG), _p(hs), _p(dw), None, 0, _p(ws), ws.numel(), _p(ps), _stream())
+        torch.cuda.synchronize()
+        return dG, dh0, dc0, dw
+
+    (dG, dh0, dc0, dw), (rG, r0, rc0, rw) = run(True), run(False)
+    assert torch.equal(dG, rG) and torch.equal(dh0, r0) and torch.equal(dc0, rc0)
+    assert torch.isfinite(dw).all()
+    hprev = (hs[1:] if reverse else hs[:-1]).reshape(T * B, H).double()
+    ref = dG.reshape(T * B, 4 * H).double().T @ hprev
+    grp = ref.abs().view(4, H // 32, 32, H).amax(dim=(2, 3), keepdim=True).expand(4, H // 32, 32, H).reshape(4 * H, H)
+    assert ((dw.double() - ref).abs() <= 3e-6 * grp + 1e-37).all()
+    # accumulate = 1 adds onto what is there
+    dw2 = torch.ones(4 * H, H, device=dev)
+    ap = ops._ap_scratch(T, B, H, 1, dev, lstm=True)
+    dG2 = torch.zeros(T, B, 4 * H, device=dev)
+    scr, wT = torch.empty(2, B, H, device=dev), torch.empty(H, 4 * H, device=dev)
+    a0, c0 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+    call("cpg_lstm_seq_bwd_ap", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dh), _p(dG2), _p(scr), _p(a0), _p(c0), _p(wT), _p(ap), _stream())
+    call("cpg_lstm_wgrad_hh_ap", T, B, H, int(reverse), _p(ap), _p(hs), _p(dw2), 1, _p(ws), ws.numel(), _stream())
+    torch.cuda.synchronize()
+    assert ((dw2.double() - 1.0 - ref).abs() <= 3e-6 * grp + 2.5e-7).all()
+    # dG = null: the images are the only copy - same dW_hh bit for bit; the input-side reductions read them (cpg_lstm_dgi_reduce_ap)
+    ap3 = ops._ap_scratch(T, B, H, 1, dev, lstm=True)
+    ap3.fill_(0xFF)
+    a1, c1 = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
+    call("cpg_lstm_seq_bwd_ap", T, B, H, int(reverse), _p(d["w_hh"]), _p(cs), _p(gates), _p(dh), None, _p(scr), _p(a1), _p(c1), _p(wT), _p(ap3), _stream())
+    dw3 = torch.zeros(4 * H, H, device=dev)
+    call("cpg_lstm_wgrad_hh_ap", T, B, H, int(reverse), _p(ap3), _p(hs), _p(dw3), 0, _p(ws), ws.numel(), _stream())
+    dtab, dsum, drowc = torch.zeros(24, 4 * H, device=dev), torch.zeros(4 * H, device=dev), torch.zeros(B, 4 * H, device=dev)
+    call("cpg_lstm_dgi_reduce_ap", T, B, H, _p(ap3), _p(d["tok"]), 24, _p(dtab), _p(dsum), _p(drowc), 0, _p(ws), ws.numel(), _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dw3, dw) and torch.equal(a1, dh0) and torch.equal(c1, dc0)
+    G64 = dG.double()
+    oh = torch.nn.functional.one_hot(d["tok"].long().reshape(-1), 24).double()
+    rt, rs_, rr = oh.T @ G64.reshape(T * B, 4 * H), G64.sum((0, 1)), G64.sum(0)
+    at, as_, ar = oh.T @ G64.abs().reshape(T * B, 4 * H), G64.abs().sum((0, 1)), G64.abs().sum(0)
+    # the images hold dG to 2^-22 of each 32 x 32 group's largest value (f16 pairs); sums in f32
+    gmax = dG.abs().view(T, B // 32, 32, 4, H // 32, 32).amax(dim=(2, 5), keepdim=True).expand(T, B // 32, 32, 4, H // 32, 32).reshape(T, B, 4 * H).double()
+    qt, qs, qr = oh.T @ gmax.reshape(T * B, 4 * H), gmax.sum((0, 1)), gmax.sum(0)
+    assert ((dtab.double() - rt).abs() <= 3e-6 * at + 5e-7 * qt + 1e-37).all()
+    assert ((dsum.double() - rs_).abs() <= 3e-6 * as_ + 5e-7 * qs + 1e-37).all()
+    assert ((drowc.double() - rr).abs() <= 3e-6 * ar + 5e-7 * qr + 1e-37).all()
+    if reverse:
+        return
+    # paired launches: the forward direction of a (this sequence, its own copy run as the reverse direction of another) pair
+    d2 = _lstm_inputs(B, H, T, 24, seed=B + H + 6)
+    hs2, cs2, gates2 = _lstm_run(d2, B, H, T, True, False)
+    apb = ops._ap_scratch(T, B, H, 2, dev, lstm=True)
+    dGf, dGr = torch.zeros(T, B, 4 * H, device=dev), torch.zeros(T, B, 4 * H, device=dev)
+    sc = torch.empty(2, 2, B, H, device=dev)
+    wT2 = torch.empty(2, H, 4 * H, device=dev)
+    call("cpg_lstm_biseq_bwd_ap", T, B, H, _p(d["w_hh"]), _p(d2["w_hh"]), _p(cs), _p(cs2), _p(gates), _p(gates2), _p(dh), _p(dh), None, None,
+         _p(dGf), _p(dGr), _p(sc[0]), _p(sc[1]), _p(wT2[0]), _p(wT2[1]), _p(apb[0]), _p(apb[1]), _stream())
+    dwf = torch.zeros(4 * H, H, device=dev)
+    call("cpg_lstm_wgrad_hh_ap", T, B, H, 0, _p(apb[0]), _p(hs), _p(dwf), 0, _p(ws), ws.numel(), _stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dGf, dG) and torch.equal(dwf, dw)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,He,Z,T,layers", [(64, 32, 30, 9, 1), (2048, 512, 510, 25, 1), (256, 128, 126, 12, 2)])
 def test_lstm_model_step_vs_torch_ref(B, He, Z, T, layers):
     """A whole WAE training step of the LSTM extension (BASELINE.json configs[1] names an LSTM: encoder biLSTM, LSTM decoder with
