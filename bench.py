@@ -659,6 +659,18 @@ def main():
                    "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}"},
         "roofline": compact_roofline(head["roofline"], keep_all=True), "extra": extra,
     }
+    line["config"]["step_launch"] = "eager (one host enqueue per kernel)"
+    g = extra.get("graph_replay")
+    forced = os.environ.get("CPG_BENCH_FORCE_GRAPH_LINE", "") == "1"   # (exercises this branch on a healthy box)
+    if world == 1 and g and (forced or (head["host_enqueue_ms_per_step"] >= 0.9 * head["ms_per_step"] and g["ms_per_step"] < 0.97 * head["ms_per_step"])):
+        # a host-bound box (the enqueue of a step took as long as the step: seen on one box in eight of the pool, 5.8 ms of enqueue against
+        # 5.1 ms of device work): the product's remedy is cfg.hw.graph - the SAME train_step captured once and replayed (bit-identical,
+        # DESIGN 5.7), K steps timed by the same bracket.  The line then carries that leg and says so; the eager numbers stay beside it.
+        extra["eager_step"] = {"value": head["value"], "ms_per_step": head["ms_per_step"], "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"]}
+        line["value"], line["ms_per_step"] = g["value"], g["ms_per_step"]
+        line["config"]["step_launch"] = ("hipGraph replay (cfg.hw.graph): this run's eager step was HOST-bound "
+                                         f"({head['host_enqueue_ms_per_step']} ms of enqueue per {head['ms_per_step']} ms step, extra.eager_step); "
+                                         "kernel families / roofline are the eager leg's HIP-event timings of the same kernels")
     if rccl is not None:
         rccl["ms_per_step_per_rank"] = head.get("ms_per_step_per_rank")
         line["rccl"] = rccl
