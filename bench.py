@@ -303,6 +303,9 @@ def launch_count_per_step(step_fn):
         return None
 
 
+_PROBE_HUNG = []   # set when the collectives probe left a thread stuck inside RCCL: main() then leaves through os._exit
+
+
 def rccl_probe(dev, grad_numel, backend, world, iters=20):
     """Times the two collectives of the path on their real payloads: the SUM all-reduce of a flat f32 gradient buffer of the
     model's size, and the all-gather of one CLaSS round's rows (cpg.dist.allgather_rows on a [65536/world, 26] int16 + f32
@@ -334,12 +337,40 @@ def rccl_probe(dev, grad_numel, backend, world, iters=20):
     # a ring moves 2 (N-1)/N of the payload over every GPU's links; one link = 153 GB/s, a GPU has 7 (one per peer at N = 8)
     ranks_seen = None
     if on_gpu and not os.environ.get("CPG_SHARED_DEVICE"):
+        # The probe builds a SECOND communicator (ncclCommInitRank on every rank).  It must not take the bench line down: (i) the ranks
+        # first agree (MIN all-reduce) that every one of them can reach the library's entry points - a rank that cannot would leave
+        # the others waiting inside the init; (ii) the init runs on a watchdog thread - after 45 s the run goes on without the number
+        # and leaves through os._exit at the end (a thread stuck inside RCCL cannot be joined).
+        import threading
+        ok = torch.ones(1, device=dev)
+        api = None
         try:
-            lc = cdist.LibComm(tdist.get_rank(), world)
-            ranks_seen = lc.ranks_seen()
-            lc.close()
-        except Exception as exc:   # the probe must not take the bench line down
-            ranks_seen = "unavailable: %s" % (str(exc)[:80],)
+            api = cdist._CApi()
+            if not hasattr(api, "count"):
+                raise RuntimeError("cpg_comm_count missing")
+        except Exception:
+            ok.zero_()
+        tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            ranks_seen = "unavailable: a rank cannot reach the library's RCCL entry points"
+        else:
+            res = {}
+
+            def work():
+                try:
+                    lc = cdist.LibComm(tdist.get_rank(), world, api=api)
+                    res["n"] = lc.ranks_seen()
+                    lc.close()
+                except Exception as exc:
+                    res["err"] = "unavailable: %s" % (str(exc)[:80],)
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            th.join(45.0)
+            if th.is_alive():
+                ranks_seen = "timeout: the library communicator's init did not return within 45 s"
+                _PROBE_HUNG.append(True)
+            else:
+                ranks_seen = res.get("n", res.get("err"))
     ring = 2.0 * (world - 1) / world * nbytes
     t_one, t_all = ring / XGMI_LINK_GBS / 1e9 * 1e3, ring / (XGMI_LINK_GBS * min(world - 1, 7)) / 1e9 * 1e3
     return {"backend": backend, "ranks": world, "ranks_seen": ranks_seen, "allreduce_ms": round(ar, 4), "allreduce_bytes": nbytes,
@@ -938,3 +969,7 @@ def class_wide(dev, Z=510, N=131072):
 
 if __name__ == "__main__":
     main()
+    if _PROBE_HUNG:   # a probe thread is stuck inside RCCL: do not wait for it at interpreter shutdown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
