@@ -34,7 +34,14 @@ HBM_PEAK_GBS = 8000.0
 # tools/pmc_summary.py --json): counters cannot be collected from inside this script, so the per-kernel means of the
 # committed profile are looked up BY THE KERNEL NAME THE LAUNCHER REPORTS - a tile-policy change yields null, not a stale
 # number.  (2*FETCH + WRITE)*1024: the gfx950 read-side correction of MI355X_MICROARCH.md, HBM section.
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
+def _pmc_json():
+    """The newest committed PMC profile (profiles/rNN_pmc.json) - pmc_traffic() only trusts it when its source fingerprint matches."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
+    return c[-1] if c else os.path.join(ROOT, "profiles", "r05_pmc.json")
+
+
+PMC_JSON = _pmc_json()
 
 
 def csrc_fingerprint():
@@ -943,8 +950,12 @@ def class_wide(dev, Z=510, N=131072):
     EVAL_FLOPS = 2.0 * 3 * H * (150 + H + H) + 2.0 * H * 24
     out = {"workload": f"one CLaSS round of {N} proposals at z={Z} / decoder h={H} (config-B width), per-step decode launches", "flops_per_eval": EVAL_FLOPS}
     sp.run_rounds(m, ds, Q, 8192, 10 ** 9, max_rounds=1, sample_mode='greedy')
+    from cpg import lib
     kname = _cname("cpg_gru_step_kernel_name", 0, 65536, H, 1, 0)
     wpeak = PEAK_PAIR_TFLOPS if kname.endswith(", 8>") else PEAK_SPLIT_TFLOPS   # the step kernel's product form (f16 pairs / bf16 triple)
+    if lib().dll.cpg_gru_step_planes_ok(N, H) == 1 and not os.environ.get("CPG_NO_STEP_PLANES"):
+        # round 5: the step runs on f16-pair plane images (cpg_gru_step_fwd_planes) - greedy rows N, beam rows N x 5
+        kname, wpeak = "gru_step_fwd_planes_kernel", PEAK_PAIR_TFLOPS
     for tag, mode in (("greedy_all", "greedy"), ("beam5_all", "beam")):
         torch.cuda.synchronize()
         ops.PROFILE = []
