@@ -64,6 +64,7 @@ enum CpgOpt {
     OPT_BF16_STORE,       // 0: f32 saved gates in the bf16 compute mode too (default there: bf16, see cpg_gru_gates_bf16)
     OPT_BF16_DG,          // 0: f32 gate gradients in the bf16 compute mode too (default there: bf16 where covered, see cpg_gru_dg_bf16)
     OPT_GRU_AP,           // 0: f32 gate gradients + ping-pong planes instead of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes)
+    OPT_GRU_SMALL_SEQ,    // 0: per-step launches for small GRU recurrences too (default: whole-sequence launches, csrc/decode_fused.hip gru_seq_small_*)
     OPT__COUNT
 };
 struct CpgOptVal {
@@ -73,5 +74,13 @@ struct CpgOptVal {
 };
 CpgOptVal cpg_opt(CpgOpt o);   // a copy, taken under the table's mutex (api.hip)
 int cpg_persist_planes();      // operand planes of the persistent forward kernels now: 1 bf16 compute mode, 2 f16 pair, 3 bf16 triple
+// Whole-sequence launches for SMALL GRU recurrences in training (csrc/decode_fused.hip): hidden <= 128, token-table input (+ optional
+// per-row constant), dense batch, f32-grade mode.  One workgroup keeps a 32-row tile's state on its CU for all T steps with W_hh in
+// registers - the reference's default sizes (h = 80 / 102, batch 32) are otherwise one 8-20 us launch per time step and direction.
+struct CpgSmallFwdDir { const float* w_hh; const float* b_hh; const int32_t* tok; const float* tab; const float* rowc; float* hs; float* gates; int reverse; };
+struct CpgSmallBwdDir { const float* w_hh; const float* hs; const float* gates; const float* dhs_ext; const float* dh_last; float* dG; float* dh0; int reverse; };
+bool cpg_gru_small_seq_ok(int B, int H);
+int cpg_gru_small_seq_fwd(int T, int B, int H, int ndir, const CpgSmallFwdDir* d, hipStream_t s);
+int cpg_gru_small_seq_bwd(int T, int B, int H, int ndir, const CpgSmallBwdDir* d, hipStream_t s);
 int cpg_device_cus();                                   // CUs of the current device (cached per device)
 int cpg_allow_big_lds(const void* kernel, int bytes);   // opt a kernel into > 64 KB dynamic LDS, once per (kernel, device)

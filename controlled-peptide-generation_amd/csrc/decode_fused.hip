@@ -904,7 +904,315 @@ int device_limits(int* cus, int* lds) {
         return LAUNCH<8, 0>(__VA_ARGS__);                                      \
     } while (0)
 
+// ================================================================================================ training: whole sequences
+// The same residency for TRAINING at these sizes (cpg_gru_seq_fwd / _bwd, _biseq_* dispatch here: cpg_gru_small_seq_ok).  A workgroup
+// owns a tile of 32 batch rows of one direction for all T steps:
+//   forward  - W_hh in registers as above (gru_product), the state double-buffered in LDS, the token of a row read per step (teacher
+//              forcing), h_t and the saved gates (r, z, n, W_hn h + b_hn) written to the slabs cpg_gru_seq_bwd reads;
+//   backward - W_hh once more in registers, now as exact-f32 MFMA B fragments of the OTHER orientation (dH = dG_rec W_hh contracts
+//              over the 3H gate rows); the recurrent gate gradients of the tile live in LDS ([32][3H]), the carry z (.) dH and the
+//              cell's backward run in the accumulator layout on the wave's own hidden units: nothing but dG / dh0 leaves the CU.
+// Same arithmetic as the per-step kernels (csrc/gru.hip: the staged exact-f32 backward step; forward on f16 pairs as the decode kernels).
+constexpr int RS = 32;   // rows per workgroup tile
+
+struct SmallFwdArgs {
+    CpgSmallFwdDir d[2];
+    int B, H, T, ntiles;
+};
+
+template <int G, int R>
+__global__ __launch_bounds__(256, 1) void gru_seq_small_fwd_kernel(SmallFwdArgs a) {
+    using C = FusedCfg<G, R>;
+    extern __shared__ float4 cpg_fused_smem[];
+    const CpgSmallFwdDir& d = a.d[blockIdx.y];
+    const int H = a.H, H3 = 3 * H, B = a.B, T = a.T;
+    const size_t BH = (size_t)B * H;
+    float* h_a = reinterpret_cast<float*>(cpg_fused_smem);   // [RS][LDH]
+    float* h_b = h_a + RS * C::LDH;
+    float* rowc_l = h_b + RS * C::LDH;                        // [RS][3H]
+    int* tok_l = reinterpret_cast<int*>(rowc_l + RS * H3);    // [T][RS]: the tile's tokens of every step
+    const int tid = threadIdx.x, lane = tid & 63, lq = lane >> 4;
+    WaveWeights<G, R> ww;
+    ww.load(DecoderWeights{d.tab, d.w_hh, d.b_hh, nullptr, nullptr, H, 0, 1});
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int row0 = tile * RS, nrows = min(RS, B - row0);
+        __syncthreads();
+        const float* h0 = d.hs + (size_t)(d.reverse ? T : 0) * BH;   // the caller put the initial state into its slot
+        for (int i = tid; i < RS * C::LDH; i += 256) {
+            const int r = i / C::LDH, k = i - r * C::LDH;
+            h_a[i] = (r < nrows && k < H) ? h0[(size_t)(row0 + r) * H + k] : 0.f;
+            h_b[i] = 0.f;
+        }
+        for (int i = tid; i < RS * H3; i += 256) {
+            const int r = i / H3;
+            rowc_l[i] = (d.rowc && r < nrows) ? d.rowc[(size_t)row0 * H3 + i] : 0.f;
+        }
+        for (int i = tid; i < T * RS; i += 256) {
+            const int t = i / RS, r = i - t * RS;
+            tok_l[i] = r < nrows ? d.tok[(size_t)t * B + row0 + r] : 0;
+        }
+        __syncthreads();
+        // input-side pre-activations gi = tab[tok] + rowc of this lane's (row, unit) pairs, fetched ONE STEP AHEAD: the token-table rows
+        // come from global memory (L2), and their latency runs under the previous step's product and cell
+        float gi[RS / 16][4][2][3];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = mt * 16 + 4 * lq + jj;
+                    const float* tr = d.tab + (size_t)tok_l[t * RS + row] * H3;
+                    const float* rc = rowc_l + row * H3;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const int uc = ww.ucl[sub];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) gi[mt][jj][sub][q] = tr[q * H + uc] + rc[q * H + uc];
+                    }
+                }
+        };
+        fetch(d.reverse ? T - 1 : 0);
+        float* hs_src = h_a;
+        float* hs_dst = h_b;
+        for (int p = 0; p < T; ++p) {
+            const int t = d.reverse ? T - 1 - p : p;
+            f32x4 acc[RS / 16][6];
+            gru_product<G, R, 0, RS / 16>(ww, hs_src, acc);
+            float* hs_out = d.hs + (size_t)(d.reverse ? t : t + 1) * BH + (size_t)row0 * H;
+            float* g_out = d.gates ? d.gates + (size_t)t * 4 * BH + (size_t)row0 * H : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = mt * 16 + 4 * lq + jj;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const int uc = ww.ucl[sub];
+                        const float hn = acc[mt][4 + sub][jj] + ww.bh[4 + sub];
+                        const float rg = sigmoid_c(gi[mt][jj][sub][0] + (acc[mt][sub][jj] + ww.bh[sub]));
+                        const float zg = sigmoid_c(gi[mt][jj][sub][1] + (acc[mt][2 + sub][jj] + ww.bh[2 + sub]));
+                        const float ng = tanh_bf(gi[mt][jj][sub][2] + rg * hn);
+                        const float hold = hs_src[row * C::LDH + uc];
+                        const float hnew = (1.f - zg) * ng + zg * hold;
+                        hs_dst[row * C::LDH + ww.col[sub]] = hnew * ww.ownf[sub];
+                        if (ww.ownf[sub] != 0.f && row < nrows) {
+                            const size_t o = (size_t)row * H + uc;
+                            hs_out[o] = hnew;
+                            if (g_out) {
+                                g_out[o] = rg;
+                                g_out[BH + o] = zg;
+                                g_out[2 * BH + o] = ng;
+                                g_out[3 * BH + o] = hn;
+                            }
+                        }
+                    }
+                }
+            if (p + 1 < T) fetch(d.reverse ? t - 1 : t + 1);
+            __syncthreads();   // the new state is complete (and the old one no longer read)
+            float* sw = hs_src;
+            hs_src = hs_dst;
+            hs_dst = sw;
+        }
+    }
+}
+
+static size_t small_fwd_lds(int ldh, int H, int T) { return ((size_t)2 * RS * ldh + (size_t)RS * 3 * H) * 4 + (size_t)T * RS * sizeof(int); }
+
+template <int G, int R>
+int launch_small_fwd(const SmallFwdArgs& a, int ndir, int cus, hipStream_t s) {
+    const size_t bytes = small_fwd_lds(FusedCfg<G, R>::LDH, a.H, a.T);
+    auto kern = gru_seq_small_fwd_kernel<G, R>;
+    int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(kern), (int)bytes);
+    if (rc) return rc;
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipLaunchKernelGGL(kern, dim3(grid, ndir), dim3(256), bytes, s, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- backward.  G3 = 16-deep groups of the contraction over the 3H recurrent gate rows (zero padded): k of MFMA step s, lane group q
+// is 16 (s >> 2) + 4 q + (s & 3) as in the exact-f32 form above.
+struct SmallBwdArgs {
+    CpgSmallBwdDir d[2];
+    int B, H, T, ntiles, upw;   // upw: hidden units per wave (= fused_kp(H) / 4, the forward kernels' split)
+};
+
+template <int G3>
+__global__ __launch_bounds__(256, 1) void gru_seq_small_bwd_kernel(SmallBwdArgs a) {
+    constexpr int KP3 = 16 * G3, KS3 = 4 * G3;
+    constexpr int LDG = ((KP3 / 4 + 1) % 2 == 1) ? KP3 + 4 : KP3 + 8;   // row stride = 4 * odd (ds_read_b128 lane groups on disjoint banks)
+    extern __shared__ float4 cpg_fused_smem[];
+    float* dg_l = reinterpret_cast<float*>(cpg_fused_smem);   // [RS][LDG]: dr_pre | dz_pre | r (.) dn_pre of the step just processed
+    const CpgSmallBwdDir& d = a.d[blockIdx.y];
+    const int H = a.H, B = a.B, T = a.T;
+    const size_t BH = (size_t)B * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    // this wave's hidden units (two 16-column tiles) and W_hh[k][unit] fragments
+    int unit[2];
+    bool own[2];
+    float Bf[KS3][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        const int ul = 16 * sub + l15;
+        unit[sub] = a.upw * wave + ul;
+        own[sub] = ul < a.upw && unit[sub] < H;
+        const int uc = min(unit[sub], H - 1);
+#pragma unroll
+        for (int s = 0; s < KS3; ++s) {
+            const int k = 16 * (s >> 2) + 4 * lq + (s & 3);
+            Bf[s][sub] = (own[sub] && k < 3 * H) ? d.w_hh[(size_t)k * H + uc] : 0.f;
+        }
+        unit[sub] = uc;
+    }
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int row0 = tile * RS, nrows = min(RS, B - row0);
+        __syncthreads();
+        for (int i = tid; i < RS * LDG; i += 256) dg_l[i] = 0.f;
+        float carry[RS / 16][2][4], prod[RS / 16][2][4];
+#pragma unroll
+        for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) carry[mt][sub][jj] = prod[mt][sub][jj] = 0.f;
+        __syncthreads();
+        // epilogue operands of a step (saved gates, h_prev, the external gradients) for this lane's (row, unit) pairs: loaded one step
+        // AHEAD, before the product of the step in front of it - their latency then runs under the MFMAs instead of in front of the cell
+        struct Ep { float rg, zg, ng, hn, hp, ex; };
+        Ep ep[RS / 16][2][4];
+        auto fetch = [&](int p) {
+            const int t = d.reverse ? T - 1 - p : p;
+            const float* gt = d.gates + (size_t)t * 4 * BH + (size_t)row0 * H;
+            const float* hp = d.hs + (size_t)(d.reverse ? t + 1 : t) * BH + (size_t)row0 * H;
+            const float* ex = d.dhs_ext ? d.dhs_ext + (size_t)t * BH + (size_t)row0 * H : nullptr;
+            const float* ex2 = (p == T - 1 && d.dh_last) ? d.dh_last + (size_t)row0 * H : nullptr;
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = min(mt * 16 + 4 * lq + jj, nrows - 1);   // (clamped: branch-free loads; the stores below are guarded)
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const size_t o = (size_t)row * H + unit[sub];
+                        Ep& e = ep[mt][sub][jj];
+                        e.rg = gt[o]; e.zg = gt[BH + o]; e.ng = gt[2 * BH + o]; e.hn = gt[3 * BH + o]; e.hp = hp[o];
+                        e.ex = (ex ? ex[o] : 0.f) + (ex2 ? ex2[o] : 0.f);
+                    }
+                }
+        };
+        fetch(T - 1);
+        for (int p = T - 1; p >= 0; --p) {
+            const int t = d.reverse ? T - 1 - p : p;
+            float* dg = d.dG + ((size_t)t * B + row0) * 4 * H;
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = mt * 16 + 4 * lq + jj;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        if (!(own[sub] && row < nrows)) continue;
+                        const int u = unit[sub];
+                        const Ep e = ep[mt][sub][jj];
+                        const float dh = prod[mt][sub][jj] + carry[mt][sub][jj] + e.ex;
+                        const float rg = e.rg, zg = e.zg, ng = e.ng, hn = e.hn, hprev = e.hp;
+                        const float dn_pre = dh * (1.f - zg) * (1.f - ng * ng);
+                        const float dz_pre = dh * (hprev - ng) * zg * (1.f - zg);
+                        const float dr_pre = dn_pre * hn * rg * (1.f - rg);
+                        carry[mt][sub][jj] = dh * zg;
+                        float* o4 = dg + (size_t)row * 4 * H + u;
+                        o4[0] = dr_pre;
+                        o4[H] = dz_pre;
+                        o4[2 * H] = dn_pre * rg;
+                        o4[3 * H] = dn_pre;
+                        float* l = dg_l + row * LDG + u;
+                        l[0] = dr_pre;
+                        l[H] = dz_pre;
+                        l[2 * H] = dn_pre * rg;
+                    }
+                }
+            if (p > 0) fetch(p - 1);
+            __syncthreads();   // the tile's recurrent gate gradients are complete
+            f32x4 acc[RS / 16][2];
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) acc[mt][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < G3; ++g) {
+                f32x4 af[RS / 16];
+#pragma unroll
+                for (int mt = 0; mt < RS / 16; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(&dg_l[(mt * 16 + l15) * LDG + 16 * g + 4 * lq]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+                            acc[mt][sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][j], Bf[4 * g + j][sub], acc[mt][sub], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) prod[mt][sub][jj] = acc[mt][sub][jj];
+            __syncthreads();   // every wave has read the tile before the next step overwrites it
+        }
+        if (d.dh0) {
+#pragma unroll
+            for (int mt = 0; mt < RS / 16; ++mt)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int row = mt * 16 + 4 * lq + jj;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+                        if (own[sub] && row < nrows) d.dh0[(size_t)(row0 + row) * H + unit[sub]] = prod[mt][sub][jj] + carry[mt][sub][jj];
+                }
+        }
+    }
+}
+
+template <int G3>
+int launch_small_bwd(const SmallBwdArgs& a, int ndir, int cus, hipStream_t s) {
+    constexpr int KP3 = 16 * G3;
+    constexpr int LDG = ((KP3 / 4 + 1) % 2 == 1) ? KP3 + 4 : KP3 + 8;
+    const size_t bytes = (size_t)RS * LDG * 4;
+    auto kern = gru_seq_small_bwd_kernel<G3>;
+    int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(kern), (int)bytes);
+    if (rc) return rc;
+    const int grid = a.ntiles < cus ? a.ntiles : cus;
+    hipLaunchKernelGGL(kern, dim3(grid, ndir), dim3(256), bytes, s, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
+
+// ---- whole-sequence training launches for small GRU recurrences (cpg_internal.h)
+bool cpg_gru_small_seq_ok(int B, int H) {
+    const CpgOptVal o = cpg_opt(OPT_GRU_SMALL_SEQ);
+    if (o.set && o.i == 0) return false;
+    return B > 0 && H > 0 && H <= 128 && cpg_compute_mode_get() != 1;
+}
+int cpg_gru_small_seq_fwd(int T, int B, int H, int ndir, const CpgSmallFwdDir* d, hipStream_t s) {
+    SmallFwdArgs a;
+    for (int i = 0; i < 2; ++i) a.d[i] = d[i < ndir ? i : 0];
+    a.B = B; a.H = H; a.T = T; a.ntiles = cdiv(B, RS);
+    const int cus = cpg_device_cus();
+    CPG_FUSED_DISPATCH(launch_small_fwd, H, a, ndir, cus, s);
+}
+int cpg_gru_small_seq_bwd(int T, int B, int H, int ndir, const CpgSmallBwdDir* d, hipStream_t s) {
+    SmallBwdArgs a;
+    for (int i = 0; i < 2; ++i) a.d[i] = d[i < ndir ? i : 0];
+    a.B = B; a.H = H; a.T = T; a.ntiles = cdiv(B, RS); a.upw = fused_kp(H) / 4;
+    const int cus = cpg_device_cus();
+    if (3 * H <= 96) return launch_small_bwd<6>(a, ndir, cus, s);
+    if (3 * H <= 192) return launch_small_bwd<12>(a, ndir, cus, s);
+    if (3 * H <= 288) return launch_small_bwd<18>(a, ndir, cus, s);
+    if (3 * H <= 320) return launch_small_bwd<20>(a, ndir, cus, s);
+    return launch_small_bwd<24>(a, ndir, cus, s);
+}
 
 CPG_EXPORT size_t cpg_decode_greedy_fused_lds_bytes(int H, int V, int Vt) {
     if (H <= 0 || H > 128 || V <= 0 || V > 32 || Vt <= 0) return 0;

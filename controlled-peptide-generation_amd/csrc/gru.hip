@@ -1116,6 +1116,11 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     const size_t BH = (size_t)B * H;
     const bool gbf = gates && cpg_gru_store_bf16(B, H, step_rows == nullptr);
+    if (tok && !dense && !step_rows && row_begin == 0 && row_end == B && !gbf && T <= 256 && cpg_gru_small_seq_ok(B, H)) {
+        // small recurrence: the whole sequence in one launch (csrc/decode_fused.hip: gru_seq_small_fwd_kernel)
+        const CpgSmallFwdDir d{w_hh, b_hh, tok, tab, rowc, hs, gates, reverse};
+        return cpg_gru_small_seq_fwd(T, B, H, 1, &d, (hipStream_t)stream);
+    }
     for (int p = 0; p < T; ++p) {
         const int t = reverse ? T - 1 - p : p;
         GruFwdArgs a;
@@ -1215,6 +1220,11 @@ static int gru_seq_bwd_impl(int T, int B, int H, int reverse, const float* w_hh,
     const bool allb = ap_scratch != nullptr && dgb;   // bf16 mode's all-T form: bf16 dG as ever + the bf16 state copy in ap_scratch
     const bool allt = ap_scratch != nullptr && !dgb;  // all-T planes: the caller asked cpg_gru_ap_bytes
     const bool pair = allt || (pair_scratch && w_hhT_scratch && !dgb && cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) > 0 && row_begin % 64 == 0);
+    if (!pair && !allb && !dgb && !gbf && !step_rows && row_begin == 0 && row_end == B && !w_hhT_scratch && cpg_gru_small_seq_ok(B, H)) {
+        // small recurrence the direct-to-LDS step does not cover: the whole BPTT chain in one launch (gru_seq_small_bwd_kernel)
+        const CpgSmallBwdDir d{w_hh, hs, gates, dhs_ext, dh_last, dG, dh0, reverse};
+        return cpg_gru_small_seq_bwd(T, B, H, 1, &d, (hipStream_t)stream);
+    }
     uint16_t* PP[2] = {nullptr, nullptr};
     int* EX[2] = {nullptr, nullptr};
     int* EMIN = nullptr;
@@ -1677,6 +1687,10 @@ CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && b_hh_f && w_hh_r && b_hh_r && hs_f && hs_r);
     CPG_CHECK_ARG((tok == nullptr) == (tab_f == nullptr) && (tab_f == nullptr) == (tab_r == nullptr));
     CPG_CHECK_ARG((dense_f == nullptr) == (dense_r == nullptr) && (gates_f == nullptr) == (gates_r == nullptr));
+    if (tok && !dense_f && !(gates_f && cpg_gru_store_bf16(B, H, true)) && T <= 256 && cpg_gru_small_seq_ok(B, H)) {   // small recurrence: one launch for both directions
+        const CpgSmallFwdDir d[2] = {{w_hh_f, b_hh_f, tok, tab_f, nullptr, hs_f, gates_f, 0}, {w_hh_r, b_hh_r, tok, tab_r, nullptr, hs_r, gates_r, 1}};
+        return cpg_gru_small_seq_fwd(T, B, H, 2, d, (hipStream_t)stream);
+    }
     for (int p = 0; p < T; ++p) {
         GruFwdPair pr;
         fill_fwd(pr.d[0], p, T, B, H, 0, w_hh_f, b_hh_f, tok, tab_f, dense_f, hs_f, gates_f);
@@ -1733,6 +1747,12 @@ static int gru_biseq_bwd_impl(int T, int B, int H, const float* w_hh_f, const fl
     const bool allb = ap_f != nullptr && ap_r != nullptr && dgb;   // bf16 mode: bf16 state copies
     const bool allt = ap_f != nullptr && ap_r != nullptr && !dgb;
     const bool pair = allt || (pair_scratch_f && pair_scratch_r && w_hhT_scratch_f && !dgb && cpg_gru_bwd_pair_bytes(B, H, 2) > 0);
+    if (!pair && !allb && !dgb && !cpg_gru_store_bf16(B, H, true) && !w_hhT_scratch_f && cpg_gru_small_seq_ok(B, H)) {
+        // small recurrence: both directions' BPTT chains in one launch (csrc/decode_fused.hip: gru_seq_small_bwd_kernel)
+        const CpgSmallBwdDir d[2] = {{w_hh_f, hs_f, gates_f, dhs_ext_f, dh_last_f, dG_f, nullptr, 0},
+                                     {w_hh_r, hs_r, gates_r, dhs_ext_r, dh_last_r, dG_r, nullptr, 1}};
+        return cpg_gru_small_seq_bwd(T, B, H, 2, d, (hipStream_t)stream);
+    }
     uint16_t* PP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EXP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int* EMIN[2] = {nullptr, nullptr};

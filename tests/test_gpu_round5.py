@@ -478,3 +478,68 @@ def test_vocab_fc_backward_streaming_form_vs_f64(R, H, V, masked):
         tol_w = 3e-6 * dw_bound + (2e-7 * dw0.abs().double() if accumulate else 0)
         assert ((dw_c - dw_ref).abs() <= tol_w).all(), float(((dw_c - dw_ref).abs() / dw_bound).max())
         assert ((db_c - db_ref).abs() <= 3e-6 * dl.abs().double().sum(0) + (2e-7 * db0.abs().double() if accumulate else 0)).all()
+
+
+# ------------------------------------------------------------------------------------------------ small recurrences: whole-sequence launches
+@pytest.mark.parametrize("B,H,T,reverse,with_rowc", [(32, 80, 25, False, False), (32, 80, 25, True, False), (32, 102, 25, False, True),
+                                                     (45, 102, 7, False, True), (100, 20, 5, True, False), (64, 128, 9, False, True),
+                                                     (2048, 102, 25, False, True), (7, 100, 3, True, True)])
+def test_small_recurrence_whole_sequence_launch_vs_per_step(B, H, T, reverse, with_rowc):
+    """The training recurrence of small GRUs as ONE launch per sequence (csrc/decode_fused.hip: gru_seq_small_fwd_kernel /
+    gru_seq_small_bwd_kernel; the reference's default sizes h = 80 / 102, batch 32) against the per-step launches it replaces (option
+    gru_small_seq = 0: csrc/gru.hip's step kernels, the path every golden fixture has pinned): states, saved gates, gate gradients and
+    the initial-state gradient - ragged row counts, widths that are no multiple of anything, both directions, with and without the
+    per-row constant input term, the final-state gradient and external gradients on every state."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 7 + H)
+    V = 24
+    w_hh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(dev)
+    b_hh = (torch.randn(3 * H, generator=g) * 0.1).to(dev)
+    tab = (torch.randn(V, 3 * H, generator=g) * 0.4).to(dev)
+    rowc = (torch.randn(B, 3 * H, generator=g) * 0.4).to(dev) if with_rowc else None
+    tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
+    h0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
+    dlast = (torch.randn(B, H, generator=g) * 0.1).to(dev)
+    out = {}
+    try:
+        for small in (1, 0):
+            ops.set_option("gru_small_seq", small)
+            hs = torch.full((T + 1, B, H), float("nan"), device=dev)
+            hs[T if reverse else 0] = h0
+            gates = torch.full((T, 4, B, H), float("nan"), device=dev)
+            call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, None,
+                 _stream())
+            dG = torch.full((T, B, 4 * H), float("nan"), device=dev)
+            scr = torch.empty(2, B, H, device=dev)
+            dh0 = torch.full((B, H), float("nan"), device=dev)
+            call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs), _p(dlast), _p(dG), _p(scr), _p(dh0), 0, B, None,
+                 None, None, 0, _stream())
+            torch.cuda.synchronize()
+            out[small] = (hs.clone(), gates.clone(), dG.clone(), dh0.clone())
+    finally:
+        ops.set_option("gru_small_seq", None)
+    (hs1, g1, dG1, d01), (hs0, g0, dG0, d00) = out[1], out[0]
+    for a in out[1]:
+        assert torch.isfinite(a).all()
+    # forward: f16-pair products + hardware exp / rcp cell forms against the per-step kernel's engine: a few 1e-6 on O(1) values
+    assert (hs1 - hs0).abs().max().item() <= 2e-5
+    assert (g1 - g0).abs().max().item() <= 4e-5
+    # backward on each path's OWN saved forward values: compare through the gradient scale
+    sc = dG0.abs().max().item()
+    assert (dG1 - dG0).abs().max().item() <= 3e-4 * sc
+    assert (d01 - d00).abs().max().item() <= 3e-4 * max(d00.abs().max().item(), 1e-6)
+    # the backward kernels alone, on identical inputs (the per-step path's forward values): exact-f32 products on both sides
+    ops.set_option("gru_small_seq", 1)
+    try:
+        dG = torch.full((T, B, 4 * H), float("nan"), device=dev)
+        dh0 = torch.full((B, H), float("nan"), device=dev)
+        call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs0), _p(g0), _p(dhs), _p(dlast), _p(dG), _p(torch.empty(2, B, H, device=dev)),
+             _p(dh0), 0, B, None, None, None, 0, _stream())
+        torch.cuda.synchronize()
+    finally:
+        ops.set_option("gru_small_seq", None)
+    assert (dG - dG0).abs().max().item() <= 2e-5 * sc
+    assert (dh0 - d00).abs().max().item() <= 2e-5 * max(d00.abs().max().item(), 1e-6)

@@ -25,7 +25,7 @@ for r in step:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     gap = max(0, s - busy_end) / 1e3
     idle += gap
-    k = r['Kernel_Name'].replace('void ', '')
+    k = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')
     k = k[:k.find('(')] if '(' in k else k
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {gap:7.1f}  q{r.get('Queue_Id', '?'):>3}  {k[:120]}")
     busy_end = max(busy_end, e)
