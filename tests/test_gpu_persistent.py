@@ -15,6 +15,16 @@ def _need_gpu():
         pytest.fail("GPU tests need a real MI355X: no CUDA/HIP device visible")
 
 
+@pytest.fixture(autouse=True)
+def _per_step_kernels():
+    """This module compares the per-step and the persistent kernels with each other, partly bit for bit, also at widths <= 128 where a
+    whole-batch cpg_gru_seq_* call would take round 5's whole-sequence launch (tests/test_gpu_round5.py compares that one): off here."""
+    from cpg import ops
+    ops.set_option("gru_small_seq", 0)
+    yield
+    ops.set_option("gru_small_seq", None)
+
+
 def _inputs(B, H, T, V, seed, dense=False, rowc=True):
     g = torch.Generator().manual_seed(seed)
     dev = torch.device("cuda")
