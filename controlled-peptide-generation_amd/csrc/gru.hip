@@ -1439,6 +1439,106 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
             for (int ks = 0; ks < 8; ++ks) xv[ks] = *reinterpret_cast<const f32x4*>(base + (size_t)ks * C4);
         }
     };
+    if constexpr (DGAP) {
+        // ---- all-T planes form: the operand IS f16 pairs, so the token-grouped sums run on the f16 matrix pipe - per 32 rows, token tile
+        // and column set two v_mfma_f32_16x16x32_f16 (one-hot x high halves, one-hot x low halves: exact products, f32 sums) in place
+        // of eight v_mfma_f32_16x16x4_f32, the step's power of two applied to the step's block sums.  (The exact-f32 form kept the
+        // matrix pipe busy for half of the launch: 64 MFMAs of 32 cycles per wave and step, PMC in profiles/r05_pmc.json.)  The f32
+        // dn_pre block of the GRU (dG = dN) is split here, with one power of two per wave and step (its 32 x 64 values).
+        struct Raw {
+            uint2 hi[8], lo[8];   // row 8 lq + ks: the four columns' high / low halves
+            float sc;             // value = (hi + lo) * sc
+        };
+        const int qb = col / H, cb = col - qb * H;   // (block-uniform)
+        const int G = lstm ? 4 : 3;
+        auto fetch_raw = [&](int t, Raw& r, int (&tv)[8]) {
+            const int4 t0 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw), t1 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw + 4);
+            tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
+            if (qb < G) {
+                const int e = ap_ex[((size_t)t * (B / 32) + bw / 32) * (H / 32) + cb / 32];
+                r.sc = __builtin_bit_cast(float, (unsigned)(127 - (e == INT_MAX ? 0 : e)) << 23);
+                const size_t ldp = (size_t)2 * G * H;
+                const uint16_t* base = ap_planes + ((size_t)t * B + bw) * ldp + (size_t)(G * (cb / 32) + qb) * 64 + (cb & 31);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    r.hi[ks] = *reinterpret_cast<const uint2*>(base + (size_t)ks * ldp);
+                    r.lo[ks] = *reinterpret_cast<const uint2*>(base + (size_t)ks * ldp + 32);
+                }
+            } else {
+                const float* base = dG + ((size_t)t * B + bw) * H + cb;
+                f32x4 v[8];
+                float vmax = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    v[ks] = *reinterpret_cast<const f32x4*>(base + (size_t)ks * H);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) vmax = fmaxf(vmax, fabsf(v[ks][j]));
+                }
+                vmax = wave_max(vmax);
+                // largest value -> [2^13, 2^14): high halves normal down to 2^-27 of it, nothing overflows; all-zero block: scale 1
+                const int ex = vmax > 0.f ? 14 - (int)((__builtin_bit_cast(unsigned, vmax) >> 23) & 0xff) + 126 : 0;
+                const int exc = max(-100, min(100, ex));
+                const float up = __builtin_bit_cast(float, (unsigned)(127 + exc) << 23);
+                r.sc = __builtin_bit_cast(float, (unsigned)(127 - exc) << 23);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    uint32_t h0, l0, h1, l1;
+                    split2h_pair(v[ks][0] * up, v[ks][1] * up, h0, l0);
+                    split2h_pair(v[ks][2] * up, v[ks][3] * up, h1, l1);
+                    r.hi[ks] = make_uint2(h0, h1);
+                    r.lo[ks] = make_uint2(l0, l1);
+                }
+            }
+        };
+        // column j of the lane's 8 rows x 4 columns as an MFMA B fragment (k = 8 lq + i <-> row 8 lq + i)
+        auto colfrag = [&](const uint2 (&w)[8], int j) {
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t a = (j & 2) ? w[2 * i].y : w[2 * i].x, b = (j & 2) ? w[2 * i + 1].y : w[2 * i + 1].x;
+                o[i] = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+            return __builtin_bit_cast(cpg_f16x8, make_uint4(o[0], o[1], o[2], o[3]));
+        };
+        Raw ra, rb;
+        fetch_raw(0, ra, tk);
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) fetch_raw(t + 1, rb, tkn);
+            if (ROWC) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const cpg_f16x2 h0 = __builtin_bit_cast(cpg_f16x2, ra.hi[ks].x), h1 = __builtin_bit_cast(cpg_f16x2, ra.hi[ks].y);
+                    const cpg_f16x2 l0 = __builtin_bit_cast(cpg_f16x2, ra.lo[ks].x), l1 = __builtin_bit_cast(cpg_f16x2, ra.lo[ks].y);
+                    racc[ks] += f32x4{((float)h0[0] + (float)l0[0]) * ra.sc, ((float)h0[1] + (float)l0[1]) * ra.sc,
+                                      ((float)h1[0] + (float)l1[0]) * ra.sc, ((float)h1[1] + (float)l1[1]) * ra.sc};
+                }
+            }
+            cpg_f16x8 oh[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int tokm = 16 * m + l15;
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o[i] = ((tk[2 * i] == tokm || tokm == V) ? 0x3C00u : 0u) | ((tk[2 * i + 1] == tokm || tokm == V) ? 0x3C000000u : 0u);
+                oh[m] = __builtin_bit_cast(cpg_f16x8, make_uint4(o[0], o[1], o[2], o[3]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cpg_f16x8 bh = colfrag(ra.hi, j), bl = colfrag(ra.lo, j);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (m == 1 && !two) break;
+                    f32x4 st = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[m], bl, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(oh[m], bh, st, 0, 0, 0);
+                    acc[m][j] += st * ra.sc;
+                }
+            }
+            ra = rb;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) tk[ks] = tkn[ks];
+        }
+    } else {
     fetch(0, x, tk);
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) fetch(t + 1, xn, tkn);
@@ -1459,6 +1559,7 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
             x[ks] = xn[ks];
             tk[ks] = tkn[ks];
         }
+    }
     }
     if (ROWC) {   // sums over time (the GRU's dhn block, columns [2H,3H) of dG, is not an input-side gradient)
         const bool is_dgi = lstm || col < 2 * H || col >= 3 * H;
