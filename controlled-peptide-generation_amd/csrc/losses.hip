@@ -152,16 +152,49 @@ __global__ void recon_ce_bwd_kernel(const int64_t* ids, const float* logits, int
     const int tgt = (t + 1 < T) ? (int)ids[(size_t)b * T + t + 1] : pad;
     float* d = dlogits + (size_t)row * V;
     if (tgt == pad) {
-        for (int k = 0; k < V; ++k) d[k] = 0.f;
+        if (V % 4 == 0 && (((uintptr_t)dlogits) & 15) == 0)
+            for (int k = 0; k < V; k += 4) *reinterpret_cast<float4*>(d + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else
+            for (int k = 0; k < V; ++k) d[k] = 0.f;
         return;
     }
     const float* l = logits + (size_t)row * V;
+    const float sc = gout[0] / fmaxf(count[0], 1.f);
+    if (V % 4 == 0 && V <= 32 && ((((uintptr_t)logits) | ((uintptr_t)dlogits)) & 15) == 0) {
+        // the row in registers: 16-byte loads / stores (a thread's row is V contiguous floats), the same operations in the same order
+        float x[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (4 * q < V) {
+                const float4 v = *reinterpret_cast<const float4*>(l + 4 * q);
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < V) m = fmaxf(m, x[k]);
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < V) se += expf(x[k] - m);
+        const float lse = m + logf(se);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (4 * q < V) {
+                float4 o;
+                o.x = (expf(x[4 * q] - lse) - (4 * q == tgt ? 1.f : 0.f)) * sc;
+                o.y = (expf(x[4 * q + 1] - lse) - (4 * q + 1 == tgt ? 1.f : 0.f)) * sc;
+                o.z = (expf(x[4 * q + 2] - lse) - (4 * q + 2 == tgt ? 1.f : 0.f)) * sc;
+                o.w = (expf(x[4 * q + 3] - lse) - (4 * q + 3 == tgt ? 1.f : 0.f)) * sc;
+                *reinterpret_cast<float4*>(d + 4 * q) = o;
+            }
+        return;
+    }
     float m = -INFINITY;
     for (int k = 0; k < V; ++k) m = fmaxf(m, l[k]);
     float se = 0.f;
     for (int k = 0; k < V; ++k) se += expf(l[k] - m);
     const float lse = m + logf(se);
-    const float sc = gout[0] / fmaxf(count[0], 1.f);
     for (int k = 0; k < V; ++k) d[k] = (expf(l[k] - lse) - (k == tgt ? 1.f : 0.f)) * sc;
 }
 
@@ -277,7 +310,15 @@ __global__ void rf_colsum_final_kernel(const float* part, int chunks, int R, flo
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * R + r];
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {   // eight loads in flight, added in chunk order (the sums of the plain loop)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + u) * R + r];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < chunks; ++c) s += part[(size_t)c * R + r];
     out[r] = s;
 }
 // feature column sums: sums[R] = sum_b phi(z_b)   (raw [B,R] = z @ rf_w computed by the caller)

@@ -10,7 +10,30 @@
 __global__ void sumsq_partial_kernel(const float* x, size_t n, float* part) {
     __shared__ float red[4];
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * 256) s += x[i] * x[i];
+    if ((((uintptr_t)x) & 15) == 0) {   // 16-byte loads, four running sums per lane, two loads in flight; the tail as scalars
+        const size_t n4 = n / 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t st = (size_t)SUMSQ_BLOCKS * 256;
+        for (; i + st < n4; i += 2 * st) {
+            const float4 u = reinterpret_cast<const float4*>(x)[i], w = reinterpret_cast<const float4*>(x)[i + st];
+            a.x += u.x * u.x + w.x * w.x;
+            a.y += u.y * u.y + w.y * w.y;
+            a.z += u.z * u.z + w.z * w.z;
+            a.w += u.w * u.w + w.w * w.w;
+        }
+        if (i < n4) {
+            const float4 u = reinterpret_cast<const float4*>(x)[i];
+            a.x += u.x * u.x;
+            a.y += u.y * u.y;
+            a.z += u.z * u.z;
+            a.w += u.w * u.w;
+        }
+        s = (a.x + a.y) + (a.z + a.w);
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += x[4 * n4 + threadIdx.x] * x[4 * n4 + threadIdx.x];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * 256) s += x[i] * x[i];
+    }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -41,6 +64,7 @@ CPG_EXPORT int cpg_sumsq(const float* x, size_t n, float mult, int accumulate, f
     return 0;
 }
 
+template <bool VEC>
 __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                                  float eps, float bc1, float bc2_sqrt, const float* sumsq, float max_norm, int coef_pow,
                                  float gscale, int step, const int32_t* iter, int step_mult) {
@@ -55,21 +79,39 @@ __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, s
         bc1 = s_bc[0];
         bc2_sqrt = s_bc[1];
     }
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     float coef = 1.f;
     if (sumsq) {
         const float c = fminf(max_norm / (sqrtf(sumsq[0]) * gscale + 1e-6f), 1.f);  // norm of the scaled gradient
         coef = c;
         for (int k = 1; k < coef_pow; ++k) coef *= c;
     }
-    const float gi = g[i] * gscale * coef;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    auto upd = [&](float gx, float& mx, float& vx, float& px) {
+        const float gi = gx * gscale * coef;
+        mx = b1 * mx + (1.f - b1) * gi;
+        vx = b2 * vx + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vx) / bc2_sqrt + eps;
+        px = px - (lr / bc1) * (mx / denom);
+    };
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC) {   // four elements per thread, 16-byte accesses (the launcher checked the alignment): same arithmetic per element
+        const size_t i = 4 * q;
+        if (i + 3 < n) {
+            float4 gv = *reinterpret_cast<const float4*>(g + i), mv = *reinterpret_cast<const float4*>(m + i);
+            float4 vv = *reinterpret_cast<const float4*>(v + i), pv = *reinterpret_cast<const float4*>(p + i);
+            upd(gv.x, mv.x, vv.x, pv.x);
+            upd(gv.y, mv.y, vv.y, pv.y);
+            upd(gv.z, mv.z, vv.z, pv.z);
+            upd(gv.w, mv.w, vv.w, pv.w);
+            *reinterpret_cast<float4*>(m + i) = mv;
+            *reinterpret_cast<float4*>(v + i) = vv;
+            *reinterpret_cast<float4*>(p + i) = pv;
+        } else {
+            for (size_t j = i; j < n; ++j) upd(g[j], m[j], v[j], p[j]);
+        }
+        return;
+    }
+    if (q >= n) return;
+    upd(g[q], m[q], v[q], p[q]);
 }
 
 // One Adam update (torch.optim.Adam defaults: no weight decay, no amsgrad) of p[0..n) with step number `step` (1-based) - or,
@@ -81,8 +123,12 @@ CPG_EXPORT int cpg_adam_step(float* p, const float* g, float* m, float* v, size_
     CPG_CHECK_ARG(p && g && m && v && n > 0 && step >= 1 && coef_pow >= 1);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                       lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), sumsq, max_norm, coef_pow, gscale, step, iter, step_mult);
+    if (n >= 4096 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v))
+        hipLaunchKernelGGL(adam_step_kernel<true>, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                           lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), sumsq, max_norm, coef_pow, gscale, step, iter, step_mult);
+    else
+        hipLaunchKernelGGL(adam_step_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                           lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), sumsq, max_norm, coef_pow, gscale, step, iter, step_mult);
     CPG_LAUNCH_CHECK();
     return 0;
 }

@@ -80,6 +80,12 @@ __global__ void rng_bernoulli_kernel(uint8_t* out, size_t n, float p_one, uint64
     if (q * 4 >= n) return;
     uint32_t r[4];
     philox4x32(seed, offset + (base ? *base : 0) + q, 2u, r);
+    if (q * 4 + 3 < n && ((((uintptr_t)out) & 3) == 0)) {   // the four flags as one 32-bit store
+        const uint32_t w = (u01(r[0]) < p_one ? 1u : 0u) | (u01(r[1]) < p_one ? 0x100u : 0u) | (u01(r[2]) < p_one ? 0x10000u : 0u) |
+                           (u01(r[3]) < p_one ? 0x1000000u : 0u);
+        reinterpret_cast<uint32_t*>(out)[q] = w;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (q * 4 + k < n) out[q * 4 + k] = u01(r[k]) < p_one ? 1 : 0;

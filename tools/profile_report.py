@@ -22,7 +22,7 @@ def short(n):
 
 line = json.load(open(os.path.join(src, "bench_line.json")))
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_trace.csv"))))
-adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_step")]
+adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].replace("void ", "").startswith("adam_step")]
 per_step = 3   # adam launches per step (duplicate embedding segment twice + the rest)
 steps_total = len(adam) // per_step
 lo = adam[per_step * 5 - 1] + 1           # skip the 5 warm-up steps

@@ -10,7 +10,7 @@ python - <<'PY'
 import csv, collections, glob
 f = glob.glob('gpurun_out/qt/trace/**/t_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-adam = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('adam_step')]
+adam = [i for i, r in enumerate(rows) if r['Kernel_Name'].replace('void ', '').startswith('adam_step')]
 lo, hi = adam[3 * 4 - 1] + 1, adam[-1] + 1
 n = len(adam) // 3 - 4
 agg = collections.defaultdict(lambda: [0, 0.0])
