@@ -1538,6 +1538,57 @@ __global__ __launch_bounds__(256) void dgi_mfma_kernel(const float* dG, const in
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) tk[ks] = tkn[ks];
         }
+    } else if constexpr (DGBF) {
+        // ---- bf16 gradient storage (bf16 compute mode): the operand IS bf16, the one-hot operand is exact in bf16 - ONE v_mfma_f32_16x16x32_bf16
+        // per 32 rows, token tile and column set in place of eight exact-f32 MFMAs on widened values (same products, f32 sums)
+        uint2 wa[8], wb[8];
+        auto fetch_bf = [&](int t, uint2 (&w)[8], int (&tv)[8]) {
+            const int4 t0 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw), t1 = *reinterpret_cast<const int4*>(tok + (size_t)t * B + bw + 4);
+            tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
+            const uint16_t* base = reinterpret_cast<const uint16_t*>(dG) + ((size_t)t * B + bw) * C4 + col;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) w[ks] = *reinterpret_cast<const uint2*>(base + (size_t)ks * C4);
+        };
+        auto colfrag = [&](const uint2 (&w)[8], int j) {   // column j of the lane's 8 rows x 4 columns: k = 8 lq + i <-> row 8 lq + i
+            uint32_t o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t a = (j & 2) ? w[2 * i].y : w[2 * i].x, b = (j & 2) ? w[2 * i + 1].y : w[2 * i + 1].x;
+                o[i] = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+            }
+            return __builtin_bit_cast(cpg_bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+        };
+        fetch_bf(0, wa, tk);
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) fetch_bf(t + 1, wb, tkn);
+            if (ROWC) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    racc[ks] += f32x4{__builtin_bit_cast(float, wa[ks].x << 16), __builtin_bit_cast(float, wa[ks].x & 0xffff0000u),
+                                      __builtin_bit_cast(float, wa[ks].y << 16), __builtin_bit_cast(float, wa[ks].y & 0xffff0000u)};
+            }
+            cpg_bf16x8 oh[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int tokm = 16 * m + l15;
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    o[i] = ((tk[2 * i] == tokm || tokm == V) ? 0x3F80u : 0u) | ((tk[2 * i + 1] == tokm || tokm == V) ? 0x3F800000u : 0u);
+                oh[m] = __builtin_bit_cast(cpg_bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const cpg_bf16x8 bj = colfrag(wa, j);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oh[0], bj, acc[0][j], 0, 0, 0);
+                if (two) acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oh[1], bj, acc[1][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                wa[ks] = wb[ks];
+                tk[ks] = tkn[ks];
+            }
+        }
     } else {
     fetch(0, x, tk);
     for (int t = 0; t < T; ++t) {
