@@ -34,12 +34,16 @@ class PlaneStep:
     state travels as (h f32, image), W_hh's image is built once per decode.  `ok` where the form covers (rows, H); GRU, one layer of
     the recurrence per object (layer 0: token table + row constant)."""
 
-    def __init__(self, decoder, rows, H, lstm):
-        self.ok = (not lstm and os.environ.get("CPG_NO_STEP_PLANES", "") == "" and bool(ops.query("cpg_gru_step_planes_ok", int(rows), int(H))))
+    def __init__(self, decoder, rows, H, lstm, nsent=None):
+        """nsent: sentences of a beam decode (rows = K * nsent) - the step folds the beam re-gather and the per-sentence row constant
+        into its operand loads only from 128 sentences on (cpg_gru_step_fwd_planes checks it); fewer sentences at a wide beam
+        (K = 16, N = 64) keep the round-4 chain instead of failing that check (round-5 advisor finding)."""
+        self.ok = (not lstm and os.environ.get("CPG_NO_STEP_PLANES", "") == "" and bool(ops.query("cpg_gru_step_planes_ok", int(rows), int(H)))
+                   and (nsent is None or int(nsent) >= 128))
         if not self.ok:
             return
         w = decoder.rnn.weight_hh_l0
-        self.wimg = torch.empty(int(ops.query("cpg_pair_rows_bytes", 3 * H, H)), device=w.device, dtype=torch.uint8)
+        self.wimg = torch.empty(int(ops.query("cpg_weight_image_bytes", 3 * H, H)), device=w.device, dtype=torch.uint8)
         call("cpg_gru_step_w_image", _p(w.contiguous()), H, _p(self.wimg), _stream())
         self.b_hh = decoder.rnn.bias_hh_l0
         self.rows, self.H = rows, H
@@ -74,12 +78,19 @@ class UpperLayers:
         self.rnn, self.lstm, self.L = decoder.rnn, lstm, decoder.layers
         self.hs = [torch.stack([h0, torch.empty_like(h0)]) for _ in range(1, self.L)]
         self.cs = [torch.zeros(2, *h0.shape, device=h0.device, dtype=torch.float32) for _ in range(1, self.L)] if lstm else None
+        self._wx_cache = {}
 
     def __bool__(self):
         return self.L > 1
 
     def _w(self, name, l):
         return getattr(self.rnn, f"{name}_l{l}")
+
+    def _wx(self, l):
+        """Exponent record of layer l's W_hh (ops.weight_exp), once per decode."""
+        if l not in self._wx_cache:
+            self._wx_cache[l] = ops.weight_exp(self._w("weight_hh", l))
+        return self._wx_cache[l]
 
     def step(self, x):
         """x [R,H]: layer 0's state after this step -> the top layer's state after this step."""
@@ -91,7 +102,7 @@ class UpperLayers:
                      _p(dense), _p(self.hs[j]), _p(self.cs[j]), None, _stream())
             else:
                 call("cpg_gru_seq_fwd", 1, R, H, 0, _p(self._w("weight_hh", l)), _p(self._w("bias_hh", l)), None, None, None,
-                     _p(dense), _p(self.hs[j]), None, 0, R, None, _stream())
+                     _p(dense), _p(self.hs[j]), None, 0, R, None, _p(self._wx(l)), _stream())
             x = self.hs[j][1]
         return x
 
@@ -224,6 +235,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
     planes = PlaneStep(decoder, N, zc.shape[1], lstm)
     if planes.ok:
         planes.start(h_a)
+    wx = None if (lstm or planes.ok) else ops.weight_exp(w_hh)   # the per-step kernel's f16-pair engine: W_hh's exponent record, once per decode
     tok = torch.full((N,), START_IDX, device=dev, dtype=torch.int32)
     finished = torch.zeros(N, device=dev, dtype=torch.uint8)
     ids = torch.full((N, max_len + 1), PAD_IDX, device=dev, dtype=torch.int64)
@@ -240,7 +252,7 @@ def decode_hard(decoder, z, c, max_len, mode="greedy", temp=1.0, prevent_empty=F
         elif planes.ok:
             planes.step(tok, tab, rowc, h_a, h_b)
         else:
-            ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
+            ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh, wx)
         _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         pe = 1 if (prevent_empty and i == 0) else 0
         if mode == "greedy":
@@ -302,12 +314,13 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
     onehot[:, START_IDX] = 1.0
     ids, softs = [tok.to(torch.int64)], [onehot]
     soft = None
+    wx = None if lstm else ops.weight_exp(rnn.weight_hh_l0)
     for i in range(max_len):
         if soft is None:
             if lstm:
                 ops.lstm_step(tok, tab, rowc, hs[0], cs[0], hs[1], cs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
             else:
-                ops.gru_step(tok, tab, rowc, hs[0], hs[1], rnn.weight_hh_l0, rnn.bias_hh_l0)
+                ops.gru_step(tok, tab, rowc, hs[0], hs[1], rnn.weight_hh_l0, rnn.bias_hh_l0, wx)
         else:
             dense = ops.LinearFn.apply(soft, w_soft, rnn.bias_ih_l0).contiguous()
             if lstm:
@@ -315,7 +328,7 @@ def decode_soft(decoder, z, c, max_len, mode="greedy_softmax", temp=1.0, min_len
                      _p(hs), _p(cs), None, _stream())
             else:
                 call("cpg_gru_seq_fwd", 1, N, H, 0, _p(rnn.weight_hh_l0), _p(rnn.bias_hh_l0), None, None, _p(rowc), _p(dense),
-                     _p(hs), None, 0, N, None, _stream())
+                     _p(hs), None, 0, N, None, _p(wx), _stream())
         _fc(decoder, upper.step(hs[1]) if upper else hs[1], logits, sz, _step_keep(decoder, out_keep, i, N, dev))
         soft = torch.softmax(logits / temp, dim=1)
         if mode == "greedy_softmax":
@@ -379,11 +392,12 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
     w_hh, b_hh = decoder.rnn.weight_hh_l0, decoder.rnn.bias_hh_l0
     upper = UpperLayers(decoder, h_a, lstm)
     H = h_a.shape[1]
-    planes = PlaneStep(decoder, K * N, H, lstm)
+    planes = PlaneStep(decoder, K * N, H, lstm, nsent=N)
     fold = planes.ok and not upper      # the plane step gathers its previous state through the back-pointers: Beam.advance moves no state
     if planes.ok:
         planes.start(h_a)
         rowc1 = rowc1.contiguous()
+    wx = None if (lstm or planes.ok) else ops.weight_exp(w_hh)
     V = decoder.fc[1].weight.shape[0]
     i32 = dict(device=dev, dtype=torch.int32)
     scores = torch.zeros(N, K, device=dev, dtype=torch.float32)
@@ -411,7 +425,7 @@ def decode_beam_raw(decoder, z, c, max_len, beam_size=5, n_best=3, min_length=1,
             # the f32 state and its image), and the constant input term once per sentence instead of once per beam row
             planes.step(tok, tab, rowc1, h_a, h_b, origin if (fold and i > 0) else None, N, K)
         else:
-            ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh)
+            ops.gru_step(tok, tab, rowc, h_a, h_b, w_hh, b_hh, wx)
         _fc(decoder, upper.step(h_b) if upper else h_b, logits, sz, _step_keep(decoder, out_keep, i, K * N, dev))
         call("cpg_beam_select", _p(logits), N, V, K, i, n_best, min_length, START_IDX, EOS_IDX, _p(scores), _p(last_tok),
              _p(n_fin), _p(done), _p(hist_tok), _p(hist_prev), _p(hist_score), _p(origin), _p(tok), _p(n_active),

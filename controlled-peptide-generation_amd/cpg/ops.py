@@ -361,16 +361,31 @@ def _grad_buf(p):
     return g
 
 
+def weight_exp(w):
+    """Exponent record of a weight matrix (cpg_weight_exp: int32 [32] of partial maxima of |w|, one small launch): what the kernels that
+    split weights into f16 pairs on the fly - the per-step GRU forward, cpg_linear_fwd_pairs - take the weights' power of two from, so
+    that ANY finite f32 weight is covered (rounds 4-5 multiplied weights by a fixed 2^8: |w| >= 256 overflowed the f16 high half).
+    A decode computes it once and hands it to every step."""
+    w, ldw = _rowmajor(w)
+    out = torch.empty(int(query("cpg_weight_exp_bytes")) // 4, device=w.device, dtype=torch.int32)
+    call("cpg_weight_exp", _p(w), w.shape[0], w.shape[1], ldw, _p(out), _stream())
+    return out
+
+
 def linear_raw(x, w, b, out=None, accumulate=False, states=False):
-    """states: x holds recurrent states (magnitudes O(1)) - large products then run on f16 pairs (cpg_linear_fwd_pairs)."""
+    """states: x holds recurrent states (magnitudes O(1)) - large products then run on f16 pairs (cpg_linear_fwd_pairs; the weights'
+    range is covered by their exponent record)."""
     x, ldx = _rowmajor(x)
     w, ldw = _rowmajor(w)
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-    call("cpg_linear_fwd_pairs" if states else "cpg_linear_fwd", _p(x), ldx, _p(w), ldw, _p(b), _p(out), out.stride(0), M, N, K,
-         int(accumulate), _stream())
+    if states:
+        call("cpg_linear_fwd_pairs", _p(x), ldx, _p(w), ldw, _p(b), _p(out), out.stride(0), M, N, K, int(accumulate), _p(weight_exp(w)),
+             _stream())
+    else:
+        call("cpg_linear_fwd", _p(x), ldx, _p(w), ldw, _p(b), _p(out), out.stride(0), M, N, K, int(accumulate), _stream())
     return out
 
 
@@ -530,7 +545,7 @@ class Linear2PlanesFn(Function):
         assert K == K1 + K2 and N % gates == 0
         wc = w.contiguous()
         y = torch.empty(R, N, device=w.device, dtype=torch.float32)
-        sc = workspace(int(query("cpg_pair_rows_bytes", N, K)), w.device, tag=7)
+        sc = workspace(int(query("cpg_weight_image_bytes", N, K)), w.device, tag=7)
         call("cpg_linear_fwd_planes", _p(ximg), R, K, _p(wc), K, _p(b), _p(y), N, N, 0, _p(sc), sc.numel(), _stream())
         ctx.save_for_backward(ximg, wc)
         ctx.dims = (R, K1, K2, N, int(gates))
@@ -547,7 +562,7 @@ class Linear2PlanesFn(Function):
         gp = torch.empty(int(query("cpg_grad_planes_bytes", R, H, G)), device=dev, dtype=torch.uint8)
         call("cpg_grad_planes", _p(dy), lddy, R, H, G, off, _p(gp), _stream())
         dx = torch.empty(R, K, device=dev, dtype=torch.float32)
-        sc = workspace(int(query("cpg_pair_rows_bytes", K, N)), dev, tag=7)
+        sc = workspace(int(query("cpg_weight_image_bytes", K, N)), dev, tag=7)
         call("cpg_linear_bwd_input_planes", _p(gp), R, H, G, _p(w), K, _p(dx), K, K, 0, _p(sc), sc.numel(), _stream())
         dw = torch.empty_like(w)
         ws = workspace(int(query("cpg_linear_bwd_weight_planes_workspace", R, H, G, K)), dev)
@@ -756,9 +771,16 @@ def _pair_scratch(B, H, ndir, dev, lstm=False):
     return t if ndir == 2 else t[0]
 
 
-def _ap_scratch(T, B, H, ndir, dev, lstm=False):
+AP_VMAX = 31   # largest token table the plane-reading input-side reductions take (csrc/gru.hip: DM_VMAX)
+
+
+def _ap_scratch(T, B, H, ndir, dev, lstm=False, V=1):
     """Scratch of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes / cpg_lstm_ap_bytes: kept gate-gradient planes of
-    every step, their exponent tables, the state planes): [ndir, bytes] uint8, or None where the form does not cover the shape / mode."""
+    every step, their exponent tables, the state planes): [ndir, bytes] uint8, or None where the form does not cover the shape / mode.
+    V: rows of the layer's token table - the form's input-side reductions (cpg_*_dgi_reduce_ap) take 1..AP_VMAX of them; a larger
+    vocabulary keeps the round-4 form, whose reductions have one-hot GEMM / by-token fallbacks (round-5 advisor finding)."""
+    if not 0 < int(V) <= AP_VMAX:
+        return None
     nb = int(query("cpg_lstm_ap_bytes", int(T), int(B), int(H))) if lstm else int(query("cpg_gru_ap_bytes", int(T), int(B), int(H), int(ndir)))
     if nb == 0:
         return None
@@ -849,7 +871,7 @@ class GruSeqFn(Function):
         else:
             with _prof("fwd_step", T, T=T, B=B, H=H, ndir=1):
                 call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh_c), _p(b_hh_c), _p(tok), _p(tab_c), _p(rowc_c),
-                     _p(dense_c), _p(hs), _p(gates), 0, B, _p(step_rows), _stream())
+                     _p(dense_c), _p(hs), _p(gates), 0, B, _p(step_rows), _p(weight_exp(w_hh_c)), _stream())
         ctx.save_for_backward(tok, w_hh_c, hs, gates)
         ctx.step_rows = step_rows
         ctx.dims = (T, B, H, bool(reverse))
@@ -877,7 +899,7 @@ class GruSeqFn(Function):
         # consumed by the plane-reading reductions only); the recurrent dG blocks then exist only as the kept f16-pair planes
         # (bf16 compute mode with bf16 gradient storage: the same entry points keep that mode's dG and add a bf16 copy of the states,
         # so that its dW_hh product runs the conversion-free loop on one bf16 plane per operand)
-        ap = _ap_scratch(T, B, H, 1, dev) if (step_rows is None and has_tab and not has_dense and gates is not None
+        ap = _ap_scratch(T, B, H, 1, dev, V=ctx.V) if (step_rows is None and has_tab and not has_dense and gates is not None
                                               and (dgb or gates.dtype == torch.float32)) else None
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(B, H, device=dev, dtype=torch.float32) if has_h0 else None
@@ -988,7 +1010,7 @@ class GruBiSeqFn(Function):
         else:
             with _prof("fwd_step", T, T=T, B=B, H=H, ndir=2):
                 call("cpg_gru_biseq_fwd", T, B, H, _p(wf), _p(bf), _p(wr), _p(br), _p(tok), _p(tf), _p(tr), _p(df), _p(dr),
-                     _p(hs_f), _p(hs_r), _p(g_f), _p(g_r), _stream())
+                     _p(hs_f), _p(hs_r), _p(g_f), _p(g_r), _p(weight_exp(wf)), _p(weight_exp(wr)), _stream())
         ctx.save_for_backward(tok, wf, wr, hs_f, hs_r, g_f, g_r)
         ctx.leaves = (w_hh_f, w_hh_r)
         ctx.dims = (T, B, H)
@@ -1015,7 +1037,7 @@ class GruBiSeqFn(Function):
         dgt = dg_dtype(B, H, ctx.V if ctx.has_tab else 0) if (gt_f is not None and gt_f.dtype == torch.bfloat16) else torch.float32
         dgb = int(dgt == torch.bfloat16)   # bf16 gradient storage (bf16 compute mode; see GruSeqFn.backward)
         # all-T planes form (see GruSeqFn.backward): token-table layers only
-        ap = _ap_scratch(T, B, H, 2, dev) if (ctx.has_tab and not ctx.has_dense and (dgb or gt_f.dtype == torch.float32)) else None
+        ap = _ap_scratch(T, B, H, 2, dev, V=ctx.V) if (ctx.has_tab and not ctx.has_dense and (dgb or gt_f.dtype == torch.float32)) else None
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)
         wT = torch.empty(2, H, 3 * H, device=dev, dtype=torch.float32)
         _check_gates(gt_f, B, H)
@@ -1101,10 +1123,13 @@ def join_deferred():
         cur.wait_event(_pending_events.pop())
 
 
-def gru_step(tok, tab, rowc, h_prev, h_out, w_hh, b_hh):
-    """One decode step's recurrent part (GRUDecoder.forward_sample, models/decoder.py:86-99); inference only."""
+def gru_step(tok, tab, rowc, h_prev, h_out, w_hh, b_hh, wx=None):
+    """One decode step's recurrent part (GRUDecoder.forward_sample, models/decoder.py:86-99); inference only.
+    wx: weight_exp(w_hh) - a decode loop computes it once and passes it to every step (None: computed here, one more launch)."""
     B, H = h_prev.shape
-    call("cpg_gru_step_fwd", B, H, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(h_prev), _p(h_out), _stream())
+    if wx is None:
+        wx = weight_exp(w_hh)
+    call("cpg_gru_step_fwd", B, H, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), _p(h_prev), _p(h_out), _p(wx), _stream())
     return h_out
 
 
@@ -1153,7 +1178,7 @@ class LstmSeqFn(Function):
         has_tab, has_rowc, has_dense, has_h0, has_c0 = ctx.has
         # all-T planes form (token-table layers: their bias gradient comes from the input-side reduction): the images of dG the steps
         # hand to each other are kept, feed the conversion-free dW_hh product and the input-side reductions - no f32 dG at all
-        ap = _ap_scratch(T, B, H, 1, dev, lstm=True) if (has_tab and not has_dense) else None
+        ap = _ap_scratch(T, B, H, 1, dev, lstm=True, V=ctx.V) if (has_tab and not has_dense) else None
         dG = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32) if ap is None else None
         scratch = torch.empty(2, B, H, device=dev, dtype=torch.float32)
         need0 = has_h0 or has_c0
@@ -1243,7 +1268,7 @@ class LstmBiSeqFn(Function):
         else:
             ext_f = z(g_hs_f, hs_f).view(-1)[BH:]        # slots 1..T
             ext_r = z(g_hs_r, hs_r).view(-1)[:T * BH]    # slots 0..T-1
-        ap = _ap_scratch(T, B, H, 2, dev, lstm=True) if (ctx.has_tab and not ctx.has_dense) else None   # all-T planes form (see LstmSeqFn.backward)
+        ap = _ap_scratch(T, B, H, 2, dev, lstm=True, V=ctx.V) if (ctx.has_tab and not ctx.has_dense) else None   # all-T planes form (see LstmSeqFn.backward)
         dG_f = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32) if ap is None else None
         dG_r = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32) if ap is None else None
         sc = torch.empty(2, 2, B, H, device=dev, dtype=torch.float32)

@@ -254,7 +254,10 @@ __global__ __launch_bounds__(1024) void vocab_bwd_final_kernel(const float* __re
 // the streaming form covers: V <= 32, H a multiple of 256, enough rows to fill the chip; CPG_VOCAB_BWD=gemm keeps the tile engine
 static bool vocab_bwd_streams(int R, int H, int V) {
     static const bool off = [] { const char* e = getenv("CPG_VOCAB_BWD"); return e && !strcmp(e, "gemm"); }();
-    return !off && V <= 32 && H % 256 == 0 && (H / 256 <= 4 || (H / 256) % 4 == 0) && R >= 4096;
+    // (H / 256 = 3 is NOT covered: four waves per workgroup would be 3 column blocks + a fourth wave re-walking rows of the first -
+    // its bias partial landed in the next workgroup's slot; that width goes to the tile engine - round-5 advisor finding)
+    const int nqb = H / 256;
+    return !off && V <= 32 && H % 256 == 0 && (nqb == 1 || nqb == 2 || nqb % 4 == 0) && R >= 4096;
 }
 static int vocab_bwd_wgs(int R) {
     int g = 2 * cpg_device_cus();

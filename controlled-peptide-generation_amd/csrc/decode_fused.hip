@@ -25,7 +25,7 @@
 #include <stdio.h>
 
 // Product engine of the two fused kernels.  1 (default, round 4): f32-grade on f16 pairs (gemm_core.h: split2h_pair) - W_hh lives in
-// registers as f16-pair MFMA B-fragments times 2^8 (the register count of the f32 fragments it replaces), the A fragments (state
+// registers as f16-pair MFMA B-fragments times a power of two chosen from the wave's own rows (the register count of the f32 fragments it replaces), the A fragments (state
 // rows from LDS) and the fc rows are split when they are read, THREE v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block in place of
 // eight v_mfma_f32_16x16x4_f32 (48-61 matrix-pipe cycles against 268; products exact in the f32 accumulator, dropped lo x lo term
 // <= 2^-22 of a product: closer to the exact sums than a k-ordered f32 fma chain, tests/test_gpu_persistent.py).  0: exact-f32 MFMA.
@@ -81,7 +81,7 @@ __device__ __forceinline__ int k_of_step(int s, int lq) {
 template <int G, int R>
 struct WaveWeights {
 #if CPG_FUSED_PAIR
-    cpg_f16x8 Bh[FusedCfg<G, R>::KB][6], Bl[FusedCfg<G, R>::KB][6];   // W_hh x 2^8 as f16 pairs: lane (unit l15, k = 32 kb + 8 lq + i)
+    cpg_f16x8 Bh[FusedCfg<G, R>::KB][6], Bl[FusedCfg<G, R>::KB][6];   // W_hh x 2^e_w as f16 pairs: lane (unit l15, k = 32 kb + 8 lq + i)
     cpg_f16x4 Bth[FusedCfg<G, R>::KT > 0 ? FusedCfg<G, R>::KT : 1][6], Btl[FusedCfg<G, R>::KT > 0 ? FusedCfg<G, R>::KT : 1][6];   // tail: k = 32 KB + 16 kt + 4 lq + i
 #else
     float Bf[FusedCfg<G, R>::KSTEPS][6];
@@ -92,10 +92,38 @@ struct WaveWeights {
     int col[2];     // LDS column h' goes to: the unit, or one of the row's padding columns [KP, LDH) for idle lanes
     int vclamp0, vclamp1;
     float fcb0, fcb1;
+    // f16-pair build: powers of two of the weights' images, chosen from their largest magnitudes (gemm_core.h: weight_exp_of - any
+    // finite weight is covered; rounds 4-5 used a fixed 2^8).  wback = 2^-e of THIS wave's W_hh rows (its own accumulator columns);
+    // fsc / fback = 2^(+-e) of the vocabulary projection's weights, which stage_tables applies when it fills the LDS copy.
+    float wback, fsc, fback;
 
     __device__ __forceinline__ void load(const DecoderWeights& w) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
         using C = FusedCfg<G, R>;
+        wback = fsc = fback = 1.f;
+#if CPG_FUSED_PAIR
+        float wsc = 1.f;
+        {
+            float m = 0.f;
+            for (int g = 0; g < 3; ++g)
+                for (int u = 0; u < C::UPW; ++u) {
+                    const int unit = C::UPW * wave + u;
+                    if (unit >= w.H) break;
+                    const float* row = w.w_hh + (size_t)(g * w.H + unit) * w.H;
+                    for (int k = lane; k < w.H; k += 64) m = fmaxf(m, fabsf(row[k]));
+                }
+            const int e = weight_exp_of(wave_max(m));
+            wsc = pair_pow2(e);
+            wback = pair_pow2(-e);
+            if (w.fc_w && w.V > 0) {
+                float fm = 0.f;
+                for (int i = lane; i < w.V * w.H; i += 64) fm = fmaxf(fm, fabsf(w.fc_w[i]));
+                const int ef = weight_exp_of(wave_max(fm));
+                fsc = pair_pow2(ef);
+                fback = pair_pow2(-ef);
+            }
+        }
+#endif
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) {
             const int g = nt >> 1, ul = 16 * (nt & 1) + l15, unit = C::UPW * wave + ul;
@@ -108,8 +136,8 @@ struct WaveWeights {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int k = 32 * kb + 8 * lq + 2 * i;
-                    const float x0 = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] * 256.f : 0.f;
-                    const float x1 = (own && k + 1 < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k + 1] * 256.f : 0.f;
+                    const float x0 = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] * wsc : 0.f;
+                    const float x1 = (own && k + 1 < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k + 1] * wsc : 0.f;
                     split2h_pair(x0, x1, hi[i], lo[i]);
                 }
                 Bh[kb][nt] = __builtin_bit_cast(cpg_f16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
@@ -121,8 +149,8 @@ struct WaveWeights {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int k = 32 * C::KB + 16 * kt + 4 * lq + 2 * i;
-                    const float x0 = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] * 256.f : 0.f;
-                    const float x1 = (own && k + 1 < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k + 1] * 256.f : 0.f;
+                    const float x0 = (own && k < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k] * wsc : 0.f;
+                    const float x1 = (own && k + 1 < w.H) ? w.w_hh[(size_t)(g * w.H + unit) * w.H + k + 1] * wsc : 0.f;
                     split2h_pair(x0, x1, hi[i], lo[i]);
                 }
                 Bth[kt][nt] = __builtin_bit_cast(cpg_f16x4, make_uint2(hi[0], hi[1]));
@@ -150,14 +178,14 @@ struct WaveWeights {
     }
 };
 
-// tab -> LDS, fc_w -> LDS rows of stride LDH (zero padded in k)
+// tab -> LDS, fc_w x fsc -> LDS rows of stride LDH (zero padded in k; fsc = WaveWeights::fsc, the power of two of the f16-pair build)
 template <int G, int R>
-__device__ __forceinline__ void stage_tables(const DecoderWeights& w, float* tab_l, float* fc_l) {
+__device__ __forceinline__ void stage_tables(const DecoderWeights& w, float* tab_l, float* fc_l, float fsc) {
     using C = FusedCfg<G, R>;
     for (int i = threadIdx.x; i < w.Vt * 3 * w.H; i += 256) tab_l[i] = w.tab[i];
     for (int i = threadIdx.x; i < w.V * C::LDH; i += 256) {
         const int v = i / C::LDH, k = i - v * C::LDH;
-        fc_l[i] = k < w.H ? w.fc_w[(size_t)v * w.H + k] : 0.f;
+        fc_l[i] = k < w.H ? w.fc_w[(size_t)v * w.H + k] * fsc : 0.f;
     }
 }
 
@@ -236,7 +264,7 @@ __device__ __forceinline__ void gru_product(const WaveWeights<G, R>& ww, const f
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] *= (1.f / 256.f);   // the weights' 2^8 back out (exact)
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] *= ww.wback;   // the weights' power of two back out (exact)
     return;
 #else
 #pragma unroll
@@ -346,8 +374,8 @@ __device__ __forceinline__ void vocab_logits(const WaveWeights<G, R>& ww, const 
     for (int kb = 0; kb < C::KB; ++kb) {
         cpg_f16x8 ah, al, bh0, bl0, bh1, bl1;
         pair_frag<C::KP>(h + (wave * 16 + l15) * C::LDH, kb, lq, 1.f, ah, al);
-        pair_frag<C::KP>(fc_l + ww.vclamp0 * C::LDH, kb, lq, 256.f, bh0, bl0);
-        pair_frag<C::KP>(fc_l + ww.vclamp1 * C::LDH, kb, lq, 256.f, bh1, bl1);
+        pair_frag<C::KP>(fc_l + ww.vclamp0 * C::LDH, kb, lq, 1.f, bh0, bl0);
+        pair_frag<C::KP>(fc_l + ww.vclamp1 * C::LDH, kb, lq, 1.f, bh1, bl1);
         lg[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, lg[0], 0, 0, 0);
         lg[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, lg[1], 0, 0, 0);
         lg[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, lg[0], 0, 0, 0);
@@ -360,8 +388,8 @@ __device__ __forceinline__ void vocab_logits(const WaveWeights<G, R>& ww, const 
         const int k0 = 32 * C::KB + 16 * kt + 4 * lq;
         cpg_f16x4 ah, al, bh0, bl0, bh1, bl1;
         pair_frag16<C::KP>(h + (wave * 16 + l15) * C::LDH, k0, 1.f, ah, al);
-        pair_frag16<C::KP>(fc_l + ww.vclamp0 * C::LDH, k0, 256.f, bh0, bl0);
-        pair_frag16<C::KP>(fc_l + ww.vclamp1 * C::LDH, k0, 256.f, bh1, bl1);
+        pair_frag16<C::KP>(fc_l + ww.vclamp0 * C::LDH, k0, 1.f, bh0, bl0);
+        pair_frag16<C::KP>(fc_l + ww.vclamp1 * C::LDH, k0, 1.f, bh1, bl1);
         lg[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh0, lg[0], 0, 0, 0);
         lg[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh1, lg[1], 0, 0, 0);
         lg[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl0, lg[0], 0, 0, 0);
@@ -369,8 +397,8 @@ __device__ __forceinline__ void vocab_logits(const WaveWeights<G, R>& ww, const 
         lg[0] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh0, lg[0], 0, 0, 0);
         lg[1] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh1, lg[1], 0, 0, 0);
     }
-    lg[0] *= (1.f / 256.f);
-    lg[1] *= (1.f / 256.f);
+    lg[0] *= ww.fback;   // the LDS copy of fc_w carries 2^e_fc (stage_tables)
+    lg[1] *= ww.fback;
 #else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -427,7 +455,7 @@ __device__ __forceinline__ void interleave_mfma_with_rest() {
 
 // One quarter of a half-tile's vocabulary projection per wave: m-tile MT0 + (wave>>1), vocabulary columns 16*(wave&1)..+15.
 template <int G, int R, int MT0>
-__device__ __forceinline__ void half_logits(const float* h, const float* fc_l, const float* fc_b, int V, float* logit_l) {
+__device__ __forceinline__ void half_logits(const float* h, const float* fc_l, const float* fc_b, int V, float* logit_l, float fback) {
     using C = FusedCfg<G, R>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
     const int mrow = (MT0 + (wave >> 1)) * 16, v = 16 * (wave & 1) + l15, vc = min(v, V - 1);
@@ -437,7 +465,7 @@ __device__ __forceinline__ void half_logits(const float* h, const float* fc_l, c
     for (int kb = 0; kb < C::KB; ++kb) {
         cpg_f16x8 ah, al, bh, bl;
         pair_frag<C::KP>(h + (mrow + l15) * C::LDH, kb, lq, 1.f, ah, al);
-        pair_frag<C::KP>(fc_l + vc * C::LDH, kb, lq, 256.f, bh, bl);
+        pair_frag<C::KP>(fc_l + vc * C::LDH, kb, lq, 1.f, bh, bl);
         lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, lg, 0, 0, 0);
@@ -447,12 +475,12 @@ __device__ __forceinline__ void half_logits(const float* h, const float* fc_l, c
         const int k0 = 32 * C::KB + 16 * kt + 4 * lq;
         cpg_f16x4 ah, al, bh, bl;
         pair_frag16<C::KP>(h + (mrow + l15) * C::LDH, k0, 1.f, ah, al);
-        pair_frag16<C::KP>(fc_l + vc * C::LDH, k0, 256.f, bh, bl);
+        pair_frag16<C::KP>(fc_l + vc * C::LDH, k0, 1.f, bh, bl);
         lg = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, lg, 0, 0, 0);
         lg = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, lg, 0, 0, 0);
     }
-    lg *= (1.f / 256.f);
+    lg *= fback;
 #else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     WaveWeights<G, R> ww;
     ww.load(a.w);
-    stage_tables<G, R>(a.w, tab_l, fc_l);
+    stage_tables<G, R>(a.w, tab_l, fc_l, ww.fsc);
     if (tid < 32) fcb_l[tid] = a.w.fc_b[min(tid, V - 1)];
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -548,14 +576,14 @@ __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs 
         for (int step = 0; step < a.T; ++step) {
             // region 1
             gru_product<G, R, 2, 2>(ww, h_l, accQ);
-            half_logits<G, R, 2>(h_l, fc_l, fcb_l, V, logit_l);  // step 0: hQ(0), result unused
+            half_logits<G, R, 2>(h_l, fc_l, fcb_l, V, logit_l, ww.fback);  // step 0: hQ(0), result unused
             gru_cell<G, R, 0, 2>(ww, accP, H, tab_l, rowc_l, tokw_l, nullptr, h_l, h_l);
             interleave_mfma_with_rest<13 * C::KSTEPS>();
             __syncthreads();
             if (step > 0) liveQ = greedy_select_half(a, logit_l, 1, row0, step - 1, finQ, tokw_l);
             // region 2
             gru_product<G, R, 0, 2>(ww, h_l, accP);  // last step: unused
-            half_logits<G, R, 0>(h_l, fc_l, fcb_l, V, logit_l);
+            half_logits<G, R, 0>(h_l, fc_l, fcb_l, V, logit_l, ww.fback);
             gru_cell<G, R, 2, 2>(ww, accQ, H, tab_l, rowc_l, tokw_l, nullptr, h_l, h_l);
             interleave_mfma_with_rest<13 * C::KSTEPS>();
             __syncthreads();
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(256, 1) void decode_greedy_fused_kernel(GreedyArgs 
             if (liveP + liveQ == 0) break;  // whole tile finished (identical decision in every wave): the rest stays <pad>
         }
         if (liveP + liveQ != 0) {  // drain: Q's last step
-            half_logits<G, R, 2>(h_l, fc_l, fcb_l, V, logit_l);
+            half_logits<G, R, 2>(h_l, fc_l, fcb_l, V, logit_l, ww.fback);
             __syncthreads();
             greedy_select_half(a, logit_l, 1, row0, a.T - 1, finQ, tokw_l);
         }
@@ -633,7 +661,7 @@ __global__ __launch_bounds__(256, 1) void decode_beam_fused_kernel(BeamArgs a) {
     const int tid = threadIdx.x;
     WaveWeights<G, R> ww;
     ww.load(a.w);
-    stage_tables<G, R>(a.w, tab_l, fc_l);
+    stage_tables<G, R>(a.w, tab_l, fc_l, ww.fsc);
     if (tid < RM) rcrow_l[tid] = min(tid / K, S - 1);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {

@@ -34,7 +34,8 @@ struct GemmArgs {
     int a_bf16 = 0;                // A holds bf16 elements (OpA::bf16): the dW_hh product on bf16 gate gradients
     const int* a_exps = nullptr;   // PREC 8 (f16 pairs): power-of-two exponent per 32-column group of A's M axis (OpA::exps); the kernel
     int a_exps_mod = 1;            // multiplies the columns by 2^e on the way in and the output rows by 2^-e on the way out
-    float b_pscale = 1.f;          // PREC 8, nn.Linear-shaped form: B (the weights) times this power of two before the split, the result by its inverse
+    const int* b_wx = nullptr;     // PREC 8, nn.Linear-shaped form: partial maxima of B (the weights; cpg_weight_absmax) - B goes in times 2^e_w
+                                   // (gemm_core.h: weight_exp_from_parts), the result comes out times its inverse
 };
 
 // PREC: 7 = f32-grade (three bf16 planes), 8 = f32-grade on f16 pairs (the dW_hh product behind the f16-pair BPTT), 1 = bf16 compute
@@ -63,7 +64,12 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
     OpA a{g.a_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g.A) + aoff) : g.A + aoff, g.lda, m0, g.M,
           g.a_mask ? g.a_mask + aoff : nullptr, g.a_mscale, g.pairs_a, g.a_bf16, g.a_exps, g.a_exps_mod};
     OpB b{g.B + boff, g.ldb, n0, g.N, 0, g.b_mask ? g.b_mask + boff : nullptr, g.b_mscale, g.pairs_b};
-    if constexpr (PREC == 8 && A_KC && B_KC) b.pscale = g.b_pscale;
+    float b_back = 1.f;
+    if constexpr (PREC == 8 && A_KC && B_KC) {
+        const int e = weight_exp_from_parts(g.b_wx);
+        b.pscale = pair_pow2(e);
+        b_back = pair_pow2(-e);
+    }
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(TC::NT) void gemm_kernel(GemmArgs g) {
                 if (row >= g.M) continue;
                 const size_t o = (size_t)row * g.ldc + col;
                 if constexpr (PREC == 8 && A_KC && B_KC) {
-                    acc[mi][ni][r] *= 1.f / g.b_pscale;   // the weights' power of two back out (exact)
+                    acc[mi][ni][r] *= b_back;   // the weights' power of two back out (exact)
                 } else if constexpr (PREC == 8) {   // take the column scale of the A operand back out (exact)
                     const int e = g.a_exps ? g.a_exps[(row % g.a_exps_mod) / 32] : 0;
                     acc[mi][ni][r] *= __builtin_bit_cast(float, (unsigned)(127 - (e == INT_MAX ? 0 : e)) << 23);
@@ -344,16 +350,52 @@ int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const 
     return launch_gemm<true, true>(g, 1, s);
 }
 
+// ---- largest magnitude of a weight matrix, for the engines that split weights into f16 pairs (gemm_core.h: weight_exp_from_parts).
+// Block b takes rows b, b + WX_PARTS, ...; 16-byte loads where the rows allow them.  wx[b] = float bits of the block's maximum.
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, int rows, int cols, int ld, int vec, int* __restrict__ wx) {
+    __shared__ float red[4];
+    float m = 0.f;
+    if (vec) {
+        const int q4 = cols >> 2;
+        for (int r = blockIdx.x; r < rows; r += WX_PARTS)
+            for (int c = threadIdx.x; c < q4; c += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)r * ld + 4 * c);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            }
+    } else {
+        for (int r = blockIdx.x; r < rows; r += WX_PARTS)
+            for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(w[(size_t)r * ld + c]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) wx[blockIdx.x] = __builtin_bit_cast(int, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+int cpg_weight_absmax(const float* w, int rows, int cols, int ld, int* wx, hipStream_t s) {
+    if (!w || !wx || rows <= 0 || cols <= 0 || ld < cols) { cpg_set_error("cpg_weight_absmax: bad argument"); return -2; }
+    const int vec = (cols % 4 == 0 && ld % 4 == 0 && aligned16(w)) ? 1 : 0;
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3(WX_PARTS), dim3(256), 0, s, w, rows, cols, ld, vec, wx);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// C ABI: the exponent record (cpg_weight_exp_bytes() bytes, device memory) of a weight matrix [rows, cols] (row stride ld) - what the
+// entry points that split weights into f16 pairs on the fly take as `wx` (cpg_gru_step_fwd, cpg_gru_seq_fwd, cpg_linear_fwd_pairs)
+CPG_EXPORT size_t cpg_weight_exp_bytes(void) { return WX_PARTS * sizeof(int); }
+CPG_EXPORT int cpg_weight_exp(const float* w, int rows, int cols, int ld, void* wx, void* stream) {
+    return cpg_weight_absmax(w, rows, cols, ld, (int*)wx, (hipStream_t)stream);
+}
+
 // y = x W^T + b on f16 pairs (three f16 MFMAs per block, gemm_core.h) for inputs the CALLER vouches for: magnitudes O(1) (|x| < 65504,
-// absolute precision 2^-25 below 2^-14) - recurrent states.  W goes in times 2^8 (weights of magnitude 2^-11 .. 255 keep full precision).
+// absolute precision 2^-25 below 2^-14) - recurrent states.  W goes in times 2^e_w, e_w from the matrix' own largest magnitude (wx:
+// cpg_weight_exp over W - any finite weight is covered; without wx the product runs the exact-f32 engine).
 // Large products only (the 128 x 64 tile, 16-byte staging path); everything else runs cpg_gemm_nt.
 int cpg_gemm_nt_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M, int N, int K,
-                      int accumulate, hipStream_t s) {
+                      int accumulate, const int* wx, hipStream_t s) {
     const bool vec = aligned16(X) && aligned16(W) && ldx % 4 == 0 && ldw % 4 == 0 && K % 4 == 0;
-    if (!vec || cpg_compute_mode_get() == 1 || (long)cdiv(M, 128) * cdiv(N, 64) < 512 || K < 256)
+    if (!wx || !vec || cpg_compute_mode_get() == 1 || (long)cdiv(M, 128) * cdiv(N, 64) < 512 || K < 256)
         return cpg_gemm_nt(X, ldx, nullptr, 1.f, W, ldw, bias, Y, ldy, M, N, K, accumulate, s);
     GemmArgs g{X, ldx, M, W, ldw, N, K, Y, ldy, bias, accumulate, nullptr, 1.f, nullptr, 1.f, nullptr, 1.f, 0, 0};
-    g.b_pscale = 256.f;
+    g.b_wx = wx;
     using TC = TileCfg<128, 64, 32, 2, 2, 1>;
     const size_t smem = GemmLoop<TC, true, true, true, false, 8>::smem_bytes();
     if (smem > 64 * 1024) {
@@ -624,9 +666,9 @@ CPG_EXPORT int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
 // cpg_linear_fwd for an input of O(1) magnitudes (recurrent states: the input projection of an upper encoder layer) - large products
 // then run on f16 pairs, see cpg_gemm_nt_pairs; same results within f32 rounding
 CPG_EXPORT int cpg_linear_fwd_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
-                                    int N, int K, int accumulate, void* stream) {
+                                    int N, int K, int accumulate, const void* wx, void* stream) {
     CPG_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
-    return cpg_gemm_nt_pairs(X, ldx, W, ldw, bias, Y, ldy, M, N, K, accumulate, (hipStream_t)stream);
+    return cpg_gemm_nt_pairs(X, ldx, W, ldw, bias, Y, ldy, M, N, K, accumulate, (const int*)wx, (hipStream_t)stream);
 }
 
 CPG_EXPORT int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,

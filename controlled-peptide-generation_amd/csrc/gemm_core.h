@@ -67,8 +67,8 @@ struct OpB {
     const uint8_t* mask;
     float mscale;
     int pairs = 0;   // as OpA::pairs
-    float pscale = 1.f;   // SPLIT 8 (f16 pairs): power of two the operand is multiplied by before the split (weights: 2^8, see the f16-pair
-                          // notes above split2h_pair); the caller takes it back out of the accumulators
+    float pscale = 1.f;   // SPLIT 8 (f16 pairs): power of two the operand is multiplied by before the split (weights: 2^e_w from
+                          // weight_exp_from_parts below); the caller takes it back out of the accumulators
 };
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NSEG_, int NT_ = 256>
@@ -207,6 +207,33 @@ __device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t& w0, u
     w0 = __builtin_bit_cast(uint32_t, a);
     w1 = __builtin_bit_cast(uint32_t, c);
 }
+
+__device__ __forceinline__ float pair_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // |e| <= 126
+
+// ---- the power of two a WEIGHT matrix is multiplied by before it is split into f16 pairs (round 6; rounds 4-5 used a fixed 2^8, which
+// turned a weight of magnitude >= 256 into an f16 infinity).  Chosen per matrix from its largest magnitude, on the device:
+// cpg_weight_absmax (gemm.hip) leaves WX_PARTS partial maxima (float bits) in `wx`; every kernel that images or consumes the matrix
+// derives the same exponent e from them - max|W| 2^e in [2^13, 2^14), the convention of the gradient images and of the persistent
+// forward's W_hh slices - so any finite f32 weight is representable and the pair keeps 22 significand bits down to 2^-26 max|W|
+// (absolute floor 2^-25 2^-e below that).  An all-zero matrix takes e = 0; an infinity among the weights goes in unscaled and reaches
+// the result as it is (as in f32 arithmetic).
+constexpr int WX_PARTS = 32;
+__device__ __forceinline__ int weight_exp_of(float vmax) {
+    if (!(vmax > 0.f) || vmax >= 3.0e38f) return 0;
+    int fe = 0;
+    (void)frexpf(vmax, &fe);
+    return max(-100, min(100, 14 - fe));
+}
+// every lane of a wave gets the matrix' exponent (wave-uniform by construction: all lanes reduce the same WX_PARTS values)
+__device__ __forceinline__ int weight_exp_from_parts(const int* __restrict__ wx) {
+    float v = __builtin_bit_cast(float, wx[__lane_id() & (WX_PARTS - 1)]);
+#pragma unroll
+    for (int o = WX_PARTS / 2; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return __builtin_amdgcn_readfirstlane(weight_exp_of(v));
+}
+// wx[0 .. WX_PARTS) = float bits of partial maxima of |w| over a [rows, cols] matrix of row stride ld (one launch)
+int cpg_weight_absmax(const float* w, int rows, int cols, int ld, int* wx, hipStream_t s);
+
 
 // SPLIT = 0: exact-f32 MFMA on f32 LDS images (the layouts described at the top of this file).
 // (Splitting per wave at fragment-read time on the f32 LDS images was tried first: the conversion is then repeated by

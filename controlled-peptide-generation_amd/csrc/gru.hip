@@ -44,6 +44,8 @@ struct GruFwdArgs {
                          // can run as separate launch chains on separate streams, out of phase with each other
     const int32_t* nrows;  // device scalar or null: only rows < *nrows are live at this step (length-sorted batches:
                            // rows whose remaining targets are all <pad> need no state) - read on the device, no host sync
+    const int* wx = nullptr;   // exponent record of w_hh (cpg_weight_exp): the f16-pair engine multiplies W_hh by 2^e_w before its split
+                               // (gemm_core.h: weight_exp_from_parts); null: the launch runs the bf16x3 engine, which needs none
 };
 
 // Up to two independent sequences (the two directions of a biGRU layer) share one launch: gridDim.z selects the
@@ -114,8 +116,13 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
 
     OpA a{g.h_prev, H, m0, B, nullptr, 1.f};
     OpB b{g.w_hh, H, j0, H, H, nullptr, 1.f};
-    constexpr bool PAIR = FwdLoop<TC, VEC, PREC>::NP == 2;   // PREC 8 on the plane engine: f16 pairs, W_hh times 2^8 (gemm_core.h)
-    if constexpr (PAIR) b.pscale = 256.f;
+    constexpr bool PAIR = FwdLoop<TC, VEC, PREC>::NP == 2;   // PREC 8 on the plane engine: f16 pairs, W_hh times 2^e_w (gemm_core.h)
+    float w_back = 1.f;
+    if constexpr (PAIR) {
+        const int e = weight_exp_from_parts(g.wx);
+        b.pscale = pair_pow2(e);
+        w_back = pair_pow2(-e);
+    }
     f32x4 acc[TC::MI][TC::NI];
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(GruFwdPair pr) {
 #pragma unroll
         for (int mi = 0; mi < TC::MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] *= (1.f / 256.f);
+            for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] *= w_back;
     }
 #if !CPG_FWD_PREFETCH
     fetch();
@@ -189,7 +196,7 @@ struct GruBwdArgs {
     // f16-pair engine of the direct-to-LDS step (PREC 3, below): the three recurrent blocks of dG once more, as the NEXT launch's
     // A operand - [B][6H] f16, k-groups of 32 in the order (column group, block), each 128 bytes = [32 hi | 32 lo] of the values
     // times 2^e, e = ex[(row / 32) * (H / 32) + column group] (INT_MAX: the 32 x 32 x 3 values are all zero).  w_hhT then holds the
-    // same layout of W_hh^T times 2^W_PAIR_EXP.
+    // same layout of W_hh^T times 2^e_w (pair_engine.h: weight_exp_from_parts over ex_min + H/32).
     const uint16_t* pp_next;
     const int* ex_next;
     uint16_t* pp_out;
@@ -471,6 +478,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             }
     };
     PairConsumer<MI, NI, 3> pc;   // PREC 3 (pair_engine.h)
+    const int w_exp = (PREC == 3 && g.dG_next) ? weight_exp_from_parts(g.ex_min + H / 32) : 0;   // power of two of the W_hh^T image
     if (g.dG_next && !(CPG_DL_ABLATE & 4)) {
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3;
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
             pc.init(g.ex_next + (size_t)((m0 + wm * 32) / 32) * (H / 32), H / 32, lane);
             DL::run(g.pp_next + (size_t)m0 * 6 * H, (size_t)6 * H, reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 6 * H,
                     (size_t)6 * H, 6 * H, cpg_smem, acc, min(phase * g.ep_step, 3 * H / 32 - 1), load_ep, [&](int kt) { return pc.pre(kt, acc); });
-            pc.finish(acc);
+            pc.finish(acc, w_exp);
         } else if constexpr (PREC == 2)
             DL::run(reinterpret_cast<const uint16_t*>(g.dG_next) + (size_t)m0 * 4 * H, (size_t)4 * H,
                     reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 3 * H, (size_t)3 * H, 3 * H, cpg_smem, acc,
@@ -647,7 +655,9 @@ template <class TC>
 static int launch_fwd(const GruFwdPair& pr, int nd, bool vec, hipStream_t s) {
     // f32-grade mode: the engine of the persistent forward kernels (option f32_engine: f16 pairs by default, three bf16 planes)
     const int np = cpg_persist_planes();
-    return np == 1 ? launch_fwd_p<TC, 1>(pr, nd, vec, s) : np == 2 ? launch_fwd_p<TC, 8>(pr, nd, vec, s) : launch_fwd_p<TC, 7>(pr, nd, vec, s);
+    bool have_wx = true;   // the f16-pair engine needs the exponent record of every direction's W_hh; without it: bf16x3 (no range to guard)
+    for (int d = 0; d < nd; ++d) have_wx = have_wx && pr.d[d].wx != nullptr;
+    return np == 1 ? launch_fwd_p<TC, 1>(pr, nd, vec, s) : (np == 2 && have_wx) ? launch_fwd_p<TC, 8>(pr, nd, vec, s) : launch_fwd_p<TC, 7>(pr, nd, vec, s);
 }
 
 template <class TC>
@@ -889,12 +899,13 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
 }
 
 // W_hh^T as f16 pairs for the PREC 3 backward steps (pair_engine.h): out[j][2 G H] f16, k-groups of 32 in the order (column group,
-// block) as the dG planes, each [32 hi | 32 lo] of W_hh[k][j] x 2^W_PAIR_EXP.  The scale is FIXED: weights of magnitude
-// 2^-11 .. 255 keep a normal low half (2^-22 relative), smaller ones 2^-33 absolute; a weight of 256 or more overflows the f16 high
-// half to infinity (loud: it reaches every gradient).  grid (H/32, G H/32), block (32, 8).
+// block) as the dG planes, each [32 hi | 32 lo] of W_hh[k][j] x 2^e_w.  e_w follows the matrix' largest magnitude (pair_engine.h:
+// weight_exp_from_parts over wx = ex_min + H/32, filled by cpg_weight_absmax just before): max|W| 2^e_w in [2^13, 2^14), so any finite
+// weight has an image (rounds 4-5 scaled by a fixed 2^8: a weight of 256 or more became an f16 infinity).  grid (H/32, G H/32), block (32, 8).
 __global__ void pair_w_kernel(const float* w, int G, int H, uint16_t* out, int* ex_min) {
     __shared__ float tile[32][33];
-    if (ex_min && blockIdx.x == 0 && blockIdx.y == 0) {   // a new sequence: no exponent seen yet
+    const float sc = pair_pow2(weight_exp_from_parts(ex_min + H / 32));
+    if (blockIdx.x == 0 && blockIdx.y == 0) {   // a new sequence: no exponent seen yet
         for (int i = threadIdx.y * 32 + threadIdx.x; i < H / 32; i += 256) ex_min[i] = INT_MAX;
     }
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // tile[k - r0][j - c0]
@@ -902,7 +913,6 @@ __global__ void pair_w_kernel(const float* w, int G, int H, uint16_t* out, int* 
     __syncthreads();
     const int tid = threadIdx.y * 32 + threadIdx.x, jj = tid >> 3, q = tid & 7, c8 = (q & 3) * 8;
     const int blk = r0 / H, grp = (r0 - blk * H) / 32;
-    const float sc = pair_pow2(W_PAIR_EXP);
     uint32_t hi[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2h_pair(tile[c8 + 2 * i][jj] * sc, tile[c8 + 2 * i + 1][jj] * sc, hi[i], lo[i]);
@@ -910,6 +920,9 @@ __global__ void pair_w_kernel(const float* w, int G, int H, uint16_t* out, int* 
     *reinterpret_cast<uint4*>(d) = (q >> 2) ? make_uint4(lo[0], lo[1], lo[2], lo[3]) : make_uint4(hi[0], hi[1], hi[2], hi[3]);
 }
 int cpg_pair_w(const float* w_hh, int G, int H, uint16_t* out, int* ex_min, hipStream_t s) {
+    if (!ex_min) { cpg_set_error("cpg_pair_w: the f16-pair image of W_hh needs the scratch that carries its exponent"); return -4; }
+    const int rc = cpg_weight_absmax(w_hh, G * H, H, H, ex_min + H / 32, s);
+    if (rc) return rc;
     hipLaunchKernelGGL(pair_w_kernel, dim3(H / 32, G * H / 32), dim3(32, 8), 0, s, w_hh, G, H, out, ex_min);
     CPG_LAUNCH_CHECK();
     return 0;
@@ -1111,7 +1124,7 @@ CPG_EXPORT int cpg_gru_dg_bf16(int B, int H, int ragged, int V) { return cpg_gru
 
 CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                                const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                               int row_begin, int row_end, const int32_t* step_rows, void* stream) {
+                               int row_begin, int row_end, const int32_t* step_rows, const void* wx, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh && b_hh && hs && 0 <= row_begin && row_begin < row_end && row_end <= B);
     CPG_CHECK_ARG((tok == nullptr) == (tab == nullptr));
     const size_t BH = (size_t)B * H;
@@ -1139,6 +1152,7 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
         a.row0 = row_begin;
         a.row1 = row_end;
         a.nrows = step_rows ? step_rows + t : nullptr;
+        a.wx = (const int*)wx;
         int rc = cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
         if (rc) return rc;
     }
@@ -1147,9 +1161,9 @@ CPG_EXPORT int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_
 
 // One decode step (GRUDecoder.forward_sample, models/decoder.py:86-109, without the vocab projection).
 CPG_EXPORT int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
-                                const float* rowc, const float* h_prev, float* h_out, void* stream) {
+                                const float* rowc, const float* h_prev, float* h_out, const void* wx, void* stream) {
     CPG_CHECK_ARG(B > 0 && H > 0 && w_hh && b_hh && h_prev && h_out && h_prev != h_out);
-    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, 0, B, H, 0, B, nullptr};
+    GruFwdArgs a{h_prev, w_hh, b_hh, tok, tab, rowc, nullptr, h_out, nullptr, 0, B, H, 0, B, nullptr, (const int*)wx};
     return cpg_gru_step_fwd_launch(a, (hipStream_t)stream);
 }
 
@@ -1835,7 +1849,7 @@ static void fill_fwd(GruFwdArgs& a, int t, int T, int B, int H, int reverse, con
 CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const float* b_hh_f, const float* w_hh_r,
                                  const float* b_hh_r, const int32_t* tok, const float* tab_f, const float* tab_r,
                                  const float* dense_f, const float* dense_r, float* hs_f, float* hs_r, float* gates_f,
-                                 float* gates_r, void* stream) {
+                                 float* gates_r, const void* wx_f, const void* wx_r, void* stream) {
     CPG_CHECK_ARG(T > 0 && B > 0 && H > 0 && w_hh_f && b_hh_f && w_hh_r && b_hh_r && hs_f && hs_r);
     CPG_CHECK_ARG((tok == nullptr) == (tab_f == nullptr) && (tab_f == nullptr) == (tab_r == nullptr));
     CPG_CHECK_ARG((dense_f == nullptr) == (dense_r == nullptr) && (gates_f == nullptr) == (gates_r == nullptr));
@@ -1847,6 +1861,8 @@ CPG_EXPORT int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const
         GruFwdPair pr;
         fill_fwd(pr.d[0], p, T, B, H, 0, w_hh_f, b_hh_f, tok, tab_f, dense_f, hs_f, gates_f);
         fill_fwd(pr.d[1], T - 1 - p, T, B, H, 1, w_hh_r, b_hh_r, tok, tab_r, dense_r, hs_r, gates_r);
+        pr.d[0].wx = (const int*)wx_f;
+        pr.d[1].wx = (const int*)wx_r;
         int rc = gru_fwd_launch(pr, 2, (hipStream_t)stream);
         if (rc) return rc;
     }

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
             }
     };
     PairConsumer<MI, NI, 4> pc;
+    const int w_exp = (PREC == 3 && g.pp_next) ? weight_exp_from_parts(g.ex_min + H / 32) : 0;   // power of two of the W_hh^T image (pair_engine.h)
     if (PREC == 3 ? g.pp_next != nullptr : g.dG_next != nullptr) {   // (the all-T planes form has no f32 dG)
         const int hb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int phase = ((hb >> 3) + (hb >> 8)) & 3, KT = 4 * H / 32;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
             pc.init(g.ex_next + (size_t)((m0 + wm * 32) / 32) * (H / 32), H / 32, lane);
             DL::run(g.pp_next + (size_t)m0 * 8 * H, (size_t)8 * H, reinterpret_cast<const uint16_t*>(g.w_hhT) + (size_t)j0 * 8 * H,
                     (size_t)8 * H, 8 * H, cpg_smem, acc, min(phase * ((KT / 4) & ~1), KT - 1), load_ep, [&](int kt) { return pc.pre(kt, acc); });
-            pc.finish(acc);
+            pc.finish(acc, w_exp);
         } else {
             DL::run(g.dG_next + (size_t)m0 * 4 * H, (size_t)4 * H, g.w_hhT + (size_t)j0 * 4 * H, (size_t)4 * H, 4 * H, cpg_smem, acc,
                     min(phase * ((KT / 4) & ~1), KT - 1), load_ep);

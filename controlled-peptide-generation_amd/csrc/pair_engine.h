@@ -2,7 +2,8 @@
 // DlLoop in gemm_core.h).  A launch leaves the G recurrent blocks of its gate gradients dG [B, G H] once more, as the NEXT launch's
 // A operand: planes[B][2 G H] f16, k-groups of 32 in the order (32-column group, block), each 128 bytes = [32 hi | 32 lo] of the
 // values times 2^e, e = ex[(row / 32) * (H / 32) + group] chosen so that the largest magnitude of the 32 rows x 32 columns x G
-// blocks lands in [2^13, 2^14) (INT_MAX: all zero).  W_hh^T is laid out the same way (cpg_pair_w) times 2^W_PAIR_EXP.  The consumer
+// blocks lands in [2^13, 2^14) (INT_MAX: all zero).  W_hh^T is laid out the same way (cpg_pair_w) times 2^e_w, e_w = the matrix' own exponent
+// (weight_exp_from_parts below).  The consumer
 // rescales its accumulators (an exact power of two) where the exponent changes along k and skips groups that are all zero or more
 // than 2^60 below the largest one.  ex_min[group] keeps the smallest exponent any launch of the sequence recorded: the column scale
 // of the dW_hh product on f16 pairs (gemm.hip, PREC 8).
@@ -10,9 +11,7 @@
 #include "gemm_core.h"
 #include <limits.h>
 
-constexpr int W_PAIR_EXP = 8;   // power-of-two scale of the f16-pair image of W_hh^T
-
-__device__ __forceinline__ float pair_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // |e| <= 126
+// (pair_pow2, WX_PARTS, weight_exp_from_parts, cpg_weight_absmax: gemm_core.h - every engine that splits weights shares them)
 
 // ---- consumer side: exponents of this wave's 32 rows (lane l holds group l's), the rescaling hook of DlLoop::run, the final factor
 template <int MI, int NI, int G>
@@ -44,9 +43,9 @@ struct PairConsumer {
         }
         return live;
     }
-    // accumulators hold (sum) x 2^(e_cur + W_PAIR_EXP): back to the unit of the result, two exact factors (each a normal f32)
-    __device__ __forceinline__ void finish(f32x4 (&acc)[MI][NI]) const {
-        const float f0 = pair_pow2(-e_cur), f1 = pair_pow2(-W_PAIR_EXP);
+    // accumulators hold (sum) x 2^(e_cur + w_exp): back to the unit of the result, two exact factors (each a normal f32)
+    __device__ __forceinline__ void finish(f32x4 (&acc)[MI][NI], int w_exp) const {
+        const float f0 = pair_pow2(-e_cur), f1 = pair_pow2(-w_exp);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -94,8 +93,9 @@ __device__ __forceinline__ void pair_store4(uint16_t* planes, size_t row, int H,
 }
 
 // scratch of one direction: two plane images (ping-pong over the steps), their two exponent tables, the column minima
+// (+ WX_PARTS ints behind ex_min: the partial maxima of W_hh, see weight_exp_from_parts)
 static inline size_t pair_scratch_bytes(int rows, int H, int G) {
-    return 2 * ((size_t)rows * 2 * G * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int)) + (size_t)(H / 32) * sizeof(int);
+    return 2 * ((size_t)rows * 2 * G * H * sizeof(uint16_t) + (size_t)(rows / 32) * (H / 32) * sizeof(int)) + (size_t)(H / 32 + WX_PARTS) * sizeof(int);
 }
 static inline void pair_split(void* scratch, int B, int H, int G, uint16_t* (&pp)[2], int* (&ex)[2], int*& ex_min) {
     const size_t plane = (size_t)B * 2 * G * H;
@@ -115,10 +115,10 @@ struct ApScratch {
     uint16_t* planes;    // [T][B][2 G H]
     uint16_t* hplanes;   // [T][B][2 H]
     int* ex;             // [T][B/32][H/32]
-    int* ex_min;         // [H/32]
+    int* ex_min;         // [H/32], then WX_PARTS ints: partial maxima of W_hh (wx = ex_min + H/32)
 };
 static inline size_t ap_scratch_bytes(int T, int B, int H, int G) {
-    return (size_t)T * B * 2 * (G + 1) * H * sizeof(uint16_t) + ((size_t)T * (B / 32) * (H / 32) + (size_t)(H / 32)) * sizeof(int);
+    return (size_t)T * B * 2 * (G + 1) * H * sizeof(uint16_t) + ((size_t)T * (B / 32) * (H / 32) + (size_t)(H / 32) + WX_PARTS) * sizeof(int);
 }
 static inline ApScratch ap_split(void* scratch, int T, int B, int H, int G) {
     ApScratch a;
@@ -128,5 +128,6 @@ static inline ApScratch ap_split(void* scratch, int T, int B, int H, int G) {
     a.ex_min = a.ex + (size_t)T * (B / 32) * (H / 32);
     return a;
 }
-// W_hh [G H, H] -> f16-pair image of W_hh^T (csrc/gru.hip), resetting ex_min for a new sequence
+// W_hh [G H, H] -> f16-pair image of W_hh^T times 2^e_w (csrc/gru.hip), resetting ex_min for a new sequence; wx = ex_min + H/32 receives
+// the matrix' partial maxima first (one more launch) and is what the consuming step kernels take e_w from
 int cpg_pair_w(const float* w_hh, int G, int H, uint16_t* out, int* ex_min, hipStream_t s);

@@ -15,8 +15,10 @@
 namespace {
 
 // ---- x [R, C1 (+ C2)] f32 -> unscaled image [R][2 (C1 + C2)] (|x| <= 65504; states: |x| <= 1).  One thread = 4 columns of one row.
+// wx (weights only): the matrix' exponent record - the image holds x 2^e_w (gemm_core.h: weight_exp_from_parts); null: unscaled (states).
 __global__ void pair_rows_kernel(const float* __restrict__ x1, int ld1, int C1, const float* __restrict__ x2, int ld2, int C2, int R,
-                                 uint16_t* __restrict__ img, float scale) {
+                                 uint16_t* __restrict__ img, const int* __restrict__ wx) {
+    const float scale = wx ? pair_pow2(weight_exp_from_parts(wx)) : 1.f;
     const int C = C1 + C2, q4 = C / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)R * q4) return;
@@ -27,15 +29,15 @@ __global__ void pair_rows_kernel(const float* __restrict__ x1, int ld1, int C1, 
 }
 
 // ---- W [G Hk, Nc] (row-major, ld) -> image of W^T: out[n][2 G Hk], k-segments in the order (32-unit group, block) - the k order of a
-// gradient image (below) - times 2^W_PAIR_EXP.  grid (Nc/32, G Hk/32), block (32, 8): a 32 x 32 tile through LDS.
-__global__ void pair_wT_kernel(const float* __restrict__ w, int ld, int G, int Hk, int Nc, uint16_t* __restrict__ out) {
+// gradient image (below) - times 2^e_w (wx: the matrix' exponent record).  grid (Nc/32, G Hk/32), block (32, 8): a 32 x 32 tile through LDS.
+__global__ void pair_wT_kernel(const float* __restrict__ w, int ld, int G, int Hk, int Nc, uint16_t* __restrict__ out, const int* __restrict__ wx) {
     __shared__ float tile[32][33];
+    const float sc = pair_pow2(weight_exp_from_parts(wx));
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;   // tile[k - r0][n - c0]
     for (int i = threadIdx.y; i < 32; i += 8) tile[i][threadIdx.x] = w[(size_t)(r0 + i) * ld + c0 + threadIdx.x];
     __syncthreads();
     const int tid = threadIdx.y * 32 + threadIdx.x, jj = tid >> 3, q = tid & 7, c8 = (q & 3) * 8;
     const int blk = r0 / Hk, grp = (r0 - blk * Hk) / 32;
-    const float sc = pair_pow2(W_PAIR_EXP);
     uint32_t hi[4], lo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) split2h_pair(tile[c8 + 2 * i][jj] * sc, tile[c8 + 2 * i + 1][jj] * sc, hi[i], lo[i]);
@@ -91,7 +93,7 @@ __global__ void fill_int_kernel(int* p, int n, int v) {
 }
 
 // ---- C[R, N] (+)= A B^T on K-contiguous images.  A: [R][K2] with optional exponents (one per 32-row block and group of G consecutive
-// 32-k segments: a gradient image), B: [N][K2] times 2^b_exp.  128 x 128 tiles, 2 x 2 waves of 64 x 64.
+// 32-k segments: a gradient image), B: [N][K2] times 2^e_w of its exponent record b_wx.  128 x 128 tiles, 2 x 2 waves of 64 x 64.
 struct PairNtArgs {
     const uint16_t* A; size_t lda;
     const int* a_ex; int a_groups;     // null: unscaled A
@@ -99,7 +101,8 @@ struct PairNtArgs {
     int K2;                            // elements of a row of either image (2 x logical K)
     float* C; size_t ldc;
     const float* bias;
-    int accumulate, b_exp;
+    int accumulate;
+    const int* b_wx;
 };
 template <int G>
 __global__ __launch_bounds__(256) void pair_nt_kernel(PairNtArgs g) {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void pair_nt_kernel(PairNtArgs g) {
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float back = pair_pow2(-g.b_exp);
+    const float back = pair_pow2(-weight_exp_from_parts(g.b_wx));
     float f0 = 1.f, f1 = 1.f;   // per 32-row block of the wave's 64 rows: 2^-e_ref takes the block's unit back out
     if (g.a_ex) {
         // A wave's 64 rows are TWO 32-row blocks with their own exponents per group (accumulator rows mi 0,1 / mi 2,3).  Every segment
@@ -185,6 +188,7 @@ struct StepPlanesArgs {
     int rowc_rows;            // rowc holds this many rows, row r reads rowc[r % rowc_rows] (beam-major rows k N + i share sentence i's term)
     const int32_t* origin;    // beam search: [nsent][K] back-pointers - row k nsent + i takes its previous state from row origin[i][k] nsent + i
     int nsent, K;             // (the re-gather of _update_hidden, models/model.py:378-385, folded into the operand loads); null: identity
+    const int* wx;            // exponent record of W_hh (behind its image): the image holds W_hh 2^e_w
 };
 __global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs g) {
     using DL = DlLoop<128, 96, 2, 3>;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs
                 DlNoScale{}, [&](int i, int r) { return g.hp_in + src_row((unsigned)(32 * i + r)) * 2 * H; });
     else
         DL::run(g.hp_in + (size_t)m0 * 2 * H, (size_t)2 * H, g.wimg + (size_t)bx * 96 * 2 * H, (size_t)2 * H, 2 * H, cpg_smem, acc, -1, []() {});
-    const float back = 1.f / (float)(1 << W_PAIR_EXP);
+    const float back = pair_pow2(-weight_exp_from_parts(g.wx));
     const int u = j0 + wn * 16 + l15;
     const float bh_r = g.b_hh[u], bh_z = g.b_hh[H + u], bh_n = g.b_hh[2 * H + u];
 #pragma unroll
@@ -258,15 +262,16 @@ __global__ __launch_bounds__(256) void gru_step_fwd_planes_kernel(StepPlanesArgs
         pair_store4<1>(g.hp_out, (size_t)m0 + wm * 64 + mi * 16 + (lane >> 2), H, j0 + wn * 16 + 4 * (lane & 3), 0, v);
     }
 }
-// W_hh [3H, H] -> image [3H][2H] x 2^W_PAIR_EXP with rows in tile order: image row 96 t + 48 w + 16 gate + i = W_hh row gate H + 32 t + 16 w + i
-__global__ void gru_step_w_image_kernel(const float* __restrict__ w, int H, uint16_t* __restrict__ img) {
+// W_hh [3H, H] -> image [3H][2H] x 2^e_w with rows in tile order: image row 96 t + 48 w + 16 gate + i = W_hh row gate H + 32 t + 16 w + i
+__global__ void gru_step_w_image_kernel(const float* __restrict__ w, int H, uint16_t* __restrict__ img, const int* __restrict__ wx) {
+    const float sc = pair_pow2(weight_exp_from_parts(wx));
     const int q4 = H / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)3 * H * q4) return;
     const int ir = (int)(i / q4), col = (int)(i - (size_t)ir * q4) * 4;
     const int t = ir / 96, rr = ir - 96 * t, wv = rr / 48, gate = (rr - 48 * wv) / 16, ii = rr & 15;
     const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(gate * H + 32 * t + 16 * wv + ii) * H + col);
-    pair_store4<1>(img, (size_t)ir, H, col, 0, v * (float)(1 << W_PAIR_EXP));
+    pair_store4<1>(img, (size_t)ir, H, col, 0, v * sc);
 }
 
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
@@ -280,29 +285,36 @@ CPG_EXPORT int cpg_planes_ok(int R, int K, int N) {
 }
 // image of x = [x1 | x2] (x2 optional): R rows of 2 (C1 + C2) f16
 CPG_EXPORT size_t cpg_pair_rows_bytes(int R, int C) { return (size_t)R * 2 * C * sizeof(uint16_t); }
+// image of a WEIGHT matrix [R, C]: the image + its exponent record (cpg_weight_exp) behind it - the scratch the plane products and
+// the plane decode step ask for
+CPG_EXPORT size_t cpg_weight_image_bytes(int R, int C) { return align256(cpg_pair_rows_bytes(R, C)) + WX_PARTS * sizeof(int); }
+static int* weight_image_wx(void* img, int R, int C) { return (int*)((char*)img + align256(cpg_pair_rows_bytes(R, C))); }
 CPG_EXPORT int cpg_pair_rows(const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int R, void* img, void* stream) {
     CPG_CHECK_ARG(x1 && img && R > 0 && C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0 && (C2 == 0 || x2) && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0));
     CPG_CHECK_ARG(aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(img));
     const size_t n = (size_t)R * ((C1 + C2) / 4);
     hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x1, ld1, C1, x2, ld2, C2, R,
-                       (uint16_t*)img, 1.f);
+                       (uint16_t*)img, (const int*)nullptr);
     CPG_LAUNCH_CHECK();
     return 0;
 }
-// y [R, N] (+)= ximg [R][2K] . W[N, K]^T + bias; scratch: cpg_pair_rows_bytes(N, K) bytes for W's image
+// y [R, N] (+)= ximg [R][2K] . W[N, K]^T + bias; scratch: cpg_weight_image_bytes(N, K) bytes for W's image and exponent record
 CPG_EXPORT int cpg_linear_fwd_planes(const void* ximg, int R, int K, const float* W, int ldw, const float* bias, float* Y, int ldy, int N,
                                      int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
     CPG_CHECK_ARG(ximg && W && Y && scratch && cpg_planes_ok(R, K, N) && ldw % 4 == 0 && aligned16(W) && aligned16(scratch));
-    CPG_CHECK_ARG(scratch_bytes >= cpg_pair_rows_bytes(N, K));
+    CPG_CHECK_ARG(scratch_bytes >= cpg_weight_image_bytes(N, K));
     hipStream_t s = (hipStream_t)stream;
+    int* const wx = weight_image_wx(scratch, N, K);
+    int rc = cpg_weight_absmax(W, N, K, ldw, wx, s);
+    if (rc) return rc;
     const size_t n = (size_t)N * (K / 4);
     hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, W, ldw, K, (const float*)nullptr, 0, 0, N,
-                       (uint16_t*)scratch, (float)(1 << W_PAIR_EXP));
+                       (uint16_t*)scratch, (const int*)wx);
     CPG_LAUNCH_CHECK();
     PairNtArgs g{(const uint16_t*)ximg, (size_t)2 * K, nullptr, 0, (const uint16_t*)scratch, (size_t)2 * K, 2 * K, Y, (size_t)ldy, bias, accumulate,
-                 W_PAIR_EXP};
+                 wx};
     const size_t smem = DlLoop<128, 128, 2, 3>::smem_floats() * sizeof(float);
-    int rc = cpg_allow_big_lds((const void*)pair_nt_kernel<3>, (int)smem);
+    rc = cpg_allow_big_lds((const void*)pair_nt_kernel<3>, (int)smem);
     if (rc) return rc;
     hipLaunchKernelGGL(pair_nt_kernel<3>, dim3(N / 128, R / 128), dim3(256), smem, s, g);
     CPG_LAUNCH_CHECK();
@@ -333,20 +345,23 @@ CPG_EXPORT int cpg_grad_planes(const float* dG, int ldg, int R, int H, int G, co
     CPG_LAUNCH_CHECK();
     return 0;
 }
-// dx [R, In] (+)= dGin . W   (W [G H, In] row-major); scratch: cpg_pair_rows_bytes(In, G H) bytes for the image of W^T
+// dx [R, In] (+)= dGin . W   (W [G H, In] row-major); scratch: cpg_weight_image_bytes(In, G H) bytes for the image of W^T and W's exponent record
 CPG_EXPORT int cpg_linear_bwd_input_planes(const void* gp, int R, int H, int G, const float* W, int ldw, float* dX, int lddx, int In,
                                            int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
     CPG_CHECK_ARG(gp && W && dX && scratch && (G == 3 || G == 4) && cpg_planes_ok(R, G * H, In) && H % 32 == 0 && H / 32 <= 64 && aligned16(scratch));
-    CPG_CHECK_ARG(scratch_bytes >= cpg_pair_rows_bytes(In, G * H));
+    CPG_CHECK_ARG(scratch_bytes >= cpg_weight_image_bytes(In, G * H));
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(pair_wT_kernel, dim3(In / 32, G * H / 32), dim3(32, 8), 0, s, W, ldw, G, H, In, (uint16_t*)scratch);
+    int* const wx = weight_image_wx(scratch, In, G * H);
+    int rc = cpg_weight_absmax(W, G * H, In, ldw, wx, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pair_wT_kernel, dim3(In / 32, G * H / 32), dim3(32, 8), 0, s, W, ldw, G, H, In, (uint16_t*)scratch, (const int*)wx);
     CPG_LAUNCH_CHECK();
     uint16_t* img; int* ex; int* emin;
     grad_planes_split(const_cast<void*>(gp), R, H, G, img, ex, emin);
-    PairNtArgs g{img, (size_t)2 * G * H, ex, H / 32, (const uint16_t*)scratch, (size_t)2 * G * H, 2 * G * H, dX, (size_t)lddx, nullptr, accumulate, W_PAIR_EXP};
+    PairNtArgs g{img, (size_t)2 * G * H, ex, H / 32, (const uint16_t*)scratch, (size_t)2 * G * H, 2 * G * H, dX, (size_t)lddx, nullptr, accumulate, wx};
     const size_t smem = DlLoop<128, 128, 2, 3>::smem_floats() * sizeof(float);
     const void* k = G == 3 ? (const void*)pair_nt_kernel<3> : (const void*)pair_nt_kernel<4>;
-    int rc = cpg_allow_big_lds(k, (int)smem);
+    rc = cpg_allow_big_lds(k, (int)smem);
     if (rc) return rc;
     if (G == 3) hipLaunchKernelGGL(pair_nt_kernel<3>, dim3(In / 128, R / 128), dim3(256), smem, s, g);
     else hipLaunchKernelGGL(pair_nt_kernel<4>, dim3(In / 128, R / 128), dim3(256), smem, s, g);
@@ -365,15 +380,19 @@ CPG_EXPORT int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G,
 }
 
 // ---- GRU decode step on plane images (see gru_step_fwd_planes_kernel).  cpg_gru_step_planes_ok: 1 where the form covers N rows at width H
-// (f32-grade mode, N % 128 == 0, H % 128 == 0, enough rows to amortise the images).  The W_hh image (cpg_pair_rows_bytes(3H, H) bytes) is
+// (f32-grade mode, N % 128 == 0, H % 128 == 0, enough rows to amortise the images).  The W_hh image (cpg_weight_image_bytes(3H, H) bytes: image + exponent record) is
 // built once per decode by cpg_gru_step_w_image; the state travels as (h f32 [N,H], image [N][2H]) - cpg_pair_rows makes the first image.
 CPG_EXPORT int cpg_gru_step_planes_ok(int N, int H) {
     return (cpg_compute_mode_get() != 1 && N >= 1024 && N % 128 == 0 && H >= 128 && H % 128 == 0) ? 1 : 0;
 }
 CPG_EXPORT int cpg_gru_step_w_image(const float* w_hh, int H, void* wimg, void* stream) {
     CPG_CHECK_ARG(w_hh && wimg && H > 0 && H % 128 == 0 && aligned16(w_hh) && aligned16(wimg));
+    int* const wx = weight_image_wx(wimg, 3 * H, H);
+    const int rc = cpg_weight_absmax(w_hh, 3 * H, H, H, wx, (hipStream_t)stream);
+    if (rc) return rc;
     const size_t n = (size_t)3 * H * (H / 4);
-    hipLaunchKernelGGL(gru_step_w_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_hh, H, (uint16_t*)wimg);
+    hipLaunchKernelGGL(gru_step_w_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_hh, H, (uint16_t*)wimg,
+                       (const int*)wx);
     CPG_LAUNCH_CHECK();
     return 0;
 }
@@ -384,7 +403,7 @@ CPG_EXPORT int cpg_gru_step_fwd_planes(int N, int H, const void* wimg, const flo
     CPG_CHECK_ARG((!rowc || (rowc_rows >= 128 && N % rowc_rows == 0)) && (!origin || (nsent >= 128 && K > 0 && (long)nsent * K == N)));
     CPG_CHECK_ARG(!origin || !rowc || rowc_rows == nsent || rowc_rows == N);
     StepPlanesArgs g{(const uint16_t*)hp_in, (uint16_t*)hp_out, h_prev, h_out, (const uint16_t*)wimg, b_hh, tok, tab, rowc, N, H,
-                     rowc ? rowc_rows : N, origin, nsent, K};
+                     rowc ? rowc_rows : N, origin, nsent, K, weight_image_wx(const_cast<void*>(wimg), 3 * H, H)};
     const size_t smem = (DlLoop<128, 96, 2, 3>::smem_floats() + 4 * 256) * sizeof(float);
     int rc = cpg_allow_big_lds((const void*)gru_step_fwd_planes_kernel, (int)smem);
     if (rc) return rc;

@@ -195,7 +195,8 @@ class GRUDecoder(nn.Module):
                              ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), ops._p(cs), None, ops._stream())
                 else:
                     ops.call("cpg_gru_seq_fwd", 1, N, H, 0, ops._p(rnn.weight_hh_l0), ops._p(rnn.bias_hh_l0), None, None,
-                             ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), None, 0, N, None, ops._stream())
+                             ops._p(rowc.contiguous()), ops._p(dense.contiguous()), ops._p(hs), None, 0, N, None,
+                             ops._p(ops.weight_exp(rnn.weight_hh_l0)), ops._stream())
             else:
                 tok = sampleHard.to(torch.int32).contiguous()
                 if lstm:

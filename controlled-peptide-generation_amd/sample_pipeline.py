@@ -83,6 +83,18 @@ def _states_path(split, savepath=None, n_iter=None, ext=None):
     return base + '.npz'
 
 
+def _require_h5py(what):
+    """The reference's states files are gzip-9 HDF5 (vis/scripts/build_index.py:32-81).  h5py is an optional dependency here: the npz
+    form with the same fields is what this package writes by default and what its tests exercise; asking for h5 without h5py is an
+    error, never a silent switch of formats."""
+    try:
+        import h5py
+    except ImportError as e:
+        raise RuntimeError("cannot {}: the h5 form of the states dump needs h5py, which is not installed; use the npz form "
+                           "(dump_encodings(fmt='npz'), the default) or install h5py".format(what)) from e
+    return h5py
+
+
 def get_encodings_from_states(query, split, attributes=None, savepath=None, n_iter=None):
     """mu, logvar (float64 tensors) of the dumped encodings whose labels match `query` ({attr: value}); reads the
     reference's `states_<split>_<iter>.h5` (when h5py is importable) or this package's npz with the same fields
@@ -91,7 +103,7 @@ def get_encodings_from_states(query, split, attributes=None, savepath=None, n_it
     fn = _states_path(split, savepath, n_iter)
     assert os.path.exists(fn), 'need dumped states ({}); run dump_encodings first'.format(fn)
     if fn.endswith('.h5'):
-        import h5py
+        h5py = _require_h5py('read ' + fn)
         with h5py.File(fn, 'r') as f:
             mu_a, lv_a, lab_a = f['mu'][:], f['logvar'][:], f['label'][:]
     else:
@@ -109,8 +121,9 @@ def get_encodings_from_states(query, split, attributes=None, savepath=None, n_it
 def dump_encodings(model, ids, labels, split, savepath, n_iter, batch=4096, fmt=None):
     """The encode pass of vis/scripts/build_index.py:93-118 - `model(batch.text, q_c='classifier', sample_z='max')`, i.e.
     encoder + CNN classifier + teacher-forced decoder with z = mu - and its on-disk schema (:32-81): src int [N,T];
-    z, mu, logvar float16 [N,Z]; label int [N,n_attr]; split int [N,1].  Written as gzip-9 h5 when h5py is importable
-    (the reference's format), else as a compressed npz with the same field names."""
+    z, mu, logvar float16 [N,Z]; label int [N,n_attr]; split int [N,1].  Written as a compressed npz with the reference's field names
+    (fmt=None / 'npz': the tested interchange), or as the reference's gzip-9 h5 with fmt='h5' - which REQUIRES h5py and raises
+    without it (the h5 branch has never run on a box of this build: h5py is absent from the image)."""
     was_training = model.training
     model.eval()
     zs, mus, lvs = [], [], []
@@ -128,14 +141,12 @@ def dump_encodings(model, ids, labels, split, savepath, n_iter, batch=4096, fmt=
                   split=np.full((ids.shape[0], 1), SPLIT_CODE.get(split, 0), np.int64))
     os.makedirs(savepath, exist_ok=True)
     if fmt is None:
-        try:
-            import h5py  # noqa: F401
-            fmt = 'h5'
-        except ImportError:
-            fmt = 'npz'
+        fmt = 'npz'      # the TESTED interchange of this package (same field names, dtypes and shapes as the reference's h5)
+    if fmt not in ('npz', 'h5'):
+        raise ValueError("dump_encodings: fmt must be 'npz' or 'h5', not {!r}".format(fmt))
     fn = _states_path(split, savepath, n_iter, '.' + fmt)
     if fmt == 'h5':
-        import h5py
+        h5py = _require_h5py('write ' + fn)
         with h5py.File(fn, 'w') as f:
             for k, v in fields.items():
                 f.create_dataset(k, data=v, maxshape=(None, None), compression='gzip', compression_opts=9)
@@ -350,16 +361,15 @@ def gather_frame(frame):
     return out
 
 
-KEY_WORDS = 4   # int64 words of a row key (dedup_frame); rows of up to 13 * KEY_WORDS residues pack exactly, longer ones 8 letters per word
-
-
-def _keys(letters):
-    """Residue rows (uint8 ids, 0 = past the end) -> [n, W] int64 keys: row equality = key equality.  Ids below 25 pack 13 to a word
-    in base 25 (25^13 < 2^63: the usual 20-residue vocabulary with its 4 specials fits 26 residues into TWO words - two sorts in
-    dedup_frame instead of one per 8 letters); wider vocabularies / longer rows fall back to 8 letters (bytes) per word."""
+def _keys(letters, n_vocab):
+    """Residue rows (uint8 ids, 0 = past the end) -> [n, W] int64 keys: row equality = key equality.  The key form is a function of
+    the RUN - vocabulary size and row width - never of a round's contents, so every round of a run (and every rank) keys alike
+    (round-5 advisor finding: a data-dependent choice let rounds disagree).  n_vocab <= 25 and rows of up to 26 residues pack 13 ids
+    to a word in base 25 (25^13 < 2^63: the usual 20-residue vocabulary with its 4 specials fits a row into TWO words - two sorts in
+    dedup_frame instead of one per 8 letters); wider vocabularies / longer rows take 8 letters (bytes) per word."""
     n, L = letters.shape
     dev = letters.device
-    if L <= 26 and (n == 0 or int(letters.max().item()) < 25):
+    if L <= 26 and int(n_vocab) <= 25:
         pad = torch.zeros(n, 26, dtype=torch.int64, device=dev)
         pad[:, :L] = letters
         w = (25 ** torch.arange(13, device=dev, dtype=torch.int64))
@@ -370,14 +380,14 @@ def _keys(letters):
     return pad.view(torch.int64).reshape(n, W)
 
 
-def dedup_frame(frame, seen):
+def dedup_frame(frame, seen, n_vocab=24):
     """drop_duplicates within the round (first occurrence kept, original order) and against earlier rounds (reference
     :312-314), on the stripped residue rows, on the device the frame lives on.  seen: key tensor of every row kept so far;
     returns (frame, new seen).
     Exact, sort-based: the rows' keys (seen rows first) are ordered by one STABLE sort per key word, last word first - rows with
     equal keys end up adjacent IN THEIR ORIGINAL ORDER, so the first row of every run is the occurrence drop_duplicates keeps; a
     round of 10^6 rows costs two 10^6-element sorts (torch.unique(dim=0) + scatter-min before: 11 ms of a 177 ms round)."""
-    keys = _keys(frame['letters'])
+    keys = _keys(frame['letters'], n_vocab)
     n = keys.shape[0]
     if n == 0:
         return frame, seen
@@ -503,7 +513,7 @@ def run_rounds(model, dataset, Q, n_samples_per_round, n_samples_acc, max_rounds
         frame, st = sample_round_arrays(model, dataset, Q, n_samples_per_round, sample_mode, decode_accepted_only, (rank, world))
         frame = {k: torch.as_tensor(v) for k, v in frame.items()}
         frame = gather_frame(frame)            # identical on every rank from here on
-        frame, seen = dedup_frame(frame, seen)
+        frame, seen = dedup_frame(frame, seen, dataset.n_vocab)
         frames.append(frame)
         for k in ('proposed', 'decoded', 'decoder_evals'):
             stats[k] += st[k] * world if world > 1 else st[k]   # ranks do equal shares (decoded: this rank's count scaled)
@@ -516,6 +526,18 @@ def run_rounds(model, dataset, Q, n_samples_per_round, n_samples_acc, max_rounds
 
 def _write_table(table, stem):
     table.drop(columns='z').to_csv(stem + '.csv', index_label='idx')
+    if not (len(table) == 0 or table['z'].dtype == object):
+        # the pickled table is the reference's interchange file (:149-160): its consumers expect an object column of numpy rows, not the
+        # Arrow list column the in-memory table carries (round-5 advisor finding).  One numpy view per row, at write time only.
+        table = table.copy(deep=False)
+        pa_arr = getattr(table['z'].array, '_pa_array', None)
+        z = (pa_arr.combine_chunks().flatten().to_numpy(zero_copy_only=False) if pa_arr is not None
+             else np.asarray(table['z'].tolist(), dtype=np.float32))
+        z = z.reshape(len(table), -1)
+        col = np.empty(len(table), dtype=object)
+        for i in range(len(table)):
+            col[i] = z[i]
+        table['z'] = col
     table.to_pickle(stem + '.pkl')
 
 

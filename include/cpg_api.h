@@ -57,10 +57,18 @@ CPG_API int cpg_transpose01_u8(const uint8_t* src, int d0, int d1, int inner, ui
 /* Y[M,N] (+)= X[M,K] W[N,K]^T + bias[N] */
 CPG_API int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                            int M, int N, int K, int accumulate, void* stream);
-/* The same for an input whose magnitudes are O(1) - recurrent states (|x| < 65504; absolute precision 2^-25 below 2^-14): large products
- * run on f16 pairs (three f16 MFMAs per block), same results within f32 rounding.  The caller vouches for the input's range. */
+/* Exponent record of a weight matrix W [rows, cols] (row stride ld): cpg_weight_exp_bytes() bytes of device memory holding partial maxima
+ * of |W|, from which every kernel that splits W into f16 pairs derives the SAME power of two 2^e_w (max|W| 2^e_w in [2^13, 2^14)) - any
+ * finite f32 weight has a pair image (rounds 4-5 scaled weights by a fixed 2^8: |w| >= 256 became an f16 infinity).  One launch.  The
+ * entry points that build a weight image themselves (BPTT chains, plane products) do this internally; the ones that split W on the fly
+ * take the record as `wx` and run their bf16x3 / exact-f32 engine without it. */
+CPG_API size_t cpg_weight_exp_bytes(void);
+CPG_API int cpg_weight_exp(const float* w, int rows, int cols, int ld, void* wx, void* stream);
+/* cpg_linear_fwd for an input whose magnitudes are O(1) - recurrent states (|x| < 65504; absolute precision 2^-25 below 2^-14): large
+ * products run on f16 pairs (three f16 MFMAs per block), same results within f32 rounding.  The caller vouches for the INPUT's range;
+ * the weights' range is covered by wx = cpg_weight_exp(W) (null: exact-f32 engine). */
 CPG_API int cpg_linear_fwd_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
-                                 int N, int K, int accumulate, void* stream);
+                                 int N, int K, int accumulate, const void* wx, void* stream);
 /* dX[M,K] (+)= dY[M,N] W[N,K] */
 CPG_API int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,
                                  int K, int accumulate, void* stream);
@@ -121,10 +129,12 @@ CPG_API int cpg_gru_gates_bf16(int B, int H, int ragged /* step_rows given */);
 CPG_API int cpg_gru_dg_bf16(int B, int H, int ragged, int V);
 CPG_API int cpg_gru_seq_fwd(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh, const int32_t* tok,
                             const float* tab, const float* rowc, const float* dense, float* hs, float* gates,
-                            int row_begin, int row_end, const int32_t* step_rows, void* stream);
-/* one decode step = GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) */
+                            int row_begin, int row_end, const int32_t* step_rows,
+                            const void* wx /* cpg_weight_exp record of w_hh [3H,H] (f32-grade mode: the step kernel's f16-pair engine takes the
+                            weights' power of two from it), or null: the bf16x3 engine, which needs no range guard */, void* stream);
+/* one decode step = GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99); wx as above */
 CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh, const int32_t* tok, const float* tab,
-                             const float* rowc, const float* h_prev, float* h_out, void* stream);
+                             const float* rowc, const float* h_prev, float* h_out, const void* wx, void* stream);
 /* BPTT.  dhs_ext [T,B,H]: gradient arriving at each step's output (time-aligned; may be null);
  * dh_last [B,H]: gradient on the final state (may be null); dG out [T,B,4H] = (dr_pre, dz_pre, d(W_hn h+b_hn), dn_pre):
  * columns 0..3H are the hidden-side gate gradients, columns {0..2H, 3H..4H} the input-side ones;
@@ -134,7 +144,8 @@ CPG_API int cpg_gru_step_fwd(int B, int H, const float* w_hh, const float* b_hh,
  * pair_scratch (optional; with w_hhT_scratch): cpg_gru_bwd_pair_bytes(row_end - row_begin, H, 1) bytes for the f16-pair form of
  * that step (f32-grade mode, 64-row tiles): every launch then also writes the three recurrent blocks of its dG as f16 pairs
  * times a power of two per 32 x 32 group - the next launch's operand, three f16 MFMAs per block in place of eight f32 ones -
- * and w_hhT_scratch receives W_hh^T in the same form.  null (or a query answer of 0): the exact-f32 product. */
+ * and w_hhT_scratch receives W_hh^T in the same form, times a power of two chosen from its largest magnitude (one more small launch per
+ * sequence; any finite weight is covered).  null (or a query answer of 0): the exact-f32 product. */
 CPG_API size_t cpg_gru_bwd_pair_bytes(int rows, int H, int ndir /* 1 | 2: directions per launch */);
 CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh, const float* hs, const float* gates,
                             const float* dhs_ext, const float* dh_last, float* dG, float* dH_scratch, float* dh0,
@@ -147,7 +158,8 @@ CPG_API int cpg_gru_seq_bwd(int T, int B, int H, int reverse, const float* w_hh,
 CPG_API int cpg_gru_biseq_fwd(int T, int B, int H, const float* w_hh_f, const float* b_hh_f, const float* w_hh_r,
                               const float* b_hh_r, const int32_t* tok, const float* tab_f, const float* tab_r,
                               const float* dense_f, const float* dense_r, float* hs_f, float* hs_r, float* gates_f,
-                              float* gates_r, void* stream);
+                              float* gates_r, const void* wx_f, const void* wx_r /* as cpg_gru_seq_fwd's wx; both or the bf16x3 engine */,
+                              void* stream);
 CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const float* w_hh_r, const float* hs_f,
                               const float* hs_r, const float* gates_f, const float* gates_r, const float* dhs_ext_f,
                               const float* dhs_ext_r, const float* dh_last_f /* [B,H] gradient on the final state of the
@@ -245,14 +257,15 @@ CPG_API int cpg_gru_dgi_reduce_ap(int T, int B, int H, const void* ap, const flo
  * products run conversion-free: LDS-DMA operands, three f16 MFMAs per block, f32 accumulation - f32-grade like the f16-pair recurrence.
  *   cpg_planes_ok(R, K, N)     1 where the forms cover a product of R rows, contraction K, N outputs (f32-grade mode, multiples of 128)
  *   cpg_pair_rows              x = [x1 | x2] (x2 optional) f32 -> image [R][2 (C1 + C2)], unscaled (|x| <= 65504; states: |x| <= 1)
- *   cpg_linear_fwd_planes      Y [R, N] (+)= x W^T + bias from x's image; scratch = cpg_pair_rows_bytes(N, K) bytes (W's image, x 2^8)
+ *   cpg_linear_fwd_planes      Y [R, N] (+)= x W^T + bias from x's image; scratch = cpg_weight_image_bytes(N, K) bytes (W's image x 2^e_w + its exponent record)
  *   cpg_grad_planes            gate gradients dG [R, ldg] (G = 3 | 4 blocks of H columns at column offsets off[]) -> `gp`
  *                              (cpg_grad_planes_bytes): image [R][2 G H] in the order (32-unit group, block) times ONE power of two per
  *                              (32 rows x group), the exponent table, the smallest exponent per group
- *   cpg_linear_bwd_input_planes   dX [R, In] (+)= dGin W   (W [G H, In]); scratch = cpg_pair_rows_bytes(In, G H) bytes (image of W^T)
+ *   cpg_linear_bwd_input_planes   dX [R, In] (+)= dGin W   (W [G H, In]); scratch = cpg_weight_image_bytes(In, G H) bytes (image of W^T + exponent record)
  *   cpg_linear_bwd_weight_planes  dW [G H, In] (+)= dGin^T x from gp and x's image (csrc/pair_tn.h); workspace per the _workspace query */
 CPG_API int cpg_planes_ok(int R, int K, int N);
 CPG_API size_t cpg_pair_rows_bytes(int R, int C);
+CPG_API size_t cpg_weight_image_bytes(int R, int C);   /* image of a weight matrix [R, C] + the exponent record (cpg_weight_exp) behind it */
 CPG_API int cpg_pair_rows(const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int R, void* img, void* stream);
 CPG_API int cpg_linear_fwd_planes(const void* ximg, int R, int K, const float* W, int ldw, const float* bias, float* Y, int ldy, int N,
                                   int accumulate, void* scratch, size_t scratch_bytes, void* stream);
@@ -266,7 +279,7 @@ CPG_API int cpg_linear_bwd_weight_planes(const void* gp, int R, int H, int G, co
 /* One GRU decode step on plane images: GRUDecoder.forward_sample's recurrent part (models/decoder.py:86-99) for decode chains over MANY
  * rows of decoders too wide for the whole-loop kernels (CLaSS at config-B / C width: models/model.py:295-363 over 10^5..10^6 rows).
  * The state travels as (h f32 [N,H], its f16-pair image [N][2H]: cpg_pair_rows makes the first one, every step writes the next);
- * W_hh's image (cpg_pair_rows_bytes(3H, H) bytes, rows in tile order) is built once per decode.  Same cell arithmetic and the same
+ * W_hh's image (cpg_weight_image_bytes(3H, H) bytes: rows in tile order, times 2^e_w, + its exponent record) is built once per decode.  Same cell arithmetic and the same
  * 22-bit operands as cpg_gru_step_fwd, no conversion in the product loop.  cpg_gru_step_planes_ok: f32-grade mode, N % 128 == 0,
  * N >= 1024, H % 128 == 0.  cpg_beam_select with H = 0 advances the beams WITHOUT moving any state (h_in / h_out ignored): the next
  * plane step gathers through `origin`. */

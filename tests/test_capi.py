@@ -19,7 +19,7 @@ def test_header_parses():
     sigs = parse_header(HEADER)
     assert len(sigs) >= 40
     ret, args = sigs["cpg_gru_seq_fwd"]
-    assert ret is ctypes.c_int and len(args) == 16
+    assert ret is ctypes.c_int and len(args) == 17
     assert sigs["cpg_last_error"][0] is ctypes.c_char_p
     assert sigs["cpg_mmd_full_workspace"][0] is ctypes.c_size_t
 

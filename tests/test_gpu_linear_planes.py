@@ -43,7 +43,7 @@ def test_plane_products_vs_f64(R, H, G, K1, K2, wild):
     # ---- forward
     ximg = ops.pair_rows(x1, x2)
     y = torch.full((R, N), float("nan"), device=dev)
-    sc_ = torch.empty(int(query("cpg_pair_rows_bytes", N, K)), device=dev, dtype=torch.uint8)
+    sc_ = torch.empty(int(query("cpg_weight_image_bytes", N, K)), device=dev, dtype=torch.uint8)
     call("cpg_linear_fwd_planes", _p(ximg), R, K, _p(w), K, _p(b), _p(y), N, N, 0, _p(sc_), sc_.numel(), _stream())
     want = X @ w.double().T + b.double()
     bound = (X.abs() @ w.double().abs().T).amax()
@@ -57,7 +57,7 @@ def test_plane_products_vs_f64(R, H, G, K1, K2, wild):
     gp.fill_(0xFF)
     call("cpg_grad_planes", _p(dy), N, R, H, G, off, _p(gp), _stream())
     dx = torch.full((R, K), float("nan"), device=dev)
-    sc2 = torch.empty(int(query("cpg_pair_rows_bytes", K, N)), device=dev, dtype=torch.uint8)
+    sc2 = torch.empty(int(query("cpg_weight_image_bytes", K, N)), device=dev, dtype=torch.uint8)
     call("cpg_linear_bwd_input_planes", _p(gp), R, H, G, _p(w), K, _p(dx), K, K, 0, _p(sc2), sc2.numel(), _stream())
     want_dx = dy.double() @ w.double()
     # per 32-row block: relative to what the block's largest |dy| row could contribute (f32 accumulate + 22-bit operands)

@@ -155,6 +155,7 @@ def test_split_and_row_range_forms_match_fused():
 
 
 def _split_and_row_range_body():
+    from cpg import ops
     from cpg.ops import _p, _stream, call
     g = torch.Generator().manual_seed(0)
     B, H, T, V = 200, 96, 6, 24
@@ -166,16 +167,17 @@ def _split_and_row_range_body():
     tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
     h0 = torch.randn(B, H, generator=g).to(dev)
     outs = []
+    wx = ops.weight_exp(w_hh)   # the f16-pair engine of the step kernel takes W_hh's power of two from it
     for mode in ("fused", "rows", "exact"):
         hs = torch.zeros(T + 1, B, H, device=dev)
         hs[0] = h0
         gates = torch.zeros(T, 4, B, H, device=dev)
         gh = torch.empty(B, 3 * H, device=dev)
         if mode == "fused":
-            call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, None, _stream())
+            call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, None, _p(wx), _stream())
         elif mode == "rows":
             for r0, r1 in ((0, 64), (64, 128), (128, B)):
-                call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1, None, _stream())
+                call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), r0, r1, None, _p(wx), _stream())
         else:
             # the same recurrence with its product taken from the exact-f32 MFMA kernel (cpg_linear_fwd) and the cell in torch
             for t in range(T):

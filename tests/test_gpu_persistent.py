@@ -50,7 +50,7 @@ def _run(d, B, H, T, reverse, persistent):
         ops.check_persistent()
     else:
         call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(d["w_hh"]), _p(d["b_hh"]), _p(d["tok"]), _p(d["tab"]), _p(d["rowc"]),
-             _p(d["dense"]), _p(hs), _p(gates), 0, B, None, _stream())
+             _p(d["dense"]), _p(hs), _p(gates), 0, B, None, _p(ops.weight_exp(d["w_hh"])), _stream())
     torch.cuda.synchronize()
     return hs, gates
 

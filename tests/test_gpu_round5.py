@@ -437,7 +437,8 @@ def test_class_round_of_one_million_rows(golden, mode):
 
 
 # ------------------------------------------------------------------------------------------------ vocabulary projection, backward
-@pytest.mark.parametrize("R,H,V,masked", [(51200, 512, 24, True), (8192, 1024, 24, False), (4099, 256, 20, True), (6000, 2048, 32, True)])
+@pytest.mark.parametrize("R,H,V,masked", [(51200, 512, 24, True), (8192, 1024, 24, False), (4099, 256, 20, True), (6000, 2048, 32, True),
+                                          (5000, 768, 24, True)])   # H / 256 = 3: not a streaming shape (round-5 advisor finding)
 def test_vocab_fc_backward_streaming_form_vs_f64(R, H, V, masked):
     """nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab) backward (models/decoder.py:43-45,83) in its small-vocabulary streaming form
     (csrc/decode.hip: vocab_bwd_*_kernel) against f64 products of the same f32 inputs, with and without the keep-mask, writing and
@@ -511,7 +512,7 @@ def test_small_recurrence_whole_sequence_launch_vs_per_step(B, H, T, reverse, wi
             hs[T if reverse else 0] = h0
             gates = torch.full((T, 4, B, H), float("nan"), device=dev)
             call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, None,
-                 _stream())
+                 _p(ops.weight_exp(w_hh)), _stream())
             dG = torch.full((T, B, 4 * H), float("nan"), device=dev)
             scr = torch.empty(2, B, H, device=dev)
             dh0 = torch.full((B, H), float("nan"), device=dev)

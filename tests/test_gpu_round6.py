@@ -1,0 +1,189 @@
+"""Round-6 parity additions.
+
+  * the f16-pair engines' weight range: rounds 4-5 multiplied weights by a fixed 2^8 before the f16 split, so
+    a weight of magnitude >= 256 became an infinity.  Every engine now takes the power of two from the weight matrix' own largest
+    magnitude (csrc/gemm_core.h: weight_exp_from_parts) - tested here with weights of 300 / -400 / 5000 planted into every recurrent
+    matrix, at the benchmarked size (B = 2048, h = 512: persistent forward, f16-pair BPTT chain, all-T planes, plane decode step,
+    per-step decode kernel) and at the reference's own size (whole-sequence training kernels, fused greedy / beam decode), against
+    the float64 oracle - results must stay FINITE and inside the usual bars;
+  * the two benchmarked shapes that were parity-tested below their benchmarked size: configs[4] as named
+    (2-layer biLSTM encoder + 2-layer LSTM decoder) at bench.py's batch of 1024, and the plane-step CLaSS chain at 131 072 rows.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import cu, set_losses_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X: no CUDA/HIP device visible")
+
+
+# ------------------------------------------------------------------------------------------------ weight range of the f16-pair engines
+def _plant(m, P, values):
+    """Overwrite a few entries of every recurrent weight matrix (W_hh of each GRU, the vocabulary projection) with `values`, in the
+    model and in the oracle's dict - entries spread over different rows / columns so that different workgroup slices see them."""
+    with torch.no_grad():
+        for k, prm in m.named_parameters():
+            if ".rnn.weight_hh" in k or k == "decoder.fc.1.weight":
+                R, C = prm.shape
+                for j, v in enumerate(values):
+                    r, c = (7 + 37 * j) % R, (3 + 11 * j) % C
+                    prm[r, c] = float(v)
+                    P[k][r, c] = np.float32(v)
+
+
+@pytest.mark.parametrize("values", [(300.0, -400.0), (5000.0,)], ids=["300", "5000"])
+def test_large_recurrent_weights_at_config_b_vs_f64_oracle(values):
+    """configs[1] dimensions (B = 2048, h = 512, T = 25) with weights far beyond the old fixed scale's range in every W_hh and in the
+    vocabulary projection: loss terms / mu / logits / every gradient against the float64 oracle (bars of _check_step_vs_oracle, with
+    the f32 restatement's own departure as slack where the planted weights make the recurrence ill-conditioned), greedy ids of 1024 z
+    through the plane decode step and of 256 z through the per-step kernel bit-exact.  /root/reference/models/decoder.py:40-41,77."""
+    import test_gpu_tiles as tt
+    m, P, ids, rnd = tt._random_case(2048, 25, 24, 510, 512, 1, seed=int(70 + abs(values[0])) % 1000)
+    _plant(m, P, values)
+    tt._check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", f64=True, tag=f"config B, planted weights {values}")
+    for prm in m.parameters():
+        if prm.grad is not None:
+            assert bool(torch.isfinite(prm.grad).all())
+    tt._check_greedy_vs_oracle(m, P, 1024, 25, seed=81, f64=True, tag=f"config B planes step, planted weights {values}")
+    tt._check_greedy_vs_oracle(m, P, 256, 25, seed=82, f64=True, tag=f"config B per-step kernel, planted weights {values}")
+
+
+def test_large_recurrent_weights_at_reference_dims_vs_f64_oracle():
+    """The reference's default sizes (encoder h = 80, decoder h = 102): the whole-sequence training kernels and the fused greedy /
+    beam decode kernels hold W_hh (and the vocabulary projection) as f16-pair fragments in registers / LDS; with planted weights of
+    300 / -400 the step matches the float64 oracle, greedy ids are bit-exact and beam hypotheses exact."""
+    import test_gpu_tiles as tt
+    from oracle import decode as odec
+    m, P, ids, rnd = tt._random_case(64, 25, 24, 100, 80, 1, seed=91)
+    _plant(m, P, (300.0, -400.0))
+    tt._check_step_vs_oracle(m, P, ids, rnd, regu="mmdrf", f64=True, tag="config A, planted weights")
+    tt._check_greedy_vs_oracle(m, P, 256, 25, seed=92, f64=True, tag="config A fused greedy, planted weights")
+    rs = np.random.RandomState(93)
+    N = 48
+    z = rs.randn(N, 100).astype(np.float32)
+    c = np.zeros((N, 2), np.float32)
+    c[np.arange(N), rs.randint(0, 2, N)] = 1
+    m.eval()
+    got, _, _ = m.generate_sentences(N, cu(z), cu(c), sample_mode='beam', beam_size=5, n_best=3)
+    hyps, _, margins = odec.beam(P, z, c, 25, beam_size=5, n_best=3, return_margins=True)
+    bad = [i for i in range(N) if [list(map(int, h)) for h in got[i]] != hyps[i]]
+    assert all(margins[i] < 2e-5 for i in bad) and len(bad) <= 1, (bad, [margins[i] for i in bad])
+
+
+def test_weight_exponent_record():
+    """cpg_weight_exp: the record's maximum is the matrix' largest magnitude (any layout the callers use: contiguous, column blocks of a
+    wider matrix, widths that are no multiple of four), zeros give exponent 0."""
+    from cpg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    for shape, cols in (((1536, 512), None), ((306, 252), (150, 252)), ((24, 102), None), ((7, 5), None)):
+        w = torch.randn(*shape, generator=g).to(dev)
+        w[shape[0] // 2, shape[1] - 1] = -37.5
+        v = w if cols is None else w[:, cols[0]:cols[1]]
+        rec = ops.weight_exp(v).view(torch.float32)
+        assert rec.numel() == 32 and float(rec.max()) == float(v.abs().max())
+    assert float(ops.weight_exp(torch.zeros(64, 64, device=dev)).view(torch.float32).max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ benchmarked shapes at their benchmarked size
+def test_configs4_lstm_two_layer_decoder_at_bench_batch_vs_torch_ref():
+    """`extra.config_c_lstm` of the bench line - BASELINE.json configs[4] as named: 2-layer bidirectional LSTM encoder + 2-layer LSTM
+    decoder, h = 1024, T = 50 - at the batch bench.py times it on (B = 1024: above 512 rows the persistent forward runs as row-range
+    launches) against torch.nn.LSTM(num_layers=2) + autograd with every draw injected.  Extension: parity unpinned against the reference
+    (it has no LSTM and a one-layer decoder)."""
+    import test_gpu_round5 as t5
+    set_losses_cfg()
+    m, P, ids, rnd = t5._case(1024, 50, 24, 1022, 1024, 2, 2, "lstm", seed=1961)
+    beta, lam_l1, lam_kl = 1.5, 0.0, 1e-3
+    terms, aux, G = t5._ref_step(P, ids, rnd, "lstm", beta, lam_l1, lam_kl)
+    m, out, mu, logits = t5._hip_step(m, ids, rnd, beta, lam_l1, lam_kl)
+    for name in ("recon", "kl", "mmdrf", "l1", "klmu", "total"):
+        want = float(terms[name].detach())
+        assert abs(out[name].item() - want) < 1e-4 * max(1.0, abs(want)), (name, out[name].item(), want)
+    np.testing.assert_allclose(mu.detach().cpu().numpy(), aux["mu"].detach().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), aux["logits"].detach().numpy(), atol=1e-4, rtol=0)
+    for k, prm in m.named_parameters():
+        if k.startswith("classifier") or k == "decoder.emb.weight":
+            continue
+        want, got = G[k], prm.grad.cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=2e-6 + 1e-4 * np.abs(want).max(), rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["greedy", "beam"])
+def test_class_round_at_config_b_width_131072_rows(mode):
+    """`class.config_b_width` of the bench line at its own size: ONE round of 131 072 proposals at z = 510 / decoder h = 512 through
+    sample_pipeline.sample_round_arrays - the per-step decode chain on plane images (cpg_gru_step_fwd_planes; beam: re-gather folded
+    into the operand loads).  (i) 1/64 shards of the round - drawn, scored and DECODED ALONE (2 048 rows: still the plane step) - equal
+    those rows of the big round at its start, middle and very end; (ii) decoded residues of rows spread over the round equal
+    oracle.decode's greedy / beam-5 of the same z.  /root/reference/sample_pipeline.py:129-139, models/model.py:225-385."""
+    import sample_pipeline as sp
+    import test_gpu_round5 as t5
+    from bench import model_kwargs
+    from cpg import decode as cdecode
+    from cpg.synth import SyntheticPeptideLoader
+    from density_modeling import mogQ
+    from models.model import RNN_VAE
+    from models.mutils import EOS_IDX
+    from oracle import decode as odec
+    dev = torch.device("cuda")
+    Z, T = 510, 25
+    torch.manual_seed(77)
+    m = RNN_VAE(n_vocab=24, max_seq_len=T, **model_kwargs(Z, 32)).to(dev)
+    m.device = dev
+    with torch.no_grad():
+        m.decoder.fc[1].bias[EOS_IDX] += 0.5       # hypotheses of several lengths
+    m.eval()
+    P = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("classifier")}
+    rs = np.random.RandomState(4)
+    Q = mogQ.from_params(np.ones(4) / 4, 0.3 * rs.randn(4, Z), np.full((4, Z), 0.9))
+    Q.init_attr_classifiers({'amp': t5._clf(0.1 * rs.randn(1, Z), np.zeros(1)), 'tox': t5._clf(0.1 * rs.randn(1, Z), np.zeros(1))},
+                            clf_targets={'amp': 1, 'tox': 0})
+    Q.rng = 'device'
+    ds = SyntheticPeptideLoader(4, T, 'cuda', size=16)
+    n, W = 1 << 17, 64
+    K = 5 if mode == "beam" else 1
+    assert cdecode.PlaneStep(m.decoder, K * n, Z + 2, False, nsent=n).ok and cdecode.PlaneStep(m.decoder, K * (n // W), Z + 2, False, nsent=n // W).ok
+    Q._philox = [2026, 0]
+    frame, st = sp.sample_round_arrays(m, ds, Q, n, sample_mode=mode)
+    assert st['proposed'] == n and st['decoded'] == n
+    for r in (0, 31, 63):
+        Q._philox = [2026, 0]
+        f, _ = sp.sample_round_arrays(m, ds, Q, n, sample_mode=mode, shard=(r, W))
+        lo, hi = r * n // W, (r + 1) * n // W
+        for k in frame:
+            a, b = f[k], frame[k][lo:hi]
+            if k == 'letters':
+                w = min(a.shape[1], b.shape[1])
+                assert bool((a[:, w:] == 0).all()) and bool((b[:, w:] == 0).all())
+                a, b = a[:, :w], b[:, :w]
+            assert torch.equal(a, b), (k, r)
+    per = 24 if mode == "beam" else 48
+    rows = np.concatenate([np.arange(per), n // 2 + np.arange(per), n - per + np.arange(per)])
+    sel = torch.from_numpy(rows).cuda()
+    zz = frame['z'][sel].cpu().numpy()
+    cbit = frame['c'][sel].cpu().numpy()
+    c = np.zeros((len(rows), 2), np.float32)
+    c[np.arange(len(rows)), cbit] = 1
+    if mode == "greedy":
+        ids = odec.greedy(P, zz, c, T)
+    else:
+        hyps, _ = odec.beam(P, zz, c, T, beam_size=5, n_best=3)
+        L = max(len(h[0]) for h in hyps)
+        ids = np.full((len(rows), L), -1, np.int64)
+        for i, h in enumerate(hyps):
+            ids[i, :len(h[0])] = h[0]
+    ref_letters, ref_n = sp.residue_rows(torch.from_numpy(ids), ds.n_vocab)
+    got_letters, got_n = frame['letters'][sel].cpu().numpy(), frame['n_res'][sel].cpu().numpy()
+    assert np.array_equal(ref_n.numpy(), got_n)
+    w = min(ref_letters.shape[1], got_letters.shape[1])
+    assert np.array_equal(ref_letters.numpy()[:, :w], got_letters[:, :w])
+    assert len(set(got_n.tolist())) >= 3

@@ -434,8 +434,9 @@ def test_linear_fwd_on_f16_pairs_for_state_inputs():
     outs = {}
     for name in ("cpg_linear_fwd_pairs", "cpg_linear_fwd"):
         y = torch.zeros(M, N, device=dev)
-        call(name, _p(x), K, _p(w), K, _p(b), _p(y), N, M, N, K, 0, _stream())
-        call(name, _p(x), K, _p(w), K, None, _p(y), N, M, N, K, 1, _stream())     # accumulate: y = 2 x W^T + b
+        extra = (_p(ops.weight_exp(w)),) if name == "cpg_linear_fwd_pairs" else ()
+        call(name, _p(x), K, _p(w), K, _p(b), _p(y), N, M, N, K, 0, *extra, _stream())
+        call(name, _p(x), K, _p(w), K, None, _p(y), N, M, N, K, 1, *extra, _stream())     # accumulate: y = 2 x W^T + b
         torch.cuda.synchronize()
         outs[name] = ((y.double() - (2 * ref - b.double())).abs().max().item(), y)
     scale = ref.abs().max().item()
@@ -443,6 +444,6 @@ def test_linear_fwd_on_f16_pairs_for_state_inputs():
     assert outs["cpg_linear_fwd_pairs"][0] < 1.5 * outs["cpg_linear_fwd"][0] + 1e-7
     xs, ws = x[:256].contiguous(), w[:96].contiguous()
     ya, yb = torch.zeros(256, 96, device=dev), torch.zeros(256, 96, device=dev)
-    call("cpg_linear_fwd_pairs", _p(xs), K, _p(ws), K, None, _p(ya), 96, 256, 96, K, 0, _stream())
+    call("cpg_linear_fwd_pairs", _p(xs), K, _p(ws), K, None, _p(ya), 96, 256, 96, K, 0, _p(ops.weight_exp(ws)), _stream())
     call("cpg_linear_fwd", _p(xs), K, _p(ws), K, None, _p(yb), 96, 256, 96, K, 0, _stream())
     assert torch.equal(ya, yb)

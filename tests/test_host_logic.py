@@ -211,6 +211,59 @@ def test_save_samples_writes_the_reference_file_set(tmp_path):
     assert open(stem + '.plain.txt').read().split('\n')[1].strip() == 'D E F'
 
 
+def test_pickled_table_keeps_an_object_z_column(tmp_path):
+    """The in-memory sample table carries z as one Arrow fixed-size-list column; the PICKLED table - the reference's interchange file
+    (sample_pipeline.py:149-160) - must hold an object column of numpy rows, which is what its consumers index (round-5 advisor)."""
+    import pandas as pd
+    import sample_pipeline as sp
+    z = np.random.RandomState(0).randn(5, 7).astype(np.float32)
+    df = pd.DataFrame({'peptide': list('ABCDE'), 'z': sp._z_column(z), 'accept_z': [True, False, True, True, False],
+                       'accept': [True, False, True, True, False]})
+    stem = sp.save_samples(df, str(tmp_path), 'smp')
+    back = pd.read_pickle(stem + '.pkl')
+    assert back['z'].dtype == object and isinstance(back['z'].iloc[0], np.ndarray)
+    assert np.array_equal(np.stack(list(back['z'])), z)
+    acc = pd.read_pickle(stem + '.accepted.3.pkl')
+    assert acc['z'].dtype == object and np.array_equal(np.stack(list(acc['z'])), z[[0, 2, 3]])
+
+
+def test_dedup_key_form_is_static_per_run():
+    """sample_pipeline._keys: the key encoding follows the vocabulary size and the row width, never a round's contents - two rounds of
+    one run whose largest residue id differs must produce comparable keys (round-5 advisor finding), and duplicates across such
+    rounds must be found."""
+    import sample_pipeline as sp
+    a = torch.tensor([[4, 5, 6, 0, 0, 0, 0, 0, 0, 0], [7, 8, 0, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.uint8)       # ids < 25 only
+    b = torch.tensor([[4, 5, 6, 0, 0, 0, 0, 0, 0, 0], [30, 8, 0, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.uint8)      # a round with id 30
+    for nv in (24, 40):
+        ka, kb = sp._keys(a, nv), sp._keys(b, nv)
+        assert ka.shape == kb.shape and torch.equal(ka[0], kb[0]) and not torch.equal(ka[1], kb[1])
+    assert sp._keys(a, 24).shape[1] == 2 and sp._keys(a, 40).shape[1] == 2      # L = 10: both forms are two words wide - and differ
+    assert not torch.equal(sp._keys(a, 24), sp._keys(a, 40))
+    f1 = {'letters': a, 'accept_z': torch.tensor([True, True])}
+    f1, seen = sp.dedup_frame(f1, None, 40)
+    f2, seen = sp.dedup_frame({'letters': b, 'accept_z': torch.tensor([True, False])}, seen, 40)
+    assert f2['letters'].shape[0] == 1 and int(f2['letters'][0, 0]) == 30 and seen.shape[0] == 3
+
+
+def test_h5_states_dump_fails_loudly_without_h5py(tmp_path, monkeypatch):
+    """dump_encodings(fmt='h5') / reading a states_*.h5 need h5py; without it they raise - never a silent switch to npz.  (npz is the
+    interchange this package writes by default and tests: test_gpu_pipeline.py::test_dump_encodings_roundtrip.)"""
+    import builtins
+    import sample_pipeline as sp
+    real_import = builtins.__import__
+
+    def no_h5py(name, *a, **k):
+        if name == 'h5py':
+            raise ImportError('h5py hidden by the test')
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(builtins, '__import__', no_h5py)
+    with pytest.raises(RuntimeError, match='h5py'):
+        sp._require_h5py('write x.h5')
+    open(tmp_path / 'states_train_10.h5', 'wb').write(b'not hdf5')
+    with pytest.raises(RuntimeError, match='h5py'):
+        sp.get_encodings_from_states({'amp': 1}, 'train', attributes=[('amp', 1)], savepath=str(tmp_path), n_iter=10)
+
+
 def test_oracle_precision_context_is_scoped():
     import oracle
     from oracle import decode, gru, optim, wae

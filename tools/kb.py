@@ -65,7 +65,7 @@ def main():
     fns = {
         "fwdp": (lambda: ops.gru_seq_fwd_persistent(T, B, H, False, w_hh, b_hh, tok, tab, rowc, None, hs, gates), T),
         "fwd": (lambda: call("cpg_gru_seq_fwd", T, B, H, 0, _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B,
-                             None, _stream()), T),
+                             None, _p(ops.weight_exp(w_hh)), _stream()), T),
         "bwd": (lambda: call("cpg_gru_seq_bwd", T, B, H, 0, _p(w_hh), _p(hs), _p(gates), _p(dhs), None, _p(dG), _p(scr), _p(dh0), 0, B, None,
                              _p(wT), _p(ps1), 0, _stream()), T + 1),
         "bwd2": (lambda: call("cpg_gru_biseq_bwd", T, B, H, _p(w_hh), _p(w_hh), _p(hs), _p(hs), _p(gates), _p(gates), _p(dhs), _p(dhs), None,
