@@ -389,6 +389,218 @@ def linear_raw(x, w, b, out=None, accumulate=False, states=False):
     return out
 
 
+class _GemmProb(ctypes.Structure):
+    """CpgGemmProb of include/cpg_api.h, field for field (cpg_gemm_group_prob_bytes() pins the size at first use)."""
+    _fields_ = [("A", ctypes.c_void_p * 2), ("B", ctypes.c_void_p * 2), ("lda", ctypes.c_int * 2), ("ldb", ctypes.c_int * 2),
+                ("K", ctypes.c_int * 2), ("M", ctypes.c_int), ("N", ctypes.c_int), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
+                ("ldc", ctypes.c_int), ("ldc2", ctypes.c_int), ("n_split", ctypes.c_int), ("accumulate", ctypes.c_int),
+                ("bias", ctypes.c_void_p), ("reserved", ctypes.c_void_p)]
+
+
+NT, NN, TN = 0, 1, 2
+_gemm_prob_checked = False
+
+
+def _dp(t):
+    return None if t is None else (_p(t).value)
+
+
+def gemm_prob(segs, C, M, N, bias=None, accumulate=False, C2=None, n_split=0):
+    """One problem of a grouped launch.  segs: one or two (A, lda, B, ldb, K) tuples chained into the same accumulators; C (and C2 for
+    columns >= n_split): 2-D row-major destinations (row stride = .stride(0))."""
+    pr = _GemmProb()
+    assert 1 <= len(segs) <= 2
+    for i, (A, lda, B, ldb, K) in enumerate(segs):
+        pr.A[i], pr.B[i], pr.lda[i], pr.ldb[i], pr.K[i] = _dp(A), _dp(B), int(lda), int(ldb), int(K)
+    pr.M, pr.N = int(M), int(N)
+    pr.C, pr.ldc = _dp(C), int(C.stride(0))
+    if C2 is not None:
+        pr.C2, pr.ldc2, pr.n_split = _dp(C2), int(C2.stride(0)), int(n_split)
+    pr.accumulate = int(bool(accumulate))
+    pr.bias = _dp(bias)
+    return pr
+
+
+def gemm_group(form, probs):
+    """Up to six independent products of one form (NT / NN / TN) in ONE launch (cpg_gemm_group, csrc/gemm.hip)."""
+    global _gemm_prob_checked
+    if not _gemm_prob_checked:
+        assert ctypes.sizeof(_GemmProb) == int(query("cpg_gemm_group_prob_bytes")), "CpgGemmProb layout drifted from the library's"
+        _gemm_prob_checked = True
+    arr = (_GemmProb * len(probs))(*probs)
+    call("cpg_gemm_group", int(form), len(probs), ctypes.cast(arr, ctypes.c_void_p), _stream())
+
+
+def _ld(t):
+    """(tensor, row stride) of a 2-D operand whose rows are contiguous (a column block of a wider matrix keeps its parent's stride)."""
+    assert t.dim() == 2
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def colsum_into(x, out, accumulate=False, tag=9):
+    """out[n] (+)= sum over rows of x [M, N] (cpg_colsum_f32)."""
+    x, ld = _ld(x)
+    M, N = x.shape
+    nb = int(query("cpg_colsum_workspace_bytes", M, N))
+    ws = workspace(nb, x.device, tag=tag)
+    call("cpg_colsum_f32", _p(x), ld, M, N, _p(out), int(bool(accumulate)), _p(ws), nb, _stream())
+    return out
+
+
+def colsum_multi(xs, outs, accumulate=False):
+    """outs[i][n] (+)= column sums of xs[i] [M, N] for up to four matrices of one shape, ONE single-stage launch (cpg_colsum_multi)."""
+    xs = [_ld(x) for x in xs]
+    M, N = xs[0][0].shape
+    k = len(xs)
+    px = (ctypes.c_void_p * 4)(*[_dp(x) for x, _ in xs], *([None] * (4 - k)))
+    ld = (ctypes.c_int * 4)(*[int(l) for _, l in xs], *([0] * (4 - k)))
+    po = (ctypes.c_void_p * 4)(*[_dp(o) for o in outs], *([None] * (4 - k)))
+    call("cpg_colsum_multi", k, px, ld, M, N, po, int(bool(accumulate)), _stream())
+
+
+class TokenTablesFn(Function):
+    """tab_i = emb W_i[:, c0:c1]^T + b_i for n layers / directions in ONE launch (the W_ih half of nn.GRU over a V-row vocabulary:
+    models/encoder.py:25-30, models/decoder.py:70-77; csrc/gemm.hip: cpg_gemm_group).  Arguments: emb [V,E]; meta = (c0, c1, leaf,
+    pad_row): the columns of every W_i that the embedding multiplies, and - optionally - the LEAF embedding parameter behind `emb` with
+    its padding row (emb = ZeroRowGradFn(leaf): inside backward_scope the embedding gradient is then accumulated straight into
+    leaf.grad with that row skipped, instead of travelling through autograd's add / index_fill / AccumulateGrad launches); then
+    (W_1, b_1, ..., W_n, b_n).  Backward: the n weight-gradient blocks as one grouped launch, the embedding gradient and the bias
+    gradients by cpg_token_tables_bwd (one launch)."""
+
+    @staticmethod
+    def forward(ctx, emb, meta, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[0::2], wb[1::2]
+        c0, c1, leaf, pad_row = meta
+        embc, lde = _ld(emb)
+        V, E = embc.shape
+        assert c1 - c0 == E
+        G = ws[0].shape[0]
+        out = torch.empty(n, V, G, device=emb.device, dtype=torch.float32)
+        probs = []
+        for i in range(n):
+            w = ws[i]
+            assert w.stride(1) == 1 and w.shape[0] == G
+            probs.append(gemm_prob([(embc, lde, w[:, c0:c1], w.stride(0), E)], out[i], V, G, bias=bs[i]))
+        gemm_group(NT, probs)
+        ctx.save_for_backward(embc, *ws)
+        ctx.cols, ctx.n, ctx.leaves, ctx.emb_leaf = (c0, c1), n, (ws, bs), (leaf, pad_row)
+        return tuple(out[i] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dtabs):
+        embc, *ws = ctx.saved_tensors
+        c0, c1 = ctx.cols
+        n = ctx.n
+        V, E = embc.shape
+        G = ws[0].shape[0]
+        dev = embc.device
+        lw, lb = ctx.leaves
+        live = [i for i in range(n) if dtabs[i] is not None]
+        outs = [None, None] + [None] * (2 * n)
+        if not live:
+            return tuple(outs)
+        dts = {i: dtabs[i].contiguous() for i in live}
+        gws = [_grad_buf(lw[i]) for i in range(n)]
+        gbs = [_grad_buf(lb[i]) if lb[i] is not None else None for i in range(n)]
+        direct = all(gws[i] is not None and (lb[i] is None or gbs[i] is not None) for i in live)
+        dws, dbs, probs = {}, {}, []
+        for i in live:
+            if direct:
+                dst = gws[i]
+            else:
+                dst = dws[i] = torch.zeros_like(ws[i])
+                dbs[i] = torch.empty(G, device=dev, dtype=torch.float32) if lb[i] is not None else None
+            probs.append(gemm_prob([(dts[i], G, embc, embc.stride(0), V)], dst[:, c0:c1], G, E, accumulate=direct))
+        gemm_group(TN, probs)
+        leaf, pad_row = ctx.emb_leaf
+        gemb = _grad_buf(leaf) if leaf is not None else None
+        demb, acc_emb, skip = None, 0, -1
+        if gemb is not None:
+            demb, acc_emb, skip = gemb, 1, (int(pad_row) if pad_row is not None else -1)
+        elif ctx.needs_input_grad[0]:
+            demb = torch.empty(V, E, device=dev, dtype=torch.float32)
+        nl = len(live)
+        pt = (ctypes.c_void_p * 4)(*[_dp(dts[i]) for i in live], *([None] * (4 - nl)))
+        pw = (ctypes.c_void_p * 4)(*[_dp(ws[i][:, c0:c1]) for i in live], *([None] * (4 - nl)))
+        ldw = (ctypes.c_int * 4)(*[int(ws[i].stride(0)) for i in live], *([0] * (4 - nl)))
+        pb = (ctypes.c_void_p * 4)(*[_dp(gbs[i] if direct else dbs[i]) for i in live], *([None] * (4 - nl)))
+        call("cpg_token_tables_bwd", nl, V, G, E, pt, pw, ldw, _p(demb), int(demb.stride(0)) if demb is not None else E, acc_emb, skip,
+             pb, int(direct), _stream())
+        outs[0] = None if gemb is not None else demb
+        if not direct:
+            for i in live:
+                outs[2 + 2 * i], outs[3 + 2 * i] = dws[i], dbs[i]
+        return tuple(outs)
+
+
+class EncoderHeadsFn(Function):
+    """(mu, logvar) = (h Wmu^T + bmu, h Wlv^T + blv) with h = [hf | hr] - the encoder's two final states, never concatenated - in ONE
+    launch (models/encoder.py:35-36,46-51; cpg_gemm_group: two problems of two chained segments each).  Backward: dh = dmu Wmu + dlv Wlv
+    as one chained product whose columns go straight to (dhf, dhr), the two weight gradients as one grouped launch (four problems), the
+    two bias gradients as column sums - three launches in place of four products, two split-K reductions, four column-sum launches, two
+    adds and two slicing copies."""
+
+    @staticmethod
+    def forward(ctx, hf, hr, wmu, bmu, wlv, blv):
+        hfc, ldf = _ld(hf)
+        hrc, ldr = (None, 0) if hr is None else _ld(hr)
+        B, H = hfc.shape
+        Z = wmu.shape[0]
+        Hr = hrc.shape[1] if hrc is not None else 0
+        assert wmu.shape[1] == H + Hr and wmu.stride(1) == 1 and wlv.stride(1) == 1
+        out = torch.empty(2, B, Z, device=hf.device, dtype=torch.float32)
+        probs = []
+        for k, (w, b) in enumerate(((wmu, bmu), (wlv, blv))):
+            segs = [(hfc, ldf, w[:, :H], w.stride(0), H)]
+            if hrc is not None:
+                segs.append((hrc, ldr, w[:, H:], w.stride(0), Hr))
+            probs.append(gemm_prob(segs, out[k], B, Z, bias=b))
+        gemm_group(NT, probs)
+        ctx.save_for_backward(hfc, hrc, wmu, wlv)
+        ctx.leaves = (wmu, bmu, wlv, blv)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, dmu, dlv):
+        hf, hr, wmu, wlv = ctx.saved_tensors
+        B, H = hf.shape
+        Hr = hr.shape[1] if hr is not None else 0
+        Z = wmu.shape[0]
+        dev = hf.device
+        if dmu is None:
+            dmu = torch.zeros(B, Z, device=dev)
+        if dlv is None:
+            dlv = torch.zeros(B, Z, device=dev)
+        dmu, ldm = _ld(dmu)
+        dlv, ldl = _ld(dlv)
+        dhf = dhr = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dhf = torch.empty(B, H, device=dev, dtype=torch.float32)
+            dhr = torch.empty(B, Hr, device=dev, dtype=torch.float32) if hr is not None else None
+            gemm_group(NN, [gemm_prob([(dmu, ldm, wmu, wmu.stride(0), Z), (dlv, ldl, wlv, wlv.stride(0), Z)], dhf, B, H + Hr,
+                                      C2=dhr, n_split=H)])
+        lw = ctx.leaves
+        g = [_grad_buf(p) for p in lw]
+        direct = all(x is not None for x in g)
+        dwmu = g[0] if direct else torch.empty_like(wmu)
+        dwlv = g[2] if direct else torch.empty_like(wlv)
+        dbmu = g[1] if direct else torch.empty(Z, device=dev, dtype=torch.float32)
+        dblv = g[3] if direct else torch.empty(Z, device=dev, dtype=torch.float32)
+        probs = []
+        for dy, ldy, dw in ((dmu, ldm, dwmu), (dlv, ldl, dwlv)):
+            probs.append(gemm_prob([(dy, ldy, hf, hf.stride(0), B)], dw[:, :H], Z, H, accumulate=direct))
+            if hr is not None:
+                probs.append(gemm_prob([(dy, ldy, hr, hr.stride(0), B)], dw[:, H:], Z, Hr, accumulate=direct))
+        gemm_group(TN, probs)
+        colsum_multi([dmu, dlv], [dbmu, dblv], accumulate=direct)
+        if direct:
+            return dhf, dhr, None, None, None, None
+        return dhf, dhr, dwmu, dbmu, dwlv, dblv
+
+
 class LinearFn(Function):
     """y = x W^T + b (nn.Linear: models/encoder.py:35-36,50-51; also the token-table and [z;c] projections that
     replace the W_ih half of nn.GRU at models/decoder.py:70-77)."""
@@ -655,6 +867,16 @@ class SkipAddFn(Function):
         ws = workspace(nb, dev)
         call("cpg_colsum_f32", _p(dy), B * H, T, B * H, _p(dsz), 0, _p(ws), ws.numel(), _stream())
         return dx, (None if gw is not None else dw), dsz, None
+
+
+def tag_emb(t, leaf, pad_row):
+    """Remember, on the tensor object, the leaf embedding parameter (and its padding row) a graph-side view of it stands for."""
+    t._cpg_emb_leaf = (leaf, pad_row)
+    return t
+
+
+def emb_leaf(t):
+    return getattr(t, "_cpg_emb_leaf", (None, None))
 
 
 class ZeroRowGradFn(Function):
@@ -1345,11 +1567,65 @@ class VocabFcFn(Function):
         db = gb if direct else torch.empty(V, device=dev, dtype=torch.float32)
         nb = query("cpg_vocab_fc_bwd_workspace", R, H, V)
         ws = workspace(nb, dev)
-        call("cpg_vocab_fc_bwd", _p(dl), _p(hs), _p(keep), ctx.scale, _p(w), _p(dhs), _p(dw), _p(db), R, H, V, int(direct), _p(ws),
-             ws.numel(), _stream())
+        call("cpg_vocab_fc_bwd", _p(dl), _p(hs), _p(keep), ctx.scale, _p(w), _p(dhs), _p(dw), _p(db), R, H, V, int(direct), None, None,
+             _p(ws), ws.numel(), _stream())
         if direct:
             dw = db = None
         return dhs, None, None, dw, db
+
+
+class VocabReconFn(Function):
+    """The trainer's form of the decoder's tail: nn.Dropout(p_out) + nn.Linear(h_dim, n_vocab) + losses.recon_dec (models/decoder.py:43-45,
+    83, losses.py:18-31) as ONE node over time-major rows - the logits are never transposed to [B,T,V] and back, the cross-entropy pass
+    leaves the unscaled logit gradient (cpg_recon_ce_tm_fwd), and the backward of the projection takes the upstream gradient and the
+    target count as device scalars (cpg_vocab_fc_bwd's g / count): no separate d-logits launch.  hs [T B, H] time-major step outputs,
+    ids int64 [B,T]; count_override (optional device scalar: the GLOBAL number of scored targets under data parallelism).
+    Returns (loss, logits_tm [T B, V] - not differentiable: the loss is the only consumer)."""
+
+    @staticmethod
+    def forward(ctx, hs, keep, scale, w, b, ids, count_override):
+        hs = hs.contiguous()
+        R, H = hs.shape
+        V = w.shape[0]
+        B, T = ids.shape
+        assert R == B * T
+        dev = hs.device
+        w_c, b_c, ids = w.contiguous(), b.contiguous(), ids.contiguous()
+        logits = torch.empty(R, V, device=dev, dtype=torch.float32)
+        call("cpg_vocab_fc_fwd", _p(hs), _p(keep), float(scale), _p(w_c), _p(b_c), _p(logits), R, H, V, _stream())
+        out = torch.empty(3, device=dev, dtype=torch.float32)
+        dl = torch.empty(R, V, device=dev, dtype=torch.float32)
+        ws = workspace(512 * 4, dev, tag=1)
+        call("cpg_recon_ce_tm_fwd", _p(ids), _p(logits), B, T, V, PAD_IDX, _p(out), _p(dl), _p(ws), _stream())
+        if count_override is None:
+            count, loss = out[1:2], out[2]
+        else:
+            count = count_override.reshape(1).to(torch.float32).contiguous()
+            loss = out[0] / count.clamp(min=1.0)[0]
+        ctx.save_for_backward(hs, keep, w_c, dl, count)
+        ctx.scale, ctx.leaves = float(scale), (w, b)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, g, _glogits):
+        hs, keep, w, dl, count = ctx.saved_tensors
+        R, H = hs.shape
+        V = w.shape[0]
+        dev = hs.device
+        g = g.contiguous()
+        dhs = torch.empty(R, H, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        gw, gb = _grad_buf(ctx.leaves[0]), _grad_buf(ctx.leaves[1])
+        direct = gw is not None and gb is not None
+        dw = gw if direct else torch.empty(V, H, device=dev, dtype=torch.float32)
+        db = gb if direct else torch.empty(V, device=dev, dtype=torch.float32)
+        nb = query("cpg_vocab_fc_bwd_workspace", R, H, V)
+        ws = workspace(nb, dev)
+        call("cpg_vocab_fc_bwd", _p(dl), _p(hs), _p(keep), ctx.scale, _p(w), _p(dhs), _p(dw), _p(db), R, H, V, int(direct), _p(g), _p(count),
+             _p(ws), ws.numel(), _stream())
+        if direct:
+            dw = db = None
+        return dhs, None, None, dw, db, None, None
 
 
 # ----------------------------------------------------------------------------------------------- latent / losses
@@ -1427,6 +1703,59 @@ class LatentTermsFn(Function):
         call("cpg_latent_stats_bwd", _p(mu), _p(logvar), mu.numel(), ctx.bg, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(dmu), _p(dlv), 0,
              _stream())
         return dmu, dlv, None
+
+
+class LatentFn(Function):
+    """The latent block of a training step as ONE node (cpg_latent_fused_fwd / _bwd): z = mu + exp(logvar / 2) eps
+    (RNN_VAE.sample_z, models/model.py:107-112), c ~ Cat(.5,.5) (sample_c_prior :121-126) or a given c, the decoder's initial state /
+    constant input zc = [z ; c] (GRUDecoder.init_hidden, models/decoder.py:53-54) and the three analytic penalties kl_gaussianprior,
+    kl_gaussian_sharedmu, |logvar|_1 (losses.py:8-15, train_vae.py:33).  eps / c None: drawn inside the kernel from the model's device
+    streams (`rng` = DeviceRng; the numbers DeviceRng.normal / onehot2 would have produced at the same point of the stream).
+    Returns (z, zc, c, kl, klmu, l1, sums5); backward = one launch for every gradient that reaches mu / logvar through them."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, c, rng):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        B, Z = mu.shape
+        dev = mu.device
+        C = 2 if c is None else c.shape[1]
+        seed = off_e = off_c = 0
+        base = None
+        if eps is None or c is None:
+            assert rng is not None, "LatentFn: draws inside the kernel need the model's DeviceRng"
+            base = rng.base_for(dev)
+            if eps is None:
+                seed, off_e = rng.next(B * Z)
+            if c is None:
+                seed, off_c = rng.next(B)
+        need = mu.requires_grad or logvar.requires_grad
+        eps_c = eps.contiguous() if eps is not None else None
+        eps_keep = eps_c if eps_c is not None else (torch.empty(B, Z, device=dev, dtype=torch.float32) if need else None)
+        z = torch.empty(B, Z, device=dev, dtype=torch.float32)
+        zc = torch.empty(B, Z + C, device=dev, dtype=torch.float32)
+        c_out = torch.empty(B, C, device=dev, dtype=torch.float32)
+        out5 = torch.empty(5, device=dev, dtype=torch.float32)
+        ws = workspace(int(query("cpg_latent_fused_workspace")), dev, tag=1)
+        call("cpg_latent_fused_fwd", _p(mu), _p(logvar), _p(eps_c), _p(c.contiguous() if c is not None else None), B, Z, C, int(seed),
+             int(off_e), int(off_c), _p(base), 0.5, _p(eps_keep) if eps_c is None else None, _p(z), _p(zc), _p(c_out), _p(out5), _p(ws),
+             _stream())
+        ctx.save_for_backward(mu, logvar, eps_keep)
+        ctx.mark_non_differentiable(c_out, out5)
+        return z, zc, c_out, out5[0], out5[1], out5[2], out5
+
+    @staticmethod
+    def backward(ctx, dz, dzc, _dc, g_kl, g_klmu, g_l1, _d5):
+        mu, logvar, eps = ctx.saved_tensors
+        B, Z = mu.shape
+        dz = dz.contiguous() if dz is not None else None
+        ldzc = 0
+        if dzc is not None:
+            dzc, ldzc = _ld(dzc)
+        gs = [g.contiguous() if g is not None else None for g in (g_kl, g_klmu, g_l1)]
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        call("cpg_latent_fused_bwd", _p(dz), _p(dzc), int(ldzc), _p(mu), _p(logvar), _p(eps), B, Z, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(dmu),
+             _p(dlv), _stream())
+        return dmu, dlv, None, None, None
 
 
 class WeightedSumFn(Function):

@@ -157,6 +157,15 @@ class FusedAdamClip:
         self.iter_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.ws = torch.empty(ops.query("cpg_sumsq_workspace") // 4, device=dev, dtype=torch.float32)
+        self.rng = None
+        # the one-launch forms cover: at most two parameters listed more than once, all the same number (<= 4) of times
+        import ctypes
+        dups = [((off, pad(k)), mm) for (off, k), mm in zip(self.segs, self.mult) if mm > 1]
+        self._ndup = len(dups)
+        self._fused_ok = self._ndup <= 2 and all(mm <= 4 and mm == dups[0][1] for _, mm in dups)
+        self._dup_off = (ctypes.c_ulonglong * 2)(*([d[0][0] for d in dups] + [0, 0])[:2])
+        self._dup_len = (ctypes.c_ulonglong * 2)(*([d[0][1] for d in dups] + [0, 0])[:2])
+        self._dup_mult = (ctypes.c_int * 2)(*([d[1] for d in dups] + [1, 1])[:2])
 
     @property
     def _reduced(self):          # tags whose all-reduce was started from a gradient boundary of the current backward pass
@@ -194,6 +203,20 @@ class FusedAdamClip:
         self._finish_reduce()            # SUM over ranks; the 1/world factor is folded into the update (gscale)
         gscale = 1.0 / self.world
         n = self.flat_g.numel()
+        b1, b2 = self.betas
+        if self._fused_ok:
+            # two launches for the whole iteration: partial sums of the weighted squares, then ONE Adam launch over the flat buffer that
+            # reduces the partials itself and walks the doubly-listed embedding through its two consecutive steps (csrc/optim.hip)
+            part = None
+            if self.max_norm is not None:
+                call("cpg_sumsq_segs", _p(self.flat_g), n, self._ndup, self._dup_off, self._dup_len, self._dup_mult, _p(self.ws), _stream())
+                part = self.ws
+            call("cpg_adam_step_segs", _p(self.flat_p), _p(self.flat_g), _p(self.m), _p(self.v), n, float(self.lr), float(b1), float(b2),
+                 float(self.eps), _p(part), _p(self.sumsq) if part is not None else None,
+                 float(self.max_norm if self.max_norm is not None else 0.0), float(gscale), _p(self.iter_dev), self._ndup, self._dup_off,
+                 self._dup_len, self._dup_mult, _stream())
+            self._advance_counters()
+            return
         sumsq = None
         if self.max_norm is not None:
             call("cpg_sumsq", _p(self.flat_g), n, 1.0, 0, _p(self.sumsq), _p(self.ws), _stream())
@@ -201,7 +224,6 @@ class FusedAdamClip:
                 if mm > 1:
                     call("cpg_sumsq", _p(self.flat_g[off:]), k, float(mm - 1), 1, _p(self.sumsq), _p(self.ws), _stream())
             sumsq = self.sumsq
-        b1, b2 = self.betas
 
         def adam(off, k, step_add, step_mult, coef_pow):
             # step number = step_mult * iter_dev + step_add, formed on the device
@@ -219,4 +241,18 @@ class FusedAdamClip:
         if i < len(self.order):
             off = self.segs[i][0]
             adam(off, n - off, 1, 1, 1)
-        call("cpg_counter_add_i32", _p(self.iter_dev), 1, _stream())
+        self._advance_counters()
+
+    def _advance_counters(self):
+        """iter_dev += 1 - together with the model's Philox base when a DeviceRng was attached (`attach_rng`): one launch for both
+        device-side counters of a step (cpg_step_counters_add)."""
+        rng = self.rng
+        if rng is not None and rng.base is not None and rng.offset:
+            call("cpg_step_counters_add", _p(rng.base), int(rng.offset), _p(self.iter_dev), 1, _stream())
+            rng.offset = 0
+        else:
+            call("cpg_step_counters_add", None, 0, _p(self.iter_dev), 1, _stream())
+
+    def attach_rng(self, rng):
+        """The model's DeviceRng: step() then also closes the step's draws (DeviceRng.end_step's work) in its counter launch."""
+        self.rng = rng

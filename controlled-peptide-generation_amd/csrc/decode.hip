@@ -23,8 +23,10 @@ __device__ __forceinline__ float lane_value(float x, int l) {   // x of lane l (
 
 template <int VV, bool MASK>
 __global__ __launch_bounds__(256) void vocab_bwd_dh_kernel(const float* __restrict__ dl, const uint8_t* __restrict__ keep, float scale,
-                                                           const float* __restrict__ w, float* __restrict__ dhs, int R, int H, int V) {
-    constexpr int NR = 8;   // rows per trip; the next trip's loads are issued before this trip's arithmetic (no branch in the pipelined loop)
+                                                           const float* __restrict__ w, float* __restrict__ dhs, int R, int H, int V,
+                                                           const float* __restrict__ gnum, const float* __restrict__ gden) {
+    constexpr int NR = 8;
+    const float gs = gnum ? gnum[0] / (gden ? fmaxf(gden[0], 1.f) : 1.f) : 1.f;   // dl arrives unscaled (cpg_recon_ce_tm_fwd): times gout / count   // rows per trip; the next trip's loads are issued before this trip's arithmetic (no branch in the pipelined loop)
     const int lane = threadIdx.x & 63;
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nqb = H >> 8, nrs = (gridDim.x * 4) / nqb;   // 256-column blocks, row streams
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void vocab_bwd_dh_kernel(const float* __restri
     };
     auto row = [&](int r, uchar4 kp, float dv) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        dv = lvok ? dv : 0.f;
+        dv = lvok ? dv * gs : 0.f;
 #pragma unroll
         for (int v = 0; v < VV; ++v) {
             const float g = lane_value(dv, v);
@@ -99,8 +101,10 @@ __global__ __launch_bounds__(256) void vocab_bwd_dh_kernel(const float* __restri
 template <int VV, bool MASK>
 __global__ __launch_bounds__(256) void vocab_bwd_dw_kernel(const float* __restrict__ dl, const float* __restrict__ hs,
                                                            const uint8_t* __restrict__ keep, float scale, float* __restrict__ part,
-                                                           float* __restrict__ part_db, int R, int H, int V, int rows_per_wg) {
+                                                           float* __restrict__ part_db, int R, int H, int V, int rows_per_wg,
+                                                           const float* __restrict__ gnum, const float* __restrict__ gden) {
     constexpr int NR = 4;
+    const float gs = gnum ? gnum[0] / (gden ? fmaxf(gden[0], 1.f) : 1.f) : 1.f;
     extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
     float4* red = reinterpret_cast<float4*>(cpg_smem);   // [qpw][VV][64]
     const int lane = threadIdx.x & 63;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void vocab_bwd_dw_kernel(const float* __restri
         }
     };
     auto row = [&](float4 h, uchar4 kp, float dv) {
-        dv = lvok ? dv : 0.f;
+        dv = lvok ? dv * gs : 0.f;
         if constexpr (MASK) {
             h.x *= kp.x ? scale : 0.f;
             h.y *= kp.y ? scale : 0.f;
@@ -269,19 +273,19 @@ CPG_EXPORT size_t cpg_vocab_fc_bwd_workspace(int R, int H, int V) {
     size_t a = cpg_gemm_tn_workspace(R, V, H), b = cpg_colsum_workspace(R, V);
     size_t c = vocab_bwd_streams(R, H, V) ? (size_t)vocab_bwd_wgs(R) * ((size_t)V * H + 4 * 32) * sizeof(float) : 0;
     a = a > b ? a : b;
-    return (a > c ? a : c) + 256;
+    return (a > c ? a : c) + (size_t)R * V * sizeof(float) + 256;   // + a scaled copy of dlogits for the tile-engine fallback with g / count
 }
 
 template <int VV>
 static int vocab_bwd_launch(const float* dl, const float* hs, const uint8_t* keep, float scale, const float* w, float* dhs, float* dw, float* db,
-                            int R, int H, int V, int accumulate, float* ws, hipStream_t s) {
+                            int R, int H, int V, int accumulate, float* ws, hipStream_t s, const float* gnum, const float* gden) {
     if (dhs) {
         int g = 2 * cpg_device_cus();
         while ((g * 4) % (H / 256)) ++g;
         if (keep)
-            hipLaunchKernelGGL((vocab_bwd_dh_kernel<VV, true>), dim3(g), dim3(256), 0, s, dl, keep, scale, w, dhs, R, H, V);
+            hipLaunchKernelGGL((vocab_bwd_dh_kernel<VV, true>), dim3(g), dim3(256), 0, s, dl, keep, scale, w, dhs, R, H, V, gnum, gden);
         else
-            hipLaunchKernelGGL((vocab_bwd_dh_kernel<VV, false>), dim3(g), dim3(256), 0, s, dl, keep, scale, w, dhs, R, H, V);
+            hipLaunchKernelGGL((vocab_bwd_dh_kernel<VV, false>), dim3(g), dim3(256), 0, s, dl, keep, scale, w, dhs, R, H, V, gnum, gden);
         CPG_LAUNCH_CHECK();
     }
     if (dw || db) {
@@ -291,9 +295,9 @@ static int vocab_bwd_launch(const float* dl, const float* hs, const uint8_t* kee
         float* part_db = ws + (size_t)G * V * H;
         const size_t smem = nrl > 1 ? (size_t)qpw * VV * 64 * sizeof(float4) : 0;
         if (keep)
-            hipLaunchKernelGGL((vocab_bwd_dw_kernel<VV, true>), dim3(G, nqb / qpw), dim3(256), smem, s, dl, hs, keep, scale, part, part_db, R, H, V, rows);
+            hipLaunchKernelGGL((vocab_bwd_dw_kernel<VV, true>), dim3(G, nqb / qpw), dim3(256), smem, s, dl, hs, keep, scale, part, part_db, R, H, V, rows, gnum, gden);
         else
-            hipLaunchKernelGGL((vocab_bwd_dw_kernel<VV, false>), dim3(G, nqb / qpw), dim3(256), smem, s, dl, hs, keep, scale, part, part_db, R, H, V, rows);
+            hipLaunchKernelGGL((vocab_bwd_dw_kernel<VV, false>), dim3(G, nqb / qpw), dim3(256), smem, s, dl, hs, keep, scale, part, part_db, R, H, V, rows, gnum, gden);
         CPG_LAUNCH_CHECK();
         const int nblk = cdiv(V * H / 4, 32);
         hipLaunchKernelGGL(vocab_bwd_final_kernel, dim3(nblk + 1), dim3(32, 32), 0, s, part, part_db, G, G * nrl, V, H, dw, db, accumulate);
@@ -303,19 +307,35 @@ static int vocab_bwd_launch(const float* dl, const float* hs, const uint8_t* kee
 }
 
 // dhs[R,H] = (dlogits W) .* keep*scale ; dw[V,H] (+)= dlogits^T (hs .* keep*scale) ; db[V] (+)= colsum(dlogits)
+// g / count (optional device scalars): dlogits arrives UNSCALED (cpg_recon_ce_tm_fwd) and is multiplied by g[0] / max(count[0], 1) on
+// the way in (count null: by g[0]); the tile-engine fallback scales a copy first (workspace: + R V floats then).
+__global__ void scale_rows_kernel(const float* __restrict__ x, size_t n, const float* gnum, const float* gden, float* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * (gnum[0] / (gden ? fmaxf(gden[0], 1.f) : 1.f));
+}
 CPG_EXPORT int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uint8_t* keep, float scale, const float* w,
-                                float* dhs, float* dw, float* db, int R, int H, int V, int accumulate, void* workspace,
-                                size_t workspace_bytes, void* stream) {
-    CPG_CHECK_ARG(dlogits && hs && w && R > 0 && H > 0 && V > 0);
+                                float* dhs, float* dw, float* db, int R, int H, int V, int accumulate, const float* g, const float* count,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(dlogits && hs && w && R > 0 && H > 0 && V > 0 && (g || !count));
     hipStream_t s = (hipStream_t)stream;
     int rc = 0;
     if (vocab_bwd_streams(R, H, V) && (!(dw || db) || (dw && db && workspace && workspace_bytes >= cpg_vocab_fc_bwd_workspace(R, H, V) - 256)) &&
         aligned16(hs) && aligned16(w) && (!dhs || aligned16(dhs)) && (!dw || aligned16(dw))) {
         float* ws = (float*)workspace;
-        if (V <= 8) return vocab_bwd_launch<8>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
-        if (V <= 16) return vocab_bwd_launch<16>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
-        if (V <= 24) return vocab_bwd_launch<24>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
-        return vocab_bwd_launch<32>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s);
+        if (V <= 8) return vocab_bwd_launch<8>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s, g, count);
+        if (V <= 16) return vocab_bwd_launch<16>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s, g, count);
+        if (V <= 24) return vocab_bwd_launch<24>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s, g, count);
+        return vocab_bwd_launch<32>(dlogits, hs, keep, scale, w, dhs, dw, db, R, H, V, accumulate, ws, s, g, count);
+    }
+    if (g) {   // the generic products take a scaled copy (tail of the workspace)
+        const size_t need = cpg_vocab_fc_bwd_workspace(R, H, V);
+        CPG_CHECK_ARG(workspace && workspace_bytes >= need);
+        float* sc = (float*)((char*)workspace + need - 256 - (size_t)R * V * sizeof(float));
+        const size_t n = (size_t)R * V;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dlogits, n, g, count, sc);
+        CPG_LAUNCH_CHECK();
+        dlogits = sc;
+        workspace_bytes = need - 256 - (size_t)R * V * sizeof(float);
     }
     if (dhs) rc = cpg_gemm_nn(dlogits, V, w, H, dhs, H, R, H, V, 0, keep, scale, s);
     if (rc) return rc;

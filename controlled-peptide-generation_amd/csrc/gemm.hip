@@ -350,6 +350,263 @@ int cpg_gemm_nt(const float* X, int ldx, const uint8_t* xmask, float xms, const 
     return launch_gemm<true, true>(g, 1, s);
 }
 
+// ------------------------------------------------------------------------------------------ grouped small products (round 6)
+// A training step issues ~20 independent nn.Linear-shaped products of a few GFLOP at most - the three token tables, the two encoder heads
+// and their gradients, ... (models/encoder.py:35-36,50-51, models/decoder.py:70-77) - each of which fills a fraction of the chip when it runs
+// alone, one after the other.  cpg_gemm_group runs up to GEMM_GROUP_MAX problems of one form in ONE launch (a flat grid over all
+// their tiles), and a problem may chain TWO (A, B, K) segments into the same accumulators:
+//   * an input that is the concatenation of two tensors (the encoder's two final states) needs no torch.cat,
+//   * dX = dY1 W1 + dY2 W2 (the two heads' input gradients) is one product instead of two products and an add,
+//   * columns of the result can go to two destinations (n_split): the gradient of a concatenation needs no slicing copies.
+// Engines: forms NT / NN run the exact-f32 MFMA, TN (weight gradients) the three-plane bf16 split, exactly as the single-problem
+// launchers above - the sums of a problem are those cpg_linear_* would form (a chained problem adds its second segment's slabs
+// behind the first's).
+constexpr int GEMM_GROUP_MAX = 6;
+struct GemmProb {            // mirrors CpgGemmProb of include/cpg_api.h field for field
+    const float* A[2];
+    const float* B[2];
+    int lda[2], ldb[2], K[2];
+    int M, N;
+    float* C;
+    float* C2;
+    int ldc, ldc2, n_split;
+    int accumulate;
+    const float* bias;
+    const void* reserved;
+};
+struct GemmGroup {
+    GemmProb p[GEMM_GROUP_MAX];
+    int tile0[GEMM_GROUP_MAX + 1];   // first flat tile of each problem
+    int tiles_n[GEMM_GROUP_MAX];
+    int pairs_a[GEMM_GROUP_MAX][2], pairs_b[GEMM_GROUP_MAX][2];
+    int n;
+};
+
+template <class TC, bool A_KC, bool B_KC, bool VEC>
+__global__ __launch_bounds__(TC::NT) void gemm_group_kernel(GemmGroup G) {
+    using Loop = GemmLoop<TC, A_KC, B_KC, VEC, false, 7>;
+    const int t = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_GROUP_MAX; ++i)
+        if (i < G.n && t >= G.tile0[i]) pi = i;
+    const GemmProb& g = G.p[pi];
+    const int tl = t - G.tile0[pi];
+    const int by = tl / G.tiles_n[pi], bx = tl - by * G.tiles_n[pi];
+    const int m0 = by * TC::BM, n0 = bx * TC::BN;
+    f32x4 acc[TC::MI][TC::NI];
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sg = 0; sg < 2; ++sg) {
+        if (g.K[sg] <= 0) break;
+        if (sg) __syncthreads();
+        OpA a{g.A[sg], g.lda[sg], m0, g.M, nullptr, 1.f, G.pairs_a[pi][sg], 0, nullptr, 1};
+        OpB b{g.B[sg], g.ldb[sg], n0, g.N, 0, nullptr, 1.f, G.pairs_b[pi][sg]};
+        Loop::run(a, b, g.K[sg], acc);
+    }
+#pragma unroll
+    for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) {
+            const int col = n0 + acc_col<TC>(ni);
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+            float* dst = g.C;
+            int ld = g.ldc, c = col;
+            if (g.C2 && col >= g.n_split) { dst = g.C2; ld = g.ldc2; c = col - g.n_split; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + acc_row<TC>(mi, r);
+                if (row >= g.M) continue;
+                const size_t o = (size_t)row * ld + c;
+                float v = acc[mi][ni][r] + bv;
+                if (g.accumulate) v += dst[o];
+                dst[o] = v;
+            }
+        }
+}
+
+template <class TC, bool A_KC, bool B_KC>
+static int launch_group(GemmGroup& G, bool vec, hipStream_t s) {
+    int tiles = 0;
+    for (int i = 0; i < G.n; ++i) {
+        G.tile0[i] = tiles;
+        G.tiles_n[i] = cdiv(G.p[i].N, TC::BN);
+        tiles += G.tiles_n[i] * cdiv(G.p[i].M, TC::BM);
+    }
+    G.tile0[G.n] = tiles;
+    const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false, 7>::smem_bytes();
+    const void* k = vec ? reinterpret_cast<const void*>(gemm_group_kernel<TC, A_KC, B_KC, true>)
+                        : reinterpret_cast<const void*>(gemm_group_kernel<TC, A_KC, B_KC, false>);
+    if (smem > 64 * 1024) {
+        const int rc = cpg_allow_big_lds(k, (int)smem);
+        if (rc) return rc;
+    }
+    if (vec) hipLaunchKernelGGL((gemm_group_kernel<TC, A_KC, B_KC, true>), dim3(tiles), dim3(TC::NT), smem, s, G);
+    else hipLaunchKernelGGL((gemm_group_kernel<TC, A_KC, B_KC, false>), dim3(tiles), dim3(TC::NT), smem, s, G);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool A_KC, bool B_KC>
+static int gemm_group(GemmGroup& G, hipStream_t s) {
+    bool vec = true;
+    int maxM = 0, maxN = 0, maxK = 0;
+    long t64 = 0;
+    for (int i = 0; i < G.n; ++i) {
+        const GemmProb& g = G.p[i];
+        maxM = g.M > maxM ? g.M : maxM;
+        maxN = g.N > maxN ? g.N : maxN;
+        t64 += (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+        for (int sg = 0; sg < 2 && g.K[sg] > 0; ++sg) {
+            const int K = g.K[sg];
+            maxK = K > maxK ? K : maxK;
+            const bool even_k = K % 2 == 0;
+            G.pairs_a[i][sg] = (((uintptr_t)g.A[sg]) & 7) == 0 && g.lda[sg] % 2 == 0 && (A_KC ? even_k : g.M % 2 == 0);
+            G.pairs_b[i][sg] = (((uintptr_t)g.B[sg]) & 7) == 0 && g.ldb[sg] % 2 == 0 && (B_KC ? even_k : g.N % 2 == 0);
+            vec = vec && aligned16(g.A[sg]) && aligned16(g.B[sg]) && g.lda[sg] % 4 == 0 && g.ldb[sg] % 4 == 0 &&
+                  ((A_KC || B_KC) ? K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) && (B_KC || g.N % 4 == 0);
+        }
+    }
+    // tiles as launch_gemm picks them for one problem, on the group's totals (tools/gbench.py, tools/lin_sweep.py)
+    if (maxM <= 32) return launch_group<T32x128, A_KC, B_KC>(G, vec, s);
+    if (maxN <= 32) return launch_group<T128x32, A_KC, B_KC>(G, vec, s);
+    if (A_KC && maxK >= 1024 && t64 < 512) return launch_group<T64x32, A_KC, B_KC>(G, vec, s);
+    return launch_group<T64x64, A_KC, B_KC>(G, vec, s);
+}
+
+// form: 0 = NT  C[M,N] (+)= sum_s A_s[M,K_s] B_s[N,K_s]^T (+ bias)     nn.Linear forward
+//       1 = NN  C[M,N] (+)= sum_s A_s[M,K_s] B_s[K_s,N]   (+ bias)     input gradient dX = dY W
+//       2 = TN  C[M,N] (+)= sum_s A_s[K_s,M]^T B_s[K_s,N]              weight gradient dW = dY^T X
+CPG_EXPORT int cpg_gemm_group_prob_bytes(void) { return (int)sizeof(GemmProb); }
+CPG_EXPORT int cpg_gemm_group(int form, int nprob, const void* probs, void* stream) {
+    CPG_CHECK_ARG(form >= 0 && form <= 2 && nprob >= 1 && nprob <= GEMM_GROUP_MAX && probs);
+    GemmGroup G;
+    memset(&G, 0, sizeof(G));
+    G.n = nprob;
+    memcpy(G.p, probs, sizeof(GemmProb) * nprob);
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProb& g = G.p[i];
+        CPG_CHECK_ARG(g.A[0] && g.B[0] && g.C && g.M > 0 && g.N > 0 && g.K[0] > 0 && g.K[1] >= 0 && (g.K[1] == 0 || (g.A[1] && g.B[1])));
+        CPG_CHECK_ARG(!g.C2 || (g.n_split > 0 && g.n_split < g.N));
+        CPG_CHECK_ARG(form != 2 || !g.bias);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    return form == 0 ? gemm_group<true, true>(G, s) : form == 1 ? gemm_group<true, false>(G, s) : gemm_group<false, false>(G, s);
+}
+
+// ---- backward of n token tables tab_i = emb W_i^T + b_i (ops.TokenTablesFn) that the grouped TN launch does not cover, ONE launch:
+//   demb[v][e] (+)= sum_i sum_j dtab_i[v][j] W_i[j][e]     (V x E outputs, contraction over n G gate rows: blocks [0, nA))
+//   db_i[j]    (+)= sum_v dtab_i[v][j]                      (blocks [nA, nA + nB))
+// demb rows equal to skip_row are left untouched when accumulating (nn.Embedding(padding_idx): that row gets no gradient) / written as
+// zeros otherwise.  Fixed summation order (16 k-lanes per output, reduced through LDS in lane order).
+struct TabBwdArgs {
+    const float* dtab[4];
+    const float* W[4];
+    int ldw[4];
+    float* db[4];
+    float* demb;
+    int n, V, G, E, lde, nA, acc_emb, acc_db, skip_row;
+};
+__global__ __launch_bounds__(1024) void token_tables_bwd_kernel(TabBwdArgs a) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    if ((int)blockIdx.x < a.nA) {
+        if (!a.demb) return;
+        const int ne = (a.E + 63) / 64;
+        const int v = blockIdx.x / ne, e = (blockIdx.x - v * ne) * 64 + tx;
+        float s = 0.f;
+        if (e < a.E)
+            for (int i = 0; i < a.n; ++i) {
+                const float* dt = a.dtab[i] + (size_t)v * a.G;
+                const float* w = a.W[i] + e;
+                for (int j = ty; j < a.G; j += 16) s = fmaf(dt[j], w[(size_t)j * a.ldw[i]], s);
+            }
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && e < a.E) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][tx];
+            float* o = a.demb + (size_t)v * a.lde + e;
+            if (v == a.skip_row) { if (!a.acc_emb) *o = 0.f; }
+            else *o = a.acc_emb ? *o + t : t;
+        }
+        return;
+    }
+    const int b = blockIdx.x - a.nA, nj = (a.G + 1023) / 1024;
+    const int i = b / nj, j = (b - i * nj) * 1024 + ty * 64 + tx;
+    if (i >= a.n || j >= a.G || !a.db[i]) return;
+    float s = 0.f;
+    for (int v = 0; v < a.V; ++v) s += a.dtab[i][(size_t)v * a.G + j];
+    a.db[i][j] = a.acc_db ? a.db[i][j] + s : s;
+}
+// dtab / W / db: host arrays of n (<= 4) device pointers (W_i = the [G, E] column block of the layer's W_ih the embedding multiplies,
+// row stride ldw[i]; db entries may be null).  demb [V, lde >= E] or null.  skip_row: < 0 for none.
+CPG_EXPORT int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* dtab, const void* const* W, const int* ldw, float* demb,
+                                    int lde, int accumulate_emb, int skip_row, void* const* db, int accumulate_db, void* stream) {
+    CPG_CHECK_ARG(n >= 1 && n <= 4 && V > 0 && G > 0 && E > 0 && dtab && W && ldw && db && (!demb || lde >= E));
+    TabBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) {
+        CPG_CHECK_ARG(dtab[i] && W[i] && ldw[i] >= E);
+        a.dtab[i] = (const float*)dtab[i];
+        a.W[i] = (const float*)W[i];
+        a.ldw[i] = ldw[i];
+        a.db[i] = (float*)db[i];
+    }
+    a.demb = demb; a.n = n; a.V = V; a.G = G; a.E = E; a.lde = lde;
+    a.nA = cdiv(E, 64) * V;
+    a.acc_emb = accumulate_emb; a.acc_db = accumulate_db; a.skip_row = skip_row;
+    const int nB = n * cdiv(G, 1024);
+    hipLaunchKernelGGL(token_tables_bwd_kernel, dim3(a.nA + nB), dim3(64, 16), 0, (hipStream_t)stream, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- column sums of up to four [M, N] matrices in ONE single-stage launch (bias gradients of a group of heads: M = batch rows):
+// out_i[n] (+)= sum_m X_i[m][n]; 64 columns x 16 row lanes per block, lanes reduced through LDS in lane order.
+struct ColsumMultiArgs {
+    const float* X[4];
+    float* out[4];
+    int ld[4];
+    int M, N, accumulate;
+};
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumMultiArgs a) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x, ty = threadIdx.y, i = blockIdx.y, n = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (n < a.N) {
+        const float* x = a.X[i] + n;
+        for (int m = ty; m < a.M; m += 16) s += x[(size_t)m * a.ld[i]];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < a.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        a.out[i][n] = a.accumulate ? a.out[i][n] + t : t;
+    }
+}
+CPG_EXPORT int cpg_colsum_multi(int nmat, const void* const* X, const int* ld, int M, int N, void* const* out, int accumulate, void* stream) {
+    CPG_CHECK_ARG(nmat >= 1 && nmat <= 4 && X && ld && out && M > 0 && N > 0);
+    ColsumMultiArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < nmat; ++i) {
+        CPG_CHECK_ARG(X[i] && out[i] && ld[i] >= N);
+        a.X[i] = (const float*)X[i];
+        a.out[i] = (float*)out[i];
+        a.ld[i] = ld[i];
+    }
+    a.M = M; a.N = N; a.accumulate = accumulate;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(N, 64), nmat), dim3(64, 16), 0, (hipStream_t)stream, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- largest magnitude of a weight matrix, for the engines that split weights into f16 pairs (gemm_core.h: weight_exp_from_parts).
 // Block b takes rows b, b + WX_PARTS, ...; 16-byte loads where the rows allow them.  wx[b] = float bits of the block's maximum.
 __global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, int rows, int cols, int ld, int vec, int* __restrict__ wx) {

@@ -4,6 +4,7 @@
 // still obtain the single-device value.
 #include "gemm_core.h"
 #include "cpg_internal.h"
+#include "rng_core.h"
 
 #define RED_BLOCKS 256
 
@@ -94,6 +95,89 @@ CPG_EXPORT int cpg_recon_ce_loss_fwd(const int64_t* ids, const float* logits, in
     CPG_CHECK_ARG(ids && logits && out && workspace && B > 0 && T > 0 && V > 0);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(recon_ce_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, ids, logits, B, T, V, pad, workspace);
+    hipLaunchKernelGGL(recon_ce_final3_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, RED_BLOCKS, out);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// The trainer's form (round 6): cross-entropy of TIME-MAJOR logits [T B, V] (what the vocabulary projection writes: no transposition
+// to [B,T,V] and back) that also leaves the UNSCALED logit gradient softmax - onehot of every scored row (zeros on <pad> targets) -
+// the backward of the vocabulary projection multiplies it by gout / count on the way in (cpg_vocab_fc_bwd's g / count), so the
+// forward needs neither the count nor the upstream gradient.  Same arithmetic per row as recon_ce_partial_kernel / recon_ce_bwd_kernel.
+__global__ void recon_ce_tm_kernel(const int64_t* __restrict__ ids, const float* __restrict__ logits, int B, int T, int V, int pad,
+                                   float* __restrict__ part, float* __restrict__ dl) {
+    __shared__ float red[8];
+    float v[2] = {0.f, 0.f};
+    const int rows = B * T;
+    const bool v4 = V % 4 == 0 && V <= 32 && ((((uintptr_t)logits) | ((uintptr_t)dl)) & 15) == 0;
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < rows; row += RED_BLOCKS * 256) {
+        const int t = row / B, b = row - t * B;
+        const int tgt = (t + 1 < T) ? (int)ids[(size_t)b * T + t + 1] : pad;
+        float* d = dl + (size_t)row * V;
+        const float* l = logits + (size_t)row * V;
+        if (tgt == pad) {
+            if (v4)
+                for (int k = 0; k < V; k += 4) *reinterpret_cast<float4*>(d + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else
+                for (int k = 0; k < V; ++k) d[k] = 0.f;
+            continue;
+        }
+        if (v4) {
+            float x[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (4 * q < V) {
+                    const float4 w = *reinterpret_cast<const float4*>(l + 4 * q);
+                    x[4 * q] = w.x; x[4 * q + 1] = w.y; x[4 * q + 2] = w.z; x[4 * q + 3] = w.w;
+                }
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (k < V) m = fmaxf(m, x[k]);
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (k < V) se += expf(x[k] - m);
+            const float lse = m + logf(se);
+            float xt = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (k < V && k == tgt) xt = x[k];
+            v[0] += lse - xt;
+            v[1] += 1.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (4 * q < V) {
+                    float4 o;
+                    o.x = expf(x[4 * q] - lse) - (4 * q == tgt ? 1.f : 0.f);
+                    o.y = expf(x[4 * q + 1] - lse) - (4 * q + 1 == tgt ? 1.f : 0.f);
+                    o.z = expf(x[4 * q + 2] - lse) - (4 * q + 2 == tgt ? 1.f : 0.f);
+                    o.w = expf(x[4 * q + 3] - lse) - (4 * q + 3 == tgt ? 1.f : 0.f);
+                    *reinterpret_cast<float4*>(d + 4 * q) = o;
+                }
+            continue;
+        }
+        float m = -INFINITY;
+        for (int k = 0; k < V; ++k) m = fmaxf(m, l[k]);
+        float se = 0.f;
+        for (int k = 0; k < V; ++k) se += expf(l[k] - m);
+        const float lse = m + logf(se);
+        v[0] += lse - l[tgt];
+        v[1] += 1.f;
+        for (int k = 0; k < V; ++k) d[k] = expf(l[k] - lse) - (k == tgt ? 1.f : 0.f);
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = v[0];
+        part[blockIdx.x * 2 + 1] = v[1];
+    }
+}
+// out[0] = sum of NLL, out[1] = number of scored targets, out[2] = out[0] / max(out[1], 1); dl [T B, V] = softmax - onehot (unscaled)
+CPG_EXPORT int cpg_recon_ce_tm_fwd(const int64_t* ids, const float* logits_tm, int B, int T, int V, int pad, float* out, float* dl,
+                                   float* workspace, void* stream) {
+    CPG_CHECK_ARG(ids && logits_tm && out && dl && workspace && B > 0 && T > 0 && V > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(recon_ce_tm_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, ids, logits_tm, B, T, V, pad, workspace, dl);
     hipLaunchKernelGGL(recon_ce_final3_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, RED_BLOCKS, out);
     CPG_LAUNCH_CHECK();
     return 0;
@@ -284,6 +368,139 @@ CPG_EXPORT int cpg_latent_stats_bwd(const float* mu, const float* logvar, size_t
     CPG_CHECK_ARG(mu && logvar && dmu && dlogvar && n > 0 && B > 0);
     hipLaunchKernelGGL(latent_stats_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu,
                        logvar, n, 1.f / (float)B, g_kl, g_klmu, g_l1, dmu, dlogvar, accumulate);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ the latent block of a training step, fused
+// RNN_VAE.sample_z + sample_c_prior + GRUDecoder.init_hidden + the three analytic latent penalties (models/model.py:107-126,
+// models/decoder.py:53-54, losses.py:8-15, train_vae.py:33) as ONE elementwise launch (+ the 5-value final sum):
+//   eps ~ N(0,1) drawn here when not injected (the numbers cpg_rng_normal would have written: rng_core.h), c ~ Cat(.5,.5) likewise
+//   z = mu + exp(logvar / 2) eps  ->  z [B,Z] AND the decoder's initial state / constant input zc = [z ; c] [B, Z + C] (no torch.cat)
+//   partial sums of the five latent statistics (latent_stats_partial_kernel's) per block
+// and its backward as one launch: dmu, dlogvar from the gradients on z, on zc[:, :Z] and on the three penalties.
+struct LatentFwdArgs {
+    const float* mu; const float* lv;
+    const float* eps_in;            // [B,Z] or null: draw (seed, off_eps, base)
+    const float* c_in;              // [B,C] or null: draw one-hot rows of Bernoulli(p_one) (seed, off_c, base), C == 2
+    float* eps_out;                 // [B,Z] or null (kept for the backward pass when eps is drawn here)
+    float* z; float* zc; float* c_out;   // [B,Z], [B,Z+C], [B,C]
+    float* part;                    // [RED_BLOCKS][5]
+    int B, Z, C;
+    uint64_t seed, off_eps, off_c;
+    const uint64_t* base;
+    float p_one;
+};
+__global__ __launch_bounds__(256) void latent_fwd_kernel(LatentFwdArgs a) {
+    __shared__ float red[20];
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t n = (size_t)a.B * a.Z, nq = (n + 3) / 4;
+    const uint64_t base = a.base ? *a.base : 0;
+    const int ZC = a.Z + a.C;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (size_t)RED_BLOCKS * 256) {
+        float e4[4];
+        if (!a.eps_in) philox_normal4(a.seed, a.off_eps + base + q, e4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = 4 * q + k;
+            if (i >= n) break;
+            const float m = a.mu[i], l = a.lv[i];
+            const float ep = a.eps_in ? a.eps_in[i] : e4[k];
+            const float zz = m + expf(l * 0.5f) * ep;
+            const size_t b = i / a.Z;
+            const int j = (int)(i - b * a.Z);
+            a.z[i] = zz;
+            a.zc[b * ZC + j] = zz;
+            if (a.eps_out) a.eps_out[i] = ep;
+            const float ex = expf(l);
+            v[0] += 0.5f * (ex + m * m - 1.f - l);
+            v[1] += 0.5f * (ex - 1.f - l);
+            v[2] += fabsf(l);
+            v[3] += fabsf(m);
+            v[4] += l;
+        }
+    }
+    // the class block: rows of c, copied into zc[:, Z:]
+    if (a.c_in) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)a.B * a.C; i += (size_t)RED_BLOCKS * 256) {
+            const size_t b = i / a.C;
+            const int j = (int)(i - b * a.C);
+            const float cv = a.c_in[i];
+            a.zc[b * ZC + a.Z + j] = cv;
+            if (a.c_out) a.c_out[i] = cv;
+        }
+    } else if (a.C == 2) {
+        const size_t nb4 = ((size_t)a.B + 3) / 4;
+        for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < nb4; q += (size_t)RED_BLOCKS * 256) {
+            uint32_t r[4];
+            philox4x32(a.seed, a.off_c + base + q, 2u, r);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t b = 4 * q + k;
+                if (b >= (size_t)a.B) break;
+                const bool one = u01(r[k]) < a.p_one;
+                const float c0 = one ? 0.f : 1.f, c1 = one ? 1.f : 0.f;
+                a.zc[b * ZC + a.Z] = c0;
+                a.zc[b * ZC + a.Z + 1] = c1;
+                a.c_out[2 * b] = c0;
+                a.c_out[2 * b + 1] = c1;
+            }
+        }
+    }
+    block_sum<5>(v, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 5; ++k) a.part[blockIdx.x * 5 + k] = v[k];
+}
+// out[0..2] = the three penalties (sums / B), out[3..4] = sum |mu|, sum logvar (logged means)
+__global__ void latent_final_kernel(const float* part, float invB, float* out) {
+    __shared__ float red[20];
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += part[(size_t)i * 5 + k];
+    block_sum<5>(v, red);
+    if (threadIdx.x == 0) {
+        out[0] = v[0] * invB; out[1] = v[1] * invB; out[2] = v[2] * invB;
+        out[3] = v[3]; out[4] = v[4];
+    }
+}
+CPG_EXPORT size_t cpg_latent_fused_workspace(void) { return (size_t)RED_BLOCKS * 5 * sizeof(float); }
+CPG_EXPORT int cpg_latent_fused_fwd(const float* mu, const float* logvar, const float* eps_in, const float* c_in, int B, int Z, int C,
+                                    uint64_t seed, uint64_t off_eps, uint64_t off_c, const uint64_t* base, float p_one, float* eps_out,
+                                    float* z, float* zc, float* c_out, float* out5, float* workspace, void* stream) {
+    CPG_CHECK_ARG(mu && logvar && z && zc && out5 && workspace && B > 0 && Z > 0 && C >= 0 && (c_in || C == 0 || (C == 2 && c_out)));
+    LatentFwdArgs a{mu, logvar, eps_in, c_in, eps_out, z, zc, c_out, workspace, B, Z, C, seed, off_eps, off_c, base, p_one};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(RED_BLOCKS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(latent_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, 1.f / (float)B, out5);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+// dmu = dzt + g_kl mu / B ;  dlogvar = dzt eps exp(logvar / 2) / 2 + ((g_kl + g_klmu) (e^logvar - 1) / 2 + g_l1 sign(logvar)) / B
+// with dzt = dz + dzc[:, :Z] (either may be null); g_* device scalars or null.
+__global__ void latent_fused_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dzc, int ldzc, const float* __restrict__ mu,
+                                        const float* __restrict__ lv, const float* __restrict__ eps, int B, int Z, float invB,
+                                        const float* g_kl, const float* g_klmu, const float* g_l1, float* __restrict__ dmu,
+                                        float* __restrict__ dlv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * Z) return;
+    const float a = g_kl ? g_kl[0] : 0.f, b = g_klmu ? g_klmu[0] : 0.f, c = g_l1 ? g_l1[0] : 0.f;
+    const size_t row = i / Z;
+    const int j = (int)(i - row * Z);
+    float d = dz ? dz[i] : 0.f;
+    if (dzc) d += dzc[row * ldzc + j];
+    const float l = lv[i];
+    const float sgn = (l > 0.f) ? 1.f : ((l < 0.f) ? -1.f : 0.f);
+    dmu[i] = d + a * mu[i] * invB;
+    dlv[i] = d * eps[i] * 0.5f * expf(l * 0.5f) + ((a + b) * 0.5f * (expf(l) - 1.f) + c * sgn) * invB;
+}
+CPG_EXPORT int cpg_latent_fused_bwd(const float* dz, const float* dzc, int ldzc, const float* mu, const float* logvar, const float* eps,
+                                    int B, int Z, const float* g_kl, const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar,
+                                    void* stream) {
+    CPG_CHECK_ARG(mu && logvar && eps && dmu && dlogvar && B > 0 && Z > 0 && (!dzc || ldzc >= Z));
+    const size_t n = (size_t)B * Z;
+    hipLaunchKernelGGL(latent_fused_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz, dzc, ldzc, mu, logvar,
+                       eps, B, Z, 1.f / (float)B, g_kl, g_klmu, g_l1, dmu, dlogvar);
     CPG_LAUNCH_CHECK();
     return 0;
 }

@@ -8,44 +8,13 @@
 // step (cpg_counter_add_u64), so every replay draws fresh numbers.  These are NEW streams (the reference mixes torch and numpy generators); parity tests
 // inject the reference's captured draws instead.
 #include "cpg_internal.h"
-
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
-__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t ctr, uint32_t stream, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0u};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+#include "rng_core.h"
 
 __global__ void rng_normal_kernel(float* out, size_t n, uint64_t seed, uint64_t offset, const uint64_t* base) {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 outputs per thread
     if (q * 4 >= n) return;
-    uint32_t r[4];
-    philox4x32(seed, offset + (base ? *base : 0) + q, 0u, r);
     float v[4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float rad = sqrtf(-2.f * logf(u01(r[2 * h])));
-        const float ang = 6.283185307179586f * u01(r[2 * h + 1]);
-        v[2 * h] = rad * cosf(ang);
-        v[2 * h + 1] = rad * sinf(ang);
-    }
+    philox_normal4(seed, offset + (base ? *base : 0) + q, v);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (q * 4 + k < n) out[q * 4 + k] = v[k];

@@ -52,20 +52,30 @@ def logvar_l1(logvar):
 def latent_terms(mu, logvar):
     """(kl_gaussianprior, kl_gaussian_sharedmu, logvar_l1) of one (mu, logvar) pair from a single pass - what train_step uses;
     each equals the stand-alone function's value and gradient."""
+    fused = getattr(mu, '_cpg_latent', None)
+    if fused is not None and fused[0] is logvar:
+        return fused[1], fused[2], fused[3]      # the model's fused latent node (ops.LatentFn) has them: same sums, one backward launch
     return ops.LatentTermsFn.apply(mu, logvar, mu.size(0))
 
 
+def global_target_count(sequences):
+    """Data parallel: the GLOBAL number of non-PAD targets / world as a device scalar (the mean is over the global batch; the gradient
+    all-reduce is a SUM / world, so the local term is pre-scaled by world); None on a single rank (the kernel's own count)."""
+    if _dist["reduce"] is None:
+        return None
+    with torch.no_grad():
+        B, T = sequences.shape
+        tgt = torch.cat([sequences[:, 1:], torch.full((B, 1), ops.PAD_IDX, device=sequences.device)], 1)
+        count = (tgt != ops.PAD_IDX).sum().float().reshape(1)
+        _dist["reduce"](count)
+        return count / _dist["world"]
+
+
 def recon_dec(sequences, logits):
-    count = None
-    if _dist["reduce"] is not None:
-        # mean over the GLOBAL number of non-PAD targets; the gradient all-reduce is a SUM / world, so pre-scale by world
-        with torch.no_grad():
-            B, T = sequences.shape
-            tgt = torch.cat([sequences[:, 1:], torch.full((B, 1), ops.PAD_IDX, device=sequences.device)], 1)
-            count = (tgt != ops.PAD_IDX).sum().float().reshape(1)
-            _dist["reduce"](count)
-            count = count / _dist["world"]
-    return ops.ReconLossFn.apply(logits, sequences, count)
+    fused = getattr(logits, '_cpg_recon', None)
+    if fused is not None and fused[0] is sequences:
+        return fused[1]      # the decoder ended in ops.VocabReconFn for exactly these targets (train_vae.train_step): its loss
+    return ops.ReconLossFn.apply(logits, sequences, global_target_count(sequences))
 
 
 def wae_mmd_gaussianprior(z, method='full_kernel', z_prior=None, global_batch=False):

@@ -76,35 +76,45 @@ class GRUDecoder(nn.Module):
         # such positions are then fc(0) instead of the reference's values, so this is OFF for the model API and switched
         # on by the trainer (train_vae.train_step), which only consumes the loss.
         self.ragged = False
+        # ids [B,T] whose reconstruction loss the caller will ask for (losses.recon_dec on this forward's logits), or None: set by
+        # train_vae.train_step around its forward pass - the decoder then ends in ops.VocabReconFn
+        self.recon_targets = None
 
     def init_hidden(self, z, c):
         return torch.cat([z, c], dim=1)
 
     def _emb_w(self):
-        return ops.ZeroRowGradFn.apply(self.emb.weight, self.emb.padding_idx) if self.emb.padding_idx is not None \
-            else self.emb.weight
+        if self.emb.padding_idx is None:
+            return self.emb.weight
+        return ops.tag_emb(ops.ZeroRowGradFn.apply(self.emb.weight, self.emb.padding_idx), self.emb.weight, self.emb.padding_idx)
 
     def _tables(self, zc, emb_w=None):
         E = self.emb.weight.shape[1]
         w_ih = self.rnn.weight_ih_l0
         if emb_w is None:
             emb_w = self._emb_w()
-        tab = ops.LinearColsFn.apply(emb_w, w_ih, self.rnn.bias_ih_l0, 0, E)        # [V,3H]
+        leaf, pad = ops.emb_leaf(emb_w)
+        tab, = ops.TokenTablesFn.apply(emb_w, (0, E, leaf, pad), w_ih, self.rnn.bias_ih_l0)   # [V,3H]
         rowc = ops.LinearColsFn.apply(zc, w_ih, None, E, w_ih.shape[1])            # [B,3H]
         return tab, rowc
 
-    def forward(self, x, z, c, wd_mask=None, out_keep=None, emb_w=None):
+    def forward(self, x, z, c, wd_mask=None, out_keep=None, emb_w=None, zc=None):
         """Teacher forcing.  x ids [B,T]; returns logits [B,T,V].
         wd_mask uint8 [B,T] / out_keep uint8 [B,T,H] inject the two dropout masks (otherwise sampled here).
-        emb_w: the pad-masked embedding matrix shared with the step's other consumers (RNN_VAE.forward), or None."""
+        emb_w: the pad-masked embedding matrix shared with the step's other consumers (RNN_VAE.forward), or None.
+        zc: [z;c] when the caller has it already (ops.LatentFn writes it beside z), else formed here."""
         B, T = x.shape
-        zc = self.init_hidden(z, c)
+        if zc is None:
+            zc = self.init_hidden(z, c)
         if wd_mask is None:
             wd_mask = self.word_dropout.sample_mask(x)
         tok = ops.tokens_prepare(x, wd_mask)
         # gradient-bucket boundary: once the gradients of [z;c] and of the embedding rows the decoder reads are complete, every
         # gradient of the decoder's own parameters has been enqueued (cpg.optim starts their all-reduce there)
-        zc, emb_w = ops.grad_boundary('decoder', zc, self._emb_w() if emb_w is None else emb_w)
+        emb_w = self._emb_w() if emb_w is None else emb_w
+        leaf = ops.emb_leaf(emb_w)
+        zc, emb_w = ops.grad_boundary('decoder', zc, emb_w)
+        emb_w = ops.tag_emb(emb_w, *leaf)
         tab, rowc = self._tables(zc, emb_w)
         ragged = self.ragged and self.cell == 'gru' and self.layers == 1 and torch.is_grad_enabled()
         perm = inv = step_rows = None
@@ -156,6 +166,15 @@ class GRUDecoder(nn.Module):
             keep = self._sample_keep((T, B, self.h_dim), x.device)
             scale = 1.0 / (1.0 - self.p_out)
         fc = self.fc[1]
+        if self.recon_targets is not None and not ragged:
+            # the trainer's form (train_vae.train_step sets recon_targets = the batch): projection + cross-entropy as one node over the
+            # time-major rows; the returned logits are a [B,T,V] VIEW of them that carries the loss (losses.recon_dec picks it up)
+            import losses as _losses
+            loss, ltm = ops.VocabReconFn.apply(hs, keep, scale, fc.weight, fc.bias, self.recon_targets,
+                                               _losses.global_target_count(self.recon_targets))
+            logits = ltm.view(T, B, -1).transpose(0, 1)
+            logits._cpg_recon = (self.recon_targets, loss)
+            return logits
         logits_tm = ops.VocabFcFn.apply(hs, keep, scale, fc.weight, fc.bias).view(T, B, -1)
         if ragged:
             logits_tm = logits_tm.index_select(1, inv)                   # back to the caller's row order

@@ -73,11 +73,17 @@ class GRUEncoder(nn.Module):
                 if ops.planes_ok(T * Bq, 2 * self.h_dim, gates * self.h_dim):
                     with torch.no_grad():
                         ximg = ops.pair_rows(slabs[0][1:].reshape(T * Bq, -1), slabs[1][:T].reshape(T * Bq, -1))
-            for sfx, rev in self._dirs():
+            tabs = None
+            if l == 0 and tok is not None:
+                # [V,3H] per direction: W_ih emb[v] + b_ih for every token - both directions in one launch (ops.TokenTablesFn)
+                wb = [t for sfx, _ in self._dirs() for t in (self._w("weight_ih", l, sfx), self._w("bias_ih", l, sfx))]
+                leaf, pad = ops.emb_leaf(emb_weight)
+                tabs = ops.TokenTablesFn.apply(emb_weight, (0, emb_weight.shape[1], leaf, pad), *wb)
+            for d_, (sfx, rev) in enumerate(self._dirs()):
                 w_ih, b_ih = self._w("weight_ih", l, sfx), self._w("bias_ih", l, sfx)
                 tab = dense = None
-                if l == 0 and tok is not None:
-                    tab = ops.LinearFn.apply(emb_weight, w_ih, b_ih)  # [V,3H]: W_ih emb[v] + b_ih for every token
+                if tabs is not None:
+                    tab = tabs[d_]
                 elif l == 0:
                     B = dense_x.shape[1]
                     dense = ops.LinearFn.apply(dense_x.reshape(T * B, -1), w_ih, b_ih).view(T, B, -1)
@@ -119,11 +125,14 @@ class GRUEncoder(nn.Module):
         # final states of the top layer: forward slab slot T, reverse slab slot 0 (reference: cat(h[-2], h[-1]))
         if finals is None:
             finals = [slabs[0][T]] + ([slabs[1][0]] if self.biGRU else [])
-        h = torch.cat(finals, 1) if len(finals) > 1 else finals[0]
-        h = ops.grad_boundary('encoder_heads', h)   # gradient-bucket boundary: the two heads' gradients are final behind it
-        mu = ops.LinearFn.apply(h, self.q_mu.weight, self.q_mu.bias)
-        logvar = ops.LinearFn.apply(h, self.q_logvar.weight, self.q_logvar.bias)
-        return mu, logvar
+        # gradient-bucket boundary: the two heads' gradients are final behind it.  The heads read the two final states where they are
+        # (no torch.cat) and run as one grouped launch forward, three launches backward (ops.EncoderHeadsFn)
+        hf, hr = finals[0], (finals[1] if len(finals) > 1 else None)
+        if hr is not None:
+            hf, hr = ops.grad_boundary('encoder_heads', hf, hr)
+        else:
+            hf = ops.grad_boundary('encoder_heads', hf)
+        return ops.EncoderHeadsFn.apply(hf, hr, self.q_mu.weight, self.q_mu.bias, self.q_logvar.weight, self.q_logvar.bias)
 
     def forward_tokens(self, ids, emb_weight, enc_keep=None):
         """ids int64 [B,T]: fused path, W_ih emb[tok] is a V-row lookup table (never a [B,T,E] GEMM).

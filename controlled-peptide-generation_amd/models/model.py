@@ -62,6 +62,10 @@ class RNN_VAE(nn.Module):
             raise NotImplementedError('normalizing flows are dead code in the reference training path '
                                       '(models/model.py:173-177 raises) and are not provided')
         self.rng = None  # DeviceRng -> on-device Philox draws; None -> the reference's torch/numpy generators
+        # train_vae.train_step switches this on around its forward pass: fused latent / reconstruction nodes whose outputs are consumed
+        # through the losses.* functions only (same values and parameter gradients; intermediate tensors such as z no longer see every
+        # gradient path through autograd).  Off: every intermediate behaves exactly as in the reference's graph.
+        self.fused_train = False
 
     # ------------------------------------------------------------------ randomness
     def use_device_rng(self, seed):
@@ -94,7 +98,10 @@ class RNN_VAE(nn.Module):
 
     # ------------------------------------------------------------------ pieces of the forward pass
     def _emb_weight(self):
-        return ops.ZeroRowGradFn.apply(self.word_emb.weight, PAD_IDX)
+        """The embedding matrix as the step's graph sees it: row PAD gets no gradient (nn.Embedding(padding_idx), models/model.py:47).
+        The leaf behind it rides along (ops.emb_leaf): kernels that produce an embedding gradient inside FusedAdamClip.backward add it
+        straight into the parameter's gradient buffer, PAD row skipped."""
+        return ops.tag_emb(ops.ZeroRowGradFn.apply(self.word_emb.weight, PAD_IDX), self.word_emb.weight, PAD_IDX)
 
     def forward_encoder(self, inputs, emb_w=None, enc_keep=None):
         """ids [mbsize, seq_len] -> (mu, logvar);  soft inputs [mbsize, seq_len, n_vocab] go through soft_embed.
@@ -120,8 +127,8 @@ class RNN_VAE(nn.Module):
             return self.rng.onehot2(mbsize, 0.5, self.device)   # the draws of bernoulli((mbsize,), 0.5) as one-hot rows, one launch
         return torch.from_numpy(np.random.multinomial(1, [0.5, 0.5], mbsize).astype('float32')).to(self.device)
 
-    def forward_decoder(self, inputs, z, c, wd_mask=None, out_keep=None, emb_w=None):
-        return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep, emb_w=emb_w)
+    def forward_decoder(self, inputs, z, c, wd_mask=None, out_keep=None, emb_w=None, zc=None):
+        return self.decoder(inputs, z, c, wd_mask=wd_mask, out_keep=out_keep, emb_w=emb_w, zc=zc)
 
     def forward_classifier(self, inputs, emb_w=None):
         """Token inputs run the HIP path (token-table convolutions), differentiable like the reference's: with q_c='classifier'
@@ -140,23 +147,34 @@ class RNN_VAE(nn.Module):
         emb_w = self._emb_weight() if sequences.dim() == 2 else None
         mu, logvar = self.forward_encoder(sequences, emb_w, enc_keep=rnd.get('enc_keep'))
         assert mu.size(0) == logvar.size(0) == mbsize
-        if sample_z == 'max':
-            z = mu
-        else:
+        if sample_z != 'max':
             assert sample_z == 1, 'sample_z > 1 is not supported (reference: TODO)'
-            z = self.sample_z(mu, logvar, rnd.get('eps'))
+        c = None
         if 'c' in rnd:
             c = rnd['c']
         elif isinstance(q_c, torch.Tensor):
             c = torch.zeros(mbsize, 2, device=self.device)
             c.scatter_(1, q_c.unsqueeze(1), 1)
-        elif q_c == 'prior':
-            c = self.sample_c_prior(mbsize)
         elif q_c == 'classifier':
             c = torch.softmax(self.forward_classifier(sequences, emb_w), dim=1)
-        else:
+        elif q_c != 'prior':
             raise ValueError("q_c is not labels, prior, or classifier")
-        dec_logits = self.forward_decoder(sequences, z, c, wd_mask=rnd.get('wd_mask'), out_keep=rnd.get('out_mask'), emb_w=emb_w)
+        zc = None
+        fused = (self.fused_train and sample_z == 1 and (c is None or not c.requires_grad) and mu.is_cuda
+                 and (self.rng is not None or (rnd.get('eps') is not None and c is not None)))
+        if fused:
+            # the trainer's form (self.fused_train, set by train_vae.train_step): ONE node for reparameterisation + class prior + [z;c] +
+            # the analytic latent penalties (ops.LatentFn); losses.latent_terms finds the penalties on `mu` (same values as its own
+            # pass, one backward launch for all of them).  z then receives only the gradients of its direct consumers (the MMD terms);
+            # what arrives through the decoder's [z;c] goes to mu / logvar inside the node (z._cpg_zc carries that tensor).
+            z, zc, c, kl, klmu, l1, sums5 = ops.LatentFn.apply(mu, logvar, rnd.get('eps'), c, self.rng)
+            mu._cpg_latent = (logvar, kl, klmu, l1, sums5)
+            z._cpg_zc = zc
+        else:
+            z = mu if sample_z == 'max' else self.sample_z(mu, logvar, rnd.get('eps'))
+            if c is None:
+                c = self.sample_c_prior(mbsize)
+        dec_logits = self.forward_decoder(sequences, z, c, wd_mask=rnd.get('wd_mask'), out_keep=rnd.get('out_mask'), emb_w=emb_w, zc=zc)
         return (mu, logvar), (z, c), dec_logits
 
     # ------------------------------------------------------------------ generation

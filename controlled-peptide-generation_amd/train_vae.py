@@ -39,12 +39,14 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None), 
     what a captured step needs (GraphedTrainStep rewrites it between replays)."""
     beta = utils.anneal(cfgv.beta, it)
     # the trainer consumes the logits only through recon_dec (pad targets ignored): the decoder may skip dead rows
-    ragged_before = model.decoder.ragged
+    ragged_before, fused_before = model.decoder.ragged, model.fused_train
     model.decoder.ragged = bool(cfg.hw.ragged_decoder)
+    model.fused_train = True     # the trainer consumes the step's intermediates through losses.* only: fused latent / reconstruction nodes
+    model.decoder.recon_targets = text
     try:
         (z_mu, z_logvar), (z, c), dec_logits = model(text, q_c='prior', sample_z=1, rnd=rnd)
     finally:
-        model.decoder.ragged = ragged_before
+        model.decoder.ragged, model.fused_train, model.decoder.recon_targets = ragged_before, fused_before, None
     recon_loss = losses.recon_dec(text, dec_logits)
     kl_loss, z_logvar_KL_penalty, z_logvar_L1 = losses.latent_terms(z_mu, z_logvar)
     # the full-kernel MMD couples every pair of rows of the GLOBAL batch: as the regulariser it is evaluated on the all-gathered
@@ -59,9 +61,12 @@ def train_step(cfgv, model, trainer, text, it, rnd=None, z_priors=(None, None), 
     loss = WeightedSumFn.apply(weights, recon_loss, z_regu_loss, z_logvar_L1, z_logvar_KL_penalty)
     trainer.zero_grad()
     trainer.backward(loss)
+    if model.rng is not None:
+        trainer.attach_rng(model.rng)   # step() advances the Philox base together with its own iteration counter: one launch
     trainer.step()
     if model.rng is not None:
-        model.rng.end_step()     # the device-side Philox base moves past this step's draws; host offsets restart at 0
+        model.rng.end_step()     # the device-side Philox base moves past this step's draws; host offsets restart at 0 (a no-op
+        #                          when step() has already done it)
     return dict(z_mu=z_mu, z_logvar=z_logvar, z_logvar_L1=z_logvar_L1, z_logvar_KL_penalty=z_logvar_KL_penalty, L_vae=loss,
                 L_vae_recon=recon_loss, L_vae_kl=kl_loss, L_wae_mmd=wae_mmd_loss, L_wae_mmdrf=wae_mmdrf_loss, beta=beta)
 

@@ -69,6 +69,34 @@ CPG_API int cpg_weight_exp(const float* w, int rows, int cols, int ld, void* wx,
  * the weights' range is covered by wx = cpg_weight_exp(W) (null: exact-f32 engine). */
 CPG_API int cpg_linear_fwd_pairs(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy, int M,
                                  int N, int K, int accumulate, const void* wx, void* stream);
+/* ---- grouped small products (round 6): up to 6 independent nn.Linear-shaped problems of ONE form in one launch (a flat grid over all
+ * their tiles) - the token tables, the two encoder heads (models/encoder.py:35-36,50-51) and their gradients each fill a fraction of the
+ * chip when launched alone.  A problem may chain two (A, B, K) segments into the same accumulators (an input that is the concatenation
+ * of two tensors needs no cat; dX = dY1 W1 + dY2 W2 is one product) and send result columns >= n_split to a second destination (the
+ * gradient of a concatenation needs no slicing copies).  form: 0 = NT  C[M,N] (+)= sum_s A_s[M,K_s] B_s[N,K_s]^T (+ bias);
+ * 1 = NN  C (+)= sum_s A_s[M,K_s] B_s[K_s,N] (+ bias);  2 = TN  C (+)= sum_s A_s[K_s,M]^T B_s[K_s,N] (no bias).  Same engines and
+ * sums as cpg_linear_fwd / _bwd_input / _bwd_weight.  probs: nprob records of cpg_gemm_group_prob_bytes() bytes each. */
+typedef struct CpgGemmProb {
+    const float* A[2];
+    const float* B[2];
+    int lda[2], ldb[2], K[2];   /* K[1] = 0: one segment */
+    int M, N;
+    float* C;
+    float* C2;                  /* optional: columns >= n_split are written to C2[:, col - n_split] */
+    int ldc, ldc2, n_split;
+    int accumulate;
+    const float* bias;          /* [N], forms 0 / 1, or null */
+    const void* reserved;       /* null */
+} CpgGemmProb;
+CPG_API int cpg_gemm_group_prob_bytes(void);
+CPG_API int cpg_gemm_group(int form, int nprob, const void* probs, void* stream);
+/* Backward of n <= 4 token tables tab_i = emb W_i^T + b_i beside the grouped weight-gradient launch, ONE launch: demb [V, lde] (+)= sum_i
+ * dtab_i W_i (row skip_row untouched / zero: nn.Embedding(padding_idx), models/model.py:47), db_i [G] (+)= column sums of dtab_i.
+ * dtab / W / db: HOST arrays of n device pointers (W_i: the [G, E] column block of W_ih the embedding multiplies, row stride ldw[i]). */
+CPG_API int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* dtab, const void* const* W, const int* ldw, float* demb,
+                                 int lde, int accumulate_emb, int skip_row, void* const* db, int accumulate_db, void* stream);
+/* out_i[N] (+)= column sums of X_i [M, N] (row stride ld[i]) for nmat <= 4 matrices in one single-stage launch (X / ld / out: HOST arrays) */
+CPG_API int cpg_colsum_multi(int nmat, const void* const* X, const int* ld, int M, int N, void* const* out, int accumulate, void* stream);
 /* dX[M,K] (+)= dY[M,N] W[N,K] */
 CPG_API int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,
                                  int K, int accumulate, void* stream);
@@ -369,9 +397,17 @@ CPG_API int cpg_lstm_dgi_reduce_ap(int T, int B, int H, const void* ap, const in
 CPG_API int cpg_vocab_fc_fwd(const float* hs, const uint8_t* keep, float scale, const float* w, const float* b,
                              float* logits, int R, int H, int V, void* stream);
 CPG_API size_t cpg_vocab_fc_bwd_workspace(int R, int H, int V);
+/* g / count (optional device scalars): dlogits is UNSCALED (cpg_recon_ce_tm_fwd's softmax - onehot) and enters times
+ * g[0] / max(count[0], 1) (count null: times g[0]) - the trainer's form, in which neither the target count nor the upstream gradient is
+ * known when the forward pass writes dlogits. */
 CPG_API int cpg_vocab_fc_bwd(const float* dlogits, const float* hs, const uint8_t* keep, float scale, const float* w,
-                             float* dhs, float* dw, float* db, int R, int H, int V, int accumulate, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             float* dhs, float* dw, float* db, int R, int H, int V, int accumulate, const float* g,
+                             const float* count, void* workspace, size_t workspace_bytes, void* stream);
+/* losses.recon_dec (losses.py:18-31) on TIME-MAJOR logits [T B, V] (as the vocabulary projection writes them): out[0] = sum of NLL over
+ * the non-<pad> targets, out[1] = their number, out[2] = out[0] / max(out[1], 1); dl [T B, V] = softmax - onehot of every scored row
+ * (zeros elsewhere), UNSCALED: the backward of the projection applies gout / count (cpg_vocab_fc_bwd).  workspace: 512 floats. */
+CPG_API int cpg_recon_ce_tm_fwd(const int64_t* ids, const float* logits_tm, int B, int T, int V, int pad, float* out, float* dl,
+                                float* workspace, void* stream);
 
 /* ---- decoding: RNN_VAE.sample_G, models/model.py:225-385; models/Beam.py ----------------------------------------- */
 /* greedy: tok = argmax (first max), finished rows emit <pad>, rows that emit <eos> become finished; writes column `col`
@@ -453,6 +489,21 @@ CPG_API int cpg_latent_stats_fwd(const float* mu, const float* logvar, size_t n,
 CPG_API int cpg_latent_stats_bwd(const float* mu, const float* logvar, size_t n, int B, const float* g_kl,
                                  const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar, int accumulate,
                                  void* stream);
+/* The latent block of a training step, fused (round 6): RNN_VAE.sample_z + sample_c_prior + GRUDecoder.init_hidden + the three analytic
+ * latent penalties (models/model.py:107-126, models/decoder.py:53-54, losses.py:8-15, train_vae.py:33) as one elementwise launch + its
+ * 5-value final sum.  eps_in / c_in (optional): injected draws; null = drawn here from the counter streams (seed, off_eps / off_c, base)
+ * - the numbers cpg_rng_normal / cpg_rng_onehot2 write for the same (seed, offset); C = 2 then.  Outputs: z [B,Z]; zc = [z ; c]
+ * [B, Z + C] (the decoder's initial state and constant input: no concatenation launch); c_out [B,C]; eps_out [B,Z] (optional: what the
+ * backward needs when eps was drawn here); out5 = (kl, kl_sharedmu, logvar_L1 - each / B -, sum |mu|, sum logvar).
+ * workspace: cpg_latent_fused_workspace() bytes.  Backward: dmu, dlogvar from the gradients on z (dz), on zc (dzc, row stride ldzc;
+ * its first Z columns) and on the three penalties (device scalars; any of these may be null). */
+CPG_API size_t cpg_latent_fused_workspace(void);
+CPG_API int cpg_latent_fused_fwd(const float* mu, const float* logvar, const float* eps_in, const float* c_in, int B, int Z, int C,
+                                 uint64_t seed, uint64_t off_eps, uint64_t off_c, const uint64_t* base, float p_one, float* eps_out,
+                                 float* z, float* zc, float* c_out, float* out5, float* workspace, void* stream);
+CPG_API int cpg_latent_fused_bwd(const float* dz, const float* dzc, int ldzc, const float* mu, const float* logvar, const float* eps,
+                                 int B, int Z, const float* g_kl, const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar,
+                                 void* stream);
 /* mmd_rf, losses.py:59-93: raw = z @ rf_w by cpg_matmul_nn; sums[R] = sum_b cos(raw/sigma + rf_b)*sqrt(2/R) */
 CPG_API int cpg_rf_feature_sums(const float* raw, const float* rf_b, int Bn, int R, float sigma, float* sums,
                                 float* workspace, size_t workspace_bytes, void* stream);
@@ -476,6 +527,20 @@ CPG_API int cpg_sumsq(const float* x, size_t n, float mult, int accumulate, floa
 CPG_API int cpg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                           float eps, int step, const float* sumsq, float max_norm, int coef_pow, float gscale,
                           const int32_t* iter, int step_mult, void* stream);
+/* One-launch forms (round 6): the whole flat buffer's clipped-norm partials (cpg_sumsq_segs: SUMSQ partial sums of w_i g_i^2 into
+ * `workspace`, w_i = the multiplicity of element i's parameter) and the whole Adam iteration (cpg_adam_step_segs: every block reduces
+ * the partials in the same order, then updates its elements; an element of a parameter listed m times takes m consecutive Adam steps
+ * with its gradient scaled by coef^m - SURVEY F6).  dup_off / dup_len: the PADDED flat-buffer segments (multiples of 4 elements;
+ * padding holds zero gradients) of the ndup <= 2 parameters listed dup_mult <= 4 (the same for all) times.  iter: device int32, the
+ * completed iterations (step numbers are formed from it; the caller advances it afterwards: cpg_step_counters_add). */
+CPG_API int cpg_sumsq_segs(const float* g, size_t n, int ndup, const unsigned long long* dup_off, const unsigned long long* dup_len,
+                           const int* dup_mult, float* workspace, void* stream);
+CPG_API int cpg_adam_step_segs(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                               const float* partials /* or null: no clipping */, float* sumsq_out /* optional: sum of squares */,
+                               float max_norm, float gscale, const int32_t* iter, int ndup, const unsigned long long* dup_off,
+                               const unsigned long long* dup_len, const int* dup_mult, void* stream);
+/* *rng_base += rng_by ; *iter += iter_by (either pointer may be null): the device-side counters a training step advances, one launch */
+CPG_API int cpg_step_counters_add(uint64_t* rng_base, uint64_t rng_by, int32_t* iter, int32_t iter_by, void* stream);
 
 /* ---- CLaSS sampler: density_modeling.py:43-60,79-80 (sklearn GaussianMixture.sample / LogisticRegression) ---------- */
 CPG_API int cpg_gmm_sample(const double* means, const double* covars, const int32_t* comp, const double* normals, int n,

@@ -319,8 +319,9 @@ def test_wgrad_hh_on_f16_pairs_vs_split_engine(B, H, T, reverse):
 def test_backward_f16_pair_step_edge_values():
     """Edge values through the f16-pair backward step: all-zero gradients (every group takes the all-zero path: results exactly
     zero, nothing read from the unwritten planes), a NaN and an infinity in the incoming gradient (they reach dh0 / dG: loud, as
-    with the exact step), and a recurrent weight beyond the f16-pair image's range (|w| >= 256 at the fixed 2^8 scale, csrc/pair_engine.h:
-    documented to overflow to infinity - the gradients become non-finite instead of silently wrong)."""
+    with the exact step), and recurrent weights beyond the range of rounds 4-5's fixed 2^8 image scale (|w| >= 256 overflowed the f16
+    high half): the image's power of two now follows the matrix' largest magnitude (csrc/gemm_core.h: weight_exp_from_parts), so the
+    step stays finite and agrees with the exact-f32 step."""
     from cpg import ops
     B, H, T = 256, 128, 5
     d = _inputs(B, H, T, 24, seed=77)
@@ -334,11 +335,16 @@ def test_backward_f16_pair_step_edge_values():
             dG, dh0 = _bwd(d, B, H, T, False, hs, gates, x, last, pair=True)
             assert not torch.isfinite(dh0[3]).all() and not torch.isfinite(dG[0, 3]).all()
             assert torch.isfinite(dh0[4:]).all()          # other rows are independent recurrences
-        d2 = dict(d)
-        d2["w_hh"] = d["w_hh"].clone()
-        d2["w_hh"][7, 9] = 300.0
-        dG, dh0 = _bwd(d2, B, H, T, False, hs, gates, dhs, last, pair=True)
-        assert not torch.isfinite(dh0).all()
+        for big in (300.0, -7.0e4, 2.0e6):
+            d2 = dict(d)
+            d2["w_hh"] = d["w_hh"].clone()
+            d2["w_hh"][7, 9] = big
+            d2["w_hh"][200, 100] = -big
+            dG, dh0 = _bwd(d2, B, H, T, False, hs, gates, dhs, last, pair=True)
+            dG_x, dh0_x = _bwd(d2, B, H, T, False, hs, gates, dhs, last, pair=False)
+            assert torch.isfinite(dh0).all() and torch.isfinite(dG).all()
+            scale = dh0_x.abs().amax(1, keepdim=True).clamp_min(1e-30)
+            assert ((dh0 - dh0_x).abs() / scale).max().item() < 1e-5, big
 
 
 def ctypes_name(kind, B, H, ndir):

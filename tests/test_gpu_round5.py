@@ -466,7 +466,7 @@ def test_vocab_fc_backward_streaming_form_vs_f64(R, H, V, masked):
         dw, db = dw0.to(dev), db0.to(dev)
         ws = ops.workspace(ops.query("cpg_vocab_fc_bwd_workspace", R, H, V), dev)
         ops.call("cpg_vocab_fc_bwd", ops._p(dl_d), ops._p(hs_d), ops._p(keep_d), float(scale), ops._p(w_d), ops._p(dhs), ops._p(dw), ops._p(db),
-                 R, H, V, accumulate, ops._p(ws), ws.numel(), ops._stream())
+                 R, H, V, accumulate, None, None, ops._p(ws), ws.numel(), ops._stream())
         torch.cuda.synchronize()
         dhs_c = dhs.cpu().double()
         assert torch.isfinite(dhs_c).all()

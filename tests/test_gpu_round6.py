@@ -187,3 +187,233 @@ def test_class_round_at_config_b_width_131072_rows(mode):
     w = min(ref_letters.shape[1], got_letters.shape[1])
     assert np.array_equal(ref_letters.numpy()[:, :w], got_letters[:, :w])
     assert len(set(got_n.tolist())) >= 3
+
+
+# ------------------------------------------------------------------------------------------------ round-6 launch fusions
+@pytest.mark.parametrize("form", ["NT", "NN", "TN"])
+def test_gemm_group_vs_f64(form):
+    """cpg_gemm_group: several problems of one form in one launch, chained segments, split destinations, bias, accumulation, widths that
+    are no multiple of anything (z_dim = 510) - against float64 products of the same f32 inputs."""
+    from cpg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    F = {"NT": ops.NT, "NN": ops.NN, "TN": ops.TN}[form]
+    probs, checks = [], []
+    shapes = [(2048, 510, 512, 512), (24, 1536, 150, 0), (300, 70, 33, 96), (2048, 1024, 510, 510)]
+    for pi, (M, N, K0, K1) in enumerate(shapes):
+        segs, ref = [], torch.zeros(M, N, dtype=torch.float64)
+        for K in (K0, K1):
+            if K == 0:
+                continue
+            if form == "NT":
+                A, Bm = rn(M, K), rn(N, K)
+                ref += A.double().cpu() @ Bm.double().cpu().T
+                segs.append((A, K, Bm, K, K))
+            elif form == "NN":
+                A, Bm = rn(M, K), rn(K, N)
+                ref += A.double().cpu() @ Bm.double().cpu()
+                segs.append((A, K, Bm, N, K))
+            else:
+                A, Bm = rn(K, M), rn(K, N)
+                ref += A.double().cpu().T @ Bm.double().cpu()
+                segs.append((A, M, Bm, N, K))
+        bias = rn(N) if form != "TN" and pi % 2 == 0 else None
+        acc = pi == 2
+        split = pi == 3
+        C = rn(M, N if not split else 512) if acc or split else torch.full((M, N), float("nan"), device=dev)
+        C2 = torch.full((M, N - 512), float("nan"), device=dev) if split else None
+        if split:
+            C = torch.full((M, 512), float("nan"), device=dev)
+        c0 = C.clone()
+        if bias is not None:
+            ref += bias.double().cpu()[None, :]
+        if acc:
+            ref += c0.double().cpu()
+        probs.append(ops.gemm_prob(segs, C, M, N, bias=bias, accumulate=acc, C2=C2, n_split=512 if split else 0))
+        checks.append((C, C2, ref, sum(s[4] for s in segs)))
+    ops.gemm_group(F, probs)
+    torch.cuda.synchronize()
+    for C, C2, ref, K in checks:
+        got = C.double().cpu() if C2 is None else torch.cat([C.double().cpu(), C2.double().cpu()], 1)
+        assert torch.isfinite(got).all()
+        tol = (3e-6 if form != "TN" else 2e-5) * (K ** 0.5) * max(1.0, ref.abs().max().item() / (K ** 0.5))
+        assert (got - ref).abs().max().item() < tol, ((got - ref).abs().max().item(), tol)
+
+
+def _grads(loss, params):
+    gs = torch.autograd.grad(loss, params, allow_unused=True)
+    return [None if g is None else g.detach().clone() for g in gs]
+
+
+def test_token_tables_and_heads_fns_vs_linear_fns():
+    """ops.TokenTablesFn / ops.EncoderHeadsFn (grouped launches) against the one-product-per-launch Functions they replace (LinearFn /
+    LinearColsFn + torch.cat): values and every gradient, through plain autograd AND with the direct accumulation of
+    FusedAdamClip.backward (gradients added straight into existing .grad buffers, embedding row PAD skipped)."""
+    from cpg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(21)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev).requires_grad_()
+    V, E, H, Z, B = 24, 150, 96, 70, 200
+    emb = rn(V, E)
+    w_f, b_f, w_r, b_r = rn(3 * H, E), rn(3 * H), rn(3 * H, E), rn(3 * H)
+    w_d, b_d = rn(3 * H, E + Z), rn(3 * H)
+    up = [torch.randn(V, 3 * H, generator=g).to(dev) for _ in range(3)]
+
+    def tables(fused):
+        ew = ops.ZeroRowGradFn.apply(emb, 1)
+        if fused:
+            tf, tr = ops.TokenTablesFn.apply(ew, (0, E, None, None), w_f, b_f, w_r, b_r)
+            td, = ops.TokenTablesFn.apply(ew, (0, E, None, None), w_d, b_d)
+        else:
+            tf, tr = ops.LinearFn.apply(ew, w_f, b_f), ops.LinearFn.apply(ew, w_r, b_r)
+            td = ops.LinearColsFn.apply(ew, w_d, b_d, 0, E)
+        return (tf, tr, td), sum((t * u).sum() for t, u in zip((tf, tr, td), up))
+    P = [emb, w_f, b_f, w_r, b_r, w_d, b_d]
+    (ta, la), (tb, lb) = tables(True), tables(False)
+    for x, y in zip(ta, tb):
+        assert torch.allclose(x, y, atol=2e-5, rtol=0)
+    for ga, gb in zip(_grads(la, P), _grads(lb, P)):
+        assert torch.allclose(ga, gb, atol=2e-5 * max(1.0, gb.abs().max().item()), rtol=0)
+    assert float(_grads(la, [emb])[0][1].abs().max()) == 0.0     # row PAD of the embedding
+    # heads
+    hf, hr = rn(B, H), rn(B, H)
+    wm, bm, wl, bl = rn(Z, 2 * H), rn(Z), rn(Z, 2 * H), rn(Z)
+    um, ul = torch.randn(B, Z, generator=g).to(dev), torch.randn(B, Z, generator=g).to(dev)
+
+    def heads(fused):
+        if fused:
+            mu, lv = ops.EncoderHeadsFn.apply(hf, hr, wm, bm, wl, bl)
+        else:
+            h = torch.cat([hf, hr], 1)
+            mu, lv = ops.LinearFn.apply(h, wm, bm), ops.LinearFn.apply(h, wl, bl)
+        return (mu, lv), (mu * um).sum() + (lv * ul).sum()
+    Ph = [hf, hr, wm, bm, wl, bl]
+    (ha, la), (hb, lb) = heads(True), heads(False)
+    for x, y in zip(ha, hb):
+        assert torch.allclose(x, y, atol=3e-5, rtol=0)
+    for ga, gb in zip(_grads(la, Ph), _grads(lb, Ph)):
+        assert torch.allclose(ga, gb, atol=3e-5 * max(1.0, gb.abs().max().item()), rtol=0)
+    # direct accumulation (inside backward_scope): existing .grad buffers receive the sums, the pad row of the embedding stays untouched
+    for prm in P + Ph:
+        prm.grad = torch.full_like(prm, 0.25)
+    ew = ops.tag_emb(ops.ZeroRowGradFn.apply(emb, 1), emb, 1)
+    tf, tr = ops.TokenTablesFn.apply(ew, (0, E, emb, 1), w_f, b_f, w_r, b_r)
+    td, = ops.TokenTablesFn.apply(ew, (0, E, emb, 1), w_d, b_d)
+    mu, lv = ops.EncoderHeadsFn.apply(hf, hr, wm, bm, wl, bl)
+    loss = sum((t * u).sum() for t, u in zip((tf, tr, td), up)) + (mu * um).sum() + (lv * ul).sum()
+    want = _grads(tables(False)[1] + heads(False)[1], P + Ph)
+    with ops.backward_scope():
+        loss.backward()
+    torch.cuda.synchronize()
+    for prm, w in zip(P + Ph, want):
+        assert torch.allclose(prm.grad - 0.25, w, atol=4e-5 * max(1.0, w.abs().max().item()), rtol=0)
+    assert bool((emb.grad[1] == 0.25).all())
+
+
+def test_latent_fn_vs_unfused_and_stream_equivalence():
+    """ops.LatentFn (reparameterisation + class prior + [z;c] + the three analytic penalties in one node) against ReparamFn /
+    LatentTermsFn / torch.cat with injected draws - values and gradients of mu, logvar - and, with the draws made INSIDE the kernel,
+    against DeviceRng.normal / onehot2 of the same stream position (bit-identical eps and c)."""
+    from cpg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(31)
+    B, Z = 300, 510
+    mu = (torch.randn(B, Z, generator=g) * 0.5).to(dev).requires_grad_()
+    lv = (torch.randn(B, Z, generator=g) * 0.5).to(dev).requires_grad_()
+    eps = torch.randn(B, Z, generator=g).to(dev)
+    c = torch.zeros(B, 2, device=dev)
+    c[torch.arange(B), torch.randint(0, 2, (B,), generator=g)] = 1
+    uz, uzc = torch.randn(B, Z, generator=g).to(dev), torch.randn(B, Z + 2, generator=g).to(dev)
+    wts = (0.7, 1e-3, 0.1)
+    z, zc, c2, kl, klmu, l1, s5 = ops.LatentFn.apply(mu, lv, eps, c, None)
+    la = (z * uz).sum() + (zc * uzc).sum() + wts[0] * kl + wts[1] * klmu + wts[2] * l1
+    zb = ops.ReparamFn.apply(mu, lv, eps)
+    zcb = torch.cat([zb, c], 1)
+    klb, klmub, l1b = ops.LatentTermsFn.apply(mu, lv, B)
+    lb = (zb * uz).sum() + (zcb * uzc).sum() + wts[0] * klb + wts[1] * klmub + wts[2] * l1b
+    assert torch.equal(z, zb) and torch.equal(zc, zcb) and torch.equal(c2, c)
+    for a, b in ((kl, klb), (klmu, klmub), (l1, l1b)):
+        assert abs(a.item() - b.item()) < 1e-5 * max(1.0, abs(b.item()))
+    for ga, gb in zip(_grads(la, [mu, lv]), _grads(lb, [mu, lv])):
+        assert torch.allclose(ga, gb, atol=1e-6 * max(1.0, gb.abs().max().item()), rtol=0)
+    r1, r2 = ops.DeviceRng(77), ops.DeviceRng(77)
+    for rr in (r1, r2):
+        rr.normal((5,), dev)       # both streams stand at the same, non-zero position
+    with torch.no_grad():
+        z, zc, cc, *_ = ops.LatentFn.apply(mu.detach(), lv.detach(), None, None, r1)
+        e2 = r2.normal((B, Z), dev)
+        c_ref = r2.onehot2(B, 0.5, dev)
+        assert torch.equal(z, ops.ReparamFn.apply(mu.detach(), lv.detach(), e2)) and torch.equal(cc, c_ref)
+        assert torch.equal(zc, torch.cat([z, c_ref], 1)) and r1.offset == r2.offset
+
+
+@pytest.mark.parametrize("B,He,Z,T", [(2048, 512, 510, 25), (32, 80, 100, 25)], ids=["config-B", "config-A"])
+def test_fused_train_forward_vs_oracle(B, He, Z, T):
+    """The trainer's forward (model.fused_train + decoder.recon_targets, what train_vae.train_step runs: ops.LatentFn, ops.VocabReconFn,
+    the grouped tables / heads) against the oracle: loss terms 1e-4 and EVERY parameter gradient at 2e-6 + 1e-4 max|g| - at configs[1]
+    dimensions and at the reference's defaults.  /root/reference/train_vae.py:24-42."""
+    import losses
+    import test_gpu_tiles as tt
+    from cpg.ops import WeightedSumFn
+    from oracle import wae
+    m, P, ids, rnd = tt._random_case(B, T, 24, Z, He, 1, seed=7 + B)
+    set_losses_cfg()
+    beta, lam_l1, lam_kl = 1.5, 0.1, 1e-3
+    terms, G, aux = wae.train_loss_and_grads(P, ids, rnd, beta, lam_l1, lam_kl, "mmdrf")
+    losses.rf.clear()
+    losses.rf['gaussian'] = (cu(rnd["rf_w"]), cu(rnd["rf_b"]))
+    idt = cu(ids)
+    rc = dict(eps=cu(rnd["eps"]), c=cu(rnd["c"]), wd_mask=cu(rnd["wd_mask"]), out_mask=cu(rnd["out_mask"]))
+    m.fused_train, m.decoder.recon_targets = True, idt
+    try:
+        (mu, lv), (z, c), logits = m(idt, q_c='prior', sample_z=1, rnd=rc)
+    finally:
+        m.fused_train, m.decoder.recon_targets = False, None
+    assert hasattr(logits, "_cpg_recon") and hasattr(mu, "_cpg_latent")
+    recon = losses.recon_dec(idt, logits)
+    kl, klmu, l1 = losses.latent_terms(mu, lv)
+    mmdrf = losses.wae_mmd_gaussianprior(z, method='rf', z_prior=cu(rnd["z_prior_rf"]))
+    loss = WeightedSumFn.apply((1.0, beta, lam_l1, lam_kl), recon, mmdrf, l1, klmu)
+    loss.backward()
+    torch.cuda.synchronize()
+    slack = {}
+    if lam_l1 > 0:
+        tt._l1_kink_correction(G, aux, lv.detach().cpu().numpy(), P, lam_l1, slack, "fused")
+    for name, got in (("recon", recon), ("kl", kl), ("mmdrf", mmdrf), ("klmu", klmu), ("l1", l1), ("total", loss)):
+        ref = float(terms[name])
+        assert abs(got.item() - ref) < 1e-4 * max(1.0, abs(ref)), (name, got.item(), ref)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), aux["logits"], atol=1e-4, rtol=0)
+    for k, prm in m.named_parameters():
+        if k.startswith("classifier") or k == "decoder.emb.weight":
+            continue
+        ref, got = G[k], prm.grad.cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=2e-6 + 1e-4 * np.abs(ref).max() + slack.get("g." + k, 0.0), rtol=0, err_msg=k)
+
+
+def test_fused_optimizer_step_matches_the_per_segment_launches():
+    """FusedAdamClip.step in its two-launch form (cpg_sumsq_segs + cpg_adam_step_segs, csrc/optim.hip) against the per-segment launches
+    it replaces, on a model with the reference's duplicate embedding entry, clip active: parameters after five steps agree to
+    float rounding of the norm's summation order; the iteration counter and the Philox base advance together."""
+    import copy
+    import test_gpu_tiles as tt
+    from cpg.optim import FusedAdamClip
+    m, P, ids, rnd = tt._random_case(64, 25, 24, 100, 80, 1, seed=5)
+    m2 = copy.deepcopy(m)
+    outs = []
+    for mod, fused in ((m, True), (m2, False)):
+        opt = FusedAdamClip(mod.vae_params(), lr=1e-3, max_norm=0.05)
+        assert opt._fused_ok and opt._ndup == 1
+        opt._fused_ok = fused
+        g = torch.Generator().manual_seed(3)
+        for it in range(5):
+            opt.zero_grad()
+            for prm in opt.order:
+                prm.grad.copy_(torch.randn(prm.shape, generator=g).to(prm.device) * 0.01)
+            opt.step()
+        torch.cuda.synchronize()
+        outs.append(([prm.detach().clone() for prm in opt.order], opt.grad_norm().item(), int(opt.iter_dev.item())))
+    (pa, na, ia), (pb, nb, ib) = outs
+    assert ia == ib == 5 and abs(na - nb) < 1e-6 * nb
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() < 2e-7
