@@ -321,6 +321,9 @@ class GradBoundaryFn(Function):
     @staticmethod
     def forward(ctx, tag, *ts):
         ctx.tag = tag
+        # an output nobody differentiates (the embedding view when its consumers add their gradient straight into the parameter's
+        # buffer) stays an undefined gradient: materialised zeros would travel on as a fill, an index_fill and an add per step
+        ctx.set_materialize_grads(False)
         return tuple(t.view_as(t) for t in ts)
 
     @staticmethod
@@ -474,6 +477,7 @@ class TokenTablesFn(Function):
         n = len(wb) // 2
         ws, bs = wb[0::2], wb[1::2]
         c0, c1, leaf, pad_row = meta
+        ctx.set_materialize_grads(False)
         embc, lde = _ld(emb)
         V, E = embc.shape
         assert c1 - c0 == E
@@ -506,15 +510,11 @@ class TokenTablesFn(Function):
         gws = [_grad_buf(lw[i]) for i in range(n)]
         gbs = [_grad_buf(lb[i]) if lb[i] is not None else None for i in range(n)]
         direct = all(gws[i] is not None and (lb[i] is None or gbs[i] is not None) for i in live)
-        dws, dbs, probs = {}, {}, []
+        dws, dbs = {}, {}
         for i in live:
-            if direct:
-                dst = gws[i]
-            else:
-                dst = dws[i] = torch.zeros_like(ws[i])
+            if not direct:
+                dws[i] = torch.zeros_like(ws[i])
                 dbs[i] = torch.empty(G, device=dev, dtype=torch.float32) if lb[i] is not None else None
-            probs.append(gemm_prob([(dts[i], G, embc, embc.stride(0), V)], dst[:, c0:c1], G, E, accumulate=direct))
-        gemm_group(TN, probs)
         leaf, pad_row = ctx.emb_leaf
         gemb = _grad_buf(leaf) if leaf is not None else None
         demb, acc_emb, skip = None, 0, -1
@@ -523,12 +523,37 @@ class TokenTablesFn(Function):
         elif ctx.needs_input_grad[0]:
             demb = torch.empty(V, E, device=dev, dtype=torch.float32)
         nl = len(live)
-        pt = (ctypes.c_void_p * 4)(*[_dp(dts[i]) for i in live], *([None] * (4 - nl)))
-        pw = (ctypes.c_void_p * 4)(*[_dp(ws[i][:, c0:c1]) for i in live], *([None] * (4 - nl)))
-        ldw = (ctypes.c_int * 4)(*[int(ws[i].stride(0)) for i in live], *([0] * (4 - nl)))
-        pb = (ctypes.c_void_p * 4)(*[_dp(gbs[i] if direct else dbs[i]) for i in live], *([None] * (4 - nl)))
-        call("cpg_token_tables_bwd", nl, V, G, E, pt, pw, ldw, _p(demb), int(demb.stride(0)) if demb is not None else E, acc_emb, skip,
-             pb, int(direct), _stream())
+        if V > 32 or E > 256 or nl > 4:
+            # shapes the two-launch kernel does not cover (large vocabularies / embeddings): one product pair per table
+            for i in live:
+                d = gws[i] if direct else dws[i]
+                nbw = query("cpg_linear_bwd_weight_workspace", V, G, E)
+                wsp = workspace(nbw, dev)
+                call("cpg_linear_bwd_weight", _p(dts[i]), G, _p(embc), int(embc.stride(0)), _p(d[:, c0:c1]), int(d.stride(0)),
+                     _p(gbs[i] if direct else dbs[i]), V, G, E, int(direct), _p(wsp), wsp.numel(), _stream())
+            dx = None
+            if demb is not None:
+                dx = torch.zeros(V, E, device=dev, dtype=torch.float32)
+                for i in live:
+                    call("cpg_linear_bwd_input", _p(dts[i]), G, _p(ws[i][:, c0:c1]), int(ws[i].stride(0)), _p(dx), E, V, G, E, 1, _stream())
+                if gemb is not None:
+                    if skip >= 0:
+                        dx[skip].zero_()
+                    gemb.add_(dx)
+            outs[0] = None if gemb is not None else dx
+            if not direct:
+                for i in live:
+                    outs[2 + 2 * i], outs[3 + 2 * i] = dws[i], dbs[i]
+            return tuple(outs)
+        arr = lambda xs: (ctypes.c_void_p * 4)(*xs, *([None] * (4 - nl)))
+        iarr = lambda xs: (ctypes.c_int * 4)(*xs, *([0] * (4 - nl)))
+        dst = [gws[i] if direct else dws[i] for i in live]
+        nb = int(query("cpg_token_tables_bwd_workspace", nl, V, G, E))
+        wsp = workspace(nb, dev, tag=12)
+        call("cpg_token_tables_bwd", nl, V, G, E, arr([_dp(dts[i]) for i in live]), arr([_dp(ws[i][:, c0:c1]) for i in live]),
+             iarr([int(ws[i].stride(0)) for i in live]), _p(embc), int(embc.stride(0)), arr([_dp(d[:, c0:c1]) for d in dst]),
+             iarr([int(d.stride(0)) for d in dst]), int(direct), arr([_dp(gbs[i] if direct else dbs[i]) for i in live]), int(direct), _p(demb),
+             int(demb.stride(0)) if demb is not None else E, acc_emb, skip, _p(wsp), nb, _stream())
         outs[0] = None if gemb is not None else demb
         if not direct:
             for i in live:
@@ -545,6 +570,7 @@ class EncoderHeadsFn(Function):
 
     @staticmethod
     def forward(ctx, hf, hr, wmu, bmu, wlv, blv):
+        ctx.set_materialize_grads(False)
         hfc, ldf = _ld(hf)
         hrc, ldr = (None, 0) if hr is None else _ld(hr)
         B, H = hfc.shape
@@ -570,6 +596,8 @@ class EncoderHeadsFn(Function):
         Hr = hr.shape[1] if hr is not None else 0
         Z = wmu.shape[0]
         dev = hf.device
+        if dmu is None and dlv is None:
+            return None, None, None, None, None, None
         if dmu is None:
             dmu = torch.zeros(B, Z, device=dev)
         if dlv is None:
@@ -885,10 +913,13 @@ class ZeroRowGradFn(Function):
     @staticmethod
     def forward(ctx, w, row):
         ctx.row = row
+        ctx.set_materialize_grads(False)   # no consumer returned a gradient (they added it straight into .grad): nothing to do, not a zero fill
         return w.view_as(w)
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         key = (g.device, ctx.row)
         idx = _ROW_IDX.get(key)
         if idx is None:   # built once per process: a host -> device copy inside a step would stall the enqueue
@@ -1584,6 +1615,7 @@ class VocabReconFn(Function):
 
     @staticmethod
     def forward(ctx, hs, keep, scale, w, b, ids, count_override):
+        ctx.set_materialize_grads(False)
         hs = hs.contiguous()
         R, H = hs.shape
         V = w.shape[0]
@@ -1610,6 +1642,8 @@ class VocabReconFn(Function):
     @staticmethod
     def backward(ctx, g, _glogits):
         hs, keep, w, dl, count = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None, None, None, None
         R, H = hs.shape
         V = w.shape[0]
         dev = hs.device
@@ -1715,6 +1749,7 @@ class LatentFn(Function):
 
     @staticmethod
     def forward(ctx, mu, logvar, eps, c, rng):
+        ctx.set_materialize_grads(False)     # penalties that do not enter the loss, c, the logged sums: undefined gradients, not zero fills
         mu, logvar = mu.contiguous(), logvar.contiguous()
         B, Z = mu.shape
         dev = mu.device
@@ -1747,6 +1782,8 @@ class LatentFn(Function):
     def backward(ctx, dz, dzc, _dc, g_kl, g_klmu, g_l1, _d5):
         mu, logvar, eps = ctx.saved_tensors
         B, Z = mu.shape
+        if dz is None and dzc is None and g_kl is None and g_klmu is None and g_l1 is None:
+            return None, None, None, None, None
         dz = dz.contiguous() if dz is not None else None
         ldzc = 0
         if dzc is not None:
@@ -1852,15 +1889,27 @@ class MmdRfFn(Function):
     @staticmethod
     def forward(ctx, z, z_prior, rf_w, rf_b, sigma, b_global, reduce, world=1):
         rf_w, rf_b = rf_w.contiguous(), rf_b.contiguous()
-        raw1, s1 = rf_sums(z, rf_w, rf_b, sigma)
-        _, s2 = rf_sums(z_prior, rf_w, rf_b, sigma)
-        if reduce is not None:
-            reduce(s1)
-            reduce(s2)
+        z, z_prior = z.contiguous(), z_prior.contiguous()
+        B, Z = z.shape
         R = rf_w.shape[1]
-        loss = torch.empty(1, device=z.device, dtype=torch.float32)
-        diff = torch.empty(R, device=z.device, dtype=torch.float32)
-        call("cpg_rf_loss", _p(s1), _p(s2), R, int(b_global), _p(loss), _p(diff), _stream())
+        dev = z.device
+        # both feature sums from ONE grouped launch whose epilogue applies the cosine and sums 64-row chunks (cpg_rf_features), then
+        # one launch for the chunk sums + the loss (three launches in place of eight)
+        raw1 = torch.empty(B, R, device=dev, dtype=torch.float32)
+        nb = int(query("cpg_rf_features_workspace", 2, B, R))
+        part = workspace(nb, dev, tag=11)
+        call("cpg_rf_features", 2, _p(z), _p(z_prior), Z, B, Z, _p(rf_w), R, _p(rf_b), float(sigma), _p(raw1), _p(part), nb, _stream())
+        chunks = (B + 63) // 64
+        s12 = torch.empty(2, R, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        diff = torch.empty(R, device=dev, dtype=torch.float32)
+        if reduce is None:
+            call("cpg_rf_sums_loss", _p(part), chunks, R, int(b_global), _p(s12[0]), _p(s12[1]), _p(loss), _p(diff), _stream())
+        else:
+            call("cpg_rf_sums_loss", _p(part), chunks, R, int(b_global), _p(s12[0]), _p(s12[1]), None, None, _stream())
+            reduce(s12[0])
+            reduce(s12[1])
+            call("cpg_rf_loss", _p(s12[0]), _p(s12[1]), R, int(b_global), _p(loss), _p(diff), _stream())
         ctx.save_for_backward(raw1, rf_w, rf_b, diff)
         # every rank differentiates the GLOBAL loss wrt its local rows; the later gradient all-reduce averages over
         # ranks (SUM * 1/world), so the local contribution is pre-scaled by world: 1/B_global -> 1/B_local.

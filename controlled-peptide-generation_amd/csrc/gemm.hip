@@ -382,8 +382,17 @@ struct GemmGroup {
     int n;
 };
 
-template <class TC, bool A_KC, bool B_KC, bool VEC>
-__global__ __launch_bounds__(TC::NT) void gemm_group_kernel(GemmGroup G) {
+// EPI 1 (random Fourier features, losses.py:84-88): the product raw = x W is turned into phi = cos(raw / sigma + phase[col]) * amp in the
+// epilogue and summed over the tile's rows: part[problem][row tile][N] (fixed order: lanes, row blocks, then the two wave rows through
+// LDS); raw itself is stored only where C is given.  The [B, R] feature matrix never exists.
+struct RfEpi {
+    const float* phase;
+    float inv_sigma, amp;
+    float* part;            // [nprob][max row tiles][N]
+    int row_tiles;          // stride (in row tiles) between problems
+};
+template <class TC, bool A_KC, bool B_KC, bool VEC, int EPI = 0>
+__global__ __launch_bounds__(TC::NT) void gemm_group_kernel(GemmGroup G, RfEpi E) {
     using Loop = GemmLoop<TC, A_KC, B_KC, VEC, false, 7>;
     const int t = blockIdx.x;
     int pi = 0;
@@ -405,6 +414,36 @@ __global__ __launch_bounds__(TC::NT) void gemm_group_kernel(GemmGroup G) {
         OpA a{g.A[sg], g.lda[sg], m0, g.M, nullptr, 1.f, G.pairs_a[pi][sg], 0, nullptr, 1};
         OpB b{g.B[sg], g.ldb[sg], n0, g.N, 0, nullptr, 1.f, G.pairs_b[pi][sg]};
         Loop::run(a, b, g.K[sg], acc);
+    }
+    if constexpr (EPI == 1) {
+        static_assert(TC::WM == 2 && TC::NT == 256, "two wave rows per tile");
+        extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / TC::WN;
+        float* red = cpg_smem;   // [WM][BN]; the main loop ended on a barrier
+#pragma unroll
+        for (int ni = 0; ni < TC::NI; ++ni) {
+            const int cl = acc_col<TC>(ni), col = n0 + cl;
+            const float ph = col < g.N ? E.phase[col] : 0.f;
+            float cs = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < TC::MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + acc_row<TC>(mi, r);
+                    const float raw = acc[mi][ni][r];
+                    if (row < g.M && col < g.N) {
+                        if (g.C) g.C[(size_t)row * g.ldc + col] = raw;
+                        cs += cosf(raw * E.inv_sigma + ph) * E.amp;
+                    }
+                }
+            cs += __shfl_xor(cs, 16);
+            cs += __shfl_xor(cs, 32);
+            if (lane < 16) red[wm * TC::BN + cl] = cs;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < TC::BN; c += TC::NT)
+            if (n0 + c < g.N) E.part[((size_t)pi * E.row_tiles + by) * g.N + n0 + c] = red[c] + red[TC::BN + c];
+        return;
     }
 #pragma unroll
     for (int mi = 0; mi < TC::MI; ++mi)
@@ -428,8 +467,8 @@ __global__ __launch_bounds__(TC::NT) void gemm_group_kernel(GemmGroup G) {
         }
 }
 
-template <class TC, bool A_KC, bool B_KC>
-static int launch_group(GemmGroup& G, bool vec, hipStream_t s) {
+template <class TC, bool A_KC, bool B_KC, int EPI = 0>
+static int launch_group(GemmGroup& G, bool vec, hipStream_t s, RfEpi E = RfEpi{}) {
     int tiles = 0;
     for (int i = 0; i < G.n; ++i) {
         G.tile0[i] = tiles;
@@ -438,21 +477,59 @@ static int launch_group(GemmGroup& G, bool vec, hipStream_t s) {
     }
     G.tile0[G.n] = tiles;
     const size_t smem = GemmLoop<TC, A_KC, B_KC, true, false, 7>::smem_bytes();
-    const void* k = vec ? reinterpret_cast<const void*>(gemm_group_kernel<TC, A_KC, B_KC, true>)
-                        : reinterpret_cast<const void*>(gemm_group_kernel<TC, A_KC, B_KC, false>);
+    const void* k = vec ? reinterpret_cast<const void*>(gemm_group_kernel<TC, A_KC, B_KC, true, EPI>)
+                        : reinterpret_cast<const void*>(gemm_group_kernel<TC, A_KC, B_KC, false, EPI>);
     if (smem > 64 * 1024) {
         const int rc = cpg_allow_big_lds(k, (int)smem);
         if (rc) return rc;
     }
-    if (vec) hipLaunchKernelGGL((gemm_group_kernel<TC, A_KC, B_KC, true>), dim3(tiles), dim3(TC::NT), smem, s, G);
-    else hipLaunchKernelGGL((gemm_group_kernel<TC, A_KC, B_KC, false>), dim3(tiles), dim3(TC::NT), smem, s, G);
+    if (vec) hipLaunchKernelGGL((gemm_group_kernel<TC, A_KC, B_KC, true, EPI>), dim3(tiles), dim3(TC::NT), smem, s, G, E);
+    else hipLaunchKernelGGL((gemm_group_kernel<TC, A_KC, B_KC, false, EPI>), dim3(tiles), dim3(TC::NT), smem, s, G, E);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 
 template <bool A_KC, bool B_KC>
-static int gemm_group(GemmGroup& G, hipStream_t s) {
+static bool group_flags(GemmGroup& G) {
     bool vec = true;
+    for (int i = 0; i < G.n; ++i) {
+        const GemmProb& g = G.p[i];
+        for (int sg = 0; sg < 2 && g.K[sg] > 0; ++sg) {
+            const int K = g.K[sg];
+            const bool even_k = K % 2 == 0;
+            G.pairs_a[i][sg] = (((uintptr_t)g.A[sg]) & 7) == 0 && g.lda[sg] % 2 == 0 && (A_KC ? even_k : g.M % 2 == 0);
+            G.pairs_b[i][sg] = (((uintptr_t)g.B[sg]) & 7) == 0 && g.ldb[sg] % 2 == 0 && (B_KC ? even_k : g.N % 2 == 0);
+            vec = vec && aligned16(g.A[sg]) && aligned16(g.B[sg]) && g.lda[sg] % 4 == 0 && g.ldb[sg] % 4 == 0 &&
+                  ((A_KC || B_KC) ? K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) && (B_KC || g.N % 4 == 0);
+        }
+    }
+    return vec;
+}
+// phi-sums of the random-feature MMD term (losses.compute_gaussian_rf, losses.py:84-93) for nx <= 2 inputs x_i [Bn, Z] against one basis
+// rf_w [Z, R] in ONE launch: part[i][chunk][R] = sums over the chunk's 64 rows of cos(x_i rf_w / sigma + rf_b) * sqrt(2 / R); raw0 (optional)
+// receives x_0 rf_w (what the backward pass needs).  *chunks_out = number of 64-row chunks.  part: nx * chunks * R floats.
+CPG_EXPORT size_t cpg_rf_features_workspace(int nx, int Bn, int R) { return (size_t)nx * cdiv(Bn, 64) * R * sizeof(float); }
+CPG_EXPORT int cpg_rf_features(int nx, const float* x0, const float* x1, int ldx, int Bn, int Z, const float* rf_w, int R, const float* rf_b,
+                               float sigma, float* raw0, float* part, size_t part_bytes, void* stream) {
+    CPG_CHECK_ARG(nx >= 1 && nx <= 2 && x0 && (nx == 1 || x1) && rf_w && rf_b && part && Bn > 0 && Z > 0 && R > 0 && sigma > 0.f && ldx >= Z);
+    CPG_CHECK_ARG(part_bytes >= cpg_rf_features_workspace(nx, Bn, R));
+    GemmGroup G;
+    memset(&G, 0, sizeof(G));
+    G.n = nx;
+    for (int i = 0; i < nx; ++i) {
+        GemmProb& g = G.p[i];
+        g.A[0] = i ? x1 : x0; g.lda[0] = ldx; g.B[0] = rf_w; g.ldb[0] = R; g.K[0] = Z;
+        g.M = Bn; g.N = R;
+        g.C = i ? nullptr : raw0; g.ldc = R;
+    }
+    const bool vec = group_flags<true, false>(G);
+    RfEpi E{rf_b, 1.f / sigma, sqrtf(2.f / (float)R), part, cdiv(Bn, 64)};
+    return launch_group<T64x64, true, false, 1>(G, vec, (hipStream_t)stream, E);
+}
+
+template <bool A_KC, bool B_KC>
+static int gemm_group(GemmGroup& G, hipStream_t s) {
+    bool vec = group_flags<A_KC, B_KC>(G);
     int maxM = 0, maxN = 0, maxK = 0;
     long t64 = 0;
     for (int i = 0; i < G.n; ++i) {
@@ -460,15 +537,7 @@ static int gemm_group(GemmGroup& G, hipStream_t s) {
         maxM = g.M > maxM ? g.M : maxM;
         maxN = g.N > maxN ? g.N : maxN;
         t64 += (long)cdiv(g.M, 64) * cdiv(g.N, 64);
-        for (int sg = 0; sg < 2 && g.K[sg] > 0; ++sg) {
-            const int K = g.K[sg];
-            maxK = K > maxK ? K : maxK;
-            const bool even_k = K % 2 == 0;
-            G.pairs_a[i][sg] = (((uintptr_t)g.A[sg]) & 7) == 0 && g.lda[sg] % 2 == 0 && (A_KC ? even_k : g.M % 2 == 0);
-            G.pairs_b[i][sg] = (((uintptr_t)g.B[sg]) & 7) == 0 && g.ldb[sg] % 2 == 0 && (B_KC ? even_k : g.N % 2 == 0);
-            vec = vec && aligned16(g.A[sg]) && aligned16(g.B[sg]) && g.lda[sg] % 4 == 0 && g.ldb[sg] % 4 == 0 &&
-                  ((A_KC || B_KC) ? K % 4 == 0 : true) && (A_KC || g.M % 4 == 0) && (B_KC || g.N % 4 == 0);
-        }
+        for (int sg = 0; sg < 2 && g.K[sg] > 0; ++sg) maxK = g.K[sg] > maxK ? g.K[sg] : maxK;
     }
     // tiles as launch_gemm picks them for one problem, on the group's totals (tools/gbench.py, tools/lin_sweep.py)
     if (maxM <= 32) return launch_group<T32x128, A_KC, B_KC>(G, vec, s);
@@ -497,77 +566,202 @@ CPG_EXPORT int cpg_gemm_group(int form, int nprob, const void* probs, void* stre
     return form == 0 ? gemm_group<true, true>(G, s) : form == 1 ? gemm_group<true, false>(G, s) : gemm_group<false, false>(G, s);
 }
 
-// ---- backward of n token tables tab_i = emb W_i^T + b_i (ops.TokenTablesFn) that the grouped TN launch does not cover, ONE launch:
-//   demb[v][e] (+)= sum_i sum_j dtab_i[v][j] W_i[j][e]     (V x E outputs, contraction over n G gate rows: blocks [0, nA))
-//   db_i[j]    (+)= sum_v dtab_i[v][j]                      (blocks [nA, nA + nB))
-// demb rows equal to skip_row are left untouched when accumulating (nn.Embedding(padding_idx): that row gets no gradient) / written as
-// zeros otherwise.  Fixed summation order (16 k-lanes per output, reduced through LDS in lane order).
+// ---- backward of n <= 4 token tables tab_i = emb W_i^T + b_i (ops.TokenTablesFn), two launches for everything:
+// stage 1, one workgroup per (table, chunk of TB_J = 16 gate rows j), all operands of the chunk in LDS:
+//   dW_i[j][e]  (+)= sum_v dtab_i[v][j] emb[v][e]                 the chunk's rows of the weight gradient (contraction over V <= 32)
+//   db_i[j]     (+)= sum_v dtab_i[v][j]
+//   part[i][chunk][v][e] = sum_{j in chunk} dtab_i[v][j] W_i[j][e]   the chunk's share of the embedding gradient
+// stage 2: demb[v][e] (+)= the shares summed in (table, chunk) order; row skip_row untouched when accumulating (nn.Embedding(padding_idx))
+// / zero otherwise.  Plain f32 FMAs in a fixed order.  (Round 6, first version: one thread block per 64 embedding columns walked all
+// n G gate rows - 72 workgroups, 66-79 us per call; and the weight gradient was a separate grouped launch whose 24-deep contraction kept
+// the tile engine at 57 us.)
+constexpr int TB_J = 16, TB_VMAX = 32, TB_EMAX = 256;   // (64-row chunks: 24-48 workgroups, each a 100-us chain of dependent loads; 16: short chains on 96-192 CUs)
 struct TabBwdArgs {
     const float* dtab[4];
     const float* W[4];
-    int ldw[4];
+    float* dW[4];
     float* db[4];
-    float* demb;
-    int n, V, G, E, lde, nA, acc_emb, acc_db, skip_row;
+    const float* emb;
+    float* part;
+    int ldw[4], lddw[4];
+    int n, V, G, E, lde, acc_w, acc_db, chunks;
 };
-__global__ __launch_bounds__(1024) void token_tables_bwd_kernel(TabBwdArgs a) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x, ty = threadIdx.y;
-    if ((int)blockIdx.x < a.nA) {
-        if (!a.demb) return;
-        const int ne = (a.E + 63) / 64;
-        const int v = blockIdx.x / ne, e = (blockIdx.x - v * ne) * 64 + tx;
-        float s = 0.f;
-        if (e < a.E)
-            for (int i = 0; i < a.n; ++i) {
-                const float* dt = a.dtab[i] + (size_t)v * a.G;
-                const float* w = a.W[i] + e;
-                for (int j = ty; j < a.G; j += 16) s = fmaf(dt[j], w[(size_t)j * a.ldw[i]], s);
-            }
-        red[ty][tx] = s;
-        __syncthreads();
-        if (ty == 0 && e < a.E) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t += red[k][tx];
-            float* o = a.demb + (size_t)v * a.lde + e;
-            if (v == a.skip_row) { if (!a.acc_emb) *o = 0.f; }
-            else *o = a.acc_emb ? *o + t : t;
-        }
-        return;
+__global__ __launch_bounds__(256) void token_tables_bwd_kernel(TabBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int i = blockIdx.y, ch = blockIdx.x, j0 = ch * TB_J, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.V, E = a.E, EP = E + 1, nj = min(TB_J, a.G - j0);
+    constexpr int EC = TB_EMAX / 64;         // column slots per lane: e = lane + 64 c
+    float* dt_l = cpg_smem;                  // [V][TB_J + 1]
+    float* emb_l = dt_l + V * (TB_J + 1);    // [V][EP]
+    float* w_l = emb_l + V * EP;             // [TB_J][EP]
+    // staging: rows over waves, columns over lanes - no index arithmetic, a wave's loads of a row group all in flight
+    const float* const dtab = a.dtab[i];
+    const float* const Wi = a.W[i];
+    float* const dWi = a.dW[i];
+    const int ldw = a.ldw[i], lddw = a.lddw[i];
+    for (int x = tid; x < V * TB_J; x += 256) {
+        const int v = x / TB_J, j = x - v * TB_J;
+        dt_l[v * (TB_J + 1) + j] = j < nj ? dtab[(size_t)v * a.G + j0 + j] : 0.f;
     }
-    const int b = blockIdx.x - a.nA, nj = (a.G + 1023) / 1024;
-    const int i = b / nj, j = (b - i * nj) * 1024 + ty * 64 + tx;
-    if (i >= a.n || j >= a.G || !a.db[i]) return;
-    float s = 0.f;
-    for (int v = 0; v < a.V; ++v) s += a.dtab[i][(size_t)v * a.G + j];
-    a.db[i][j] = a.acc_db ? a.db[i][j] + s : s;
+    for (int v0 = wave; v0 < V; v0 += 16) {
+        float t[4][EC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const int v = v0 + 4 * u, e = lane + 64 * c;
+                t[u][c] = (v < V && e < E) ? a.emb[(size_t)v * a.lde + e] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const int v = v0 + 4 * u, e = lane + 64 * c;
+                if (v < V && e < E) emb_l[v * EP + e] = t[u][c];
+            }
+    }
+    for (int r0 = wave; r0 < TB_J; r0 += 16) {
+        float t[4][EC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const int j = r0 + 4 * u, e = lane + 64 * c;
+                t[u][c] = (j < nj && e < E) ? Wi[(size_t)(j0 + j) * ldw + e] : 0.f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < EC; ++c) {
+                const int j = r0 + 4 * u, e = lane + 64 * c;
+                if (e < E) w_l[j * EP + e] = t[u][c];
+            }
+    }
+    __syncthreads();
+    // dW rows of the chunk: wave -> rows j = wave, wave + 4, ..., lane -> columns; V-deep
+    if (dWi)
+        for (int r0 = wave; r0 < nj; r0 += 16) {
+            float s[4][EC], old[4][EC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const int j = r0 + 4 * u, e = lane + 64 * c;
+                    s[u][c] = 0.f;
+                    old[u][c] = (a.acc_w && j < nj && e < E) ? dWi[(size_t)(j0 + j) * lddw + e] : 0.f;
+                }
+            for (int v = 0; v < V; ++v) {
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = dt_l[v * (TB_J + 1) + min(r0 + 4 * u, TB_J - 1)];
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const float ev = emb_l[v * EP + min(lane + 64 * c, E - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s[u][c] = fmaf(d[u], ev, s[u][c]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const int j = r0 + 4 * u, e = lane + 64 * c;
+                    if (j < nj && e < E) dWi[(size_t)(j0 + j) * lddw + e] = old[u][c] + s[u][c];
+                }
+        }
+    if (a.db[i] && tid < nj) {
+        float sb = 0.f;
+        for (int v = 0; v < V; ++v) sb += dt_l[v * (TB_J + 1) + tid];
+        float* o = a.db[i] + j0 + tid;
+        *o = a.acc_db ? *o + sb : sb;
+    }
+    // the chunk's share of demb: wave -> rows v = wave, wave + 4, ..., lane -> columns; TB_J-deep
+    if (a.part) {
+        float* p = a.part + ((size_t)i * a.chunks + ch) * V * E;
+        for (int v0 = wave; v0 < V; v0 += 16) {
+            float s[4][EC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < EC; ++c) s[u][c] = 0.f;
+            for (int j = 0; j < TB_J; ++j) {
+                float d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = dt_l[min(v0 + 4 * u, V - 1) * (TB_J + 1) + j];
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const float wv = w_l[j * EP + min(lane + 64 * c, E - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s[u][c] = fmaf(d[u], wv, s[u][c]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < EC; ++c) {
+                    const int v = v0 + 4 * u, e = lane + 64 * c;
+                    if (v < V && e < E) p[v * E + e] = s[u][c];
+                }
+        }
+    }
 }
-// dtab / W / db: host arrays of n (<= 4) device pointers (W_i = the [G, E] column block of the layer's W_ih the embedding multiplies,
-// row stride ldw[i]; db entries may be null).  demb [V, lde >= E] or null.  skip_row: < 0 for none.
-CPG_EXPORT int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* dtab, const void* const* W, const int* ldw, float* demb,
-                                    int lde, int accumulate_emb, int skip_row, void* const* db, int accumulate_db, void* stream) {
-    CPG_CHECK_ARG(n >= 1 && n <= 4 && V > 0 && G > 0 && E > 0 && dtab && W && ldw && db && (!demb || lde >= E));
+// 16 lanes per output: lane l sums shares l, l + 16, ... (all loads in flight at once), the 16 sums are combined in a fixed tree
+__global__ void token_tables_demb_kernel(const float* __restrict__ part, int nparts, int V, int E, float* __restrict__ demb, int lde, int accumulate,
+                                         int skip_row) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, x = t >> 4, l = t & 15;
+    const bool ok = x < V * E;
+    float s = 0.f;
+    if (ok)
+        for (int c = l; c < nparts; c += 16) s += part[(size_t)c * V * E + x];
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (!ok || l) return;
+    const int v = x / E, e = x - v * E;
+    float* o = demb + (size_t)v * lde + e;
+    if (v == skip_row) { if (!accumulate) *o = 0.f; }
+    else *o = accumulate ? *o + s : s;
+}
+// dtab / W / dW / db: HOST arrays of n device pointers (W_i, dW_i: the [G, E] column block of the layer's W_ih / of its gradient that
+// the embedding multiplies, row strides ldw[i] / lddw[i]; dW / db entries may be null).  emb [V, lde_in]; demb [V, lde] or null.
+// workspace: cpg_token_tables_bwd_workspace(n, V, G, E) bytes.
+CPG_EXPORT size_t cpg_token_tables_bwd_workspace(int n, int V, int G, int E) { return (size_t)n * cdiv(G, TB_J) * V * E * sizeof(float); }
+CPG_EXPORT int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* dtab, const void* const* W, const int* ldw,
+                                    const float* emb, int lde_in, void* const* dW, const int* lddw, int accumulate_w, void* const* db,
+                                    int accumulate_db, float* demb, int lde, int accumulate_emb, int skip_row, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    CPG_CHECK_ARG(n >= 1 && n <= 4 && V > 0 && V <= TB_VMAX && G > 0 && E > 0 && E <= TB_EMAX && dtab && W && ldw && emb && lde_in >= E && dW &&
+                  lddw && db && (!demb || (lde >= E && workspace && workspace_bytes >= cpg_token_tables_bwd_workspace(n, V, G, E))));
     TabBwdArgs a;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < n; ++i) {
-        CPG_CHECK_ARG(dtab[i] && W[i] && ldw[i] >= E);
+        CPG_CHECK_ARG(dtab[i] && W[i] && ldw[i] >= E && (!dW[i] || lddw[i] >= E));
         a.dtab[i] = (const float*)dtab[i];
         a.W[i] = (const float*)W[i];
-        a.ldw[i] = ldw[i];
+        a.dW[i] = (float*)dW[i];
         a.db[i] = (float*)db[i];
+        a.ldw[i] = ldw[i];
+        a.lddw[i] = lddw[i];
     }
-    a.demb = demb; a.n = n; a.V = V; a.G = G; a.E = E; a.lde = lde;
-    a.nA = cdiv(E, 64) * V;
-    a.acc_emb = accumulate_emb; a.acc_db = accumulate_db; a.skip_row = skip_row;
-    const int nB = n * cdiv(G, 1024);
-    hipLaunchKernelGGL(token_tables_bwd_kernel, dim3(a.nA + nB), dim3(64, 16), 0, (hipStream_t)stream, a);
+    a.emb = emb; a.lde = lde_in; a.part = demb ? (float*)workspace : nullptr;
+    a.n = n; a.V = V; a.G = G; a.E = E; a.acc_w = accumulate_w; a.acc_db = accumulate_db; a.chunks = cdiv(G, TB_J);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = ((size_t)V * (TB_J + 1) + (size_t)V * (E + 1) + (size_t)TB_J * (E + 1)) * sizeof(float);
+    if (smem > 64 * 1024) {
+        const int rc = cpg_allow_big_lds((const void*)token_tables_bwd_kernel, (int)smem);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(token_tables_bwd_kernel, dim3(a.chunks, n), dim3(256), smem, s, a);
     CPG_LAUNCH_CHECK();
+    if (demb) {
+        hipLaunchKernelGGL(token_tables_demb_kernel, dim3(cdiv(V * E * 16, 256)), dim3(256), 0, s, (const float*)workspace, n * a.chunks, V, E, demb, lde,
+                           accumulate_emb, skip_row);
+        CPG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
 // ---- column sums of up to four [M, N] matrices in ONE single-stage launch (bias gradients of a group of heads: M = batch rows):
-// out_i[n] (+)= sum_m X_i[m][n]; 64 columns x 16 row lanes per block, lanes reduced through LDS in lane order.
+// out_i[n] (+)= sum_m X_i[m][n]; 16 columns x 64 row lanes per block (many blocks, short row loops), lanes reduced through LDS in lane order.
 struct ColsumMultiArgs {
     const float* X[4];
     float* out[4];
@@ -575,19 +769,19 @@ struct ColsumMultiArgs {
     int M, N, accumulate;
 };
 __global__ __launch_bounds__(1024) void colsum_multi_kernel(ColsumMultiArgs a) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x, ty = threadIdx.y, i = blockIdx.y, n = blockIdx.x * 64 + tx;
+    __shared__ float red[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4, i = blockIdx.y, n = blockIdx.x * 16 + tx;
     float s = 0.f;
     if (n < a.N) {
         const float* x = a.X[i] + n;
-        for (int m = ty; m < a.M; m += 16) s += x[(size_t)m * a.ld[i]];
+        for (int m = ty; m < a.M; m += 64) s += x[(size_t)m * a.ld[i]];
     }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && n < a.N) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        for (int k = 0; k < 64; ++k) t += red[k][tx];
         a.out[i][n] = a.accumulate ? a.out[i][n] + t : t;
     }
 }
@@ -602,36 +796,42 @@ CPG_EXPORT int cpg_colsum_multi(int nmat, const void* const* X, const int* ld, i
         a.ld[i] = ld[i];
     }
     a.M = M; a.N = N; a.accumulate = accumulate;
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(N, 64), nmat), dim3(64, 16), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(N, 16), nmat), dim3(1024), 0, (hipStream_t)stream, a);
     CPG_LAUNCH_CHECK();
     return 0;
 }
 
 // ---- largest magnitude of a weight matrix, for the engines that split weights into f16 pairs (gemm_core.h: weight_exp_from_parts).
 // Block b takes rows b, b + WX_PARTS, ...; 16-byte loads where the rows allow them.  wx[b] = float bits of the block's maximum.
-__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, int rows, int cols, int ld, int vec, int* __restrict__ wx) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void weight_absmax_kernel(const float* __restrict__ w, int rows, int cols, int ld, int vec, int* __restrict__ wx) {
+    __shared__ float red[16];
     float m = 0.f;
-    if (vec) {
+    if (vec) {   // the block's rows as one index space of 16-byte quads: every thread has several independent loads in flight
         const int q4 = cols >> 2;
-        for (int r = blockIdx.x; r < rows; r += WX_PARTS)
-            for (int c = threadIdx.x; c < q4; c += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)r * ld + 4 * c);
-                m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-            }
+        const int nr = (rows - (int)blockIdx.x + WX_PARTS - 1) / WX_PARTS;   // rows blockIdx.x, + WX_PARTS, ...
+        for (int i = threadIdx.x; i < nr * q4; i += 1024) {
+            const int rr = i / q4, c = i - rr * q4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(blockIdx.x + rr * WX_PARTS) * ld + 4 * c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
     } else {
         for (int r = blockIdx.x; r < rows; r += WX_PARTS)
-            for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(w[(size_t)r * ld + c]));
+            for (int c = threadIdx.x; c < cols; c += 1024) m = fmaxf(m, fabsf(w[(size_t)r * ld + c]));
     }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) wx[blockIdx.x] = __builtin_bit_cast(int, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t = fmaxf(t, red[k]);
+        wx[blockIdx.x] = __builtin_bit_cast(int, t);
+    }
 }
 int cpg_weight_absmax(const float* w, int rows, int cols, int ld, int* wx, hipStream_t s) {
     if (!w || !wx || rows <= 0 || cols <= 0 || ld < cols) { cpg_set_error("cpg_weight_absmax: bad argument"); return -2; }
     const int vec = (cols % 4 == 0 && ld % 4 == 0 && aligned16(w)) ? 1 : 0;
-    hipLaunchKernelGGL(weight_absmax_kernel, dim3(WX_PARTS), dim3(256), 0, s, w, rows, cols, ld, vec, wx);
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3(WX_PARTS), dim3(1024), 0, s, w, rows, cols, ld, vec, wx);
     CPG_LAUNCH_CHECK();
     return 0;
 }

@@ -575,6 +575,42 @@ CPG_EXPORT int cpg_rf_loss(const float* sums1, const float* sums2, int R, int B_
     CPG_LAUNCH_CHECK();
     return 0;
 }
+// the tail of the random-feature term in ONE launch (single rank): s1 / s2 = sums over the chunks of cpg_rf_features' partials (chunk
+// order), diff = (s1 - s2) / B, loss = sum diff^2  (rf_colsum_final_kernel x 2 + rf_loss_kernel; one block)
+__global__ void rf_sums_loss_kernel(const float* __restrict__ part, int chunks, int R, float invB, float* __restrict__ s1, float* __restrict__ s2,
+                                    float* __restrict__ loss, float* __restrict__ diff) {
+    __shared__ float red[4];
+    float v[1] = {0.f};
+    const float* p1 = part;
+    const float* p2 = part + (size_t)chunks * R;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < chunks; ++c) {
+            a += p1[(size_t)c * R + r];
+            b += p2[(size_t)c * R + r];
+        }
+        s1[r] = a;
+        s2[r] = b;
+        if (loss) {
+            const float d = (a - b) * invB;
+            diff[r] = d;
+            v[0] += d * d;
+        }
+    }
+    if (loss) {
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0) loss[0] = v[0];
+    }
+}
+// loss / diff null: only the two sum vectors (a data-parallel caller all-reduces them, then calls cpg_rf_loss)
+CPG_EXPORT int cpg_rf_sums_loss(const float* part, int chunks, int R, int B_global, float* sums1, float* sums2, float* loss, float* diff,
+                                void* stream) {
+    CPG_CHECK_ARG(part && sums1 && sums2 && chunks > 0 && R > 0 && B_global > 0 && ((loss == nullptr) == (diff == nullptr)));
+    hipLaunchKernelGGL(rf_sums_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, chunks, R, 1.f / (float)B_global, sums1, sums2,
+                       loss, diff);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
 // dpre[b,r] = gout * (2*diff[r]/B_global) * (-sin(raw/sigma + b) * sqrt(2/R)) / sigma    (then dz1 = dpre @ rf_w^T)
 __global__ void rf_bwd_kernel(const float* raw, const float* rf_b, const float* diff, const float* gout, int Bn, int R,
                               float inv_sigma, float amp, float invB, float* dpre) {

@@ -90,11 +90,15 @@ typedef struct CpgGemmProb {
 } CpgGemmProb;
 CPG_API int cpg_gemm_group_prob_bytes(void);
 CPG_API int cpg_gemm_group(int form, int nprob, const void* probs, void* stream);
-/* Backward of n <= 4 token tables tab_i = emb W_i^T + b_i beside the grouped weight-gradient launch, ONE launch: demb [V, lde] (+)= sum_i
- * dtab_i W_i (row skip_row untouched / zero: nn.Embedding(padding_idx), models/model.py:47), db_i [G] (+)= column sums of dtab_i.
- * dtab / W / db: HOST arrays of n device pointers (W_i: the [G, E] column block of W_ih the embedding multiplies, row stride ldw[i]). */
-CPG_API int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* dtab, const void* const* W, const int* ldw, float* demb,
-                                 int lde, int accumulate_emb, int skip_row, void* const* db, int accumulate_db, void* stream);
+/* Backward of n <= 4 token tables tab_i = emb W_i^T + b_i (V <= 32 rows, E <= 256), two launches: dW_i (+)= dtab_i^T emb (the [G, E]
+ * column block of W_ih's gradient, row stride lddw[i]), db_i [G] (+)= column sums of dtab_i, demb [V, lde] (+)= sum_i dtab_i W_i with row
+ * skip_row untouched (accumulating) / zero: nn.Embedding(padding_idx), models/model.py:47.  dtab / W / dW / db: HOST arrays of n device
+ * pointers (dW / db entries and demb may be null).  workspace: cpg_token_tables_bwd_workspace bytes. */
+CPG_API size_t cpg_token_tables_bwd_workspace(int n, int V, int G, int E);
+CPG_API int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* dtab, const void* const* W, const int* ldw,
+                                 const float* emb, int lde_in, void* const* dW, const int* lddw, int accumulate_w, void* const* db,
+                                 int accumulate_db, float* demb, int lde, int accumulate_emb, int skip_row, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 /* out_i[N] (+)= column sums of X_i [M, N] (row stride ld[i]) for nmat <= 4 matrices in one single-stage launch (X / ld / out: HOST arrays) */
 CPG_API int cpg_colsum_multi(int nmat, const void* const* X, const int* ld, int M, int N, void* const* out, int accumulate, void* stream);
 /* dX[M,K] (+)= dY[M,N] W[N,K] */
@@ -509,6 +513,17 @@ CPG_API int cpg_rf_feature_sums(const float* raw, const float* rf_b, int Bn, int
                                 float* workspace, size_t workspace_bytes, void* stream);
 CPG_API int cpg_rf_loss(const float* sums1, const float* sums2, int R, int B_global, float* loss, float* diff,
                         void* stream);
+/* The same term in three launches instead of eight (round 6): cpg_rf_features = the feature sums of nx <= 2 inputs (z and z_prior:
+ * x0, x1 [Bn, Z], row stride ldx) against one basis in ONE grouped launch whose epilogue applies cos(. / sigma + rf_b) sqrt(2 / R) and
+ * sums each 64-row chunk - part [nx][chunks][R], cpg_rf_features_workspace bytes; the [Bn, R] feature matrix never exists, raw0
+ * (optional) receives x0 rf_w for the backward pass.  cpg_rf_sums_loss: sums over the chunks (chunk order) -> sums1, sums2 [R], and,
+ * where loss / diff are given, diff = (s1 - s2) / B_global and loss = sum diff^2 in the same launch (null: a data-parallel caller
+ * all-reduces the sums, then calls cpg_rf_loss). */
+CPG_API size_t cpg_rf_features_workspace(int nx, int Bn, int R);
+CPG_API int cpg_rf_features(int nx, const float* x0, const float* x1, int ldx, int Bn, int Z, const float* rf_w, int R, const float* rf_b,
+                            float sigma, float* raw0, float* part, size_t part_bytes, void* stream);
+CPG_API int cpg_rf_sums_loss(const float* part, int chunks, int R, int B_global, float* sums1, float* sums2, float* loss, float* diff,
+                             void* stream);
 CPG_API int cpg_rf_bwd(const float* raw, const float* rf_b, const float* diff, const float* gout, int Bn, int R,
                        float sigma, int B_global, float* dpre, void* stream);
 /* mmd_full_kernel, losses.py:47-56,96-108 (incl. the `H - diag(H)` broadcast).

@@ -343,8 +343,10 @@ def test_backward_f16_pair_step_edge_values():
             dG, dh0 = _bwd(d2, B, H, T, False, hs, gates, dhs, last, pair=True)
             dG_x, dh0_x = _bwd(d2, B, H, T, False, hs, gates, dhs, last, pair=False)
             assert torch.isfinite(dh0).all() and torch.isfinite(dG).all()
-            scale = dh0_x.abs().amax(1, keepdim=True).clamp_min(1e-30)
-            assert ((dh0 - dh0_x).abs() / scale).max().item() < 1e-5, big
+            # the pair images carry ONE power of two per 32 rows x 32 columns: an element is exact to 2^-22 of its block's largest
+            # value (the engine's documented bar, per step: 4e-6 of the 32-row block's maximum), five steps deep here
+            scale = dh0_x.abs().view(B // 32, 32, H).amax(dim=(1, 2), keepdim=True).expand(B // 32, 32, H).reshape(B, H).clamp_min(1e-30)
+            assert ((dh0 - dh0_x).abs() / scale).max().item() < 5e-5, (big, ((dh0 - dh0_x).abs() / scale).max().item())
 
 
 def ctypes_name(kind, B, H, ndir):

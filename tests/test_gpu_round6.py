@@ -199,7 +199,7 @@ def test_gemm_group_vs_f64(form):
     g = torch.Generator().manual_seed(11)
     rn = lambda *s: torch.randn(*s, generator=g).to(dev)
     F = {"NT": ops.NT, "NN": ops.NN, "TN": ops.TN}[form]
-    probs, checks = [], []
+    probs, checks, alive = [], [], []      # (a problem record holds raw pointers: the operands must outlive the launch)
     shapes = [(2048, 510, 512, 512), (24, 1536, 150, 0), (300, 70, 33, 96), (2048, 1024, 510, 510)]
     for pi, (M, N, K0, K1) in enumerate(shapes):
         segs, ref = [], torch.zeros(M, N, dtype=torch.float64)
@@ -219,6 +219,7 @@ def test_gemm_group_vs_f64(form):
                 ref += A.double().cpu().T @ Bm.double().cpu()
                 segs.append((A, M, Bm, N, K))
         bias = rn(N) if form != "TN" and pi % 2 == 0 else None
+        alive.append((segs, bias))
         acc = pi == 2
         split = pi == 3
         C = rn(M, N if not split else 512) if acc or split else torch.full((M, N), float("nan"), device=dev)
@@ -273,9 +274,10 @@ def test_token_tables_and_heads_fns_vs_linear_fns():
     (ta, la), (tb, lb) = tables(True), tables(False)
     for x, y in zip(ta, tb):
         assert torch.allclose(x, y, atol=2e-5, rtol=0)
-    for ga, gb in zip(_grads(la, P), _grads(lb, P)):
+    GA, GB = _grads(la, P), _grads(lb, P)
+    for ga, gb in zip(GA, GB):
         assert torch.allclose(ga, gb, atol=2e-5 * max(1.0, gb.abs().max().item()), rtol=0)
-    assert float(_grads(la, [emb])[0][1].abs().max()) == 0.0     # row PAD of the embedding
+    assert float(GA[0][1].abs().max()) == 0.0     # row PAD of the embedding
     # heads
     hf, hr = rn(B, H), rn(B, H)
     wm, bm, wl, bl = rn(Z, 2 * H), rn(Z), rn(Z, 2 * H), rn(Z)

@@ -10,9 +10,13 @@ python - <<'PY'
 import csv, collections, glob
 f = glob.glob('gpurun_out/qt/trace/**/t_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-adam = [i for i, r in enumerate(rows) if r['Kernel_Name'].replace('void ', '').startswith('adam_step')]
-lo, hi = adam[3 * 4 - 1] + 1, adam[-1] + 1
-n = len(adam) // 3 - 4
+nm = lambda r: r['Kernel_Name'].replace('void ', '')
+adam = [i for i, r in enumerate(rows) if nm(r).startswith('adam_segs')]     # one per step (round 6); older libraries: three adam_step launches
+per = 1
+if not adam:
+    adam, per = [i for i, r in enumerate(rows) if nm(r).startswith('adam_step')], 3
+lo, hi = adam[per * 4 - 1] + 1, adam[-1] + 1
+n = len(adam) // per - 4
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows[lo:hi]:
     k = r['Kernel_Name'].replace('void ', '')

@@ -11,9 +11,13 @@ root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/qt/trace'
 f = glob.glob(root + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if r['Kernel_Name'].replace('void ', '').startswith('adam_step')]
-# a step ends with three adam launches; take the step before the last one (the last may be followed by leg teardown)
-ends = adam[2::3]
+nm = lambda r: r['Kernel_Name'].replace('void ', '')
+adam = [i for i, r in enumerate(rows) if nm(r).startswith('adam_segs')]     # one Adam launch per step since round 6
+ends = adam
+if not adam:    # older libraries: a step ends with three adam_step launches
+    adam = [i for i, r in enumerate(rows) if nm(r).startswith('adam_step')]
+    ends = adam[2::3]
+# take the step before the last one (the last may be followed by leg teardown)
 lo, hi = ends[-3] + 1, ends[-2] + 1
 step = rows[lo:hi]
 t0 = int(step[0]['Start_Timestamp'])
