@@ -214,8 +214,9 @@ __device__ __forceinline__ float pair_pow2(int e) { return __builtin_bit_cast(fl
 // turned a weight of magnitude >= 256 into an f16 infinity).  Chosen per matrix from its largest magnitude, on the device:
 // cpg_weight_absmax (gemm.hip) leaves WX_PARTS partial maxima (float bits) in `wx`; every kernel that images or consumes the matrix
 // derives the same exponent e from them - max|W| 2^e in [2^13, 2^14), the convention of the gradient images and of the persistent
-// forward's W_hh slices - so any finite f32 weight is representable and the pair keeps 22 significand bits down to 2^-26 max|W|
-// (absolute floor 2^-25 2^-e below that).  An all-zero matrix takes e = 0; an infinity among the weights goes in unscaled and reaches
+// forward's W_hh slices - so any finite f32 weight is representable.  The pair keeps 22 significand bits for weights down to 2^-16 of
+// the matrix' largest magnitude (the low half stays a normal f16) and an absolute precision of 2^-25 2^-e = 2^-39 max|W| below that -
+// more than f32 needs for any matrix whose entries span less than five decimal orders (rounds 4-5: 2^-11 .. 255 at the fixed scale).  An all-zero matrix takes e = 0; an infinity among the weights goes in unscaled and reaches
 // the result as it is (as in f32 arithmetic).
 constexpr int WX_PARTS = 32;
 __device__ __forceinline__ int weight_exp_of(float vmax) {

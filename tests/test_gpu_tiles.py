@@ -420,6 +420,7 @@ def test_linear_fwd_on_f16_pairs_for_state_inputs():
     cpg_gemm_nt_pairs) against cpg_linear_fwd (exact-f32 MFMA) and an f64 product: both f32-grade, the pair form no further from f64;
     with accumulate; small products fall through to the exact kernel (bit-identical)."""
     import torch
+    from cpg import ops
     from cpg.ops import _p, _stream, call
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a real MI355X")
