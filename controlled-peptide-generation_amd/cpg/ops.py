@@ -397,7 +397,7 @@ class _GemmProb(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p * 2), ("B", ctypes.c_void_p * 2), ("lda", ctypes.c_int * 2), ("ldb", ctypes.c_int * 2),
                 ("K", ctypes.c_int * 2), ("M", ctypes.c_int), ("N", ctypes.c_int), ("C", ctypes.c_void_p), ("C2", ctypes.c_void_p),
                 ("ldc", ctypes.c_int), ("ldc2", ctypes.c_int), ("n_split", ctypes.c_int), ("accumulate", ctypes.c_int),
-                ("bias", ctypes.c_void_p), ("reserved", ctypes.c_void_p)]
+                ("bias", ctypes.c_void_p), ("wx_a", ctypes.c_void_p), ("wx_b", ctypes.c_void_p), ("pairs", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
 NT, NN, TN = 0, 1, 2
@@ -408,7 +408,7 @@ def _dp(t):
     return None if t is None else (_p(t).value)
 
 
-def gemm_prob(segs, C, M, N, bias=None, accumulate=False, C2=None, n_split=0):
+def gemm_prob(segs, C, M, N, bias=None, accumulate=False, C2=None, n_split=0, pairs=False, wx_a=None, wx_b=None):
     """One problem of a grouped launch.  segs: one or two (A, lda, B, ldb, K) tuples chained into the same accumulators; C (and C2 for
     columns >= n_split): 2-D row-major destinations (row stride = .stride(0))."""
     pr = _GemmProb()
@@ -421,6 +421,7 @@ def gemm_prob(segs, C, M, N, bias=None, accumulate=False, C2=None, n_split=0):
         pr.C2, pr.ldc2, pr.n_split = _dp(C2), int(C2.stride(0)), int(n_split)
     pr.accumulate = int(bool(accumulate))
     pr.bias = _dp(bias)
+    pr.pairs, pr.wx_a, pr.wx_b = int(bool(pairs)), _dp(wx_a), _dp(wx_b)
     return pr
 
 
@@ -561,12 +562,33 @@ class TokenTablesFn(Function):
         return tuple(outs)
 
 
+def weight_exp2(w1, w2):
+    """ONE exponent record for two matrices (their joint largest magnitude: cpg_weight_exp2)."""
+    w1, l1 = _rowmajor(w1)
+    w2, l2 = _rowmajor(w2)
+    out = torch.empty(int(query("cpg_weight_exp_bytes")) // 4, device=w1.device, dtype=torch.int32)
+    call("cpg_weight_exp2", _p(w1), w1.shape[0], w1.shape[1], l1, _p(w2), w2.shape[0], w2.shape[1], l2, _p(out), _stream())
+    return out
+
+
+def transpose_pad(src, Rpad=None, out=None):
+    """out[c][r] = src[r][c], zeros for rows R <= r < Rpad (cpg_transpose_pad): a k-rows operand as K-contiguous, slab-padded rows."""
+    src, lds = _ld(src)
+    R, C = src.shape
+    Rpad = R if Rpad is None else int(Rpad)
+    if out is None:
+        out = torch.empty(C, Rpad, device=src.device, dtype=torch.float32)
+    call("cpg_transpose_pad", _p(src), lds, R, C, _p(out), int(out.stride(0)), Rpad, _stream())
+    return out
+
+
 class EncoderHeadsFn(Function):
     """(mu, logvar) = (h Wmu^T + bmu, h Wlv^T + blv) with h = [hf | hr] - the encoder's two final states, never concatenated - in ONE
     launch (models/encoder.py:35-36,46-51; cpg_gemm_group: two problems of two chained segments each).  Backward: dh = dmu Wmu + dlv Wlv
-    as one chained product whose columns go straight to (dhf, dhr), the two weight gradients as one grouped launch (four problems), the
-    two bias gradients as column sums - three launches in place of four products, two split-K reductions, four column-sum launches, two
-    adds and two slicing copies."""
+    as one chained product whose columns go straight to (dhf, dhr), the two weight gradients as one grouped launch, the two bias
+    gradients as column sums.  Where the shapes allow (batch and widths multiples of 32, aligned rows) all three products run the
+    direct-to-LDS loop on f16 pairs (csrc/gemm.hip: gemm_group_dl_kernel<., ., 4>) - the k-rows operands of the two backward products
+    are transposed into K-contiguous, slab-padded rows first (bandwidth passes of a few MB)."""
 
     @staticmethod
     def forward(ctx, hf, hr, wmu, bmu, wlv, blv):
@@ -578,38 +600,36 @@ class EncoderHeadsFn(Function):
         Hr = hrc.shape[1] if hrc is not None else 0
         assert wmu.shape[1] == H + Hr and wmu.stride(1) == 1 and wlv.stride(1) == 1
         out = torch.empty(2, B, Z, device=hf.device, dtype=torch.float32)
+        # f16-pair form: states (|h| <= 1) against weights scaled by ONE power of two for both heads (their joint largest magnitude)
+        fast = (B % 32 == 0 and H % 32 == 0 and Hr % 32 == 0 and B >= 64 and Z >= 32
+                and _os.environ.get("CPG_HEADS_EXACT", "") == "")
+        wx = weight_exp2(wmu, wlv) if fast else None
         probs = []
         for k, (w, b) in enumerate(((wmu, bmu), (wlv, blv))):
             segs = [(hfc, ldf, w[:, :H], w.stride(0), H)]
             if hrc is not None:
                 segs.append((hrc, ldr, w[:, H:], w.stride(0), Hr))
-            probs.append(gemm_prob(segs, out[k], B, Z, bias=b))
+            probs.append(gemm_prob(segs, out[k], B, Z, bias=b, pairs=fast, wx_b=wx))
         gemm_group(NT, probs)
-        ctx.save_for_backward(hfc, hrc, wmu, wlv)
+        ctx.save_for_backward(hfc, hrc, wmu, wlv, wx)
         ctx.leaves = (wmu, bmu, wlv, blv)
+        ctx.fast = fast
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, dmu, dlv):
-        hf, hr, wmu, wlv = ctx.saved_tensors
+        hf, hr, wmu, wlv, wx = ctx.saved_tensors
         B, H = hf.shape
         Hr = hr.shape[1] if hr is not None else 0
         Z = wmu.shape[0]
         dev = hf.device
         if dmu is None and dlv is None:
             return None, None, None, None, None, None
+        pair = _take_padded_pair(dmu, dlv) if ctx.fast else None
         if dmu is None:
             dmu = torch.zeros(B, Z, device=dev)
         if dlv is None:
             dlv = torch.zeros(B, Z, device=dev)
-        dmu, ldm = _ld(dmu)
-        dlv, ldl = _ld(dlv)
-        dhf = dhr = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dhf = torch.empty(B, H, device=dev, dtype=torch.float32)
-            dhr = torch.empty(B, Hr, device=dev, dtype=torch.float32) if hr is not None else None
-            gemm_group(NN, [gemm_prob([(dmu, ldm, wmu, wmu.stride(0), Z), (dlv, ldl, wlv, wlv.stride(0), Z)], dhf, B, H + Hr,
-                                      C2=dhr, n_split=H)])
         lw = ctx.leaves
         g = [_grad_buf(p) for p in lw]
         direct = all(x is not None for x in g)
@@ -617,13 +637,46 @@ class EncoderHeadsFn(Function):
         dwlv = g[2] if direct else torch.empty_like(wlv)
         dbmu = g[1] if direct else torch.empty(Z, device=dev, dtype=torch.float32)
         dblv = g[3] if direct else torch.empty(Z, device=dev, dtype=torch.float32)
-        probs = []
-        for dy, ldy, dw in ((dmu, ldm, dwmu), (dlv, ldl, dwlv)):
-            probs.append(gemm_prob([(dy, ldy, hf, hf.stride(0), B)], dw[:, :H], Z, H, accumulate=direct))
+        need_dh = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dhf = torch.empty(B, H, device=dev, dtype=torch.float32) if need_dh else None
+        dhr = torch.empty(B, Hr, device=dev, dtype=torch.float32) if (need_dh and hr is not None) else None
+        if ctx.fast:
+            Zp = -(-Z // 32) * 32
+            if pair is None:      # gradients that did not come from LatentFn.backward: pad them here
+                pair = torch.zeros(B, 2, Zp, device=dev, dtype=torch.float32)
+                pair[:, 0, :Z].copy_(dmu)
+                pair[:, 1, :Z].copy_(dlv)
+            d2 = pair.view(B, 2 * Zp)
+            wxd = weight_exp(d2)                      # ONE power of two for the gradient pair (its largest magnitude)
+            if need_dh:
+                # dh = [dmu | dlv] [Wmu ; Wlv]: NT over the transposed, row-padded weights
+                wT = torch.empty(2, H + Hr, Zp, device=dev, dtype=torch.float32)
+                transpose_pad(wmu, Zp, out=wT[0])
+                transpose_pad(wlv, Zp, out=wT[1])
+                gemm_group(NT, [gemm_prob([(d2, 2 * Zp, wT[0], Zp, Zp), (d2[:, Zp:], 2 * Zp, wT[1], Zp, Zp)], dhf, B, H + Hr, C2=dhr, n_split=H,
+                                          pairs=True, wx_a=wxd, wx_b=wx)])
+            # dW_s = d_s^T h: NT over the transposed gradient pair [2 Zp, B] and the transposed states [H + Hr, B]
+            dT = transpose_pad(d2)
+            hT = torch.empty(H + Hr, B, device=dev, dtype=torch.float32)
+            transpose_pad(hf, out=hT[:H])
             if hr is not None:
-                probs.append(gemm_prob([(dy, ldy, hr, hr.stride(0), B)], dw[:, H:], Z, Hr, accumulate=direct))
-        gemm_group(TN, probs)
-        colsum_multi([dmu, dlv], [dbmu, dblv], accumulate=direct)
+                transpose_pad(hr, out=hT[H:])
+            gemm_group(NT, [gemm_prob([(dT[s * Zp:], B, hT, B, B)], dw, Z, H + Hr, accumulate=direct, pairs=True, wx_a=wxd)
+                            for s, dw in ((0, dwmu), (1, dwlv))])
+            colsum_multi([d2[:, :Z], d2[:, Zp:Zp + Z]], [dbmu, dblv], accumulate=direct)
+        else:
+            dmu, ldm = _ld(dmu)
+            dlv, ldl = _ld(dlv)
+            if need_dh:
+                gemm_group(NN, [gemm_prob([(dmu, ldm, wmu, wmu.stride(0), Z), (dlv, ldl, wlv, wlv.stride(0), Z)], dhf, B, H + Hr,
+                                          C2=dhr, n_split=H)])
+            probs = []
+            for dy, ldy, dw in ((dmu, ldm, dwmu), (dlv, ldl, dwlv)):
+                probs.append(gemm_prob([(dy, ldy, hf, hf.stride(0), B)], dw[:, :H], Z, H, accumulate=direct))
+                if hr is not None:
+                    probs.append(gemm_prob([(dy, ldy, hr, hr.stride(0), B)], dw[:, H:], Z, Hr, accumulate=direct))
+            gemm_group(TN, probs)
+            colsum_multi([dmu, dlv], [dbmu, dblv], accumulate=direct)
         if direct:
             return dhf, dhr, None, None, None, None
         return dhf, dhr, dwmu, dbmu, dwlv, dblv
@@ -1739,6 +1792,23 @@ class LatentTermsFn(Function):
         return dmu, dlv, None
 
 
+_PADDED_PAIRS = {}   # data_ptr -> [B, 2, Zp] buffer whose halves LatentFn.backward returned as (dmu, dlogvar): taken by EncoderHeadsFn.backward
+
+
+def _take_padded_pair(dmu, dlv):
+    """The zero-padded [B, 2, Zp] buffer behind (dmu, dlv) if they are exactly the two views LatentFn.backward handed out, else None."""
+    if dmu is None or dlv is None or dmu.dim() != 2:
+        return None
+    buf = _PADDED_PAIRS.pop(dmu.data_ptr(), None)
+    _PADDED_PAIRS.clear()
+    if buf is None:
+        return None
+    Zp = buf.shape[2]
+    ok = (dmu.shape == dlv.shape and dmu.stride() == (2 * Zp, 1) and dlv.stride() == (2 * Zp, 1) and dmu.shape[0] == buf.shape[0]
+          and dlv.data_ptr() == dmu.data_ptr() + 4 * Zp)
+    return buf if ok else None
+
+
 class LatentFn(Function):
     """The latent block of a training step as ONE node (cpg_latent_fused_fwd / _bwd): z = mu + exp(logvar / 2) eps
     (RNN_VAE.sample_z, models/model.py:107-112), c ~ Cat(.5,.5) (sample_c_prior :121-126) or a given c, the decoder's initial state /
@@ -1789,9 +1859,15 @@ class LatentFn(Function):
         if dzc is not None:
             dzc, ldzc = _ld(dzc)
         gs = [g.contiguous() if g is not None else None for g in (g_kl, g_klmu, g_l1)]
-        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        # dmu / dlogvar as the two halves of ONE row-padded buffer [B, 2, Zp] (Zp = Z rounded up to whole 32-deep slabs, zeros behind
+        # column Z): what the encoder heads' backward products contract over, read as it lies (EncoderHeadsFn.backward)
+        Zp = -(-Z // 32) * 32
+        pair = torch.empty(B, 2, Zp, device=mu.device, dtype=torch.float32)
+        dmu, dlv = pair[:, 0, :Z], pair[:, 1, :Z]
         call("cpg_latent_fused_bwd", _p(dz), _p(dzc), int(ldzc), _p(mu), _p(logvar), _p(eps), B, Z, _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(dmu),
-             _p(dlv), _stream())
+             _p(dlv), 2 * Zp, Zp, _stream())
+        _PADDED_PAIRS.clear()
+        _PADDED_PAIRS[pair.data_ptr()] = pair
         return dmu, dlv, None, None, None
 
 

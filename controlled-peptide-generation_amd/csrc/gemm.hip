@@ -372,7 +372,10 @@ struct GemmProb {            // mirrors CpgGemmProb of include/cpg_api.h field f
     int ldc, ldc2, n_split;
     int accumulate;
     const float* bias;
-    const void* reserved;
+    const int* wx_a;         // exponent records (cpg_weight_exp) of the A / B operands of BOTH segments, or null (2^0): a group whose every
+    const int* wx_b;         // problem carries one for each side that needs it runs the NT form on f16 pairs (below)
+    int pairs;               // 1: the caller vouches for f16-pair products of this problem (form 0 only)
+    int pad_;
 };
 struct GemmGroup {
     GemmProb p[GEMM_GROUP_MAX];
@@ -467,6 +470,107 @@ __global__ __launch_bounds__(TC::NT) void gemm_group_kernel(GemmGroup G, RfEpi E
         }
 }
 
+// ---- the NT form on the direct-to-LDS loop (gemm_core.h: DlLoop<64, 64, 3, 0>, the BPTT step's main loop): both operands go global -> LDS by
+// LDS-DMA three slabs deep, no staging registers - a slab costs ~0.3 us against 1.5-3 us on the register-staged loop, which is what
+// bounds these mid-sized products (16-64 slabs per workgroup, one round of workgroups: a latency chain).  Exact-f32 MFMA in MainLoop's
+// contraction order: the sums are gemm_group_kernel's.  Needs 16-byte aligned rows and contractions that are multiples of 32 (the
+// launcher checks); M / N tails are handled by clamping the rows the LDS-DMA reads and masking the stores.
+// PREC 4: the same loop with the f32 slab values split into f16 pairs where the fragments are read (three f16 MFMAs per block in place
+// of eight f32 ones: the exact form is bound by the f32 matrix pipe - 48 us for the encoder heads' 4.3 GFLOP).  Each operand is
+// multiplied by a power of two from its exponent record first (its largest magnitude -> [2^13, 2^14): weights AND gradient matrices;
+// values more than 2^16 below an operand's largest keep an absolute precision of 2^-39 of it), the result by the inverse.
+template <int BM, int BN, int PREC>
+__global__ __launch_bounds__(256) void gemm_group_dl_kernel(GemmGroup G) {
+    using DL = DlLoop<BM, BN, 3, PREC>;
+    constexpr int MI = DL::MI, NI = DL::NI;
+    extern __shared__ __attribute__((aligned(16))) float cpg_smem[];
+    const int t = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_GROUP_MAX; ++i)
+        if (i < G.n && t >= G.tile0[i]) pi = i;
+    const GemmProb& g = G.p[pi];
+    const int tl = t - G.tile0[pi];
+    const int by = tl / G.tiles_n[pi], bx = tl - by * G.tiles_n[pi];
+    const int m0 = by * BM, n0 = bx * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int M = g.M, N = g.N;
+    float back = 1.f;
+    DlPairScale ps{1.f, 1.f};
+    if constexpr (PREC == 4) {
+        const int ea = g.wx_a ? weight_exp_from_parts(g.wx_a) : 0, eb = g.wx_b ? weight_exp_from_parts(g.wx_b) : 0;
+        ps.a = pair_pow2(ea);
+        ps.b = pair_pow2(eb);
+        back = pair_pow2(-ea) * pair_pow2(-eb);
+    }
+    for (int sg = 0; sg < 2; ++sg) {
+        const int K = g.K[sg];
+        if (K <= 0) break;
+        if (sg) __syncthreads();      // the ring is reused: every fragment read of the first segment is done
+        const float* A = g.A[sg];
+        const float* B = g.B[sg];
+        const size_t lda = (size_t)g.lda[sg], ldb = (size_t)g.ldb[sg];
+        auto ar = [&](int i, int r) { return A + (size_t)min(m0 + 32 * i + r, M - 1) * lda; };
+        auto br = [&](int i, int r) { return B + (size_t)min(n0 + 32 * i + r, N - 1) * ldb; };
+        if constexpr (PREC == 4) DL::run(A, lda, B, ldb, K, cpg_smem, acc, -1, []() {}, [](int) { return true; }, ps, ar, br);
+        else DL::run(A, lda, B, ldb, K, cpg_smem, acc, -1, []() {}, [](int) { return true; }, DlNoScale{}, ar, br);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = n0 + wn * (BN / 2) + ni * 16 + l15;
+            if (col >= N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+            float* dst = g.C;
+            int ld = g.ldc, c = col;
+            if (g.C2 && col >= g.n_split) { dst = g.C2; ld = g.ldc2; c = col - g.n_split; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * (BM / 2) + mi * 16 + 4 * lq + r;
+                if (row >= M) continue;
+                const size_t o = (size_t)row * ld + c;
+                float v = acc[mi][ni][r] * back + bv;
+                if (g.accumulate) v += dst[o];
+                dst[o] = v;
+            }
+        }
+}
+// the direct-to-LDS form covers a group whose every segment has 16-byte aligned rows and a contraction of whole 32-deep slabs
+static bool group_dl_ok(const GemmGroup& G) {
+    for (int i = 0; i < G.n; ++i) {
+        const GemmProb& g = G.p[i];
+        if (g.M < 32 || g.N < 32) return false;
+        for (int sg = 0; sg < 2 && g.K[sg] > 0; ++sg)
+            if (g.K[sg] % 32 || g.lda[sg] % 4 || g.ldb[sg] % 4 || !aligned16(g.A[sg]) || !aligned16(g.B[sg])) return false;
+    }
+    return true;
+}
+static int launch_group_dl(GemmGroup& G, hipStream_t s) {
+    constexpr int BM = 64, BN = 64;
+    int tiles = 0;
+    for (int i = 0; i < G.n; ++i) {
+        G.tile0[i] = tiles;
+        G.tiles_n[i] = cdiv(G.p[i].N, BN);
+        tiles += G.tiles_n[i] * cdiv(G.p[i].M, BM);
+    }
+    G.tile0[G.n] = tiles;
+    const size_t smem = DlLoop<BM, BN, 3, 0>::smem_floats() * sizeof(float);
+    bool pairs = true;
+    for (int i = 0; i < G.n; ++i) pairs = pairs && G.p[i].pairs != 0;
+    if (pairs) hipLaunchKernelGGL((gemm_group_dl_kernel<BM, BN, 4>), dim3(tiles), dim3(256), smem, s, G);
+    else hipLaunchKernelGGL((gemm_group_dl_kernel<BM, BN, 0>), dim3(tiles), dim3(256), smem, s, G);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 template <class TC, bool A_KC, bool B_KC, int EPI = 0>
 static int launch_group(GemmGroup& G, bool vec, hipStream_t s, RfEpi E = RfEpi{}) {
     int tiles = 0;
@@ -538,6 +642,9 @@ static int gemm_group(GemmGroup& G, hipStream_t s) {
         maxN = g.N > maxN ? g.N : maxN;
         t64 += (long)cdiv(g.M, 64) * cdiv(g.N, 64);
         for (int sg = 0; sg < 2 && g.K[sg] > 0; ++sg) maxK = g.K[sg] > maxK ? g.K[sg] : maxK;
+    }
+    if constexpr (A_KC && B_KC) {
+        if (group_dl_ok(G) && !(cpg_opt(OPT_GEMM_TILE).set)) return launch_group_dl(G, s);
     }
     // tiles as launch_gemm picks them for one problem, on the group's totals (tools/gbench.py, tools/lin_sweep.py)
     if (maxM <= 32) return launch_group<T32x128, A_KC, B_KC>(G, vec, s);
@@ -801,8 +908,63 @@ CPG_EXPORT int cpg_colsum_multi(int nmat, const void* const* X, const int* ld, i
     return 0;
 }
 
+// ---- dst[c][r] = src[r][c] (r < R, c < C), zeros for R <= r < Rpad: operands of the NN / TN forms turned into K-contiguous rows
+// (padded to whole 32-deep slabs) for the direct-to-LDS NT loop.  32 x 32 tiles through LDS.
+__global__ void transpose_pad_kernel(const float* __restrict__ src, int lds, int R, int C, float* __restrict__ dst, int ldd, int Rpad) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * lds + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < C && r < Rpad) dst[(size_t)c * ldd + r] = tile[threadIdx.x][i];
+    }
+}
+CPG_EXPORT int cpg_transpose_pad(const float* src, int lds, int R, int C, float* dst, int ldd, int Rpad, void* stream) {
+    CPG_CHECK_ARG(src && dst && R > 0 && C > 0 && lds >= C && Rpad >= R && ldd >= Rpad);
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(cdiv(C, 32), cdiv(Rpad, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, lds, R, C, dst, ldd, Rpad);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- largest magnitude of a weight matrix, for the engines that split weights into f16 pairs (gemm_core.h: weight_exp_from_parts).
 // Block b takes rows b, b + WX_PARTS, ...; 16-byte loads where the rows allow them.  wx[b] = float bits of the block's maximum.
+__device__ __forceinline__ float absmax_part(const float* __restrict__ w, int rows, int cols, int ld, int vec);
+__global__ __launch_bounds__(1024) void weight_absmax2_kernel(const float* __restrict__ w1, int rows1, int cols1, int ld1, int vec1,
+                                                               const float* __restrict__ w2, int rows2, int cols2, int ld2, int vec2,
+                                                               int* __restrict__ wx) {
+    __shared__ float red[16];
+    float m = absmax_part(w1, rows1, cols1, ld1, vec1);
+    if (w2) m = fmaxf(m, absmax_part(w2, rows2, cols2, ld2, vec2));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t = fmaxf(t, red[k]);
+        wx[blockIdx.x] = __builtin_bit_cast(int, t);
+    }
+}
+__device__ __forceinline__ float absmax_part(const float* __restrict__ w, int rows, int cols, int ld, int vec) {
+    float m = 0.f;
+    if (vec) {
+        const int q4 = cols >> 2;
+        const int nr = (rows - (int)blockIdx.x + WX_PARTS - 1) / WX_PARTS;
+        for (int i = threadIdx.x; i < nr * q4; i += 1024) {
+            const int rr = i / q4, c = i - rr * q4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + (size_t)(blockIdx.x + rr * WX_PARTS) * ld + 4 * c);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    } else {
+        for (int r = blockIdx.x; r < rows; r += WX_PARTS)
+            for (int c = threadIdx.x; c < cols; c += 1024) m = fmaxf(m, fabsf(w[(size_t)r * ld + c]));
+    }
+    return m;
+}
 __global__ __launch_bounds__(1024) void weight_absmax_kernel(const float* __restrict__ w, int rows, int cols, int ld, int vec, int* __restrict__ wx) {
     __shared__ float red[16];
     float m = 0.f;
@@ -838,6 +1000,16 @@ int cpg_weight_absmax(const float* w, int rows, int cols, int ld, int* wx, hipSt
 // C ABI: the exponent record (cpg_weight_exp_bytes() bytes, device memory) of a weight matrix [rows, cols] (row stride ld) - what the
 // entry points that split weights into f16 pairs on the fly take as `wx` (cpg_gru_step_fwd, cpg_gru_seq_fwd, cpg_linear_fwd_pairs)
 CPG_EXPORT size_t cpg_weight_exp_bytes(void) { return WX_PARTS * sizeof(int); }
+// ONE record for two matrices (their joint largest magnitude): operands that enter the same accumulators as two chained segments
+CPG_EXPORT int cpg_weight_exp2(const float* w1, int rows1, int cols1, int ld1, const float* w2, int rows2, int cols2, int ld2, void* wx,
+                               void* stream) {
+    CPG_CHECK_ARG(w1 && w2 && wx && rows1 > 0 && cols1 > 0 && ld1 >= cols1 && rows2 > 0 && cols2 > 0 && ld2 >= cols2);
+    const int v1 = (cols1 % 4 == 0 && ld1 % 4 == 0 && aligned16(w1)) ? 1 : 0, v2 = (cols2 % 4 == 0 && ld2 % 4 == 0 && aligned16(w2)) ? 1 : 0;
+    hipLaunchKernelGGL(weight_absmax2_kernel, dim3(WX_PARTS), dim3(1024), 0, (hipStream_t)stream, w1, rows1, cols1, ld1, v1, w2, rows2, cols2, ld2,
+                       v2, (int*)wx);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
 CPG_EXPORT int cpg_weight_exp(const float* w, int rows, int cols, int ld, void* wx, void* stream) {
     return cpg_weight_absmax(w, rows, cols, ld, (int*)wx, (hipStream_t)stream);
 }

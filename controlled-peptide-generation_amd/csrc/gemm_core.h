@@ -909,6 +909,9 @@ __device__ __forceinline__ f32x4 acc_block_to_rows(float* tb, const f32x4 v, int
 // 48 matrix-pipe cycles per block and slab in place of the 268 of eight f32 MFMAs.  `pre(kt)` runs ahead of slab kt's products
 // (the caller rescales its accumulators when the operands' power-of-two scale changes along k) and returns false to skip them.
 struct DlNoScale {};   // DlLoop::run without a fragment-scale hook
+struct DlPairScale {   // PREC 4: powers of two the A / B operand values are multiplied by before their f16-pair split (passed in the fscale slot)
+    float a, b;
+};
 template <int BM, int BN, int NS = 3, int PREC = 0>
 struct DlLoop {
     static constexpr int MI = BM / 32, NI = BN / 32;
@@ -942,7 +945,16 @@ struct DlLoop {
     template <class Hook, class E, class Pre, class FS, class AR>
     __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
                                                f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre, FS&& fscale, AR&& arow) {
-        static_assert((PREC >= 2) == (sizeof(E) == 2), "PREC 2 / 3 <-> 16-bit operands in memory");
+        run(A, lda, Bt, ldb, K, smem, acc, hook_kt, hook, pre, fscale, arow, DlNoScale{});
+    }
+    // brow (optional): the same for the B operand's rows (tile column 32 i + r) - products whose N is no multiple of the tile clamp
+    // the rows past it onto the last valid one (round 6: the grouped nn.Linear-shaped launches)
+    template <class Hook, class E, class Pre, class FS, class AR, class BR>
+    __device__ static __forceinline__ void run(const E* A, size_t lda, const E* Bt, size_t ldb, int K, float* smem,
+                                               f32x4 (&acc)[MI][NI], int hook_kt, Hook&& hook, Pre&& pre, FS&& fscale, AR&& arow, BR&& brow) {
+        static_assert((PREC == 2 || PREC == 3) == (sizeof(E) == 2), "PREC 2 / 3 <-> 16-bit operands in memory");
+        float pscale_a = 1.f, pscale_b = 1.f;
+        if constexpr (__is_same(__remove_cvref(FS), DlPairScale)) { pscale_a = fscale.a; pscale_b = fscale.b; }
         constexpr int EPC = 16 / (int)sizeof(E);   // elements per 16-byte chunk
         constexpr int BKE = 8 * EPC;               // elements per slab (a row of a slab is always 128 bytes)
         // (a 512-thread workgroup runs two of these loops side by side - its two 256-thread halves, each on its own ring and its
@@ -962,13 +974,19 @@ struct DlLoop {
             if constexpr (__is_same(__remove_cvref(AR), DlNoScale)) gar[i] = ga + i * ga32;
             else gar[i] = arow(i, srow) + EPC * sch;
         }
+        const E* gbr[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if constexpr (__is_same(__remove_cvref(BR), DlNoScale)) gbr[i] = gb + i * gb32;
+            else gbr[i] = brow(i, srow) + EPC * sch;
+        }
         auto issue = [&](int kt, float* stage) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 __builtin_amdgcn_global_load_lds(gar[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                __builtin_amdgcn_global_load_lds(gb + i * gb32 + kt * BKE, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gbr[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
         };
         // fragment word offsets inside a stage (slab-invariant): row r of block mi / ni, k-chunk q = 4h + lq -> slot q ^ f(r)
         const int ra = wm * (BM / 2) + l15, rbn = wn * (BN / 2) + l15;
@@ -1061,6 +1079,43 @@ struct DlLoop {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            } else if constexpr (PREC == 4) {
+                // f32 operands in LDS, split into f16 pairs where the fragments are read: lane group lq takes k = 4 lq .. + 3 and
+                // 16 + 4 lq .. + 3 of the slab for BOTH operands (any k order the two sides share is a dot product), times the
+                // operands' powers of two (pscale_a / pscale_b: exact), three f16 MFMAs per block (lo x hi, hi x lo, hi x hi)
+                cpg_f16x8 fa[2][MI], fb[2][NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(cur + oa0 + mi * 512) * pscale_a;
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(cur + oa1 + mi * 512) * pscale_a;
+                    uint32_t h[4], l[4];
+                    split2h_pair(x0[0], x0[1], h[0], l[0]);
+                    split2h_pair(x0[2], x0[3], h[1], l[1]);
+                    split2h_pair(x1[0], x1[1], h[2], l[2]);
+                    split2h_pair(x1[2], x1[3], h[3], l[3]);
+                    fa[0][mi] = __builtin_bit_cast(cpg_f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+                    fa[1][mi] = __builtin_bit_cast(cpg_f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(cur + ob0 + ni * 512) * pscale_b;
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(cur + ob1 + ni * 512) * pscale_b;
+                    uint32_t h[4], l[4];
+                    split2h_pair(x0[0], x0[1], h[0], l[0]);
+                    split2h_pair(x0[2], x0[3], h[1], l[1]);
+                    split2h_pair(x1[0], x1[1], h[2], l[2]);
+                    split2h_pair(x1[2], x1[3], h[3], l[3]);
+                    fb[0][ni] = __builtin_bit_cast(cpg_f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+                    fb[1][ni] = __builtin_bit_cast(cpg_f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+                }
+                constexpr int HA[3] = {1, 0, 0}, HB[3] = {0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[HA[t]][mi], fb[HB[t]][ni], acc[mi][ni], 0, 0, 0);
             } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {

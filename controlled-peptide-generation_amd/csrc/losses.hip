@@ -478,29 +478,38 @@ CPG_EXPORT int cpg_latent_fused_fwd(const float* mu, const float* logvar, const 
 }
 // dmu = dzt + g_kl mu / B ;  dlogvar = dzt eps exp(logvar / 2) / 2 + ((g_kl + g_klmu) (e^logvar - 1) / 2 + g_l1 sign(logvar)) / B
 // with dzt = dz + dzc[:, :Z] (either may be null); g_* device scalars or null.
+// dmu / dlv rows have stride ldo >= Zp and are written for Zp >= Z columns, zeros from column Z on (Zp > Z: the padded pair
+// [dmu | dlv] the encoder heads' backward products read as whole 32-deep slabs)
 __global__ void latent_fused_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dzc, int ldzc, const float* __restrict__ mu,
                                         const float* __restrict__ lv, const float* __restrict__ eps, int B, int Z, float invB,
                                         const float* g_kl, const float* g_klmu, const float* g_l1, float* __restrict__ dmu,
-                                        float* __restrict__ dlv) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * Z) return;
+                                        float* __restrict__ dlv, int ldo, int Zp) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * Zp) return;
+    const size_t row = t / Zp;
+    const int j = (int)(t - row * Zp);
+    const size_t o = row * ldo + j;
+    if (j >= Z) {
+        dmu[o] = 0.f;
+        dlv[o] = 0.f;
+        return;
+    }
+    const size_t i = row * Z + j;
     const float a = g_kl ? g_kl[0] : 0.f, b = g_klmu ? g_klmu[0] : 0.f, c = g_l1 ? g_l1[0] : 0.f;
-    const size_t row = i / Z;
-    const int j = (int)(i - row * Z);
     float d = dz ? dz[i] : 0.f;
     if (dzc) d += dzc[row * ldzc + j];
     const float l = lv[i];
     const float sgn = (l > 0.f) ? 1.f : ((l < 0.f) ? -1.f : 0.f);
-    dmu[i] = d + a * mu[i] * invB;
-    dlv[i] = d * eps[i] * 0.5f * expf(l * 0.5f) + ((a + b) * 0.5f * (expf(l) - 1.f) + c * sgn) * invB;
+    dmu[o] = d + a * mu[i] * invB;
+    dlv[o] = d * eps[i] * 0.5f * expf(l * 0.5f) + ((a + b) * 0.5f * (expf(l) - 1.f) + c * sgn) * invB;
 }
 CPG_EXPORT int cpg_latent_fused_bwd(const float* dz, const float* dzc, int ldzc, const float* mu, const float* logvar, const float* eps,
                                     int B, int Z, const float* g_kl, const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar,
-                                    void* stream) {
-    CPG_CHECK_ARG(mu && logvar && eps && dmu && dlogvar && B > 0 && Z > 0 && (!dzc || ldzc >= Z));
-    const size_t n = (size_t)B * Z;
+                                    int ldo, int Zp, void* stream) {
+    CPG_CHECK_ARG(mu && logvar && eps && dmu && dlogvar && B > 0 && Z > 0 && (!dzc || ldzc >= Z) && Zp >= Z && ldo >= Zp);
+    const size_t n = (size_t)B * Zp;
     hipLaunchKernelGGL(latent_fused_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz, dzc, ldzc, mu, logvar,
-                       eps, B, Z, 1.f / (float)B, g_kl, g_klmu, g_l1, dmu, dlogvar);
+                       eps, B, Z, 1.f / (float)B, g_kl, g_klmu, g_l1, dmu, dlogvar, ldo, Zp);
     CPG_LAUNCH_CHECK();
     return 0;
 }

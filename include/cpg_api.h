@@ -64,6 +64,9 @@ CPG_API int cpg_linear_fwd(const float* X, int ldx, const float* W, int ldw, con
  * take the record as `wx` and run their bf16x3 / exact-f32 engine without it. */
 CPG_API size_t cpg_weight_exp_bytes(void);
 CPG_API int cpg_weight_exp(const float* w, int rows, int cols, int ld, void* wx, void* stream);
+/* one record for TWO matrices (their joint largest magnitude): operands chained into the same accumulators */
+CPG_API int cpg_weight_exp2(const float* w1, int rows1, int cols1, int ld1, const float* w2, int rows2, int cols2, int ld2, void* wx,
+                            void* stream);
 /* cpg_linear_fwd for an input whose magnitudes are O(1) - recurrent states (|x| < 65504; absolute precision 2^-25 below 2^-14): large
  * products run on f16 pairs (three f16 MFMAs per block), same results within f32 rounding.  The caller vouches for the INPUT's range;
  * the weights' range is covered by wx = cpg_weight_exp(W) (null: exact-f32 engine). */
@@ -75,7 +78,9 @@ CPG_API int cpg_linear_fwd_pairs(const float* X, int ldx, const float* W, int ld
  * of two tensors needs no cat; dX = dY1 W1 + dY2 W2 is one product) and send result columns >= n_split to a second destination (the
  * gradient of a concatenation needs no slicing copies).  form: 0 = NT  C[M,N] (+)= sum_s A_s[M,K_s] B_s[N,K_s]^T (+ bias);
  * 1 = NN  C (+)= sum_s A_s[M,K_s] B_s[K_s,N] (+ bias);  2 = TN  C (+)= sum_s A_s[K_s,M]^T B_s[K_s,N] (no bias).  Same engines and
- * sums as cpg_linear_fwd / _bwd_input / _bwd_weight.  probs: nprob records of cpg_gemm_group_prob_bytes() bytes each. */
+ * sums as cpg_linear_fwd / _bwd_input / _bwd_weight - except form 0 problems flagged `pairs` (all of a group), which run the direct-to-LDS
+ * loop on f16 pairs (22-bit operands, f32 accumulation: f32-grade like the recurrent products).  probs: nprob records of
+ * cpg_gemm_group_prob_bytes() bytes each. */
 typedef struct CpgGemmProb {
     const float* A[2];
     const float* B[2];
@@ -86,7 +91,10 @@ typedef struct CpgGemmProb {
     int ldc, ldc2, n_split;
     int accumulate;
     const float* bias;          /* [N], forms 0 / 1, or null */
-    const void* reserved;       /* null */
+    const void* wx_a;           /* form 0 with pairs = 1: exponent records (cpg_weight_exp over the operand) of A / B, or null (2^0: an */
+    const void* wx_b;           /* operand of O(1) magnitudes) */
+    int pairs;                  /* 1 (form 0, rows 16-byte aligned, K multiples of 32): f32-grade products on f16 pairs - three f16 MFMAs */
+    int pad_;                   /* per block on operands split in registers, each times the power of two of its record */
 } CpgGemmProb;
 CPG_API int cpg_gemm_group_prob_bytes(void);
 CPG_API int cpg_gemm_group(int form, int nprob, const void* probs, void* stream);
@@ -101,6 +109,9 @@ CPG_API int cpg_token_tables_bwd(int n, int V, int G, int E, const void* const* 
                                  size_t workspace_bytes, void* stream);
 /* out_i[N] (+)= column sums of X_i [M, N] (row stride ld[i]) for nmat <= 4 matrices in one single-stage launch (X / ld / out: HOST arrays) */
 CPG_API int cpg_colsum_multi(int nmat, const void* const* X, const int* ld, int M, int N, void* const* out, int accumulate, void* stream);
+/* dst[c][r] = src[r][c] for r < R, c < C; zeros for R <= r < Rpad (dst [C, ldd >= Rpad]): the k-rows operand of an NN / TN product as
+ * K-contiguous rows padded to whole 32-deep slabs, for cpg_gemm_group's direct-to-LDS NT form. */
+CPG_API int cpg_transpose_pad(const float* src, int lds, int R, int C, float* dst, int ldd, int Rpad, void* stream);
 /* dX[M,K] (+)= dY[M,N] W[N,K] */
 CPG_API int cpg_linear_bwd_input(const float* dY, int lddy, const float* W, int ldw, float* dX, int lddx, int M, int N,
                                  int K, int accumulate, void* stream);
@@ -507,7 +518,7 @@ CPG_API int cpg_latent_fused_fwd(const float* mu, const float* logvar, const flo
                                  float* z, float* zc, float* c_out, float* out5, float* workspace, void* stream);
 CPG_API int cpg_latent_fused_bwd(const float* dz, const float* dzc, int ldzc, const float* mu, const float* logvar, const float* eps,
                                  int B, int Z, const float* g_kl, const float* g_klmu, const float* g_l1, float* dmu, float* dlogvar,
-                                 void* stream);
+                                 int ldo /* row stride of dmu / dlogvar */, int Zp /* >= Z columns written, zeros from Z on */, void* stream);
 /* mmd_rf, losses.py:59-93: raw = z @ rf_w by cpg_matmul_nn; sums[R] = sum_b cos(raw/sigma + rf_b)*sqrt(2/R) */
 CPG_API int cpg_rf_feature_sums(const float* raw, const float* rf_b, int Bn, int R, float sigma, float* sums,
                                 float* workspace, size_t workspace_bytes, void* stream);
