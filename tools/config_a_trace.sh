@@ -22,7 +22,8 @@ PY
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if r['Kernel_Name'].replace('void ', '').startswith('adam_step')][2::3]
+nm = lambda r: r['Kernel_Name'].replace('void ', '')
+adam = [i for i, r in enumerate(rows) if nm(r).startswith('adam_segs')] or [i for i, r in enumerate(rows) if nm(r).startswith('adam_step')][2::3]
 lo, hi = adam[-21] + 1, adam[-1] + 1
 ks = rows[lo:hi]
 kt = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in ks) / 20e3
