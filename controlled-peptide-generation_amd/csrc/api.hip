@@ -21,7 +21,7 @@ CPG_EXPORT int cpg_version(void) { return CPG_ABI_VERSION; }
 // environment (CPG_<NAME IN CAPITALS>), afterwards changed only through cpg_set_option: no launch path calls getenv.
 static const char* const g_opt_names[OPT__COUNT] = {
     "gru_persist", "lstm_persist", "f32_engine", "lstm_persist_groups", "gru_fwd_bm", "gru_bwd_dl", "gru_bwd_tile", "gru_bwd_dl2", "gru_bwd_stagger", "gru_bwd_engine", "lstm_bwd_dl",
-    "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl", "bf16_store", "bf16_dg", "gru_ap", "gru_small_seq"};
+    "tn_tile", "tn_split", "gemm_tile", "dgi_mode", "mmd_dl", "bf16_store", "bf16_dg", "gru_ap", "gru_small_seq", "small_seq_rows"};
 static CpgOptVal g_opts[OPT__COUNT];
 static std::once_flag g_opts_once;
 static std::mutex g_opts_mu;   // cpg_set_option may run on one thread while launch paths on another (autograd's backward thread) read

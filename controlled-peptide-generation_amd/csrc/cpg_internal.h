@@ -65,6 +65,7 @@ enum CpgOpt {
     OPT_BF16_DG,          // 0: f32 gate gradients in the bf16 compute mode too (default there: bf16 where covered, see cpg_gru_dg_bf16)
     OPT_GRU_AP,           // 0: f32 gate gradients + ping-pong planes instead of the all-T planes form of the f16-pair BPTT chain (cpg_gru_ap_bytes)
     OPT_GRU_SMALL_SEQ,    // 0: per-step launches for small GRU recurrences too (default: whole-sequence launches, csrc/decode_fused.hip gru_seq_small_*)
+    OPT_SMALL_SEQ_ROWS,   // 16 | 32: batch rows per workgroup of those launches (default: 16 while every tile still gets its own CU)
     OPT__COUNT
 };
 struct CpgOptVal {
@@ -76,7 +77,7 @@ CpgOptVal cpg_opt(CpgOpt o);   // a copy, taken under the table's mutex (api.hip
 int cpg_persist_planes();      // operand planes of the persistent forward kernels now: 1 bf16 compute mode, 2 f16 pair, 3 bf16 triple
 // Whole-sequence launches for SMALL GRU recurrences in training (csrc/decode_fused.hip): hidden <= 128, token-table input (+ optional
 // per-row constant), dense batch, f32-grade mode.  One workgroup keeps a 32-row tile's state on its CU for all T steps with W_hh in
-// registers - the reference's default sizes (h = 80 / 102, batch 32) are otherwise one 8-20 us launch per time step and direction.
+// registers (16-row tiles while those still get a CU each) - the reference's default sizes (h = 80 / 102, batch 32) are otherwise one 8-20 us launch per time step and direction.
 struct CpgSmallFwdDir { const float* w_hh; const float* b_hh; const int32_t* tok; const float* tab; const float* rowc; float* hs; float* gates; int reverse; };
 struct CpgSmallBwdDir { const float* w_hh; const float* hs; const float* gates; const float* dhs_ext; const float* dh_last; float* dG; float* dh0; int reverse; };
 bool cpg_gru_small_seq_ok(int B, int H);

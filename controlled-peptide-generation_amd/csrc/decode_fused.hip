@@ -941,14 +941,15 @@ int device_limits(int* cus, int* lds) {
 //              over the 3H gate rows); the recurrent gate gradients of the tile live in LDS ([32][3H]), the carry z (.) dH and the
 //              cell's backward run in the accumulator layout on the wave's own hidden units: nothing but dG / dh0 leaves the CU.
 // Same arithmetic as the per-step kernels (csrc/gru.hip: the staged exact-f32 backward step; forward on f16 pairs as the decode kernels).
-constexpr int RS = 32;   // rows per workgroup tile
+// rows per workgroup tile: RS = 32, or 16 when that still fits one round of workgroups (a tile's step is bound by the instruction
+// stream of its four waves - one per SIMD - so half the rows are ~0.55 of the time: small batches spread over twice the CUs)
 
 struct SmallFwdArgs {
     CpgSmallFwdDir d[2];
-    int B, H, T, ntiles;
+    int B, H, T, ntiles, rs;
 };
 
-template <int G, int R>
+template <int G, int R, int RS>
 __global__ __launch_bounds__(256, 1) void gru_seq_small_fwd_kernel(SmallFwdArgs a) {
     using C = FusedCfg<G, R>;
     extern __shared__ float4 cpg_fused_smem[];
@@ -1044,12 +1045,12 @@ __global__ __launch_bounds__(256, 1) void gru_seq_small_fwd_kernel(SmallFwdArgs 
     }
 }
 
-static size_t small_fwd_lds(int ldh, int H, int T) { return ((size_t)2 * RS * ldh + (size_t)RS * 3 * H) * 4 + (size_t)T * RS * sizeof(int); }
+static size_t small_fwd_lds(int RS, int ldh, int H, int T) { return ((size_t)2 * RS * ldh + (size_t)RS * 3 * H) * 4 + (size_t)T * RS * sizeof(int); }
 
 template <int G, int R>
 int launch_small_fwd(const SmallFwdArgs& a, int ndir, int cus, hipStream_t s) {
-    const size_t bytes = small_fwd_lds(FusedCfg<G, R>::LDH, a.H, a.T);
-    auto kern = gru_seq_small_fwd_kernel<G, R>;
+    const size_t bytes = small_fwd_lds(a.rs, FusedCfg<G, R>::LDH, a.H, a.T);
+    auto kern = a.rs == 16 ? gru_seq_small_fwd_kernel<G, R, 16> : gru_seq_small_fwd_kernel<G, R, 32>;
     int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(kern), (int)bytes);
     if (rc) return rc;
     const int grid = a.ntiles < cus ? a.ntiles : cus;
@@ -1062,10 +1063,10 @@ int launch_small_fwd(const SmallFwdArgs& a, int ndir, int cus, hipStream_t s) {
 // is 16 (s >> 2) + 4 q + (s & 3) as in the exact-f32 form above.
 struct SmallBwdArgs {
     CpgSmallBwdDir d[2];
-    int B, H, T, ntiles, upw;   // upw: hidden units per wave (= fused_kp(H) / 4, the forward kernels' split)
+    int B, H, T, ntiles, upw, rs;   // upw: hidden units per wave (= fused_kp(H) / 4, the forward kernels' split)
 };
 
-template <int G3>
+template <int G3, int RS>
 __global__ __launch_bounds__(256, 1) void gru_seq_small_bwd_kernel(SmallBwdArgs a) {
     constexpr int KP3 = 16 * G3, KS3 = 4 * G3;
     constexpr int LDG = ((KP3 / 4 + 1) % 2 == 1) ? KP3 + 4 : KP3 + 8;   // row stride = 4 * odd (ds_read_b128 lane groups on disjoint banks)
@@ -1205,8 +1206,8 @@ template <int G3>
 int launch_small_bwd(const SmallBwdArgs& a, int ndir, int cus, hipStream_t s) {
     constexpr int KP3 = 16 * G3;
     constexpr int LDG = ((KP3 / 4 + 1) % 2 == 1) ? KP3 + 4 : KP3 + 8;
-    const size_t bytes = (size_t)RS * LDG * 4;
-    auto kern = gru_seq_small_bwd_kernel<G3>;
+    const size_t bytes = (size_t)a.rs * LDG * 4;
+    auto kern = a.rs == 16 ? gru_seq_small_bwd_kernel<G3, 16> : gru_seq_small_bwd_kernel<G3, 32>;
     int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(kern), (int)bytes);
     if (rc) return rc;
     const int grid = a.ntiles < cus ? a.ntiles : cus;
@@ -1218,6 +1219,12 @@ int launch_small_bwd(const SmallBwdArgs& a, int ndir, int cus, hipStream_t s) {
 }  // namespace
 
 // ---- whole-sequence training launches for small GRU recurrences (cpg_internal.h)
+// rows per tile: 16 while every 16-row tile of the launch still gets its own CU, else 32 (option small_seq_rows = 16 | 32 overrides)
+static int small_rows(int B, int ndir, int cus) {
+    const CpgOptVal o = cpg_opt(OPT_SMALL_SEQ_ROWS);
+    if (o.set && (o.i == 16 || o.i == 32)) return o.i;
+    return (long)cdiv(B, 16) * ndir <= cus ? 16 : 32;
+}
 bool cpg_gru_small_seq_ok(int B, int H) {
     const CpgOptVal o = cpg_opt(OPT_GRU_SMALL_SEQ);
     if (o.set && o.i == 0) return false;
@@ -1226,15 +1233,17 @@ bool cpg_gru_small_seq_ok(int B, int H) {
 int cpg_gru_small_seq_fwd(int T, int B, int H, int ndir, const CpgSmallFwdDir* d, hipStream_t s) {
     SmallFwdArgs a;
     for (int i = 0; i < 2; ++i) a.d[i] = d[i < ndir ? i : 0];
-    a.B = B; a.H = H; a.T = T; a.ntiles = cdiv(B, RS);
     const int cus = cpg_device_cus();
+    a.rs = small_rows(B, ndir, cus);
+    a.B = B; a.H = H; a.T = T; a.ntiles = cdiv(B, a.rs);
     CPG_FUSED_DISPATCH(launch_small_fwd, H, a, ndir, cus, s);
 }
 int cpg_gru_small_seq_bwd(int T, int B, int H, int ndir, const CpgSmallBwdDir* d, hipStream_t s) {
     SmallBwdArgs a;
     for (int i = 0; i < 2; ++i) a.d[i] = d[i < ndir ? i : 0];
-    a.B = B; a.H = H; a.T = T; a.ntiles = cdiv(B, RS); a.upw = fused_kp(H) / 4;
     const int cus = cpg_device_cus();
+    a.rs = small_rows(B, ndir, cus);
+    a.B = B; a.H = H; a.T = T; a.ntiles = cdiv(B, a.rs); a.upw = fused_kp(H) / 4;
     if (3 * H <= 96) return launch_small_bwd<6>(a, ndir, cus, s);
     if (3 * H <= 192) return launch_small_bwd<12>(a, ndir, cus, s);
     if (3 * H <= 288) return launch_small_bwd<18>(a, ndir, cus, s);

@@ -1091,6 +1091,7 @@ static TnPlan tn_plan(int M, int N, int K, bool pairs = false) {
     if (p.tile == TN_AUTO && M >= 512 && N >= 256 && K >= 8192 && M % 4 == 0 && N % 4 == 0)
         p.tile = ((cpg_compute_mode_get() == 1 || (pairs && CPG_PAIR_TN_128)) && M % 128 == 0 && N % 128 == 0) ? TN_128x128 : TN_256x128;
     long want;
+    bool small_out = false;
     if (p.tile == TN_256x128) {
         const long tiles = (long)cdiv(M, 256) * cdiv(N, 128);
         want = 256 / tiles;
@@ -1105,11 +1106,16 @@ static TnPlan tn_plan(int M, int N, int K, bool pairs = false) {
         // last round is not half empty (measured at M=1536,N=512,K=51200: S=4 (384 WGs) 1356 us, S=16 (1536 WGs) 1084 us).
         const long tiles = (long)cdiv(M, 128) * cdiv(N, 64);
         want = (1536 + tiles - 1) / tiles;
+        small_out = tiles <= 16;
     }
     if (split.set && split.i > 0) want = split.i;
     if (want < 1) want = 1;
     long maxs = K / 512;  // at least 16 slabs per workgroup: shorter chunks are all prologue (measured: K=2048 split 16 ways
-    if (maxs < 1) maxs = 1;  // ran a 3.2 GFLOP product in 0.46 ms)
+                          // ran a 3.2 GFLOP product in 0.46 ms)
+    // ... except for outputs of a few tiles (the reference's default sizes: dW_hh [306,102] over K = T*B = 800 rows): there ONE
+    // workgroup per tile walks all of K slab by slab (~1.1 us per slab, 28-69 us per product on 2-8 CUs); 4-slab chunks instead
+    if (small_out) maxs = K / 128;
+    if (maxs < 1) maxs = 1;
     if (!(split.set && split.i > 0) && want > maxs) want = maxs;
     if (want > 64) want = 64;
     p.k_chunk = cdiv(cdiv(K, (int)want), 32) * 32;

@@ -419,3 +419,44 @@ def test_fused_optimizer_step_matches_the_per_segment_launches():
     assert ia == ib == 5 and abs(na - nb) < 1e-6 * nb
     for a, b in zip(pa, pb):
         assert (a - b).abs().max().item() < 2e-7
+
+
+# ------------------------------------------------------------------------------------------------ small recurrences: 16-row tiles
+@pytest.mark.parametrize("B,H,T,reverse", [(32, 80, 25, False), (40, 102, 9, True), (2048, 102, 25, False), (5, 64, 4, True)])
+def test_small_recurrence_tile_rows_bitwise(B, H, T, reverse):
+    """Whole-sequence launches of small GRU recurrences (csrc/decode_fused.hip) tile the batch by 16 rows while every tile still gets a CU
+    of its own, by 32 above that (option small_seq_rows).  Rows are independent and both forms run the same instruction sequence per
+    row: states, saved gates, gate gradients and the initial-state gradient must be BIT-identical - ragged last tiles included."""
+    from cpg import ops
+    from cpg.ops import _p, _stream, call
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 3 + H)
+    V = 24
+    w_hh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(dev)
+    b_hh = (torch.randn(3 * H, generator=g) * 0.1).to(dev)
+    tab = (torch.randn(V, 3 * H, generator=g) * 0.4).to(dev)
+    rowc = (torch.randn(B, 3 * H, generator=g) * 0.4).to(dev)
+    tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
+    h0 = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    dhs = (torch.randn(T, B, H, generator=g) * 0.1).to(dev)
+    dlast = (torch.randn(B, H, generator=g) * 0.1).to(dev)
+    out = {}
+    try:
+        for rows in (16, 32):
+            ops.set_option("small_seq_rows", rows)
+            hs = torch.full((T + 1, B, H), float("nan"), device=dev)
+            hs[T if reverse else 0] = h0
+            gates = torch.full((T, 4, B, H), float("nan"), device=dev)
+            call("cpg_gru_seq_fwd", T, B, H, int(reverse), _p(w_hh), _p(b_hh), _p(tok), _p(tab), _p(rowc), None, _p(hs), _p(gates), 0, B, None,
+                 _p(ops.weight_exp(w_hh)), _stream())
+            dG = torch.full((T, B, 4 * H), float("nan"), device=dev)
+            dh0 = torch.full((B, H), float("nan"), device=dev)
+            call("cpg_gru_seq_bwd", T, B, H, int(reverse), _p(w_hh), _p(hs), _p(gates), _p(dhs), _p(dlast), _p(dG), _p(torch.empty(2, B, H, device=dev)),
+                 _p(dh0), 0, B, None, None, None, 0, _stream())
+            torch.cuda.synchronize()
+            out[rows] = (hs, gates, dG, dh0)
+    finally:
+        ops.set_option("small_seq_rows", None)
+    for a, b in zip(out[16], out[32]):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
