@@ -23,7 +23,8 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise CpgError("cpg ops run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()   # a plain int: the bindings carry argtypes (cpg/_lib.py), ctypes converts it to void* itself - a c_void_p object per
+    #                       argument was 0.2 ms of the 1.5 ms of host time of a step at the reference's default sizes (tools/host_profile.py)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -405,7 +406,7 @@ _gemm_prob_checked = False
 
 
 def _dp(t):
-    return None if t is None else (_p(t).value)
+    return None if t is None else _p(t)
 
 
 def gemm_prob(segs, C, M, N, bias=None, accumulate=False, C2=None, n_split=0, pairs=False, wx_a=None, wx_b=None):
