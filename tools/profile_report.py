@@ -22,8 +22,10 @@ def short(n):
 
 line = json.load(open(os.path.join(src, "bench_line.json")))
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "t_kernel_trace.csv"))))
-adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].replace("void ", "").startswith("adam_step")]
-per_step = 3   # adam launches per step (duplicate embedding segment twice + the rest)
+adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].replace("void ", "").startswith("adam_segs")]
+per_step = 1   # one Adam launch per step since round 6
+if not adam:   # older libraries: three adam_step launches per step (duplicate embedding segment twice + the rest)
+    adam, per_step = [i for i, r in enumerate(rows) if r["Kernel_Name"].replace("void ", "").startswith("adam_step")], 3
 steps_total = len(adam) // per_step
 lo = adam[per_step * 5 - 1] + 1           # skip the 5 warm-up steps
 hi = adam[-1] + 1
