@@ -50,6 +50,25 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // ---- device math (accurate forms: parity with the CPU reference is the first gate) ------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Cell nonlinearities of the persistent sequence kernels (round 6): hardware exp2 / rcp forms, 4 and 16 VALU instructions against the
+// ~35 / ~50 of the library forms (a wave64 VALU instruction occupies its SIMD for 4 cycles; the cell was 2.1 of the 14.6 us of a
+// step and ran against the partner wave's MFMAs).  Accuracy: sigmoid within 2 ulp of 1 in absolute terms (v_exp_f32 and v_rcp_f32 are
+// 1 ulp each; the argument product rounds once); tanh within 3 ulp of the result: odd series through a^9 below 0.25 (next term 2e-9),
+// (1 - e) / (1 + e) with e = exp(-2|x|) above.  Saturates to 0 / 1 / +-1, NaN stays NaN.
+__device__ __forceinline__ float cell_sigmoidf(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float cell_tanhf(float x) {
+    const float a = fabsf(x), a2 = a * a;
+    const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * a);
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    float p = fmaf(a2, 62.f / 2835.f, -17.f / 315.f);
+    p = fmaf(a2, p, 2.f / 15.f);
+    p = fmaf(a2, p, -1.f / 3.f);
+    const float small = fmaf(a * a2, p, a);
+    return copysignf(a < 0.25f ? small : big, x);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -58,7 +58,7 @@
 #endif
 
 #ifndef CPG_PERSIST_FAST_CELL
-#define CPG_PERSIST_FAST_CELL 0
+#define CPG_PERSIST_FAST_CELL 1
 #endif
 // Diagnostic builds only (-DCPG_DIAG -DCPG_PERSIST_TRACE=1, tools/persist_trace.py): every wave writes 8 time stamps (10-ns
 // ticks) per step into a trace area behind the exchange slots - where a step's time goes, wave by wave.
@@ -89,18 +89,17 @@
 
 namespace {
 
-// cell nonlinearities: the accurate library forms (as the per-step kernels) or hardware exp / rcp based ones (~2-3 ulp)
+// cell nonlinearities: 0 the library forms of the per-step kernels, 1 (default) the hardware exp2 / rcp forms of cpg_common.h
 __device__ __forceinline__ float p_sigmoid(float x) {
 #if CPG_PERSIST_FAST_CELL
-    return __frcp_rn(1.0f + __expf(-x));
+    return cell_sigmoidf(x);
 #else
     return sigmoidf_(x);
 #endif
 }
 __device__ __forceinline__ float p_tanh(float x) {
 #if CPG_PERSIST_FAST_CELL
-    const float e = __expf(-2.0f * fabsf(x));
-    return copysignf((1.0f - e) * __frcp_rn(1.0f + e), x);
+    return cell_tanhf(x);
 #else
     return tanhf(x);
 #endif
@@ -751,6 +750,23 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     else if (np == 2) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<2, 8>), grid, block, lds, s, a);
     else if (ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<3, 16>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<3, 8>), grid, block, lds, s, a);
+    CPG_LAUNCH_CHECK();
+    return 0;
+}
+
+// The cell nonlinearities of the persistent kernels, evaluated elementwise (tests: units in the last place against float64)
+namespace {
+__global__ void cell_probe_kernel(const float* x, float* sg, float* th, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        sg[i] = p_sigmoid(x[i]);
+        th[i] = p_tanh(x[i]);
+    }
+}
+}  // namespace
+CPG_EXPORT int cpg_persistent_cell_probe(const float* x, float* sigmoid_out, float* tanh_out, int n, void* stream) {
+    CPG_CHECK_ARG(x && sigmoid_out && tanh_out && n > 0);
+    hipLaunchKernelGGL(cell_probe_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, sigmoid_out, tanh_out, n);
     CPG_LAUNCH_CHECK();
     return 0;
 }

@@ -28,6 +28,12 @@ namespace {
 // state per step - rows x H x 2 NP bytes - shrinks by NG: 524 -> 131 KB at H = 512 in the bf16 mode, with a quarter of the producers
 // per row tile to wait for.  A wave owns 64 / NG rows and, per group, the two MFMA blocks [i|f], [g|o] described above.
 constexpr int L_WAVES = 8;
+// cell nonlinearities: 0 the library forms of the per-step kernels, 1 (default) the hardware exp2 / rcp forms of cpg_common.h
+#ifndef CPG_PERSIST_FAST_CELL
+#define CPG_PERSIST_FAST_CELL 1
+#endif
+__device__ __forceinline__ float l_sigmoid(float x) { return CPG_PERSIST_FAST_CELL ? cell_sigmoidf(x) : sigmoidf_(x); }
+__device__ __forceinline__ float l_tanh(float x) { return CPG_PERSIST_FAST_CELL ? cell_tanhf(x) : tanhf(x); }
 #ifndef CPG_LSTM_PERSIST_DEPTH
 #define CPG_LSTM_PERSIST_DEPTH 2
 #endif
@@ -345,13 +351,13 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
                     const float m0 = half ? acc[m][2 * gp][2 + e] : acc[m][2 * gp][e];
                     const float m1 = half ? acc[m][2 * gp + 1][2 + e] : acc[m][2 * gp + 1][e];
                     const float pi = half ? r0 : m0, pf = half ? m0 : r0, pg = half ? r1 : m1, po = half ? m1 : r1;
-                    ig[e] = sigmoidf_(gi[gp][mi][e][0] + (pi + bh[gp][0]));
-                    fg[e] = sigmoidf_(gi[gp][mi][e][1] + (pf + bh[gp][1]));
-                    gg[e] = tanhf(gi[gp][mi][e][2] + (pg + bh[gp][2]));
-                    og[e] = sigmoidf_(gi[gp][mi][e][3] + (po + bh[gp][3]));
+                    ig[e] = l_sigmoid(gi[gp][mi][e][0] + (pi + bh[gp][0]));
+                    fg[e] = l_sigmoid(gi[gp][mi][e][1] + (pf + bh[gp][1]));
+                    gg[e] = l_tanh(gi[gp][mi][e][2] + (pg + bh[gp][2]));
+                    og[e] = l_sigmoid(gi[gp][mi][e][3] + (po + bh[gp][3]));
                     const float cn = fg[e] * cst[gp][mi][e] + ig[e] * gg[e];
                     cst[gp][mi][e] = cn;
-                    hv[e] = og[e] * tanhf(cn);
+                    hv[e] = og[e] * l_tanh(cn);
                 }
                 // ---- publish h_t (split planes, write-through), then the f32 slabs and the saved gates, all as 16-byte row accesses
                 const int row = row0 + 16 * mi + srow;

@@ -240,6 +240,10 @@ CPG_API int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const f
                                        void* err_host /* pinned, host-mapped uint32 that a timed-out wave also sets; may be null */,
                                        void* stream);
 CPG_API int cpg_gru_persistent_kernel_name(int H, char* buf, int n);
+/* sigmoid / tanh exactly as the persistent sequence kernels (GRU and LSTM) evaluate them - hardware exp2 / rcp forms, <= 2 / 3 ulp
+ * (csrc/cpg_common.h) where torch.nn.GRU's cell (models/encoder.py:25-30, models/decoder.py:40-41) calls the library forms - for n
+ * elements: tests measure the units in the last place against float64 */
+CPG_API int cpg_persistent_cell_probe(const float* x, float* sigmoid_out, float* tanh_out, int n, void* stream);
 CPG_API int cpg_gru_persistent_status(int B, const void* sync_scratch, void* stream);
 /* Launcher introspection (bench.py labels its roofline object with these instead of literals): the kernel a step launch /
  * a dW = dY^T X product would run, named as rocprofv3 prints it (no "void ", no argument list); returns the length.

@@ -460,3 +460,32 @@ def test_small_recurrence_tile_rows_bitwise(B, H, T, reverse):
     for a, b in zip(out[16], out[32]):
         assert torch.isfinite(a).all()
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ persistent kernels' cell nonlinearities
+def test_persistent_cell_nonlinearities_ulp_vs_f64():
+    """The persistent sequence kernels evaluate sigmoid / tanh with hardware exp2 / rcp forms (csrc/cpg_common.h: 4 and 15 VALU
+    instructions) where torch.nn.GRU's cell (models/encoder.py:25-30, models/decoder.py:40-41) calls the library functions.  Bars:
+    sigmoid within 2.5 ulp of 1 in absolute terms (2^-24 per ulp: its outputs are O(1) gate values), tanh within 4 ulp of the
+    result's own magnitude; exact saturation and signs at the extremes; NaN stays NaN."""
+    from cpg import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(1 << 18, generator=g) * 3.0, torch.randn(1 << 16, generator=g) * 0.2,
+                   torch.linspace(-0.26, 0.26, 1 << 14), torch.linspace(-30.0, 30.0, 1 << 14),
+                   torch.tensor([0.0, -0.0, 0.25, -0.25, 1e-20, -1e-20, 88.0, -88.0, 200.0, -200.0, float("inf"), float("-inf")])]).cuda()
+    sg, th = torch.empty_like(x), torch.empty_like(x)
+    ops.call("cpg_persistent_cell_probe", ops._p(x), ops._p(sg), ops._p(th), x.numel(), ops._stream())
+    xd = x.double().cpu()
+    sref, tref = torch.sigmoid(xd), torch.tanh(xd)
+    ulp = 2.0 ** -24
+    es = ((sg.double().cpu() - sref).abs() / ulp).max().item()
+    fin = torch.isfinite(xd)
+    et = ((th.double().cpu() - tref).abs()[fin] / (tref.abs()[fin].clamp_min(1e-30) * 2 * ulp)).max().item()
+    assert es <= 2.5, es
+    assert et <= 4.0, et
+    tail = th[-12:].cpu().tolist()
+    assert tail[0] == 0.0 and tail[1] == 0.0 and np.signbit(tail[1]) and tail[6] == 1.0 and tail[7] == -1.0 and tail[10] == 1.0 and tail[11] == -1.0
+    assert sg[-1].item() == 0.0 and sg[-2].item() == 1.0 and sg[-3].item() == 0.0 and sg[-4].item() == 1.0
+    nan = torch.full((64,), float("nan"), device="cuda")
+    ops.call("cpg_persistent_cell_probe", ops._p(nan), ops._p(sg), ops._p(th), 64, ops._stream())
+    assert torch.isnan(sg[:64]).all() and torch.isnan(th[:64]).all()
