@@ -378,6 +378,9 @@ using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 // of a row reads slot q ^ f(row).  Contraction order = the register-staged kernel's (k = 16h + 4q + j): bit-identical sums.
 // Covers dense launches with B % 32 == 0, H % 32 == 0 and 16-byte aligned operands; everything else runs gru_step_bwd_kernel.
 // BM x BN tile, 2 x 2 waves (wave tile BM/2 x BN/2 = MI x NI blocks of 16 x 16); main loop: DlLoop (gemm_core.h)
+#ifndef CPG_DL_DELAY
+#define CPG_DL_DELAY 0
+#endif
 #ifndef CPG_DL_ABLATE
 #define CPG_DL_ABLATE 0   // diagnostic builds (tools/variant_build.sh): 1 no epilogue loads, 2 no stores, 4 no main loop
 #endif
@@ -477,6 +480,12 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
                 }
             }
     };
+#if CPG_DL_DELAY   // diagnostic builds: the second workgroup of every CU (dispatch order) starts CPG_DL_DELAY 10-ns ticks late
+    if (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)CPG_DL_DELAY) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     PairConsumer<MI, NI, 3> pc;   // PREC 3 (pair_engine.h)
     const int w_exp = (PREC == 3 && g.dG_next) ? weight_exp_from_parts(g.ex_min + H / 32) : 0;   // power of two of the W_hh^T image
     if (g.dG_next && !(CPG_DL_ABLATE & 4)) {

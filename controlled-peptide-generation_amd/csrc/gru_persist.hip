@@ -24,7 +24,7 @@
 //     R1): write-through (sc1) 16-byte stores, vmcnt(0), one relaxed agent-scope atomic add on the row tile's arrival
 //     counter; consumers poll that counter relaxed, then read with sc1 loads (L1 bypassed: no acquire fence needed).
 //     Slot reuse is safe: a wave overwrites slot (p+1)&1 only after all 32 producers of its row tile have ARRIVED for step
-//     p-1, i.e. finished reading it.  Counters are zeroed by the host before every launch; every spin is bounded.
+//     p-1, i.e. finished reading it.  Counters are zero at allocation and every launch leaves them at zero; every spin is bounded.
 //   * the f32 state slab and the saved gates are plain / non-temporal stores issued behind the arrival.
 // Arithmetic is the per-step kernel's (same split, same MFMA order, same cell formulas): results are f32-grade and the
 // golden / oracle parity tests run unchanged on this path.
@@ -153,7 +153,7 @@ struct PFwdArgs {
     float* hs;             // [(T+1),B,H]
     float* gates;          // [T,4,B,H] or null; bf16 elements when gates_bf16 (NP = 1 only)
     int gates_bf16;
-    unsigned* cnt;         // [row tiles] arrival counters (zeroed before the launch)
+    unsigned* cnt;         // [row tiles] arrival counters (zero at launch; the launch leaves them at zero)
     unsigned* err;         // sticky error word
     unsigned* err_host;    // the same word in host-mapped (pinned) memory, or null: the host sees a timeout without any copy
     uint16_t* xch;         // [2 slots][3 planes][H/32 k-blocks][B][32] bf16: the state as the consumers want it - a wave's
@@ -622,6 +622,21 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
         }   // row tiles of the wave
     }
     if (CPG_PERSIST_DEFER) flush(0, P_MI);
+    // ---- the launch leaves its arrival counters at zero for the next one (round 6: a memset node in front of every launch cost
+    // ~4 us + a ~6 us bubble).  A wave whose own adds are acknowledged (vmcnt) signs off on the word behind its tile's counter; the
+    // wave that signs off last knows every consumer is past its final wait and every producer's adds are performed: it zeroes both.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+#pragma unroll
+        for (int sb = 0; sb < P_SUB; ++sb) {
+            if (row0 + 16 * sb * P_MIS >= Bend) continue;
+            unsigned* const c = cnt0 + sb * P_CNT_STRIDE;
+            if (__hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)NCT - 1u) {
+                __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 int plane_stride_words(int H) {
@@ -705,7 +720,7 @@ CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
 
 // Whole forward sequence of rows [row_begin, row_end) in one launch; other arguments as cpg_gru_seq_fwd.  sync_scratch:
 // device memory of cpg_gru_persistent_scratch_bytes(T,B,H) bytes, ZEROED BY THE CALLER when allocated: arrival counters
-// (re-zeroed here on the stream before every launch), a sticky error word (set by a wave whose wait timed out, never cleared
+// (every launch leaves them at zero again), a sticky error word (set by a wave whose wait timed out, never cleared
 // here) and the exchange slots.
 CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                           const int32_t* tok, const float* tab, const float* rowc, const float* dense,
@@ -720,7 +735,7 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     }
     hipStream_t s = (hipStream_t)stream;
     const int nrt = cdiv(rows, P_WROWS);
-    CPG_HIP(hipMemsetAsync(sync_scratch, 0, cnt_words(B) * sizeof(unsigned), s));  // counters only: the error word is sticky
+    // (no memset: the counters are zero when the scratch is allocated and every launch leaves them at zero - see the kernel's end)
     PFwdArgs a;
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.gates = gates;
     a.gates_bf16 = gates && cpg_gru_store_bf16(B, H, true);

@@ -389,6 +389,16 @@ __global__ __launch_bounds__(L_WAVES * 64, 2) void lstm_seq_fwd_persist_kernel(L
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(a.cnt + rt * L_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the launch leaves its arrival counters at zero for the next one (as gru_persist.hip: the last wave of a row tile to sign off
+    // zeroes the counter and the sign-off word behind it; no memset node in front of the launch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        unsigned* const c = a.cnt + rt * L_CNT_STRIDE;
+        if (__hip_atomic_fetch_add(c + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)NCT - 1u) {
+            __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 int l_plane_stride_words(int H) {
@@ -453,7 +463,7 @@ CPG_EXPORT size_t cpg_lstm_persistent_scratch_bytes(int T, int B, int H) {
 }
 
 // Whole forward sequence in one launch; arguments as cpg_lstm_seq_fwd.  sync_scratch: cpg_lstm_persistent_scratch_bytes(T,B,H)
-// bytes of device memory, zeroed by the caller when allocated (counters are re-zeroed here before every launch; the error
+// bytes of device memory, zeroed by the caller when allocated (every launch leaves the counters at zero again; the error
 // word is sticky, cpg_lstm_persistent_status reads it).
 CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, const float* w_hh, const float* b_hh,
                                            const int32_t* tok, const float* tab, const float* rowc, const float* dense,
@@ -466,7 +476,7 @@ CPG_EXPORT int cpg_lstm_seq_fwd_persistent(int T, int B, int H, int reverse, con
         return -5;
     }
     hipStream_t s = (hipStream_t)stream;
-    CPG_HIP(hipMemsetAsync(sync_scratch, 0, l_cnt_words(B) * sizeof(unsigned), s));
+    // (no memset: the counters are zero at allocation and every launch leaves them at zero)
     LFwdArgs a;
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.cs = cs; a.gates = gates;
     a.cnt = (unsigned*)sync_scratch;

@@ -218,7 +218,7 @@ CPG_API int cpg_gru_biseq_bwd(int T, int B, int H, const float* w_hh_f, const fl
  * cpg_gru_persistent_fits: 1 when (B,H) is covered on this device (H % 32 == 0, the plane slice fits the LDS, every
  * workgroup co-resident by hipOccupancyMaxActiveBlocksPerMultiprocessor's count; option gru_persist = 0 disables).
  * sync_scratch: cpg_gru_persistent_scratch_bytes(T,B,H) bytes of device memory, zeroed by the caller once (arrival counters,
- * re-zeroed by every call, a sticky error word at byte cpg_gru_persistent_err_offset(B), the bf16-plane exchange slots).
+ * which every launch leaves at zero again, a sticky error word at byte cpg_gru_persistent_err_offset(B), the bf16-plane exchange slots).
  * A wait that times out (workgroups not co-resident: another process or kernel holds CUs) sets the error word - and
  * *err_host, so the host notices without a copy or a synchronisation - and NaN-poisons everything the wave stores afterwards.
  * cpg_gru_persistent_status synchronises the stream and returns the error word.
