@@ -115,8 +115,13 @@ __device__ __forceinline__ float p_tanh(float x) {
 #ifndef CPG_PERSIST_DEPTH
 #define CPG_PERSIST_DEPTH 3       // k-blocks of the state operand in flight per wave (8 waves: f32-grade 21.8 / 21.7 / 22.0 us per step at
 #endif                            // depth 2 / 3 / 4; bf16 mode 10.5 / 10.0 / 10.1)
+#ifndef CPG_PERSIST_WAVES_BF16
+#define CPG_PERSIST_WAVES_BF16 16 // bf16 compute mode (one plane: half the exchange reads, 96 VGPRs): sixteen waves of 16 rows - four chains per
+                                  // SIMD - 227 -> 215 us per sequence; the f32-grade form is bound by its exchange reads and gains nothing (EXPERIMENTS R6.8)
+#endif
 constexpr int P_DEPTH = CPG_PERSIST_DEPTH;
-constexpr int P_WAVES = CPG_PERSIST_WAVES;
+constexpr int waves_of(int np) { return np == 1 ? CPG_PERSIST_WAVES_BF16 : CPG_PERSIST_WAVES; }
+constexpr int P_WAVES = CPG_PERSIST_WAVES;   // (the kernel shadows these four with the values of its own plane count)
 constexpr int P_WROWS = 256 / P_WAVES;   // rows per wave
 constexpr int P_MI = P_WROWS / 16;
 constexpr int P_SUB = CPG_PERSIST_SUBTILES;          // row tiles per wave
@@ -167,8 +172,8 @@ struct PFwdArgs {
 #endif
 };
 
-__device__ __forceinline__ void phase_delay(int wave, unsigned ticks) {
-    if (ticks == 0 || wave < P_WAVES / 2) return;
+__device__ __forceinline__ void phase_delay(int wave, int waves, unsigned ticks) {
+    if (ticks == 0 || wave < waves / 2) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
@@ -252,7 +257,9 @@ __device__ __forceinline__ void publish_rows(const f32x4 v, const __amdgpu_buffe
 typedef uint32_t pk_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NP, int CT>
-__global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
+__global__ __launch_bounds__(waves_of(NP) * 64, waves_of(NP) / 4) void gru_seq_fwd_persist_kernel(PFwdArgs a) {
+    constexpr int P_WAVES = waves_of(NP), P_WROWS = 256 / P_WAVES, P_MI = P_WROWS / 16, P_MIS = P_MI / P_SUB;   // waves, rows per wave, ...
+    static_assert(P_MI >= 1 && P_MI % P_SUB == 0, "a wave owns whole 16-row blocks");
     constexpr int NC = 3 * CT;              // gate columns (LDS plane rows) of the workgroup
     constexpr int NB = CT == 16 ? 3 : 2;    // MFMA column blocks
     static_assert(CT == 16 || CT == 8, "16 units: one block per gate; 8 units: [r|z] and [n|n]");
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(P_WAVES * 64, P_WAVES / 4) void gru_seq_fwd_persist
     const int rt = g * P_WAVES + wave;   // row tile of this wave (counted from row_begin)
     const int row0 = a.row0 + rt * P_WROWS;
     if (row0 >= Bend) return;            // wave-uniform; nobody waits for a tile that does not exist
-    phase_delay(wave, CPG_PERSIST_PHASE_FWD);
+    phase_delay(wave, P_WAVES, CPG_PERSIST_PHASE_FWD);
     const int l15 = lane & 15, lq = lane >> 4;
     const int srow = lane >> 2, scq = lane & 3;  // row-layout coordinates after acc_to_rows
     const int hcol = j0 + (l15 & (CT - 1));      // hidden unit of this lane's accumulator elements
@@ -645,7 +652,7 @@ int plane_stride_words(int H) {
     return s;
 }
 
-size_t fwd_lds_bytes(int H, int ct, int np) { return ((size_t)np * 3 * ct * plane_stride_words(H) + P_WAVES * 16 * P_TBW) * 4; }
+size_t fwd_lds_bytes(int H, int ct, int np) { return ((size_t)np * 3 * ct * plane_stride_words(H) + waves_of(np) * 16 * P_TBW) * 4; }
 
 // hidden units per workgroup for width H: 16 while the 48 x H plane slice fits the LDS, else 8 (24 x H), else 0 (not covered)
 int pick_ct(int H, int np) {
@@ -671,7 +678,7 @@ static long resident_workgroups(size_t lds) {
     const void* k = reinterpret_cast<const void*>(gru_seq_fwd_persist_kernel<NP, CT>);
     if (cpg_allow_big_lds(k, 160 * 1024) != 0) return 0;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_seq_fwd_persist_kernel<NP, CT>, P_WAVES * 64, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_seq_fwd_persist_kernel<NP, CT>, waves_of(NP) * 64, lds) != hipSuccess) return 0;
     return cache[{dev, lds}] = (long)per_cu * cpg_device_cus();
 }
 
@@ -690,8 +697,8 @@ CPG_EXPORT int cpg_gru_persistent_rows(int H) {
     const long fit = np == 1   ? (ct == 16 ? resident_workgroups<1, 16>(lds) : resident_workgroups<1, 8>(lds))
                      : np == 2 ? (ct == 16 ? resident_workgroups<2, 16>(lds) : resident_workgroups<2, 8>(lds))
                                : (ct == 16 ? resident_workgroups<3, 16>(lds) : resident_workgroups<3, 8>(lds));
-    const long groups = fit / (H / ct);          // row groups of 256 rows (8 waves x 32 rows)
-    return (int)(groups * P_WAVES * P_WROWS);
+    const long groups = fit / (H / ct);          // row groups of 256 rows (8 waves x 32 rows, or 16 x 16)
+    return (int)(groups * 256);
 }
 
 // 1 when ONE launch covers a [B rows, H hidden] sequence
@@ -701,7 +708,7 @@ CPG_EXPORT int cpg_gru_persistent_fits(int B, int H) {
     return B <= cpg_gru_persistent_rows(H);
 }
 
-static size_t cnt_words(int B) { return (size_t)cdiv(B, P_WROWS) * P_SUB * P_CNT_STRIDE; }
+static size_t cnt_words(int B) { return (size_t)cdiv(B, 16) * P_SUB * P_CNT_STRIDE; }   // one line per row tile of the smallest tile height (16 rows)
 static size_t sync_words(int B) { return (cnt_words(B) + 16 + P_XCC_WORDS + 63) / 64 * 64; }  // counters + error word + XCD table, 256-byte multiple
 
 // Byte offset, inside the scratch, of a word the last launch set to 1 (its first row tile's producers shared one XCD: the hand-off
@@ -713,7 +720,7 @@ CPG_EXPORT size_t cpg_gru_persistent_scratch_bytes(int T, int B, int H) {
     // state with CPG_PERSIST_PLAIN_LOADS)
     size_t n = sync_words(B) * sizeof(unsigned) + (size_t)(CPG_PERSIST_PLAIN_LOADS ? T + 1 : 2) * 3 * ((B + 1) & ~1) * H * sizeof(uint16_t);
 #if CPG_PERSIST_TRACE
-    n = (n + 255) / 256 * 256 + (size_t)cdiv(cdiv(B, P_WROWS), P_WAVES) * (H / 8) * P_WAVES * T * 8 * sizeof(unsigned long long);
+    n = (n + 255) / 256 * 256 + (size_t)cdiv(B, 256) * (H / 8) * 16 * T * 8 * sizeof(unsigned long long);
 #endif
     return n;
 }
@@ -734,7 +741,6 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
         return -5;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int nrt = cdiv(rows, P_WROWS);
     // (no memset: the counters are zero when the scratch is allocated and every launch leaves them at zero - see the kernel's end)
     PFwdArgs a;
     a.w_hh = w_hh; a.b_hh = b_hh; a.tok = tok; a.tab = tab; a.rowc = rowc; a.dense = dense; a.hs = hs; a.gates = gates;
@@ -746,7 +752,6 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     a.xch = (uint16_t*)(a.cnt + sync_words(B));
     a.T = T; a.B = B; a.H = H; a.reverse = reverse;
     a.row0 = row_begin; a.row1 = row_end;
-    a.groups = cdiv(nrt, P_WAVES);
     a.S = plane_stride_words(H);
 #if CPG_PERSIST_TRACE
     {
@@ -757,7 +762,8 @@ CPG_EXPORT int cpg_gru_seq_fwd_persistent(int T, int B, int H, int reverse, cons
     // (the > 64 KB dynamic-LDS opt-in happened in cpg_gru_persistent_rows -> resident_workgroups, per device)
     const int np = cpg_persist_planes();
     const int ct = pick_ct(H, np);
-    const dim3 grid(a.groups * (H / ct)), block(P_WAVES * 64);
+    a.groups = cdiv(rows, 256);          // row groups of 256 rows: waves_of(np) waves of 256 / waves_of(np) rows
+    const dim3 grid(a.groups * (H / ct)), block(waves_of(np) * 64);
     const size_t lds = fwd_lds_bytes(H, ct, np);
     if (np == 1 && ct == 16) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<1, 16>), grid, block, lds, s, a);
     else if (np == 1) hipLaunchKernelGGL((gru_seq_fwd_persist_kernel<1, 8>), grid, block, lds, s, a);

@@ -12,7 +12,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from cpg import ops  # noqa: E402
 
-B, H, T, V, W = 2048, 512, 25, 24, 8
+B, H, T, V = 2048, 512, 25, 24
+W = 16 if os.environ.get("KB_DTYPE", "f32") == "bf16" else 8    # waves per workgroup (csrc/gru_persist.hip: waves_of)
 dev = torch.device("cuda")
 ops.set_compute_mode(os.environ.get("KB_DTYPE", "f32"))
 g = torch.Generator().manual_seed(0)
@@ -23,14 +24,14 @@ rowc = (torch.randn(B, 3 * H, generator=g) * 0.3).to(dev)
 tok = torch.randint(0, V, (T, B), generator=g).to(torch.int32).to(dev)
 hs = torch.zeros(T + 1, B, H, device=dev)
 hs[0] = torch.randn(B, H, generator=g).to(dev)
-gates = torch.empty(T, 4, B, H, device=dev)
+gates = torch.empty(T, 4, B, H, device=dev, dtype=ops.gates_dtype(B, H, False))
 for _ in range(3):
     ops.gru_seq_fwd_persistent(T, B, H, False, w_hh, b_hh, tok, tab, rowc, None, hs, gates)
 torch.cuda.synchronize()
 ent = next(v for k, v in ops._persist_scratch.items() if k[0] == "gru")
 nwg = (B // 256) * (H // 16)
 n = nwg * W * T * 8
-area = (B // 256) * (H // 8) * W * T * 8 * 8                 # bytes of the trace area (sized for 8-unit column tiles)
+area = (B // 256) * (H // 8) * 16 * T * 8 * 8                # bytes of the trace area (sized for 8-unit column tiles, 16 waves)
 tr = ent[0][-area:][:n * 8].view(torch.int64).cpu().numpy().reshape(nwg, W, T, 8).astype(np.float64) * 0.01   # us
 t0 = tr[:, :, :, 0].min()
 names = ["wait", "first-kb", "mfma-loop", "cell", "publish+drain", "arrive+stores"]
