@@ -381,6 +381,11 @@ using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 #ifndef CPG_DL_DELAY
 #define CPG_DL_DELAY 0
 #endif
+#ifndef CPG_BWD_DL_NS
+#define CPG_BWD_DL_NS 3   // stages of the backward step's LDS ring (2: 44.4 / 33.7 us paired / single at config B, 3: 40.3 / 28.0, 4: EXPERIMENTS R6.9)
+#endif
+#define CPG_STR_(x) #x
+#define CPG_STR(x) CPG_STR_(x)
 #ifndef CPG_DL_ABLATE
 #define CPG_DL_ABLATE 0   // diagnostic builds (tools/variant_build.sh): 1 no epilogue loads, 2 no stores, 4 no main loop
 #endif
@@ -758,12 +763,12 @@ template <int BM, int BN, int PREC>
 static int launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(a.H / BN, (a.row1 - a.row0) / BM, nd);
-    const size_t smem = (DlLoop<BM, BN, 3, PREC>::smem_floats() + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, CPG_BWD_DL_NS, PREC>::smem_floats() + 4 * 256) * sizeof(float);
     if (smem > 64 * 1024) {
-        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, 3, PREC>), (int)smem);
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, CPG_BWD_DL_NS, PREC>), (int)smem);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, 3, PREC>), grid, dim3(256), smem, s, pr);
+    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, CPG_BWD_DL_NS, PREC>), grid, dim3(256), smem, s, pr);
     return 0;
 }
 
@@ -1106,7 +1111,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     if (kind == 1) {
         const BwdPlan pl = bwd_plan(B, H, ndir, 0, vec, have_wt != 0, true);
         if (pl.kind == BK_DL2) return snprintf(buf, n, "gru_step_bwd_dl2_kernel<%d>", pl.bf16 ? 1 : 0);
-        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, 3, %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : pl.pair_ok ? 3 : 0);
+        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, " CPG_STR(CPG_BWD_DL_NS) ", %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : pl.pair_ok ? 3 : 0);
         if (pl.tile.bm == 64) tc_name<GB64>(tc, sizeof tc);
         else if (pl.tile.bn == 64) tc_name<GB32>(tc, sizeof tc);
         else tc_name<GB32N>(tc, sizeof tc);
