@@ -259,7 +259,6 @@ def _deferred_split_ap(R, M, N):
 
 DEFER_DEC_WGRAD = _os.environ.get('CPG_DEFER_DEC_WGRAD', '1') != '0'   # the decoder's dW_hh product on the side stream (GruSeqFn(defer=True))
 DEFER_ENC_WGRAD = _os.environ.get('CPG_DEFER_ENC_WGRAD', '1') != '0'   # the encoder's reverse-direction dW_hh beside the forward one (GruBiSeqFn)
-ENC_DGI_ASIDE = _os.environ.get('CPG_ENC_DGI_ASIDE', '0') == '1'      # experiment: the encoder's input-side reductions (HBM-bound) on a side stream beside its dW_hh products
 DEFER_SMALL_WGRAD = _os.environ.get('CPG_DEFER_ROWC_WGRAD', '1') != '0'   # ... and so does the [z;c] block of its W_ih gradient (LinearColsFn)
 BOUNDARY_CB = None    # only inside backward_scope: callable(tag) fired by GradBoundaryFn.backward (gradient buckets, cpg.optim)
 
@@ -1376,23 +1375,6 @@ class GruBiSeqFn(Function):
                 with _prof("wgrad_hh", 1, T=T, B=B, H=H, ndir=1):
                     call("cpg_gru_wgrad_hh", T, B, H, rev, _p(dG), _p(hs), _p(dst), None, acc, _p(wsx), wsx.numel(),
                          _p(pair[rev]) if pair is not None else None, dgb, _stream())
-        aside = None
-        if ENC_DGI_ASIDE and OVERLAP and DEFER_WGRAD and ctx.has_tab and ap is not None and not dgb:
-            # both directions' input-side reductions (one pass over the planes each: HBM-bound) on a side stream, beside the two dW_hh
-            # products (matrix-pipe / L2-bound) of the main stream
-            aside = []
-            side = side_streams(dev)[1]
-            for rev, dG in ((0, dG_f), (1, dG_r)):
-                aside.append((torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32), torch.empty(4 * H, device=dev, dtype=torch.float32)))
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                ws2 = workspace(nb, dev)
-                for rev, dG in ((0, dG_f), (1, dG_r)):
-                    call("cpg_gru_dgi_reduce_ap", T, B, H, _p(ap[rev]), _p(dG), _p(tok), ctx.V, _p(aside[rev][0]), _p(aside[rev][1]), None, 0,
-                         _p(ws2), ws2.numel(), _stream())
-            for t in (dG_f, dG_r, ap, tok):
-                if t is not None:
-                    t.record_stream(side)
         for rev, dG, hs in ((0, dG_f, hs_f), (1, dG_r, hs_r)):
             gw = _grad_buf(ctx.leaves[rev]) if ctx.has_tab else None
             dw = gw if gw is not None else torch.empty(3 * H, H, device=dev, dtype=torch.float32)
@@ -1417,16 +1399,9 @@ class GruBiSeqFn(Function):
                     wgrad(rev, dG, hs, dw, int(gw is not None), ws)
                 if gw is not None:
                     dw = None
-                if aside is not None:
-                    dtab, dsum = aside[rev]
-                    if rev == 1:
-                        torch.cuda.current_stream().wait_stream(side_streams(dev)[1])
-                else:
-                    dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
-                    dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
-                if aside is not None:
-                    pass
-                elif ap is not None and not dgb:
+                dtab = torch.empty(ctx.V, 3 * H, device=dev, dtype=torch.float32)
+                dsum = torch.empty(4 * H, device=dev, dtype=torch.float32)
+                if ap is not None and not dgb:
                     call("cpg_gru_dgi_reduce_ap", T, B, H, _p(ap[rev]), _p(dG), _p(tok), ctx.V, _p(dtab), _p(dsum), None, 0, _p(ws), ws.numel(),
                          _stream())
                 else:
