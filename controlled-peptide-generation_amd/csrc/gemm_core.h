@@ -912,11 +912,18 @@ struct DlNoScale {};   // DlLoop::run without a fragment-scale hook
 struct DlPairScale {   // PREC 4: powers of two the A / B operand values are multiplied by before their f16-pair split (passed in the fscale slot)
     float a, b;
 };
-template <int BM, int BN, int NS = 3, int PREC = 0>
+// WR: wave rows of the loop's WR x 2 wave grid - 2: four waves (256 threads), wave tile BM/2 x BN/2; 4 (round 6: the 128 x 64 tile of the
+// paired BPTT launch, one 512-thread workgroup where two 64 x 64 ones each fetched the same W_hh^T tile): eight waves, wave tile BM/4 x BN/2
+// WC: wave columns - 2, or 4 (round 6: 64 x 64 tile on eight waves of 32 x 16 - half the epilogue state per wave, four waves per SIMD)
+template <int BM, int BN, int NS = 3, int PREC = 0, int WR = 2, int WC = 2>
 struct DlLoop {
-    static constexpr int MI = BM / 32, NI = BN / 32;
+    static constexpr int NT = 64 * WR * WC;                          // threads that run one loop
+    static constexpr int PR = NT / 8;                                // rows one pass of those threads moves (16 bytes per thread, 128 per row)
+    static constexpr int MI = BM / (16 * WR), NI = BN / (16 * WC);   // 16 x 16 blocks of a wave tile
+    static constexpr int PA = BM / PR, PB = BN / PR;                 // passes per slab: LDS-DMA instructions per thread
+    static_assert(BM % PR == 0 && BN % PR == 0 && BM % (16 * WR) == 0 && BN % (16 * WC) == 0, "whole passes, whole blocks");
     static constexpr int AF = BM * 32, BF = BN * 32, SF = AF + BF;   // floats per operand slab / per stage
-    static constexpr int LPS = MI + NI;                              // LDS-DMA instructions per thread and slab
+    static constexpr int LPS = PA + PB;                              // LDS-DMA instructions per thread and slab
     static constexpr int AHEAD = NS - 1;
     static constexpr size_t smem_floats() { return (size_t)NS * SF; }
 
@@ -959,37 +966,37 @@ struct DlLoop {
         constexpr int BKE = 8 * EPC;               // elements per slab (a row of a slab is always 128 bytes)
         // (a 512-thread workgroup runs two of these loops side by side - its two 256-thread halves, each on its own ring and its
         // own half of K: gru_step_bwd_dl2_kernel; the slab barrier is the workgroup's)
-        const int tid = threadIdx.x & 255, lane = tid & 63;
+        const int tid = threadIdx.x & (NT - 1), lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lq = lane >> 4;
+        const int wm = wave / WC, wn = wave % WC, l15 = lane & 15, lq = lane >> 4;
         const int KT = K / BKE;
-        // this thread's 16-byte pieces of a slab: piece i covers row = 32 i + tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
-        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);   // f(32 i + r) = f(r)
+        // this thread's 16-byte pieces of a slab: piece i covers row = PR i + tid / 8, slot = tid % 8 holds k-chunk slot ^ f(row)
+        const int srow = tid >> 3, sch = (tid & 7) ^ ((srow >> 1) & 7);   // f(PR i + r) = f(r): PR is a multiple of 16
         const E* ga = A + (size_t)srow * lda + EPC * sch;
         const E* gb = Bt + (size_t)srow * ldb + EPC * sch;
-        const size_t ga32 = 32 * lda, gb32 = 32 * ldb;
-        const E* gar[MI];
+        const size_t gaP = PR * lda, gbP = PR * ldb;
+        const E* gar[PA];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            if constexpr (__is_same(__remove_cvref(AR), DlNoScale)) gar[i] = ga + i * ga32;
+        for (int i = 0; i < PA; ++i) {
+            if constexpr (__is_same(__remove_cvref(AR), DlNoScale)) gar[i] = ga + i * gaP;
             else gar[i] = arow(i, srow) + EPC * sch;
         }
-        const E* gbr[NI];
+        const E* gbr[PB];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            if constexpr (__is_same(__remove_cvref(BR), DlNoScale)) gbr[i] = gb + i * gb32;
+        for (int i = 0; i < PB; ++i) {
+            if constexpr (__is_same(__remove_cvref(BR), DlNoScale)) gbr[i] = gb + i * gbP;
             else gbr[i] = brow(i, srow) + EPC * sch;
         }
         auto issue = [&](int kt, float* stage) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                __builtin_amdgcn_global_load_lds(gar[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + i * 1024 + wave * 256), 16, 0, 0);
+            for (int i = 0; i < PA; ++i)
+                __builtin_amdgcn_global_load_lds(gar[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + i * (PR * 32) + wave * 256), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-                __builtin_amdgcn_global_load_lds(gbr[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + AF + i * 1024 + wave * 256), 16, 0, 0);
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds(gbr[i] + kt * BKE, (__attribute__((address_space(3))) void*)(stage + AF + i * (PR * 32) + wave * 256), 16, 0, 0);
         };
         // fragment word offsets inside a stage (slab-invariant): row r of block mi / ni, k-chunk q = 4h + lq -> slot q ^ f(r)
-        const int ra = wm * (BM / 2) + l15, rbn = wn * (BN / 2) + l15;
+        const int ra = wm * (BM / WR) + l15, rbn = wn * (BN / WC) + l15;
         const int fa = (ra >> 1) & 7, fb = (rbn >> 1) & 7;   // f is the same for rows 16 apart
         const int oa0 = ra * 32 + 4 * (lq ^ fa), oa1 = ra * 32 + 4 * ((4 + lq) ^ fa);
         const int ob0 = AF + rbn * 32 + 4 * (lq ^ fb), ob1 = AF + rbn * 32 + 4 * ((4 + lq) ^ fb);

@@ -440,9 +440,15 @@ __device__ __forceinline__ void st_dg4(float* dG_out, size_t row, int H, int col
 
 // PREC 1: bf16 compute mode (operands rounded at the fragment read, one bf16 MFMA per block and slab); PREC 2: the same arithmetic on
 // bf16 gradient storage (dG and W_hh^T are bf16 in memory: DlLoop's 64-deep slabs)
-template <int BM, int BN, int NS, int PREC = 0>
-__global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
-    using DL = DlLoop<BM, BN, NS, PREC>;
+// WR = 4 (round 6, PREC 3): one 512-thread workgroup on a 128 x 64 tile where two 64 x 64 workgroups of a CU each fetched the same
+// W_hh^T tile - 3/4 of the operand bytes through the L2; every wave still owns 32 rows x BN/2 columns
+// WC = 4 (round 6, PREC 3): the 64 x 64 tile on EIGHT waves of 32 x 16 - the kernel's three phases (epilogue-operand loads, main loop,
+// cell arithmetic + stores) are one serial chain per wave (EXPERIMENTS R6.9: they add up), so half the epilogue state per wave and four
+// waves per SIMD (<= 128 VGPRs) shorten the chain at the same LDS and L2 traffic
+template <int BM, int BN, int NS, int PREC = 0, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(64 * WR * WC, WC == 4 ? 2 : 1) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
+    using DL = DlLoop<BM, BN, NS, PREC, WR, WC>;
+    static_assert(PREC != 3 || BM / WR == 32, "f16-pair step: a wave owns 32 rows - one exponent row of the pair planes");
     constexpr int MI = DL::MI, NI = DL::NI;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -454,8 +460,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
+    const int wm = wave / WC, wn = wave % WC;
+    const int rb0 = m0 + wm * (BM / WR) + (lane >> 2), cb0 = j0 + wn * (BN / WC) + 4 * (lane & 3);
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -543,9 +549,9 @@ __global__ __launch_bounds__(256) void gru_step_bwd_dl_kernel(GruBwdPair pr) {
     if constexpr (PREC == 3) {
         if (!g.gates || !g.pp_out) return;   // (block-uniform)
         // ---- the next launch's A operand (pair_engine.h): this wave's 32 rows x BN/2 columns x 3 blocks
-        const int grp = (j0 + wn * (BN / 2)) / 32;
-        const int e = pair_group_exponent<BN>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
-                                              g.ex_min + grp);
+        const int grp = (j0 + wn * (BN / WC)) / 32;
+        const int e = pair_group_exponent<BN / WC>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
+                                                   g.ex_min + grp);
         if (e != INT_MAX || g.hp_out) {   // kept images (all-T form) are read by consumers that do not look at the table first: zeros
             const float sc = e == INT_MAX ? 1.f : pair_pow2(e);
 #pragma unroll
@@ -723,13 +729,16 @@ int cpg_gru_step_fwd_launch(const GruFwdArgs& a, hipStream_t s) {
 // kernel; gru_bwd_dl = 0 keeps the register-staged kernel; gru_bwd_dl2 = 0 / 1 disables / forces the two-K-halves form.
 struct BwdTile {
     int bm, bn;
+    int waves = 4;   // 8: the f16-pair step's eight-wave forms (128 x 64: 4 x 2 waves; 64 x 64: 2 x 4 waves of 32 x 16) - "64x64x8"
 };
 static bool parse_tile(const CpgOptVal& o, BwdTile& t) {
     if (!o.set) return false;
-    int bm = 0, bn = 0;
-    if (sscanf(o.s, "%dx%d", &bm, &bn) != 2) return false;
-    if ((bm != 32 && bm != 64) || (bn != 32 && bn != 64)) return false;
-    t = {bm, bn};
+    int bm = 0, bn = 0, w = 4;
+    if (sscanf(o.s, "%dx%dx%d", &bm, &bn, &w) < 2) return false;
+    if (!(bm == 128 && bn == 64) && ((bm != 32 && bm != 64) || (bn != 32 && bn != 64))) return false;   // 128x64: the f16-pair step only
+    if (bm == 128) w = 8;
+    if (w != 4 && !(w == 8 && bm >= 64 && bn == 64)) return false;
+    t = {bm, bn, w};
     return true;
 }
 
@@ -737,7 +746,7 @@ static bool parse_tile(const CpgOptVal& o, BwdTile& t) {
 // B=2048, H=512), 64-row tiles for big batches otherwise, 32 x 64 for small ones.
 static BwdTile staged_tile(int rows, int H, int nd) {
     BwdTile t;
-    if (parse_tile(cpg_opt(OPT_GRU_BWD_TILE), t) && !(t.bm == 64 && t.bn == 64)) return t;
+    if (parse_tile(cpg_opt(OPT_GRU_BWD_TILE), t) && !(t.bm >= 64 && t.bn == 64)) return t;
     if ((long)cdiv(rows, 32) * cdiv(H, 32) * nd >= 1024) return {32, 32};
     return ((long)cdiv(rows, 64) * cdiv(H, 32) >= 256 || rows > 32) ? BwdTile{64, 32} : BwdTile{32, 64};
 }
@@ -759,16 +768,16 @@ static bool bwd_dl_shape_ok(int row0, int row1, int H) {
 // W_hh^T is needed by the direct-to-LDS kernel only
 static bool bwd_wants_wt(int rows, int H, int row0, bool dense) { return dense && H % 4 == 0 && bwd_dl_shape_ok(row0, row0 + rows, H); }
 
-template <int BM, int BN, int PREC>
+template <int BM, int BN, int PREC, int WR = 2, int WC = 2>
 static int launch_dl(const GruBwdPair& pr, int nd, hipStream_t s) {
     const GruBwdArgs& a = pr.d[0];
     dim3 grid(a.H / BN, (a.row1 - a.row0) / BM, nd);
-    const size_t smem = (DlLoop<BM, BN, CPG_BWD_DL_NS, PREC>::smem_floats() + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, CPG_BWD_DL_NS, PREC, WR, WC>::smem_floats() + WR * WC * 256) * sizeof(float);
     if (smem > 64 * 1024) {
-        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, CPG_BWD_DL_NS, PREC>), (int)smem);
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(gru_step_bwd_dl_kernel<BM, BN, CPG_BWD_DL_NS, PREC, WR, WC>), (int)smem);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, CPG_BWD_DL_NS, PREC>), grid, dim3(256), smem, s, pr);
+    hipLaunchKernelGGL((gru_step_bwd_dl_kernel<BM, BN, CPG_BWD_DL_NS, PREC, WR, WC>), grid, dim3(64 * WR * WC), smem, s, pr);
     return 0;
 }
 
@@ -852,8 +861,15 @@ static BwdPlan bwd_plan(int rows, int H, int nd, int row0, bool vec, bool have_w
     const bool bf16 = cpg_compute_mode_get() == 1;
     if (vec && have_wt && dense && bwd_dl_shape_ok(row0, row0 + rows, H)) {
         if (!cpg_opt(OPT_GRU_BWD_TILE).set && bwd_dl2_wanted(rows, H, nd, bf16)) return {BK_DL2, {64, 64}, bf16, false};
-        const BwdTile t = dl_tile(rows, H, nd);
-        return {BK_DL, t, bf16, t.bm == 64 && H <= 2048 && bwd_pair_enabled()};
+        BwdTile t = dl_tile(rows, H, nd);
+        const bool pair = t.bm >= 64 && H <= 2048 && bwd_pair_enabled();
+        if (t.bm == 128 && !(pair && rows % 128 == 0 && H % 64 == 0)) t.bm = 64, t.waves = 4;   // 128 x 64 exists for the f16-pair step on whole tiles only
+        if (t.waves == 8 && !(pair && t.bn == 64 && H % 64 == 0)) t.waves = 4;
+        // f16-pair step, launcher's own choice (round 6): 64 x 64 tiles on EIGHT waves of 32 x 16 from 256 tiles up - 116 VGPRs, four waves
+        // per SIMD at two workgroups per CU (paired directions: 42.9 -> 41.6 us) or eight waves on every CU (one direction at B=2048,
+        // H=512: 28.9 on 64 x 32 -> 27.8)
+        if (pair && !cpg_opt(OPT_GRU_BWD_TILE).set && rows % 64 == 0 && H % 64 == 0 && (long)(rows / 64) * (H / 64) * nd >= 256) t = {64, 64, 8};
+        return {BK_DL, t, bf16, pair};
     }
     return {BK_STAGED, staged_tile(rows, H, nd), false, false};   // exact f32 in either compute mode
 }
@@ -894,7 +910,8 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
         rc = dgb ? launch_dl2<2>(pr, nd, s) : pl.bf16 ? launch_dl2<1>(pr, nd, s) : launch_dl2<0>(pr, nd, s);
     } else if (pl.kind == BK_DL) {
 #define CPG_DL_PICK(BM, BN) (dgb ? launch_dl<BM, BN, 2>(pr, nd, s) : pl.bf16 ? launch_dl<BM, BN, 1>(pr, nd, s) : launch_dl<BM, BN, 0>(pr, nd, s))
-        if (pair) rc = pl.tile.bn == 64 ? launch_dl<64, 64, 3>(pr, nd, s) : launch_dl<64, 32, 3>(pr, nd, s);
+        if (pair) rc = pl.tile.bm == 128 ? launch_dl<128, 64, 3, 4>(pr, nd, s) : pl.tile.waves == 8 ? launch_dl<64, 64, 3, 2, 4>(pr, nd, s)
+                     : pl.tile.bn == 64 ? launch_dl<64, 64, 3>(pr, nd, s) : launch_dl<64, 32, 3>(pr, nd, s);
         else if (pl.tile.bm == 64 && pl.tile.bn == 64) rc = CPG_DL_PICK(64, 64);
         else if (pl.tile.bm == 64) rc = CPG_DL_PICK(64, 32);
         else if (pl.tile.bn == 64) rc = CPG_DL_PICK(32, 64);
@@ -1111,7 +1128,7 @@ CPG_EXPORT int cpg_gru_step_kernel_name(int kind, int B, int H, int ndir, int ha
     if (kind == 1) {
         const BwdPlan pl = bwd_plan(B, H, ndir, 0, vec, have_wt != 0, true);
         if (pl.kind == BK_DL2) return snprintf(buf, n, "gru_step_bwd_dl2_kernel<%d>", pl.bf16 ? 1 : 0);
-        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, " CPG_STR(CPG_BWD_DL_NS) ", %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : pl.pair_ok ? 3 : 0);
+        if (pl.kind == BK_DL) return snprintf(buf, n, "gru_step_bwd_dl_kernel<%d, %d, " CPG_STR(CPG_BWD_DL_NS) ", %d, %d, %d>", pl.tile.bm, pl.tile.bn, pl.bf16 ? 1 : pl.pair_ok ? 3 : 0, pl.tile.bm == 128 ? 4 : 2, (pl.tile.waves == 8 && pl.tile.bm == 64) ? 4 : 2);
         if (pl.tile.bm == 64) tc_name<GB64>(tc, sizeof tc);
         else if (pl.tile.bn == 64) tc_name<GB32>(tc, sizeof tc);
         else tc_name<GB32N>(tc, sizeof tc);

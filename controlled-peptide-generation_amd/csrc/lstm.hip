@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
     if constexpr (PREC == 3) {
         if (!g.gates || !g.pp_out) return;   // (block-uniform)
         const int grp = (j0 + wn * (BN / 2)) / 32;
-        const int e = pair_group_exponent<BN>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
+        const int e = pair_group_exponent<BN / 2>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
                                               g.ex_min + grp);
         if (e != INT_MAX || g.ap) {   // (the chain's own consumer looks at the table first; the all-T form's dW_hh product does not)
             const float sc = e != INT_MAX ? pair_pow2(e) : 0.f;

@@ -53,19 +53,20 @@ struct PairConsumer {
     }
 };
 
-// ---- producer side.  A wave of the 64 x BN tile (2 x 2 waves) owns 32 rows x BN/2 columns; vmax = the largest |value| of its G
+// ---- producer side.  A wave of the tile owns 32 rows x WCOLS columns; vmax = the largest |value| of its G
 // blocks (per lane on entry).  Returns the exponent of the wave's 32 x 32 group (two waves share one when BN = 32: `red` = 4 floats
 // of LDS that every wave is done with, the barriers are the workgroup's), records it in ex_out / ex_min.
-template <int BN>
+// WCOLS: columns of a wave tile - 32 (the wave owns its group) or 16: waves w and w ^ 1 (neighbours along the columns) share a group
+template <int WCOLS>
 __device__ __forceinline__ int pair_group_exponent(float vmax, float* red, int wave, int lane, int* ex_out_entry, int* ex_min_entry) {
-    const int wm = wave >> 1, wn = wave & 1;
+    static_assert(WCOLS == 32 || WCOLS == 16, "a wave tile is one 32-column exponent group or half of one");
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if constexpr (BN == 32) {
+    if constexpr (WCOLS == 16) {
         __syncthreads();
         if (lane == 0) red[wave] = vmax;
         __syncthreads();
-        vmax = fmaxf(red[2 * wm], red[2 * wm + 1]);
+        vmax = fmaxf(red[wave & ~1], red[wave | 1]);
     }
     int e = INT_MAX;
     if (vmax > 0.f) {
@@ -73,7 +74,7 @@ __device__ __forceinline__ int pair_group_exponent(float vmax, float* red, int w
         if (vmax < 3.0e38f) { (void)frexpf(vmax, &fe); e = max(-100, min(100, 14 - fe)); }
         else e = 0;   // an infinity among the values: unscaled, it (and any NaN) reaches the planes as it is
     }
-    if (lane == 0 && (BN == 64 || wn == 0)) {
+    if (lane == 0 && (WCOLS == 32 || (wave & 1) == 0)) {
         *ex_out_entry = e;
         // (the table only decreases: a stale read can only cause a redundant atomic)
         if (e != INT_MAX && e < __hip_atomic_load(ex_min_entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(ex_min_entry, e);

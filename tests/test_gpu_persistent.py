@@ -252,11 +252,11 @@ def test_backward_f16_pair_step_vs_exact(B, H, T, reverse):
     d = _inputs(B, H, T, 24, seed=B + H + T + 2)
     hs, gates, dhs, last = _bwd_inputs(d, B, H, T, reverse, seed=3)
     ref, ref0 = _bwd(d, B, H, T, reverse, hs, gates, dhs, last)
-    tiles = ["64x32"] + (["64x64"] if H % 64 == 0 else [])
+    tiles = ["64x32"] + (["64x64"] if H % 64 == 0 else []) + (["64x64x8"] if H % 64 == 0 else []) + (["128x64"] if H % 64 == 0 and B % 128 == 0 else [])   # eight-wave forms (round 6)
     for t in tiles:
         with ops.options(gru_bwd_tile=t):
             buf = ctypes_name(1, B, H, 1)
-            assert buf.endswith(", 3, 3>"), buf
+            assert ", 3, 3, " in buf and buf.startswith("gru_step_bwd_dl_kernel<%s, " % t.split("x")[0]), buf
             dG, dh0 = _bwd(d, B, H, T, reverse, hs, gates, dhs, last, pair=True)
         assert torch.isfinite(dG).all()
         assert (dG - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), t
