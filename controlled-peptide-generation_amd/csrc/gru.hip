@@ -381,6 +381,12 @@ using GB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 #ifndef CPG_DL_DELAY
 #define CPG_DL_DELAY 0
 #endif
+#ifndef CPG_DL_DELAY2
+#define CPG_DL_DELAY2 0
+#endif
+#if CPG_DL_DELAY2
+__device__ unsigned cpg_dl_tickets[4096];
+#endif
 #ifndef CPG_BWD_DL_NS
 #define CPG_BWD_DL_NS 3   // stages of the backward step's LDS ring (2: 44.4 / 33.7 us paired / single at config B, 3: 40.3 / 28.0, 4: EXPERIMENTS R6.9)
 #endif
@@ -491,6 +497,20 @@ __global__ __launch_bounds__(64 * WR * WC, WC == 4 ? 2 : 1) void gru_step_bwd_dl
                 }
             }
     };
+#if CPG_DL_DELAY2  // diagnostic builds: the workgroup that arrives SECOND on its CU (ticket per hardware CU id) starts CPG_DL_DELAY2 ticks late
+    if (gridDim.x * gridDim.y * gridDim.z == 512) {
+        __shared__ unsigned tk_;
+        if (threadIdx.x == 0) {
+            const unsigned cu = (unsigned)__builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4) | ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8);
+            tk_ = atomicAdd(&cpg_dl_tickets[cu & 4095], 1u);
+        }
+        __syncthreads();
+        if (tk_ & 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)CPG_DL_DELAY2) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
 #if CPG_DL_DELAY   // diagnostic builds: the second workgroup of every CU (dispatch order) starts CPG_DL_DELAY 10-ns ticks late
     if (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
