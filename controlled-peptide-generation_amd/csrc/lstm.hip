@@ -218,9 +218,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(LstmBwdPair pr) {
 // MFMA, 16-byte row-layout epilogue.  Same sums as lstm_step_bwd_kernel (same contraction order); dense full tiles only.
 // PREC 1: bf16 compute mode - operands rounded to bf16 at the fragment read, one bf16 MFMA per block and slab (as the GRU kernel)
 // PREC 3: f32-grade on f16 pairs handed from launch to launch (pair_engine.h; as gru_step_bwd_dl_kernel) - three f16 MFMAs per block
-template <int BM, int BN, int PREC = 0>
-__global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
-    using DL = DlLoop<BM, BN, 3, PREC>;
+// WR x WC: wave grid (gemm_core.h) - 2 x 2 waves of BM/2 x BN/2, or (round 6, PREC 3) 2 x 4 waves of 32 x 16 on the 64 x 64 tile
+template <int BM, int BN, int PREC = 0, int WR = 2, int WC = 2>
+__global__ __launch_bounds__(64 * WR * WC, WC == 4 ? 2 : 1) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
+    using DL = DlLoop<BM, BN, 3, PREC, WR, WC>;
     constexpr int MI = DL::MI, NI = DL::NI;
     int bx, by, bz;
     xcd_tile_order(bx, by, bz);
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const tb = cpg_smem + DL::smem_floats() + wave * 256;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int rb0 = m0 + wm * (BM / 2) + (lane >> 2), cb0 = j0 + wn * (BN / 2) + 4 * (lane & 3);
+    const int wm = wave / WC, wn = wave % WC;
+    const int rb0 = m0 + wm * (BM / WR) + (lane >> 2), cb0 = j0 + wn * (BN / WC) + 4 * (lane & 3);
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_dl_kernel(LstmBwdPair pr) {
         }
     if constexpr (PREC == 3) {
         if (!g.gates || !g.pp_out) return;   // (block-uniform)
-        const int grp = (j0 + wn * (BN / 2)) / 32;
-        const int e = pair_group_exponent<BN / 2>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
+        const int grp = (j0 + wn * (BN / WC)) / 32;
+        const int e = pair_group_exponent<BN / WC>(vmax, cpg_smem, wave, lane, g.ex_out + (size_t)((m0 + wm * 32) / 32) * (H / 32) + grp,
                                               g.ex_min + grp);
         if (e != INT_MAX || g.ap) {   // (the chain's own consumer looks at the table first; the all-T form's dW_hh product does not)
             const float sc = e != INT_MAX ? pair_pow2(e) : 0.f;
@@ -337,6 +338,7 @@ using LB32N = TileCfg<32, 32, 32, 2, 2, 1>;
 
 static bool lstm_dl_ok(int B, int H);
 // f16-pair form of the direct-to-LDS backward step: f32-grade mode, option gru_bwd_engine = exact switches it off (as csrc/gru.hip)
+static bool lstm_dl_w8(int B, int H, int nd);
 static bool lstm_pair_enabled(int H) {
     if (cpg_compute_mode_get() == 1 || H > 2048) return false;
     const CpgOptVal o = cpg_opt(OPT_GRU_BWD_ENGINE);
@@ -364,8 +366,12 @@ CPG_EXPORT int cpg_lstm_step_kernel_name(int kind, int B, int H, char* buf, int 
     }
     if (kind == 1) {
         if (lstm_dl_ok(B, H) && H % 4 == 0)
-            return snprintf(buf, n, "lstm_step_bwd_dl_kernel<64, %d, %d>", (H % 64 == 0 && (long)(B / 64) * (H / 64) >= 512) ? 64 : 32,
-                            cpg_compute_mode_get() == 1 ? 1 : lstm_pair_enabled(H) ? 3 : 0);   // (B: rows of the launch - both directions' rows for a paired one)
+        {   // (B: rows of the launch - both directions' rows for a paired one)
+            const int prec = cpg_compute_mode_get() == 1 ? 1 : lstm_pair_enabled(H) ? 3 : 0;
+            const bool w8 = prec == 3 && lstm_dl_w8(B, H, 1);
+            return snprintf(buf, n, "lstm_step_bwd_dl_kernel<64, %d, %d, 2, %d>", (w8 || (H % 64 == 0 && (long)(B / 64) * (H / 64) >= 512)) ? 64 : 32,
+                            prec, w8 ? 4 : 2);
+        }
         const int c = lstm_bwd_choice(B, H);
         if (c == 0) lstm_tc_name<LB32N>(tc, sizeof tc);
         else if (c == 1) lstm_tc_name<LB64>(tc, sizeof tc);
@@ -429,21 +435,23 @@ static bool lstm_dl_ok(int B, int H) {
     if (o.set && o.i == 0) return false;
     return B % 64 == 0 && H % 32 == 0;
 }
-template <int BM, int BN, int PREC>
+template <int BM, int BN, int PREC, int WR = 2, int WC = 2>
 static int lstm_launch_dl_p(const LstmBwdPair& pr, int nd, hipStream_t s) {
     const LstmBwdArgs& a = pr.d[0];
-    const size_t smem = (DlLoop<BM, BN, 3, PREC>::smem_floats() + 4 * 256) * sizeof(float);
+    const size_t smem = (DlLoop<BM, BN, 3, PREC, WR, WC>::smem_floats() + WR * WC * 256) * sizeof(float);
     if (smem > 64 * 1024) {
-        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN, PREC>), (int)smem);
+        const int rc = cpg_allow_big_lds(reinterpret_cast<const void*>(lstm_step_bwd_dl_kernel<BM, BN, PREC, WR, WC>), (int)smem);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN, PREC>), dim3(a.H / BN, a.B / BM, nd), dim3(256), smem, s, pr);
+    hipLaunchKernelGGL((lstm_step_bwd_dl_kernel<BM, BN, PREC, WR, WC>), dim3(a.H / BN, a.B / BM, nd), dim3(64 * WR * WC), smem, s, pr);
     return 0;
 }
+// f16-pair step on eight waves of 32 x 16 (as csrc/gru.hip): 64 x 64 tiles from 256 tiles up
+static bool lstm_dl_w8(int B, int H, int nd) { return H % 64 == 0 && (long)(B / 64) * (H / 64) * nd >= 256; }
 // bf16 compute mode (cpg_set_compute_mode(1)): the step product with bf16-rounded operands, like every other recurrent product of the mode
 template <int BM, int BN>
 static int lstm_launch_dl(const LstmBwdPair& pr, int nd, hipStream_t s) {
-    if (pr.d[0].pp_next || pr.d[0].pp_out) return lstm_launch_dl_p<BM, BN, 3>(pr, nd, s);
+    if (pr.d[0].pp_next || pr.d[0].pp_out) return lstm_launch_dl_p<BM, BN, 3>(pr, nd, s);   // (the eight-wave form is picked by the caller)
     return cpg_compute_mode_get() == 1 ? lstm_launch_dl_p<BM, BN, 1>(pr, nd, s) : lstm_launch_dl_p<BM, BN, 0>(pr, nd, s);
 }
 
@@ -460,8 +468,9 @@ static int lstm_bwd_launch(const LstmBwdPair& pr, int nd, hipStream_t s) {
         }
         if (al) {
             // 64 x 64 tiles once they give two workgroups per CU, else 64 x 32 (as the GRU kernel: csrc/gru.hip)
-            const int rc = (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) * nd >= 512) ? lstm_launch_dl<64, 64>(pr, nd, s)
-                                                                                        : lstm_launch_dl<64, 32>(pr, nd, s);
+            const int rc = ((a.pp_next || a.pp_out) && lstm_dl_w8(a.B, a.H, nd)) ? lstm_launch_dl_p<64, 64, 3, 2, 4>(pr, nd, s)
+                           : (a.H % 64 == 0 && (long)(a.B / 64) * (a.H / 64) * nd >= 512) ? lstm_launch_dl<64, 64>(pr, nd, s)
+                                                                                          : lstm_launch_dl<64, 32>(pr, nd, s);
             if (rc) return rc;
             CPG_LAUNCH_CHECK();
             return 0;
