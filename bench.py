@@ -57,9 +57,10 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, grid=None):
     """HBM bytes per launch of `kernel` from the committed PMC profile - only when that profile was taken from THESE kernel
-    sources (its "_csrc_sha256_16" stamp equals csrc_fingerprint()); otherwise null."""
+    sources (its "_csrc_sha256_16" stamp equals csrc_fingerprint()); otherwise null.  grid (work-items of the launch): picks the row of
+    that launch shape where one instantiation serves several (tools/pmc_summary.py: "name @grid=N")."""
     try:
         d = json.load(open(PMC_JSON))
     except (OSError, ValueError):
@@ -67,7 +68,7 @@ def pmc_traffic(kernel):
     if d.get("_csrc_sha256_16") != csrc_fingerprint():
         return None
     # (rocprofv3 prints gemm_kernel's trailing bf16-operand template argument, the launcher's name query does not)
-    r = d.get(kernel) or d.get(kernel[:-1] + ", false>") or d.get(kernel[:-1] + ", true>")
+    r = (d.get("%s @grid=%d" % (kernel, grid)) if grid else None) or d.get(kernel) or d.get(kernel[:-1] + ", false>") or d.get(kernel[:-1] + ", true>")
     if not r or "FETCH_SIZE" not in r or "WRITE_SIZE" not in r:
         return None
     return (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
@@ -170,7 +171,12 @@ def family_roofline(family, dims, avg_us, launches):
     nbytes = family_bytes(family, dims, bf16_gates)
     gbs = nbytes / (avg_us * 1e-6) / 1e9 if (nbytes and avg_us > 0) else 0.0
     mfma_frac, hbm_frac = ach / peak, gbs / HBM_PEAK_GBS
-    traffic = pmc_traffic(kernel)
+    grid = None
+    if family == "bwd_step" and kernel.startswith("gru_step_bwd_dl_kernel<"):   # <BM, BN, stages, engine, wave rows, wave columns>
+        ta = [int(x) for x in kernel[kernel.index("<") + 1:-1].split(",")]
+        if len(ta) == 6:
+            grid = (B // ta[0]) * (H // ta[1]) * nd * 64 * ta[4] * ta[5]
+    traffic = pmc_traffic(kernel, grid)
     pipe = {1: "bf16 MFMA x6 on 3-way split operands (f32-grade): 2500/6", 0: "exact f32 MFMA: 157.3", 2: "bf16 MFMA: 2500",
             3: "f16 MFMA x3 on f16-pair operands (f32-grade): 2500/3"}[int(split)]
     r = {"kernel": kernel, "avg_launch_us": round(avg_us, 2), "launches_timed": launches, "traffic": traffic,

@@ -41,21 +41,32 @@ def main():
             files.append(p)
     vals = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel -> counter -> [per-dispatch values]
     durs = collections.defaultdict(list)
+    grids = collections.defaultdict(set)   # kernel -> grid sizes it was launched with: one instantiation serving two launch shapes (the
+    #                                        BPTT step: both encoder directions / the decoder's one) also gets a row per shape, "name @grid=N"
     for f in files:
         with open(f, newline="") as fh:
             rd = csv.DictReader(fh)
             cols = rd.fieldnames or []
             if "Counter_Name" in cols:
                 per = collections.defaultdict(float)
+                grid_of = {}
                 for r in rd:
                     per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+                    grid_of[(short(r["Kernel_Name"]), r["Dispatch_Id"])] = r.get("Grid_Size", "")
                 for (k, d, c), v in per.items():
                     vals[k][c].append((int(d), v))
+                    grids[k].add(grid_of[(k, d)])
+                    vals[k + " @grid=" + grid_of[(k, d)]][c].append((int(d), v))
             elif "Start_Timestamp" in cols and "Kernel_Name" in cols:
                 for r in rd:
-                    durs[short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+                    k, us = short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                    gs = r.get("Grid_Size") or str(int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1))
+                    durs[k].append((int(r["Dispatch_Id"]), us))
+                    durs[k + " @grid=" + gs].append((int(r["Dispatch_Id"]), us))
+                    grids[k].add(gs)
     out = {}
     names = sorted(set(vals) | set(durs))
+    names = [k for k in names if " @grid=" not in k or len(grids[k.split(" @grid=")[0]]) > 1]   # per-shape rows only where shapes differ
     for k in names:
         if a.match and not any(m in k for m in a.match):
             continue
