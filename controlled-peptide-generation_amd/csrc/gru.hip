@@ -884,11 +884,14 @@ static BwdPlan bwd_plan(int rows, int H, int nd, int row0, bool vec, bool have_w
         BwdTile t = dl_tile(rows, H, nd);
         const bool pair = t.bm >= 64 && H <= 2048 && bwd_pair_enabled();
         if (t.bm == 128 && !(pair && rows % 128 == 0 && H % 64 == 0)) t.bm = 64, t.waves = 4;   // 128 x 64 exists for the f16-pair step on whole tiles only
-        if (t.waves == 8 && !(pair && t.bn == 64 && H % 64 == 0)) t.waves = 4;
+        if (t.waves == 8 && !((pair || bf16) && t.bm == 64 && t.bn == 64 && H % 64 == 0 && rows % 64 == 0)) t.waves = 4;
         // f16-pair step, launcher's own choice (round 6): 64 x 64 tiles on EIGHT waves of 32 x 16 from 256 tiles up - 116 VGPRs, four waves
         // per SIMD at two workgroups per CU (paired directions: 42.9 -> 41.6 us) or eight waves on every CU (one direction at B=2048,
         // H=512: 28.9 on 64 x 32 -> 27.8)
         if (pair && !cpg_opt(OPT_GRU_BWD_TILE).set && rows % 64 == 0 && H % 64 == 0 && (long)(rows / 64) * (H / 64) * nd >= 256) t = {64, 64, 8};
+        // bf16 compute mode: the same from 512 tiles up (paired directions at config B: 24.2 -> 22.8 us; one direction stays on the
+        // two-K-halves kernel above: 15.4 against 16.5)
+        if (bf16 && !cpg_opt(OPT_GRU_BWD_TILE).set && t.bm == 64 && t.bn == 64 && rows % 64 == 0 && (long)(rows / 64) * (H / 64) * nd >= 512) t.waves = 8;
         return {BK_DL, t, bf16, pair};
     }
     return {BK_STAGED, staged_tile(rows, H, nd), false, false};   // exact f32 in either compute mode
@@ -932,6 +935,8 @@ static int gru_bwd_launch(const GruBwdPair& pr_in, int nd, hipStream_t s) {
 #define CPG_DL_PICK(BM, BN) (dgb ? launch_dl<BM, BN, 2>(pr, nd, s) : pl.bf16 ? launch_dl<BM, BN, 1>(pr, nd, s) : launch_dl<BM, BN, 0>(pr, nd, s))
         if (pair) rc = pl.tile.bm == 128 ? launch_dl<128, 64, 3, 4>(pr, nd, s) : pl.tile.waves == 8 ? launch_dl<64, 64, 3, 2, 4>(pr, nd, s)
                      : pl.tile.bn == 64 ? launch_dl<64, 64, 3>(pr, nd, s) : launch_dl<64, 32, 3>(pr, nd, s);
+        else if (pl.tile.bm == 64 && pl.tile.bn == 64 && pl.tile.waves == 8 && pl.bf16)   // bf16 compute mode on eight waves
+            rc = dgb ? launch_dl<64, 64, 2, 2, 4>(pr, nd, s) : launch_dl<64, 64, 1, 2, 4>(pr, nd, s);
         else if (pl.tile.bm == 64 && pl.tile.bn == 64) rc = CPG_DL_PICK(64, 64);
         else if (pl.tile.bm == 64) rc = CPG_DL_PICK(64, 32);
         else if (pl.tile.bn == 64) rc = CPG_DL_PICK(32, 64);
