@@ -664,6 +664,15 @@ def main():
     if args.dist_selftest:
         return dist_selftest(args)
 
+    # launched by an outside torch.distributed.run with more ranks on this node than it has GPUs (a 1-GPU box): the same functional fallback
+    # as the self-spawn above - RCCL refuses two ranks on one device ("Duplicate GPU detected"), so gloo carries the collectives and the
+    # persistent kernels (which need every CU of a device to themselves) are switched off.  Decided BEFORE cpg.ops is imported.
+    if "WORLD_SIZE" in os.environ and torch.cuda.is_available():
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+        if 0 < torch.cuda.device_count() < lw:
+            os.environ.setdefault("CPG_DIST_BACKEND", "gloo")
+            os.environ["CPG_SHARED_DEVICE"] = "1"
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from cpg import dist as cdist
     world, rank, local = cdist.init()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
