@@ -30,9 +30,20 @@ steps_total = len(adam) // per_step
 lo = adam[per_step * 5 - 1] + 1           # skip the 5 warm-up steps
 hi = adam[-1] + 1
 nsteps = steps_total - 5
+def grid(r):
+    return int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+
+
+# one instantiation can serve two launch shapes (the eight-wave BPTT step: both encoder directions in one launch / the decoder's one
+# direction): such kernels get a row per shape, labelled with the launch's workgroup count
+shapes = collections.defaultdict(set)
+for r in rows[lo:hi]:
+    shapes[short(r["Kernel_Name"])].add(grid(r))
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows[lo:hi]:
     k = short(r["Kernel_Name"])
+    if len(shapes[k]) > 1:
+        k += " [%d workgroups]" % (grid(r) // max(int(r.get("Workgroup_Size_X", 1) or 1), 1))
     agg[k][0] += 1
     agg[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(v[1] for v in agg.values())
